@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="session")
+def mutag_graphs():
+    """MUTAG in grakel input form [set_of_(u,v), {node: label}] rebuilt from the packed arrays."""
+    z = load_golden("mutag.npz")
+    n_graphs = int(z["node_graph"].max()) + 1
+    labels = [dict() for _ in range(n_graphs)]
+    edges = [set() for _ in range(n_graphs)]
+    g_of = dict()
+    for v, g, l in zip(z["node_id"].tolist(), z["node_graph"].tolist(), z["node_label"].tolist()):
+        labels[g][v] = l
+        g_of[v] = g
+    for a, b in zip(z["edge_src"].tolist(), z["edge_dst"].tolist()):
+        edges[g_of[a]].add((a, b))
+    return [[edges[g], labels[g]] for g in range(n_graphs)], z
+
+
+def reference_available():
+    """True only in the build container where the real grakel was built (oracle/build_ref.sh)."""
+    ref = os.environ.get("GK_REF_BUILD", "/tmp/grakel_oracle")
+    return os.path.isdir(os.path.join(ref, "grakel"))

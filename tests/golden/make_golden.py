@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference; see oracle/build_ref.sh):
+
+    bash oracle/build_ref.sh && python tests/golden/make_golden.py [--skip-big]
+
+Every number stored here was produced by grakel 0.1.11's own classes
+(WeisfeilerLehman / VertexHistogram / ShortestPath); the fixtures are data, no
+reference code is copied.  The GPU box has no /root/reference, so the parity
+tests compare against these files (and against oracle/grakel_oracle.py, which
+tests/test_oracle.py pins to the same files).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("GK_REF_BUILD", "/tmp/grakel_oracle")
+sys.path.insert(0, REF)
+
+import grakel  # noqa: E402  (the real reference)
+from grakel import WeisfeilerLehman, VertexHistogram, ShortestPath  # noqa: E402
+from grakel.datasets.base import read_data  # noqa: E402
+
+from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs  # noqa: E402
+sys.path.insert(0, HERE)
+from small_sets import SMALL_SETS, split, sp_inputs  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+
+def as_int(K):
+    Ki = np.rint(K).astype(np.int64)
+    assert np.array_equal(Ki.astype(np.float64), K), "Gram matrix is not integer valued"
+    return Ki
+
+
+def sample_entries(K, m, seed):
+    rs = np.random.RandomState(seed)
+    i = rs.randint(0, K.shape[0], m)
+    j = rs.randint(0, K.shape[1], m)
+    return i.astype(np.int32), j.astype(np.int32), K[i, j]
+
+
+def doc_goldens():
+    H2O = [{'a': ['b', 'c'], 'b': ['a'], 'c': ['a']}, {'a': 'O', 'b': 'H', 'c': 'H'}]
+    H3O = [{'a': ['b', 'c', 'd'], 'b': ['a'], 'c': ['a'], 'd': ['a']},
+           {'a': 'O', 'b': 'H', 'c': 'H', 'd': 'H'}]
+    out = {}
+    sp = ShortestPath()
+    out["sp_fit_h2o"] = sp.fit_transform([H2O]).tolist()
+    out["sp_tr_h3o"] = sp.transform([H3O]).tolist()
+    spn = ShortestPath(normalize=True)
+    spn.fit([H2O])
+    out["sp_norm_tr_h3o"] = spn.transform([H3O]).tolist()
+    vh = VertexHistogram(normalize=True)
+    vh.fit([H2O])
+    out["vh_norm_tr_h3o"] = vh.transform([H3O]).tolist()
+    wl = WeisfeilerLehman(n_iter=5)
+    out["wl5_fit_both"] = wl.fit_transform([H2O, H3O]).tolist()
+    out["wl5_inv_labels"] = {str(k): v for k, v in wl._inv_labels.items()}
+    wl1 = WeisfeilerLehman(n_iter=5)
+    wl1.fit([H2O])
+    out["wl5_fit_h2o_tr_h3o"] = wl1.transform([H3O]).tolist()
+    # the 4x4 known-answer APSP matrix of grakel/tests/test_graph.py:61-74
+    from grakel import Graph
+    A = np.array([[0, 1, 0, 3], [1, 0, 0, 2], [2, 3, 0, 1], [1, 0, 0, 0]])
+    S, _ = Graph(A, {0: 'a', 1: 'b', 2: 'c', 3: 'd'}).build_shortest_path_matrix("auto")
+    out["apsp_4x4"] = [[None if np.isinf(x) else float(x) for x in r] for r in S]
+    with open(os.path.join(HERE, "doc_goldens.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("doc goldens", out["sp_fit_h2o"], out["sp_tr_h3o"], out["wl5_fit_both"])
+
+
+def mutag():
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "grakel", "tests", "data"))
+    try:
+        G = read_data('MUTAG', with_classes=True).data
+    finally:
+        os.chdir(cwd)
+    # pack the dataset itself (public TU data: arrays only)
+    gi, labs, src, dst = [], [], [], []
+    node_ids = []
+    for g, (edges, nl, _el) in enumerate(G):
+        for v in sorted(nl):
+            node_ids.append(v), gi.append(g), labs.append(nl[v])
+        for (a, b) in sorted(edges):
+            src.append(a), dst.append(b)
+    K_vh = as_int(VertexHistogram().fit_transform(G))
+    K_wl = as_int(WeisfeilerLehman(n_iter=5).fit_transform(G))
+    K_sp = as_int(ShortestPath().fit_transform(G))
+    wl = WeisfeilerLehman(n_iter=3)
+    wl.fit(G[:120])
+    K_wl_tr = as_int(wl.transform(G[120:]))
+    sp = ShortestPath()
+    sp.fit(G[:120])
+    K_sp_tr = as_int(sp.transform(G[120:]))
+    wln = WeisfeilerLehman(n_iter=3, normalize=True)
+    wln.fit(G[:120])
+    K_wl_tr_norm = wln.transform(G[120:])
+    wl5 = WeisfeilerLehman(n_iter=5)
+    wl5.fit(G)
+    np.savez_compressed(
+        os.path.join(HERE, "mutag.npz"),
+        node_id=np.array(node_ids, np.int32), node_graph=np.array(gi, np.int32),
+        node_label=np.array(labs, np.int32), edge_src=np.array(src, np.int32),
+        edge_dst=np.array(dst, np.int32),
+        K_vh=K_vh.astype(np.int32), K_wl5=K_wl.astype(np.int32), K_sp=K_sp.astype(np.int64),
+        K_wl3_tr=K_wl_tr.astype(np.int32), K_sp_tr=K_sp_tr.astype(np.int64),
+        K_wl3_tr_norm=K_wl_tr_norm,
+        wl5_label_counts=np.array([len(wl5._inv_labels[i]) for i in range(6)], np.int64))
+    print("MUTAG sums", K_vh.sum(), K_wl.sum(), K_sp.sum(), "traces",
+          np.trace(K_vh), np.trace(K_wl), np.trace(K_sp))
+
+
+def small_sets():
+    out = {}
+    for name, kw in SMALL_SETS:
+        G = random_labelled_graphs(**kw)
+        tr, te = split(G)
+        for h in (1, 3):
+            wl = WeisfeilerLehman(n_iter=h)
+            out["%s/wl%d_fit" % (name, h)] = as_int(wl.fit_transform(tr))
+            out["%s/wl%d_tr" % (name, h)] = as_int(wl.transform(te))
+            out["%s/wl%d_counts" % (name, h)] = np.array(
+                [len(wl._inv_labels[i]) for i in range(h + 1)], np.int64)
+        wln = WeisfeilerLehman(n_iter=2, normalize=True)
+        out[name + "/wl2n_fit"] = wln.fit_transform(tr)
+        out[name + "/wl2n_tr"] = wln.transform(te)
+        vh = VertexHistogram()
+        out[name + "/vh_fit"] = as_int(vh.fit_transform(tr))
+        out[name + "/vh_tr"] = as_int(vh.transform(te))
+        vhn = VertexHistogram(normalize=True)
+        out[name + "/vhn_fit"] = vhn.fit_transform(tr)
+        out[name + "/vhn_tr"] = vhn.transform(te)
+        trs, tes = sp_inputs(kw, tr), sp_inputs(kw, te)
+        try:
+            sp = ShortestPath()
+            out[name + "/sp_fit"] = as_int(sp.fit_transform(trs))
+            out[name + "/sp_tr"] = as_int(sp.transform(tes))
+            spn = ShortestPath(normalize=True)
+            out[name + "/spn_fit"] = spn.fit_transform(trs)
+            out[name + "/spn_tr"] = spn.transform(tes)
+            spu = ShortestPath(with_labels=False)
+            out[name + "/spu_fit"] = as_int(spu.fit_transform(trs))
+            out[name + "/spu_tr"] = as_int(spu.transform(tes))
+        except KeyError as e:           # tuples sets can hit the Dijkstra sink-vertex bug
+            print("  SP skipped for", name, "(reference KeyError %s)" % e)
+    np.savez_compressed(os.path.join(HERE, "small_sets.npz"), **out)
+    print("small sets:", len(out), "arrays")
+
+
+def er_config(tag, N, n, p, L, seed, h, nsamp):
+    G = er_dataset(N, n, p, L, seed)
+    t0 = time.perf_counter()
+    wl = WeisfeilerLehman(n_iter=h)
+    K = wl.fit_transform(G)
+    dt = time.perf_counter() - t0
+    Ki = as_int(K)
+    i, j, v = sample_entries(Ki, nsamp, 123)
+    np.savez_compressed(
+        os.path.join(HERE, "er_%s.npz" % tag),
+        params=np.array([N, n, L, seed, h], np.int64), p=np.array([p]),
+        label_counts=np.array([len(wl._inv_labels[k]) for k in range(h + 1)], np.int64),
+        K_sum=np.array([Ki.sum()], np.int64), K_trace=np.array([np.trace(Ki)], np.int64),
+        K_max=np.array([Ki.max()], np.int64), diag=np.diagonal(Ki).astype(np.int32),
+        K_block=Ki[:64, :64].astype(np.int32), row_sums=Ki.sum(axis=1).astype(np.int64),
+        samp_i=i, samp_j=j, samp_v=v.astype(np.int32),
+        ref_seconds=np.array([dt]))
+    print("ER", tag, "ref %.2fs" % dt, "sum", Ki.sum(), "trace", np.trace(Ki), "max", Ki.max(),
+          "counts", [len(wl._inv_labels[k]) for k in range(h + 1)])
+
+
+def nci1_sp(N):
+    G = nci1_like(N, 0, as_adj=True)
+    t0 = time.perf_counter()
+    sp = ShortestPath()
+    K = sp.fit_transform(G)
+    dt = time.perf_counter() - t0
+    Ki = as_int(K)
+    i, j, v = sample_entries(Ki, 10000, 321)
+    np.savez_compressed(
+        os.path.join(HERE, "nci1_like_sp_%d.npz" % N),
+        K_sum=np.array([Ki.sum()], np.int64), K_max=np.array([Ki.max()], np.int64),
+        n_features=np.array([len(sp._enum)], np.int64), diag=np.diagonal(Ki).astype(np.int64),
+        K_block=Ki[:64, :64].astype(np.int64), row_sums=Ki.sum(axis=1).astype(np.int64),
+        samp_i=i, samp_j=j, samp_v=v.astype(np.int64), ref_seconds=np.array([dt]))
+    print("NCI1-like SP N=%d ref %.2fs sum %d max %d nfeat %d" % (N, dt, Ki.sum(), Ki.max(),
+                                                                  len(sp._enum)))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-big", action="store_true", help="skip config 3 (~100 s) and NCI1-4110")
+    a = ap.parse_args()
+    print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
+    doc_goldens()
+    mutag()
+    small_sets()
+    er_config("n200", 200, 30, 0.1, 4, 3, 4, 4000)
+    er_config("config2", 1000, 50, 0.1, 5, 0, 3, 20000)
+    nci1_sp(300)
+    if not a.skip_big:
+        nci1_sp(4110)
+        er_config("config3", 10000, 100, 0.05, 5, 0, 5, 20000)

@@ -1,0 +1,144 @@
+"""Pin oracle/grakel_oracle.py to the reference: golden fixtures made by the real grakel
+(tests/golden/make_golden.py) and the reference's own known-answer vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from oracle import grakel_oracle as O
+from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs
+
+H2O = [{'a': ['b', 'c'], 'b': ['a'], 'c': ['a']}, {'a': 'O', 'b': 'H', 'c': 'H'}]
+H3O = [{'a': ['b', 'c', 'd'], 'b': ['a'], 'c': ['a'], 'd': ['a']},
+       {'a': 'O', 'b': 'H', 'c': 'H', 'd': 'H'}]
+
+
+@pytest.fixture(scope="module")
+def doc():
+    with open(os.path.join(GOLDEN, "doc_goldens.json")) as f:
+        return json.load(f)
+
+
+def test_known_answers_from_reference_docs(doc):
+    # doc/documentation/introduction.rst:313-343, creating_kernels.rst:104-109
+    sp = O.SPOracle()
+    assert sp.fit_transform([H2O]).tolist() == [[12.0]] == doc["sp_fit_h2o"]
+    assert sp.transform([H3O]).tolist() == [[24.0]] == doc["sp_tr_h3o"]
+    spn = O.SPOracle(normalize=True)
+    spn.fit_transform([H2O])
+    assert abs(spn.transform([H3O])[0, 0] - 0.94280904) < 1e-8
+    assert np.allclose(spn.transform([H3O]), doc["sp_norm_tr_h3o"], rtol=0, atol=1e-15)
+    vh = O.VHOracle(normalize=True)
+    vh.fit_transform([H2O])
+    assert vh.transform([H3O])[0, 0] == pytest.approx(0.9899494936611665, abs=1e-15)
+    wl = O.WLOracle(n_iter=5)
+    assert wl.fit_transform([H2O, H3O]).tolist() == [[30, 13], [13, 60]] == doc["wl5_fit_both"]
+    assert {str(k): v for k, v in wl.inv_labels.items()} == doc["wl5_inv_labels"]
+    wl1 = O.WLOracle(n_iter=5)
+    wl1.fit_transform([H2O])
+    assert wl1.transform([H3O]).tolist() == doc["wl5_fit_h2o_tr_h3o"]
+
+
+def test_apsp_known_answer(doc):
+    # grakel/tests/test_graph.py:61-74 -- same matrix via Floyd-Warshall and Dijkstra
+    A = np.array([[0, 1, 0, 3], [1, 0, 0, 2], [2, 3, 0, 1], [1, 0, 0, 0]])
+    want = np.array([[np.inf if x is None else x for x in r] for r in doc["apsp_4x4"]])
+    assert np.array_equal(want, [[0, 1, np.inf, 3], [1, 0, np.inf, 2], [2, 3, 0, 1], [1, 2, np.inf, 0]])
+    g = O.parse_graph(A, {})
+    assert np.array_equal(O.sp_matrix(g, "floyd_warshall")[0], want)
+    assert np.array_equal(O.sp_matrix(g, "dijkstra")[0], want)
+
+
+def test_mutag_against_reference(mutag_graphs):
+    G, z = mutag_graphs
+    assert np.array_equal(O.VHOracle().fit_transform(G), z["K_vh"])
+    wl = O.WLOracle(n_iter=5)
+    assert np.array_equal(wl.fit_transform(G), z["K_wl5"])
+    assert wl.label_counts == z["wl5_label_counts"].tolist()
+    assert np.array_equal(O.SPOracle().fit_transform(G), z["K_sp"])
+    assert int(z["K_vh"].sum()) == 6207377 and int(z["K_wl5"].sum()) == 10152522
+    assert int(z["K_sp"].sum()) == 202174524          # SURVEY.md 6 / BASELINE.md 2
+    wl3 = O.WLOracle(n_iter=3)
+    wl3.fit_transform(G[:120])
+    assert np.array_equal(wl3.transform(G[120:]), z["K_wl3_tr"])
+    wl3n = O.WLOracle(n_iter=3, normalize=True)
+    wl3n.fit_transform(G[:120])
+    assert np.allclose(wl3n.transform(G[120:]), z["K_wl3_tr_norm"], rtol=1e-13, atol=0)
+    sp = O.SPOracle()
+    sp.fit_transform(G[:120])
+    assert np.array_equal(sp.transform(G[120:]), z["K_sp_tr"])
+
+
+@pytest.mark.parametrize("name", ["dict_u", "adj_u", "adj_d", "tuples_d", "dense_big"])
+def test_small_sets_against_reference(name):
+    from golden.small_sets import SMALL_SETS, split, sp_inputs
+    z = load_golden("small_sets.npz")
+    kw = dict(SMALL_SETS)[name]
+    tr, te = split(random_labelled_graphs(**kw))
+    for h in (1, 3):
+        wl = O.WLOracle(n_iter=h)
+        assert np.array_equal(wl.fit_transform(tr), z["%s/wl%d_fit" % (name, h)])
+        assert np.array_equal(wl.transform(te), z["%s/wl%d_tr" % (name, h)])
+        assert wl.label_counts == z["%s/wl%d_counts" % (name, h)].tolist()
+    wln = O.WLOracle(n_iter=2, normalize=True)
+    assert np.allclose(wln.fit_transform(tr), z[name + "/wl2n_fit"], rtol=1e-13, atol=0)
+    assert np.allclose(wln.transform(te), z[name + "/wl2n_tr"], rtol=1e-13, atol=0)
+    vh = O.VHOracle()
+    assert np.array_equal(vh.fit_transform(tr), z[name + "/vh_fit"])
+    assert np.array_equal(vh.transform(te), z[name + "/vh_tr"])
+    vhn = O.VHOracle(normalize=True)
+    assert np.allclose(vhn.fit_transform(tr), z[name + "/vhn_fit"], rtol=1e-13, atol=0, equal_nan=True)
+    assert np.allclose(vhn.transform(te), z[name + "/vhn_tr"], rtol=1e-13, atol=0, equal_nan=True)
+    if name + "/sp_fit" in z.files:
+        trs, tes = sp_inputs(kw, tr), sp_inputs(kw, te)
+        sp = O.SPOracle()
+        assert np.array_equal(sp.fit_transform(trs), z[name + "/sp_fit"])
+        assert np.array_equal(sp.transform(tes), z[name + "/sp_tr"])
+        spn = O.SPOracle(normalize=True)
+        assert np.allclose(spn.fit_transform(trs), z[name + "/spn_fit"], rtol=1e-13, atol=0, equal_nan=True)
+        assert np.allclose(spn.transform(tes), z[name + "/spn_tr"], rtol=1e-13, atol=0, equal_nan=True)
+        spu = O.SPOracle(with_labels=False)
+        assert np.array_equal(spu.fit_transform(trs), z[name + "/spu_fit"])
+        assert np.array_equal(spu.transform(tes), z[name + "/spu_tr"])
+
+
+def test_er_n200_and_config2_against_reference():
+    for tag in ("n200", "config2"):
+        z = load_golden("er_%s.npz" % tag)
+        N, n, L, seed, h = z["params"].tolist()
+        G = er_dataset(N, n, float(z["p"][0]), L, seed)
+        wl = O.WLOracle(n_iter=h)
+        K = wl.fit_transform(G)
+        assert wl.label_counts == z["label_counts"].tolist()
+        assert int(K.sum()) == int(z["K_sum"][0]) and int(np.trace(K)) == int(z["K_trace"][0])
+        assert np.array_equal(K[:64, :64], z["K_block"])
+        assert np.array_equal(K[z["samp_i"], z["samp_j"]], z["samp_v"])
+        assert np.array_equal(K.sum(axis=1), z["row_sums"])
+    assert z["label_counts"].tolist() == [5, 6456, 49608, 49730]
+    assert int(z["K_sum"][0]) == 501709926 and int(z["K_trace"][0]) == 691748
+
+
+def test_nci1_like_sp_against_reference():
+    z = load_golden("nci1_like_sp_300.npz")
+    G = nci1_like(300, 0, as_adj=True)
+    sp = O.SPOracle()
+    K = sp.fit_transform(G)
+    assert len(sp.enum) == int(z["n_features"][0])
+    assert int(K.sum()) == int(z["K_sum"][0]) and int(K.max()) == int(z["K_max"][0])
+    assert np.array_equal(K[:64, :64], z["K_block"])
+    # the Dijkstra route (dict input) gives the same matrix
+    K2 = O.SPOracle().fit_transform(nci1_like(300, 0, as_adj=False))
+    assert np.array_equal(K, K2)
+
+
+def test_error_behaviour_matches_reference():
+    # weisfeiler_lehman.py:143-144,193-194 ; shortest_path.py:251-252
+    with pytest.raises(TypeError):
+        O.WLOracle().fit_transform(5)
+    with pytest.raises(ValueError):
+        with pytest.warns(UserWarning):
+            O.WLOracle().fit_transform([[]])
+    with pytest.raises(ValueError):
+        O.SPOracle(algorithm_type="bfs").fit_transform([H2O])
