@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: WL-subtree(h=5) fit_transform Gram matrix, graph-pairs/second.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one full pass of the hot path over BASELINE config 3 (10 000 synthetic
+Erdos-Renyi graphs, n=100, p=0.05, 5 labels, seed 0): WL relabelling for 5
+iterations, label-count features of the 6 levels, and the N x N Gram matrix, with the packed
+CSR batch already resident in HBM when the timed region starts and the float64 matrix left in
+HBM when it ends.  N>1: the graphs (and the Gram rows) are sharded over the ranks; a step then
+also contains the RCCL all-gather of the CSR shards (grakel_amd/dist.py).  Total work is
+fixed, so the scaling is "strong".
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the
+dominant kernel (the int8 MFMA Gram) and `cpu_baseline` (the oracle timed on this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = dict(N=10000, n=100, p=0.05, L=5, seed=0, n_iter=5)
+I8_DENSE_PEAK_TOPS = 5000.0      # int8 MFMA dense = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
+F64_PEAK_TFLOPS = 78.6
+
+
+def cpu_baseline(sample_graphs, cfg):
+    """The CPU oracle (a literal restatement of the reference's algorithm) on a bounded sample
+    of the same workload: the first `sample_graphs` graphs of config 3, one host core."""
+    from oracle import grakel_oracle as O
+    from grakel_amd.synthetic import er_dataset
+    X = er_dataset(sample_graphs, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])
+    t0 = time.perf_counter()
+    K = O.WLOracle(n_iter=cfg["n_iter"]).fit_transform(X)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_graphs * sample_graphs / dt, unit="graph-pairs/s", cores=1, kind="port",
+                sample="first %d graphs of the config-3 generator (n=%d p=%.2f h=%d), "
+                       "oracle.WLOracle.fit_transform, %.1f s, K sum %d"
+                       % (sample_graphs, cfg["n"], cfg["p"], cfg["n_iter"], dt, int(K.sum()))), K, X
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--graphs", type=int, default=WORKLOAD["N"], help="(debug) smaller workload")
+    ap.add_argument("--cpu-sample", type=int, default=1500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from grakel_amd import GraphBatch, _lib
+    from grakel_amd.engine import get_engine
+    from grakel_amd.synthetic import er_dataset_csr
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run" % a.gpus)
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    assert torch.cuda.is_available() and _lib.device_count() > 0, "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = dict(WORKLOAD)
+    cfg["N"] = a.graphs
+    N, h = cfg["N"], cfg["n_iter"]
+    eng = get_engine(local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    gp, rp, ci, lab = er_dataset_csr(N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])
+    full = GraphBatch(gp, rp, ci, lab, cfg["L"])
+    info = {}
+
+    if world == 1:
+        db = eng.upload(full)                 # input resident in HBM before the timed region
+
+        def step():
+            eng.wl_relabel(db, h)
+            feat = eng.features(db, h + 1)
+            eng.gram(feat, 0, to_host=False)
+            info.update(n_cols=feat.n_cols, dtype=feat.dtype, gram=eng.gram_stats(feat),
+                        label_counts=db.label_counts, nnz=feat.nnz)
+            feat.close()
+    else:
+        from grakel_amd.dist import ShardedWL, shard_bounds
+        b = shard_bounds(N, world)
+        local = full.slice_graphs(b[rank], b[rank + 1])
+        sw = ShardedWL(eng, n_iter=h)
+
+        def step():
+            _, i = sw.step(local)
+            info.update(i)
+
+    def sync():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    gram_ms = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        gram_ms.append(info["gram"][1])
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-phase device times (one extra, untimed, profiled step; single GPU only)
+    phases = None
+    if world == 1:
+        eng.profile(True)
+        step()
+        phases = {k: round(eng.profile_get(k)[0], 4) for k in ("relabel", "features", "gram")}
+        eng.profile(False)
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        flops, _ = info["gram"]
+        gram_avg_ms = float(np.mean(gram_ms))
+        dtype = ("i8", "f64")[info["dtype"]]
+        peak = I8_DENSE_PEAK_TOPS if dtype == "i8" else F64_PEAK_TFLOPS
+        achieved = flops / (gram_avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "graph-pairs/sec for NxN WL-subtree(h=%d) fit_transform" % h,
+            "value": N * N / (dt / a.steps),
+            "unit": "graph-pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: %d Erdos-Renyi graphs n=%d p=%.2f, %d labels, seed %d, "
+                                   "WL-subtree h=%d, full NxN float64 Gram left in HBM"
+                                   % (N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"], h),
+                       "graphs": N, "nodes": int(full.n_nodes), "edges": int(full.n_edges),
+                       "parallelism": "graphs+Gram rows sharded over %d GPU(s)" % world,
+                       "label_counts": info.get("label_counts"), "gram_columns_kept": info.get("n_cols")},
+            "roofline": {
+                "kernel": "gram_i8_kernel" if dtype == "i8" else "gram_f64_kernel",
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None,
+                "note": "achieved = 2*rows*N*D_kept integer MACs*2 per launch (full product, no symmetry "
+                        "skipping; rows = this rank's Gram rows) / avg HIP-event duration of the launch"},
+            "phases_ms": phases,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cb, Kcpu, X = cpu_baseline(min(a.cpu_sample, N), cfg)
+            out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

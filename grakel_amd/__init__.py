@@ -1,0 +1,10 @@
+"""grakel_amd: MI355X-native WL-subtree / VertexHistogram / ShortestPath graph kernels
+behind GraKeL's ``Kernel`` API (fit / transform / fit_transform / diagonal)."""
+from .batch import GraphBatch
+from .kernel import Kernel
+from .vertex_histogram import VertexHistogram
+from .weisfeiler_lehman import WeisfeilerLehman
+from .shortest_path import ShortestPath
+
+__all__ = ["GraphBatch", "Kernel", "VertexHistogram", "WeisfeilerLehman", "ShortestPath"]
+__version__ = "0.1.0"

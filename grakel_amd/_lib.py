@@ -1,0 +1,87 @@
+"""ctypes binding of libgk_hip.so (the C ABI declared in include/gk_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or no MI355X is
+visible, every entry point raises -- a silent CPU path would void the parity claims.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgk_hip.so")
+
+
+class GkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_i32p = POINTER(c_int32)
+_i64p = POINTER(c_int64)
+_u64p = POINTER(c_uint64)
+_f64p = POINTER(c_double)
+_vpp = POINTER(c_void_p)
+
+# name -> (restype, argtypes); mirrors include/gk_hip.h one to one
+SIGNATURES = {
+    "gk_last_error": (c_char_p, []),
+    "gk_version": (c_char_p, []),
+    "gk_device_count": (c_int, [POINTER(c_int)]),
+    "gk_create": (c_int, [c_int, _vpp]),
+    "gk_destroy": (c_int, [c_void_p]),
+    "gk_set_stream": (c_int, [c_void_p, c_void_p]),
+    "gk_synchronize": (c_int, [c_void_p]),
+    "gk_timer_start": (c_int, [c_void_p]),
+    "gk_timer_stop_ms": (c_int, [c_void_p, _f64p]),
+    "gk_profile_enable": (c_int, [c_void_p, c_int]),
+    "gk_profile_reset": (c_int, [c_void_p]),
+    "gk_profile_get": (c_int, [c_void_p, c_char_p, _f64p, _i64p]),
+    "gk_batch_create": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_int32, c_int, _vpp]),
+    "gk_batch_destroy": (c_int, [c_void_p]),
+    "gk_batch_info": (c_int, [c_void_p, _i64p, _i64p, _i64p]),
+    "gk_wl_relabel": (c_int, [c_void_p, c_void_p, c_int, c_int, _i64p, POINTER(c_int)]),
+    "gk_wl_get_labels": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "gk_wl_debug_signature": (c_int, [c_void_p, c_void_p, c_int, c_uint64, c_void_p, c_void_p]),
+    "gk_features_build": (c_int, [c_void_p, c_void_p, c_int, c_int64, _vpp]),
+    "gk_features_destroy": (c_int, [c_void_p]),
+    "gk_features_info": (c_int, [c_void_p, _i64p, _i64p, _i64p, POINTER(c_int)]),
+    "gk_features_selfk": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gk_gram": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "gk_gram_dev_ptr": (c_int, [c_void_p, _vpp, _i64p, _i64p]),
+    "gk_gram_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "gk_gram_last_stats": (c_int, [c_void_p, _f64p, _f64p]),
+    "gk_sp_build": (c_int, [c_void_p, c_void_p, c_void_p, c_int, _vpp, _i64p, _i64p]),
+    "gk_sp_debug_apsp": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+}
+
+
+def load():
+    """Load libgk_hip.so (built by ``__graft_entry__.build()`` / ``make -C grakel_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GkError("libgk_hip.so is not built (%s missing): run `python -c 'import "
+                      "__graft_entry__ as g; g.build()'` or `make -C grakel_amd/csrc`. "
+                      "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().gk_last_error()
+        raise GkError("libgk_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def device_count():
+    n = c_int(0)
+    check(load().gk_device_count(ctypes.byref(n)))
+    return n.value

@@ -1,0 +1,395 @@
+"""Host-side ingestion: grakel input objects -> packed CSR ``GraphBatch``.
+
+Replaces, for the WL / VH / SP path only, what the reference does per graph with
+``grakel.Graph`` objects (``grakel/graph.py:147-232``, format detection
+``:1542-1709``) and the ``parse_input`` loops of the three kernels
+(``weisfeiler_lehman.py:142-194``, ``vertex_histogram.py:75-121``,
+``shortest_path.py:441-466``).  No ``Graph`` objects are built: every accepted
+input form is flattened straight into int32 arrays.
+
+Accepted element forms (same as the reference, ``SURVEY.md`` 8b): an iterable
+``[graph_obj, node_labels(, edge_labels(, *extras))]`` where ``graph_obj`` is an
+adjacency matrix (ndarray / list of lists / scipy.sparse) or an edge dictionary
+(``{(u,v): w}``, ``{u: [v..]}``, ``{u: {v: w}}``, iterable of 2-/3-tuples), or any
+object exposing ``get_edge_dictionary()`` / ``get_labels()`` (a ``grakel.Graph``).
+"""
+import numbers
+import warnings
+from collections.abc import Iterable
+from itertools import chain
+
+import numpy as np
+from scipy.sparse import issparse
+
+
+class GraphBatch(object):
+    """A set of graphs packed as CSR (int32), the unit the HIP library consumes.
+
+    graph_ptr[n_graphs+1], row_ptr[n_nodes+1], col_idx[n_edges] (global node ids),
+    node_label[n_nodes] (dense level-0 ids), n_labels (ids are < n_labels),
+    edge_weight[n_edges] or None (ShortestPath only).
+    """
+
+    def __init__(self, graph_ptr, row_ptr, col_idx, node_label, n_labels, edge_weight=None):
+        self.graph_ptr = np.ascontiguousarray(graph_ptr, dtype=np.int32)
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        self.node_label = np.ascontiguousarray(node_label, dtype=np.int32)
+        self.n_labels = int(n_labels)
+        self.edge_weight = None if edge_weight is None else np.ascontiguousarray(edge_weight, np.int32)
+        if self.row_ptr.shape[0] != self.node_label.shape[0] + 1:
+            raise ValueError("GraphBatch: row_ptr must have n_nodes+1 entries")
+        if int(self.graph_ptr[-1]) != self.n_nodes or int(self.row_ptr[-1]) != self.n_edges:
+            raise ValueError("GraphBatch: inconsistent pointer arrays")
+
+    n_graphs = property(lambda self: self.graph_ptr.shape[0] - 1)
+    n_nodes = property(lambda self: self.node_label.shape[0])
+    n_edges = property(lambda self: self.col_idx.shape[0])
+
+    def slice_graphs(self, lo, hi):
+        """Sub-batch of graphs [lo, hi) (multi-GPU sharding of the input)."""
+        v0, v1 = int(self.graph_ptr[lo]), int(self.graph_ptr[hi])
+        e0, e1 = int(self.row_ptr[v0]), int(self.row_ptr[v1])
+        ew = None if self.edge_weight is None else self.edge_weight[e0:e1]
+        return GraphBatch(self.graph_ptr[lo:hi + 1] - v0, self.row_ptr[v0:v1 + 1] - e0,
+                          self.col_idx[e0:e1] - v0, self.node_label[v0:v1], self.n_labels, ew)
+
+    @staticmethod
+    def concat(a, b):
+        """Union batch: graphs of ``a`` first, then graphs of ``b`` (transform = fit + targets)."""
+        ew = None
+        if a.edge_weight is not None and b.edge_weight is not None:
+            ew = np.concatenate([a.edge_weight, b.edge_weight])
+        return GraphBatch(
+            np.concatenate([a.graph_ptr, b.graph_ptr[1:] + a.n_nodes]),
+            np.concatenate([a.row_ptr, b.row_ptr[1:] + a.n_edges]),
+            np.concatenate([a.col_idx, b.col_idx + a.n_nodes]),
+            np.concatenate([a.node_label, b.node_label]),
+            max(a.n_labels, b.n_labels), ew)
+
+
+# ------------------------------------------------------------------------------------------
+# element validation shared by the three kernels
+# ------------------------------------------------------------------------------------------
+def _is_graph_object(x):
+    return hasattr(x, "get_edge_dictionary") and hasattr(x, "get_labels")
+
+
+def iter_elements(X, len_ok, type_msg, not_iterable=TypeError):
+    """Yield validated elements; empty elements warn and are skipped (reference behaviour)."""
+    if not isinstance(X, Iterable):
+        raise not_iterable('input must be an iterable\n')
+    n = 0
+    for idx, x in enumerate(iter(X)):
+        if _is_graph_object(x):
+            n += 1
+            yield x
+            continue
+        if not isinstance(x, Iterable):
+            raise TypeError(type_msg)
+        x = list(x)
+        if len(x) == 0:
+            warnings.warn('Ignoring empty element on index: ' + str(idx))
+            continue
+        if not len_ok(len(x)):
+            raise TypeError(type_msg)
+        n += 1
+        yield x
+    if n == 0:
+        raise ValueError('parsed input is empty')
+
+
+# ------------------------------------------------------------------------------------------
+# graph object -> (sources, destinations[, weights]) in the graph's own vertex symbols
+# ------------------------------------------------------------------------------------------
+def _adjacency_array(g):
+    if isinstance(g, np.ndarray) and g.ndim == 2:
+        return g
+    if issparse(g):
+        return np.asarray(g.todense())
+    if type(g) is list and all(isinstance(r, list) and
+                               all(isinstance(i, numbers.Number) for i in r) for r in g):
+        return np.array(g)
+    return None
+
+
+def _edge_lists(g):
+    """Normalise an edge-dictionary style object to {u: {v: w}} (weights kept for SP).
+
+    Detection order follows grakel/graph.py:1613-1705.  Returns (vertices_set, nested dict)
+    or None when the object is not a supported edge dictionary.
+    """
+    nested = None
+    if type(g) is dict:
+        if all(type(k) is tuple and len(k) == 2 and isinstance(w, numbers.Number)
+               for k, w in g.items()):
+            nested = dict()
+            for (a, b), w in g.items():
+                nested.setdefault(a, dict())[b] = w
+            keys = {k[0] for k in g}
+        elif all(isinstance(d, list) for d in g.values()):
+            nested = {a: dict.fromkeys(lst, 1.) for a, lst in g.items() if len(lst)}
+            keys = set(g.keys())
+        elif all(isinstance(d, dict) and all(isinstance(w, numbers.Number) for w in d.values())
+                 for d in g.values()):
+            nested = {a: d for a, d in g.items()}
+            keys = set(g.keys())
+    if nested is None:
+        try:
+            items = list(g)
+        except TypeError:
+            return None
+        if all(type(t) is tuple and len(t) == 2 for t in items):
+            nested = dict()
+            for a, b in items:
+                nested.setdefault(a, dict())[b] = 1.
+        elif all(type(t) is tuple and len(t) == 3 for t in items):
+            nested = dict()
+            for a, b, w in items:
+                nested.setdefault(a, dict())[b] = w
+        else:
+            return None
+        keys = set(nested.keys())
+    vertices = set(keys)
+    for d in nested.values():
+        vertices.update(d.keys())
+    return vertices, nested
+
+
+def _unsupported():
+    return ValueError('Unsupported input type. For more information check the documentation, '
+                      'concerning valid input types for graph type object.')
+
+
+# ------------------------------------------------------------------------------------------
+# WL / VH ingestion: nodes are the LABELLED vertices (weisfeiler_lehman.py:234: `for v in L[j]`)
+# ------------------------------------------------------------------------------------------
+def _wl_graph_arrays(gobj, labels):
+    """-> (label_values list, src idx array, dst idx array) with node index = position in labels."""
+    if not isinstance(labels, dict):
+        raise TypeError('node labels must be a dictionary')
+    n = len(labels)
+    keys = list(labels.keys())
+    identity = keys == list(range(n))
+    A = _adjacency_array(gobj)
+    if A is not None:
+        if A.shape[0] != A.shape[1]:
+            raise ValueError('input matrix must be squared')
+        ii, jj = np.nonzero(A > 0)                       # graph.py:963-965
+        if identity and A.shape[0] == n:
+            return list(labels.values()), ii, jj
+        pos = {k: i for i, k in enumerate(keys)}
+        keep = np.fromiter((i in pos for i in ii.tolist()), bool, len(ii))
+        ii, jj = ii[keep], jj[keep]
+        try:
+            jmap = np.fromiter((pos[j] for j in jj.tolist()), np.int64, len(jj))
+        except KeyError as e:
+            raise KeyError(e.args[0])                    # unlabelled neighbour: weisfeiler_lehman.py:238
+        imap = np.fromiter((pos[i] for i in ii.tolist()), np.int64, len(ii))
+        return list(labels.values()), imap, jmap
+    if type(gobj) is dict and identity and len(gobj) and all(type(l) is list for l in gobj.values()):
+        # fast path: {u: [v, ...]} over vertices 0..n-1 (what graph generators emit)
+        try:
+            gkeys = np.fromiter(gobj.keys(), np.int64, len(gobj))
+            lens = np.fromiter(map(len, gobj.values()), np.int64, len(gobj))
+            flat = np.fromiter(chain.from_iterable(gobj.values()), np.int64, int(lens.sum()))
+            ok = (gkeys.min() >= 0 and gkeys.max() < n and
+                  (flat.size == 0 or (flat.min() >= 0 and flat.max() < n)))
+        except (TypeError, ValueError):
+            ok = False
+        if ok:
+            return list(labels.values()), np.repeat(gkeys, lens), flat
+    if _is_graph_object(gobj):
+        nested = gobj.get_edge_dictionary()
+    else:
+        r = _edge_lists(gobj)
+        if r is None:
+            raise _unsupported()
+        nested = r[1]
+    pos = {k: i for i, k in enumerate(keys)}
+    src, dst = [], []
+    for v, i in pos.items():
+        d = nested.get(v)
+        if d:
+            for nb in d.keys():
+                src.append(i)
+                dst.append(pos[nb])                       # KeyError like the reference
+    return list(labels.values()), np.asarray(src, np.int64), np.asarray(dst, np.int64)
+
+
+def compress_labels(values, fitted=None):
+    """Level-0 label compression (weisfeiler_lehman.py:199-210, transform :417-418).
+
+    values: flat python list of label objects.  fit: ids follow ``sorted(distinct)``;
+    transform: fitted ids are reused, unseen values get ids >= len(fitted) in sorted order.
+    Returns (int32 ids, mapping dict label -> id used for FIT (or the extension for transform)).
+    """
+    arr = None
+    try:
+        cand = np.asarray(values)
+        if cand.ndim == 1 and cand.dtype.kind in "iu" and len(values) == cand.shape[0]:
+            arr = cand
+    except Exception:
+        arr = None
+    if fitted is None:
+        if arr is not None:
+            uniq, inv = np.unique(arr, return_inverse=True)
+            return inv.astype(np.int32), {int(u): i for i, u in enumerate(uniq.tolist())}
+        mapping = {dv: i for i, dv in enumerate(sorted(set(values)))}
+        return np.fromiter((mapping[v] for v in values), np.int32, len(values)), mapping
+    nl = len(fitted)
+    fresh = sorted({v for v in values if v not in fitted})
+    ext = {dv: nl + i for i, dv in enumerate(fresh)}
+    ids = np.fromiter((fitted[v] if v in fitted else ext[v] for v in values), np.int32, len(values))
+    return ids, ext
+
+
+def _pack_csr(n_nodes_per_graph, srcs, dsts, weights=None):
+    """Concatenate per-graph local (src,dst) arrays into one global, de-duplicated CSR."""
+    sizes = np.asarray(n_nodes_per_graph, dtype=np.int64)
+    graph_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=graph_ptr[1:])
+    V = int(graph_ptr[-1])
+    if V >= 2 ** 31 - 1:
+        raise ValueError("batch too large for int32 node indices")
+    offs = np.repeat(graph_ptr[:-1], [len(s) for s in srcs]) if srcs else np.zeros(0, np.int64)
+    src = (np.concatenate(srcs) if srcs else np.zeros(0, np.int64)) + offs
+    dst = (np.concatenate(dsts) if dsts else np.zeros(0, np.int64)) + offs
+    w = np.concatenate(weights) if weights is not None and weights else None
+    key = src * np.int64(V if V > 0 else 1) + dst
+    if key.size and not np.all(key[1:] > key[:-1]):
+        # not already (src,dst)-sorted & unique: sort and collapse duplicates (dict semantics:
+        # a repeated edge is one key; for weights the LAST occurrence wins like a dict assignment)
+        order = np.argsort(key, kind="stable")
+        key, src, dst = key[order], src[order], dst[order]
+        last = np.ones(key.size, bool)
+        last[:-1] = key[1:] != key[:-1]
+        src, dst = src[last], dst[last]
+        if w is not None:
+            w = w[order][last]
+    row_ptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=V), out=row_ptr[1:])
+    return graph_ptr, row_ptr, dst, w
+
+
+def wl_batch_from_input(X, fitted_labels=None, min_len=2, not_iterable=TypeError):
+    """Ingest the WL / VH input -> (GraphBatch, label mapping)."""
+    if isinstance(X, GraphBatch):
+        return X, None
+    msg = ('each element of X must be either a graph object or a list with at least a graph '
+           'like object and node labels dict \n')
+    sizes, srcs, dsts, values = [], [], [], []
+    for x in iter_elements(X, lambda n: n >= min_len, msg, not_iterable):
+        if _is_graph_object(x):
+            if hasattr(x, "desired_format"):
+                x.desired_format("dictionary")
+            gobj, labels = x, x.get_labels(purpose="dictionary")
+        else:
+            gobj, labels = x[0], x[1]
+        vals, s, d = _wl_graph_arrays(gobj, labels)
+        sizes.append(len(vals)), srcs.append(s), dsts.append(d)
+        values.extend(vals)
+    ids, mapping = compress_labels(values, fitted_labels)
+    n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
+    graph_ptr, row_ptr, col, _ = _pack_csr(sizes, srcs, dsts)
+    return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1)), mapping
+
+
+def vh_batch_from_input(X, fitted_labels=None):
+    """VertexHistogram only reads x[1].values() (vertex_histogram.py:96,107): no edges."""
+    if isinstance(X, GraphBatch):
+        return X, None
+    msg = ('each element of X must be either a graph object or a list with at least a graph '
+           'like object and node labels dict \n')
+    sizes, values = [], []
+    for x in iter_elements(X, lambda n: n in (2, 3), msg):
+        L = x.get_labels(purpose="any") if _is_graph_object(x) else x[1]
+        vals = list(L.values())
+        sizes.append(len(vals))
+        values.extend(vals)
+    ids, mapping = compress_labels(values, fitted_labels)
+    n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
+    gp = np.zeros(len(sizes) + 1, np.int64)
+    np.cumsum(sizes, out=gp[1:])
+    V = int(gp[-1])
+    return GraphBatch(gp, np.zeros(V + 1, np.int64), np.zeros(0, np.int64), ids, max(n_labels, 1)), mapping
+
+
+# ------------------------------------------------------------------------------------------
+# ShortestPath ingestion: nodes are ALL vertices of the graph, in the order the reference
+# indexes them (sorted symbols for edge dictionaries, graph.py:894-907; 0..n-1 for matrices)
+# ------------------------------------------------------------------------------------------
+def _sp_graph_arrays(gobj, labels, with_labels):
+    """-> (n, label_values list or None, src, dst, weight) with local vertex indices."""
+    A = _adjacency_array(gobj)
+    if A is not None:
+        if A.shape[0] != A.shape[1]:
+            raise ValueError('input matrix must be squared')
+        if np.any(A < 0):
+            raise NotImplementedError('ShortestPath on MI355X needs non-negative edge weights')
+        n = A.shape[0]
+        ii, jj = np.nonzero(A)                      # floyd_warshall: zero == no edge (graph.py:1785)
+        ww = A[ii, jj]
+        verts = range(n)
+    else:
+        if _is_graph_object(gobj):
+            nested = gobj.get_edge_dictionary()
+            vertices = set(nested.keys())
+            for d in nested.values():
+                vertices.update(d.keys())
+        else:
+            r = _edge_lists(gobj)
+            if r is None:
+                raise _unsupported()
+            vertices, nested = r
+        verts = sorted(vertices)
+        n = len(verts)
+        pos = {v: i for i, v in enumerate(verts)}
+        src, dst, wl = [], [], []
+        for a, d in nested.items():
+            ia = pos[a]
+            for b, w in d.items():
+                src.append(ia), dst.append(pos[b]), wl.append(w)
+        ii, jj, ww = np.asarray(src, np.int64), np.asarray(dst, np.int64), np.asarray(wl)
+    if ww.size:
+        wi = np.rint(ww).astype(np.int64)
+        if not np.array_equal(wi, ww) or wi.min() <= 0:
+            raise NotImplementedError('ShortestPath on MI355X supports positive integer edge '
+                                      'weights only (float weights make the reference use float '
+                                      'sums as dictionary keys, SURVEY.md 7.5c)')
+        if wi.max() >= 2 ** 20:
+            raise NotImplementedError('edge weight too large for the int32 distance path')
+    else:
+        wi = np.zeros(0, np.int64)
+    vals = None
+    if with_labels:
+        if not labels:
+            raise ValueError('Graph does not have any labels for vertices.')   # graph.py:737-738
+        vals = [labels[v] for v in verts]            # KeyError when a vertex has no label
+    return n, vals, ii, jj, wi
+
+
+def sp_batch_from_input(X, with_labels, fitted_labels=None):
+    if isinstance(X, GraphBatch):
+        return X, None
+    msg = 'each element of X must have at least one and at most 3 elements\n'
+    ok = (lambda n: n in (2, 3)) if with_labels else (lambda n: n in (1, 2, 3))
+    sizes, srcs, dsts, wts, values = [], [], [], [], []
+    for x in iter_elements(X, ok, msg):
+        if _is_graph_object(x):
+            gobj, labels = x, (x.get_labels(purpose="dictionary") if with_labels else {})
+        else:
+            gobj, labels = x[0], (x[1] if len(x) > 1 else {})
+        n, vals, s, d, w = _sp_graph_arrays(gobj, labels, with_labels)
+        sizes.append(n), srcs.append(s), dsts.append(d), wts.append(w)
+        if with_labels:
+            values.extend(vals)
+    if with_labels:
+        ids, mapping = compress_labels(values, fitted_labels)
+        n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
+    else:
+        ids, mapping, n_labels = np.zeros(int(np.sum(sizes)), np.int32), {}, 1
+    graph_ptr, row_ptr, col, w = _pack_csr(sizes, srcs, dsts, wts)
+    if w is None:
+        w = np.zeros(0, np.int64)
+    return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1), edge_weight=w), mapping

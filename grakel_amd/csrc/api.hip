@@ -1,0 +1,135 @@
+// Context, error reporting, allocation and timing entry points of libgk_hip.so.
+#include "common.h"
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+
+void gk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* gk_last_error(void) { return g_err; }
+extern "C" const char* gk_version(void) { return "gk_hip 0.1 (gfx950)"; }
+
+extern "C" int gk_device_count(int* out_count) {
+    GK_ARG(out_count, "gk_device_count: null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *out_count = n;
+    return GK_OK;
+}
+
+extern "C" int gk_create(int device_id, gk_ctx** out) {
+    GK_ARG(out, "gk_create: null out");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        gk_set_error("gk_create: no HIP device visible (this library has no CPU fallback)");
+        return GK_ERR_HIP;
+    }
+    GK_ARG(device_id >= 0 && device_id < n, "gk_create: bad device id");
+    GK_HIP_CHECK(hipSetDevice(device_id));
+    gk_ctx* ctx = new gk_ctx();
+    ctx->device = device_id;
+    GK_HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    GK_HIP_CHECK(hipEventCreate(&ctx->ev0));
+    GK_HIP_CHECK(hipEventCreate(&ctx->ev1));
+    GK_HIP_CHECK(hipEventCreate(&ctx->pv0));
+    GK_HIP_CHECK(hipEventCreate(&ctx->pv1));
+    // keep freed blocks cached in the pool: the per-level temporaries are re-requested
+    // every iteration and must not go back to the driver
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess) {
+        uint64_t thr = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    (void)hipGetLastError();
+    *out = ctx;
+    return GK_OK;
+}
+
+extern "C" int gk_destroy(gk_ctx* ctx) {
+    if (!ctx) return GK_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipEventDestroy(ctx->pv0);
+    (void)hipEventDestroy(ctx->pv1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return GK_OK;
+}
+
+extern "C" int gk_set_stream(gk_ctx* ctx, void* hip_stream) {
+    GK_ARG(ctx, "gk_set_stream: null ctx");
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return GK_OK;
+}
+
+extern "C" int gk_synchronize(gk_ctx* ctx) {
+    GK_ARG(ctx, "gk_synchronize: null ctx");
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return GK_OK;
+}
+
+extern "C" int gk_timer_start(gk_ctx* ctx) {
+    GK_ARG(ctx, "gk_timer_start: null ctx");
+    GK_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+    return GK_OK;
+}
+
+extern "C" int gk_timer_stop_ms(gk_ctx* ctx, double* out_ms) {
+    GK_ARG(ctx && out_ms, "gk_timer_stop_ms: null argument");
+    GK_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    GK_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    GK_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *out_ms = ms;
+    return GK_OK;
+}
+
+extern "C" int gk_profile_enable(gk_ctx* ctx, int enable) {
+    GK_ARG(ctx, "gk_profile_enable: null ctx");
+    ctx->profile = enable != 0;
+    return GK_OK;
+}
+
+extern "C" int gk_profile_reset(gk_ctx* ctx) {
+    GK_ARG(ctx, "gk_profile_reset: null ctx");
+    ctx->prof.clear();
+    return GK_OK;
+}
+
+extern "C" int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_launches) {
+    GK_ARG(ctx && name, "gk_profile_get: null argument");
+    auto it = ctx->prof.find(name);
+    if (out_ms) *out_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    if (out_launches) *out_launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return GK_OK;
+}
+
+int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMallocAsync(p, bytes, ctx->stream);
+    if (e != hipSuccess) {
+        gk_set_error("device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        *p = nullptr;
+        return GK_ERR_HIP;
+    }
+    return GK_OK;
+}
+
+void gk_dev_free(gk_ctx* ctx, void* p) {
+    if (p) (void)hipFreeAsync(p, ctx->stream);
+}

@@ -1,0 +1,173 @@
+// Internal declarations shared by the translation units of libgk_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/gk_hip.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int64_t i64;
+typedef int32_t i32;
+
+void gk_set_error(const char* fmt, ...);
+
+#define GK_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            gk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                         __LINE__);                                                     \
+            return GK_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define GK_TRY(expr)                 \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != GK_OK) return _r;  \
+    } while (0)
+
+#define GK_ARG(cond, msg)            \
+    do {                             \
+        if (!(cond)) {               \
+            gk_set_error("%s", msg); \
+            return GK_ERR_ARG;       \
+        }                            \
+    } while (0)
+
+static inline i64 cdiv(i64 a, i64 b) { return (a + b - 1) / b; }
+static inline i64 round_up(i64 a, i64 b) { return cdiv(a, b) * b; }
+
+struct ProfSlot {
+    double ms = 0;
+    i64 launches = 0;
+};
+
+struct gk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // user timer
+    hipEvent_t pv0 = nullptr, pv1 = nullptr;   // profile timer
+    bool profile = false;
+    std::map<std::string, ProfSlot> prof;
+};
+
+// Stream-ordered device allocation from the device's default mempool (release threshold is
+// raised in gk_create so freed blocks are cached instead of being returned to the driver).
+int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes);
+void gk_dev_free(gk_ctx* ctx, void* p);
+
+// RAII temp buffer (freed stream-ordered at scope exit).
+template <typename T>
+struct Tmp {
+    gk_ctx* ctx;
+    T* p = nullptr;
+    explicit Tmp(gk_ctx* c) : ctx(c) {}
+    int alloc(size_t n) {
+        void* q = nullptr;
+        int r = gk_dev_alloc(ctx, &q, (n ? n : 1) * sizeof(T));
+        p = (T*)q;
+        return r;
+    }
+    ~Tmp() {
+        if (p) gk_dev_free(ctx, p);
+    }
+    Tmp(const Tmp&) = delete;
+    Tmp& operator=(const Tmp&) = delete;
+};
+
+struct ProfScope {
+    gk_ctx* ctx;
+    const char* name;
+    i64 launches;
+    ProfScope(gk_ctx* c, const char* n, i64 l = 1) : ctx(c), name(n), launches(l) {
+        if (ctx->profile) (void)hipEventRecord(ctx->pv0, ctx->stream);
+    }
+    ~ProfScope() {
+        if (ctx->profile) {
+            (void)hipEventRecord(ctx->pv1, ctx->stream);
+            (void)hipEventSynchronize(ctx->pv1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ctx->pv0, ctx->pv1);
+            ProfSlot& s = ctx->prof[name];
+            s.ms += ms;
+            s.launches += launches;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Batch: CSR graphs + per-level WL labels and label-grouped node orders.
+// ---------------------------------------------------------------------------------------
+struct gk_batch {
+    gk_ctx* ctx = nullptr;
+    i64 n_graphs = 0, n_nodes = 0, n_edges = 0;
+    i32 n_labels0 = 0;
+    i32 max_graph_nodes = 0;
+    i32* graph_ptr = nullptr;   // [n_graphs+1]
+    i32* row_ptr = nullptr;     // [n_nodes+1]
+    i32* col_idx = nullptr;     // [n_edges]
+    i32* node_graph = nullptr;  // [n_nodes]
+    i32* big_nodes = nullptr;   // [n_big] nodes with degree > WL_DEG_SMALL
+    i64 n_big = 0;
+    i32 max_degree = 0;
+    // levels
+    int n_levels = 0;                  // levels currently valid (0 = only level-0 labels)
+    int cap_levels = 0;
+    i32* labels = nullptr;             // [cap_levels][n_nodes]
+    i32* perm = nullptr;               // [cap_levels][n_nodes] nodes grouped by label (stable)
+    std::vector<i64> label_counts;     // per level
+    // scratch kept between levels
+    i32* nbr_sorted = nullptr;         // [n_edges] sorted neighbour labels of the level being built
+    bool is_pair_batch = false;        // ShortestPath items: no CSR, level 0 only
+};
+
+// ---------------------------------------------------------------------------------------
+// Features
+// ---------------------------------------------------------------------------------------
+struct LevelTriples {
+    i32* tri_pos = nullptr;    // [n_nodes+1] start position (in perm order) of each triple
+    i32* tri_graph = nullptr;  // [n_nodes+1]
+    i32* tri_run = nullptr;    // [n_nodes+1] label run index of each triple
+    i32* tstart = nullptr;     // [n_nodes+1] first triple of each label run
+    i32* colid = nullptr;      // [n_nodes]   kept-column id per label run or -1
+};
+
+struct gk_feat {
+    gk_ctx* ctx = nullptr;
+    gk_batch* batch = nullptr;
+    int n_levels = 0;
+    i64 n_graphs = 0, n_fit = 0, n_nodes = 0;
+    bool symmetric = true;
+    std::vector<LevelTriples> lev;
+    u32* meta = nullptr;        // device: per level {T, R, ncols_cum}, then globals
+    u64* selfk = nullptr;       // [n_graphs] exact integer self similarity
+    i64 n_cols = 0, n_cols_pad = 0, nnz = 0, max_count = 0;
+    i64 n_rows_pad = 0;
+    int dtype = 0;              // 0: int8 Phi, 1: f64 Phi
+    void* phi = nullptr;        // [n_rows_pad][n_cols_pad]
+    double* K = nullptr;        // last Gram output (device)
+    i64 K_rows = 0, K_cols = 0;
+    double last_flops = 0, last_ms = 0;
+};
+
+// ---- primitives (scan_sort.hip) -------------------------------------------------------
+// inclusive/exclusive sums; `total` (device, may be null) receives the grand total.
+int gk_scan_u32(gk_ctx* ctx, const u32* in, u32* out, i64 n, bool exclusive, u32* total);
+int gk_scan_u64(gk_ctx* ctx, const u64* in, u64* out, i64 n, bool exclusive, u64* total);
+// Stable LSD radix sort of (key,value) pairs on key bits [0,key_bits). Result in keys_out /
+// vals_out; keys_in/vals_in are clobbered (used as ping-pong buffers).
+int gk_radix_sort_pairs(gk_ctx* ctx, u64* keys_in, u32* vals_in, u64* keys_out, u32* vals_out,
+                        i64 n, int key_bits);
+
+// ---- wl.hip ---------------------------------------------------------------------------
+int gk_batch_ensure_levels(gk_batch* b, int n_levels);
+
+// ---- gram.hip -------------------------------------------------------------------------
+int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normalize, double* K);

@@ -1,0 +1,240 @@
+// Label-count features (the VertexHistogram of every WL level) on gfx950.
+//
+// Input per level: labels[v] and perm[] = nodes grouped by label, ascending node (hence
+// ascending graph) inside a group -- exactly what the relabel sort leaves behind.  One pass
+// over perm order finds label-run heads and (label,graph) sub-run heads; a packed 64-bit
+// scan turns them into run ids and triple ids, so the sparse feature matrix falls out in
+// column-major (label-major) order without any per-graph sort:
+//      triple t = (label run r, graph g, count c),   c = tri_pos[t+1] - tri_pos[t]
+//      df[r]    = tstart[r+1] - tstart[r]            (# graphs containing the label)
+// selfk[g] += c^2 over ALL triples (the exact Gram diagonal); only columns that can touch an
+// off-diagonal entry are kept for the dense Phi_s that feeds the MFMA Gram:
+//      symmetric job   : df >= 2
+//      rectangular job : present in a fit graph (< n_fit) AND a target graph (>= n_fit)
+// HBM-bound integer work: ~16 bytes per node per level.
+#include "common.h"
+
+static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
+
+// meta layout (u32): per level l: [3l+0]=T (triples) [3l+1]=R (label runs) [3l+2]=cols kept so far
+// (cumulative INCLUDING level l); globals at [3*n_levels + 0]=max count
+#define META_T(l) (3 * (l) + 0)
+#define META_R(l) (3 * (l) + 1)
+#define META_C(l) (3 * (l) + 2)
+
+__global__ void feat_flags_kernel(const i32* __restrict__ perm, const i32* __restrict__ lab,
+                                  const i32* __restrict__ node_graph, u64* __restrict__ flag, i64 n) {
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    i32 v = perm[k];
+    u64 f = 0x100000001ull;
+    if (k > 0) {
+        i32 p = perm[k - 1];
+        bool lh = lab[v] != lab[p];
+        bool sh = lh || node_graph[v] != node_graph[p];
+        f = ((u64)lh << 32) | (u64)sh;
+    }
+    flag[k] = f;
+}
+
+__global__ void feat_emit_kernel(const i32* __restrict__ perm, const i32* __restrict__ node_graph,
+                                 const u64* __restrict__ flag, const u64* __restrict__ scan,
+                                 i32* __restrict__ tri_pos, i32* __restrict__ tri_graph,
+                                 i32* __restrict__ tri_run, i32* __restrict__ tstart,
+                                 u32* __restrict__ meta, int level, i64 n) {
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    u64 f = flag[k], s = scan[k];
+    i32 t = (i32)(u32)(s & 0xffffffffull) - 1;
+    i32 r = (i32)(u32)(s >> 32) - 1;
+    if (f & 1ull) {
+        tri_pos[t] = (i32)k;
+        tri_graph[t] = node_graph[perm[k]];
+        tri_run[t] = r;
+    }
+    if (f >> 32) tstart[r] = t;
+    if (k == n - 1) {   // sentinels + counts
+        tri_pos[t + 1] = (i32)n;
+        tstart[r + 1] = t + 1;
+        meta[META_T(level)] = (u32)(t + 1);
+        meta[META_R(level)] = (u32)(r + 1);
+    }
+}
+
+// per triple: exact self similarity and the largest count
+__global__ void feat_stats_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_graph,
+                                  u64* __restrict__ selfk, u32* __restrict__ meta, int level,
+                                  int n_levels) {
+    const u32 T = meta[META_T(level)];
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = 0;
+    if (t < T) {
+        c = (u32)(tri_pos[t + 1] - tri_pos[t]);
+        atomicAdd((unsigned long long*)&selfk[tri_graph[t]], (unsigned long long)c * c);
+    }
+    // wave max, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        u32 o = __shfl_down(c, off, 64);
+        c = o > c ? o : c;
+    }
+    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(&meta[3 * n_levels], c);
+}
+
+__global__ void feat_colflag_kernel(const i32* __restrict__ tstart, const i32* __restrict__ tri_graph,
+                                    u32* __restrict__ flag, const u32* __restrict__ meta, int level,
+                                    int symmetric, i32 n_fit, i64 n) {
+    i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    u32 keep = 0;
+    if (r < (i64)meta[META_R(level)]) {
+        i32 t0 = tstart[r], t1 = tstart[r + 1];
+        if (symmetric) keep = (t1 - t0) >= 2;
+        else keep = (tri_graph[t0] < n_fit) && (tri_graph[t1 - 1] >= n_fit);
+    }
+    flag[r] = keep;
+}
+
+__global__ void feat_colid_kernel(const u32* __restrict__ flag, const u32* __restrict__ excl,
+                                  const u32* __restrict__ total, i32* __restrict__ colid,
+                                  u32* __restrict__ meta, int level, i64 n) {
+    i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 base = level > 0 ? meta[META_C(level - 1)] : 0u;
+    if (r < n) colid[r] = flag[r] ? (i32)(base + excl[r]) : -1;
+    if (r == 0) meta[META_C(level)] = base + *total;
+}
+
+template <typename T>
+__global__ void feat_scatter_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_graph,
+                                    const i32* __restrict__ tri_run, const i32* __restrict__ colid,
+                                    const u32* __restrict__ meta, int level, T* __restrict__ phi, i64 ld) {
+    const u32 Tn = meta[META_T(level)];
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tn) return;
+    i32 c = colid[tri_run[t]];
+    if (c < 0) return;
+    phi[(i64)tri_graph[t] * ld + c] = (T)(tri_pos[t + 1] - tri_pos[t]);
+}
+
+extern "C" int gk_features_destroy(gk_feat* f) {
+    if (!f) return GK_OK;
+    gk_ctx* ctx = f->ctx;
+    for (auto& L : f->lev) {
+        void* ptrs[] = {L.tri_pos, L.tri_graph, L.tri_run, L.tstart, L.colid};
+        for (void* p : ptrs)
+            if (p) gk_dev_free(ctx, p);
+    }
+    void* ptrs[] = {f->meta, f->selfk, f->phi, f->K};
+    for (void* p : ptrs)
+        if (p) gk_dev_free(ctx, p);
+    delete f;
+    return GK_OK;
+}
+
+extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, gk_feat** out) {
+    GK_ARG(ctx && b && out, "gk_features_build: null argument");
+    GK_ARG(n_levels >= 1 && n_levels <= (b->n_levels > 0 ? b->n_levels : 1),
+           "gk_features_build: levels not computed (call gk_wl_relabel first)");
+    GK_ARG(n_fit >= 1 && n_fit <= b->n_graphs, "gk_features_build: bad n_fit");
+    GK_ARG(b->n_levels > 0, "gk_features_build: batch has no label-grouped order (call gk_wl_relabel with n_iter>=0)");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    ProfScope prof(ctx, "features");
+    const i64 V = b->n_nodes, N = b->n_graphs;
+    gk_feat* f = new gk_feat();
+    f->ctx = ctx, f->batch = b, f->n_levels = n_levels, f->n_graphs = N, f->n_fit = n_fit, f->n_nodes = V;
+    f->symmetric = (n_fit == N);
+    f->lev.resize(n_levels);
+    auto fail = [&](int r) { gk_features_destroy(f); return r; };
+    int r;
+    void* q = nullptr;
+    const size_t n_meta = 3 * (size_t)n_levels + 4;
+    if ((r = gk_dev_alloc(ctx, &q, n_meta * 4))) return fail(r);
+    f->meta = (u32*)q;
+    if ((r = gk_dev_alloc(ctx, &q, (size_t)N * 8))) return fail(r);
+    f->selfk = (u64*)q;
+    if (hipMemsetAsync(f->meta, 0, n_meta * 4, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(f->selfk, 0, (size_t)N * 8, ctx->stream) != hipSuccess) {
+        gk_set_error("gk_features_build: memset failed");
+        return fail(GK_ERR_HIP);
+    }
+    Tmp<u64> flag(ctx), scan(ctx);
+    Tmp<u32> cflag(ctx), cexcl(ctx), ctotal(ctx);
+    if ((r = flag.alloc(V)) || (r = scan.alloc(V)) || (r = cflag.alloc(V)) || (r = cexcl.alloc(V)) ||
+        (r = ctotal.alloc(1)))
+        return fail(r);
+    for (int l = 0; l < n_levels && V > 0; ++l) {
+        LevelTriples& L = f->lev[l];
+        i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid};
+        for (i32** a : arrs) {
+            if ((r = gk_dev_alloc(ctx, &q, (size_t)(V + 1) * 4))) return fail(r);
+            *a = (i32*)q;
+        }
+        const i32* lab = b->labels + (size_t)l * V;
+        const i32* perm = b->perm + (size_t)l * V;
+        feat_flags_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, lab, b->node_graph, flag.p, V);
+        if ((r = gk_scan_u64(ctx, flag.p, scan.p, V, false, nullptr))) return fail(r);
+        feat_emit_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, b->node_graph, flag.p, scan.p, L.tri_pos,
+                                                                    L.tri_graph, L.tri_run, L.tstart, f->meta, l, V);
+        feat_stats_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(L.tri_pos, L.tri_graph, f->selfk, f->meta, l, n_levels);
+        feat_colflag_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(L.tstart, L.tri_graph, cflag.p, f->meta, l,
+                                                                       f->symmetric ? 1 : 0, (i32)n_fit, V);
+        if ((r = gk_scan_u32(ctx, cflag.p, cexcl.p, V, true, ctotal.p))) return fail(r);
+        feat_colid_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(cflag.p, cexcl.p, ctotal.p, L.colid, f->meta, l, V);
+    }
+    // one host sync: sizes of the dense operand
+    std::vector<u32> h(n_meta);
+    if (hipMemcpyAsync(h.data(), f->meta, n_meta * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        gk_set_error("gk_features_build: %s", hipGetErrorString(hipGetLastError()));
+        return fail(GK_ERR_HIP);
+    }
+    f->nnz = 0;
+    for (int l = 0; l < n_levels; ++l) f->nnz += h[META_T(l)];
+    f->n_cols = V > 0 ? h[META_C(n_levels - 1)] : 0;
+    f->max_count = h[3 * n_levels];
+    // int8 operands need counts <= 127 and every Gram entry < 2^31:
+    // K_ij <= sqrt(K_ii K_jj) <= n_levels * max_graph_nodes^2
+    const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
+    f->dtype = (f->max_count <= 127 && bound < 2147483647.0) ? 0 : 1;
+    const i64 esz = f->dtype == 0 ? 1 : 8;
+    f->n_cols_pad = round_up(f->n_cols > 0 ? f->n_cols : 1, 128);
+    f->n_rows_pad = round_up(N, 256) + 256;   // slack so that tile loads never need row guards
+    const size_t phi_bytes = (size_t)f->n_rows_pad * f->n_cols_pad * esz;
+    if ((r = gk_dev_alloc(ctx, &q, phi_bytes))) return fail(r);
+    f->phi = q;
+    if (hipMemsetAsync(f->phi, 0, phi_bytes, ctx->stream) != hipSuccess) return fail(GK_ERR_HIP);
+    for (int l = 0; l < n_levels && V > 0; ++l) {
+        LevelTriples& L = f->lev[l];
+        u32 T = h[META_T(l)];
+        if (T == 0) continue;
+        if (f->dtype == 0)
+            feat_scatter_kernel<int8_t><<<grid_for(T, 256), 256, 0, ctx->stream>>>(
+                L.tri_pos, L.tri_graph, L.tri_run, L.colid, f->meta, l, (int8_t*)f->phi, f->n_cols_pad);
+        else
+            feat_scatter_kernel<double><<<grid_for(T, 256), 256, 0, ctx->stream>>>(
+                L.tri_pos, L.tri_graph, L.tri_run, L.colid, f->meta, l, (double*)f->phi, f->n_cols_pad);
+    }
+    if (hipGetLastError() != hipSuccess) {
+        gk_set_error("gk_features_build: kernel launch failed");
+        return fail(GK_ERR_HIP);
+    }
+    *out = f;
+    return GK_OK;
+}
+
+extern "C" int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* nnz, int64_t* max_count, int* dtype) {
+    GK_ARG(f, "gk_features_info: null");
+    if (n_cols_kept) *n_cols_kept = f->n_cols;
+    if (nnz) *nnz = f->nnz;
+    if (max_count) *max_count = f->max_count;
+    if (dtype) *dtype = f->dtype;
+    return GK_OK;
+}
+
+extern "C" int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk) {
+    GK_ARG(ctx && f && out_selfk, "gk_features_selfk: null argument");
+    std::vector<u64> h(f->n_graphs);
+    GK_HIP_CHECK(hipMemcpyAsync(h.data(), f->selfk, (size_t)f->n_graphs * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (i64 i = 0; i < f->n_graphs; ++i) out_selfk[i] = (double)h[i];
+    return GK_OK;
+}

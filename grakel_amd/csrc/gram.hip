@@ -1,0 +1,275 @@
+// Gram matrix  K = Phi_rows . Phi_cols^T  on the MFMA units of gfx950.
+//
+// Label counts are small non-negative integers, so the product is EXACT integer arithmetic:
+//   dtype 0: int8 operands, v_mfma_i32_32x32x32_i8, int32 accumulate (counts <= 127 and
+//            K < 2^31 are checked when the features are built) -- the fast path, 2x the bf16
+//            MFMA rate and bit-exact versus the reference's float64 result;
+//   dtype 1: float64 operands, v_mfma_f64_16x16x4_f64 -- general path (any count, exact while
+//            K < 2^53), used by ShortestPath histograms with counts > 127.
+// The epilogue fuses what the reference does in three extra N^2 passes: the per-level sum
+// (all levels are concatenated along K), the diagonal (graph-unique label columns are not
+// in Phi_s; K_ii is written from the exact selfk vector instead) and the normalisation
+// K_ij / sqrt(K_ii K_jj) (weisfeiler_lehman.py:323-328, kernel.py:195-204).
+#include "common.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double finish_entry(double val, i64 grow, i64 gcol, bool symmetric,
+                                               const u64* __restrict__ selfk, i64 n_fit, int normalize) {
+    // rows index graphs [row_base, ...), cols index graphs [0, n_cols)
+    if (symmetric && grow == gcol) val = (double)selfk[grow];
+    if (normalize) {
+        double dr = (double)selfk[symmetric ? grow : n_fit + grow];
+        double dc = (double)selfk[gcol];
+        val = val / sqrt(dr * dc);
+        if (normalize == 2) {   // numpy.nan_to_num
+            if (val != val) val = 0.0;
+            else if (val > 1.7976931348623157e308) val = 1.7976931348623157e308;
+        }
+    }
+    return val;
+}
+
+// ---------------------------------------------------------------------------------------
+// int8 path: 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave as 2x2
+// MFMA 32x32 tiles), K-step 64 bytes, register-staged double buffering through LDS.
+// LDS rows are padded to 80 B so that both the ds_write_b128 (8-lane groups) and the
+// ds_read_b128 (16-lane groups) are bank-conflict free: slot = (5*row + c) mod 16.
+// ---------------------------------------------------------------------------------------
+#define GI_BM 128
+#define GI_BN 128
+#define GI_BK 64
+#define GI_LD 80
+
+__global__ __launch_bounds__(256, 2) void gram_i8_kernel(
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles,
+    const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
+    int symmetric, i64 n_fit, int normalize, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) int8_t sA[2][GI_BM * GI_LD];
+    __shared__ __attribute__((aligned(16))) int8_t sB[2][GI_BN * GI_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+
+    const int lrow = tid >> 2, lkc = tid & 3;   // 16-byte chunk owned by this thread (and +64 rows)
+    const int8_t* gA = A + ((i64)bm * GI_BM + lrow) * ld + lkc * 16;
+    const int8_t* gB = B + ((i64)bn * GI_BN + lrow) * ld + lkc * 16;
+    const i64 half = 64 * ld;
+    const int soff = lrow * GI_LD + lkc * 16;
+
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    v4i ra0 = *(const v4i*)(gA), ra1 = *(const v4i*)(gA + half);
+    v4i rb0 = *(const v4i*)(gB), rb1 = *(const v4i*)(gB + half);
+    *(v4i*)(&sA[0][soff]) = ra0;
+    *(v4i*)(&sA[0][soff + 64 * GI_LD]) = ra1;
+    *(v4i*)(&sB[0][soff]) = rb0;
+    *(v4i*)(&sB[0][soff + 64 * GI_LD]) = rb1;
+    __syncthreads();
+
+    const int a_off = (wm * 64 + (lane & 31)) * GI_LD + (lane >> 5) * 16;
+    const int b_off = (wn * 64 + (lane & 31)) * GI_LD + (lane >> 5) * 16;
+
+    for (int kt = 0; kt < k_tiles; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < k_tiles;
+        if (more) {
+            const i64 go = (i64)(kt + 1) * GI_BK;
+            ra0 = *(const v4i*)(gA + go);
+            ra1 = *(const v4i*)(gA + go + half);
+            rb0 = *(const v4i*)(gB + go);
+            rb1 = *(const v4i*)(gB + go + half);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i a0 = *(const v4i*)(&sA[cur][a_off + ks * 32]);
+            v4i a1 = *(const v4i*)(&sA[cur][a_off + 32 * GI_LD + ks * 32]);
+            v4i b0 = *(const v4i*)(&sB[cur][b_off + ks * 32]);
+            v4i b1 = *(const v4i*)(&sB[cur][b_off + 32 * GI_LD + ks * 32]);
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            const int nxt = cur ^ 1;
+            *(v4i*)(&sA[nxt][soff]) = ra0;
+            *(v4i*)(&sA[nxt][soff + 64 * GI_LD]) = ra1;
+            *(v4i*)(&sB[nxt][soff]) = rb0;
+            *(v4i*)(&sB[nxt][soff + 64 * GI_LD]) = rb1;
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const i64 col = (i64)bn * GI_BN + wn * 64 + nt * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const i64 row = (i64)bm * GI_BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < M && col < N) {
+                    double v = finish_entry((double)acc[mt][nt][r], row_base + row, col, symmetric != 0,
+                                            selfk, n_fit, normalize);
+                    K[row * N + col] = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// float64 path: 64x64 output tile per 256-thread workgroup (2x2 waves, 32x32 per wave as 2x2
+// MFMA 16x16x4 tiles), K-step 16.  A[i][k]: lane l holds i = l&15, k = l>>4; D: col = l&15,
+// row = (l>>4) + 4*reg.
+// ---------------------------------------------------------------------------------------
+#define GD_BM 64
+#define GD_BN 64
+#define GD_BK 16
+#define GD_LD 17
+
+__global__ __launch_bounds__(256) void gram_f64_kernel(
+    const double* __restrict__ A, const double* __restrict__ B, i64 ld, int k_tiles,
+    const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
+    int symmetric, i64 n_fit, int normalize, int tiles_n) {
+    __shared__ double sA[GD_BM * GD_LD];
+    __shared__ double sB[GD_BN * GD_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+    v4d acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+    // 64 rows x 16 doubles per operand tile = 1024 elements, 4 per thread
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    const double* gA = A + ((i64)bm * GD_BM + lrow) * ld + lk;
+    const double* gB = B + ((i64)bn * GD_BN + lrow) * ld + lk;
+    for (int kt = 0; kt < k_tiles; ++kt) {
+        const i64 go = (i64)kt * GD_BK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sA[lrow * GD_LD + lk + q] = gA[go + q];
+            sB[lrow * GD_LD + lk + q] = gB[go + q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = ks * 4 + (lane >> 4);
+            double a0 = sA[(wm * 32 + (lane & 15)) * GD_LD + kk];
+            double a1 = sA[(wm * 32 + 16 + (lane & 15)) * GD_LD + kk];
+            double b0 = sB[(wn * 32 + (lane & 15)) * GD_LD + kk];
+            double b1 = sB[(wn * 32 + 16 + (lane & 15)) * GD_LD + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const i64 col = (i64)bn * GD_BN + wn * 32 + nt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const i64 row = (i64)bm * GD_BM + wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
+                if (row < M && col < N) {
+                    double v = finish_entry(acc[mt][nt][r], row_base + row, col, symmetric != 0, selfk,
+                                            n_fit, normalize);
+                    K[row * N + col] = v;
+                }
+            }
+        }
+}
+
+// rows [row_lo,row_hi) of the job's Gram matrix into K ([row_hi-row_lo] x n_cols, row major)
+int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normalize, double* K) {
+    const i64 n_cols = f->symmetric ? f->n_graphs : f->n_fit;
+    const i64 M = row_hi - row_lo;
+    if (M <= 0) return GK_OK;
+    const i64 first_row_graph = (f->symmetric ? 0 : f->n_fit) + row_lo;   // row of Phi
+    hipEvent_t e0, e1;
+    GK_HIP_CHECK(hipEventCreate(&e0));
+    GK_HIP_CHECK(hipEventCreate(&e1));
+    GK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    if (f->dtype == 0) {
+        const int8_t* phi = (const int8_t*)f->phi;
+        const int tiles_m = (int)cdiv(M, GI_BM), tiles_n = (int)cdiv(n_cols, GI_BN);
+        gram_i8_kernel<<<dim3((unsigned)(tiles_m * (i64)tiles_n)), dim3(256), 0, ctx->stream>>>(
+            phi + first_row_graph * f->n_cols_pad, phi, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK),
+            f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_n);
+    } else {
+        const double* phi = (const double*)f->phi;
+        const int tiles_m = (int)cdiv(M, GD_BM), tiles_n = (int)cdiv(n_cols, GD_BN);
+        gram_f64_kernel<<<dim3((unsigned)(tiles_m * (i64)tiles_n)), dim3(256), 0, ctx->stream>>>(
+            phi + first_row_graph * f->n_cols_pad, phi, f->n_cols_pad, (int)(f->n_cols_pad / GD_BK),
+            f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_n);
+    }
+    GK_HIP_CHECK(hipGetLastError());
+    GK_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    GK_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    GK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    f->last_ms = ms;
+    f->last_flops = 2.0 * (double)M * (double)n_cols * (double)f->n_cols;
+    return GK_OK;
+}
+
+extern "C" int gk_gram_rows(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_hi, int normalize,
+                            double* out_host) {
+    GK_ARG(ctx && f, "gk_gram: null argument");
+    const i64 n_rows = f->symmetric ? f->n_graphs : f->n_graphs - f->n_fit;
+    const i64 n_cols = f->symmetric ? f->n_graphs : f->n_fit;
+    GK_ARG(row_lo >= 0 && row_hi <= n_rows && row_lo <= row_hi, "gk_gram: bad row range");
+    GK_ARG(normalize >= 0 && normalize <= 2, "gk_gram: bad normalize");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    ProfScope prof(ctx, "gram");
+    const i64 M = row_hi - row_lo;
+    if (f->K) { gk_dev_free(ctx, f->K); f->K = nullptr; }
+    void* q = nullptr;
+    GK_TRY(gk_dev_alloc(ctx, &q, (size_t)(M > 0 ? M : 1) * n_cols * 8));
+    f->K = (double*)q, f->K_rows = M, f->K_cols = n_cols;
+    GK_TRY(gk_gram_launch(ctx, f, row_lo, row_hi, normalize, f->K));
+    if (out_host && M > 0) {
+        GK_HIP_CHECK(hipMemcpyAsync(out_host, f->K, (size_t)M * n_cols * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return GK_OK;
+}
+
+extern "C" int gk_gram(gk_ctx* ctx, gk_feat* f, int normalize, double* out_host) {
+    GK_ARG(f, "gk_gram: null features");
+    const i64 n_rows = f->symmetric ? f->n_graphs : f->n_graphs - f->n_fit;
+    return gk_gram_rows(ctx, f, 0, n_rows, normalize, out_host);
+}
+
+extern "C" int gk_gram_dev_ptr(gk_feat* f, void** out_dev_ptr, int64_t* n_rows, int64_t* n_cols) {
+    GK_ARG(f && out_dev_ptr, "gk_gram_dev_ptr: null argument");
+    *out_dev_ptr = f->K;
+    if (n_rows) *n_rows = f->K_rows;
+    if (n_cols) *n_cols = f->K_cols;
+    return GK_OK;
+}
+
+extern "C" int gk_gram_last_stats(gk_feat* f, double* out_flops, double* out_ms_event) {
+    GK_ARG(f, "gk_gram_last_stats: null");
+    if (out_flops) *out_flops = f->last_flops;
+    if (out_ms_event) *out_ms_event = f->last_ms;
+    return GK_OK;
+}

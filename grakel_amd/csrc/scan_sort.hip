@@ -1,0 +1,236 @@
+// Device-wide prefix sums and a stable LSD radix sort for (u64 key, u32 value) pairs.
+// Hand-written for gfx950: 64-lane wave scans via DPP shuffles, wave-ballot digit matching
+// for the stable scatter.  Used by the WL dictionary (sort node signatures), the feature
+// builder (head flags -> run ids) and the ShortestPath pair dictionary.
+#include "common.h"
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        T y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    return x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums_kernel(const T* __restrict__ in,
+                                                                       T* __restrict__ partial,
+                                                                       i64 n) {
+    __shared__ T wsum[SCAN_THREADS / 64];
+    const i64 base = (i64)blockIdx.x * SCAN_TILE;
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        i64 idx = base + (i64)i * SCAN_THREADS + threadIdx.x;   // striped: coalesced
+        if (idx < n) s += in[idx];
+    }
+    T w = wave_incl_scan(s);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T t = 0;
+        for (int i = 0; i < SCAN_THREADS / 64; ++i) t += wsum[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// One block: partial[] -> exclusive prefix in place; grand total to *total (if non-null).
+template <typename T>
+__global__ __launch_bounds__(1024) void scan_partials_kernel(T* __restrict__ partial, i64 m,
+                                                              T* __restrict__ total) {
+    __shared__ T wsum[16];
+    __shared__ T carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (i64 c0 = 0; c0 < m; c0 += 1024) {
+        i64 idx = c0 + threadIdx.x;
+        T x = idx < m ? partial[idx] : (T)0;
+        T inc = wave_incl_scan(x);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        T woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        T carry = carry_s;
+        if (idx < m) partial[idx] = carry + woff + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+template <typename T, bool EXCL>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const T* __restrict__ in,
+                                                                   T* __restrict__ out, i64 n,
+                                                                   const T* __restrict__ partial) {
+    __shared__ T wsum[SCAN_THREADS / 64];
+    const i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_ITEMS;   // blocked
+    T v[SCAN_ITEMS];
+    T run = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        i64 idx = base + i;
+        v[i] = idx < n ? in[idx] : (T)0;
+        run += v[i];
+    }
+    T inc = wave_incl_scan(run);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    T woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+    T acc = inc - run + woff + partial[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        i64 idx = base + i;
+        if (idx < n) {
+            if (EXCL) out[idx] = acc;
+            acc += v[i];
+            if (!EXCL) out[idx] = acc;
+        }
+    }
+}
+
+template <typename T>
+static int scan_impl(gk_ctx* ctx, const T* in, T* out, i64 n, bool exclusive, T* total) {
+    if (n <= 0) {
+        if (total) GK_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(T), ctx->stream));
+        return GK_OK;
+    }
+    i64 nblk = cdiv(n, SCAN_TILE);
+    Tmp<T> partial(ctx);
+    GK_TRY(partial.alloc(nblk));
+    scan_tile_sums_kernel<T><<<dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, ctx->stream>>>(in, partial.p, n);
+    scan_partials_kernel<T><<<dim3(1), dim3(1024), 0, ctx->stream>>>(partial.p, nblk, total);
+    if (exclusive)
+        scan_apply_kernel<T, true><<<dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, ctx->stream>>>(in, out, n, partial.p);
+    else
+        scan_apply_kernel<T, false><<<dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, ctx->stream>>>(in, out, n, partial.p);
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
+}
+
+int gk_scan_u32(gk_ctx* ctx, const u32* in, u32* out, i64 n, bool exclusive, u32* total) {
+    return scan_impl<u32>(ctx, in, out, n, exclusive, total);
+}
+int gk_scan_u64(gk_ctx* ctx, const u64* in, u64* out, i64 n, bool exclusive, u64* total) {
+    return scan_impl<u64>(ctx, in, out, n, exclusive, total);
+}
+
+// ---------------------------------------------------------------------------------------
+// Radix sort: 8-bit digits, per pass  histogram -> exclusive scan -> stable scatter.
+// A block owns a tile of RS_TILE consecutive keys and processes it in RS_ROUNDS rounds of
+// 256 keys (one per thread, in index order) so that stability only needs (a) the rank of a
+// key among equal digits inside its wave (ballot match) and (b) a per-digit running count
+// across waves and rounds, which thread d keeps in a register for digit d.
+// ---------------------------------------------------------------------------------------
+#define RS_THREADS 256
+#define RS_ROUNDS 8
+#define RS_TILE (RS_THREADS * RS_ROUNDS)
+
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const u64* __restrict__ kin, i64 n,
+                                                                int shift, u32* __restrict__ hist,
+                                                                int nblk) {
+    __shared__ u32 h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const i64 tile0 = (i64)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        i64 idx = tile0 + r * RS_THREADS + tid;
+        if (idx < n) {
+            u32 d = (u32)(kin[idx] >> shift) & 255u;
+            atomicAdd(&h[d], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(i64)tid * nblk + blockIdx.x] = h[tid];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+    const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
+    u32* __restrict__ vout, i64 n, int shift, const u32* __restrict__ offs, int nblk) {
+    __shared__ u32 gbase[256];
+    __shared__ u32 wcnt[RS_THREADS / 64][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    gbase[tid] = offs[(i64)tid * nblk + blockIdx.x];
+    u32 running = 0;   // keys of digit `tid` already placed by this block
+    const i64 tile0 = (i64)blockIdx.x * RS_TILE;
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        i64 idx = tile0 + r * RS_THREADS + tid;
+        bool act = idx < n;
+        u64 key = act ? kin[idx] : 0ull;
+        u32 val = act ? vin[idx] : 0u;
+        u32 d = (u32)(key >> shift) & 255u;
+#pragma unroll
+        for (int q = 0; q < RS_THREADS / 64; ++q) wcnt[q][tid] = 0;
+        __syncthreads();
+        u64 m = __ballot(act);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            bool bit = (d >> b) & 1u;
+            u64 bb = __ballot(act && bit);
+            m &= bit ? bb : ~bb;
+        }
+        u32 rank = (u32)__popcll(m & ((1ull << lane) - 1ull));
+        u32 cnt = (u32)__popcll(m);
+        if (act && rank == 0) wcnt[w][d] = cnt;
+        __syncthreads();
+        {
+            u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+            wcnt[0][tid] = running;
+            wcnt[1][tid] = running + c0;
+            wcnt[2][tid] = running + c0 + c1;
+            wcnt[3][tid] = running + c0 + c1 + c2;
+            running += c0 + c1 + c2 + c3;
+        }
+        __syncthreads();
+        if (act) {
+            u32 pos = gbase[d] + wcnt[w][d] + rank;
+            kout[pos] = key;
+            vout[pos] = val;
+        }
+        __syncthreads();
+    }
+}
+
+int gk_radix_sort_pairs(gk_ctx* ctx, u64* keys_in, u32* vals_in, u64* keys_out, u32* vals_out,
+                        i64 n, int key_bits) {
+    // Result always lands in keys_out/vals_out; keys_in/vals_in are scratch afterwards.
+    if (n <= 0) return GK_OK;
+    if (key_bits < 0) key_bits = 0;
+    if (key_bits > 64) key_bits = 64;
+    int passes = (key_bits + 7) / 8;
+    if (passes == 0) {
+        GK_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+        return GK_OK;
+    }
+    int nblk = (int)cdiv(n, RS_TILE);
+    Tmp<u32> hist(ctx);
+    GK_TRY(hist.alloc((size_t)256 * nblk));
+    u64 *ks = keys_in, *kd = keys_out;
+    u32 *vs = vals_in, *vd = vals_out;
+    if ((passes & 1) == 0) {   // even number of passes: start from the out buffers
+        GK_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+        ks = keys_out, kd = keys_in, vs = vals_out, vd = vals_in;
+    }
+    for (int p = 0; p < passes; ++p) {
+        int shift = p * 8;
+        radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, n, shift, hist.p, nblk);
+        GK_TRY(gk_scan_u32(ctx, hist.p, hist.p, (i64)256 * nblk, true, nullptr));
+        radix_scatter_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, vs, kd, vd, n, shift, hist.p, nblk);
+        u64* tk = ks; ks = kd; kd = tk;
+        u32* tv = vs; vs = vd; vd = tv;
+    }
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
+}

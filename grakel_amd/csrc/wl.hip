@@ -1,0 +1,504 @@
+// Weisfeiler-Lehman relabelling on gfx950.
+//
+// One level (reference: grakel/kernels/weisfeiler_lehman.py:223-258):
+//   1. wl_signature_*  : per node, gather the previous labels of its out-neighbours (coalesced
+//                        col_idx stream, LDS-staged), sort them, write the sorted list to
+//                        nbr_sorted[] and form a 64-bit multiset hash of (own, degree, list).
+//   2. radix sort       : (hash, node) pairs, stable -> equal signatures become adjacent and
+//                        keep ascending node order inside a group.
+//   3. heads + scan     : group index = new dense label id; first node = representative.
+//   4. verify           : every node compares its FULL signature (own label, degree, sorted
+//                        list) with its group's representative -> the dictionary is exact, the
+//                        hash only proposes groups.  Any mismatch (a 64-bit collision) is
+//                        counted; the host then re-runs that level in "exact" mode, refining
+//                        groups with re-seeded hashes until no mismatch is left.
+// HBM-bound integer work: algorithmic bytes per level 8E + 12V.
+#include "common.h"
+
+#define WL_DEG_SMALL 32       // nodes up to this degree: one thread sorts its list in LDS
+#define SIG_THREADS 256
+#define SIG_LDS_CAP 6144      // ints staged per 256-node chunk (24 KiB)
+#define BIG_THREADS 256
+#define BIG_LDS_CAP 16384     // ints: one workgroup bitonic-sorts a big node's list in LDS
+
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ULL;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ u64 sig_elem(u32 lab, u64 seed) {
+    return mix64(((u64)lab + 1ull) * 0x9E3779B97F4A7C15ULL + seed);
+}
+__device__ __forceinline__ u64 sig_head(u32 own, u32 deg, u64 seed) {
+    return mix64(mix64((u64)own + 0x632BE59BD9B4E019ULL * (seed | 1ull)) ^
+                 ((u64)deg * 0xD6E8FEB86659FD93ULL));
+}
+
+template <typename P>
+__device__ __forceinline__ void insertion_sort(P x, int d) {
+    for (int i = 1; i < d; ++i) {
+        i32 key = x[i];
+        int j = i - 1;
+        while (j >= 0 && x[j] > key) {
+            x[j + 1] = x[j];
+            --j;
+        }
+        x[j + 1] = key;
+    }
+}
+
+__global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
+    const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
+    const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted, u64* __restrict__ hash,
+    i64 V, u64 seed, u64 mask) {
+    __shared__ i32 buf[SIG_LDS_CAP];
+    const int tid = threadIdx.x;
+    const i64 v0 = (i64)blockIdx.x * SIG_THREADS;
+    const i64 v1 = (v0 + SIG_THREADS < V) ? v0 + SIG_THREADS : V;
+    const i32 e0 = row_ptr[v0], e1 = row_ptr[v1];
+    const int cnt = e1 - e0;
+    const bool use_lds = cnt <= SIG_LDS_CAP;   // block-uniform
+    // coalesced stream over the chunk's col_idx; the label gather hits L2 (4 B x V table)
+    for (int i = tid; i < cnt; i += SIG_THREADS) {
+        i32 l = lab_prev[col_idx[e0 + i]];
+        if (use_lds) buf[i] = l;
+        else nbr_sorted[e0 + i] = l;
+    }
+    __syncthreads();
+    const i64 v = v0 + tid;
+    if (v < v1) {
+        const i32 s = row_ptr[v];
+        const int d = row_ptr[v + 1] - s;
+        if (d <= WL_DEG_SMALL) {
+            u64 acc = sig_head((u32)lab_prev[v], (u32)d, seed);
+            if (use_lds) {
+                i32* x = buf + (s - e0);
+                insertion_sort(x, d);
+                for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+            } else {
+                i32* x = nbr_sorted + s;
+                insertion_sort(x, d);
+                for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+            }
+            hash[v] = mix64(acc) & mask;
+        }
+    }
+    __syncthreads();
+    if (use_lds)
+        for (int i = tid; i < cnt; i += SIG_THREADS) nbr_sorted[e0 + i] = buf[i];
+}
+
+// Normalised bitonic network (every comparator puts the minimum at the lower index), so a
+// length that is not a power of two needs no padding: virtual +inf elements never move.
+template <typename P>
+__device__ __forceinline__ void block_bitonic_sort(P x, int n) {
+    for (int k = 2; (k >> 1) < n; k <<= 1) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            int l = i ^ (k - 1);
+            if (l > i && l < n) {
+                i32 a = x[i], b = x[l];
+                if (a > b) { x[i] = b; x[l] = a; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                int l = i ^ j;
+                if (l > i && l < n) {
+                    i32 a = x[i], b = x[l];
+                    if (a > b) { x[i] = b; x[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(BIG_THREADS) void wl_signature_big_kernel(
+    const i32* __restrict__ big_nodes, const i32* __restrict__ row_ptr,
+    const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+    i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask) {
+    __shared__ i32 buf[BIG_LDS_CAP];
+    __shared__ u64 red[BIG_THREADS / 64];
+    const int tid = threadIdx.x;
+    const i32 v = big_nodes[blockIdx.x];
+    const i32 e0 = row_ptr[v];
+    const int d = row_ptr[v + 1] - e0;
+    u64 part = 0;
+    if (d <= BIG_LDS_CAP) {
+        for (int i = tid; i < d; i += BIG_THREADS) {
+            i32 l = lab_prev[col_idx[e0 + i]];
+            buf[i] = l;
+            part += sig_elem((u32)l, seed);
+        }
+        __syncthreads();
+        block_bitonic_sort(buf, d);
+        for (int i = tid; i < d; i += BIG_THREADS) nbr_sorted[e0 + i] = buf[i];
+    } else {   // hub larger than LDS: same network directly on the global scratch
+        for (int i = tid; i < d; i += BIG_THREADS) {
+            i32 l = lab_prev[col_idx[e0 + i]];
+            nbr_sorted[e0 + i] = l;
+            part += sig_elem((u32)l, seed);
+        }
+        __syncthreads();
+        block_bitonic_sort(nbr_sorted + e0, d);
+    }
+    // block reduction of the (order independent) multiset sum
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        u64 t = 0;
+        for (int i = 0; i < BIG_THREADS / 64; ++i) t += red[i];
+        hash[v] = mix64(sig_head((u32)lab_prev[v], (u32)d, seed) + t) & mask;
+    }
+}
+
+__global__ void iota_u32_kernel(u32* __restrict__ p, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (u32)i;
+}
+
+__global__ void labels_to_keys_kernel(const i32* __restrict__ lab, u64* __restrict__ keys, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (u64)(u32)lab[i];
+}
+
+// exact-mode refinement key: (label of the previous round, re-seeded hash)
+__global__ void refine_keys_kernel(const i32* __restrict__ lab_round, const u64* __restrict__ hash,
+                                   u64* __restrict__ keys, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ((u64)(u32)lab_round[i] << 32) | (hash[i] & 0xffffffffull);
+}
+
+__global__ void head_flags_kernel(const u64* __restrict__ ks, u32* __restrict__ flag, i64 n) {
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) flag[k] = (k == 0 || ks[k] != ks[k - 1]) ? 1u : 0u;
+}
+
+__global__ void assign_labels_kernel(const u32* __restrict__ perm, const u32* __restrict__ flag,
+                                     const u32* __restrict__ scan_incl, i32* __restrict__ lab,
+                                     i32* __restrict__ rep, i64 n) {
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        u32 v = perm[k];
+        i32 r = (i32)scan_incl[k] - 1;
+        lab[v] = r;
+        if (flag[k]) rep[r] = (i32)v;
+    }
+}
+
+__global__ void verify_kernel(const i32* __restrict__ row_ptr, const i32* __restrict__ lab_prev,
+                              const i32* __restrict__ nbr_sorted, const i32* __restrict__ lab,
+                              const i32* __restrict__ rep, u32* __restrict__ unresolved, i64 n) {
+    i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    i32 r = rep[lab[v]];
+    if (r == (i32)v) return;
+    bool ok = lab_prev[v] == lab_prev[r];
+    i32 s = row_ptr[v], sr = row_ptr[r];
+    int d = row_ptr[v + 1] - s;
+    ok = ok && (d == row_ptr[r + 1] - sr);
+    if (ok)
+        for (int k = 0; k < d; ++k)
+            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+    if (!ok) atomicAdd(unresolved, 1u);
+}
+
+__global__ void node_graph_kernel(const i32* __restrict__ graph_ptr, i32* __restrict__ node_graph,
+                                  i64 n_graphs, i64 n_nodes) {
+    i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_nodes) return;
+    i64 lo = 0, hi = n_graphs;   // largest g with graph_ptr[g] <= v
+    while (hi - lo > 1) {
+        i64 mid = (lo + hi) >> 1;
+        if (graph_ptr[mid] <= v) lo = mid; else hi = mid;
+    }
+    node_graph[v] = (i32)lo;
+}
+
+__global__ void batch_stats_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr,
+                                   i64 n_graphs, i64 n_nodes, u32* __restrict__ big_flag,
+                                   i32* __restrict__ stats /* [0]=max graph nodes [1]=max degree */) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_graphs) atomicMax(&stats[0], graph_ptr[i + 1] - graph_ptr[i]);
+    if (i < n_nodes) {
+        int d = row_ptr[i + 1] - row_ptr[i];
+        atomicMax(&stats[1], d);
+        big_flag[i] = d > WL_DEG_SMALL ? 1u : 0u;
+    }
+}
+
+__global__ void compact_big_kernel(const u32* __restrict__ big_flag, const u32* __restrict__ excl,
+                                   i32* __restrict__ big_nodes, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && big_flag[i]) big_nodes[excl[i]] = (i32)i;
+}
+
+static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+extern "C" int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, int64_t n_edges,
+                               const int32_t* graph_ptr, const int32_t* row_ptr,
+                               const int32_t* col_idx, const int32_t* node_label,
+                               int32_t n_labels0, int src_on_device, gk_batch** out) {
+    GK_ARG(ctx && out, "gk_batch_create: null ctx/out");
+    GK_ARG(n_graphs > 0 && n_nodes >= 0 && n_edges >= 0, "gk_batch_create: bad sizes");
+    GK_ARG(n_nodes < (1ll << 31) - 1 && n_edges < (1ll << 31) - 1, "gk_batch_create: int32 index overflow");
+    GK_ARG(graph_ptr && row_ptr && node_label && (col_idx || n_edges == 0), "gk_batch_create: null array");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    gk_batch* b = new gk_batch();
+    b->ctx = ctx;
+    b->n_graphs = n_graphs, b->n_nodes = n_nodes, b->n_edges = n_edges, b->n_labels0 = n_labels0;
+    hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    auto fail = [&](int r) { gk_batch_destroy(b); return r; };
+#define B_ALLOC(ptr, n) { void* q = nullptr; int r = gk_dev_alloc(ctx, &q, (size_t)((n) > 0 ? (n) : 1) * 4); if (r) return fail(r); ptr = (i32*)q; }
+    B_ALLOC(b->graph_ptr, n_graphs + 1);
+    B_ALLOC(b->row_ptr, n_nodes + 1);
+    B_ALLOC(b->col_idx, n_edges);
+    B_ALLOC(b->node_graph, n_nodes);
+    B_ALLOC(b->nbr_sorted, n_edges);
+    b->cap_levels = 1;
+    B_ALLOC(b->labels, n_nodes);
+    B_ALLOC(b->perm, n_nodes);
+#define B_COPY(dst, src, n) if ((n) > 0 && hipMemcpyAsync(dst, src, (size_t)(n) * 4, kind, ctx->stream) != hipSuccess) { gk_set_error("gk_batch_create: copy failed"); return fail(GK_ERR_HIP); }
+    B_COPY(b->graph_ptr, graph_ptr, n_graphs + 1);
+    B_COPY(b->row_ptr, row_ptr, n_nodes + 1);
+    B_COPY(b->col_idx, col_idx, n_edges);
+    B_COPY(b->labels, node_label, n_nodes);
+#undef B_COPY
+    if (n_nodes > 0) {
+        node_graph_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->node_graph, n_graphs, n_nodes);
+    }
+    // statistics + list of high-degree nodes
+    Tmp<u32> flag(ctx), excl(ctx), total(ctx);
+    Tmp<i32> stats(ctx);
+    int r;
+    if ((r = flag.alloc(n_nodes)) || (r = excl.alloc(n_nodes)) || (r = total.alloc(1)) || (r = stats.alloc(2))) return fail(r);
+    if (hipMemsetAsync(stats.p, 0, 8, ctx->stream) != hipSuccess) return fail(GK_ERR_HIP);
+    i64 m = n_graphs > n_nodes ? n_graphs : n_nodes;
+    batch_stats_kernel<<<grid_for(m, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, n_graphs, n_nodes, flag.p, stats.p);
+    if ((r = gk_scan_u32(ctx, flag.p, excl.p, n_nodes, true, total.p))) return fail(r);
+    i32 hstats[2] = {0, 0};
+    u32 hbig = 0;
+    if (hipMemcpyAsync(hstats, stats.p, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(&hbig, total.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        gk_set_error("gk_batch_create: stats readback failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(GK_ERR_HIP);
+    }
+    b->max_graph_nodes = hstats[0], b->max_degree = hstats[1], b->n_big = hbig;
+    B_ALLOC(b->big_nodes, b->n_big);
+#undef B_ALLOC
+    if (b->n_big > 0)
+        compact_big_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(flag.p, excl.p, b->big_nodes, n_nodes);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        gk_set_error("gk_batch_create: %s", hipGetErrorString(hipGetLastError()));
+        return fail(GK_ERR_HIP);
+    }
+    b->n_levels = 0;
+    b->label_counts.assign(1, n_labels0);
+    *out = b;
+    return GK_OK;
+}
+
+extern "C" int gk_batch_destroy(gk_batch* b) {
+    if (!b) return GK_OK;
+    gk_ctx* ctx = b->ctx;
+    void* ptrs[] = {b->graph_ptr, b->row_ptr, b->col_idx, b->node_graph, b->big_nodes,
+                    b->labels, b->perm, b->nbr_sorted};
+    for (void* p : ptrs)
+        if (p) gk_dev_free(ctx, p);
+    delete b;
+    return GK_OK;
+}
+
+extern "C" int gk_batch_info(gk_batch* b, int64_t* n_graphs, int64_t* n_nodes, int64_t* n_edges) {
+    GK_ARG(b, "gk_batch_info: null batch");
+    if (n_graphs) *n_graphs = b->n_graphs;
+    if (n_nodes) *n_nodes = b->n_nodes;
+    if (n_edges) *n_edges = b->n_edges;
+    return GK_OK;
+}
+
+int gk_batch_ensure_levels(gk_batch* b, int n_levels) {
+    if (n_levels <= b->cap_levels) return GK_OK;
+    gk_ctx* ctx = b->ctx;
+    size_t per = (size_t)(b->n_nodes > 0 ? b->n_nodes : 1) * 4;
+    void *nl = nullptr, *np = nullptr;
+    GK_TRY(gk_dev_alloc(ctx, &nl, per * n_levels));
+    GK_TRY(gk_dev_alloc(ctx, &np, per * n_levels));
+    GK_HIP_CHECK(hipMemcpyAsync(nl, b->labels, per * b->cap_levels, hipMemcpyDeviceToDevice, ctx->stream));
+    GK_HIP_CHECK(hipMemcpyAsync(np, b->perm, per * b->cap_levels, hipMemcpyDeviceToDevice, ctx->stream));
+    gk_dev_free(ctx, b->labels);
+    gk_dev_free(ctx, b->perm);
+    b->labels = (i32*)nl, b->perm = (i32*)np, b->cap_levels = n_levels;
+    return GK_OK;
+}
+
+static int bits_for(u64 max_value) {
+    int b = 0;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b;
+}
+
+static u64 level_seed(int level, int round) {
+    u64 z = 0x243F6A8885A308D3ULL + (u64)level * 0x9E3779B97F4A7C15ULL + (u64)round * 0xC2B2AE3D27D4EB4FULL;
+    z ^= z >> 31; z *= 0xff51afd7ed558ccdULL; z ^= z >> 29;
+    return z;
+}
+
+static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash, u64 seed, u64 mask) {
+    i64 V = b->n_nodes;
+    if (V == 0) return GK_OK;
+    wl_signature_small_kernel<<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
+        b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask);
+    if (b->n_big > 0)
+        wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
+            b->big_nodes, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, seed, mask);
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
+}
+
+// Sort (key,node) pairs, turn equal-key groups into dense ids. keys[] is clobbered.
+// Writes lab[node], perm[] (nodes in key order, ascending node inside a group), rep[id]
+// (may be null) and the number of groups to *count_dev.
+static int dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
+                                i32* rep, u32* count_dev) {
+    if (n == 0) {
+        GK_HIP_CHECK(hipMemsetAsync(count_dev, 0, 4, ctx->stream));
+        return GK_OK;
+    }
+    Tmp<u64> ks(ctx);
+    Tmp<u32> iota(ctx), flag(ctx), scan(ctx);
+    GK_TRY(ks.alloc(n)); GK_TRY(iota.alloc(n)); GK_TRY(flag.alloc(n)); GK_TRY(scan.alloc(n));
+    iota_u32_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(iota.p, n);
+    GK_TRY(gk_radix_sort_pairs(ctx, keys, iota.p, ks.p, (u32*)perm, n, key_bits));
+    head_flags_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(ks.p, flag.p, n);
+    GK_TRY(gk_scan_u32(ctx, flag.p, scan.p, n, false, count_dev));
+    Tmp<i32> rep_tmp(ctx);
+    if (!rep) { GK_TRY(rep_tmp.alloc(n)); rep = rep_tmp.p; }
+    assign_labels_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>((const u32*)perm, flag.p, scan.p, lab, rep, n);
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
+}
+
+// exported for sp.hip
+int gk_dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32* lab, i32* perm, u32* count_dev) {
+    return dictionary_from_keys(ctx, keys, n, key_bits, lab, perm, nullptr, count_dev);
+}
+
+static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, bool exact,
+                         u32* count_dev, u32* unresolved_dev, int* rounds) {
+    const i64 V = b->n_nodes;
+    const i32* prev = b->labels + (size_t)(level - 1) * V;
+    i32* cur = b->labels + (size_t)level * V;
+    i32* perm = b->perm + (size_t)level * V;
+    Tmp<u64> hash(ctx), keys(ctx);
+    Tmp<i32> rep(ctx);
+    GK_TRY(hash.alloc(V)); GK_TRY(keys.alloc(V)); GK_TRY(rep.alloc(V));
+    const u64 mask = hash_bits >= 64 ? ~0ull : ((1ull << hash_bits) - 1ull);
+    for (int round = 0;; ++round) {
+        GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), mask));
+        int bits;
+        if (round == 0) {
+            GK_HIP_CHECK(hipMemcpyAsync(keys.p, hash.p, V * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+            bits = hash_bits;
+        } else {
+            refine_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(cur, hash.p, keys.p, V);
+            bits = 64;
+        }
+        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, cur, perm, rep.p, count_dev));
+        GK_HIP_CHECK(hipMemsetAsync(unresolved_dev, 0, 4, ctx->stream));
+        verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
+        GK_HIP_CHECK(hipGetLastError());
+        if (!exact) break;
+        u32 un = 0;
+        GK_HIP_CHECK(hipMemcpyAsync(&un, unresolved_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (un == 0) break;
+        if (rounds) ++*rounds;
+        if (round > 200) {
+            gk_set_error("gk_wl_relabel: refinement did not converge at level %d", level);
+            return GK_ERR_STATE;
+        }
+    }
+    return GK_OK;
+}
+
+extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits,
+                             int64_t* out_label_counts, int* out_rounds) {
+    GK_ARG(ctx && b, "gk_wl_relabel: null ctx/batch");
+    GK_ARG(!b->is_pair_batch, "gk_wl_relabel: pair batches have no adjacency");
+    GK_ARG(n_iter >= 0 && n_iter < 4096, "gk_wl_relabel: bad n_iter");
+    if (hash_bits <= 0 || hash_bits > 64) hash_bits = 64;
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    ProfScope prof(ctx, "relabel");
+    const int n_levels = n_iter + 1;
+    const i64 V = b->n_nodes;
+    GK_TRY(gk_batch_ensure_levels(b, n_levels));
+    Tmp<u32> meta(ctx);   // [n_levels] counts, [n_levels] unresolved
+    GK_TRY(meta.alloc(2 * (size_t)n_levels));
+    GK_HIP_CHECK(hipMemsetAsync(meta.p, 0, 8 * (size_t)n_levels, ctx->stream));
+    if (out_rounds) *out_rounds = 0;
+    // level 0: group nodes by the given label ids
+    {
+        Tmp<u64> keys(ctx);
+        Tmp<i32> lab_tmp(ctx);
+        GK_TRY(keys.alloc(V)); GK_TRY(lab_tmp.alloc(V));
+        if (V > 0) labels_to_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels, keys.p, V);
+        int bits = bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0);
+        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p));
+    }
+    std::vector<u32> h(2 * (size_t)n_levels);
+    int first_bad = -1;
+    for (int lvl = 1; lvl < n_levels; ++lvl)
+        GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, meta.p + lvl, meta.p + n_levels + lvl, nullptr));
+    GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 8 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int lvl = 1; lvl < n_levels; ++lvl)
+        if (h[n_levels + lvl] != 0) { first_bad = lvl; break; }
+    if (first_bad > 0) {   // a hash collision was detected: redo from that level, exactly
+        for (int lvl = first_bad; lvl < n_levels; ++lvl)
+            GK_TRY(relabel_level(ctx, b, lvl, hash_bits, true, meta.p + lvl, meta.p + n_levels + lvl, out_rounds));
+        GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 8 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    b->n_levels = n_levels;
+    b->label_counts.resize(n_levels);
+    for (int lvl = 0; lvl < n_levels; ++lvl) {
+        b->label_counts[lvl] = h[lvl];
+        if (out_label_counts) out_label_counts[lvl] = h[lvl];
+    }
+    return GK_OK;
+}
+
+extern "C" int gk_wl_get_labels(gk_ctx* ctx, gk_batch* b, int level, int32_t* out_labels) {
+    GK_ARG(ctx && b && out_labels, "gk_wl_get_labels: null argument");
+    GK_ARG(level >= 0 && level < (b->n_levels > 0 ? b->n_levels : 1), "gk_wl_get_labels: level not computed");
+    if (b->n_nodes == 0) return GK_OK;
+    GK_HIP_CHECK(hipMemcpyAsync(out_labels, b->labels + (size_t)level * b->n_nodes, b->n_nodes * 4,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return GK_OK;
+}
+
+extern "C" int gk_wl_debug_signature(gk_ctx* ctx, gk_batch* b, int level, uint64_t seed,
+                                     uint64_t* out_hash, int32_t* out_sorted) {
+    GK_ARG(ctx && b, "gk_wl_debug_signature: null argument");
+    GK_ARG(level >= 1 && level <= (b->n_levels > 0 ? b->n_levels : 1), "gk_wl_debug_signature: previous level not computed");
+    Tmp<u64> hash(ctx);
+    GK_TRY(hash.alloc(b->n_nodes));
+    GK_TRY(launch_signature(ctx, b, b->labels + (size_t)(level - 1) * b->n_nodes, hash.p, seed, ~0ull));
+    if (out_hash && b->n_nodes)
+        GK_HIP_CHECK(hipMemcpyAsync(out_hash, hash.p, b->n_nodes * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_sorted && b->n_edges)
+        GK_HIP_CHECK(hipMemcpyAsync(out_sorted, b->nbr_sorted, b->n_edges * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return GK_OK;
+}

@@ -1,0 +1,198 @@
+"""Thin Python wrapper over the C ABI: device context, device batches, features, Gram.
+
+Host logic only; all compute happens in libgk_hip.so.  One ``Engine`` per device/process
+(multi-GPU = one process per GPU, see ``grakel_amd.dist``).
+"""
+import ctypes
+from ctypes import byref, c_double, c_int, c_int64, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+class DeviceBatch(object):
+    def __init__(self, engine, handle, n_graphs, n_nodes, n_edges):
+        self.engine, self.handle = engine, handle
+        self.n_graphs, self.n_nodes, self.n_edges = n_graphs, n_nodes, n_edges
+        self.label_counts = None
+
+    def close(self):
+        if self.handle is not None and self.engine.handle is not None:
+            self.engine.lib.gk_batch_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceFeatures(object):
+    def __init__(self, engine, handle, batch, n_fit):
+        self.engine, self.handle, self.batch, self.n_fit = engine, handle, batch, n_fit
+        nc, nnz, mc, dt = c_int64(), c_int64(), c_int64(), c_int()
+        check(engine.lib.gk_features_info(handle, byref(nc), byref(nnz), byref(mc), byref(dt)))
+        self.n_cols, self.nnz, self.max_count, self.dtype = nc.value, nnz.value, mc.value, dt.value
+        self.symmetric = n_fit == batch.n_graphs
+        self.n_rows = batch.n_graphs if self.symmetric else batch.n_graphs - n_fit
+        self.n_out_cols = n_fit
+
+    def close(self):
+        if self.handle is not None and self.engine.handle is not None:
+            self.engine.lib.gk_features_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine(object):
+    """A libgk_hip context bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if _lib.device_count() <= 0:
+            raise _lib.GkError("no MI355X / HIP device visible: grakel_amd has no CPU fallback")
+        h = c_void_p()
+        check(self.lib.gk_create(int(device), byref(h)))
+        self.handle, self.device = h, int(device)
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.gk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing -------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        check(self.lib.gk_set_stream(self.handle, c_void_p(stream_ptr) if stream_ptr else None))
+
+    def synchronize(self):
+        check(self.lib.gk_synchronize(self.handle))
+
+    def timer_start(self):
+        check(self.lib.gk_timer_start(self.handle))
+
+    def timer_stop_ms(self):
+        ms = c_double()
+        check(self.lib.gk_timer_stop_ms(self.handle, byref(ms)))
+        return ms.value
+
+    def profile(self, enable):
+        check(self.lib.gk_profile_enable(self.handle, 1 if enable else 0))
+        check(self.lib.gk_profile_reset(self.handle))
+
+    def profile_get(self, name):
+        ms, n = c_double(), c_int64()
+        check(self.lib.gk_profile_get(self.handle, name.encode(), byref(ms), byref(n)))
+        return ms.value, n.value
+
+    # -- batches --------------------------------------------------------------------------
+    def upload(self, gb):
+        h = c_void_p()
+        check(self.lib.gk_batch_create(self.handle, gb.n_graphs, gb.n_nodes, gb.n_edges,
+                                       _ptr(gb.graph_ptr), _ptr(gb.row_ptr), _ptr(gb.col_idx),
+                                       _ptr(gb.node_label), gb.n_labels, 0, byref(h)))
+        return DeviceBatch(self, h, gb.n_graphs, gb.n_nodes, gb.n_edges)
+
+    def upload_from_device(self, n_graphs, n_nodes, n_edges, graph_ptr, row_ptr, col_idx, node_label,
+                           n_labels):
+        """Arrays are raw device pointers (ints), e.g. torch tensors' ``data_ptr()``."""
+        h = c_void_p()
+        check(self.lib.gk_batch_create(self.handle, n_graphs, n_nodes, n_edges, c_void_p(graph_ptr),
+                                       c_void_p(row_ptr), c_void_p(col_idx), c_void_p(node_label),
+                                       n_labels, 1, byref(h)))
+        return DeviceBatch(self, h, n_graphs, n_nodes, n_edges)
+
+    # -- WL ---------------------------------------------------------------------------------
+    def wl_relabel(self, db, n_iter, hash_bits=0):
+        counts = (c_int64 * (n_iter + 1))()
+        rounds = c_int(0)
+        check(self.lib.gk_wl_relabel(self.handle, db.handle, int(n_iter), int(hash_bits), counts,
+                                     byref(rounds)))
+        db.label_counts = [int(c) for c in counts]
+        db.refine_rounds = rounds.value
+        return db.label_counts
+
+    def wl_labels(self, db, level):
+        out = np.empty(db.n_nodes, dtype=np.int32)
+        check(self.lib.gk_wl_get_labels(self.handle, db.handle, int(level), _ptr(out)))
+        return out
+
+    def wl_debug_signature(self, db, level, seed):
+        h = np.empty(db.n_nodes, dtype=np.uint64)
+        s = np.empty(db.n_edges, dtype=np.int32)
+        check(self.lib.gk_wl_debug_signature(self.handle, db.handle, int(level),
+                                             ctypes.c_uint64(seed), _ptr(h), _ptr(s)))
+        return h, s
+
+    # -- features / Gram -----------------------------------------------------------------------
+    def features(self, db, n_levels, n_fit=None):
+        n_fit = db.n_graphs if n_fit is None else int(n_fit)
+        h = c_void_p()
+        check(self.lib.gk_features_build(self.handle, db.handle, int(n_levels), n_fit, byref(h)))
+        return DeviceFeatures(self, h, db, n_fit)
+
+    def selfk(self, feat):
+        out = np.empty(feat.batch.n_graphs, dtype=np.float64)
+        check(self.lib.gk_features_selfk(self.handle, feat.handle, _ptr(out)))
+        return out
+
+    def gram(self, feat, normalize=0, rows=None, to_host=True):
+        lo, hi = (0, feat.n_rows) if rows is None else rows
+        out = np.empty((hi - lo, feat.n_out_cols), dtype=np.float64) if to_host else None
+        check(self.lib.gk_gram_rows(self.handle, feat.handle, lo, hi, int(normalize), _ptr(out)))
+        return out
+
+    def gram_stats(self, feat):
+        fl, ms = c_double(), c_double()
+        check(self.lib.gk_gram_last_stats(feat.handle, byref(fl), byref(ms)))
+        return fl.value, ms.value
+
+    # -- shortest paths -------------------------------------------------------------------------
+    def sp_build(self, db, edge_weight, with_labels):
+        h = c_void_p()
+        npairs, nkeys = c_int64(), c_int64()
+        check(self.lib.gk_sp_build(self.handle, db.handle, _ptr(edge_weight), 1 if with_labels else 0,
+                                   byref(h), byref(npairs), byref(nkeys)))
+        pb = DeviceBatch(self, h, db.n_graphs, npairs.value, 0)
+        pb.label_counts = [nkeys.value]
+        return pb
+
+    def sp_debug_apsp(self, db, edge_weight, graph, n):
+        out = np.empty((n, n), dtype=np.int32)
+        check(self.lib.gk_sp_debug_apsp(self.handle, db.handle, _ptr(edge_weight), int(graph), _ptr(out)))
+        return out
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Process-wide engine per device (created on first use; raises if no GPU)."""
+    import os
+    if device is None:
+        device = int(os.environ.get("GK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = _lib.device_count()
+        if n > 0:
+            device %= n
+    e = _engines.get(device)
+    if e is None or e.handle is None:
+        e = Engine(device)
+        _engines[device] = e
+    return e

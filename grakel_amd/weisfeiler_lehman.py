@@ -1,0 +1,111 @@
+"""Weisfeiler-Lehman subtree kernel on MI355X (drop-in for ``grakel.WeisfeilerLehman``,
+``grakel/kernels/weisfeiler_lehman.py:20``)."""
+from sklearn.utils.validation import check_is_fitted
+
+from .batch import wl_batch_from_input
+from .kernel import Kernel, NORM_NONE, NORM_NAN_TO_NUM
+from .vertex_histogram import VertexHistogram, FittedFeatures
+
+
+class WeisfeilerLehman(Kernel):
+    """Sum over WL levels 0..n_iter of the vertex-histogram kernel of the relabelled graphs.
+
+    Parameters as the reference (weisfeiler_lehman.py:58-65): n_jobs, verbose, normalize,
+    n_iter=5, base_graph_kernel=VertexHistogram (the only base kernel on the accelerated path).
+    """
+
+    _graph_format = "dictionary"
+    _norm_mode = NORM_NAN_TO_NUM
+
+    def __init__(self, n_jobs=None, verbose=False, normalize=False, n_iter=5,
+                 base_graph_kernel=VertexHistogram):
+        super(WeisfeilerLehman, self).__init__(n_jobs=n_jobs, verbose=verbose, normalize=normalize)
+        self.n_iter = n_iter
+        self.base_graph_kernel = base_graph_kernel
+        self._initialized.update({"n_iter": False, "base_graph_kernel": False})
+        self._base_graph_kernel = None
+
+    def initialize(self):
+        """weisfeiler_lehman.py:74-115."""
+        super(WeisfeilerLehman, self).initialize()
+        if not self._initialized["base_graph_kernel"]:
+            base = self.base_graph_kernel
+            if base is None:
+                base, params = VertexHistogram, dict()
+            elif type(base) is type and issubclass(base, Kernel):
+                params = dict()
+            else:
+                try:
+                    base, params = base
+                except Exception:
+                    raise TypeError('Base kernel was not formulated in the correct way. '
+                                    'Check documentation.')
+                if not (type(base) is type and issubclass(base, Kernel)):
+                    raise TypeError('The first argument must be a valid grakel.kernel.kernel Object')
+                if type(params) is not dict:
+                    raise ValueError('If the second argument of base kernel exists, it must be a '
+                                     'dictionary between parameters names and values')
+                params.pop("normalize", None)
+            if base is not VertexHistogram:
+                raise NotImplementedError(
+                    'grakel_amd accelerates WeisfeilerLehman with the VertexHistogram base kernel '
+                    '(the WL-subtree kernel); other base kernels are outside the MI355X hot path')
+            params["normalize"] = False
+            params["verbose"] = self.verbose
+            params["n_jobs"] = None
+            self._base_graph_kernel = base
+            self._params = params
+            self._initialized["base_graph_kernel"] = True
+        if not self._initialized["n_iter"]:
+            if type(self.n_iter) is not int or self.n_iter <= 0:
+                raise TypeError("'n_iter' must be a positive integer")
+            self._n_iter = self.n_iter + 1
+            self._initialized["n_iter"] = True
+
+    def _ingest(self, X, fitted):
+        not_iter = TypeError if fitted is None else ValueError      # :143-144 vs :358-359
+        return wl_batch_from_input(X, fitted, min_len=2, not_iterable=not_iter)
+
+    def _prepare(self, engine, dbatch):
+        engine.wl_relabel(dbatch, self._n_iter - 1)
+        return dbatch, self._n_iter
+
+    def _after_fit(self):
+        self._inv_labels = {0: dict(self._label_map) if self._label_map is not None else {}}
+        self.X = {i: FittedFeatures(self._nx, None) for i in range(self._n_iter)}
+
+    def fit(self, X, y=None):
+        """kernel.py:86-121 with weisfeiler_lehman.py:117-290 as parse_input."""
+        self._is_transformed = False
+        self._method_calling = 1
+        self.initialize()
+        if X is None:
+            raise ValueError('`fit` input cannot be None')
+        self._fit_host(X)
+        self._after_fit()
+        return self
+
+    def fit_transform(self, X, y=None):
+        """weisfeiler_lehman.py:292-328."""
+        self._method_calling = 2
+        self._is_transformed = False
+        self.initialize()
+        if X is None:
+            raise ValueError('transform input cannot be None')
+        self._fit_host(X)
+        self._after_fit()
+        eng, feat = self._gram_fit()
+        self.X = {i: FittedFeatures(self._nx, c) for i, c in enumerate(self._last_info["label_counts"])}
+        return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
+
+    def transform(self, X):
+        """weisfeiler_lehman.py:330-500.  The targets are relabelled JOINTLY with the fitted
+        graphs: the WL partition of the union restricted to the fitted graphs is the fitted
+        partition, so K[targets, fitted] equals the reference's dictionary look-up path."""
+        self._method_calling = 3
+        check_is_fitted(self, ['X', '_nx', '_inv_labels'])
+        if X is None:
+            raise ValueError('transform input cannot be None')
+        eng, feat = self._gram_transform(X)
+        self._is_transformed = True
+        return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)

@@ -1,0 +1,155 @@
+/*
+ * gk_hip.h -- C ABI of libgk_hip.so, the MI355X (gfx950) implementation of GraKeL's
+ * WeisfeilerLehman / VertexHistogram / ShortestPath Gram-matrix path.
+ *
+ * The reference (ysig/GraKeL, /root/reference) is pure Python on this path and has NO FFI
+ * of its own; the interface each entry point replaces is therefore a Python method of the
+ * reference, cited per function below (file:line into /root/reference).  The binding a
+ * GraKeL maintainer would add is a ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, caller-owned HOST buffers unless the name says `_dev`; the library owns all
+ *     device memory; no C++/torch types cross this boundary.
+ *   - every function returns 0 on success, <0 on error; gk_last_error() gives the message
+ *     (thread-local).  No exceptions cross the boundary.
+ *   - a gk_ctx is bound to one device and one HIP stream and is NOT thread-safe.
+ *   - a "batch" is a set of graphs packed as CSR:
+ *        graph_ptr[n_graphs+1]  node range of each graph (nodes of a graph are contiguous)
+ *        row_ptr[n_nodes+1]     out-neighbour range of each node
+ *        col_idx[n_edges]       GLOBAL node index of each out-neighbour (same graph)
+ *        node_label[n_nodes]    dense level-0 label id in [0, n_labels0)
+ *     all int32.  Neighbour = key of the reference's edge dictionary of that vertex
+ *     (out-neighbours only, self loops kept, multi-edges collapsed, weights ignored:
+ *     grakel/kernels/weisfeiler_lehman.py:235-239).
+ */
+#ifndef GK_HIP_H
+#define GK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gk_ctx gk_ctx;
+typedef struct gk_batch gk_batch;
+typedef struct gk_feat gk_feat;
+
+#define GK_OK 0
+#define GK_ERR_ARG (-1)
+#define GK_ERR_HIP (-2)
+#define GK_ERR_STATE (-3)
+#define GK_ERR_UNSUPPORTED (-4)
+
+/* ---- library / context ------------------------------------------------------------- */
+const char* gk_last_error(void);
+const char* gk_version(void);
+/* Number of visible HIP devices (0 when none: callers must then fail loudly, there is no
+ * CPU fallback in this library). */
+int gk_device_count(int* out_count);
+int gk_create(int device_id, gk_ctx** out);
+int gk_destroy(gk_ctx* ctx);
+/* Borrow an external HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL
+ * restores the context's own stream. */
+int gk_set_stream(gk_ctx* ctx, void* hip_stream);
+int gk_synchronize(gk_ctx* ctx);
+/* HIP-event timing on the context's stream (bench.py's roofline clock). */
+int gk_timer_start(gk_ctx* ctx);
+int gk_timer_stop_ms(gk_ctx* ctx, double* out_ms);
+/* Per-kernel-class accumulated device time since the last reset, measured with HIP events
+ * around each launch group when profiling is enabled (enable=1 adds sync overhead). */
+int gk_profile_enable(gk_ctx* ctx, int enable);
+int gk_profile_reset(gk_ctx* ctx);
+/* names: "relabel", "features", "gram".  Returns total ms and launch count. */
+int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_launches);
+
+/* ---- batches ------------------------------------------------------------------------ */
+/* Replaces the per-graph Python containers built by WeisfeilerLehman.parse_input
+ * (grakel/kernels/weisfeiler_lehman.py:142-194: Gs_ed / L dictionaries) and
+ * Graph.__init__ (grakel/graph.py:147-232).  src_on_device!=0: the four arrays are device
+ * pointers on ctx's device (multi-GPU path: the all-gathered shards). */
+int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, int64_t n_edges,
+                    const int32_t* graph_ptr, const int32_t* row_ptr, const int32_t* col_idx,
+                    const int32_t* node_label, int32_t n_labels0, int src_on_device,
+                    gk_batch** out);
+int gk_batch_destroy(gk_batch* b);
+int gk_batch_info(gk_batch* b, int64_t* n_graphs, int64_t* n_nodes, int64_t* n_edges);
+
+/* ---- Weisfeiler-Lehman relabelling --------------------------------------------------- */
+/* Replaces the `generate_graphs` relabel loop, weisfeiler_lehman.py:223-258 (fit) and
+ * :435-476 (transform: run on the union batch fit+target graphs; the partition restricted
+ * to the fit graphs is unchanged).  After the call the batch holds, for every level
+ * 0..n_iter, a dense label id per node such that two nodes (of any graphs) share an id iff
+ * (own previous label, sorted multiset of out-neighbour previous labels) are equal.
+ * Exact: 64-bit multiset hashes are only used to group candidates, every node's full
+ * signature is compared with its group representative, and groups that fail are refined
+ * with re-seeded hashes until none fails.
+ *   out_label_counts[n_iter+1] : number of distinct labels per level (host)
+ *   hash_bits : 0 = default (64); tests pass small values to force collisions
+ *   out_rounds : total extra refinement rounds that were needed (0 in practice), may be NULL */
+int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits,
+                  int64_t* out_label_counts, int* out_rounds);
+/* Level labels back to the host (parity tests: partition equality with the oracle). */
+int gk_wl_get_labels(gk_ctx* ctx, gk_batch* b, int level, int32_t* out_labels);
+/* Kernel-level test hooks: the raw 64-bit signature hash and the sorted neighbour-label
+ * lists of level `level` (computed from level-1 labels), before dictionary assignment. */
+int gk_wl_debug_signature(gk_ctx* ctx, gk_batch* b, int level, uint64_t seed,
+                          uint64_t* out_hash, int32_t* out_sorted_nbr_labels);
+
+/* ---- label-count features ------------------------------------------------------------ */
+/* Replaces VertexHistogram.parse_input (grakel/kernels/vertex_histogram.py:57-154), called
+ * once per WL level by weisfeiler_lehman.py:260-285.  Builds, over levels [0, n_levels) of
+ * the batch, the per-graph label-count features:  the sparse (label, graph, count) triples,
+ * the self-similarities  selfk[g] = sum over all columns of count^2  (= the Gram diagonal,
+ * vertex_histogram.py:186-219 / weisfeiler_lehman.py:502-555) and a dense, column-compacted
+ * Phi_s holding only the columns that can contribute to an off-diagonal entry.
+ *   n_fit == n_graphs : symmetric job (fit_transform); a column is kept iff it occurs in
+ *                       >= 2 graphs, singletons are folded into selfk.
+ *   n_fit <  n_graphs : rectangular job (transform): rows = graphs [n_fit, n_graphs),
+ *                       cols = graphs [0, n_fit); a column is kept iff it occurs on both sides
+ *                       (unseen labels are dropped exactly like vertex_histogram.py:179). */
+int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, gk_feat** out);
+int gk_features_destroy(gk_feat* f);
+/* n_cols_kept: width of Phi_s; nnz: number of (label,graph) triples over all levels;
+ * max_count: largest single count; dtype: 0 = int8 Phi / i32 MFMA, 1 = f64 Phi / f64 MFMA. */
+int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* nnz, int64_t* max_count,
+                     int* dtype);
+int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk /* [n_graphs] */);
+
+/* ---- Gram matrix ---------------------------------------------------------------------- */
+/* Replaces VertexHistogram._calculate_kernel_matrix (vertex_histogram.py:156-184: X.dot(X.T)
+ * per level), the np.sum over levels (weisfeiler_lehman.py:269-270) and the normalisation
+ * tails (weisfeiler_lehman.py:323-328,493-498; kernel.py:158-165,195-204).
+ * Output is row-major float64 [n_rows x n_cols]:
+ *   symmetric job:   n_rows = n_cols = n_graphs
+ *   rectangular job: n_rows = n_graphs - n_fit, n_cols = n_fit
+ * normalize: 0 none; 1 divide by sqrt(selfk_row*selfk_col) leaving 0/0 = NaN (Kernel);
+ *            2 same with nan_to_num -> 0 (WeisfeilerLehman).
+ * out_host may be NULL: the matrix then stays on the device (gk_gram_dev_ptr), which is what
+ * bench.py times. */
+int gk_gram(gk_ctx* ctx, gk_feat* f, int normalize, double* out_host);
+int gk_gram_dev_ptr(gk_feat* f, void** out_dev_ptr, int64_t* n_rows, int64_t* n_cols);
+/* Row-sharded Gram (multi-GPU): only rows [row_lo,row_hi) of the job's matrix are computed;
+ * out_host is [(row_hi-row_lo) x n_cols]. */
+int gk_gram_rows(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_hi, int normalize,
+                 double* out_host);
+/* Algorithmic work of the last gk_gram* call, for the roofline: MACs = rows*cols*kept cols. */
+int gk_gram_last_stats(gk_feat* f, double* out_flops, double* out_ms_event);
+
+/* ---- Shortest-path kernel ------------------------------------------------------------- */
+/* Replaces Graph.build_shortest_path_matrix + floyd_warshall/dijkstra
+ * (grakel/graph.py:588-687,1712-1794) and ShortestPath.parse_input's pair enumeration
+ * (grakel/kernels/shortest_path.py:412-499,510-511).  edge_weight: NULL = unit weights, else
+ * int32[n_edges] positive integer weights.  Produces a batch of "pair items": one per ordered
+ * pair (u,v), u!=v, d(u,v) finite, keyed by (label_u, label_v, d) (with_labels!=0) or d,
+ * exposed as level 0 of a derived batch so that gk_features_build / gk_gram apply unchanged. */
+int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_labels,
+                gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys);
+/* Test hook: all-pairs distance matrix of one graph (n x n int32, -1 = unreachable). */
+int gk_sp_debug_apsp(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int64_t graph,
+                     int32_t* out_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GK_HIP_H */

@@ -1,0 +1,182 @@
+"""CPU tests: host ingestion, estimator plumbing, and the C-ABI surface (no compute)."""
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from golden.small_sets import SMALL_SETS
+from oracle import grakel_oracle as O
+import grakel_amd
+from grakel_amd import GraphBatch, ShortestPath, VertexHistogram, WeisfeilerLehman
+from grakel_amd.batch import (compress_labels, sp_batch_from_input, vh_batch_from_input,
+                              wl_batch_from_input)
+from grakel_amd.synthetic import er_dataset, er_dataset_csr, random_labelled_graphs
+
+
+def _adjacency_sets(gb):
+    out = []
+    for v in range(gb.n_nodes):
+        out.append(sorted(gb.col_idx[gb.row_ptr[v]:gb.row_ptr[v + 1]].tolist()))
+    return out
+
+
+@pytest.mark.parametrize("name", [n for n, _ in SMALL_SETS])
+def test_wl_ingestion_matches_reference_semantics(name):
+    """Nodes = labelled vertices, neighbours = keys of the edge dictionary (oracle.parse_graph
+    restates grakel/graph.py); label ids = rank in sorted(distinct labels)."""
+    X = random_labelled_graphs(**dict(SMALL_SETS)[name])
+    gb, mapping = wl_batch_from_input(X)
+    assert gb.n_graphs == len(X)
+    base = 0
+    want_adj, want_lab = [], []
+    for x in X:
+        g = O.parse_graph(x[0], x[1])
+        keys = list(x[1].keys())
+        pos = {k: base + i for i, k in enumerate(keys)}
+        for k in keys:
+            want_adj.append(sorted(pos[nb] for nb in g.edges.get(k, {}).keys()))
+            want_lab.append(x[1][k])
+        base += len(keys)
+    assert _adjacency_sets(gb) == want_adj
+    ranks = {l: i for i, l in enumerate(sorted(set(want_lab)))}
+    assert gb.node_label.tolist() == [ranks[l] for l in want_lab]
+    assert mapping == ranks
+
+
+def test_all_edge_dictionary_forms_give_the_same_batch():
+    lab = {0: 'x', 1: 'y', 2: 'x', 3: 'z'}
+    forms = [
+        {0: [1, 2], 1: [0], 2: [0, 3], 3: [2]},
+        {0: {1: 1.0, 2: 1.0}, 1: {0: 1.0}, 2: {0: 1.0, 3: 1.0}, 3: {2: 1.0}},
+        {(0, 1): 1, (0, 2): 1, (1, 0): 1, (2, 0): 1, (2, 3): 1, (3, 2): 1},
+        [(0, 1), (0, 2), (1, 0), (2, 0), (2, 3), (3, 2)],
+        [(0, 1, 2.0), (0, 2, 1.0), (1, 0, 1), (2, 0, 1), (2, 3, 1), (3, 2, 1)],
+        np.array([[0, 1, 1, 0], [1, 0, 0, 0], [1, 0, 0, 1], [0, 0, 1, 0]]),
+        [[0, 1, 1, 0], [1, 0, 0, 0], [1, 0, 0, 1], [0, 0, 1, 0]],
+    ]
+    from scipy.sparse import csr_matrix
+    forms.append(csr_matrix(forms[-2]))
+    ref = None
+    for f in forms:
+        gb, _ = wl_batch_from_input([[f, lab]])
+        cur = (_adjacency_sets(gb), gb.node_label.tolist())
+        ref = ref or cur
+        assert cur == ref
+    # duplicated neighbours collapse (dictionary keys), symbols may be anything hashable
+    gb, _ = wl_batch_from_input([[{'a': ['b', 'b', 'c'], 'b': ['a'], 'c': ['a']},
+                                  {'a': 1, 'b': 2, 'c': 2}]])
+    assert _adjacency_sets(gb) == [[1, 2], [0], [0]]
+    with pytest.raises(KeyError):                       # unlabelled neighbour: reference KeyError
+        wl_batch_from_input([[{0: [1], 1: [0]}, {0: 'a'}]])
+    with pytest.raises(ValueError):
+        wl_batch_from_input([["nonsense", {0: 'a'}]])
+
+
+def test_label_compression_fit_and_transform():
+    ids, m = compress_labels(['b', 'a', 'c', 'a'])
+    assert ids.tolist() == [1, 0, 2, 0] and m == {'a': 0, 'b': 1, 'c': 2}
+    ids2, ext = compress_labels(['c', 'zz', 'a', 'd'], m)      # unseen ids continue past the fitted
+    assert ids2.tolist() == [2, 4, 0, 3] and ext == {'d': 3, 'zz': 4}
+    ids, m = compress_labels([5, 3, 5, 9])
+    assert ids.tolist() == [1, 0, 1, 2] and m == {3: 0, 5: 1, 9: 2}
+
+
+def test_csr_emitter_describes_the_same_graphs_as_the_object_form():
+    X = er_dataset(30, 20, 0.2, 4, 7)
+    gb, _ = wl_batch_from_input(X)
+    gp, rp, ci, lab = er_dataset_csr(30, 20, 0.2, 4, 7)
+    assert np.array_equal(gb.graph_ptr, gp) and np.array_equal(gb.row_ptr, rp)
+    assert _adjacency_sets(gb) == _adjacency_sets(GraphBatch(gp, rp, ci, lab, 4))
+    assert np.array_equal(gb.node_label, lab)
+
+
+def test_concat_and_slice():
+    X = random_labelled_graphs(12, 3, 9, 0.4, 3, 2)
+    a, _ = wl_batch_from_input(X[:7])
+    b, _ = wl_batch_from_input(X[7:])
+    u = GraphBatch.concat(a, b)
+    full, _ = wl_batch_from_input(X)
+    assert np.array_equal(u.graph_ptr, full.graph_ptr) and np.array_equal(u.row_ptr, full.row_ptr)
+    assert np.array_equal(u.col_idx, full.col_idx)
+    s = full.slice_graphs(7, 12)
+    assert np.array_equal(s.graph_ptr, b.graph_ptr) and np.array_equal(s.col_idx, b.col_idx)
+
+
+def test_sp_ingestion_vertex_order_weights_and_errors():
+    g = [{'c': {'a': 2}, 'a': {'b': 1}}, {'a': 0, 'b': 1, 'c': 0}]
+    gb, m = sp_batch_from_input([g], True)
+    assert gb.n_nodes == 3 and gb.col_idx.tolist() == [1, 0] and gb.edge_weight.tolist() == [1, 2]
+    assert gb.node_label.tolist() == [0, 1, 0]
+    with pytest.raises(ValueError):                      # no labels with with_labels=True
+        sp_batch_from_input([[{0: [1], 1: [0]}, {}]], True)
+    with pytest.raises(NotImplementedError):             # float weights are out of scope
+        sp_batch_from_input([[{(0, 1): 0.5}, {0: 1, 1: 1}]], True)
+    gb, _ = sp_batch_from_input([[np.array([[0, 3], [0, 0]])]], False)
+    assert gb.edge_weight.tolist() == [3] and gb.n_labels == 1
+
+
+def test_vh_reads_only_the_label_dict():
+    gb, m = vh_batch_from_input([["anything at all", {0: 'a', 1: 'b'}], [None, {7: 'b'}]])
+    assert gb.n_graphs == 2 and gb.n_edges == 0 and gb.node_label.tolist() == [0, 1, 1]
+
+
+def test_estimator_parameters_and_lazy_initialisation():
+    # get_params must match the reference exactly
+    assert sorted(WeisfeilerLehman().get_params()) == ['base_graph_kernel', 'n_iter', 'n_jobs',
+                                                       'normalize', 'verbose']
+    assert sorted(ShortestPath().get_params()) == ['algorithm_type', 'n_jobs', 'normalize',
+                                                   'verbose', 'with_labels']
+    assert sorted(VertexHistogram().get_params()) == ['n_jobs', 'normalize', 'sparse', 'verbose']
+    wl = WeisfeilerLehman(n_iter=3)
+    wl.initialize()
+    assert wl._n_iter == 4 and wl._initialized["n_iter"]
+    wl.set_params(n_iter=7)
+    assert not wl._initialized["n_iter"]
+    wl.initialize()
+    assert wl._n_iter == 8
+    for bad in (0, -1, 2.0, "3"):
+        with pytest.raises(TypeError):
+            WeisfeilerLehman(n_iter=bad).initialize()
+    with pytest.raises(ValueError):
+        WeisfeilerLehman(n_jobs="4").initialize()
+    with pytest.raises(TypeError):
+        WeisfeilerLehman(base_graph_kernel=3).initialize()
+    WeisfeilerLehman(base_graph_kernel=(VertexHistogram, {"sparse": False})).initialize()
+    with pytest.raises(NotImplementedError):
+        WeisfeilerLehman(base_graph_kernel=ShortestPath).initialize()
+    with pytest.raises(ValueError):
+        ShortestPath(algorithm_type="bfs").initialize()
+    from sklearn.base import clone
+    assert clone(WeisfeilerLehman(n_iter=2, normalize=True)).get_params()["n_iter"] == 2
+
+
+def test_fit_is_host_only_and_picklable():
+    X = random_labelled_graphs(10, 3, 8, 0.4, 3, 1)
+    wl = WeisfeilerLehman(n_iter=2).fit(X)               # no GPU needed to fit (ingestion only)
+    wl2 = pickle.loads(pickle.dumps(wl))
+    assert wl2._nx == 10 and wl2._inv_labels == wl._inv_labels
+    assert np.array_equal(wl2._fit_batch.col_idx, wl._fit_batch.col_idx)
+    vh = pickle.loads(pickle.dumps(VertexHistogram().fit(X)))
+    assert vh._labels == VertexHistogram().fit(X)._labels
+    pickle.loads(pickle.dumps(ShortestPath().fit(X)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libgk_hip.so must load here (no GPU) and export exactly what include/gk_hip.h declares."""
+    from grakel_amd import _lib
+    header = open(os.path.join(ROOT, "include", "gk_hip.h")).read()
+    declared = set(re.findall(r"\b(gk_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gk_version().startswith(b"gk_hip")
+    if _lib.device_count() == 0:                         # product path fails loudly without a GPU
+        with pytest.raises(_lib.GkError):
+            WeisfeilerLehman(n_iter=1).fit_transform(random_labelled_graphs(3, 3, 5, 0.5, 2, 0))
