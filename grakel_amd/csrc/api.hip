@@ -4,6 +4,7 @@
 #include <string.h>
 
 static thread_local char g_err[1024] = "";
+static void cache_release_all(gk_ctx* ctx);
 
 void gk_set_error(const char* fmt, ...) {
     va_list ap;
@@ -45,14 +46,6 @@ extern "C" int gk_create(int device_id, gk_ctx** out) {
     GK_HIP_CHECK(hipEventCreate(&ctx->ev1));
     GK_HIP_CHECK(hipEventCreate(&ctx->pv0));
     GK_HIP_CHECK(hipEventCreate(&ctx->pv1));
-    // keep freed blocks cached in the pool: the per-level temporaries are re-requested
-    // every iteration and must not go back to the driver
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess) {
-        uint64_t thr = UINT64_MAX;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-    }
-    (void)hipGetLastError();
     *out = ctx;
     return GK_OK;
 }
@@ -65,6 +58,8 @@ extern "C" int gk_destroy(gk_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->pv0);
     (void)hipEventDestroy(ctx->pv1);
+    cache_release_all(ctx);
+    for (auto& kv : ctx->cache.live) (void)hipFree(kv.first);   // leaked by the caller: reclaim
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return GK_OK;
@@ -119,17 +114,76 @@ extern "C" int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int
     return GK_OK;
 }
 
+static size_t bucket_size(size_t bytes) {
+    if (bytes < 512) return 512;
+    if (bytes <= (1u << 20)) {   // next power of two up to 1 MiB
+        size_t b = 512;
+        while (b < bytes) b <<= 1;
+        return b;
+    }
+    const size_t g = 2u << 20;    // 2 MiB granules above
+    return (bytes + g - 1) / g * g;
+}
+
+static void cache_release_all(gk_ctx* ctx) {
+    for (auto& kv : ctx->cache.free_blocks) (void)hipFree(kv.second);
+    ctx->cache.free_blocks.clear();
+}
+
 int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes) {
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMallocAsync(p, bytes, ctx->stream);
+    const size_t cap = bucket_size(bytes);
+    BlockCache& c = ctx->cache;
+    auto it = c.free_blocks.lower_bound(cap);
+    if (it != c.free_blocks.end() && it->first <= cap + cap / 2) {   // bounded internal waste
+        *p = it->second;
+        c.live[*p] = it->first;
+        c.free_blocks.erase(it);
+        return GK_OK;
+    }
+    hipError_t e = hipMalloc(p, cap);
+    if (e != hipSuccess) {       // give cached blocks back to the driver and retry once
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        cache_release_all(ctx);
+        e = hipMalloc(p, cap);
+    }
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         gk_set_error("device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
         *p = nullptr;
         return GK_ERR_HIP;
     }
+    c.live[*p] = cap;
+    c.bytes_total += cap;
     return GK_OK;
 }
 
 void gk_dev_free(gk_ctx* ctx, void* p) {
-    if (p) (void)hipFreeAsync(p, ctx->stream);
+    if (!p) return;
+    BlockCache& c = ctx->cache;
+    auto it = c.live.find(p);
+    if (it == c.live.end()) return;   // not ours / double free: ignore rather than corrupt
+    c.free_blocks.insert({it->second, p});
+    c.live.erase(it);
+}
+
+// 16-byte grid-stride zero fill.  hipMallocAsync blocks are 256-byte aligned; tails are bytes.
+__global__ void gk_zero_kernel(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (; i < n16; i += stride) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+int gk_zero_async(gk_ctx* ctx, void* p, size_t bytes) {
+    if (bytes == 0) return GK_OK;
+    size_t n16 = bytes / 16;
+    int ntail = (int)(bytes - n16 * 16);
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    gk_zero_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>((uint4*)p, n16, (unsigned char*)p + n16 * 16, ntail);
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
 }

@@ -48,8 +48,19 @@ struct ProfSlot {
     i64 launches = 0;
 };
 
+// Per-context caching allocator: hipMalloc'ed blocks are kept in a size-ordered free list and
+// handed out again.  All work of a context is on ONE stream, so reusing a block as soon as
+// it is released is ordered correctly by the stream itself (same contract as a stream-ordered
+// pool, but without hipMallocAsync -- see DESIGN.md "allocator").
+struct BlockCache {
+    std::multimap<size_t, void*> free_blocks;   // capacity -> block
+    std::map<void*, size_t> live;               // block -> capacity
+    size_t bytes_total = 0;
+};
+
 struct gk_ctx {
     int device = 0;
+    BlockCache cache;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // user timer
@@ -58,10 +69,12 @@ struct gk_ctx {
     std::map<std::string, ProfSlot> prof;
 };
 
-// Stream-ordered device allocation from the device's default mempool (release threshold is
-// raised in gk_create so freed blocks are cached instead of being returned to the driver).
+// Device allocation through the context's block cache (stream-ordered reuse on ctx->stream).
 int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes);
 void gk_dev_free(gk_ctx* ctx, void* p);
+
+// Zero-fill on the context's stream with our own kernel (not hipMemsetAsync: see DESIGN.md).
+int gk_zero_async(gk_ctx* ctx, void* p, size_t bytes);
 
 // RAII temp buffer (freed stream-ordered at scope exit).
 template <typename T>

@@ -151,8 +151,8 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     f->meta = (u32*)q;
     if ((r = gk_dev_alloc(ctx, &q, (size_t)N * 8))) return fail(r);
     f->selfk = (u64*)q;
-    if (hipMemsetAsync(f->meta, 0, n_meta * 4, ctx->stream) != hipSuccess ||
-        hipMemsetAsync(f->selfk, 0, (size_t)N * 8, ctx->stream) != hipSuccess) {
+    if (gk_zero_async(ctx, f->meta, n_meta * 4) != GK_OK ||
+        gk_zero_async(ctx, f->selfk, (size_t)N * 8) != GK_OK) {
         gk_set_error("gk_features_build: memset failed");
         return fail(GK_ERR_HIP);
     }
@@ -201,7 +201,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     const size_t phi_bytes = (size_t)f->n_rows_pad * f->n_cols_pad * esz;
     if ((r = gk_dev_alloc(ctx, &q, phi_bytes))) return fail(r);
     f->phi = q;
-    if (hipMemsetAsync(f->phi, 0, phi_bytes, ctx->stream) != hipSuccess) return fail(GK_ERR_HIP);
+    if (gk_zero_async(ctx, f->phi, phi_bytes) != GK_OK) return fail(GK_ERR_HIP);
     for (int l = 0; l < n_levels && V > 0; ++l) {
         LevelTriples& L = f->lev[l];
         u32 T = h[META_T(l)];
@@ -236,5 +236,19 @@ extern "C" int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk) {
     GK_HIP_CHECK(hipMemcpyAsync(h.data(), f->selfk, (size_t)f->n_graphs * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (i64 i = 0; i < f->n_graphs; ++i) out_selfk[i] = (double)h[i];
+    return GK_OK;
+}
+
+extern "C" int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi) {
+    GK_ARG(ctx && f && out_phi, "gk_features_debug_phi: null argument");
+    const i64 N = f->n_graphs, D = f->n_cols, ld = f->n_cols_pad;
+    const size_t esz = f->dtype == 0 ? 1 : 8;
+    std::vector<unsigned char> h((size_t)N * ld * esz);
+    GK_HIP_CHECK(hipMemcpyAsync(h.data(), f->phi, h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (i64 i = 0; i < N; ++i)
+        for (i64 j = 0; j < D; ++j)
+            out_phi[i * D + j] = f->dtype == 0 ? (double)((const int8_t*)h.data())[i * ld + j]
+                                               : ((const double*)h.data())[i * ld + j];
     return GK_OK;
 }

@@ -67,9 +67,9 @@ __global__ __launch_bounds__(1024) void scan_partials_kernel(T* __restrict__ par
 }
 
 template <typename T, bool EXCL>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const T* __restrict__ in,
-                                                                   T* __restrict__ out, i64 n,
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const T* in, T* out, i64 n,
                                                                    const T* __restrict__ partial) {
+    // in and out may alias (in-place scans): no __restrict__ on them
     __shared__ T wsum[SCAN_THREADS / 64];
     const i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_ITEMS;   // blocked
     T v[SCAN_ITEMS];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const T* __res
 template <typename T>
 static int scan_impl(gk_ctx* ctx, const T* in, T* out, i64 n, bool exclusive, T* total) {
     if (n <= 0) {
-        if (total) GK_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(T), ctx->stream));
+        if (total) GK_TRY(gk_zero_async(ctx, total, sizeof(T)));
         return GK_OK;
     }
     i64 nblk = cdiv(n, SCAN_TILE);

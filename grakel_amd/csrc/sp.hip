@@ -183,8 +183,8 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     const i64 N = b->n_graphs;
     GK_TRY(s.sq.alloc(N)); GK_TRY(s.dist_ptr.alloc(N)); GK_TRY(s.total.alloc(1));
     GK_TRY(s.pair_count.alloc(N)); GK_TRY(s.maxd.alloc(1));
-    GK_HIP_CHECK(hipMemsetAsync(s.pair_count.p, 0, (size_t)N * 4, ctx->stream));
-    GK_HIP_CHECK(hipMemsetAsync(s.maxd.p, 0, 4, ctx->stream));
+    GK_TRY(gk_zero_async(ctx, s.pair_count.p, (size_t)N * 4));
+    GK_TRY(gk_zero_async(ctx, s.maxd.p, 4));
     sp_sq_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, s.sq.p, N);
     GK_TRY(gk_scan_u64(ctx, s.sq.p, s.dist_ptr.p, N, true, s.total.p));
     GK_HIP_CHECK(hipMemcpyAsync(total_sq, s.total.p, 8, hipMemcpyDeviceToHost, ctx->stream));

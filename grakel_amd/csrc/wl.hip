@@ -280,7 +280,7 @@ extern "C" int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, i
     Tmp<i32> stats(ctx);
     int r;
     if ((r = flag.alloc(n_nodes)) || (r = excl.alloc(n_nodes)) || (r = total.alloc(1)) || (r = stats.alloc(2))) return fail(r);
-    if (hipMemsetAsync(stats.p, 0, 8, ctx->stream) != hipSuccess) return fail(GK_ERR_HIP);
+    if (gk_zero_async(ctx, stats.p, 8) != GK_OK) return fail(GK_ERR_HIP);
     i64 m = n_graphs > n_nodes ? n_graphs : n_nodes;
     batch_stats_kernel<<<grid_for(m, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, n_graphs, n_nodes, flag.p, stats.p);
     if ((r = gk_scan_u32(ctx, flag.p, excl.p, n_nodes, true, total.p))) return fail(r);
@@ -371,7 +371,7 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
 static int dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
                                 i32* rep, u32* count_dev) {
     if (n == 0) {
-        GK_HIP_CHECK(hipMemsetAsync(count_dev, 0, 4, ctx->stream));
+        GK_TRY(gk_zero_async(ctx, count_dev, 4));
         return GK_OK;
     }
     Tmp<u64> ks(ctx);
@@ -414,7 +414,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             bits = 64;
         }
         GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, cur, perm, rep.p, count_dev));
-        GK_HIP_CHECK(hipMemsetAsync(unresolved_dev, 0, 4, ctx->stream));
+        GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
         GK_HIP_CHECK(hipGetLastError());
         if (!exact) break;
@@ -444,7 +444,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     GK_TRY(gk_batch_ensure_levels(b, n_levels));
     Tmp<u32> meta(ctx);   // [n_levels] counts, [n_levels] unresolved
     GK_TRY(meta.alloc(2 * (size_t)n_levels));
-    GK_HIP_CHECK(hipMemsetAsync(meta.p, 0, 8 * (size_t)n_levels, ctx->stream));
+    GK_TRY(gk_zero_async(ctx, meta.p, 8 * (size_t)n_levels));
     if (out_rounds) *out_rounds = 0;
     // level 0: group nodes by the given label ids
     {

@@ -153,6 +153,11 @@ class Engine(object):
         check(self.lib.gk_features_selfk(self.handle, feat.handle, _ptr(out)))
         return out
 
+    def debug_phi(self, feat):
+        out = np.empty((feat.batch.n_graphs, feat.n_cols), dtype=np.float64)
+        check(self.lib.gk_features_debug_phi(self.handle, feat.handle, _ptr(out)))
+        return out
+
     def gram(self, feat, normalize=0, rows=None, to_host=True):
         lo, hi = (0, feat.n_rows) if rows is None else rows
         out = np.empty((hi - lo, feat.n_out_cols), dtype=np.float64) if to_host else None

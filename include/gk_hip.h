@@ -115,6 +115,8 @@ int gk_features_destroy(gk_feat* f);
 int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* nnz, int64_t* max_count,
                      int* dtype);
 int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk /* [n_graphs] */);
+/* Test hook: the dense column-compacted Phi_s as float64 [n_graphs x n_cols_kept]. */
+int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi);
 
 /* ---- Gram matrix ---------------------------------------------------------------------- */
 /* Replaces VertexHistogram._calculate_kernel_matrix (vertex_histogram.py:156-184: X.dot(X.T)
