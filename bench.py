@@ -163,11 +163,13 @@ def main():
                        "parallelism": "graphs+Gram rows sharded over %d GPU(s)" % world,
                        "label_counts": info.get("label_counts"), "gram_columns_kept": info.get("n_cols")},
             "roofline": {
-                "kernel": "gram_i8_kernel" if dtype == "i8" else "gram_f64_kernel",
+                "kernel": "gram_i8_glds_kernel" if dtype == "i8" else "gram_f64_kernel",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": None,
-                "note": "achieved = 2*rows*N*D_kept integer MACs*2 per launch (full product, no symmetry "
-                        "skipping; rows = this rank's Gram rows) / avg HIP-event duration of the launch"},
+                "note": "achieved = integer ops EXECUTED per launch / avg HIP-event duration of the launch; "
+                        "1 GPU: only the 128x128 tiles on/above the diagonal are computed "
+                        "(2*128*128*D_kept ops each, mirrored on store); N GPUs: each rank computes its "
+                        "full row block (2*rows*N*D_kept)"},
             "phases_ms": phases,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -61,23 +61,45 @@ __global__ void feat_emit_kernel(const i32* __restrict__ perm, const i32* __rest
     }
 }
 
-// per triple: exact self similarity and the largest count
-__global__ void feat_stats_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_graph,
-                                  u64* __restrict__ selfk, u32* __restrict__ meta, int level,
-                                  int n_levels) {
-    const u32 T = meta[META_T(level)];
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+// per node: add the count of its (label,graph) triple to node_acc[v]; sum over the nodes of a
+// graph of these counts == sum over its triples of count^2, so the exact self similarity needs
+// no atomics (each node is written once per level).  Also tracks the largest count.
+__global__ void feat_count_kernel(const i32* __restrict__ perm, const u64* __restrict__ scan,
+                                  const i32* __restrict__ tri_pos, u32* __restrict__ node_acc,
+                                  u32* __restrict__ meta, int level, int n_levels, i64 n) {
+    __shared__ u32 wmax[4];
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 c = 0;
-    if (t < T) {
+    if (k < n) {
+        i32 t = (i32)(u32)(scan[k] & 0xffffffffull) - 1;
         c = (u32)(tri_pos[t + 1] - tri_pos[t]);
-        atomicAdd((unsigned long long*)&selfk[tri_graph[t]], (unsigned long long)c * c);
+        i32 v = perm[k];
+        node_acc[v] = (level == 0 ? 0u : node_acc[v]) + c;
     }
-    // wave max, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) {
         u32 o = __shfl_down(c, off, 64);
         c = o > c ? o : c;
     }
-    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(&meta[3 * n_levels], c);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 m = wmax[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = wmax[i] > m ? wmax[i] : m;
+        // plain read as a filter: once the maximum is established almost no block issues the atomic
+        if (m > meta[3 * n_levels]) atomicMax(&meta[3 * n_levels], m);
+    }
+}
+
+// one wave per graph: selfk[g] = sum of node_acc over the graph's (contiguous) nodes
+__global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* __restrict__ node_acc,
+                                  u64* __restrict__ selfk, i64 n_graphs) {
+    const i64 g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (g >= n_graphs) return;
+    u64 s = 0;
+    for (i32 v = graph_ptr[g] + lane; v < graph_ptr[g + 1]; v += 64) s += node_acc[v];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) selfk[g] = s;
 }
 
 __global__ void feat_colflag_kernel(const i32* __restrict__ tstart, const i32* __restrict__ tri_graph,
@@ -157,10 +179,14 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
         return fail(GK_ERR_HIP);
     }
     Tmp<u64> flag(ctx), scan(ctx);
-    Tmp<u32> cflag(ctx), cexcl(ctx), ctotal(ctx);
+    Tmp<u32> cflag(ctx), cexcl(ctx), ctotal(ctx), node_acc(ctx);
     if ((r = flag.alloc(V)) || (r = scan.alloc(V)) || (r = cflag.alloc(V)) || (r = cexcl.alloc(V)) ||
-        (r = ctotal.alloc(1)))
+        (r = ctotal.alloc(1)) || (r = node_acc.alloc(V)))
         return fail(r);
+    if (!b->graph_ptr) {
+        gk_set_error("gk_features_build: batch has no graph_ptr");
+        return fail(GK_ERR_STATE);
+    }
     for (int l = 0; l < n_levels && V > 0; ++l) {
         LevelTriples& L = f->lev[l];
         i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid};
@@ -174,12 +200,14 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
         if ((r = gk_scan_u64(ctx, flag.p, scan.p, V, false, nullptr))) return fail(r);
         feat_emit_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, b->node_graph, flag.p, scan.p, L.tri_pos,
                                                                     L.tri_graph, L.tri_run, L.tstart, f->meta, l, V);
-        feat_stats_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(L.tri_pos, L.tri_graph, f->selfk, f->meta, l, n_levels);
+        feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, scan.p, L.tri_pos, node_acc.p, f->meta, l, n_levels, V);
         feat_colflag_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(L.tstart, L.tri_graph, cflag.p, f->meta, l,
                                                                        f->symmetric ? 1 : 0, (i32)n_fit, V);
         if ((r = gk_scan_u32(ctx, cflag.p, cexcl.p, V, true, ctotal.p))) return fail(r);
         feat_colid_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(cflag.p, cexcl.p, ctotal.p, L.colid, f->meta, l, V);
     }
+    if (V > 0)
+        feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, node_acc.p, f->selfk, N);
     // one host sync: sizes of the dense operand
     std::vector<u32> h(n_meta);
     if (hipMemcpyAsync(h.data(), f->meta, n_meta * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

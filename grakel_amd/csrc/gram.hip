@@ -11,6 +11,7 @@
 // in Phi_s; K_ii is written from the exact selfk vector instead) and the normalisation
 // K_ij / sqrt(K_ii K_jj) (weisfeiler_lehman.py:323-328, kernel.py:195-204).
 #include "common.h"
+#include <stdlib.h>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -43,15 +44,92 @@ __device__ __forceinline__ double finish_entry(double val, i64 grow, i64 gcol, b
 #define GI_BK 64
 #define GI_LD 80
 
+#define GRAM_I8_EPILOGUE \
+    const bool mirror = tri && bm != bn; \
+    const bool even = (N & 1) == 0; \
+    _Pragma("unroll") \
+    for (int mt = 0; mt < 2; ++mt) \
+    _Pragma("unroll") \
+        for (int nt = 0; nt < 2; ++nt) { \
+            const i64 col = (i64)bn * GI_BN + wn * 64 + nt * 32 + (lane & 31); \
+    _Pragma("unroll") \
+            for (int q = 0; q < 4; ++q) { \
+                const i64 row0 = (i64)bm * GI_BM + wm * 64 + mt * 32 + 8 * q + 4 * (lane >> 5); \
+                double v[4]; \
+    _Pragma("unroll") \
+                for (int j = 0; j < 4; ++j) { \
+                    const i64 row = row0 + j; \
+                    v[j] = 0.0; \
+                    if (row < M && col < N) { \
+                        v[j] = finish_entry((double)acc[mt][nt][4 * q + j], row_base + row, col, \
+                                            symmetric != 0, selfk, n_fit, normalize); \
+                        K[row * N + col] = v[j]; \
+                    } \
+                } \
+                if (mirror && col < N) { \
+                    double* dst = K + col * N + row0; \
+                    if (even && row0 + 3 < M) { \
+                        *(double2*)(dst) = make_double2(v[0], v[1]); \
+                        *(double2*)(dst + 2) = make_double2(v[2], v[3]); \
+                    } else { \
+    _Pragma("unroll") \
+                        for (int j = 0; j < 4; ++j) \
+                            if (row0 + j < M) dst[j] = v[j]; \
+                    } \
+                } \
+            } \
+        } \
+    /* end */
+
+// Block -> output tile.  Workgroup b is observed to run on XCD b % 8 (speed assumption only),
+// so consecutive ids of ONE XCD (b>>3) walk 8x8-tile patches: the ~128 tiles resident on an
+// XCD then share 2x(8+8) operand panels instead of ~90, and its 4 MiB L2 serves the re-reads.
+// Symmetric jobs only visit patches/tiles on or above the diagonal.
+#define GI_PATCH 8
+__device__ __forceinline__ bool gram_map_tile(int b, int tiles_m, int tiles_n, int sym, int patch,
+                                              int& bm, int& bn) {
+    if (!patch) {
+        bm = b / tiles_n, bn = b % tiles_n;
+        return !(sym && bn < bm);
+    }
+    const int P = GI_PATCH;
+    const int pm = (tiles_m + P - 1) / P, pn = (tiles_n + P - 1) / P;
+    const int xcd = b & 7, i = b >> 3;
+    const int pid = (i / (P * P)) * 8 + xcd, t = i % (P * P);
+    int pr, pc;
+    if (sym) {
+        int rem = pid;
+        pr = 0;
+        while (pr < pm && rem >= pn - pr) { rem -= pn - pr; ++pr; }
+        if (pr >= pm) return false;
+        pc = pr + rem;
+    } else {
+        if (pid >= pm * pn) return false;
+        pr = pid / pn, pc = pid % pn;
+    }
+    bm = pr * P + t / P, bn = pc * P + t % P;
+    if (bm >= tiles_m || bn >= tiles_n) return false;
+    return !(sym && bn < bm);
+}
+
+static inline i64 gram_grid_blocks(int tiles_m, int tiles_n, int sym, int patch) {
+    if (!patch) return (i64)tiles_m * tiles_n;
+    const int P = GI_PATCH;
+    const i64 pm = (tiles_m + P - 1) / P, pn = (tiles_n + P - 1) / P;
+    const i64 np = sym ? (pm * pn - pm * (pm - 1) / 2) : pm * pn;   // sym: pm == pn
+    return ((np + 7) / 8) * 8 * P * P;
+}
+
 __global__ __launch_bounds__(256, 2) void gram_i8_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
-    int symmetric, i64 n_fit, int normalize, int tiles_n) {
+    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch) {
     __shared__ __attribute__((aligned(16))) int8_t sA[2][GI_BM * GI_LD];
     __shared__ __attribute__((aligned(16))) int8_t sB[2][GI_BN * GI_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+    int bm, bn;
+    if (!gram_map_tile(blockIdx.x, tiles_m, tiles_n, tri, patch, bm, bn)) return;
 
     const int lrow = tid >> 2, lkc = tid & 3;   // 16-byte chunk owned by this thread (and +64 rows)
     const int8_t* gA = A + ((i64)bm * GI_BM + lrow) * ld + lkc * 16;
@@ -109,22 +187,94 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    GRAM_I8_EPILOGUE
+}
+
+// ---------------------------------------------------------------------------------------
+// int8 path, pipelined: same 128x128 tile / 2x2 waves / 32x32x32 MFMA, but the operand tiles
+// go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write) into a
+// ring of GL_NS stages, with GL_NS-1 K-steps in flight across the per-step barrier
+// (counted s_waitcnt vmcnt, raw s_barrier).  The LDS image is linear per wave instruction
+// (16 rows x 64 B = 1 KiB), so the bank-conflict-free layout is obtained by XOR-swizzling the
+// 16-byte chunk index on the SOURCE address and on the fragment read:
+//      physical chunk = logical chunk ^ ((row >> 2) & 3)
+// which spreads every 16-lane ds_read_b128 group over all 16 slots of the 256-B bank row.
+// ---------------------------------------------------------------------------------------
+#define GL_NS 4
+#define GL_STAGE 16384   // A 8 KiB + B 8 KiB
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__global__ __launch_bounds__(256, 2) void gram_i8_glds_kernel(
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles,
+    const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
+    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch) {
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // GL_NS * GL_STAGE, ONE array
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bm, bn;
+    if (!gram_map_tile(blockIdx.x, tiles_m, tiles_n, tri, patch, bm, bn)) return;
+
+    // this wave stages rows [wave*32, wave*32+32) of A and of B: two 1-KiB pieces each
+    const int srow = lane >> 2;                              // row inside the 16-row piece
+    const int schunk = (lane & 3) ^ ((srow >> 2) & 3);       // logical chunk this lane fetches
+    const int8_t* gA = A + ((i64)bm * GI_BM + wave * 32 + srow) * ld + schunk * 16;
+    const int8_t* gB = B + ((i64)bn * GI_BN + wave * 32 + srow) * ld + schunk * 16;
+    const i64 g16 = 16 * ld;
+    const int piece = wave * 2048;                           // LDS offset of this wave's rows
+
+    v16i acc[2][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const i64 col = (i64)bn * GI_BN + wn * 64 + nt * 32 + (lane & 31);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const i64 row = (i64)bm * GI_BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M && col < N) {
-                    double v = finish_entry((double)acc[mt][nt][r], row_base + row, col, symmetric != 0,
-                                            selfk, n_fit, normalize);
-                    K[row * N + col] = v;
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+#define GL_ISSUE(KT)                                                                              \
+    {                                                                                             \
+        const i64 go = (i64)(KT) * GI_BK;                                                         \
+        int8_t* st = smem + ((KT) % GL_NS) * GL_STAGE + piece;                                    \
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gA + go), (lds_void_t*)(st), 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gA + go + g16), (lds_void_t*)(st + 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gB + go), (lds_void_t*)(st + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gB + go + g16), (lds_void_t*)(st + 8192 + 1024), 16, 0, 0); \
+    }
+
+    for (int p = 0; p < GL_NS - 1; ++p)
+        if (p < k_tiles) GL_ISSUE(p);
+
+    // fragment read offsets: row rr, logical chunk cl = 2*ks + (lane>>5), physical = cl ^ ((rr>>2)&3)
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ra0 = wm * 64 + fr, ra1 = ra0 + 32, rb0 = wn * 64 + fr, rb1 = rb0 + 32;
+    const int xa0 = (ra0 >> 2) & 3, xa1 = (ra1 >> 2) & 3, xb0 = (rb0 >> 2) & 3, xb1 = (rb1 >> 2) & 3;
+
+    for (int kt = 0; kt < k_tiles; ++kt) {
+        // own loads of stage kt have landed when at most (stages in flight after kt) * 4 remain
+        const int ahead = k_tiles - 1 - kt;
+        if (ahead >= GL_NS - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();        // everyone's pieces of stage kt are in LDS; stage kt-1 is free
+        if (kt + GL_NS - 1 < k_tiles) GL_ISSUE(kt + GL_NS - 1);
+        const int8_t* sa = smem + (kt % GL_NS) * GL_STAGE;
+        const int8_t* sb = sa + 8192;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int cl = 2 * ks + fh;
+            v4i a0 = *(const v4i*)(sa + ra0 * 64 + ((cl ^ xa0) << 4));
+            v4i a1 = *(const v4i*)(sa + ra1 * 64 + ((cl ^ xa1) << 4));
+            v4i b0 = *(const v4i*)(sb + rb0 * 64 + ((cl ^ xb0) << 4));
+            v4i b1 = *(const v4i*)(sb + rb1 * 64 + ((cl ^ xb1) << 4));
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
         }
+    }
+#undef GL_ISSUE
+    GRAM_I8_EPILOGUE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -209,9 +359,27 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     if (f->dtype == 0) {
         const int8_t* phi = (const int8_t*)f->phi;
         const int tiles_m = (int)cdiv(M, GI_BM), tiles_n = (int)cdiv(n_cols, GI_BN);
-        gram_i8_kernel<<<dim3((unsigned)(tiles_m * (i64)tiles_n)), dim3(256), 0, ctx->stream>>>(
-            phi + first_row_graph * f->n_cols_pad, phi, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK),
-            f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_n);
+        // full symmetric job: only tiles on/above the diagonal are computed, each written twice
+        const int tri = (f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
+        const int patch = getenv("GK_GRAM_NO_PATCH") ? 0 : 1;
+        const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch);
+        if (getenv("GK_GRAM_V1")) {
+            gram_i8_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(
+                phi + first_row_graph * f->n_cols_pad, phi, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK),
+                f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n,
+                tri, patch);
+        } else {
+            static bool attr_set = false;
+            if (!attr_set) {
+                GK_HIP_CHECK(hipFuncSetAttribute((const void*)gram_i8_glds_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, GL_NS * GL_STAGE));
+                attr_set = true;
+            }
+            gram_i8_glds_kernel<<<dim3((unsigned)blocks), dim3(256), GL_NS * GL_STAGE, ctx->stream>>>(
+                phi + first_row_graph * f->n_cols_pad, phi, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK),
+                f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n,
+                tri, patch);
+        }
     } else {
         const double* phi = (const double*)f->phi;
         const int tiles_m = (int)cdiv(M, GD_BM), tiles_n = (int)cdiv(n_cols, GD_BN);
@@ -228,6 +396,11 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     (void)hipEventDestroy(e1);
     f->last_ms = ms;
     f->last_flops = 2.0 * (double)M * (double)n_cols * (double)f->n_cols;
+    if (f->dtype == 0 && f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) {
+        // only tiles on/above the diagonal were executed: count the work actually done
+        const double t = (double)cdiv(M, GI_BM);
+        f->last_flops = 2.0 * (t * (t + 1) / 2) * GI_BM * GI_BN * (double)f->n_cols;
+    }
     return GK_OK;
 }
 

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums_kernel(const T* _
 }
 
 // One block: partial[] -> exclusive prefix in place; grand total to *total (if non-null).
+// (only used when there are more tiles than SCAN_DIRECT_MAX)
 template <typename T>
 __global__ __launch_bounds__(1024) void scan_partials_kernel(T* __restrict__ partial, i64 m,
                                                               T* __restrict__ total) {
@@ -66,11 +67,27 @@ __global__ __launch_bounds__(1024) void scan_partials_kernel(T* __restrict__ par
     if (threadIdx.x == 0 && total) *total = carry_s;
 }
 
-template <typename T, bool EXCL>
+// DIRECT: partial[] holds raw tile sums; every block first adds up the sums of the tiles
+// before it (a few hundred values, L2 resident) -- saves the single-block middle kernel.
+template <typename T, bool EXCL, bool DIRECT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const T* in, T* out, i64 n,
-                                                                   const T* __restrict__ partial) {
+                                                                   const T* __restrict__ partial,
+                                                                   T* __restrict__ total) {
     // in and out may alias (in-place scans): no __restrict__ on them
     __shared__ T wsum[SCAN_THREADS / 64];
+    __shared__ T bsum[SCAN_THREADS / 64];
+    T block_off;
+    if (DIRECT) {
+        T s = 0;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS) s += partial[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) bsum[threadIdx.x >> 6] = s;
+        __syncthreads();
+        block_off = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) block_off += bsum[w];
+    } else {
+        block_off = partial[blockIdx.x];
+    }
     const i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_ITEMS;   // blocked
     T v[SCAN_ITEMS];
     T run = 0;
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const T* in, T
     __syncthreads();
     T woff = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
-    T acc = inc - run + woff + partial[blockIdx.x];
+    T acc = inc - run + woff + block_off;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         i64 idx = base + i;
@@ -95,7 +112,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const T* in, T
             if (!EXCL) out[idx] = acc;
         }
     }
+    if (DIRECT && total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1)
+        *total = acc;   // last thread of the last tile: grand total
 }
+
+#define SCAN_DIRECT_MAX 8192
 
 template <typename T>
 static int scan_impl(gk_ctx* ctx, const T* in, T* out, i64 n, bool exclusive, T* total) {
@@ -107,11 +128,15 @@ static int scan_impl(gk_ctx* ctx, const T* in, T* out, i64 n, bool exclusive, T*
     Tmp<T> partial(ctx);
     GK_TRY(partial.alloc(nblk));
     scan_tile_sums_kernel<T><<<dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, ctx->stream>>>(in, partial.p, n);
-    scan_partials_kernel<T><<<dim3(1), dim3(1024), 0, ctx->stream>>>(partial.p, nblk, total);
-    if (exclusive)
-        scan_apply_kernel<T, true><<<dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, ctx->stream>>>(in, out, n, partial.p);
-    else
-        scan_apply_kernel<T, false><<<dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, ctx->stream>>>(in, out, n, partial.p);
+    const dim3 g((unsigned)nblk), t(SCAN_THREADS);
+    if (nblk <= SCAN_DIRECT_MAX) {
+        if (exclusive) scan_apply_kernel<T, true, true><<<g, t, 0, ctx->stream>>>(in, out, n, partial.p, total);
+        else scan_apply_kernel<T, false, true><<<g, t, 0, ctx->stream>>>(in, out, n, partial.p, total);
+    } else {
+        scan_partials_kernel<T><<<dim3(1), dim3(1024), 0, ctx->stream>>>(partial.p, nblk, total);
+        if (exclusive) scan_apply_kernel<T, true, false><<<g, t, 0, ctx->stream>>>(in, out, n, partial.p, total);
+        else scan_apply_kernel<T, false, false><<<g, t, 0, ctx->stream>>>(in, out, n, partial.p, total);
+    }
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }

@@ -231,9 +231,15 @@ extern "C" int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     u64 total_sq = 0;
     GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq));
     // pair offsets
-    Tmp<u32> pair_base(ctx), ptotal(ctx);
-    GK_TRY(pair_base.alloc(N)); GK_TRY(ptotal.alloc(1));
-    GK_TRY(gk_scan_u32(ctx, s.pair_count.p, pair_base.p, N, true, ptotal.p));
+    // pair offsets double as the pair batch's graph_ptr[N+1]
+    Tmp<u32> ptotal(ctx);
+    void* gpq = nullptr;
+    GK_TRY(gk_dev_alloc(ctx, &gpq, (size_t)(N + 1) * 4));
+    struct PtrGuard { gk_ctx* c; void* p; ~PtrGuard() { if (p) gk_dev_free(c, p); } } gp_guard{ctx, gpq};
+    u32* pair_base = (u32*)gpq;
+    GK_TRY(ptotal.alloc(1));
+    GK_TRY(gk_scan_u32(ctx, s.pair_count.p, pair_base, N, true, ptotal.p));
+    GK_HIP_CHECK(hipMemcpyAsync(pair_base + N, ptotal.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
     u32 h_pairs = 0, h_maxd = 0;
     GK_HIP_CHECK(hipMemcpyAsync(&h_pairs, ptotal.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipMemcpyAsync(&h_maxd, s.maxd.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -245,6 +251,8 @@ extern "C" int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     gk_batch* pb = new gk_batch();
     pb->ctx = ctx, pb->is_pair_batch = true;
     pb->n_graphs = N, pb->n_nodes = h_pairs, pb->n_edges = 0, pb->n_labels0 = 0;
+    pb->graph_ptr = (i32*)pair_base;
+    gp_guard.p = nullptr;   // owned by the pair batch from here on
     i64 nm = b->max_graph_nodes;
     pb->max_graph_nodes = (i32)((nm * (nm - 1) < 2147483647ll) ? nm * (nm - 1) : 2147483647ll);
     auto fail = [&](int r) { gk_batch_destroy(pb); return r; };
@@ -262,7 +270,7 @@ extern "C" int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     Tmp<u32> nkeys(ctx);
     if ((r = keys.alloc(np)) || (r = nkeys.alloc(1))) return fail(r);
     sp_emit_kernel<<<dim3((unsigned)N), SP_THREADS, 0, ctx->stream>>>(
-        b->graph_ptr, b->labels /* level 0 */, s.dist_ptr.p, s.dist.p, pair_base.p, keys.p, pb->node_graph,
+        b->graph_ptr, b->labels /* level 0 */, s.dist_ptr.p, s.dist.p, pair_base, keys.p, pb->node_graph,
         L, d1, with_labels ? 1 : 0);
     if ((r = gk_dictionary_from_keys(ctx, keys.p, h_pairs, key_bits, pb->labels, pb->perm, nkeys.p)))
         return fail(r);

@@ -436,7 +436,14 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     GK_ARG(ctx && b, "gk_wl_relabel: null ctx/batch");
     GK_ARG(!b->is_pair_batch, "gk_wl_relabel: pair batches have no adjacency");
     GK_ARG(n_iter >= 0 && n_iter < 4096, "gk_wl_relabel: bad n_iter");
-    if (hash_bits <= 0 || hash_bits > 64) hash_bits = 64;
+    if (hash_bits <= 0 || hash_bits > 64) {
+        // default: 2*log2(V) + 8 bits (multiple of the 8-bit radix digit, at least 32): a colliding
+        // pair then shows up in ~1/256 of the levels and is resolved exactly by the refine loop
+        int lg = bits_for((u64)(b->n_nodes > 1 ? b->n_nodes - 1 : 1));
+        hash_bits = ((2 * lg + 8 + 7) / 8) * 8;
+        if (hash_bits < 32) hash_bits = 32;
+        if (hash_bits > 64) hash_bits = 64;
+    }
     GK_HIP_CHECK(hipSetDevice(ctx->device));
     ProfScope prof(ctx, "relabel");
     const int n_levels = n_iter + 1;

@@ -317,3 +317,35 @@ def test_errors_match_reference(gk):
     from sklearn.exceptions import NotFittedError
     with pytest.raises(NotFittedError):
         gk.WeisfeilerLehman().transform([[{0: [1], 1: [0]}, {0: 1, 1: 2}]])
+
+
+def test_sharded_path_single_rank_matches_plain_path(gk):
+    """grakel_amd/dist.py end to end on one GPU: a 1-rank RCCL group exercises the all-gather,
+    the device-side CSR rebuild, gk_batch_create(src_on_device=1) and gk_gram_rows."""
+    import torch
+    import torch.distributed as dist
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.dist import ShardedWL
+    from grakel_amd.engine import get_engine
+    X = er_dataset(300, 30, 0.1, 4, 5)
+    K = gk.WeisfeilerLehman(n_iter=3).fit_transform(X)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        gb, _ = wl_batch_from_input(X)
+        Kr, info = ShardedWL(get_engine(), n_iter=3).step(gb, to_host=True)
+        assert info["rows"] == (0, 300) and np.array_equal(Kr, K)
+        # a row block (what rank r of R computes) equals the same rows of the full matrix
+        eng = get_engine()
+        db = eng.upload(gb)
+        eng.wl_relabel(db, 3)
+        feat = eng.features(db, 4)
+        assert np.array_equal(eng.gram(feat, 0, rows=(37, 211)), K[37:211])
+        Kn = gk.WeisfeilerLehman(n_iter=3, normalize=True).fit_transform(X)
+        assert np.allclose(eng.gram(feat, 2, rows=(100, 300)), Kn[100:300], rtol=REL_TOL, atol=0)
+    finally:
+        if created:
+            dist.destroy_process_group()
