@@ -67,6 +67,14 @@ def load():
         raise GkError("libgk_hip.so is not built (%s missing): run `python -c 'import "
                       "__graft_entry__ as g; g.build()'` or `make -C grakel_amd/csrc`. "
                       "There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if /opt/rocm's
+    # copy gets loaded first (through this library) a later `import torch` finds "No HIP GPUs".
+    # Importing torch first makes both share torch's runtime (measured on the MI355X box,
+    # tools/dbg_dist.py).  torch stays optional: without it the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the ABI lost a symbol

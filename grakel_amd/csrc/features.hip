@@ -13,6 +13,7 @@
 //      rectangular job : present in a fit graph (< n_fit) AND a target graph (>= n_fit)
 // HBM-bound integer work: ~16 bytes per node per level.
 #include "common.h"
+#include "scan_fn.h"
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
 
@@ -37,41 +38,42 @@ __global__ void feat_flags_kernel(const i32* __restrict__ perm, const i32* __res
     flag[k] = f;
 }
 
-__global__ void feat_emit_kernel(const i32* __restrict__ perm, const i32* __restrict__ node_graph,
-                                 const u64* __restrict__ flag, const u64* __restrict__ scan,
-                                 i32* __restrict__ tri_pos, i32* __restrict__ tri_graph,
-                                 i32* __restrict__ tri_run, i32* __restrict__ tstart,
-                                 u32* __restrict__ meta, int level, i64 n) {
-    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    u64 f = flag[k], s = scan[k];
-    i32 t = (i32)(u32)(s & 0xffffffffull) - 1;
-    i32 r = (i32)(u32)(s >> 32) - 1;
-    if (f & 1ull) {
-        tri_pos[t] = (i32)k;
-        tri_graph[t] = node_graph[perm[k]];
-        tri_run[t] = r;
+// packed (label-head, subrun-head) flags -> triple ids / run ids, triples emitted in the scan
+struct TripleEmit {
+    const i32* perm; const i32* node_graph; const u64* flag;
+    i32* tri_pos; i32* tri_graph; i32* tri_run; i32* tstart; u32* tri_of;   // tri_of[k] = triple of position k
+    u32* meta; int level; i64 n;
+    __device__ __forceinline__ u64 value(i64 k) const { return flag[k]; }
+    __device__ __forceinline__ void emit(i64 k, u64 f, u64 s) const {
+        const i32 t = (i32)(u32)(s & 0xffffffffull) - 1;
+        const i32 r = (i32)(u32)(s >> 32) - 1;
+        tri_of[k] = (u32)t;
+        if (f & 1ull) {
+            tri_pos[t] = (i32)k;
+            tri_graph[t] = node_graph[perm[k]];
+            tri_run[t] = r;
+        }
+        if (f >> 32) tstart[r] = t;
+        if (k == n - 1) {   // sentinels + counts
+            tri_pos[t + 1] = (i32)n;
+            tstart[r + 1] = t + 1;
+            meta[META_T(level)] = (u32)(t + 1);
+            meta[META_R(level)] = (u32)(r + 1);
+        }
     }
-    if (f >> 32) tstart[r] = t;
-    if (k == n - 1) {   // sentinels + counts
-        tri_pos[t + 1] = (i32)n;
-        tstart[r + 1] = t + 1;
-        meta[META_T(level)] = (u32)(t + 1);
-        meta[META_R(level)] = (u32)(r + 1);
-    }
-}
+};
 
 // per node: add the count of its (label,graph) triple to node_acc[v]; sum over the nodes of a
 // graph of these counts == sum over its triples of count^2, so the exact self similarity needs
 // no atomics (each node is written once per level).  Also tracks the largest count.
-__global__ void feat_count_kernel(const i32* __restrict__ perm, const u64* __restrict__ scan,
+__global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __restrict__ tri_of,
                                   const i32* __restrict__ tri_pos, u32* __restrict__ node_acc,
                                   u32* __restrict__ meta, int level, int n_levels, i64 n) {
     __shared__ u32 wmax[4];
     i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 c = 0;
     if (k < n) {
-        i32 t = (i32)(u32)(scan[k] & 0xffffffffull) - 1;
+        const i32 t = (i32)tri_of[k];
         c = (u32)(tri_pos[t + 1] - tri_pos[t]);
         i32 v = perm[k];
         node_acc[v] = (level == 0 ? 0u : node_acc[v]) + c;
@@ -102,27 +104,23 @@ __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* 
     if (lane == 0) selfk[g] = s;
 }
 
-__global__ void feat_colflag_kernel(const i32* __restrict__ tstart, const i32* __restrict__ tri_graph,
-                                    u32* __restrict__ flag, const u32* __restrict__ meta, int level,
-                                    int symmetric, i32 n_fit, i64 n) {
-    i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    u32 keep = 0;
-    if (r < (i64)meta[META_R(level)]) {
-        i32 t0 = tstart[r], t1 = tstart[r + 1];
-        if (symmetric) keep = (t1 - t0) >= 2;
-        else keep = (tri_graph[t0] < n_fit) && (tri_graph[t1 - 1] >= n_fit);
+// kept-column decision per label run -> compact column ids, fused into the prefix sum
+struct ColumnIds {
+    const i32* tstart; const i32* tri_graph; i32* colid; u32* meta; int level; int symmetric; i32 n_fit;
+    __device__ __forceinline__ u32 value(i64 r) const {
+        if (r >= (i64)meta[META_R(level)]) return 0u;
+        const i32 t0 = tstart[r], t1 = tstart[r + 1];
+        if (symmetric) return (t1 - t0) >= 2 ? 1u : 0u;
+        return (tri_graph[t0] < n_fit && tri_graph[t1 - 1] >= n_fit) ? 1u : 0u;
     }
-    flag[r] = keep;
-}
+    __device__ __forceinline__ void emit(i64 r, u32 keep, u32 incl) const {
+        const u32 base = level > 0 ? meta[META_C(level - 1)] : 0u;
+        colid[r] = keep ? (i32)(base + incl - 1) : -1;
+    }
+};
 
-__global__ void feat_colid_kernel(const u32* __restrict__ flag, const u32* __restrict__ excl,
-                                  const u32* __restrict__ total, i32* __restrict__ colid,
-                                  u32* __restrict__ meta, int level, i64 n) {
-    i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 base = level > 0 ? meta[META_C(level - 1)] : 0u;
-    if (r < n) colid[r] = flag[r] ? (i32)(base + excl[r]) : -1;
-    if (r == 0) meta[META_C(level)] = base + *total;
+__global__ void feat_colbase_kernel(u32* __restrict__ meta, const u32* __restrict__ total, int level) {
+    meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + *total;
 }
 
 template <typename T>
@@ -197,14 +195,13 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
         const i32* lab = b->labels + (size_t)l * V;
         const i32* perm = b->perm + (size_t)l * V;
         feat_flags_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, lab, b->node_graph, flag.p, V);
-        if ((r = gk_scan_u64(ctx, flag.p, scan.p, V, false, nullptr))) return fail(r);
-        feat_emit_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, b->node_graph, flag.p, scan.p, L.tri_pos,
-                                                                    L.tri_graph, L.tri_run, L.tstart, f->meta, l, V);
-        feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, scan.p, L.tri_pos, node_acc.p, f->meta, l, n_levels, V);
-        feat_colflag_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(L.tstart, L.tri_graph, cflag.p, f->meta, l,
-                                                                       f->symmetric ? 1 : 0, (i32)n_fit, V);
-        if ((r = gk_scan_u32(ctx, cflag.p, cexcl.p, V, true, ctotal.p))) return fail(r);
-        feat_colid_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(cflag.p, cexcl.p, ctotal.p, L.colid, f->meta, l, V);
+        TripleEmit te{perm, b->node_graph, flag.p, L.tri_pos, L.tri_graph, L.tri_run, L.tstart, cflag.p,
+                      f->meta, l, V};
+        if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, V, nullptr))) return fail(r);
+        feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, node_acc.p, f->meta, l, n_levels, V);
+        ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit};
+        if ((r = gk_scan_fn<u32, ColumnIds>(ctx, ci, V, ctotal.p))) return fail(r);
+        feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, ctotal.p, l);
     }
     if (V > 0)
         feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, node_acc.p, f->selfk, N);

@@ -12,6 +12,7 @@
 // K_ij / sqrt(K_ii K_jj) (weisfeiler_lehman.py:323-328, kernel.py:195-204).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -92,7 +93,7 @@ __device__ __forceinline__ bool gram_map_tile(int b, int tiles_m, int tiles_n, i
         bm = b / tiles_n, bn = b % tiles_n;
         return !(sym && bn < bm);
     }
-    const int P = GI_PATCH;
+    const int P = patch;
     const int pm = (tiles_m + P - 1) / P, pn = (tiles_n + P - 1) / P;
     const int xcd = b & 7, i = b >> 3;
     const int pid = (i / (P * P)) * 8 + xcd, t = i % (P * P);
@@ -114,7 +115,7 @@ __device__ __forceinline__ bool gram_map_tile(int b, int tiles_m, int tiles_n, i
 
 static inline i64 gram_grid_blocks(int tiles_m, int tiles_n, int sym, int patch) {
     if (!patch) return (i64)tiles_m * tiles_n;
-    const int P = GI_PATCH;
+    const int P = patch;
     const i64 pm = (tiles_m + P - 1) / P, pn = (tiles_n + P - 1) / P;
     const i64 np = sym ? (pm * pn - pm * (pm - 1) / 2) : pm * pn;   // sym: pm == pn
     return ((np + 7) / 8) * 8 * P * P;
@@ -191,90 +192,165 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// int8 path, pipelined: same 128x128 tile / 2x2 waves / 32x32x32 MFMA, but the operand tiles
-// go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write) into a
-// ring of GL_NS stages, with GL_NS-1 K-steps in flight across the per-step barrier
-// (counted s_waitcnt vmcnt, raw s_barrier).  The LDS image is linear per wave instruction
-// (16 rows x 64 B = 1 KiB), so the bank-conflict-free layout is obtained by XOR-swizzling the
-// 16-byte chunk index on the SOURCE address and on the fragment read:
+// int8 path, pipelined.  Operand tiles go L2 -> LDS directly (global_load_lds_dwordx4: no VGPR
+// round trip, no ds_write) into a ring of NS stages, NS-1 K-steps in flight across the per-step
+// barrier (counted s_waitcnt vmcnt, raw s_barrier).  The LDS image is linear per wave
+// instruction (16 rows x 64 B = 1 KiB), so the bank-conflict-free layout comes from
+// XOR-swizzling the 16-byte chunk index on the SOURCE address and on the fragment read:
 //      physical chunk = logical chunk ^ ((row >> 2) & 3)
 // which spreads every 16-lane ds_read_b128 group over all 16 slots of the 256-B bank row.
+// Measured: the L2->LDS path sustains ~11-14 TB/s chip-wide, so the operand bytes per MAC set
+// the ceiling -> the 256x256 tile (8 waves, 128x64 per wave) halves them versus 128x128.
+//   <WM,WN,TM,TN>: waves_m x waves_n, MFMA 32x32 tiles per wave; BM = WM*TM*32, BN = WN*TN*32.
+// Each wave stages (BM+BN)/(16*waves) = 4 sixteen-row pieces per K-step in both shapes.
 // ---------------------------------------------------------------------------------------
-#define GL_NS 4
-#define GL_STAGE 16384   // A 8 KiB + B 8 KiB
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-__global__ __launch_bounds__(256, 2) void gram_i8_glds_kernel(
+template <int WM, int WN, int TM, int TN, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
     int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch) {
-    extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // GL_NS * GL_STAGE, ONE array
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
+    constexpr int STAGE = (BM + BN) * 64;
+    constexpr int PPW = (BM + BN) / 16 / NW;                 // 1-KiB pieces per wave per stage
+    static_assert((BM + BN) % (16 * NW) == 0, "pieces must divide evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // NS * STAGE, ONE array
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     int bm, bn;
     if (!gram_map_tile(blockIdx.x, tiles_m, tiles_n, tri, patch, bm, bn)) return;
 
-    // this wave stages rows [wave*32, wave*32+32) of A and of B: two 1-KiB pieces each
-    const int srow = lane >> 2;                              // row inside the 16-row piece
+    // staging: piece q of this wave covers rows [16*(wave*PPW+q), +16) of the (A rows, B rows) list
+    const int srow = lane >> 2;                              // row inside the piece
     const int schunk = (lane & 3) ^ ((srow >> 2) & 3);       // logical chunk this lane fetches
-    const int8_t* gA = A + ((i64)bm * GI_BM + wave * 32 + srow) * ld + schunk * 16;
-    const int8_t* gB = B + ((i64)bn * GI_BN + wave * 32 + srow) * ld + schunk * 16;
-    const i64 g16 = 16 * ld;
-    const int piece = wave * 2048;                           // LDS offset of this wave's rows
+    const int8_t* gsrc[PPW];
+    int sdst[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int r0 = (wave * PPW + q) * 16;
+        if (r0 < BM) gsrc[q] = A + ((i64)bm * BM + r0 + srow) * ld + schunk * 16;
+        else gsrc[q] = B + ((i64)bn * BN + (r0 - BM) + srow) * ld + schunk * 16;
+        sdst[q] = r0 * 64;
+    }
 
-    v16i acc[2][2];
+    v16i acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-#define GL_ISSUE(KT)                                                                              \
-    {                                                                                             \
-        const i64 go = (i64)(KT) * GI_BK;                                                         \
-        int8_t* st = smem + ((KT) % GL_NS) * GL_STAGE + piece;                                    \
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(gA + go), (lds_void_t*)(st), 16, 0, 0);            \
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(gA + go + g16), (lds_void_t*)(st + 1024), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(gB + go), (lds_void_t*)(st + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(gB + go + g16), (lds_void_t*)(st + 8192 + 1024), 16, 0, 0); \
+#define GL_ISSUE(KT)                                                                        \
+    {                                                                                       \
+        const i64 go = (i64)(KT) * GI_BK;                                                   \
+        int8_t* st = smem + ((KT) % NS) * STAGE;                                            \
+        _Pragma("unroll") for (int q = 0; q < PPW; ++q)                                     \
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc[q] + go), (lds_void_t*)(st + sdst[q]), 16, 0, 0); \
     }
 
-    for (int p = 0; p < GL_NS - 1; ++p)
+    for (int p = 0; p < NS - 1; ++p)
         if (p < k_tiles) GL_ISSUE(p);
 
-    // fragment read offsets: row rr, logical chunk cl = 2*ks + (lane>>5), physical = cl ^ ((rr>>2)&3)
+    // fragment reads: row rr, logical chunk cl = 2*ks + (lane>>5), physical = cl ^ ((rr>>2)&3)
     const int fr = lane & 31, fh = lane >> 5;
-    const int ra0 = wm * 64 + fr, ra1 = ra0 + 32, rb0 = wn * 64 + fr, rb1 = rb0 + 32;
-    const int xa0 = (ra0 >> 2) & 3, xa1 = (ra1 >> 2) & 3, xb0 = (rb0 >> 2) & 3, xb1 = (rb1 >> 2) & 3;
+    int offa[TM][2], offb[TN][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rr = wm * TM * 32 + i * 32 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offa[i][ks] = rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int rr = wn * TN * 32 + j * 32 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offb[j][ks] = BM * 64 + rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
+    }
 
     for (int kt = 0; kt < k_tiles; ++kt) {
         // own loads of stage kt have landed when at most (stages in flight after kt) * 4 remain
         const int ahead = k_tiles - 1 - kt;
-        if (ahead >= GL_NS - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const int fly = ahead < NS - 2 ? ahead : NS - 2;
+        if (fly >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();        // everyone's pieces of stage kt are in LDS; stage kt-1 is free
-        if (kt + GL_NS - 1 < k_tiles) GL_ISSUE(kt + GL_NS - 1);
-        const int8_t* sa = smem + (kt % GL_NS) * GL_STAGE;
-        const int8_t* sb = sa + 8192;
+        if (kt + NS - 1 < k_tiles) GL_ISSUE(kt + NS - 1);
+        const int8_t* st = smem + (kt % NS) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int cl = 2 * ks + fh;
-            v4i a0 = *(const v4i*)(sa + ra0 * 64 + ((cl ^ xa0) << 4));
-            v4i a1 = *(const v4i*)(sa + ra1 * 64 + ((cl ^ xa1) << 4));
-            v4i b0 = *(const v4i*)(sb + rb0 * 64 + ((cl ^ xb0) << 4));
-            v4i b1 = *(const v4i*)(sb + rb1 * 64 + ((cl ^ xb1) << 4));
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+            v4i af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const v4i*)(st + offa[i][ks]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const v4i*)(st + offb[j][ks]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
 #undef GL_ISSUE
-    GRAM_I8_EPILOGUE
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool mirror = tri && bm != bn;     // off-diagonal tile of a symmetric job: also write K^T
+    const bool even = (N & 1) == 0;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const i64 col = (i64)bn * BN + (wn * TN + nt) * 32 + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i64 row0 = (i64)bm * BM + (wm * TM + mt) * 32 + 8 * q + 4 * (lane >> 5);
+                double v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i64 row = row0 + j;
+                    v[j] = 0.0;
+                    if (row < M && col < N) {
+                        v[j] = finish_entry((double)acc[mt][nt][4 * q + j], row_base + row, col,
+                                            symmetric != 0, selfk, n_fit, normalize);
+                        K[row * N + col] = v[j];           // 32 lanes -> 256 contiguous bytes
+                    }
+                }
+                if (mirror && col < N) {                    // K[col][row0..row0+3]: 32 B per lane
+                    double* dst = K + col * N + row0;
+                    if (even && row0 + 3 < M) {
+                        *(double2*)(dst) = make_double2(v[0], v[1]);
+                        *(double2*)(dst + 2) = make_double2(v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (row0 + j < M) dst[j] = v[j];
+                    }
+                }
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN, int NS>
+static int launch_glds(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
+                       i64 row_lo, int normalize, double* K, int tri, int patch, int patch_sz, double* tiles_done) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LDS = NS * (BM + BN) * 64;
+    static bool attr_set = false;
+    auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
+    if (!attr_set) {
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(n_cols, BN);
+    const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch ? patch_sz : 0);
+    kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
+        a, b, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
+        f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0);
+    *tiles_done = tri ? (double)tiles_m * (tiles_m + 1) / 2 * BM * BN : (double)M * n_cols;
+    return GK_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -356,29 +432,27 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     GK_HIP_CHECK(hipEventCreate(&e0));
     GK_HIP_CHECK(hipEventCreate(&e1));
     GK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    double tiles_done = (double)M * n_cols;
     if (f->dtype == 0) {
         const int8_t* phi = (const int8_t*)f->phi;
-        const int tiles_m = (int)cdiv(M, GI_BM), tiles_n = (int)cdiv(n_cols, GI_BN);
+        const int8_t* pa = phi + first_row_graph * f->n_cols_pad;
         // full symmetric job: only tiles on/above the diagonal are computed, each written twice
         const int tri = (f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
         const int patch = getenv("GK_GRAM_NO_PATCH") ? 0 : 1;
-        const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch);
+        const char* shape = getenv("GK_GRAM_TILE");
         if (getenv("GK_GRAM_V1")) {
+            const int tiles_m = (int)cdiv(M, GI_BM), tiles_n = (int)cdiv(n_cols, GI_BN);
+            const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch ? GI_PATCH : 0);
             gram_i8_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(
-                phi + first_row_graph * f->n_cols_pad, phi, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK),
-                f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n,
-                tri, patch);
+                pa, phi, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
+                f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? GI_PATCH : 0);
+            if (tri) tiles_done = (double)tiles_m * (tiles_m + 1) / 2 * GI_BM * GI_BN;
+        } else if (shape && !strcmp(shape, "128")) {
+            GK_TRY((launch_glds<2, 2, 2, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
+        } else if (shape && !strcmp(shape, "256x128")) {
+            GK_TRY((launch_glds<4, 2, 2, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
         } else {
-            static bool attr_set = false;
-            if (!attr_set) {
-                GK_HIP_CHECK(hipFuncSetAttribute((const void*)gram_i8_glds_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, GL_NS * GL_STAGE));
-                attr_set = true;
-            }
-            gram_i8_glds_kernel<<<dim3((unsigned)blocks), dim3(256), GL_NS * GL_STAGE, ctx->stream>>>(
-                phi + first_row_graph * f->n_cols_pad, phi, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK),
-                f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n,
-                tri, patch);
+            GK_TRY((launch_glds<2, 4, 4, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
         }
     } else {
         const double* phi = (const double*)f->phi;
@@ -395,12 +469,8 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     f->last_ms = ms;
-    f->last_flops = 2.0 * (double)M * (double)n_cols * (double)f->n_cols;
-    if (f->dtype == 0 && f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) {
-        // only tiles on/above the diagonal were executed: count the work actually done
-        const double t = (double)cdiv(M, GI_BM);
-        f->last_flops = 2.0 * (t * (t + 1) / 2) * GI_BM * GI_BN * (double)f->n_cols;
-    }
+    // work actually executed: symmetric jobs only run the tiles on/above the diagonal
+    f->last_flops = 2.0 * tiles_done * (double)f->n_cols;
     return GK_OK;
 }
 

@@ -1,0 +1,95 @@
+// Prefix sum over values produced on the fly by a functor, with the consumer fused in:
+//     struct F { __device__ T value(i64 i) const;  __device__ void emit(i64 i, T v, T inclusive) const; };
+// Two kernels (tile sums, then apply-with-direct-offset as in scan_sort.hip); no flag / scan
+// arrays ever touch HBM.  Used for run-head -> label id, triple emission and column ids.
+#pragma once
+#include "common.h"
+
+#define SF_THREADS 256
+#define SF_ITEMS 8
+#define SF_TILE (SF_THREADS * SF_ITEMS)
+
+template <typename T>
+__device__ __forceinline__ T sf_wave_incl_scan(T x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        T y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    return x;
+}
+
+template <typename T, typename F>
+__global__ __launch_bounds__(SF_THREADS) void scan_fn_sums_kernel(F f, T* __restrict__ partial, i64 n) {
+    __shared__ T wsum[SF_THREADS / 64];
+    const i64 base = (i64)blockIdx.x * SF_TILE;
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < SF_ITEMS; ++i) {
+        const i64 idx = base + (i64)i * SF_THREADS + threadIdx.x;   // striped: coalesced
+        if (idx < n) s += f.value(idx);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T t = 0;
+        for (int i = 0; i < SF_THREADS / 64; ++i) t += wsum[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// Striped tile: in row i thread t owns element tile0 + i*256 + t, so value()/emit() of a wave
+// touch 64 consecutive elements (coalesced gathers/scatters in the functors).  One block-wide
+// scan per row; the carry links the rows.
+template <typename T, typename F>
+__global__ __launch_bounds__(SF_THREADS) void scan_fn_apply_kernel(F f, const T* __restrict__ partial, i64 n,
+                                                                   T* __restrict__ total) {
+    __shared__ T wsum[SF_THREADS / 64];
+    __shared__ T bsum[SF_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T s = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SF_THREADS) s += partial[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) bsum[w] = s;
+    __syncthreads();
+    T carry = 0;
+    for (int q = 0; q < SF_THREADS / 64; ++q) carry += bsum[q];
+    const i64 tile0 = (i64)blockIdx.x * SF_TILE;
+#pragma unroll
+    for (int i = 0; i < SF_ITEMS; ++i) {
+        const i64 idx = tile0 + (i64)i * SF_THREADS + threadIdx.x;
+        const T v = idx < n ? f.value(idx) : (T)0;
+        const T inc = sf_wave_incl_scan(v);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        T woff = 0, row = 0;
+#pragma unroll
+        for (int q = 0; q < SF_THREADS / 64; ++q) {
+            const T x = wsum[q];
+            if (q < w) woff += x;
+            row += x;
+        }
+        if (idx < n) f.emit(idx, v, carry + woff + inc);
+        carry += row;
+        __syncthreads();
+    }
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = carry;
+}
+
+// total (device, may be null) receives the grand total.  n == 0: total = 0.
+template <typename T, typename F>
+static int gk_scan_fn(gk_ctx* ctx, const F& f, i64 n, T* total) {
+    if (n <= 0) {
+        if (total) GK_TRY(gk_zero_async(ctx, total, sizeof(T)));
+        return GK_OK;
+    }
+    const i64 nblk = cdiv(n, SF_TILE);
+    Tmp<T> partial(ctx);
+    GK_TRY(partial.alloc(nblk));
+    scan_fn_sums_kernel<T, F><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n);
+    scan_fn_apply_kernel<T, F><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n, total);
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
+}

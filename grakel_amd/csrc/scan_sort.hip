@@ -179,80 +179,96 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const u64* __res
     hist[(i64)tid * nblk + blockIdx.x] = h[tid];
 }
 
+// Stable scatter of one 2048-key tile.  Keys are taken in index order: round r, thread t holds
+// key tile0 + r*256 + t.  Phase 1: for every (round, wave) the lanes with equal digits find
+// each other with 8 ballots; the lowest lane of a group records the group size in
+// cnt[r][w][digit] and every lane keeps its rank inside the group.  Phase 2: thread d turns the
+// 32 counts of digit d into exclusive offsets in (round, wave) order -- exactly the order the
+// keys must keep.  Phase 3: position = global base[d] + offset[r][w][d] + rank.  Three barriers
+// per tile instead of four per round.
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
     u32* __restrict__ vout, i64 n, int shift, const u32* __restrict__ offs, int nblk) {
-    __shared__ u32 gbase[256];
-    __shared__ u32 wcnt[RS_THREADS / 64][256];
+    constexpr int NWAVE = RS_THREADS / 64;
+    __shared__ u32 cnt[RS_ROUNDS * NWAVE * 256];     // 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    gbase[tid] = offs[(i64)tid * nblk + blockIdx.x];
-    u32 running = 0;   // keys of digit `tid` already placed by this block
     const i64 tile0 = (i64)blockIdx.x * RS_TILE;
-    for (int r = 0; r < RS_ROUNDS; ++r) {
-        i64 idx = tile0 + r * RS_THREADS + tid;
-        bool act = idx < n;
-        u64 key = act ? kin[idx] : 0ull;
-        u32 val = act ? vin[idx] : 0u;
-        u32 d = (u32)(key >> shift) & 255u;
+    u64 key[RS_ROUNDS];
+    u32 val[RS_ROUNDS], rank[RS_ROUNDS];
 #pragma unroll
-        for (int q = 0; q < RS_THREADS / 64; ++q) wcnt[q][tid] = 0;
-        __syncthreads();
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const i64 idx = tile0 + r * RS_THREADS + tid;
+        const bool act = idx < n;
+        key[r] = act ? kin[idx] : 0ull;
+        val[r] = act ? (vin ? vin[idx] : (u32)idx) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < RS_ROUNDS * NWAVE; ++q) cnt[q * 256 + tid] = 0;
+    __syncthreads();
+    const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const bool act = tile0 + r * RS_THREADS + tid < n;
+        const u32 d = (u32)(key[r] >> shift) & 255u;
         u64 m = __ballot(act);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            bool bit = (d >> b) & 1u;
-            u64 bb = __ballot(act && bit);
+            const bool bit = (d >> b) & 1u;
+            const u64 bb = __ballot(act && bit);
             m &= bit ? bb : ~bb;
         }
-        u32 rank = (u32)__popcll(m & ((1ull << lane) - 1ull));
-        u32 cnt = (u32)__popcll(m);
-        if (act && rank == 0) wcnt[w][d] = cnt;
-        __syncthreads();
-        {
-            u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-            wcnt[0][tid] = running;
-            wcnt[1][tid] = running + c0;
-            wcnt[2][tid] = running + c0 + c1;
-            wcnt[3][tid] = running + c0 + c1 + c2;
-            running += c0 + c1 + c2 + c3;
+        rank[r] = (u32)__popcll(m & lt);
+        if (act && rank[r] == 0) cnt[(r * NWAVE + w) * 256 + d] = (u32)__popcll(m);
+    }
+    __syncthreads();
+    {
+        u32 run = offs[(i64)tid * nblk + blockIdx.x];    // global base of digit `tid` for this tile
+#pragma unroll
+        for (int q = 0; q < RS_ROUNDS * NWAVE; ++q) {
+            const u32 c = cnt[q * 256 + tid];
+            cnt[q * 256 + tid] = run;
+            run += c;
         }
-        __syncthreads();
-        if (act) {
-            u32 pos = gbase[d] + wcnt[w][d] + rank;
-            kout[pos] = key;
-            vout[pos] = val;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        if (tile0 + r * RS_THREADS + tid < n) {
+            const u32 d = (u32)(key[r] >> shift) & 255u;
+            const u32 pos = cnt[(r * NWAVE + w) * 256 + d] + rank[r];
+            kout[pos] = key[r];
+            vout[pos] = val[r];
         }
-        __syncthreads();
     }
 }
 
 int gk_radix_sort_pairs(gk_ctx* ctx, u64* keys_in, u32* vals_in, u64* keys_out, u32* vals_out,
-                        i64 n, int key_bits) {
+                        i64 n, int key_bits, bool implicit_iota) {
     // Result always lands in keys_out/vals_out; keys_in/vals_in are scratch afterwards.
     if (n <= 0) return GK_OK;
     if (key_bits < 0) key_bits = 0;
     if (key_bits > 64) key_bits = 64;
     int passes = (key_bits + 7) / 8;
-    if (passes == 0) {
-        GK_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
-        GK_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
-        return GK_OK;
-    }
+    if (passes == 0) passes = 1;   // nothing to distinguish: one (trivial) pass keeps the code paths uniform
     int nblk = (int)cdiv(n, RS_TILE);
     Tmp<u32> hist(ctx);
     GK_TRY(hist.alloc((size_t)256 * nblk));
     u64 *ks = keys_in, *kd = keys_out;
     u32 *vs = vals_in, *vd = vals_out;
+    // vals_in may be null on entry: the values are then the indices 0..n-1 (implicit iota);
+    // vals_scratch is the ping-pong partner of vals_out in that case
     if ((passes & 1) == 0) {   // even number of passes: start from the out buffers
         GK_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
-        GK_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+        if (vals_in && !implicit_iota)
+            GK_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
         ks = keys_out, kd = keys_in, vs = vals_out, vd = vals_in;
     }
     for (int p = 0; p < passes; ++p) {
         int shift = p * 8;
         radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, n, shift, hist.p, nblk);
         GK_TRY(gk_scan_u32(ctx, hist.p, hist.p, (i64)256 * nblk, true, nullptr));
-        radix_scatter_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, vs, kd, vd, n, shift, hist.p, nblk);
+        radix_scatter_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(
+            ks, (implicit_iota && p == 0) ? nullptr : vs, kd, vd, n, shift, hist.p, nblk);
         u64* tk = ks; ks = kd; kd = tk;
         u32* tv = vs; vs = vd; vd = tv;
     }

@@ -14,6 +14,7 @@
 //                        groups with re-seeded hashes until no mismatch is left.
 // HBM-bound integer work: algorithmic bytes per level 8E + 12V.
 #include "common.h"
+#include "scan_fn.h"
 
 #define WL_DEG_SMALL 32       // nodes up to this degree: one thread sorts its list in LDS
 #define SIG_THREADS 256
@@ -174,22 +175,20 @@ __global__ void refine_keys_kernel(const i32* __restrict__ lab_round, const u64*
     if (i < n) keys[i] = ((u64)(u32)lab_round[i] << 32) | (hash[i] & 0xffffffffull);
 }
 
-__global__ void head_flags_kernel(const u64* __restrict__ ks, u32* __restrict__ flag, i64 n) {
-    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) flag[k] = (k == 0 || ks[k] != ks[k - 1]) ? 1u : 0u;
-}
-
-__global__ void assign_labels_kernel(const u32* __restrict__ perm, const u32* __restrict__ flag,
-                                     const u32* __restrict__ scan_incl, i32* __restrict__ lab,
-                                     i32* __restrict__ rep, i64 n) {
-    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) {
-        u32 v = perm[k];
-        i32 r = (i32)scan_incl[k] - 1;
+// run heads of the sorted keys -> dense label ids, fused into the prefix sum (scan_fn.h)
+struct HeadAssign {
+    const u64* ks;     // sorted keys
+    const u32* perm;   // node at each sorted position
+    i32* lab;          // out: lab[node] = run index
+    i32* rep;          // out: rep[run]  = first node of the run
+    __device__ __forceinline__ u32 value(i64 k) const { return (k == 0 || ks[k] != ks[k - 1]) ? 1u : 0u; }
+    __device__ __forceinline__ void emit(i64 k, u32 head, u32 incl) const {
+        const u32 v = perm[k];
+        const i32 r = (i32)incl - 1;
         lab[v] = r;
-        if (flag[k]) rep[r] = (i32)v;
+        if (head) rep[r] = (i32)v;
     }
-}
+};
 
 __global__ void verify_kernel(const i32* __restrict__ row_ptr, const i32* __restrict__ lab_prev,
                               const i32* __restrict__ nbr_sorted, const i32* __restrict__ lab,
@@ -224,11 +223,19 @@ __global__ void batch_stats_kernel(const i32* __restrict__ graph_ptr, const i32*
                                    i64 n_graphs, i64 n_nodes, u32* __restrict__ big_flag,
                                    i32* __restrict__ stats /* [0]=max graph nodes [1]=max degree */) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_graphs) atomicMax(&stats[0], graph_ptr[i + 1] - graph_ptr[i]);
+    int gn = 0, d = 0;
+    if (i < n_graphs) gn = graph_ptr[i + 1] - graph_ptr[i];
     if (i < n_nodes) {
-        int d = row_ptr[i + 1] - row_ptr[i];
-        atomicMax(&stats[1], d);
+        d = row_ptr[i + 1] - row_ptr[i];
         big_flag[i] = d > WL_DEG_SMALL ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) {     // one atomic per wave, and only when it can win
+        int o = __shfl_down(gn, off, 64); gn = o > gn ? o : gn;
+        o = __shfl_down(d, off, 64); d = o > d ? o : d;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (gn > stats[0]) atomicMax(&stats[0], gn);
+        if (d > stats[1]) atomicMax(&stats[1], d);
     }
 }
 
@@ -375,16 +382,13 @@ static int dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32
         return GK_OK;
     }
     Tmp<u64> ks(ctx);
-    Tmp<u32> iota(ctx), flag(ctx), scan(ctx);
-    GK_TRY(ks.alloc(n)); GK_TRY(iota.alloc(n)); GK_TRY(flag.alloc(n)); GK_TRY(scan.alloc(n));
-    iota_u32_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(iota.p, n);
-    GK_TRY(gk_radix_sort_pairs(ctx, keys, iota.p, ks.p, (u32*)perm, n, key_bits));
-    head_flags_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(ks.p, flag.p, n);
-    GK_TRY(gk_scan_u32(ctx, flag.p, scan.p, n, false, count_dev));
+    Tmp<u32> vscratch(ctx);
+    GK_TRY(ks.alloc(n)); GK_TRY(vscratch.alloc(n));
+    GK_TRY(gk_radix_sort_pairs(ctx, keys, vscratch.p, ks.p, (u32*)perm, n, key_bits, true));
     Tmp<i32> rep_tmp(ctx);
     if (!rep) { GK_TRY(rep_tmp.alloc(n)); rep = rep_tmp.p; }
-    assign_labels_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>((const u32*)perm, flag.p, scan.p, lab, rep, n);
-    GK_HIP_CHECK(hipGetLastError());
+    HeadAssign ha{ks.p, (const u32*)perm, lab, rep};
+    GK_TRY((gk_scan_fn<u32, HeadAssign>(ctx, ha, n, count_dev)));
     return GK_OK;
 }
 

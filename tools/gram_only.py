@@ -13,7 +13,7 @@ eng.wl_relabel(db, 5)
 feat = eng.features(db, 6)
 print("cols", feat.n_cols, "dtype", feat.dtype)
 ref = None
-variants = [dict(), dict(GK_GRAM_NO_SYM="1"), dict(GK_GRAM_NO_PATCH="1"), dict(GK_GRAM_NO_SYM="1", GK_GRAM_NO_PATCH="1")]
+variants = [dict()]
 variants += [dict(x.split("=") for x in v.split(",")) for v in sys.argv[2:]]
 for env in variants:
     for k in list(os.environ):
