@@ -29,6 +29,11 @@ sys.path.insert(0, ROOT)
 WORKLOAD = dict(N=10000, n=100, p=0.05, L=5, seed=0, n_iter=5)
 I8_DENSE_PEAK_TOPS = 5000.0      # int8 MFMA dense = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6
+# HBM-side bytes per launch of the Gram kernel on this exact workload, from the PMC passes
+# committed in profiles/r01_pmc_hbm_bytes.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in
+# separate runs): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md
+# "HBM") + WRITE_SIZE, KiB -> bytes.  Algorithmic floor: read Phi_s once (197 MB) + write K (800 MB).
+GRAM_PMC_TRAFFIC_BYTES = {(10000, "i8"): (2 * 1078133.1 + 798720.5) * 1024}
 
 
 def cpu_baseline(sample_graphs, cfg):
@@ -52,7 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graphs", type=int, default=WORKLOAD["N"], help="(debug) smaller workload")
-    ap.add_argument("--cpu-sample", type=int, default=1500)
+    ap.add_argument("--cpu-sample", type=int, default=4500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -165,7 +170,8 @@ def main():
             "roofline": {
                 "kernel": "gram_i8_glds_kernel" if dtype == "i8" else "gram_f64_kernel",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": None,
+                "frac": achieved / peak,
+                "traffic": GRAM_PMC_TRAFFIC_BYTES.get((N, dtype)) if world == 1 else None,
                 "note": "achieved = integer ops EXECUTED per launch / avg HIP-event duration of the launch; "
                         "1 GPU: only the 128x128 tiles on/above the diagonal are computed "
                         "(2*128*128*D_kept ops each, mirrored on store); N GPUs: each rank computes its "

@@ -15,6 +15,7 @@
 // HBM-bound integer work: algorithmic bytes per level 8E + 12V.
 #include "common.h"
 #include "scan_fn.h"
+#include <stdlib.h>
 
 #define WL_DEG_SMALL 32       // nodes up to this degree: one thread sorts its list in LDS
 #define SIG_THREADS 256
@@ -181,14 +182,92 @@ struct HeadAssign {
     const u32* perm;   // node at each sorted position
     i32* lab;          // out: lab[node] = run index
     i32* rep;          // out: rep[run]  = first node of the run
+    u32* frozen;       // out (may be null): 1 when the node's class is a singleton
+    i64 n;
     __device__ __forceinline__ u32 value(i64 k) const { return (k == 0 || ks[k] != ks[k - 1]) ? 1u : 0u; }
     __device__ __forceinline__ void emit(i64 k, u32 head, u32 incl) const {
         const u32 v = perm[k];
         const i32 r = (i32)incl - 1;
         lab[v] = r;
         if (head) rep[r] = (i32)v;
+        if (frozen) frozen[v] = (head && (k == n - 1 || ks[k + 1] != ks[k])) ? 1u : 0u;
     }
 };
+
+// A node whose class is a singleton stays a singleton at every later level (classes only
+// split), so it needs no signature, no sort and no verification any more: it just receives a
+// fresh id.  ActiveScan compacts the still-active nodes (ascending) and numbers the frozen.
+struct ActiveScan {
+    const u32* frozen; u32* act; u32* fidx;
+    __device__ __forceinline__ u32 value(i64 v) const { return frozen[v] ? 0u : 1u; }
+    __device__ __forceinline__ void emit(i64 v, u32 a, u32 incl) const {
+        if (a) { act[incl - 1] = (u32)v; fidx[v] = 0xffffffffu; }
+        else fidx[v] = (u32)v - incl;             // rank among the frozen nodes
+    }
+};
+
+__global__ void frozen_assign_kernel(const u32* __restrict__ fidx, const u32* __restrict__ ra_dev,
+                                     i32* __restrict__ lab, i32* __restrict__ perm,
+                                     u32* __restrict__ count_out, u32 n_active, i64 n) {
+    i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 ra = *ra_dev;
+    if (v < n) {
+        const u32 f = fidx[v];
+        if (f != 0xffffffffu) {
+            lab[v] = (i32)(ra + f);
+            perm[n_active + f] = (i32)v;
+        }
+    }
+    if (v == 0) *count_out = ra + (u32)(n - n_active);
+}
+
+// signature of the listed (active, degree <= WL_DEG_SMALL) nodes: one thread per node, the
+// neighbour list is gathered and sorted in the global scratch (few nodes: not worth staging)
+__global__ void wl_signature_list_kernel(const u32* __restrict__ act, i64 n_act,
+                                         const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
+                                         const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted,
+                                         u64* __restrict__ hash_out, u64 seed, u64 mask) {
+    i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_act) return;
+    const u32 v = act[j];
+    const i32 s = row_ptr[v];
+    const int d = row_ptr[v + 1] - s;
+    if (d > WL_DEG_SMALL) return;               // hubs: wl_signature_big_kernel (writes hash_node[v])
+    i32* x = nbr_sorted + s;
+    for (int k = 0; k < d; ++k) x[k] = lab_prev[col_idx[s + k]];
+    insertion_sort(x, d);
+    u64 acc = sig_head((u32)lab_prev[v], (u32)d, seed);
+    for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+    hash_out[j] = mix64(acc) & mask;
+}
+
+// hubs write their hash indexed by node: move it to the active-list slot
+__global__ void gather_big_hash_kernel(const u32* __restrict__ act, i64 n_act, const i32* __restrict__ row_ptr,
+                                       const u64* __restrict__ hash_node, u64* __restrict__ hash_out) {
+    i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_act) return;
+    const u32 v = act[j];
+    if (row_ptr[v + 1] - row_ptr[v] > WL_DEG_SMALL) hash_out[j] = hash_node[v];
+}
+
+__global__ void verify_list_kernel(const u32* __restrict__ act, i64 n_act, const i32* __restrict__ row_ptr,
+                                   const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
+                                   const i32* __restrict__ lab, const i32* __restrict__ rep,
+                                   u32* __restrict__ unresolved) {
+    i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_act) return;
+    const i32 v = (i32)act[j];
+    const i32 r = rep[lab[v]];
+    if (r == v) return;
+    bool ok = lab_prev[v] == lab_prev[r];
+    const i32 s = row_ptr[v], sr = row_ptr[r];
+    const int d = row_ptr[v + 1] - s;
+    ok = ok && (d == row_ptr[r + 1] - sr);
+    if (ok)
+        for (int k = 0; k < d; ++k)
+            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+    if (!ok) atomicAdd(unresolved, 1u);
+}
 
 __global__ void verify_kernel(const i32* __restrict__ row_ptr, const i32* __restrict__ lab_prev,
                               const i32* __restrict__ nbr_sorted, const i32* __restrict__ lab,
@@ -375,19 +454,23 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
 // Sort (key,node) pairs, turn equal-key groups into dense ids. keys[] is clobbered.
 // Writes lab[node], perm[] (nodes in key order, ascending node inside a group), rep[id]
 // (may be null) and the number of groups to *count_dev.
+// vals == nullptr: the items are 0..n-1; otherwise vals[] (ascending node ids, clobbered) are
+// the items and lab/rep/frozen are indexed by item id, perm receives item ids.
 static int dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
-                                i32* rep, u32* count_dev) {
+                                i32* rep, u32* count_dev, u32* vals = nullptr, u32* frozen = nullptr,
+                                i64 rep_capacity = 0) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         return GK_OK;
     }
     Tmp<u64> ks(ctx);
     Tmp<u32> vscratch(ctx);
-    GK_TRY(ks.alloc(n)); GK_TRY(vscratch.alloc(n));
-    GK_TRY(gk_radix_sort_pairs(ctx, keys, vscratch.p, ks.p, (u32*)perm, n, key_bits, true));
+    GK_TRY(ks.alloc(n));
+    if (!vals) GK_TRY(vscratch.alloc(n));
+    GK_TRY(gk_radix_sort_pairs(ctx, keys, vals ? vals : vscratch.p, ks.p, (u32*)perm, n, key_bits, vals == nullptr));
     Tmp<i32> rep_tmp(ctx);
-    if (!rep) { GK_TRY(rep_tmp.alloc(n)); rep = rep_tmp.p; }
-    HeadAssign ha{ks.p, (const u32*)perm, lab, rep};
+    if (!rep) { GK_TRY(rep_tmp.alloc(rep_capacity > n ? rep_capacity : n)); rep = rep_tmp.p; }
+    HeadAssign ha{ks.p, (const u32*)perm, lab, rep, frozen, n};
     GK_TRY((gk_scan_fn<u32, HeadAssign>(ctx, ha, n, count_dev)));
     return GK_OK;
 }
@@ -397,18 +480,75 @@ int gk_dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32* la
     return dictionary_from_keys(ctx, keys, n, key_bits, lab, perm, nullptr, count_dev);
 }
 
-static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, bool exact,
+struct RelabelState {
+    Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active
+    i64 n_frozen_levels = 0;
+    explicit RelabelState(gk_ctx* c) : frozen(c), act(c), fidx(c), scratch(c) {}
+};
+
+static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, bool exact, RelabelState& st,
                          u32* count_dev, u32* unresolved_dev, int* rounds) {
     const i64 V = b->n_nodes;
     const i32* prev = b->labels + (size_t)(level - 1) * V;
     i32* cur = b->labels + (size_t)level * V;
     i32* perm = b->perm + (size_t)level * V;
+    if (V == 0) return GK_OK;
+    // ---- how many nodes still sit in classes of size >= 2 ? (one 4-byte read-back per level)
+    u32 n_act = (u32)V;
+    if (!exact && !getenv("GK_WL_NO_ACTIVE_SET")) {
+        ActiveScan as{st.frozen.p, st.act.p, st.fidx.p};
+        GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, st.scratch.p + 1)));
+        GK_HIP_CHECK(hipMemcpyAsync(&n_act, st.scratch.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    const u64 full_mask = hash_bits >= 64 ? ~0ull : ((1ull << hash_bits) - 1ull);
+    if (n_act == 0) {
+        // every class is a singleton: the partition cannot change any more
+        GK_HIP_CHECK(hipMemcpyAsync(cur, prev, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(perm, perm - V, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(count_dev, count_dev - 1, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return GK_OK;
+    }
+    if (!exact && (u64)n_act * 4 <= (u64)V) {
+        // ---- active-set path: only the n_act active nodes are hashed, sorted and verified
+        int bits = hash_bits;
+        if (hash_bits >= 32) {   // default sizing rule applied to the active set (tests may force fewer bits)
+            int lg = bits_for((u64)(n_act > 1 ? n_act - 1 : 1));
+            bits = ((2 * lg + 8 + 7) / 8) * 8;
+            if (bits < 32) bits = 32;
+            if (bits > hash_bits) bits = hash_bits;
+        }
+        const u64 mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+        Tmp<u64> hash_act(ctx), hash_node(ctx);
+        Tmp<i32> rep(ctx);
+        GK_TRY(hash_act.alloc(n_act)); GK_TRY(rep.alloc(n_act));
+        const u64 seed = level_seed(level, 0);
+        wl_signature_list_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(
+            st.act.p, n_act, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_act.p, seed, mask);
+        if (b->n_big > 0) {
+            GK_TRY(hash_node.alloc(V));
+            wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
+                b->big_nodes, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_node.p, seed, mask);
+            gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act.p, n_act, b->row_ptr, hash_node.p, hash_act.p);
+        }
+        // act[] is consumed by the sort (values ping-pong): keep a copy for verify
+        Tmp<u32> act_copy(ctx);
+        GK_TRY(act_copy.alloc(n_act));
+        GK_HIP_CHECK(hipMemcpyAsync(act_copy.p, st.act.p, (size_t)n_act * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act.p, st.frozen.p));
+        frozen_assign_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V);
+        GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
+        verify_list_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(act_copy.p, n_act, b->row_ptr, prev, b->nbr_sorted,
+                                                                           cur, rep.p, unresolved_dev);
+        GK_HIP_CHECK(hipGetLastError());
+        return GK_OK;
+    }
+    // ---- full path
     Tmp<u64> hash(ctx), keys(ctx);
     Tmp<i32> rep(ctx);
     GK_TRY(hash.alloc(V)); GK_TRY(keys.alloc(V)); GK_TRY(rep.alloc(V));
-    const u64 mask = hash_bits >= 64 ? ~0ull : ((1ull << hash_bits) - 1ull);
     for (int round = 0;; ++round) {
-        GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), mask));
+        GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), full_mask));
         int bits;
         if (round == 0) {
             GK_HIP_CHECK(hipMemcpyAsync(keys.p, hash.p, V * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
@@ -417,7 +557,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             refine_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(cur, hash.p, keys.p, V);
             bits = 64;
         }
-        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, cur, perm, rep.p, count_dev));
+        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p));
         GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
         GK_HIP_CHECK(hipGetLastError());
@@ -457,6 +597,8 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     GK_TRY(meta.alloc(2 * (size_t)n_levels));
     GK_TRY(gk_zero_async(ctx, meta.p, 8 * (size_t)n_levels));
     if (out_rounds) *out_rounds = 0;
+    RelabelState st(ctx);
+    GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
     // level 0: group nodes by the given label ids
     {
         Tmp<u64> keys(ctx);
@@ -464,19 +606,19 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         GK_TRY(keys.alloc(V)); GK_TRY(lab_tmp.alloc(V));
         if (V > 0) labels_to_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels, keys.p, V);
         int bits = bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0);
-        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p));
+        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p));
     }
     std::vector<u32> h(2 * (size_t)n_levels);
     int first_bad = -1;
     for (int lvl = 1; lvl < n_levels; ++lvl)
-        GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, meta.p + lvl, meta.p + n_levels + lvl, nullptr));
+        GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, st, meta.p + lvl, meta.p + n_levels + lvl, nullptr));
     GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 8 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int lvl = 1; lvl < n_levels; ++lvl)
         if (h[n_levels + lvl] != 0) { first_bad = lvl; break; }
     if (first_bad > 0) {   // a hash collision was detected: redo from that level, exactly
         for (int lvl = first_bad; lvl < n_levels; ++lvl)
-            GK_TRY(relabel_level(ctx, b, lvl, hash_bits, true, meta.p + lvl, meta.p + n_levels + lvl, out_rounds));
+            GK_TRY(relabel_level(ctx, b, lvl, hash_bits, true, st, meta.p + lvl, meta.p + n_levels + lvl, out_rounds));
         GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 8 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
