@@ -14,6 +14,7 @@
 // HBM-bound integer work: ~16 bytes per node per level.
 #include "common.h"
 #include "scan_fn.h"
+#include <stdlib.h>
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
 
@@ -104,23 +105,35 @@ __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* 
     if (lane == 0) selfk[g] = s;
 }
 
-// kept-column decision per label run -> compact column ids, fused into the prefix sum
+// Column classes per label run, fused into the prefix sum:
+//   dense (colid >= 0) : occurs in >= low_df graphs -> a column of the MFMA operand Phi_s
+//   low   (colid = -2) : useful but rare (df < low_df): its df*(df-1) pair products are added
+//                        to K by gram_low_kernel after the GEMM -- a column with df graphs
+//                        costs N^2 MACs in the dense product but only df^2 updates here
+//   dead  (colid = -1) : cannot touch an off-diagonal entry (graph-unique / one-sided)
+// scan value packs (low << 32 | dense) so one pass yields both running counts.
 struct ColumnIds {
     const i32* tstart; const i32* tri_graph; i32* colid; u32* meta; int level; int symmetric; i32 n_fit;
-    __device__ __forceinline__ u32 value(i64 r) const {
-        if (r >= (i64)meta[META_R(level)]) return 0u;
+    i32 low_df;
+    __device__ __forceinline__ u64 value(i64 r) const {
+        if (r >= (i64)meta[META_R(level)]) return 0ull;
         const i32 t0 = tstart[r], t1 = tstart[r + 1];
-        if (symmetric) return (t1 - t0) >= 2 ? 1u : 0u;
-        return (tri_graph[t0] < n_fit && tri_graph[t1 - 1] >= n_fit) ? 1u : 0u;
+        bool useful;
+        if (symmetric) useful = (t1 - t0) >= 2;
+        else useful = tri_graph[t0] < n_fit && tri_graph[t1 - 1] >= n_fit;
+        if (!useful) return 0ull;
+        return (t1 - t0) < low_df ? (1ull << 32) : 1ull;
     }
-    __device__ __forceinline__ void emit(i64 r, u32 keep, u32 incl) const {
+    __device__ __forceinline__ void emit(i64 r, u64 v, u64 incl) const {
         const u32 base = level > 0 ? meta[META_C(level - 1)] : 0u;
-        colid[r] = keep ? (i32)(base + incl - 1) : -1;
+        colid[r] = (v & 1ull) ? (i32)(base + (u32)(incl & 0xffffffffull) - 1) : ((v >> 32) ? -2 : -1);
     }
 };
 
-__global__ void feat_colbase_kernel(u32* __restrict__ meta, const u32* __restrict__ total, int level) {
-    meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + *total;
+__global__ void feat_colbase_kernel(u32* __restrict__ meta, const u64* __restrict__ total, int level, int n_levels) {
+    const u64 t = *total;
+    meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + (u32)(t & 0xffffffffull);
+    meta[3 * n_levels + 1] += (u32)(t >> 32);     // low columns over all levels
 }
 
 template <typename T>
@@ -176,11 +189,16 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
         gk_set_error("gk_features_build: memset failed");
         return fail(GK_ERR_HIP);
     }
-    Tmp<u64> flag(ctx), scan(ctx);
-    Tmp<u32> cflag(ctx), cexcl(ctx), ctotal(ctx), node_acc(ctx);
-    if ((r = flag.alloc(V)) || (r = scan.alloc(V)) || (r = cflag.alloc(V)) || (r = cexcl.alloc(V)) ||
-        (r = ctotal.alloc(1)) || (r = node_acc.alloc(V)))
+    Tmp<u64> flag(ctx);
+    Tmp<u32> cflag(ctx), node_acc(ctx);
+    Tmp<u64> ctotal64(ctx);
+    if ((r = flag.alloc(V)) || (r = cflag.alloc(V)) || (r = ctotal64.alloc(1)) || (r = node_acc.alloc(V)))
         return fail(r);
+    {
+        const char* e = getenv("GK_LOW_DF");     // df threshold below which a column leaves the dense operand
+        f->low_df = e ? atoi(e) : 32;
+        if (f->low_df < 2) f->low_df = 2;        // 2 == everything useful is dense
+    }
     if (!b->graph_ptr) {
         gk_set_error("gk_features_build: batch has no graph_ptr");
         return fail(GK_ERR_STATE);
@@ -199,9 +217,9 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
                       f->meta, l, V};
         if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, V, nullptr))) return fail(r);
         feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, node_acc.p, f->meta, l, n_levels, V);
-        ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit};
-        if ((r = gk_scan_fn<u32, ColumnIds>(ctx, ci, V, ctotal.p))) return fail(r);
-        feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, ctotal.p, l);
+        ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df};
+        if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, V, ctotal64.p))) return fail(r);
+        feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, ctotal64.p, l, n_levels);
     }
     if (V > 0)
         feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, node_acc.p, f->selfk, N);
@@ -216,6 +234,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     for (int l = 0; l < n_levels; ++l) f->nnz += h[META_T(l)];
     f->n_cols = V > 0 ? h[META_C(n_levels - 1)] : 0;
     f->max_count = h[3 * n_levels];
+    f->n_low_cols = h[3 * n_levels + 1];
     // int8 operands need counts <= 127 and every Gram entry < 2^31:
     // K_ij <= sqrt(K_ii K_jj) <= n_levels * max_graph_nodes^2
     const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;

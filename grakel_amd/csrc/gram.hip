@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
         // own loads of stage kt have landed when at most (stages in flight after kt) * 4 remain
         const int ahead = k_tiles - 1 - kt;
         const int fly = ahead < NS - 2 ? ahead : NS - 2;
-        if (fly >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        if (fly >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
         else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();        // everyone's pieces of stage kt are in LDS; stage kt-1 is free
@@ -334,21 +335,211 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
 }
 
 template <int WM, int WN, int TM, int TN, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds2_kernel(
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles,
+    const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
+    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int ablate) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
+    constexpr int STAGE = (BM + BN) * 64;
+    constexpr int PPW = (BM + BN) / 16 / NW;                 // 1-KiB pieces per wave per stage
+    static_assert((BM + BN) % (16 * NW) == 0, "pieces must divide evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // NS * STAGE, ONE array
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bm, bn;
+    if (!gram_map_tile(blockIdx.x, tiles_m, tiles_n, tri, patch, bm, bn)) return;
+
+    // staging: piece q of this wave covers rows [16*(wave*PPW+q), +16) of the (A rows, B rows) list
+    const int srow = lane >> 2;                              // row inside the piece
+    const int schunk = (lane & 3) ^ ((srow >> 2) & 3);       // logical chunk this lane fetches
+    const int8_t* gsrc[PPW];
+    int sdst[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int r0 = (wave * PPW + q) * 16;
+        if (r0 < BM) gsrc[q] = A + ((i64)bm * BM + r0 + srow) * ld + schunk * 16;
+        else gsrc[q] = B + ((i64)bn * BN + (r0 - BM) + srow) * ld + schunk * 16;
+        sdst[q] = r0 * 64;
+    }
+
+    v16i acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+#define GL_ISSUE(KT)                                                                        \
+    {                                                                                       \
+        const i64 go = (i64)(KT) * GI_BK;                                                   \
+        int8_t* st = smem + ((KT) % NS) * STAGE;                                            \
+        _Pragma("unroll") for (int q = 0; q < PPW; ++q)                                     \
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc[q] + go), (lds_void_t*)(st + sdst[q]), 16, 0, 0); \
+    }
+
+    // Software pipeline inside the K-step: while the MFMAs of one 32-deep K-slice run, the
+    // fragments of the next slice are already being read from LDS, so the LDS phase and the
+    // MFMA phase of the 8 barrier-synchronised waves overlap instead of alternating.
+    for (int p = 0; p < NS; ++p)
+        if (p < k_tiles) GL_ISSUE(p);
+
+    const int fr = lane & 31, fh = lane >> 5;
+    int offa[TM][2], offb[TN][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rr = wm * TM * 32 + i * 32 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offa[i][ks] = rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int rr = wn * TN * 32 + j * 32 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offb[j][ks] = BM * 64 + rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
+    }
+
+    v4i fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa1[i] = (v4i){lane, 1, 2, 3};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb1[j] = (v4i){3, 2, 1, lane};
+    {   // own pieces of stage 0 landed: up to NS-1 later stages may stay in flight
+        const int after = k_tiles - 1;
+        const int fly = after < NS - 1 ? after : NS - 1;
+        if (fly >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory");
+        else if (fly == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    {
+        const int8_t* st = smem;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa0[i] = *(const v4i*)(st + offa[i][0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb0[j] = *(const v4i*)(st + offb[j][0]);
+    }
+    for (int kt = 0; kt < k_tiles; ++kt) {
+        const int8_t* st = smem + (kt % NS) * STAGE;
+        // ---- phase A: read slice 1 of stage kt, multiply slice 0
+        if (!(ablate & 4)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa1[i] = *(const v4i*)(st + offa[i][1]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb1[j] = *(const v4i*)(st + offb[j][1]);
+        }
+        if (!(ablate & 2)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa0[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb0[j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- stage hand-over: stage kt+1 must be complete, stage kt is fully read
+        if (kt + 1 < k_tiles) {
+            const int after = k_tiles - 1 - (kt + 1);          // stages after kt+1 may stay in flight
+            const int fly = after < NS - 2 ? after : NS - 2;
+            if (fly >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PPW) : "memory");
+            else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS < k_tiles && !(ablate & 1)) GL_ISSUE(kt + NS);       // overwrites the buffer of stage kt
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B: read slice 0 of stage kt+1, multiply slice 1
+        if (kt + 1 < k_tiles && !(ablate & 4)) {
+            const int8_t* sn = smem + ((kt + 1) % NS) * STAGE;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa0[i] = *(const v4i*)(sn + offa[i][0]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb0[j] = *(const v4i*)(sn + offb[j][0]);
+        }
+        if (!(ablate & 2)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa1[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb1[j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef GL_ISSUE
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool mirror = tri && bm != bn;     // off-diagonal tile of a symmetric job: also write K^T
+    const bool even = (N & 1) == 0;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const i64 col = (i64)bn * BN + (wn * TN + nt) * 32 + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i64 row0 = (i64)bm * BM + (wm * TM + mt) * 32 + 8 * q + 4 * (lane >> 5);
+                double v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i64 row = row0 + j;
+                    v[j] = 0.0;
+                    if (row < M && col < N) {
+                        v[j] = finish_entry((double)acc[mt][nt][4 * q + j], row_base + row, col,
+                                            symmetric != 0, selfk, n_fit, normalize);
+                        K[row * N + col] = v[j];           // 32 lanes -> 256 contiguous bytes
+                    }
+                }
+                if (mirror && col < N) {                    // K[col][row0..row0+3]: 32 B per lane
+                    double* dst = K + col * N + row0;
+                    if (even && row0 + 3 < M) {
+                        *(double2*)(dst) = make_double2(v[0], v[1]);
+                        *(double2*)(dst + 2) = make_double2(v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (row0 + j < M) dst[j] = v[j];
+                    }
+                }
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN, int NS>
 static int launch_glds(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
                        i64 row_lo, int normalize, double* K, int tri, int patch, int patch_sz, double* tiles_done) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDS = NS * (BM + BN) * 64;
-    static bool attr_set = false;
-    auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
-    if (!attr_set) {
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(n_cols, BN);
     const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch ? patch_sz : 0);
-    kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
-        a, b, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
-        f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0);
+    if (getenv("GK_GRAM_PIPE1")) {
+        auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
+            a, b, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
+            f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0);
+    } else {
+        auto kern = gram_i8_glds2_kernel<WM, WN, TM, TN, NS>;
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        const char* ab = getenv("GK_GRAM_ABLATE");    // perf forensics only (results are garbage)
+        kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
+            a, b, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
+            f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0,
+            ab ? atoi(ab) : 0);
+    }
     *tiles_done = tri ? (double)tiles_m * (tiles_m + 1) / 2 * BM * BN : (double)M * n_cols;
     return GK_OK;
 }
@@ -422,6 +613,47 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
         }
 }
 
+// Rare columns (colid == -2): K[g_a][g_b] += c_a * c_b for every ordered pair of graphs that
+// share the label.  One thread per triple a walks the other triples of its label run.
+// Integer-valued float64 atomics: exact and order independent.
+__global__ void gram_low_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_graph,
+                                const i32* __restrict__ tri_run, const i32* __restrict__ tstart,
+                                const i32* __restrict__ colid, const u32* __restrict__ meta, int level,
+                                double* __restrict__ K, i64 n_cols, i64 row_lo, i64 row_hi, int symmetric,
+                                i64 n_fit) {
+    const u32 T = meta[3 * level + 0];
+    const u32 a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= T) return;
+    const i32 r = tri_run[a];
+    if (colid[r] != -2) return;
+    const i64 ga = tri_graph[a];
+    const i64 row = symmetric ? ga : ga - n_fit;       // rectangular job: rows are the target graphs
+    if (row < row_lo || row >= row_hi) return;
+    const double ca = (double)(tri_pos[a + 1] - tri_pos[a]);
+    double* krow = K + (row - row_lo) * n_cols;
+    const i32 t0 = tstart[r], t1 = tstart[r + 1];
+    for (i32 b = t0; b < t1; ++b) {
+        const i64 gb = tri_graph[b];
+        if (symmetric ? (b == (i32)a) : (gb >= n_fit)) continue;
+        atomicAdd(&krow[gb], ca * (double)(tri_pos[b + 1] - tri_pos[b]));
+    }
+}
+
+__global__ void gram_normalize_kernel(double* __restrict__ K, const u64* __restrict__ selfk, i64 M, i64 n_cols,
+                                      i64 row_lo, int symmetric, i64 n_fit, int normalize) {
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * n_cols) return;
+    const i64 row = idx / n_cols, col = idx - row * n_cols;
+    const double dr = (double)selfk[(symmetric ? 0 : n_fit) + row_lo + row];
+    const double dc = (double)selfk[col];
+    double val = K[idx] / sqrt(dr * dc);
+    if (normalize == 2) {
+        if (val != val) val = 0.0;
+        else if (val > 1.7976931348623157e308) val = 1.7976931348623157e308;
+    }
+    K[idx] = val;
+}
+
 // rows [row_lo,row_hi) of the job's Gram matrix into K ([row_hi-row_lo] x n_cols, row major)
 int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normalize, double* K) {
     const i64 n_cols = f->symmetric ? f->n_graphs : f->n_fit;
@@ -433,6 +665,9 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     GK_HIP_CHECK(hipEventCreate(&e1));
     GK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
     double tiles_done = (double)M * n_cols;
+    const int normalize_req = normalize;
+    const bool has_low = f->n_low_cols > 0;
+    if (has_low) normalize = 0;        // normalise after the pair updates instead of in the epilogue
     if (f->dtype == 0) {
         const int8_t* phi = (const int8_t*)f->phi;
         const int8_t* pa = phi + first_row_graph * f->n_cols_pad;
@@ -451,6 +686,10 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
             GK_TRY((launch_glds<2, 2, 2, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
         } else if (shape && !strcmp(shape, "256x128")) {
             GK_TRY((launch_glds<4, 2, 2, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
+        } else if (shape && !strcmp(shape, "256ns5")) {
+            GK_TRY((launch_glds<2, 4, 4, 2, 5>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
+        } else if (shape && !strcmp(shape, "256ns3")) {
+            GK_TRY((launch_glds<2, 4, 4, 2, 3>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
         } else {
             GK_TRY((launch_glds<2, 4, 4, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
         }
@@ -463,6 +702,20 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     }
     GK_HIP_CHECK(hipGetLastError());
     GK_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    if (has_low) {
+        for (int l = 0; l < f->n_levels; ++l) {
+            LevelTriples& L = f->lev[l];
+            if (!L.tri_pos) continue;
+            const i64 nt = f->n_nodes;      // upper bound on the triples of a level
+            gram_low_kernel<<<dim3((unsigned)cdiv(nt, 256)), dim3(256), 0, ctx->stream>>>(
+                L.tri_pos, L.tri_graph, L.tri_run, L.tstart, L.colid, f->meta, l, K, n_cols, row_lo, row_hi,
+                f->symmetric ? 1 : 0, f->n_fit);
+        }
+        if (normalize_req)
+            gram_normalize_kernel<<<dim3((unsigned)cdiv(M * n_cols, 256)), dim3(256), 0, ctx->stream>>>(
+                K, f->selfk, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize_req);
+        GK_HIP_CHECK(hipGetLastError());
+    }
     GK_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;
     GK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));

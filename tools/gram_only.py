@@ -19,13 +19,18 @@ for env in variants:
     for k in list(os.environ):
         if k.startswith("GK_GRAM"): del os.environ[k]
     os.environ.update(env)
-    ms = []
+    if any(k in env for k in ("GK_LOW_DF",)):
+        feat.close(); feat = eng.features(db, 6)
+        print("   features: dense cols", feat.n_cols, "low_df", env.get("GK_LOW_DF"))
+    ms, tot = [], []
     for it in range(6):
+        eng.timer_start()
         eng.gram(feat, 0, to_host=False)
+        tot.append(eng.timer_stop_ms())
         ms.append(eng.gram_stats(feat)[1])
     fl = eng.gram_stats(feat)[0]
     K = eng.gram(feat, 0)
     chk = (int(K.sum()), int(np.trace(K)), bool(np.array_equal(K, K.T)))
     if ref is None: ref = chk
-    print(env, "ms min %.3f med %.3f" % (min(ms), sorted(ms)[len(ms)//2]), "TOP/s %.0f" % (fl / min(ms) / 1e9), "chk", chk, "OK" if chk == ref else "MISMATCH")
+    print(env, "gemm ms min %.3f med %.3f | gram total min %.3f" % (min(ms), sorted(ms)[len(ms)//2], min(tot)), "TOP/s %.0f" % (fl / min(ms) / 1e9), "chk", chk, "OK" if chk == ref else "MISMATCH")
 if N == 10000: print("golden sum 200604613570 trace 25874190")
