@@ -149,7 +149,9 @@ struct LevelTriples {
     i32* tri_graph = nullptr;  // [n_nodes+1]
     i32* tri_run = nullptr;    // [n_nodes+1] label run index of each triple
     i32* tstart = nullptr;     // [n_nodes+1] first triple of each label run
-    i32* colid = nullptr;      // [n_nodes]   kept-column id per label run or -1
+    i32* colid = nullptr;      // [n_nodes]   dense column id per label run, -2 rare, -1 dead
+    i32* low_runs = nullptr;   // [n_nodes]   compact list of the rare label runs
+    i64 n_low = 0;
 };
 
 struct gk_feat {

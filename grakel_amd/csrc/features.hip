@@ -114,7 +114,7 @@ __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* 
 // scan value packs (low << 32 | dense) so one pass yields both running counts.
 struct ColumnIds {
     const i32* tstart; const i32* tri_graph; i32* colid; u32* meta; int level; int symmetric; i32 n_fit;
-    i32 low_df;
+    i32 low_df; i32* low_runs;
     __device__ __forceinline__ u64 value(i64 r) const {
         if (r >= (i64)meta[META_R(level)]) return 0ull;
         const i32 t0 = tstart[r], t1 = tstart[r + 1];
@@ -127,6 +127,7 @@ struct ColumnIds {
     __device__ __forceinline__ void emit(i64 r, u64 v, u64 incl) const {
         const u32 base = level > 0 ? meta[META_C(level - 1)] : 0u;
         colid[r] = (v & 1ull) ? (i32)(base + (u32)(incl & 0xffffffffull) - 1) : ((v >> 32) ? -2 : -1);
+        if (v >> 32) low_runs[(u32)(incl >> 32) - 1] = (i32)r;      // compact list for gram_low_kernel
     }
 };
 
@@ -134,6 +135,7 @@ __global__ void feat_colbase_kernel(u32* __restrict__ meta, const u64* __restric
     const u64 t = *total;
     meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + (u32)(t & 0xffffffffull);
     meta[3 * n_levels + 1] += (u32)(t >> 32);     // low columns over all levels
+    meta[3 * n_levels + 4 + level] = (u32)(t >> 32);   // ... and of this level
 }
 
 template <typename T>
@@ -152,7 +154,7 @@ extern "C" int gk_features_destroy(gk_feat* f) {
     if (!f) return GK_OK;
     gk_ctx* ctx = f->ctx;
     for (auto& L : f->lev) {
-        void* ptrs[] = {L.tri_pos, L.tri_graph, L.tri_run, L.tstart, L.colid};
+        void* ptrs[] = {L.tri_pos, L.tri_graph, L.tri_run, L.tstart, L.colid, L.low_runs};
         for (void* p : ptrs)
             if (p) gk_dev_free(ctx, p);
     }
@@ -179,7 +181,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     auto fail = [&](int r) { gk_features_destroy(f); return r; };
     int r;
     void* q = nullptr;
-    const size_t n_meta = 3 * (size_t)n_levels + 4;
+    const size_t n_meta = 4 * (size_t)n_levels + 4;
     if ((r = gk_dev_alloc(ctx, &q, n_meta * 4))) return fail(r);
     f->meta = (u32*)q;
     if ((r = gk_dev_alloc(ctx, &q, (size_t)N * 8))) return fail(r);
@@ -205,7 +207,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     }
     for (int l = 0; l < n_levels && V > 0; ++l) {
         LevelTriples& L = f->lev[l];
-        i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid};
+        i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid, &L.low_runs};
         for (i32** a : arrs) {
             if ((r = gk_dev_alloc(ctx, &q, (size_t)(V + 1) * 4))) return fail(r);
             *a = (i32*)q;
@@ -217,7 +219,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
                       f->meta, l, V};
         if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, V, nullptr))) return fail(r);
         feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, node_acc.p, f->meta, l, n_levels, V);
-        ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df};
+        ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df, L.low_runs};
         if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, V, ctotal64.p))) return fail(r);
         feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, ctotal64.p, l, n_levels);
     }
@@ -235,6 +237,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     f->n_cols = V > 0 ? h[META_C(n_levels - 1)] : 0;
     f->max_count = h[3 * n_levels];
     f->n_low_cols = h[3 * n_levels + 1];
+    for (int l = 0; l < n_levels; ++l) f->lev[l].n_low = h[3 * n_levels + 4 + l];
     // int8 operands need counts <= 127 and every Gram entry < 2^31:
     // K_ij <= sqrt(K_ii K_jj) <= n_levels * max_graph_nodes^2
     const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
@@ -265,9 +268,11 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     return GK_OK;
 }
 
-extern "C" int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* nnz, int64_t* max_count, int* dtype) {
+extern "C" int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* n_cols_low, int64_t* nnz,
+                                int64_t* max_count, int* dtype) {
     GK_ARG(f, "gk_features_info: null");
     if (n_cols_kept) *n_cols_kept = f->n_cols;
+    if (n_cols_low) *n_cols_low = f->n_low_cols;
     if (nnz) *nnz = f->nnz;
     if (max_count) *max_count = f->max_count;
     if (dtype) *dtype = f->dtype;

@@ -36,6 +36,63 @@ def _pad_to(t, n, torch):
     return out
 
 
+class ShardExchange(object):
+    """All-gather of the packed CSR shards.  The shard sizes are exchanged once (first call);
+    every later call is ONE fused all_gather of [graph sizes | degrees | labels | col_idx] plus
+    the pointer rebuild (two cumsums) on the device."""
+
+    def __init__(self, local, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.group, self.ws = group, dist.get_world_size(group)
+        self.dev = torch.device("cpu") if device is None else device
+        dev = self.dev
+
+        def T(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+        sizes = torch.tensor([local.n_graphs, local.n_nodes, local.n_edges, local.n_labels],
+                             dtype=torch.int64, device=dev)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(self.ws)]
+        dist.all_gather(all_sizes, sizes, group=group)
+        self.all_sizes = torch.stack(all_sizes).cpu().numpy()
+        a = self.all_sizes
+        self.mg, self.mv, self.me = int(a[:, 0].max()), int(a[:, 1].max()), int(a[:, 2].max())
+        self.n_labels = int(a[:, 3].max())
+        mg, mv, me = self.mg, self.mv, self.me
+        # this rank's message lives on the device (the shard is resident in HBM)
+        self.msg = torch.cat([_pad_to(T(np.diff(local.graph_ptr).astype(np.int32)), mg, torch),
+                              _pad_to(T(np.diff(local.row_ptr).astype(np.int32)), mv, torch),
+                              _pad_to(T(local.node_label), mv, torch),
+                              _pad_to(T(local.col_idx), me, torch)])
+        self.bounds = [0]
+        for r in range(self.ws):
+            self.bounds.append(self.bounds[-1] + int(a[r, 0]))
+        self.zero = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def gather(self):
+        import torch
+        import torch.distributed as dist
+        gathered = [torch.empty_like(self.msg) for _ in range(self.ws)]
+        dist.all_gather(gathered, self.msg, group=self.group)
+        mg, mv = self.mg, self.mv
+        gs, dg, lb, ci = [], [], [], []
+        node_off = 0
+        for r in range(self.ws):
+            ng, nv, ne = (int(x) for x in self.all_sizes[r, :3])
+            m = gathered[r]
+            gs.append(m[:ng])
+            dg.append(m[mg:mg + nv])
+            lb.append(m[mg + mv:mg + mv + nv])
+            ci.append(m[mg + 2 * mv:mg + 2 * mv + ne] + node_off)      # local -> global node ids
+            node_off += nv
+        graph_ptr = torch.cat([self.zero, torch.cumsum(torch.cat(gs), 0).to(torch.int32)])
+        row_ptr = torch.cat([self.zero, torch.cumsum(torch.cat(dg), 0).to(torch.int32)])
+        col_idx = torch.cat(ci).to(torch.int32)
+        labels = torch.cat(lb).to(torch.int32)
+        return graph_ptr.contiguous(), row_ptr.contiguous(), col_idx.contiguous(), labels.contiguous()
+
+
 def all_gather_batch(local, group=None, device=None):
     """All-gather CSR shards -> the global batch as int32 torch tensors on ``device``.
 
@@ -43,46 +100,9 @@ def all_gather_batch(local, group=None, device=None):
     (graph_ptr, row_ptr, col_idx, node_label, n_labels, shard_graph_bounds) where the four
     arrays describe ALL graphs in rank order with global node numbering.
     """
-    import torch
-    import torch.distributed as dist
-    ws = dist.get_world_size(group)
-    dev = torch.device("cpu") if device is None else device
-
-    def T(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-
-    sizes = torch.tensor([local.n_graphs, local.n_nodes, local.n_edges, local.n_labels],
-                         dtype=torch.int64, device=dev)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(ws)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    all_sizes = torch.stack(all_sizes).cpu().numpy()
-    mg, mv, me = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max()), int(all_sizes[:, 2].max())
-    # one fused message per rank: [graph sizes | degrees | labels | col_idx], zero padded
-    gsz = T(np.diff(local.graph_ptr).astype(np.int32))
-    deg = T(np.diff(local.row_ptr).astype(np.int32))
-    msg = torch.cat([_pad_to(gsz, mg, torch), _pad_to(deg, mv, torch),
-                     _pad_to(T(local.node_label), mv, torch), _pad_to(T(local.col_idx), me, torch)])
-    gathered = [torch.empty_like(msg) for _ in range(ws)]
-    dist.all_gather(gathered, msg, group=group)
-    gs, dg, lb, ci = [], [], [], []
-    node_off = 0
-    bounds = [0]
-    for r in range(ws):
-        ng, nv, ne = int(all_sizes[r, 0]), int(all_sizes[r, 1]), int(all_sizes[r, 2])
-        m = gathered[r]
-        gs.append(m[:ng])
-        dg.append(m[mg:mg + nv])
-        lb.append(m[mg + mv:mg + mv + nv])
-        ci.append(m[mg + 2 * mv:mg + 2 * mv + ne] + node_off)      # local -> global node ids
-        node_off += nv
-        bounds.append(bounds[-1] + ng)
-    zero = torch.zeros(1, dtype=torch.int32, device=dev)
-    graph_ptr = torch.cat([zero, torch.cumsum(torch.cat(gs), 0).to(torch.int32)])
-    row_ptr = torch.cat([zero, torch.cumsum(torch.cat(dg), 0).to(torch.int32)])
-    col_idx = torch.cat(ci).to(torch.int32) if ci else zero[:0]
-    labels = torch.cat(lb).to(torch.int32)
-    return (graph_ptr.contiguous(), row_ptr.contiguous(), col_idx.contiguous(), labels.contiguous(),
-            int(all_sizes[:, 3].max()), bounds)
+    ex = ShardExchange(local, group, device)
+    gp, rp, ci, lab = ex.gather()
+    return gp, rp, ci, lab, ex.n_labels, ex.bounds
 
 
 def tensors_to_batch(graph_ptr, row_ptr, col_idx, labels, n_labels):
@@ -95,6 +115,7 @@ class ShardedWL(object):
 
     def __init__(self, engine, n_iter=5, normalize=False, group=None):
         self.engine, self.n_iter, self.normalize, self.group = engine, n_iter, normalize, group
+        self._exchange, self._local = None, None
 
     def step(self, local_batch, to_host=False):
         """One fit_transform: returns (row block [n_local x N] or None, info dict)."""
@@ -102,7 +123,10 @@ class ShardedWL(object):
         import torch.distributed as dist
         rank = dist.get_rank(self.group)
         dev = torch.device("cuda", self.engine.device)
-        gp, rp, ci, lab, n_labels, bounds = all_gather_batch(local_batch, self.group, dev)
+        if self._local is not local_batch:           # shard sizes are exchanged once per local shard
+            self._exchange, self._local = ShardExchange(local_batch, self.group, dev), local_batch
+        gp, rp, ci, lab = self._exchange.gather()
+        n_labels, bounds = self._exchange.n_labels, self._exchange.bounds
         torch.cuda.current_stream(dev).synchronize()
         eng = self.engine
         db = eng.upload_from_device(gp.shape[0] - 1, lab.shape[0], ci.shape[0], gp.data_ptr(),
@@ -111,7 +135,7 @@ class ShardedWL(object):
         feat = eng.features(db, self.n_iter + 1)
         rows = (bounds[rank], bounds[rank + 1])
         K = eng.gram(feat, 2 if self.normalize else 0, rows=rows, to_host=to_host)
-        info = dict(label_counts=counts, n_cols=feat.n_cols, rows=rows, n_graphs=db.n_graphs,
+        info = dict(label_counts=counts, n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, rows=rows, n_graphs=db.n_graphs,
                     gram=eng.gram_stats(feat), dtype=feat.dtype)
         feat.close()
         db.close()

@@ -37,9 +37,10 @@ class DeviceBatch(object):
 class DeviceFeatures(object):
     def __init__(self, engine, handle, batch, n_fit):
         self.engine, self.handle, self.batch, self.n_fit = engine, handle, batch, n_fit
-        nc, nnz, mc, dt = c_int64(), c_int64(), c_int64(), c_int()
-        check(engine.lib.gk_features_info(handle, byref(nc), byref(nnz), byref(mc), byref(dt)))
-        self.n_cols, self.nnz, self.max_count, self.dtype = nc.value, nnz.value, mc.value, dt.value
+        nc, nl, nnz, mc, dt = c_int64(), c_int64(), c_int64(), c_int64(), c_int()
+        check(engine.lib.gk_features_info(handle, byref(nc), byref(nl), byref(nnz), byref(mc), byref(dt)))
+        self.n_cols, self.n_cols_low, self.nnz = nc.value, nl.value, nnz.value
+        self.max_count, self.dtype = mc.value, dt.value
         self.symmetric = n_fit == batch.n_graphs
         self.n_rows = batch.n_graphs if self.symmetric else batch.n_graphs - n_fit
         self.n_out_cols = n_fit

@@ -106,7 +106,7 @@ class Kernel(BaseEstimator, TransformerMixin):
         fb, n_levels = self._prepare(eng, db)
         feat = eng.features(fb, n_levels)
         self._X_diag = eng.selfk(feat)
-        self._last_info = dict(n_cols=feat.n_cols, nnz=feat.nnz, max_count=feat.max_count,
+        self._last_info = dict(n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, nnz=feat.nnz, max_count=feat.max_count,
                                dtype=("i8", "f64")[feat.dtype], label_counts=fb.label_counts)
         return eng, feat
 

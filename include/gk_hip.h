@@ -102,7 +102,8 @@ int gk_wl_debug_signature(gk_ctx* ctx, gk_batch* b, int level, uint64_t seed,
  * the batch, the per-graph label-count features:  the sparse (label, graph, count) triples,
  * the self-similarities  selfk[g] = sum over all columns of count^2  (= the Gram diagonal,
  * vertex_histogram.py:186-219 / weisfeiler_lehman.py:502-555) and a dense, column-compacted
- * Phi_s holding only the columns that can contribute to an off-diagonal entry.
+ * Phi_s holding only the columns that can contribute to an off-diagonal entry AND occur in
+ * enough graphs to be worth a dense column (the rest become pair updates in gk_gram).
  *   n_fit == n_graphs : symmetric job (fit_transform); a column is kept iff it occurs in
  *                       >= 2 graphs, singletons are folded into selfk.
  *   n_fit <  n_graphs : rectangular job (transform): rows = graphs [n_fit, n_graphs),
@@ -110,10 +111,12 @@ int gk_wl_debug_signature(gk_ctx* ctx, gk_batch* b, int level, uint64_t seed,
  *                       (unseen labels are dropped exactly like vertex_histogram.py:179). */
 int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, gk_feat** out);
 int gk_features_destroy(gk_feat* f);
-/* n_cols_kept: width of Phi_s; nnz: number of (label,graph) triples over all levels;
- * max_count: largest single count; dtype: 0 = int8 Phi / i32 MFMA, 1 = f64 Phi / f64 MFMA. */
-int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* nnz, int64_t* max_count,
-                     int* dtype);
+/* n_cols_kept: width of the dense MFMA operand Phi_s; n_cols_low: useful but rare columns
+ * (fewer than GK_LOW_DF=32 graphs) that are applied as exact pair updates after the GEMM instead;
+ * nnz: number of (label,graph) triples over all levels; max_count: largest single count;
+ * dtype: 0 = int8 Phi / i32 MFMA, 1 = f64 Phi / f64 MFMA. */
+int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* n_cols_low, int64_t* nnz,
+                     int64_t* max_count, int* dtype);
 int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk /* [n_graphs] */);
 /* Test hook: the dense column-compacted Phi_s as float64 [n_graphs x n_cols_kept]. */
 int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi);
