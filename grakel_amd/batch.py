@@ -168,6 +168,8 @@ def _wl_graph_arrays(gobj, labels):
     """-> (label_values list, src idx array, dst idx array) with node index = position in labels."""
     if not isinstance(labels, dict):
         raise TypeError('node labels must be a dictionary')
+    if not labels:
+        raise ValueError('Graph does not have any labels for vertices.')     # graph.py:737-738
     n = len(labels)
     keys = list(labels.keys())
     identity = keys == list(range(n))

@@ -349,3 +349,76 @@ def test_sharded_path_single_rank_matches_plain_path(gk):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
+# edge cases (ragged / degenerate inputs), each against the CPU oracle
+# ------------------------------------------------------------------------------------------
+def _edge_sets():
+    g_single = [{0: []}, {0: 'x'}]                                   # one vertex, no edge
+    g_loop = [{(0, 0): 1, (0, 1): 1, (1, 0): 1}, {0: 'a', 1: 'b'}]    # self loop
+    g_directed = [[(0, 1), (1, 2), (2, 0), (0, 3)], {0: 'a', 1: 'a', 2: 'b', 3: 'a'}]
+    g_big_ids = [{10**9: [-5], -5: [10**9]}, {10**9: -7, -5: 2**40}]
+    g_str = [{'u': {'v': 1.0, 'w': 1.0}, 'v': {'u': 1.0}, 'w': {'u': 1.0}}, {'u': 'N', 'v': 'C', 'w': 'C'}]
+    g_dup = [np.array([[0, 1, 1], [1, 0, 0], [1, 0, 0]]), {0: 'N', 1: 'C', 2: 'C'}]
+    g_float_lab = [np.array([[0, 1], [1, 0]]), {0: 0.5, 1: 1.5}]
+    g_tuple_lab = [np.array([[0, 1], [1, 0]]), {0: (1, 2), 1: (1, 3)}]
+    return dict(single=[g_single], loops=[g_loop, g_single, g_loop], directed=[g_directed, g_loop],
+                big_ids=[g_big_ids, g_big_ids], isomorphic=[g_str, g_dup, g_str],
+                float_labels=[g_float_lab, g_float_lab], tuple_labels=[g_tuple_lab, g_float_lab[:1] + [{0: (1, 2), 1: (9, 9)}]])
+
+
+@pytest.mark.parametrize("name", sorted(_edge_sets()))
+def test_edge_case_inputs_match_oracle(gk, name):
+    X = _edge_sets()[name]
+    for h in (1, 2, 4):
+        assert np.array_equal(gk.WeisfeilerLehman(n_iter=h).fit_transform(X),
+                              O.WLOracle(n_iter=h).fit_transform(X)), (name, h)
+    Kn = gk.WeisfeilerLehman(n_iter=2, normalize=True).fit_transform(X)
+    assert np.allclose(Kn, O.WLOracle(n_iter=2, normalize=True).fit_transform(X), rtol=REL_TOL, atol=0)
+    assert np.array_equal(gk.VertexHistogram().fit_transform(X), O.VHOracle().fit_transform(X))
+    wl, wo = gk.WeisfeilerLehman(n_iter=3).fit(X[:1]), O.WLOracle(n_iter=3)
+    wo.fit_transform(X[:1])
+    assert np.array_equal(wl.transform(X), wo.transform(X))
+
+
+def test_transform_with_only_unseen_labels_and_zero_diagonals(gk):
+    tr = [[{0: [1], 1: [0]}, {0: 'a', 1: 'b'}], [{0: [1, 2], 1: [0], 2: [0]}, {0: 'a', 1: 'a', 2: 'b'}]]
+    te = [[{0: [1], 1: [0]}, {0: 'zz', 1: 'yy'}], [{0: [1], 1: [0]}, {0: 'a', 1: 'yy'}]]
+    for norm in (False, True):
+        wl, wo = gk.WeisfeilerLehman(n_iter=2, normalize=norm), O.WLOracle(n_iter=2, normalize=norm)
+        wl.fit(tr), wo.fit_transform(tr)
+        K, Ko = wl.transform(te), wo.transform(te)
+        assert np.allclose(K, Ko, rtol=REL_TOL, atol=0) and np.array_equal(K[0], [0, 0])
+        vh, vo = gk.VertexHistogram(normalize=norm), O.VHOracle(normalize=norm)
+        vh.fit(tr), vo.fit_transform(tr)
+        assert np.allclose(vh.transform(te), vo.transform(te), rtol=REL_TOL, atol=0)
+    # a graph without any labelled vertex: VertexHistogram leaves 0/0 = NaN and warns
+    # (kernel.py:199-234); WeisfeilerLehman refuses it like the reference (graph.py:737-738)
+    Xz = [["unused", {}], ["unused", {0: 'a'}]]
+    with pytest.warns(RuntimeWarning):
+        Kz = gk.VertexHistogram(normalize=True).fit_transform(Xz)
+    with np.errstate(all='ignore'):
+        Kzo = O.VHOracle(normalize=True).fit_transform(Xz)
+    assert np.array_equal(np.isnan(Kz), np.isnan(Kzo))
+    assert np.array_equal(np.isnan(Kz), [[True, True], [True, False]]) and Kz[1, 1] == 1.0
+    with pytest.raises(ValueError):
+        gk.WeisfeilerLehman(n_iter=1).fit_transform([[{0: [1], 1: [0]}, {}]])
+
+
+def test_shortest_path_edge_cases_match_oracle(gk):
+    A1 = np.array([[0, 2, 0, 0], [2, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 0]])      # weighted + isolated vertex
+    A2 = np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]])                            # directed cycle
+    A3 = np.zeros((2, 2), dtype=int)                                            # no edges at all
+    X = [[A1, {0: 'a', 1: 'b', 2: 'a', 3: 'c'}], [A2, {0: 'a', 1: 'a', 2: 'b'}], [A3, {0: 'a', 1: 'b'}]]
+    for kw in (dict(), dict(with_labels=False), dict(algorithm_type="floyd_warshall")):
+        assert np.array_equal(gk.ShortestPath(**kw).fit_transform(X), O.SPOracle(**kw).fit_transform(X)), kw
+    sp, so = gk.ShortestPath(), O.SPOracle()
+    sp.fit(X[:2]), so.fit_transform(X[:2])
+    assert np.array_equal(sp.transform(X), so.transform(X))
+    # dictionary input with weights, symbols as vertex names (Dijkstra route of the reference)
+    D = [{'p': {'q': 3}, 'q': {'p': 3, 'r': 1}, 'r': {'q': 1}}, {'p': 0, 'q': 1, 'r': 0}]
+    assert np.array_equal(gk.ShortestPath().fit_transform([D, D]), O.SPOracle().fit_transform([D, D]))
+    with np.errstate(all='ignore'):
+        Kn, Kno = gk.ShortestPath(normalize=True).fit_transform(X), O.SPOracle(normalize=True).fit_transform(X)
+    assert np.allclose(Kn, Kno, rtol=REL_TOL, atol=0, equal_nan=True)
