@@ -1,5 +1,6 @@
 """Weisfeiler-Lehman subtree kernel on MI355X (drop-in for ``grakel.WeisfeilerLehman``,
 ``grakel/kernels/weisfeiler_lehman.py:20``)."""
+import numpy as np
 from sklearn.utils.validation import check_is_fitted
 
 from .batch import wl_batch_from_input
@@ -109,3 +110,42 @@ class WeisfeilerLehman(Kernel):
         eng, feat = self._gram_transform(X)
         self._is_transformed = True
         return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
+
+    def inv_labels(self):
+        """Reference-identical ``_inv_labels`` for every level.
+
+        The device uses arbitrary dense ids per level (the Gram matrix does not depend on
+        them).  The reference numbers the labels of level i by the LEXICOGRAPHIC order of the
+        credential strings ``str(own) + "," + str(sorted(neighbour ids))`` with a counter that
+        continues across levels (weisfeiler_lehman.py:235-246).  This host pass rebuilds exactly
+        that from one representative node per device label: cost O(#labels * degree) in Python,
+        so it is on demand only.  Returns the dict and stores it in ``self._inv_labels``.
+        """
+        check_is_fitted(self, ['X', '_nx', '_inv_labels'])
+        gb = self._fit_batch
+        eng = self._engine()
+        db = eng.upload(gb)
+        eng.wl_relabel(db, self._n_iter - 1)
+        ref_prev = gb.node_label.astype(np.int64)          # level-0 ids are already the reference's
+        out = {0: dict(self._inv_labels[0])}
+        count = len(out[0])
+        self._reference_labels = [ref_prev]
+        for i in range(1, self._n_iter):
+            dev = eng.wl_labels(db, i)
+            uniq, first = np.unique(dev, return_index=True)     # uniq == 0..L-1
+            creds = []
+            for v in first.tolist():
+                nb = ref_prev[gb.col_idx[gb.row_ptr[v]:gb.row_ptr[v + 1]]]
+                creds.append(str(int(ref_prev[v])) + "," + str(sorted(nb.tolist())))
+            ids = np.empty(len(creds), np.int64)
+            inv = dict()
+            for c in sorted(range(len(creds)), key=creds.__getitem__):
+                inv[creds[c]] = count
+                ids[c] = count
+                count += 1
+            out[i] = inv
+            ref_prev = ids[dev]
+            self._reference_labels.append(ref_prev)
+        db.close()
+        self._inv_labels = out
+        return out

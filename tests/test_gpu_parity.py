@@ -422,3 +422,27 @@ def test_shortest_path_edge_cases_match_oracle(gk):
     with np.errstate(all='ignore'):
         Kn, Kno = gk.ShortestPath(normalize=True).fit_transform(X), O.SPOracle(normalize=True).fit_transform(X)
     assert np.allclose(Kn, Kno, rtol=REL_TOL, atol=0, equal_nan=True)
+
+
+def test_reference_identical_inv_labels(gk, mutag_graphs):
+    """the host post-pass reproduces the reference's label dictionaries
+    (credential strings and ids) exactly; tests/golden/doc_goldens.json holds the real
+    reference's dictionary for H2O/H3O."""
+    import json
+    H2O = [{'a': ['b', 'c'], 'b': ['a'], 'c': ['a']}, {'a': 'O', 'b': 'H', 'c': 'H'}]
+    H3O = [{'a': ['b', 'c', 'd'], 'b': ['a'], 'c': ['a'], 'd': ['a']},
+           {'a': 'O', 'b': 'H', 'c': 'H', 'd': 'H'}]
+    with open(os.path.join(os.path.dirname(__file__), "golden", "doc_goldens.json")) as f:
+        doc = json.load(f)
+    wl = gk.WeisfeilerLehman(n_iter=5).fit([H2O, H3O])
+    assert {str(k): v for k, v in wl.inv_labels().items()} == doc["wl5_inv_labels"]
+    G, z = mutag_graphs
+    for X, h in ((G, 4), (random_labelled_graphs(40, 3, 14, 0.3, 3, 11, fmt="dict"), 3)):
+        wo = O.WLOracle(n_iter=h)
+        wo.fit_transform(X, keep_levels=True)
+        wl = gk.WeisfeilerLehman(n_iter=h)
+        wl.fit_transform(X)
+        assert wl.inv_labels() == wo.inv_labels
+        for lvl in range(h + 1):       # and the per-node ids are the reference's ids, not just a bijection
+            want = np.array([l for d in wo.levels[lvl] for l in d.values()])
+            assert np.array_equal(wl._reference_labels[lvl], want)
