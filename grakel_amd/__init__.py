@@ -5,6 +5,7 @@ from .kernel import Kernel
 from .vertex_histogram import VertexHistogram
 from .weisfeiler_lehman import WeisfeilerLehman
 from .shortest_path import ShortestPath
+from .graph_kernels import GraphKernel
 
-__all__ = ["GraphBatch", "Kernel", "VertexHistogram", "WeisfeilerLehman", "ShortestPath"]
+__all__ = ["GraphBatch", "Kernel", "VertexHistogram", "WeisfeilerLehman", "ShortestPath", "GraphKernel"]
 __version__ = "0.1.0"

@@ -446,3 +446,17 @@ def test_reference_identical_inv_labels(gk, mutag_graphs):
         for lvl in range(h + 1):       # and the per-node ids are the reference's ids, not just a bijection
             want = np.array([l for d in wo.levels[lvl] for l in d.values()])
             assert np.array_equal(wl._reference_labels[lvl], want)
+
+
+def test_graph_kernel_wrapper_and_extras(gk, mutag_graphs):
+    """The dispatcher and inputs with edge labels / extra tuple elements (how CoreFramework and
+    GraphKernel hand graphs to the kernels, weisfeiler_lehman.py:157-171) give the same matrices."""
+    G, z = mutag_graphs
+    K = gk.GraphKernel(kernel=[{"name": "WL", "n_iter": 5}, "VH"]).fit_transform(G)
+    assert np.array_equal(K, z["K_wl5"])
+    assert np.array_equal(gk.GraphKernel(kernel="SP").fit_transform(G[:60]), z["K_sp"][:60, :60])
+    Gx = [[g[0], g[1], {e: 1 for e in g[0]}, "extra", 7] for g in G[:50]]      # edge labels + extras
+    assert np.array_equal(gk.WeisfeilerLehman(n_iter=5).fit_transform(Gx), z["K_wl5"][:50, :50])
+    gkk = gk.GraphKernel(kernel="WL", normalize=True).fit(G[:120])
+    wl = gk.WeisfeilerLehman(normalize=True).fit(G[:120])
+    assert np.array_equal(gkk.transform(G[120:]), wl.transform(G[120:]))

@@ -180,3 +180,31 @@ def test_c_abi_exports_every_declared_symbol():
     if _lib.device_count() == 0:                         # product path fails loudly without a GPU
         with pytest.raises(_lib.GkError):
             WeisfeilerLehman(n_iter=1).fit_transform(random_labelled_graphs(3, 3, 5, 0.5, 2, 0))
+
+
+def test_graph_kernel_dispatcher():
+    """grakel/graph_kernels.py:452-554 for the accelerated kernels."""
+    from grakel_amd import GraphKernel
+    gk = GraphKernel(kernel=[{"name": "weisfeiler_lehman", "n_iter": 3}, {"name": "vertex_histogram"}],
+                     normalize=True)
+    gk.initialize()
+    assert type(gk.kernel_) is WeisfeilerLehman and gk.kernel_.n_iter == 3 and gk.kernel_.normalize
+    gk.kernel_.initialize()
+    assert gk.kernel_._base_graph_kernel is VertexHistogram
+    for name, cls in (("WL", WeisfeilerLehman), ("VH", VertexHistogram), ("ST-WL", VertexHistogram),
+                      ("SP", ShortestPath), ("shortest_path", ShortestPath)):
+        g = GraphKernel(kernel=name)
+        g.initialize()
+        assert type(g.kernel_) is cls
+    g = GraphKernel(kernel={"name": "shortest_path", "with_labels": False})
+    g.initialize()
+    assert g.kernel_.with_labels is False
+    for bad in ("random_walk", "CORE", {"name": "SP", "as_attributes": True}):
+        with pytest.raises(NotImplementedError):
+            GraphKernel(kernel=bad).initialize()
+    with pytest.raises(ValueError):
+        GraphKernel(kernel="nope").initialize()
+    with pytest.raises(NotImplementedError):
+        GraphKernel(kernel="WL", Nystroem=20).initialize()
+    assert sorted(GraphKernel().get_params()) == ['Nystroem', 'kernel', 'n_jobs', 'normalize',
+                                                  'random_state', 'verbose']
