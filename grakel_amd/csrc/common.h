@@ -151,6 +151,7 @@ struct LevelTriples {
     i32* tstart = nullptr;     // [n_nodes+1] first triple of each label run
     i32* colid = nullptr;      // [n_nodes]   dense column id per label run, -2 rare, -1 dead
     i32* low_runs = nullptr;   // [n_nodes]   compact list of the rare label runs
+    i32* wide = nullptr;       // [n_nodes+1] 1 when some count of the run exceeds the int8 range
     i64 n_low = 0;
 };
 
@@ -168,6 +169,10 @@ struct gk_feat {
     i64 n_rows_pad = 0;
     int dtype = 0;              // 0: int8 Phi, 1: f64 Phi
     void* phi = nullptr;        // [n_rows_pad][n_cols_pad]
+    // dense columns holding a count > 127 cannot be int8 operands: they form a (usually
+    // narrow) float64 side operand whose product is accumulated onto K after the int8 GEMM
+    i64 n_cols_wide = 0, n_cols_wide_pad = 0;
+    double* phi_w = nullptr;    // [n_rows_pad][n_cols_wide_pad]
     double* K = nullptr;        // last Gram output (device)
     i64 K_rows = 0, K_cols = 0;
     double last_flops = 0, last_ms = 0;

@@ -68,7 +68,8 @@ struct TripleEmit {
 // graph of these counts == sum over its triples of count^2, so the exact self similarity needs
 // no atomics (each node is written once per level).  Also tracks the largest count.
 __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __restrict__ tri_of,
-                                  const i32* __restrict__ tri_pos, u32* __restrict__ node_acc,
+                                  const i32* __restrict__ tri_pos, const i32* __restrict__ tri_run,
+                                  i32* __restrict__ wide, int wide_above, u32* __restrict__ node_acc,
                                   u32* __restrict__ meta, int level, int n_levels, i64 n) {
     __shared__ u32 wmax[4];
     i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,6 +77,7 @@ __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __res
     if (k < n) {
         const i32 t = (i32)tri_of[k];
         c = (u32)(tri_pos[t + 1] - tri_pos[t]);
+        if ((int)c > wide_above) wide[tri_run[t]] = 1;       // benign race: all writers store 1
         i32 v = perm[k];
         node_acc[v] = (level == 0 ? 0u : node_acc[v]) + c;
     }
@@ -114,7 +116,7 @@ __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* 
 // scan value packs (low << 32 | dense) so one pass yields both running counts.
 struct ColumnIds {
     const i32* tstart; const i32* tri_graph; i32* colid; u32* meta; int level; int symmetric; i32 n_fit;
-    i32 low_df; i32* low_runs;
+    i32 low_df; i32* low_runs; const i32* wide;
     __device__ __forceinline__ u64 value(i64 r) const {
         if (r >= (i64)meta[META_R(level)]) return 0ull;
         const i32 t0 = tstart[r], t1 = tstart[r + 1];
@@ -122,20 +124,49 @@ struct ColumnIds {
         if (symmetric) useful = (t1 - t0) >= 2;
         else useful = tri_graph[t0] < n_fit && tri_graph[t1 - 1] >= n_fit;
         if (!useful) return 0ull;
-        return (t1 - t0) < low_df ? (1ull << 32) : 1ull;
+        if ((t1 - t0) < low_df) return 1ull << 32;
+        return wide[r] ? (1ull << 63) : 1ull;     // bit 63: dense but not int8-able (toggles only itself)
     }
     __device__ __forceinline__ void emit(i64 r, u64 v, u64 incl) const {
         const u32 base = level > 0 ? meta[META_C(level - 1)] : 0u;
-        colid[r] = (v & 1ull) ? (i32)(base + (u32)(incl & 0xffffffffull) - 1) : ((v >> 32) ? -2 : -1);
-        if (v >> 32) low_runs[(u32)(incl >> 32) - 1] = (i32)r;      // compact list for gram_low_kernel
+        const u32 rare = (u32)(v >> 32) & 0x7fffffffu;
+        colid[r] = (v & 1ull) ? (i32)(base + (u32)(incl & 0xffffffffull) - 1)
+                              : ((v >> 63) ? -3 : (rare ? -2 : -1));
+        if (rare) low_runs[((u32)(incl >> 32) & 0x7fffffffu) - 1] = (i32)r;   // compact list for gram_low_kernel
     }
 };
 
 __global__ void feat_colbase_kernel(u32* __restrict__ meta, const u64* __restrict__ total, int level, int n_levels) {
     const u64 t = *total;
     meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + (u32)(t & 0xffffffffull);
-    meta[3 * n_levels + 1] += (u32)(t >> 32);     // low columns over all levels
-    meta[3 * n_levels + 4 + level] = (u32)(t >> 32);   // ... and of this level
+    meta[3 * n_levels + 1] += (u32)(t >> 32) & 0x7fffffffu;     // low columns over all levels
+    meta[3 * n_levels + 4 + level] = (u32)(t >> 32) & 0x7fffffffu;   // ... and of this level
+}
+
+// second pass (only when some count exceeded 127): ids for the float64 side operand
+struct ColumnIdsWide {
+    i32* colid; u32* meta; int n_levels;
+    __device__ __forceinline__ u32 value(i64 r) const { return colid[r] == -3 ? 1u : 0u; }
+    __device__ __forceinline__ void emit(i64 r, u32 w, u32 incl) const {
+        if (w) colid[r] = -4 - (i32)(meta[3 * n_levels + 2] + incl - 1);
+    }
+};
+
+__global__ void feat_widebase_kernel(u32* __restrict__ meta, const u32* __restrict__ total, int n_levels) {
+    meta[3 * n_levels + 2] += *total;
+}
+
+__global__ void feat_scatter_mixed_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_graph,
+                                          const i32* __restrict__ tri_run, const i32* __restrict__ colid,
+                                          const u32* __restrict__ meta, int level, int8_t* __restrict__ phi,
+                                          i64 ld, double* __restrict__ phi_w, i64 ldw) {
+    const u32 Tn = meta[META_T(level)];
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tn) return;
+    const i32 c = colid[tri_run[t]];
+    const i32 cnt = tri_pos[t + 1] - tri_pos[t];
+    if (c >= 0) phi[(i64)tri_graph[t] * ld + c] = (int8_t)cnt;
+    else if (c <= -4) phi_w[(i64)tri_graph[t] * ldw + (-4 - c)] = (double)cnt;
 }
 
 template <typename T>
@@ -154,11 +185,11 @@ extern "C" int gk_features_destroy(gk_feat* f) {
     if (!f) return GK_OK;
     gk_ctx* ctx = f->ctx;
     for (auto& L : f->lev) {
-        void* ptrs[] = {L.tri_pos, L.tri_graph, L.tri_run, L.tstart, L.colid, L.low_runs};
+        void* ptrs[] = {L.tri_pos, L.tri_graph, L.tri_run, L.tstart, L.colid, L.low_runs, L.wide};
         for (void* p : ptrs)
             if (p) gk_dev_free(ctx, p);
     }
-    void* ptrs[] = {f->meta, f->selfk, f->phi, f->K};
+    void* ptrs[] = {f->meta, f->selfk, f->phi, f->phi_w, f->K};
     for (void* p : ptrs)
         if (p) gk_dev_free(ctx, p);
     delete f;
@@ -205,9 +236,15 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
         gk_set_error("gk_features_build: batch has no graph_ptr");
         return fail(GK_ERR_STATE);
     }
+    // int8 operands need counts <= 127 and every Gram entry < 2^31:
+    // K_ij <= sqrt(K_ii K_jj) <= n_levels * max_graph_nodes^2.  If the bound fails everything
+    // dense goes to the float64 operand (wide_above = -1 flags every run).
+    const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
+    f->dtype = bound < 2147483647.0 ? 0 : 1;
+    const int wide_above = f->dtype == 0 ? 127 : -1;
     for (int l = 0; l < n_levels && V > 0; ++l) {
         LevelTriples& L = f->lev[l];
-        i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid, &L.low_runs};
+        i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid, &L.low_runs, &L.wide};
         for (i32** a : arrs) {
             if ((r = gk_dev_alloc(ctx, &q, (size_t)(V + 1) * 4))) return fail(r);
             *a = (i32*)q;
@@ -218,8 +255,11 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
         TripleEmit te{perm, b->node_graph, flag.p, L.tri_pos, L.tri_graph, L.tri_run, L.tstart, cflag.p,
                       f->meta, l, V};
         if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, V, nullptr))) return fail(r);
-        feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, node_acc.p, f->meta, l, n_levels, V);
-        ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df, L.low_runs};
+        if (gk_zero_async(ctx, L.wide, (size_t)(V + 1) * 4) != GK_OK) return fail(GK_ERR_HIP);
+        feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, L.tri_run, L.wide, wide_above,
+                                                                     node_acc.p, f->meta, l, n_levels, V);
+        ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df,
+                     L.low_runs, L.wide};
         if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, V, ctotal64.p))) return fail(r);
         feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, ctotal64.p, l, n_levels);
     }
@@ -238,27 +278,44 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     f->max_count = h[3 * n_levels];
     f->n_low_cols = h[3 * n_levels + 1];
     for (int l = 0; l < n_levels; ++l) f->lev[l].n_low = h[3 * n_levels + 4 + l];
-    // int8 operands need counts <= 127 and every Gram entry < 2^31:
-    // K_ij <= sqrt(K_ii K_jj) <= n_levels * max_graph_nodes^2
-    const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
-    f->dtype = (f->max_count <= 127 && bound < 2147483647.0) ? 0 : 1;
-    const i64 esz = f->dtype == 0 ? 1 : 8;
+    // ids of the float64 side operand (second pass, only when a dense column is too wide for int8)
+    f->n_cols_wide = 0;
+    if (V > 0 && (f->max_count > 127 || f->dtype == 1)) {
+        Tmp<u32> wtotal(ctx);
+        if ((r = wtotal.alloc(1))) return fail(r);
+        for (int l = 0; l < n_levels; ++l) {
+            ColumnIdsWide cw{f->lev[l].colid, f->meta, n_levels};
+            if ((r = gk_scan_fn<u32, ColumnIdsWide>(ctx, cw, V, wtotal.p))) return fail(r);
+            feat_widebase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, wtotal.p, n_levels);
+        }
+        u32 hw = 0;
+        if (hipMemcpyAsync(&hw, f->meta + 3 * n_levels + 2, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            gk_set_error("gk_features_build: %s", hipGetErrorString(hipGetLastError()));
+            return fail(GK_ERR_HIP);
+        }
+        f->n_cols_wide = hw;
+    }
     f->n_cols_pad = round_up(f->n_cols > 0 ? f->n_cols : 1, 128);
     f->n_rows_pad = round_up(N, 256) + 256;   // slack so that tile loads never need row guards
-    const size_t phi_bytes = (size_t)f->n_rows_pad * f->n_cols_pad * esz;
+    const size_t phi_bytes = (size_t)f->n_rows_pad * f->n_cols_pad;
     if ((r = gk_dev_alloc(ctx, &q, phi_bytes))) return fail(r);
     f->phi = q;
     if (gk_zero_async(ctx, f->phi, phi_bytes) != GK_OK) return fail(GK_ERR_HIP);
+    if (f->n_cols_wide > 0) {
+        f->n_cols_wide_pad = round_up(f->n_cols_wide, 16);
+        const size_t wb = (size_t)f->n_rows_pad * f->n_cols_wide_pad * 8;
+        if ((r = gk_dev_alloc(ctx, &q, wb))) return fail(r);
+        f->phi_w = (double*)q;
+        if (gk_zero_async(ctx, f->phi_w, wb) != GK_OK) return fail(GK_ERR_HIP);
+    }
     for (int l = 0; l < n_levels && V > 0; ++l) {
         LevelTriples& L = f->lev[l];
         u32 T = h[META_T(l)];
         if (T == 0) continue;
-        if (f->dtype == 0)
-            feat_scatter_kernel<int8_t><<<grid_for(T, 256), 256, 0, ctx->stream>>>(
-                L.tri_pos, L.tri_graph, L.tri_run, L.colid, f->meta, l, (int8_t*)f->phi, f->n_cols_pad);
-        else
-            feat_scatter_kernel<double><<<grid_for(T, 256), 256, 0, ctx->stream>>>(
-                L.tri_pos, L.tri_graph, L.tri_run, L.colid, f->meta, l, (double*)f->phi, f->n_cols_pad);
+        feat_scatter_mixed_kernel<<<grid_for(T, 256), 256, 0, ctx->stream>>>(
+            L.tri_pos, L.tri_graph, L.tri_run, L.colid, f->meta, l, (int8_t*)f->phi, f->n_cols_pad,
+            f->phi_w, f->n_cols_wide_pad);
     }
     if (hipGetLastError() != hipSuccess) {
         gk_set_error("gk_features_build: kernel launch failed");
@@ -271,11 +328,11 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
 extern "C" int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* n_cols_low, int64_t* nnz,
                                 int64_t* max_count, int* dtype) {
     GK_ARG(f, "gk_features_info: null");
-    if (n_cols_kept) *n_cols_kept = f->n_cols;
+    if (n_cols_kept) *n_cols_kept = f->n_cols + f->n_cols_wide;
     if (n_cols_low) *n_cols_low = f->n_low_cols;
     if (nnz) *nnz = f->nnz;
     if (max_count) *max_count = f->max_count;
-    if (dtype) *dtype = f->dtype;
+    if (dtype) *dtype = (f->n_cols_wide > 0 && f->n_cols == 0) ? 1 : 0;   // 1: only the float64 operand is in use
     return GK_OK;
 }
 
@@ -291,13 +348,11 @@ extern "C" int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk) {
 extern "C" int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi) {
     GK_ARG(ctx && f && out_phi, "gk_features_debug_phi: null argument");
     const i64 N = f->n_graphs, D = f->n_cols, ld = f->n_cols_pad;
-    const size_t esz = f->dtype == 0 ? 1 : 8;
-    std::vector<unsigned char> h((size_t)N * ld * esz);
+    std::vector<unsigned char> h((size_t)N * ld);
     GK_HIP_CHECK(hipMemcpyAsync(h.data(), f->phi, h.size(), hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (i64 i = 0; i < N; ++i)
         for (i64 j = 0; j < D; ++j)
-            out_phi[i * D + j] = f->dtype == 0 ? (double)((const int8_t*)h.data())[i * ld + j]
-                                               : ((const double*)h.data())[i * ld + j];
+            out_phi[i * D + j] = (double)((const int8_t*)h.data())[i * ld + j];
     return GK_OK;
 }

@@ -557,7 +557,7 @@ static int launch_glds(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b
 __global__ __launch_bounds__(256) void gram_f64_kernel(
     const double* __restrict__ A, const double* __restrict__ B, i64 ld, int k_tiles,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
-    int symmetric, i64 n_fit, int normalize, int tiles_n) {
+    int symmetric, i64 n_fit, int normalize, int tiles_n, int accumulate) {
     __shared__ double sA[GD_BM * GD_LD];
     __shared__ double sB[GD_BN * GD_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -605,9 +605,12 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
             for (int r = 0; r < 4; ++r) {
                 const i64 row = (i64)bm * GD_BM + wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
                 if (row < M && col < N) {
-                    double v = finish_entry(acc[mt][nt][r], row_base + row, col, symmetric != 0, selfk,
-                                            n_fit, normalize);
-                    K[row * N + col] = v;
+                    if (accumulate) {       // K already holds the int8 product (and selfk on the diagonal)
+                        if (!(symmetric && row_base + row == col)) K[row * N + col] += acc[mt][nt][r];
+                    } else {
+                        K[row * N + col] = finish_entry(acc[mt][nt][r], row_base + row, col, symmetric != 0,
+                                                        selfk, n_fit, normalize);
+                    }
                 }
             }
         }
@@ -665,9 +668,9 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     GK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
     double tiles_done = (double)M * n_cols;
     const int normalize_req = normalize;
-    const bool has_low = f->n_low_cols > 0;
-    if (has_low) normalize = 0;        // normalise after the pair updates instead of in the epilogue
-    if (f->dtype == 0) {
+    const bool has_low = f->n_low_cols > 0, has_wide = f->n_cols_wide > 0;
+    if (has_low || has_wide) normalize = 0;   // normalise after the extra terms instead of in the epilogue
+    {
         const int8_t* phi = (const int8_t*)f->phi;
         const int8_t* pa = phi + first_row_graph * f->n_cols_pad;
         // full symmetric job: only tiles on/above the diagonal are computed, each written twice
@@ -694,15 +697,16 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
         } else {
             GK_TRY((launch_glds<2, 4, 4, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
         }
-    } else {
-        const double* phi = (const double*)f->phi;
-        const int tiles_m = (int)cdiv(M, GD_BM), tiles_n = (int)cdiv(n_cols, GD_BN);
-        gram_f64_kernel<<<dim3((unsigned)(tiles_m * (i64)tiles_n)), dim3(256), 0, ctx->stream>>>(
-            phi + first_row_graph * f->n_cols_pad, phi, f->n_cols_pad, (int)(f->n_cols_pad / GD_BK),
-            f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_n);
     }
     GK_HIP_CHECK(hipGetLastError());
     GK_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    if (has_wide) {   // float64 side operand: K += Phi_w . Phi_w^T (diagonal excluded: it is selfk)
+        const double* pw = f->phi_w;
+        const int tiles_m = (int)cdiv(M, GD_BM), tiles_n = (int)cdiv(n_cols, GD_BN);
+        gram_f64_kernel<<<dim3((unsigned)(tiles_m * (i64)tiles_n)), dim3(256), 0, ctx->stream>>>(
+            pw + first_row_graph * f->n_cols_wide_pad, pw, f->n_cols_wide_pad, (int)(f->n_cols_wide_pad / GD_BK),
+            f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, 0, tiles_n, 1);
+    }
     if (has_low) {
         for (int l = 0; l < f->n_levels; ++l) {
             LevelTriples& L = f->lev[l];
@@ -711,6 +715,8 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
                 L.low_runs, L.n_low, L.tri_pos, L.tri_graph, L.tstart, K, n_cols, row_lo, row_hi,
                 f->symmetric ? 1 : 0, f->n_fit);
         }
+    }
+    if (has_low || has_wide) {
         if (normalize_req)
             gram_normalize_kernel<<<dim3((unsigned)cdiv(M * n_cols, 256)), dim3(256), 0, ctx->stream>>>(
                 K, f->selfk, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize_req);
