@@ -12,6 +12,7 @@
 //                    of the shared dictionary code leaves (key, graph) runs = Phi triples.
 // Distances are exact int32 sums of positive integer edge weights (unit by default).
 #include "common.h"
+#include <stdlib.h>
 
 #define SP_INF 0x3f000000
 #define SP_THREADS 256
@@ -38,7 +39,7 @@ __global__ void sp_sq_kernel(const i32* __restrict__ graph_ptr, u64* __restrict_
 }
 
 __device__ __forceinline__ void block_count_max(u32 cnt, u32 mx, u32* pair_count_g, u32* maxd) {
-    __shared__ u32 rc[SP_THREADS / 64], rm[SP_THREADS / 64];
+    __shared__ u32 rc[16], rm[16];
     for (int off = 32; off > 0; off >>= 1) {
         cnt += __shfl_down(cnt, off, 64);
         u32 o = __shfl_down(mx, off, 64);
@@ -48,25 +49,28 @@ __device__ __forceinline__ void block_count_max(u32 cnt, u32 mx, u32* pair_count
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 c = 0, m = 0;
-        for (int i = 0; i < SP_THREADS / 64; ++i) { c += rc[i]; m = rm[i] > m ? rm[i] : m; }
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { c += rc[i]; m = rm[i] > m ? rm[i] : m; }
         atomicAdd(pair_count_g, c);
         if (m) atomicMax(maxd, m);
     }
 }
 
-__global__ __launch_bounds__(SP_THREADS) void sp_fw_kernel(
+// One workgroup per graph with n in (n_lo, n_hi]; blockDim = 256 for small graphs, 1024 for the
+// large ones: a single 4-wave workgroup leaves one wave per SIMD and cannot hide the ~100-cycle
+// LDS latency of the relaxation (measured 3.3 us per pivot at n = 110), 16 waves can.
+__global__ __launch_bounds__(1024) void sp_fw_kernel(
     const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
     const i32* __restrict__ w, const u64* __restrict__ dist_ptr, i32* __restrict__ dist,
-    u32* __restrict__ pair_count, u32* __restrict__ maxd, int cap) {
+    u32* __restrict__ pair_count, u32* __restrict__ maxd, int n_lo, int n_hi) {
     extern __shared__ __attribute__((aligned(16))) i32 d[];
-    const int g = blockIdx.x, tid = threadIdx.x;
+    const int g = blockIdx.x, tid = threadIdx.x, NT = blockDim.x, NW = blockDim.x >> 6;
     const i32 v0 = graph_ptr[g];
     const int n = graph_ptr[g + 1] - v0;
-    if (n > cap || n == 0) return;
+    if (n <= n_lo || n > n_hi) return;
     const int ld = n | 1;
-    for (int idx = tid; idx < n * ld; idx += SP_THREADS) d[idx] = SP_INF;
+    for (int idx = tid; idx < n * ld; idx += NT) d[idx] = SP_INF;
     __syncthreads();
-    for (int i = tid; i < n; i += SP_THREADS) {
+    for (int i = tid; i < n; i += NT) {
         const i32 e0 = row_ptr[v0 + i], e1 = row_ptr[v0 + i + 1];
         for (i32 e = e0; e < e1; ++e) {
             int j = col_idx[e] - v0;
@@ -76,21 +80,36 @@ __global__ __launch_bounds__(SP_THREADS) void sp_fw_kernel(
         d[i * ld + i] = 0;                      // np.fill_diagonal(dist, 0): graph.py:1786
     }
     __syncthreads();
+    // Thread (tx, ty): columns j = tx, tx+64, ...; rows i = ty, ty+NW, ...  Per pivot k the row
+    // d[k][j] is read once into a register and four rows are relaxed at a time with independent
+    // LDS loads (a one-row-at-a-time loop is a chain of dependent LDS round trips).
     const int tx = tid & 63, ty = tid >> 6;
     for (int k = 0; k < n; ++k) {
-        for (int i = ty; i < n; i += SP_THREADS / 64) {
-            const i32 dik = d[i * ld + k];
-            if (dik < SP_INF)
-                for (int j = tx; j < n; j += 64) {
-                    i32 via = dik + d[k * ld + j];
-                    if (via < d[i * ld + j]) d[i * ld + j] = via;
+        for (int j = tx; j < n; j += 64) {
+            const i32 dkj = d[k * ld + j];
+            if (dkj < SP_INF) {
+                int i = ty;
+                for (; i + 3 * NW < n; i += 4 * NW) {
+                    const int i1 = i + NW, i2 = i + 2 * NW, i3 = i + 3 * NW;
+                    const i32 a0 = d[i * ld + k], a1 = d[i1 * ld + k], a2 = d[i2 * ld + k], a3 = d[i3 * ld + k];
+                    const i32 c0 = d[i * ld + j], c1 = d[i1 * ld + j], c2 = d[i2 * ld + j], c3 = d[i3 * ld + j];
+                    const i32 u0 = a0 + dkj, u1 = a1 + dkj, u2 = a2 + dkj, u3 = a3 + dkj;
+                    if (u0 < c0) d[i * ld + j] = u0;
+                    if (u1 < c1) d[i1 * ld + j] = u1;
+                    if (u2 < c2) d[i2 * ld + j] = u2;
+                    if (u3 < c3) d[i3 * ld + j] = u3;
                 }
+                for (; i < n; i += NW) {
+                    const i32 u = d[i * ld + k] + dkj;
+                    if (u < d[i * ld + j]) d[i * ld + j] = u;
+                }
+            }
         }
         __syncthreads();
     }
     u32 cnt = 0, mx = 0;
     i32* out = dist + dist_ptr[g];
-    for (int i = ty; i < n; i += SP_THREADS / 64)
+    for (int i = ty; i < n; i += NW)
         for (int j = tx; j < n; j += 64) {
             i32 x = d[i * ld + j];
             out[i * n + j] = x;
@@ -200,12 +219,21 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     const int cap = sp_fw_cap();
     const int nmax = b->max_graph_nodes;
     {
-        int nfw = nmax < cap ? nmax : cap;
-        size_t lds = (size_t)nfw * (nfw | 1) * 4;
-        if (lds > 64 * 1024)
-            GK_HIP_CHECK(hipFuncSetAttribute((const void*)sp_fw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        sp_fw_kernel<<<dim3((unsigned)N), SP_THREADS, lds, ctx->stream>>>(
-            b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, cap);
+        // two launches over all graphs: small graphs (n <= 48) with 256 threads, the rest up to
+        // the LDS cap with 1024 threads; a launch's workgroups exit at once for the other class
+        const int split = 48;
+        const int nsmall = nmax < split ? nmax : split;
+        size_t lds = (size_t)nsmall * (nsmall | 1) * 4;
+        sp_fw_kernel<<<dim3((unsigned)N), 256, lds, ctx->stream>>>(
+            b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, 0, split);
+        if (nmax > split) {
+            const int nfw = nmax < cap ? nmax : cap;
+            lds = (size_t)nfw * (nfw | 1) * 4;
+            if (lds > 64 * 1024)
+                GK_HIP_CHECK(hipFuncSetAttribute((const void*)sp_fw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            sp_fw_kernel<<<dim3((unsigned)N), 1024, lds, ctx->stream>>>(
+                b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, split, cap);
+        }
     }
     if (nmax > cap) {
         GK_ARG(nmax <= SP_ROW_MAX_N, "ShortestPath: graphs above 32768 vertices are not supported");
