@@ -1,15 +1,22 @@
 // Gram matrix  K = Phi_rows . Phi_cols^T  on the MFMA units of gfx950.
 //
-// Label counts are small non-negative integers, so the product is EXACT integer arithmetic:
-//   dtype 0: int8 operands, v_mfma_i32_32x32x32_i8, int32 accumulate (counts <= 127 and
-//            K < 2^31 are checked when the features are built) -- the fast path, 2x the bf16
-//            MFMA rate and bit-exact versus the reference's float64 result;
-//   dtype 1: float64 operands, v_mfma_f64_16x16x4_f64 -- general path (any count, exact while
-//            K < 2^53), used by ShortestPath histograms with counts > 127.
-// The epilogue fuses what the reference does in three extra N^2 passes: the per-level sum
-// (all levels are concatenated along K), the diagonal (graph-unique label columns are not
-// in Phi_s; K_ii is written from the exact selfk vector instead) and the normalisation
-// K_ij / sqrt(K_ii K_jj) (weisfeiler_lehman.py:323-328, kernel.py:195-204).
+// Label counts are small non-negative integers, so the product is EXACT integer arithmetic.
+// A launch sequence (gk_gram_launch) is:
+//   1. gram_i8_glds_kernel : dense columns with counts <= 127 as int8 operands,
+//                            v_mfma_i32_32x32x32_i8, int32 accumulate (K < 2^31 is checked when the
+//                            features are built): 2x the bf16 MFMA rate, bit-exact versus the
+//                            reference's float64 result.  Writes every entry of K (float64).
+//   2. gram_f64_kernel     : dense columns holding a count > 127 (typical for ShortestPath
+//                            histograms) form a narrow float64 side operand,
+//                            v_mfma_f64_16x16x4_f64, accumulated onto K (exact while K < 2^53).
+//   3. gram_low_kernel     : useful columns present in < 32 graphs never enter a dense operand;
+//                            their df*(df-1) pair products are added as float64 atomics.
+//   4. gram_normalize_kernel, only when 2. or 3. ran and normalisation was requested.
+// The int8 epilogue fuses what the reference does in three extra N^2 passes: the per-level sum
+// (all levels are concatenated along K), the diagonal (graph-unique label columns are not in
+// Phi_s; K_ii is written from the exact selfk vector instead) and -- when no extra term
+// follows -- the normalisation K_ij / sqrt(K_ii K_jj) (weisfeiler_lehman.py:323-328,
+// kernel.py:195-204).
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -34,53 +41,7 @@ __device__ __forceinline__ double finish_entry(double val, i64 grow, i64 gcol, b
     return val;
 }
 
-// ---------------------------------------------------------------------------------------
-// int8 path: 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave as 2x2
-// MFMA 32x32 tiles), K-step 64 bytes, register-staged double buffering through LDS.
-// LDS rows are padded to 80 B so that both the ds_write_b128 (8-lane groups) and the
-// ds_read_b128 (16-lane groups) are bank-conflict free: slot = (5*row + c) mod 16.
-// ---------------------------------------------------------------------------------------
-#define GI_BM 128
-#define GI_BN 128
-#define GI_BK 64
-#define GI_LD 80
-
-#define GRAM_I8_EPILOGUE \
-    const bool mirror = tri && bm != bn; \
-    const bool even = (N & 1) == 0; \
-    _Pragma("unroll") \
-    for (int mt = 0; mt < 2; ++mt) \
-    _Pragma("unroll") \
-        for (int nt = 0; nt < 2; ++nt) { \
-            const i64 col = (i64)bn * GI_BN + wn * 64 + nt * 32 + (lane & 31); \
-    _Pragma("unroll") \
-            for (int q = 0; q < 4; ++q) { \
-                const i64 row0 = (i64)bm * GI_BM + wm * 64 + mt * 32 + 8 * q + 4 * (lane >> 5); \
-                double v[4]; \
-    _Pragma("unroll") \
-                for (int j = 0; j < 4; ++j) { \
-                    const i64 row = row0 + j; \
-                    v[j] = 0.0; \
-                    if (row < M && col < N) { \
-                        v[j] = finish_entry((double)acc[mt][nt][4 * q + j], row_base + row, col, \
-                                            symmetric != 0, selfk, n_fit, normalize); \
-                        K[row * N + col] = v[j]; \
-                    } \
-                } \
-                if (mirror && col < N) { \
-                    double* dst = K + col * N + row0; \
-                    if (even && row0 + 3 < M) { \
-                        *(double2*)(dst) = make_double2(v[0], v[1]); \
-                        *(double2*)(dst + 2) = make_double2(v[2], v[3]); \
-                    } else { \
-    _Pragma("unroll") \
-                        for (int j = 0; j < 4; ++j) \
-                            if (row0 + j < M) dst[j] = v[j]; \
-                    } \
-                } \
-            } \
-        } \
-    /* end */
+#define GI_BK 64     // K-step in bytes (two 32-deep MFMA slices)
 
 // Block -> output tile.  Workgroup b is observed to run on XCD b % 8 (speed assumption only),
 // so consecutive ids of ONE XCD (b>>3) walk 8x8-tile patches: the ~128 tiles resident on an
@@ -119,76 +80,6 @@ static inline i64 gram_grid_blocks(int tiles_m, int tiles_n, int sym, int patch)
     const i64 pm = (tiles_m + P - 1) / P, pn = (tiles_n + P - 1) / P;
     const i64 np = sym ? (pm * pn - pm * (pm - 1) / 2) : pm * pn;   // sym: pm == pn
     return ((np + 7) / 8) * 8 * P * P;
-}
-
-__global__ __launch_bounds__(256, 2) void gram_i8_kernel(
-    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles,
-    const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
-    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch) {
-    __shared__ __attribute__((aligned(16))) int8_t sA[2][GI_BM * GI_LD];
-    __shared__ __attribute__((aligned(16))) int8_t sB[2][GI_BN * GI_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    int bm, bn;
-    if (!gram_map_tile(blockIdx.x, tiles_m, tiles_n, tri, patch, bm, bn)) return;
-
-    const int lrow = tid >> 2, lkc = tid & 3;   // 16-byte chunk owned by this thread (and +64 rows)
-    const int8_t* gA = A + ((i64)bm * GI_BM + lrow) * ld + lkc * 16;
-    const int8_t* gB = B + ((i64)bn * GI_BN + lrow) * ld + lkc * 16;
-    const i64 half = 64 * ld;
-    const int soff = lrow * GI_LD + lkc * 16;
-
-    v16i acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    v4i ra0 = *(const v4i*)(gA), ra1 = *(const v4i*)(gA + half);
-    v4i rb0 = *(const v4i*)(gB), rb1 = *(const v4i*)(gB + half);
-    *(v4i*)(&sA[0][soff]) = ra0;
-    *(v4i*)(&sA[0][soff + 64 * GI_LD]) = ra1;
-    *(v4i*)(&sB[0][soff]) = rb0;
-    *(v4i*)(&sB[0][soff + 64 * GI_LD]) = rb1;
-    __syncthreads();
-
-    const int a_off = (wm * 64 + (lane & 31)) * GI_LD + (lane >> 5) * 16;
-    const int b_off = (wn * 64 + (lane & 31)) * GI_LD + (lane >> 5) * 16;
-
-    for (int kt = 0; kt < k_tiles; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < k_tiles;
-        if (more) {
-            const i64 go = (i64)(kt + 1) * GI_BK;
-            ra0 = *(const v4i*)(gA + go);
-            ra1 = *(const v4i*)(gA + go + half);
-            rb0 = *(const v4i*)(gB + go);
-            rb1 = *(const v4i*)(gB + go + half);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v4i a0 = *(const v4i*)(&sA[cur][a_off + ks * 32]);
-            v4i a1 = *(const v4i*)(&sA[cur][a_off + 32 * GI_LD + ks * 32]);
-            v4i b0 = *(const v4i*)(&sB[cur][b_off + ks * 32]);
-            v4i b1 = *(const v4i*)(&sB[cur][b_off + 32 * GI_LD + ks * 32]);
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (more) {
-            const int nxt = cur ^ 1;
-            *(v4i*)(&sA[nxt][soff]) = ra0;
-            *(v4i*)(&sA[nxt][soff + 64 * GI_LD]) = ra1;
-            *(v4i*)(&sB[nxt][soff]) = rb0;
-            *(v4i*)(&sB[nxt][soff + 64 * GI_LD]) = rb1;
-        }
-        __syncthreads();
-    }
-
-    GRAM_I8_EPILOGUE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -251,133 +142,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
             __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc[q] + go), (lds_void_t*)(st + sdst[q]), 16, 0, 0); \
     }
 
-    for (int p = 0; p < NS - 1; ++p)
-        if (p < k_tiles) GL_ISSUE(p);
-
-    // fragment reads: row rr, logical chunk cl = 2*ks + (lane>>5), physical = cl ^ ((rr>>2)&3)
-    const int fr = lane & 31, fh = lane >> 5;
-    int offa[TM][2], offb[TN][2];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int rr = wm * TM * 32 + i * 32 + fr;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) offa[i][ks] = rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int rr = wn * TN * 32 + j * 32 + fr;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) offb[j][ks] = BM * 64 + rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
-    }
-
-    for (int kt = 0; kt < k_tiles; ++kt) {
-        // own loads of stage kt have landed when at most (stages in flight after kt) * 4 remain
-        const int ahead = k_tiles - 1 - kt;
-        const int fly = ahead < NS - 2 ? ahead : NS - 2;
-        if (fly >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
-        else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();        // everyone's pieces of stage kt are in LDS; stage kt-1 is free
-        if (kt + NS - 1 < k_tiles) GL_ISSUE(kt + NS - 1);
-        const int8_t* st = smem + (kt % NS) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v4i af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const v4i*)(st + offa[i][ks]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *(const v4i*)(st + offb[j][ks]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-    }
-#undef GL_ISSUE
-
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool mirror = tri && bm != bn;     // off-diagonal tile of a symmetric job: also write K^T
-    const bool even = (N & 1) == 0;
-#pragma unroll
-    for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-            const i64 col = (i64)bn * BN + (wn * TN + nt) * 32 + (lane & 31);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const i64 row0 = (i64)bm * BM + (wm * TM + mt) * 32 + 8 * q + 4 * (lane >> 5);
-                double v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const i64 row = row0 + j;
-                    v[j] = 0.0;
-                    if (row < M && col < N) {
-                        v[j] = finish_entry((double)acc[mt][nt][4 * q + j], row_base + row, col,
-                                            symmetric != 0, selfk, n_fit, normalize);
-                        K[row * N + col] = v[j];           // 32 lanes -> 256 contiguous bytes
-                    }
-                }
-                if (mirror && col < N) {                    // K[col][row0..row0+3]: 32 B per lane
-                    double* dst = K + col * N + row0;
-                    if (even && row0 + 3 < M) {
-                        *(double2*)(dst) = make_double2(v[0], v[1]);
-                        *(double2*)(dst + 2) = make_double2(v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (row0 + j < M) dst[j] = v[j];
-                    }
-                }
-            }
-        }
-}
-
-template <int WM, int WN, int TM, int TN, int NS>
-__global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds2_kernel(
-    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles,
-    const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
-    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int ablate) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
-    constexpr int STAGE = (BM + BN) * 64;
-    constexpr int PPW = (BM + BN) / 16 / NW;                 // 1-KiB pieces per wave per stage
-    static_assert((BM + BN) % (16 * NW) == 0, "pieces must divide evenly over the waves");
-    extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // NS * STAGE, ONE array
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    int bm, bn;
-    if (!gram_map_tile(blockIdx.x, tiles_m, tiles_n, tri, patch, bm, bn)) return;
-
-    // staging: piece q of this wave covers rows [16*(wave*PPW+q), +16) of the (A rows, B rows) list
-    const int srow = lane >> 2;                              // row inside the piece
-    const int schunk = (lane & 3) ^ ((srow >> 2) & 3);       // logical chunk this lane fetches
-    const int8_t* gsrc[PPW];
-    int sdst[PPW];
-#pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-        const int r0 = (wave * PPW + q) * 16;
-        if (r0 < BM) gsrc[q] = A + ((i64)bm * BM + r0 + srow) * ld + schunk * 16;
-        else gsrc[q] = B + ((i64)bn * BN + (r0 - BM) + srow) * ld + schunk * 16;
-        sdst[q] = r0 * 64;
-    }
-
-    v16i acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-#define GL_ISSUE(KT)                                                                        \
-    {                                                                                       \
-        const i64 go = (i64)(KT) * GI_BK;                                                   \
-        int8_t* st = smem + ((KT) % NS) * STAGE;                                            \
-        _Pragma("unroll") for (int q = 0; q < PPW; ++q)                                     \
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc[q] + go), (lds_void_t*)(st + sdst[q]), 16, 0, 0); \
-    }
-
     // Software pipeline inside the K-step: while the MFMAs of one 32-deep K-slice run, the
     // fragments of the next slice are already being read from LDS, so the LDS phase and the
     // MFMA phase of the 8 barrier-synchronised waves overlap instead of alternating.
@@ -400,10 +164,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds2_kernel(
     }
 
     v4i fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa1[i] = (v4i){lane, 1, 2, 3};
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb1[j] = (v4i){3, 2, 1, lane};
     {   // own pieces of stage 0 landed: up to NS-1 later stages may stay in flight
         const int after = k_tiles - 1;
         const int fly = after < NS - 1 ? after : NS - 1;
@@ -424,24 +184,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds2_kernel(
     for (int kt = 0; kt < k_tiles; ++kt) {
         const int8_t* st = smem + (kt % NS) * STAGE;
         // ---- phase A: read slice 1 of stage kt, multiply slice 0
-        if (!(ablate & 4)) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa1[i] = *(const v4i*)(st + offa[i][1]);
+        for (int i = 0; i < TM; ++i) fa1[i] = *(const v4i*)(st + offa[i][1]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb1[j] = *(const v4i*)(st + offb[j][1]);
-        }
-        if (!(ablate & 2)) {
+        for (int j = 0; j < TN; ++j) fb1[j] = *(const v4i*)(st + offb[j][1]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa0[i]));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb0[j]));
-        }
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- stage hand-over: stage kt+1 must be complete, stage kt is fully read
         if (kt + 1 < k_tiles) {
@@ -455,28 +206,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds2_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (kt + NS < k_tiles && !(ablate & 1)) GL_ISSUE(kt + NS);       // overwrites the buffer of stage kt
+        if (kt + NS < k_tiles) GL_ISSUE(kt + NS);       // overwrites the buffer of stage kt
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase B: read slice 0 of stage kt+1, multiply slice 1
-        if (kt + 1 < k_tiles && !(ablate & 4)) {
+        if (kt + 1 < k_tiles) {
             const int8_t* sn = smem + ((kt + 1) % NS) * STAGE;
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa0[i] = *(const v4i*)(sn + offa[i][0]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb0[j] = *(const v4i*)(sn + offb[j][0]);
         }
-        if (!(ablate & 2)) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa1[i]));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb1[j]));
-        }
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef GL_ISSUE
@@ -525,21 +269,11 @@ static int launch_glds(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b
     constexpr int LDS = NS * (BM + BN) * 64;
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(n_cols, BN);
     const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch ? patch_sz : 0);
-    if (getenv("GK_GRAM_PIPE1")) {
-        auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
-            a, b, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
-            f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0);
-    } else {
-        auto kern = gram_i8_glds2_kernel<WM, WN, TM, TN, NS>;
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        const char* ab = getenv("GK_GRAM_ABLATE");    // perf forensics only (results are garbage)
-        kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
-            a, b, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
-            f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0,
-            ab ? atoi(ab) : 0);
-    }
+    auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
+    GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
+        a, b, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
+        f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0);
     *tiles_done = tri ? (double)tiles_m * (tiles_m + 1) / 2 * BM * BN : (double)M * n_cols;
     return GK_OK;
 }
@@ -677,23 +411,10 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
         const int tri = (f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
         const int patch = getenv("GK_GRAM_NO_PATCH") ? 0 : 1;
         const char* shape = getenv("GK_GRAM_TILE");
-        if (getenv("GK_GRAM_V1")) {
-            const int tiles_m = (int)cdiv(M, GI_BM), tiles_n = (int)cdiv(n_cols, GI_BN);
-            const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch ? GI_PATCH : 0);
-            gram_i8_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(
-                pa, phi, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
-                f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? GI_PATCH : 0);
-            if (tri) tiles_done = (double)tiles_m * (tiles_m + 1) / 2 * GI_BM * GI_BN;
-        } else if ((shape && !strcmp(shape, "128")) || (!shape && f->n_cols_pad < 8192)) {
+        if ((shape && !strcmp(shape, "128")) || (!shape && f->n_cols_pad < 8192)) {
             // short K: the 128x128 tile runs two workgroups per CU, so one tile's float64 store
             // epilogue overlaps the other's MFMA loop (measured 0.36 vs 0.41 ms at K = 3968)
             GK_TRY((launch_glds<2, 2, 2, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
-        } else if (shape && !strcmp(shape, "256x128")) {
-            GK_TRY((launch_glds<4, 2, 2, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
-        } else if (shape && !strcmp(shape, "256ns5")) {
-            GK_TRY((launch_glds<2, 4, 4, 2, 5>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
-        } else if (shape && !strcmp(shape, "256ns3")) {
-            GK_TRY((launch_glds<2, 4, 4, 2, 3>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
         } else {
             GK_TRY((launch_glds<2, 4, 4, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
         }
