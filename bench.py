@@ -29,12 +29,12 @@ sys.path.insert(0, ROOT)
 WORKLOAD = dict(N=10000, n=100, p=0.05, L=5, seed=0, n_iter=5)
 I8_DENSE_PEAK_TOPS = 5000.0      # int8 MFMA dense = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6
-# HBM-side bytes per launch of the Gram kernel on this exact workload, from the PMC passes
-# committed in profiles/r01_pmc_hbm_bytes.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in
-# separate runs): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md
-# "HBM") + WRITE_SIZE, KiB -> bytes.  Algorithmic floor: read Phi_s once (197 MB) + write K (800 MB).
-GRAM_PMC_TRAFFIC_BYTES = {(10000, "i8"): (2 * 1078133.1 + 798720.5) * 1024}
-
+# HBM-side bytes per launch of the MFMA Gram kernel on this exact workload (config 3, 3 937 dense
+# columns, 128x128 tiles), from the PMC passes committed in profiles/r01g_pmc_hbm_bytes.csv
+# (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs): 2 x FETCH_SIZE (gfx950 reports
+# half of a wide coalesced read, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.
+# Algorithmic floor: read Phi_s once (40 MB) + write the float64 K once (800 MB).
+GRAM_PMC_TRAFFIC_BYTES = {(10000, "i8"): (2 * 345427.15 + 795499.175) * 1024}
 
 def cpu_baseline(sample_graphs, cfg):
     """The CPU oracle (a literal restatement of the reference's algorithm) on a bounded sample
@@ -171,7 +171,8 @@ def main():
                        "label_counts": info.get("label_counts"), "gram_columns_dense": info.get("n_cols"),
                        "gram_columns_rare": info.get("n_cols_low")},
             "roofline": {
-                "kernel": "gram_i8_glds2_kernel<2,4,4,2,4>" if dtype == "i8" else "gram_f64_kernel",
+                "kernel": ("gram_i8_glds_kernel<2,2,2,2,4> (128x128 tile)" if (info.get("n_cols") or 0) < 8065
+                           else "gram_i8_glds_kernel<2,4,4,2,4> (256x256 tile)"),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "traffic": GRAM_PMC_TRAFFIC_BYTES.get((N, dtype)) if world == 1 else None,
@@ -183,7 +184,7 @@ def main():
                     "flops": alg_flops, "gram_phase_ms": (phases or {}).get("gram"),
                     "achieved": (alg_flops / ((phases or {}).get("gram") * 1e-3) / 1e12) if phases else None},
                 "note": "achieved = integer ops EXECUTED by the MFMA kernel per launch / its avg HIP-event "
-                        "duration (1 GPU: only the 256x256 tiles on/above the diagonal, mirrored on store; "
+                        "duration (1 GPU: only the tiles on/above the diagonal, mirrored on store; "
                         "only the dense columns -- label columns present in < 32 graphs are applied as exact "
                         "pair updates by gram_low_kernel, inside gram_phase_ms). The kernel also writes the "
                         "whole float64 K (N^2*8 B), which bounds it at ~0.13 ms by HBM."},
