@@ -460,3 +460,12 @@ def test_graph_kernel_wrapper_and_extras(gk, mutag_graphs):
     gkk = gk.GraphKernel(kernel="WL", normalize=True).fit(G[:120])
     wl = gk.WeisfeilerLehman(normalize=True).fit(G[:120])
     assert np.array_equal(gkk.transform(G[120:]), wl.transform(G[120:]))
+
+
+def test_tu_loader_batch_gives_the_reference_gram(gk, mutag_graphs, tmp_path):
+    from grakel_amd.datasets import read_tu
+    from test_host import _write_mutag_tu
+    G, z = mutag_graphs
+    batch, _ = read_tu(_write_mutag_tu(tmp_path, z), "MUTAG")
+    assert np.array_equal(gk.WeisfeilerLehman(n_iter=5).fit_transform(batch), z["K_wl5"])
+    assert np.array_equal(gk.VertexHistogram().fit_transform(batch), z["K_vh"])

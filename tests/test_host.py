@@ -208,3 +208,26 @@ def test_graph_kernel_dispatcher():
         GraphKernel(kernel="WL", Nystroem=20).initialize()
     assert sorted(GraphKernel().get_params()) == ['Nystroem', 'kernel', 'n_jobs', 'normalize',
                                                   'random_state', 'verbose']
+
+
+def _write_mutag_tu(tmp_path, z):
+    d = os.path.join(str(tmp_path), "MUTAG")
+    os.makedirs(d)
+    np.savetxt(os.path.join(d, "MUTAG_graph_indicator.txt"), z["node_graph"] + 1, fmt="%d")
+    np.savetxt(os.path.join(d, "MUTAG_node_labels.txt"), z["node_label"], fmt="%d")
+    with open(os.path.join(d, "MUTAG_A.txt"), "w") as f:
+        for a, b in zip(z["edge_src"].tolist(), z["edge_dst"].tolist()):
+            f.write("%d, %d\n" % (a, b))
+    np.savetxt(os.path.join(d, "MUTAG_graph_labels.txt"), np.arange(188) % 2 * 2 - 1, fmt="%d")
+    return str(tmp_path)
+
+
+def test_tu_loader_gives_the_same_batch_as_the_object_path(tmp_path, mutag_graphs):
+    """files -> CSR without per-graph Python objects (grakel/datasets/base.py:135-290)."""
+    from grakel_amd.datasets import read_tu
+    G, z = mutag_graphs
+    batch, classes = read_tu(_write_mutag_tu(tmp_path, z), "MUTAG")
+    ref, mapping = wl_batch_from_input(G)
+    assert classes.shape == (188,) and batch.n_graphs == 188 and batch.label_map == mapping
+    assert np.array_equal(batch.graph_ptr, ref.graph_ptr) and np.array_equal(batch.node_label, ref.node_label)
+    assert _adjacency_sets(batch) == _adjacency_sets(ref)
