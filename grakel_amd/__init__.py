@@ -2,10 +2,10 @@
 behind GraKeL's ``Kernel`` API (fit / transform / fit_transform / diagonal)."""
 from .batch import GraphBatch
 from .kernel import Kernel
-from .vertex_histogram import VertexHistogram
+from .vertex_histogram import VertexHistogram, EdgeHistogram
 from .weisfeiler_lehman import WeisfeilerLehman
 from .shortest_path import ShortestPath
 from .graph_kernels import GraphKernel
 
-__all__ = ["GraphBatch", "Kernel", "VertexHistogram", "WeisfeilerLehman", "ShortestPath", "GraphKernel"]
+__all__ = ["GraphBatch", "Kernel", "VertexHistogram", "EdgeHistogram", "WeisfeilerLehman", "ShortestPath", "GraphKernel"]
 __version__ = "0.1.0"

@@ -297,15 +297,21 @@ def wl_batch_from_input(X, fitted_labels=None, min_len=2, not_iterable=TypeError
     return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1)), mapping
 
 
-def vh_batch_from_input(X, fitted_labels=None):
-    """VertexHistogram only reads x[1].values() (vertex_histogram.py:96,107): no edges."""
+def vh_batch_from_input(X, fitted_labels=None, edge_labels=False):
+    """VertexHistogram only reads x[1].values() (vertex_histogram.py:96,107): no edges.
+    ``edge_labels``: EdgeHistogram reads x[2].values() of 3-element inputs instead
+    (edge_histogram.py:93-96); the "nodes" of the batch are then the labelled edges."""
     if isinstance(X, GraphBatch):
         return X, None
     msg = ('each element of X must be either a graph object or a list with at least a graph '
            'like object and node labels dict \n')
     sizes, values = [], []
-    for x in iter_elements(X, lambda n: n in (2, 3), msg):
-        L = x.get_labels(purpose="any") if _is_graph_object(x) else x[1]
+    len_ok = (lambda n: n == 3) if edge_labels else (lambda n: n in (2, 3))
+    for x in iter_elements(X, len_ok, msg):
+        if _is_graph_object(x):
+            L = x.get_labels(purpose="any", label_type="edge") if edge_labels else x.get_labels(purpose="any")
+        else:
+            L = x[2] if edge_labels else x[1]
         vals = list(L.values())
         sizes.append(len(vals))
         values.extend(vals)

@@ -13,13 +13,14 @@ from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils.validation import check_is_fitted
 
 from .shortest_path import ShortestPath
-from .vertex_histogram import VertexHistogram
+from .vertex_histogram import VertexHistogram, EdgeHistogram
 from .weisfeiler_lehman import WeisfeilerLehman
 
 _VH = ("vertex_histogram", "subtree_wl", "VH", "ST-WL")       # graph_kernels.py:38-40
 _SP = ("shortest_path", "SP")
 _WL = ("weisfeiler_lehman", "WL")
-_OTHER_BASE = ("edge_histogram", "EH", "random_walk", "RW", "graphlet_sampling", "GR",
+_EH = ("edge_histogram", "EH")
+_OTHER_BASE = ("random_walk", "RW", "graphlet_sampling", "GR",
                "subgraph_matching", "SM", "multiscale_laplacian", "ML", "lovasz_theta", "LOVT",
                "svm_theta", "SVMT", "neighborhood_hash", "NH",
                "neighborhood_subgraph_pairwise_distance", "NSPD", "odd_sth", "ODD", "propagation",
@@ -55,12 +56,14 @@ class GraphKernel(BaseEstimator, TransformerMixin):
                 warnings.warn('Overriding global kernel attribute ' + str(key) + ' with ' + str(val) +
                               '. Please set this attribute as an argument of GraphKernel.')
             kernel[key] = val
-        if name in _VH or name in _SP:
+        if name in _VH or name in _SP or name in _EH:
             if len(kernel_list) != 0:
                 warnings.warn('Kernel List not empty while reaching a base-kernel - the rest kernel '
                               'names will be ignored')
             if name in _VH:
                 return VertexHistogram, kernel
+            if name in _EH:
+                return EdgeHistogram, kernel
             if kernel.pop("as_attributes", False):
                 raise NotImplementedError('ShortestPathAttr is outside the MI355X hot path')
             return ShortestPath, kernel

@@ -77,3 +77,22 @@ class VertexHistogram(Kernel):
         if self.normalize:
             self._warn_unnormalizable(self._X_diag, self._Y_diag)
         return eng.gram(feat, NORM_PLAIN if self.normalize else NORM_NONE)
+
+
+class EdgeHistogram(VertexHistogram):
+    """K[i,j] = <edge-label histogram of G_i, edge-label histogram of G_j> (drop-in for
+    ``grakel.EdgeHistogram``, ``grakel/kernels/edge_histogram.py:23``): the same
+    label-count features and Gram path as VertexHistogram, fed with the values of the edge-label
+    dictionary ``x[2]`` (inputs must have three elements, edge_histogram.py:88-96)."""
+
+    def initialize(self):
+        """edge_histogram.py:46-55."""
+        if not self._initialized["n_jobs"]:
+            if self.n_jobs is not None:
+                import warnings
+                warnings.warn('no implemented parallelization for EdgeHistogram')
+            self._parallel = None
+            self._initialized["n_jobs"] = True
+
+    def _ingest(self, X, fitted):
+        return vh_batch_from_input(X, fitted, edge_labels=True)

@@ -195,6 +195,19 @@ class VHOracle(object):
         return _normalize(K, self.y_diag, self.x_diag, False) if self.normalize else K
 
 
+class EHOracle(VHOracle):
+    """EdgeHistogram (grakel/kernels/edge_histogram.py:57-175): the VertexHistogram machinery
+    over the VALUES of the edge-label dictionary x[2]; inputs must have exactly 3 elements."""
+
+    def fit_transform(self, X):
+        els = _elements(X, lambda n: n == 3, 'a list with a graph, node labels and edge labels')
+        return VHOracle.fit_transform(self, [[x[0], x[2]] for x in els])
+
+    def transform(self, Y):
+        els = _elements(Y, lambda n: n == 3, 'a list with a graph, node labels and edge labels')
+        return VHOracle.transform(self, [[x[0], x[2]] for x in els])
+
+
 # --------------------------------------------------------------------------
 # Weisfeiler-Lehman (grakel/kernels/weisfeiler_lehman.py)
 # --------------------------------------------------------------------------

@@ -30,9 +30,12 @@ def mutag_graphs():
     for v, g, l in zip(z["node_id"].tolist(), z["node_graph"].tolist(), z["node_label"].tolist()):
         labels[g][v] = l
         g_of[v] = g
-    for a, b in zip(z["edge_src"].tolist(), z["edge_dst"].tolist()):
+    elabels = [dict() for _ in range(n_graphs)]
+    el = z["edge_label"].tolist() if "edge_label" in z.files else [0] * len(z["edge_src"])
+    for a, b, l in zip(z["edge_src"].tolist(), z["edge_dst"].tolist(), el):
         edges[g_of[a]].add((a, b))
-    return [[edges[g], labels[g]] for g in range(n_graphs)], z
+        elabels[g_of[a]][(a, b)] = l
+    return [[edges[g], labels[g], elabels[g]] for g in range(n_graphs)], z
 
 
 def reference_available():

@@ -27,7 +27,7 @@ REF = os.environ.get("GK_REF_BUILD", "/tmp/grakel_oracle")
 sys.path.insert(0, REF)
 
 import grakel  # noqa: E402  (the real reference)
-from grakel import WeisfeilerLehman, VertexHistogram, ShortestPath  # noqa: E402
+from grakel import WeisfeilerLehman, VertexHistogram, ShortestPath, EdgeHistogram  # noqa: E402
 from grakel.datasets.base import read_data  # noqa: E402
 
 from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs  # noqa: E402
@@ -88,13 +88,17 @@ def mutag():
     finally:
         os.chdir(cwd)
     # pack the dataset itself (public TU data: arrays only)
-    gi, labs, src, dst = [], [], [], []
+    gi, labs, src, dst, elab = [], [], [], [], []
     node_ids = []
-    for g, (edges, nl, _el) in enumerate(G):
+    for g, (edges, nl, el) in enumerate(G):
         for v in sorted(nl):
             node_ids.append(v), gi.append(g), labs.append(nl[v])
         for (a, b) in sorted(edges):
-            src.append(a), dst.append(b)
+            src.append(a), dst.append(b), elab.append(el[(a, b)])
+    eh = EdgeHistogram()
+    K_eh = as_int(eh.fit_transform(G[:120]))
+    K_eh_tr = as_int(eh.transform(G[120:]))
+    K_eh_norm = EdgeHistogram(normalize=True).fit_transform(G)
     K_vh = as_int(VertexHistogram().fit_transform(G))
     K_wl = as_int(WeisfeilerLehman(n_iter=5).fit_transform(G))
     K_sp = as_int(ShortestPath().fit_transform(G))
@@ -113,7 +117,8 @@ def mutag():
         os.path.join(HERE, "mutag.npz"),
         node_id=np.array(node_ids, np.int32), node_graph=np.array(gi, np.int32),
         node_label=np.array(labs, np.int32), edge_src=np.array(src, np.int32),
-        edge_dst=np.array(dst, np.int32),
+        edge_dst=np.array(dst, np.int32), edge_label=np.array(elab, np.int32),
+        K_eh=K_eh.astype(np.int32), K_eh_tr=K_eh_tr.astype(np.int32), K_eh_norm=K_eh_norm,
         K_vh=K_vh.astype(np.int32), K_wl5=K_wl.astype(np.int32), K_sp=K_sp.astype(np.int64),
         K_wl3_tr=K_wl_tr.astype(np.int32), K_sp_tr=K_sp_tr.astype(np.int64),
         K_wl3_tr_norm=K_wl_tr_norm,

@@ -469,3 +469,15 @@ def test_tu_loader_batch_gives_the_reference_gram(gk, mutag_graphs, tmp_path):
     batch, _ = read_tu(_write_mutag_tu(tmp_path, z), "MUTAG")
     assert np.array_equal(gk.WeisfeilerLehman(n_iter=5).fit_transform(batch), z["K_wl5"])
     assert np.array_equal(gk.VertexHistogram().fit_transform(batch), z["K_vh"])
+
+
+def test_edge_histogram_against_reference_goldens(gk, mutag_graphs):
+    """EdgeHistogram = the VertexHistogram path over edge labels."""
+    G, z = mutag_graphs
+    eh = gk.EdgeHistogram()
+    assert np.array_equal(eh.fit_transform(G[:120]), z["K_eh"])
+    assert np.array_equal(eh.transform(G[120:]), z["K_eh_tr"])
+    assert np.allclose(gk.EdgeHistogram(normalize=True).fit_transform(G), z["K_eh_norm"], rtol=REL_TOL, atol=0)
+    assert np.array_equal(gk.GraphKernel(kernel="EH").fit_transform(G[:120]), z["K_eh"])
+    with pytest.raises(TypeError):
+        gk.EdgeHistogram().fit_transform([[g[0], g[1]] for g in G[:3]])      # needs edge labels

@@ -69,6 +69,10 @@ def test_mutag_against_reference(mutag_graphs):
     sp = O.SPOracle()
     sp.fit_transform(G[:120])
     assert np.array_equal(sp.transform(G[120:]), z["K_sp_tr"])
+    eh = O.EHOracle()                                  # MUTAG carries edge labels (bond types)
+    assert np.array_equal(eh.fit_transform(G[:120]), z["K_eh"])
+    assert np.array_equal(eh.transform(G[120:]), z["K_eh_tr"])
+    assert np.allclose(O.EHOracle(normalize=True).fit_transform(G), z["K_eh_norm"], rtol=1e-13, atol=0)
 
 
 @pytest.mark.parametrize("name", ["dict_u", "adj_u", "adj_d", "tuples_d", "dense_big"])
