@@ -5,7 +5,7 @@ sampled entries are checked against the CPU oracle run on the two graphs of each
 (a WL kernel value only depends on the two graphs), rows against the symmetric counterpart."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from grakel_amd import GraphBatch
 from grakel_amd.engine import get_engine
 from grakel_amd.synthetic import er_dataset, er_dataset_csr
