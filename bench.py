@@ -152,6 +152,20 @@ def main():
         achieved = flops / (gram_avg_ms * 1e-3) / 1e12
         d_eff = (info.get("n_cols") or 0) + (info.get("n_cols_low") or 0)
         alg_flops = (2.0 * (N / world) * N * d_eff) if world > 1 else (2.0 * (N * (N + 1) / 2) * d_eff)
+        # HBM view of the two integer phases (SURVEY.md 8d algorithmic bytes, int32 everywhere):
+        # relabel per level 8E + 12V (signature) + 24V (dictionary pass); features 16V per level
+        V_, E_ = int(full.n_nodes), int(full.n_edges)
+        phases_hbm = None
+        if phases:
+            rb = h * (8 * E_ + 12 * V_ + 24 * V_)
+            fb = (h + 1) * 16 * V_
+            phases_hbm = {
+                "relabel": {"algorithmic_bytes": rb, "GB_per_s": rb / (phases["relabel"] * 1e-3) / 1e9,
+                            "frac_of_8TBps": rb / (phases["relabel"] * 1e-3) / 8e12},
+                "features": {"algorithmic_bytes": fb, "GB_per_s": fb / (phases["features"] * 1e-3) / 1e9,
+                             "frac_of_8TBps": fb / (phases["features"] * 1e-3) / 8e12},
+                "note": "about 230 dependent launches of 4-20 us over 1 M-element arrays per step: "
+                        "latency/launch bound, not bandwidth bound (DESIGN.md 4)"}
         out = {
             "metric": "graph-pairs/sec for NxN WL-subtree(h=%d) fit_transform" % h,
             "value": N * N / (dt / a.steps),
@@ -189,6 +203,7 @@ def main():
                         "pair updates by gram_low_kernel, inside gram_phase_ms). The kernel also writes the "
                         "whole float64 K (N^2*8 B), which bounds it at ~0.13 ms by HBM."},
             "phases_ms": phases,
+            "phases_hbm": phases_hbm,
         }
         if world == 1 and not a.no_cpu_baseline:
             cb, Kcpu, X = cpu_baseline(min(a.cpu_sample, N), cfg)
