@@ -4,8 +4,9 @@ from .batch import GraphBatch
 from .kernel import Kernel
 from .vertex_histogram import VertexHistogram, EdgeHistogram
 from .weisfeiler_lehman import WeisfeilerLehman
+from .weisfeiler_lehman_optimal_assignment import WeisfeilerLehmanOptimalAssignment
 from .shortest_path import ShortestPath
 from .graph_kernels import GraphKernel
 
-__all__ = ["GraphBatch", "Kernel", "VertexHistogram", "EdgeHistogram", "WeisfeilerLehman", "ShortestPath", "GraphKernel"]
+__all__ = ["GraphBatch", "Kernel", "VertexHistogram", "EdgeHistogram", "WeisfeilerLehman", "WeisfeilerLehmanOptimalAssignment", "ShortestPath", "GraphKernel"]
 __version__ = "0.1.0"

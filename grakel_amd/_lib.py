@@ -45,6 +45,7 @@ SIGNATURES = {
     "gk_wl_get_labels": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gk_wl_debug_signature": (c_int, [c_void_p, c_void_p, c_int, c_uint64, c_void_p, c_void_p]),
     "gk_features_build": (c_int, [c_void_p, c_void_p, c_int, c_int64, _vpp]),
+    "gk_features_build_ex": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, _vpp]),
     "gk_features_destroy": (c_int, [c_void_p]),
     "gk_features_info": (c_int, [c_void_p, _i64p, _i64p, _i64p, _i64p, POINTER(c_int)]),
     "gk_features_selfk": (c_int, [c_void_p, c_void_p, c_void_p]),

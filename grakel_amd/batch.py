@@ -75,7 +75,7 @@ def _is_graph_object(x):
     return hasattr(x, "get_edge_dictionary") and hasattr(x, "get_labels")
 
 
-def iter_elements(X, len_ok, type_msg, not_iterable=TypeError):
+def iter_elements(X, len_ok, type_msg, not_iterable=TypeError, element_error=TypeError):
     """Yield validated elements; empty elements warn and are skipped (reference behaviour)."""
     if not isinstance(X, Iterable):
         raise not_iterable('input must be an iterable\n')
@@ -86,13 +86,13 @@ def iter_elements(X, len_ok, type_msg, not_iterable=TypeError):
             yield x
             continue
         if not isinstance(x, Iterable):
-            raise TypeError(type_msg)
+            raise element_error(type_msg)
         x = list(x)
         if len(x) == 0:
             warnings.warn('Ignoring empty element on index: ' + str(idx))
             continue
         if not len_ok(len(x)):
-            raise TypeError(type_msg)
+            raise element_error(type_msg)
         n += 1
         yield x
     if n == 0:
@@ -116,10 +116,13 @@ def _adjacency_array(g):
 def _edge_lists(g):
     """Normalise an edge-dictionary style object to {u: {v: w}} (weights kept for SP).
 
-    Detection order follows grakel/graph.py:1613-1705.  Returns (vertices_set, nested dict)
-    or None when the object is not a supported edge dictionary.
+    Detection order follows grakel/graph.py:1613-1705.  Returns (vertices_set, nested dict,
+    entries) or None when the object is not a supported edge dictionary; ``entries`` is the key
+    set of the reference's edge dictionary (a ``{v: []}`` item of a dict of lists leaves no
+    entry unless v is somebody's neighbour only, graph.py:1640-1660).
     """
     nested = None
+    listy = False
     if type(g) is dict:
         if all(type(k) is tuple and len(k) == 2 and isinstance(w, numbers.Number)
                for k, w in g.items()):
@@ -130,6 +133,7 @@ def _edge_lists(g):
         elif all(isinstance(d, list) for d in g.values()):
             nested = {a: dict.fromkeys(lst, 1.) for a, lst in g.items() if len(lst)}
             keys = set(g.keys())
+            listy = True
         elif all(isinstance(d, dict) and all(isinstance(w, numbers.Number) for w in d.values())
                  for d in g.values()):
             nested = {a: d for a, d in g.items()}
@@ -153,7 +157,8 @@ def _edge_lists(g):
     vertices = set(keys)
     for d in nested.values():
         vertices.update(d.keys())
-    return vertices, nested
+    entries = (set(nested.keys()) | (vertices - keys)) if listy else vertices
+    return vertices, nested, entries
 
 
 def _unsupported():
@@ -217,6 +222,60 @@ def _wl_graph_arrays(gobj, labels):
                 src.append(i)
                 dst.append(pos[nb])                       # KeyError like the reference
     return list(labels.values()), np.asarray(src, np.int64), np.asarray(dst, np.int64)
+
+
+def _wloa_entry_mask(gobj, labels):
+    """Positions (in label order) of the vertices WL-OA keeps: those with an entry in the
+    reference's edge dictionary (weisfeiler_lehman_optimal_assignment.py:176 iterates
+    ``Gs_ed[j].keys()``).  An entry without a label is the reference's KeyError (:177)."""
+    pos = {k: i for i, k in enumerate(labels.keys())}
+    A = _adjacency_array(gobj)
+    if A is not None:
+        entries = range(A.shape[0])                        # graph.py:960: every index has an entry
+    elif _is_graph_object(gobj):
+        entries = gobj.get_edge_dictionary().keys()
+    else:
+        entries = _edge_lists(gobj)[2]
+    mask = np.zeros(len(pos), bool)
+    for v in entries:
+        mask[pos[v]] = True                                # KeyError like the reference
+    return mask
+
+
+def wloa_batch_from_input(X, fitted_labels=None, fit=True):
+    """WL-OA ingestion: the WL batch restricted to the vertices that own an edge-dictionary entry
+    (labelled vertices without one never reach the histogram, :176,:201-206).  Level-0 ids are
+    still numbered over ALL label values like the reference (:147-155).  A ready GraphBatch is
+    taken as adjacency-style input: every vertex owns an entry."""
+    if isinstance(X, GraphBatch):
+        return X, None
+    if fit:
+        len_ok, err = (lambda n: n >= 2), TypeError
+        msg = ('each element of X must be either a graph object or a list with at least a graph '
+               'like object and node labels dict \n')
+    else:
+        len_ok, err = (lambda n: n in (2, 3)), ValueError
+        msg = 'each element of X must have at least one and at most 3 elements\n'
+    sizes, srcs, dsts, values, masks = [], [], [], [], []
+    for x in iter_elements(X, len_ok, msg, err, element_error=err):
+        if _is_graph_object(x):
+            if hasattr(x, "desired_format"):
+                x.desired_format("dictionary")
+            gobj, labels = x, x.get_labels(purpose="dictionary")
+        else:
+            gobj, labels = x[0], x[1]
+        vals, s, d = _wl_graph_arrays(gobj, labels)
+        mask = _wloa_entry_mask(gobj, labels)
+        if not mask.all():
+            new = np.cumsum(mask) - 1
+            s, d = new[s], new[d]                          # edges only join vertices with entries
+        sizes.append(int(mask.sum())), srcs.append(s), dsts.append(d)
+        values.extend(vals), masks.append(mask)
+    ids, mapping = compress_labels(values, fitted_labels)
+    ids = ids[np.concatenate(masks)] if masks else ids
+    n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
+    graph_ptr, row_ptr, col, _ = _pack_csr(sizes, srcs, dsts)
+    return GraphBatch(graph_ptr, row_ptr, col, np.ascontiguousarray(ids), max(n_labels, 1)), mapping
 
 
 def compress_labels(values, fitted=None):
@@ -349,7 +408,7 @@ def _sp_graph_arrays(gobj, labels, with_labels):
             r = _edge_lists(gobj)
             if r is None:
                 raise _unsupported()
-            vertices, nested = r
+            vertices, nested = r[0], r[1]
         verts = sorted(vertices)
         n = len(verts)
         pos = {v: i for i, v in enumerate(verts)}

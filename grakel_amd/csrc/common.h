@@ -151,11 +151,13 @@ struct LevelTriples {
     i32* tstart = nullptr;     // [n_nodes+1] first triple of each label run
     i32* colid = nullptr;      // [n_nodes]   dense column id per label run, -2 rare, -1 dead
     i32* low_runs = nullptr;   // [n_nodes]   compact list of the rare label runs
-    i32* wide = nullptr;       // [n_nodes+1] 1 when some count of the run exceeds the int8 range
+    i32* wide = nullptr;       // [n_nodes+1] kind 0: 1 when some count of the run exceeds the int8 range;
+                               //             kind 1: the largest count of the run (its unary width)
     i64 n_low = 0;
 };
 
 struct gk_feat {
+    int kind = 0;               // GK_FEAT_DOT (0) | GK_FEAT_MINSUM (1), see gk_features_build_ex
     gk_ctx* ctx = nullptr;
     gk_batch* batch = nullptr;
     int n_levels = 0;

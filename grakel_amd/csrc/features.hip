@@ -12,6 +12,12 @@
 //      symmetric job   : df >= 2
 //      rectangular job : present in a fit graph (< n_fit) AND a target graph (>= n_fit)
 // HBM-bound integer work: ~16 bytes per node per level.
+//
+// kind 1 (histogram intersection, K_ij = sum_l min(c_il, c_jl); WL-OA,
+// weisfeiler_lehman_optimal_assignment.py:268-279) stays on the same integer GEMM through the
+// UNARY expansion  min(a, b) = sum_{t>=1} [a >= t][b >= t]:  a dense label column whose largest
+// count is m becomes m 0/1 columns ([c>=1], [c>=2], ...), so Phi_s . Phi_s^T IS the min-sum,
+// exactly, on the int8 MFMA path; selfk[g] = sum of counts (= nodes x levels).
 #include "common.h"
 #include "scan_fn.h"
 #include <stdlib.h>
@@ -70,7 +76,7 @@ struct TripleEmit {
 __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __restrict__ tri_of,
                                   const i32* __restrict__ tri_pos, const i32* __restrict__ tri_run,
                                   i32* __restrict__ wide, int wide_above, u32* __restrict__ node_acc,
-                                  u32* __restrict__ meta, int level, int n_levels, i64 n) {
+                                  u32* __restrict__ meta, int level, int n_levels, i64 n, int kind) {
     __shared__ u32 wmax[4];
     i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 c = 0;
@@ -79,7 +85,7 @@ __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __res
         c = (u32)(tri_pos[t + 1] - tri_pos[t]);
         if ((int)c > wide_above) wide[tri_run[t]] = 1;       // benign race: all writers store 1
         i32 v = perm[k];
-        node_acc[v] = (level == 0 ? 0u : node_acc[v]) + c;
+        node_acc[v] = (level == 0 ? 0u : node_acc[v]) + (kind ? 1u : c);   // min(c,c) summed == #nodes
     }
     for (int off = 32; off > 0; off >>= 1) {
         u32 o = __shfl_down(c, off, 64);
@@ -92,6 +98,27 @@ __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __res
         for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = wmax[i] > m ? wmax[i] : m;
         // plain read as a filter: once the maximum is established almost no block issues the atomic
         if (m > meta[3 * n_levels]) atomicMax(&meta[3 * n_levels], m);
+    }
+}
+
+// kind 1: wide[r] = largest count of label run r (the number of unary columns it expands to).
+// Triples are run-major, so a wave usually sees one run: one atomic per wave then.
+__global__ void feat_runmax_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_run,
+                                   const u32* __restrict__ meta, int level, i32* __restrict__ runmax) {
+    const u32 Tn = meta[META_T(level)];
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    i32 r = -1, c = 0;
+    if (t < Tn) r = tri_run[t], c = tri_pos[t + 1] - tri_pos[t];
+    const i32 r0 = __shfl(r, 0, 64);
+    if (__all(r == r0 || r < 0)) {
+        if (r0 < 0) return;
+        for (int off = 32; off > 0; off >>= 1) {
+            i32 o = __shfl_down(c, off, 64);
+            c = o > c ? o : c;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(&runmax[r0], c);
+    } else if (r >= 0) {
+        atomicMax(&runmax[r], c);
     }
 }
 
@@ -116,7 +143,7 @@ __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* 
 // scan value packs (low << 32 | dense) so one pass yields both running counts.
 struct ColumnIds {
     const i32* tstart; const i32* tri_graph; i32* colid; u32* meta; int level; int symmetric; i32 n_fit;
-    i32 low_df; i32* low_runs; const i32* wide;
+    i32 low_df; i32* low_runs; const i32* wide; int kind;
     __device__ __forceinline__ u64 value(i64 r) const {
         if (r >= (i64)meta[META_R(level)]) return 0ull;
         const i32 t0 = tstart[r], t1 = tstart[r + 1];
@@ -125,13 +152,15 @@ struct ColumnIds {
         else useful = tri_graph[t0] < n_fit && tri_graph[t1 - 1] >= n_fit;
         if (!useful) return 0ull;
         if ((t1 - t0) < low_df) return 1ull << 32;
+        if (kind) return (u64)(u32)wide[r];       // unary expansion: one 0/1 column per count level
         return wide[r] ? (1ull << 63) : 1ull;     // bit 63: dense but not int8-able (toggles only itself)
     }
     __device__ __forceinline__ void emit(i64 r, u64 v, u64 incl) const {
         const u32 base = level > 0 ? meta[META_C(level - 1)] : 0u;
         const u32 rare = (u32)(v >> 32) & 0x7fffffffu;
-        colid[r] = (v & 1ull) ? (i32)(base + (u32)(incl & 0xffffffffull) - 1)
-                              : ((v >> 63) ? -3 : (rare ? -2 : -1));
+        const u32 width = (u32)(v & 0xffffffffull);     // 1 (kind 0) or the run's largest count (kind 1)
+        colid[r] = width ? (i32)(base + (u32)(incl & 0xffffffffull) - width)
+                         : ((v >> 63) ? -3 : (rare ? -2 : -1));
         if (rare) low_runs[((u32)(incl >> 32) & 0x7fffffffu) - 1] = (i32)r;   // compact list for gram_low_kernel
     }
 };
@@ -159,13 +188,16 @@ __global__ void feat_widebase_kernel(u32* __restrict__ meta, const u32* __restri
 __global__ void feat_scatter_mixed_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_graph,
                                           const i32* __restrict__ tri_run, const i32* __restrict__ colid,
                                           const u32* __restrict__ meta, int level, int8_t* __restrict__ phi,
-                                          i64 ld, double* __restrict__ phi_w, i64 ldw) {
+                                          i64 ld, double* __restrict__ phi_w, i64 ldw, int kind) {
     const u32 Tn = meta[META_T(level)];
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Tn) return;
     const i32 c = colid[tri_run[t]];
     const i32 cnt = tri_pos[t + 1] - tri_pos[t];
-    if (c >= 0) phi[(i64)tri_graph[t] * ld + c] = (int8_t)cnt;
+    if (c >= 0 && kind) {
+        int8_t* row = phi + (i64)tri_graph[t] * ld + c;
+        for (i32 q = 0; q < cnt; ++q) row[q] = 1;           // [count >= q+1]
+    } else if (c >= 0) phi[(i64)tri_graph[t] * ld + c] = (int8_t)cnt;
     else if (c <= -4) phi_w[(i64)tri_graph[t] * ldw + (-4 - c)] = (double)cnt;
 }
 
@@ -197,7 +229,13 @@ extern "C" int gk_features_destroy(gk_feat* f) {
 }
 
 extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, gk_feat** out) {
+    return gk_features_build_ex(ctx, b, n_levels, n_fit, GK_FEAT_DOT, out);
+}
+
+extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, int kind,
+                                    gk_feat** out) {
     GK_ARG(ctx && b && out, "gk_features_build: null argument");
+    GK_ARG(kind == GK_FEAT_DOT || kind == GK_FEAT_MINSUM, "gk_features_build_ex: unknown kind");
     GK_ARG(n_levels >= 1 && n_levels <= (b->n_levels > 0 ? b->n_levels : 1),
            "gk_features_build: levels not computed (call gk_wl_relabel first)");
     GK_ARG(n_fit >= 1 && n_fit <= b->n_graphs, "gk_features_build: bad n_fit");
@@ -208,6 +246,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     gk_feat* f = new gk_feat();
     f->ctx = ctx, f->batch = b, f->n_levels = n_levels, f->n_graphs = N, f->n_fit = n_fit, f->n_nodes = V;
     f->symmetric = (n_fit == N);
+    f->kind = kind;
     f->lev.resize(n_levels);
     auto fail = [&](int r) { gk_features_destroy(f); return r; };
     int r;
@@ -240,8 +279,9 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     // K_ij <= sqrt(K_ii K_jj) <= n_levels * max_graph_nodes^2.  If the bound fails everything
     // dense goes to the float64 operand (wide_above = -1 flags every run).
     const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
-    f->dtype = bound < 2147483647.0 ? 0 : 1;
-    const int wide_above = f->dtype == 0 ? 127 : -1;
+    // kind 1: operands are 0/1 and K_ij <= n_levels * max_graph_nodes, always int8-able.
+    f->dtype = (kind == GK_FEAT_MINSUM || bound < 2147483647.0) ? 0 : 1;
+    const int wide_above = kind == GK_FEAT_MINSUM ? 0x7fffffff : (f->dtype == 0 ? 127 : -1);
     for (int l = 0; l < n_levels && V > 0; ++l) {
         LevelTriples& L = f->lev[l];
         i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid, &L.low_runs, &L.wide};
@@ -257,9 +297,11 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
         if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, V, nullptr))) return fail(r);
         if (gk_zero_async(ctx, L.wide, (size_t)(V + 1) * 4) != GK_OK) return fail(GK_ERR_HIP);
         feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, L.tri_run, L.wide, wide_above,
-                                                                     node_acc.p, f->meta, l, n_levels, V);
+                                                                     node_acc.p, f->meta, l, n_levels, V, kind);
+        if (kind == GK_FEAT_MINSUM)
+            feat_runmax_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(L.tri_pos, L.tri_run, f->meta, l, L.wide);
         ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df,
-                     L.low_runs, L.wide};
+                     L.low_runs, L.wide, kind};
         if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, V, ctotal64.p))) return fail(r);
         feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, ctotal64.p, l, n_levels);
     }
@@ -280,7 +322,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
     for (int l = 0; l < n_levels; ++l) f->lev[l].n_low = h[3 * n_levels + 4 + l];
     // ids of the float64 side operand (second pass, only when a dense column is too wide for int8)
     f->n_cols_wide = 0;
-    if (V > 0 && (f->max_count > 127 || f->dtype == 1)) {
+    if (V > 0 && kind == GK_FEAT_DOT && (f->max_count > 127 || f->dtype == 1)) {
         Tmp<u32> wtotal(ctx);
         if ((r = wtotal.alloc(1))) return fail(r);
         for (int l = 0; l < n_levels; ++l) {
@@ -315,7 +357,7 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
         if (T == 0) continue;
         feat_scatter_mixed_kernel<<<grid_for(T, 256), 256, 0, ctx->stream>>>(
             L.tri_pos, L.tri_graph, L.tri_run, L.colid, f->meta, l, (int8_t*)f->phi, f->n_cols_pad,
-            f->phi_w, f->n_cols_wide_pad);
+            f->phi_w, f->n_cols_wide_pad, kind);
     }
     if (hipGetLastError() != hipSuccess) {
         gk_set_error("gk_features_build: kernel launch failed");

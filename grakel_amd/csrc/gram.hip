@@ -12,6 +12,8 @@
 //   3. gram_low_kernel     : useful columns present in < 32 graphs never enter a dense operand;
 //                            their df*(df-1) pair products are added as float64 atomics.
 //   4. gram_normalize_kernel, only when 2. or 3. ran and normalisation was requested.
+// Histogram-intersection features (kind 1) arrive unary-expanded (features.hip), so step 1 computes
+// sum_l min(c_il, c_jl) exactly; step 2 never applies and step 3 adds min(c_a, c_b) per pair.
 // The int8 epilogue fuses what the reference does in three extra N^2 passes: the per-level sum
 // (all levels are concatenated along K), the diagonal (graph-unique label columns are not in
 // Phi_s; K_ii is written from the exact selfk vector instead) and -- when no extra term
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
 __global__ void gram_low_kernel(const i32* __restrict__ low_runs, i64 n_low, const i32* __restrict__ tri_pos,
                                 const i32* __restrict__ tri_graph, const i32* __restrict__ tstart,
                                 double* __restrict__ K, i64 n_cols, i64 row_lo, i64 row_hi, int symmetric,
-                                i64 n_fit) {
+                                i64 n_fit, int minsum) {
     const i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (w >= n_low) return;
@@ -370,8 +372,8 @@ __global__ void gram_low_kernel(const i32* __restrict__ low_runs, i64 n_low, con
         const i64 row = symmetric ? ga : ga - n_fit;       // rectangular job: rows are the target graphs
         if (row < row_lo || row >= row_hi) continue;
         if (symmetric ? (ia == ib) : (gb >= n_fit)) continue;
-        atomicAdd(&K[(row - row_lo) * n_cols + gb],
-                  (double)(tri_pos[a + 1] - tri_pos[a]) * (double)(tri_pos[b + 1] - tri_pos[b]));
+        const i32 ca = tri_pos[a + 1] - tri_pos[a], cb = tri_pos[b + 1] - tri_pos[b];
+        atomicAdd(&K[(row - row_lo) * n_cols + gb], minsum ? (double)(ca < cb ? ca : cb) : (double)ca * (double)cb);
     }
 }
 
@@ -434,7 +436,7 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
             if (!L.tri_pos || L.n_low == 0) continue;
             gram_low_kernel<<<dim3((unsigned)cdiv(L.n_low * 64, 256)), dim3(256), 0, ctx->stream>>>(
                 L.low_runs, L.n_low, L.tri_pos, L.tri_graph, L.tstart, K, n_cols, row_lo, row_hi,
-                f->symmetric ? 1 : 0, f->n_fit);
+                f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0);
         }
     }
     if (has_low || has_wide) {

@@ -143,10 +143,11 @@ class Engine(object):
         return h, s
 
     # -- features / Gram -----------------------------------------------------------------------
-    def features(self, db, n_levels, n_fit=None):
+    def features(self, db, n_levels, n_fit=None, kind=0):
+        """kind 0: dot product of label counts; 1: histogram intersection (min-sum)."""
         n_fit = db.n_graphs if n_fit is None else int(n_fit)
         h = c_void_p()
-        check(self.lib.gk_features_build(self.handle, db.handle, int(n_levels), n_fit, byref(h)))
+        check(self.lib.gk_features_build_ex(self.handle, db.handle, int(n_levels), n_fit, int(kind), byref(h)))
         return DeviceFeatures(self, h, db, n_fit)
 
     def selfk(self, feat):

@@ -15,6 +15,7 @@ from sklearn.utils.validation import check_is_fitted
 from .shortest_path import ShortestPath
 from .vertex_histogram import VertexHistogram, EdgeHistogram
 from .weisfeiler_lehman import WeisfeilerLehman
+from .weisfeiler_lehman_optimal_assignment import WeisfeilerLehmanOptimalAssignment
 
 _VH = ("vertex_histogram", "subtree_wl", "VH", "ST-WL")       # graph_kernels.py:38-40
 _SP = ("shortest_path", "SP")
@@ -24,8 +25,8 @@ _OTHER_BASE = ("random_walk", "RW", "graphlet_sampling", "GR",
                "subgraph_matching", "SM", "multiscale_laplacian", "ML", "lovasz_theta", "LOVT",
                "svm_theta", "SVMT", "neighborhood_hash", "NH",
                "neighborhood_subgraph_pairwise_distance", "NSPD", "odd_sth", "ODD", "propagation",
-               "PR", "pyramid_match", "PM", "graph_hopper", "GH",
-               "weisfeiler_lehman_optimal_assignment", "WL-OA")
+               "PR", "pyramid_match", "PM", "graph_hopper", "GH")
+_WLOA = ("weisfeiler_lehman_optimal_assignment", "WL-OA")
 _OTHER_FRAMEWORKS = ("hadamard_code", "HC", "core_framework", "CORE")
 
 
@@ -56,7 +57,7 @@ class GraphKernel(BaseEstimator, TransformerMixin):
                 warnings.warn('Overriding global kernel attribute ' + str(key) + ' with ' + str(val) +
                               '. Please set this attribute as an argument of GraphKernel.')
             kernel[key] = val
-        if name in _VH or name in _SP or name in _EH:
+        if name in _VH or name in _SP or name in _EH or name in _WLOA:
             if len(kernel_list) != 0:
                 warnings.warn('Kernel List not empty while reaching a base-kernel - the rest kernel '
                               'names will be ignored')
@@ -64,6 +65,8 @@ class GraphKernel(BaseEstimator, TransformerMixin):
                 return VertexHistogram, kernel
             if name in _EH:
                 return EdgeHistogram, kernel
+            if name in _WLOA:
+                return WeisfeilerLehmanOptimalAssignment, kernel
             if kernel.pop("as_attributes", False):
                 raise NotImplementedError('ShortestPathAttr is outside the MI355X hot path')
             return ShortestPath, kernel

@@ -33,6 +33,7 @@ class Kernel(BaseEstimator, TransformerMixin):
     _graph_format = "dictionary"
     _method_calling = 0
     _norm_mode = NORM_PLAIN
+    _feature_kind = 0          # GK_FEAT_DOT; WL-OA overrides with GK_FEAT_MINSUM
 
     def __init__(self, n_jobs=None, normalize=False, verbose=False):
         self.verbose = verbose
@@ -104,7 +105,7 @@ class Kernel(BaseEstimator, TransformerMixin):
         eng = self._engine()
         db = eng.upload(self._fit_batch)
         fb, n_levels = self._prepare(eng, db)
-        feat = eng.features(fb, n_levels)
+        feat = eng.features(fb, n_levels, kind=self._feature_kind)
         self._X_diag = eng.selfk(feat)
         self._last_info = dict(n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, nnz=feat.nnz, max_count=feat.max_count,
                                dtype=("i8", "f64")[feat.dtype], label_counts=fb.label_counts)
@@ -117,7 +118,7 @@ class Kernel(BaseEstimator, TransformerMixin):
         eng = self._engine()
         db = eng.upload(union)
         fb, n_levels = self._prepare(eng, db)
-        feat = eng.features(fb, n_levels, n_fit=self._nx)
+        feat = eng.features(fb, n_levels, n_fit=self._nx, kind=self._feature_kind)
         selfk = eng.selfk(feat)
         self._X_diag = selfk[:self._nx]
         self._Y_diag = selfk[self._nx:]

@@ -110,6 +110,15 @@ int gk_wl_debug_signature(gk_ctx* ctx, gk_batch* b, int level, uint64_t seed,
  *                       cols = graphs [0, n_fit); a column is kept iff it occurs on both sides
  *                       (unseen labels are dropped exactly like vertex_histogram.py:179). */
 int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, gk_feat** out);
+
+/* Same with an explicit pairwise operation on the per-level label counts:
+ *   GK_FEAT_DOT    K_ij = sum_l c_il * c_jl       (VertexHistogram, vertex_histogram.py:176-182)
+ *   GK_FEAT_MINSUM K_ij = sum_l min(c_il, c_jl)   (histogram intersection of the WL hierarchy,
+ *                  weisfeiler_lehman_optimal_assignment.py:201-206,268-279; diagonal = sum_l c_il)
+ * gk_gram / gk_gram_rows then apply unchanged. */
+#define GK_FEAT_DOT 0
+#define GK_FEAT_MINSUM 1
+int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, int kind, gk_feat** out);
 int gk_features_destroy(gk_feat* f);
 /* n_cols_kept: width of the dense MFMA operand Phi_s; n_cols_low: useful but rare columns
  * (fewer than GK_LOW_DF=32 graphs) that are applied as exact pair updates after the GEMM instead;

@@ -285,6 +285,86 @@ class WLOracle(object):
         return _normalize(K, ydiag, self.x_diag, True) if self.normalize else K
 
 
+class WLOAOracle(object):
+    """WeisfeilerLehmanOptimalAssignment (grakel/kernels/weisfeiler_lehman_optimal_assignment.py).
+
+    WL relabelling as above, but (a) from level 1 on only vertices WITH AN ENTRY in the edge
+    dictionary are relabelled (`for v in Gs_ed[j].keys()`, :176), (b) every label remembers its
+    parent label, (c) a graph's histogram counts, for each of its surviving vertices, the final
+    label and all its ancestors (:201-206) and (d) K is the histogram INTERSECTION
+    sum_l min(H_i[l], H_j[l]) (:268-279).
+    """
+
+    def __init__(self, n_iter=5, normalize=False):
+        self.n_iter, self.normalize = n_iter, normalize
+
+    @staticmethod
+    def _hist(L, parent, width):
+        H = np.zeros((len(L), width))
+        for j, d in enumerate(L):
+            for lab in d.values():
+                while lab is not None:
+                    H[j, lab] += 1
+                    lab = parent[lab]
+        return H
+
+    @staticmethod
+    def _intersection(A, B):
+        K = np.zeros((A.shape[0], B.shape[0]))
+        for i in range(A.shape[0]):
+            K[i] = np.minimum(A[i][None, :], B).sum(axis=1)
+        return K
+
+    def fit_transform(self, X):
+        eds, L = _wl_ingest(X)
+        inv0 = {dv: i for i, dv in enumerate(sorted({l for d in L for l in d.values()}))}
+        self.inv_labels = {0: inv0}
+        self.parent = {i: None for i in range(len(inv0))}          # children of the root
+        count = len(inv0)
+        L = [{k: inv0[v] for k, v in d.items()} for d in L]
+        for i in range(1, self.n_iter + 1):
+            creds = [{v: _credential(Lj, ed, v) for v in ed.keys()} for Lj, ed in zip(L, eds)]
+            pairs = sorted({(c, Lj[v]) for d, Lj in zip(creds, L) for v, c in d.items()}, key=lambda t: t[0])
+            inv = dict()
+            for c, prev in pairs:
+                inv[c] = count
+                self.parent[count] = prev
+                count += 1
+            L = [{v: inv[c] for v, c in d.items()} for d in creds]
+            self.inv_labels[i] = inv
+        self.H = self._hist(L, self.parent, count)
+        K = self._intersection(self.H, self.H)
+        self.x_diag = np.diagonal(K).copy()
+        return _normalize(K, self.x_diag, self.x_diag, True) if self.normalize else K
+
+    def transform(self, Y):
+        eds, L = _wl_ingest(Y)
+        parent = dict(self.parent)
+        count = sum(len(self.inv_labels[i]) for i in range(len(self.inv_labels)))
+        inv0 = self.inv_labels[0]
+        new0 = dict()
+        for dv in sorted({l for d in L for l in d.values() if l not in inv0}):
+            new0[dv] = count
+            parent[count] = None
+            count += 1
+        L = [{k: (inv0[v] if v in inv0 else new0[v]) for k, v in d.items()} for d in L]
+        for i in range(1, self.n_iter + 1):
+            creds = [{v: _credential(Lj, ed, v) for v in ed.keys()} for Lj, ed in zip(L, eds)]
+            inv = self.inv_labels[i]
+            unseen = sorted({(c, Lj[v]) for d, Lj in zip(creds, L) for v, c in d.items() if c not in inv},
+                            key=lambda t: t[0])
+            new = dict()
+            for c, prev in unseen:
+                new[c] = count
+                parent[count] = prev
+                count += 1
+            L = [{v: (inv[c] if c in inv else new[c]) for v, c in d.items()} for d in creds]
+        Hy = self._hist(L, parent, count)
+        K = self._intersection(Hy[:, :self.H.shape[1]], self.H)
+        self.y_diag = Hy.sum(axis=1)
+        return _normalize(K, self.y_diag, self.x_diag, True) if self.normalize else K
+
+
 # --------------------------------------------------------------------------
 # Shortest paths (grakel/graph.py:588-687,1712-1794) and the SP kernel
 # --------------------------------------------------------------------------

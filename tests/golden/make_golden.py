@@ -28,6 +28,7 @@ sys.path.insert(0, REF)
 
 import grakel  # noqa: E402  (the real reference)
 from grakel import WeisfeilerLehman, VertexHistogram, ShortestPath, EdgeHistogram  # noqa: E402
+from grakel import WeisfeilerLehmanOptimalAssignment  # noqa: E402
 from grakel.datasets.base import read_data  # noqa: E402
 
 from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs  # noqa: E402
@@ -95,6 +96,12 @@ def mutag():
             node_ids.append(v), gi.append(g), labs.append(nl[v])
         for (a, b) in sorted(edges):
             src.append(a), dst.append(b), elab.append(el[(a, b)])
+    oa = WeisfeilerLehmanOptimalAssignment(n_iter=4)
+    K_oa = as_int(oa.fit_transform(G[:120]))
+    K_oa_tr = as_int(oa.transform(G[120:]))
+    oan = WeisfeilerLehmanOptimalAssignment(n_iter=2, normalize=True)
+    K_oa_norm = oan.fit_transform(G[:120])
+    K_oa_norm_tr = oan.transform(G[120:])
     eh = EdgeHistogram()
     K_eh = as_int(eh.fit_transform(G[:120]))
     K_eh_tr = as_int(eh.transform(G[120:]))
@@ -119,6 +126,8 @@ def mutag():
         node_label=np.array(labs, np.int32), edge_src=np.array(src, np.int32),
         edge_dst=np.array(dst, np.int32), edge_label=np.array(elab, np.int32),
         K_eh=K_eh.astype(np.int32), K_eh_tr=K_eh_tr.astype(np.int32), K_eh_norm=K_eh_norm,
+        K_oa4=K_oa.astype(np.int32), K_oa4_tr=K_oa_tr.astype(np.int32), K_oa2_norm=K_oa_norm,
+        K_oa2_norm_tr=K_oa_norm_tr,
         K_vh=K_vh.astype(np.int32), K_wl5=K_wl.astype(np.int32), K_sp=K_sp.astype(np.int64),
         K_wl3_tr=K_wl_tr.astype(np.int32), K_sp_tr=K_sp_tr.astype(np.int64),
         K_wl3_tr_norm=K_wl_tr_norm,
@@ -141,6 +150,10 @@ def small_sets():
         wln = WeisfeilerLehman(n_iter=2, normalize=True)
         out[name + "/wl2n_fit"] = wln.fit_transform(tr)
         out[name + "/wl2n_tr"] = wln.transform(te)
+        if True:                      # dict sets carry isolated {v: []} vertices, which WL-OA drops entirely
+            oa = WeisfeilerLehmanOptimalAssignment(n_iter=3)
+            out[name + "/oa3_fit"] = as_int(oa.fit_transform(tr))
+            out[name + "/oa3_tr"] = as_int(oa.transform(te))
         vh = VertexHistogram()
         out[name + "/vh_fit"] = as_int(vh.fit_transform(tr))
         out[name + "/vh_tr"] = as_int(vh.transform(te))
@@ -164,8 +177,18 @@ def small_sets():
     print("small sets:", len(out), "arrays")
 
 
-def er_config(tag, N, n, p, L, seed, h, nsamp):
+def er_config(tag, N, n, p, L, seed, h, nsamp, with_oa=True):
     G = er_dataset(N, n, p, L, seed)
+    oa = dict()
+    if with_oa:      # WL-OA keeps a dense N x (all labels) float64 histogram: config 3 would need 400 GB
+        t0 = time.perf_counter()
+        Ko = as_int(WeisfeilerLehmanOptimalAssignment(n_iter=h).fit_transform(G))
+        oa_dt = time.perf_counter() - t0
+        oi, oj, ov = sample_entries(Ko, nsamp, 321)
+        oa = dict(oa_sum=np.array([Ko.sum()], np.int64), oa_row_sums=Ko.sum(axis=1).astype(np.int64),
+                  oa_block=Ko[:64, :64].astype(np.int32), oa_samp_i=oi, oa_samp_j=oj,
+                  oa_samp_v=ov.astype(np.int32), oa_ref_seconds=np.array([oa_dt]))
+        print("ER", tag, "WL-OA ref %.2fs" % oa_dt, "sum", Ko.sum())
     t0 = time.perf_counter()
     wl = WeisfeilerLehman(n_iter=h)
     K = wl.fit_transform(G)
@@ -180,7 +203,7 @@ def er_config(tag, N, n, p, L, seed, h, nsamp):
         K_max=np.array([Ki.max()], np.int64), diag=np.diagonal(Ki).astype(np.int32),
         K_block=Ki[:64, :64].astype(np.int32), row_sums=Ki.sum(axis=1).astype(np.int64),
         samp_i=i, samp_j=j, samp_v=v.astype(np.int32),
-        ref_seconds=np.array([dt]))
+        ref_seconds=np.array([dt]), **oa)
     print("ER", tag, "ref %.2fs" % dt, "sum", Ki.sum(), "trace", np.trace(Ki), "max", Ki.max(),
           "counts", [len(wl._inv_labels[k]) for k in range(h + 1)])
 
@@ -216,4 +239,4 @@ if __name__ == "__main__":
     nci1_sp(300)
     if not a.skip_big:
         nci1_sp(4110)
-        er_config("config3", 10000, 100, 0.05, 5, 0, 5, 20000)
+        er_config("config3", 10000, 100, 0.05, 5, 0, 5, 20000, with_oa=False)

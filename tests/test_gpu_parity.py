@@ -481,3 +481,85 @@ def test_edge_histogram_against_reference_goldens(gk, mutag_graphs):
     assert np.array_equal(gk.GraphKernel(kernel="EH").fit_transform(G[:120]), z["K_eh"])
     with pytest.raises(TypeError):
         gk.EdgeHistogram().fit_transform([[g[0], g[1]] for g in G[:3]])      # needs edge labels
+
+
+# ------------------------------------------------------------------------------------------
+# WL optimal assignment: histogram intersection over the WL hierarchy
+# ------------------------------------------------------------------------------------------
+def test_wloa_against_reference_goldens(gk, mutag_graphs):
+    G, z = mutag_graphs
+    oa = gk.WeisfeilerLehmanOptimalAssignment(n_iter=4)
+    assert np.array_equal(oa.fit_transform(G[:120]), z["K_oa4"])
+    assert np.array_equal(oa.diagonal(), np.diagonal(z["K_oa4"]))
+    assert np.array_equal(oa.transform(G[120:]), z["K_oa4_tr"])
+    oan = gk.WeisfeilerLehmanOptimalAssignment(n_iter=2, normalize=True)
+    assert np.allclose(oan.fit_transform(G[:120]), z["K_oa2_norm"], rtol=REL_TOL, atol=0)
+    assert np.allclose(oan.transform(G[120:]), z["K_oa2_norm_tr"], rtol=REL_TOL, atol=0)
+    assert np.array_equal(gk.GraphKernel(kernel={"name": "WL-OA", "n_iter": 4}).fit_transform(G[:120]), z["K_oa4"])
+
+
+@pytest.mark.parametrize("name", ["dict_u", "adj_u", "adj_d", "tuples_d", "dense_big"])
+def test_wloa_small_sets_against_reference(gk, name):
+    """Every input format incl. the dict set whose isolated ``{v: []}`` vertices WL-OA drops."""
+    z = load_golden("small_sets.npz")
+    tr, te = split(random_labelled_graphs(**dict(SMALL_SETS)[name]))
+    oa = gk.WeisfeilerLehmanOptimalAssignment(n_iter=3)
+    assert np.array_equal(oa.fit_transform(tr), z[name + "/oa3_fit"])
+    assert np.array_equal(oa.transform(te), z[name + "/oa3_tr"])
+
+
+@pytest.mark.parametrize("low_df", ["2", "32", "1000000"])
+def test_wloa_er_set_against_oracle_all_column_classes(gk, low_df, monkeypatch):
+    """600 ER graphs: dense (unary-expanded), rare (pair updates with min) and dead columns all
+    occur; GK_LOW_DF moves the dense/rare boundary to both extremes."""
+    monkeypatch.setenv("GK_LOW_DF", low_df)
+    G = er_dataset(600, 30, 0.12, 3, 5)
+    want = O.WLOAOracle(n_iter=3)
+    Kw = want.fit_transform(G[:400])
+    oa = gk.WeisfeilerLehmanOptimalAssignment(n_iter=3)
+    assert np.array_equal(oa.fit_transform(G[:400]), Kw)
+    assert np.array_equal(oa.transform(G[400:]), want.transform(G[400:]))
+    X_diag, Y_diag = oa.diagonal()
+    assert np.array_equal(X_diag, want.x_diag) and np.array_equal(Y_diag, want.y_diag)
+
+
+def test_wloa_counts_above_int8_and_properties(gk):
+    """Graphs with > 127 equally labelled vertices (unary width > 127), and the kernel's own
+    invariants at a size the oracle cannot reach: K_ii = (n_iter+1) * |V_i|, K symmetric,
+    K_ij <= min(K_ii, K_jj), and the h-level kernel is monotone in h."""
+    G = random_labelled_graphs(30, 150, 300, 0.03, 2, 77, fmt="adj")
+    want = O.WLOAOracle(n_iter=2).fit_transform(G)
+    assert np.array_equal(gk.WeisfeilerLehmanOptimalAssignment(n_iter=2).fit_transform(G), want)
+    batch = gk.GraphBatch(*er_dataset_csr(3000, 60, 0.08, 4, 9), 4)
+    K2 = gk.WeisfeilerLehmanOptimalAssignment(n_iter=2).fit_transform(batch)
+    K3 = gk.WeisfeilerLehmanOptimalAssignment(n_iter=3).fit_transform(batch)
+    assert np.array_equal(K2, K2.T) and np.array_equal(np.diagonal(K2), np.full(3000, 3 * 60.0))
+    assert np.all(K2 <= np.minimum.outer(np.diagonal(K2), np.diagonal(K2)))
+    assert np.all(K3 >= K2) and np.array_equal(np.diagonal(K3), np.full(3000, 4 * 60.0))
+
+
+def test_wloa_er_configs_against_reference_checksums(gk):
+    """ER n200 and BASELINE config 2 (1000 graphs, n=50, h=3; the real reference takes 185 s).
+    Dict-of-lists input on purpose: its isolated ``{v: []}`` vertices have no edge-dictionary
+    entry and drop out of WL-OA (a packed GraphBatch would keep them)."""
+    for tag in ("n200", "config2"):
+        z = load_golden("er_%s.npz" % tag)
+        N, n, L, seed, h = z["params"].tolist()
+        K = gk.WeisfeilerLehmanOptimalAssignment(n_iter=h).fit_transform(
+            er_dataset(N, n, float(z["p"][0]), L, seed))
+        assert int(K.sum()) == int(z["oa_sum"][0]) and np.array_equal(K[:64, :64], z["oa_block"])
+        assert np.array_equal(K.sum(axis=1), z["oa_row_sums"])
+        assert np.array_equal(K[z["oa_samp_i"], z["oa_samp_j"]], z["oa_samp_v"])
+        assert np.array_equal(K, K.T)
+
+
+def test_wloa_error_behaviour(gk):
+    with pytest.raises(TypeError):
+        gk.WeisfeilerLehmanOptimalAssignment(n_iter=0).fit([[{0: [1], 1: [0]}, {0: 'a', 1: 'b'}]])
+    with pytest.raises(KeyError):       # an edge-dictionary entry without a label (:177)
+        gk.WeisfeilerLehmanOptimalAssignment().fit_transform([[{0: [1], 1: [0, 2]}, {0: 'a', 1: 'b'}]])
+    oa = gk.WeisfeilerLehmanOptimalAssignment(n_iter=2).fit([[{0: [1], 1: [0]}, {0: 'a', 1: 'b'}]])
+    with pytest.raises(ValueError):
+        oa.transform([[{0: [1], 1: [0]}]])                 # transform wants 2 or 3 elements (:327-337)
+    with pytest.raises(ValueError):
+        oa.transform(None)

@@ -231,3 +231,25 @@ def test_tu_loader_gives_the_same_batch_as_the_object_path(tmp_path, mutag_graph
     assert classes.shape == (188,) and batch.n_graphs == 188 and batch.label_map == mapping
     assert np.array_equal(batch.graph_ptr, ref.graph_ptr) and np.array_equal(batch.node_label, ref.node_label)
     assert _adjacency_sets(batch) == _adjacency_sets(ref)
+
+
+def test_wloa_ingestion_keeps_only_vertices_with_an_edge_dictionary_entry():
+    """weisfeiler_lehman_optimal_assignment.py:176: from level 1 on only ``Gs_ed[j].keys()`` are
+    relabelled, and the histogram is built from those vertices alone (:201-206)."""
+    from grakel_amd.batch import wloa_batch_from_input
+    g = [[{0: [1], 1: [0], 2: []}, {0: 'a', 1: 'b', 2: 'a'}],            # {2: []} leaves no entry
+         [{0: [1, 2], 1: [0], 2: [0]}, {0: 'a', 1: 'b', 2: 'c'}]]
+    b, mapping = wloa_batch_from_input(g)
+    assert b.graph_ptr.tolist() == [0, 2, 5] and mapping == {'a': 0, 'b': 1, 'c': 2}
+    assert b.node_label.tolist() == [0, 1, 0, 1, 2]
+    assert b.col_idx.tolist() == [1, 0, 3, 4, 2, 2]
+    sink = [[{0: [1], 1: [0, 2]}, {0: 'a', 1: 'b', 2: 'a'}]]              # a pure sink gets an entry
+    assert wloa_batch_from_input(sink)[0].graph_ptr.tolist() == [0, 3]
+    A = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 0]])                       # adjacency: all indices
+    assert wloa_batch_from_input([[A, {0: 'a', 1: 'b', 2: 'c'}]])[0].graph_ptr.tolist() == [0, 3]
+    with pytest.raises(KeyError):
+        wloa_batch_from_input([[A, {0: 'a', 1: 'b'}]])                    # entry without a label
+    with pytest.raises(ValueError):
+        wloa_batch_from_input([[A]], fitted_labels={}, fit=False)
+    with pytest.raises(TypeError):
+        wloa_batch_from_input([[A]])

@@ -73,6 +73,12 @@ def test_mutag_against_reference(mutag_graphs):
     assert np.array_equal(eh.fit_transform(G[:120]), z["K_eh"])
     assert np.array_equal(eh.transform(G[120:]), z["K_eh_tr"])
     assert np.allclose(O.EHOracle(normalize=True).fit_transform(G), z["K_eh_norm"], rtol=1e-13, atol=0)
+    oa = O.WLOAOracle(n_iter=4)
+    assert np.array_equal(oa.fit_transform(G[:120]), z["K_oa4"])
+    assert np.array_equal(oa.transform(G[120:]), z["K_oa4_tr"])
+    oan = O.WLOAOracle(n_iter=2, normalize=True)
+    assert np.allclose(oan.fit_transform(G[:120]), z["K_oa2_norm"], rtol=1e-13, atol=0)
+    assert np.allclose(oan.transform(G[120:]), z["K_oa2_norm_tr"], rtol=1e-13, atol=0)
 
 
 @pytest.mark.parametrize("name", ["dict_u", "adj_u", "adj_d", "tuples_d", "dense_big"])
@@ -89,6 +95,10 @@ def test_small_sets_against_reference(name):
     wln = O.WLOracle(n_iter=2, normalize=True)
     assert np.allclose(wln.fit_transform(tr), z[name + "/wl2n_fit"], rtol=1e-13, atol=0)
     assert np.allclose(wln.transform(te), z[name + "/wl2n_tr"], rtol=1e-13, atol=0)
+    if name + "/oa3_fit" in z.files:
+        oa = O.WLOAOracle(n_iter=3)
+        assert np.array_equal(oa.fit_transform(tr), z[name + "/oa3_fit"])
+        assert np.array_equal(oa.transform(te), z[name + "/oa3_tr"])
     vh = O.VHOracle()
     assert np.array_equal(vh.fit_transform(tr), z[name + "/vh_fit"])
     assert np.array_equal(vh.transform(te), z[name + "/vh_tr"])
@@ -120,6 +130,11 @@ def test_er_n200_and_config2_against_reference():
         assert np.array_equal(K[:64, :64], z["K_block"])
         assert np.array_equal(K[z["samp_i"], z["samp_j"]], z["samp_v"])
         assert np.array_equal(K.sum(axis=1), z["row_sums"])
+        if tag == "n200":        # WL-OA (the reference needs 185 s for config 2: GPU tests use its checksums)
+            Ko = O.WLOAOracle(n_iter=h).fit_transform(G)
+            assert int(Ko.sum()) == int(z["oa_sum"][0]) and np.array_equal(Ko[:64, :64], z["oa_block"])
+            assert np.array_equal(Ko.sum(axis=1), z["oa_row_sums"])
+            assert np.array_equal(Ko[z["oa_samp_i"], z["oa_samp_j"]], z["oa_samp_v"])
     assert z["label_counts"].tolist() == [5, 6456, 49608, 49730]
     assert int(z["K_sum"][0]) == 501709926 and int(z["K_trace"][0]) == 691748
 
