@@ -436,13 +436,15 @@ def _sp_graph_arrays(gobj, labels, with_labels):
     return n, vals, ii, jj, wi
 
 
-def sp_batch_from_input(X, with_labels, fitted_labels=None):
+def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_iterable=TypeError):
     if isinstance(X, GraphBatch):
         return X, None
     msg = 'each element of X must have at least one and at most 3 elements\n'
     ok = (lambda n: n in (2, 3)) if with_labels else (lambda n: n in (1, 2, 3))
+    if len_ok is not None:
+        ok = len_ok
     sizes, srcs, dsts, wts, values = [], [], [], [], []
-    for x in iter_elements(X, ok, msg):
+    for x in iter_elements(X, ok, msg, not_iterable):
         if _is_graph_object(x):
             gobj, labels = x, (x.get_labels(purpose="dictionary") if with_labels else {})
         else:

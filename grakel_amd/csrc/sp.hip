@@ -250,15 +250,28 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
 
 extern "C" int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_labels,
                            gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys) {
+    return gk_sp_build_levels(ctx, b, edge_weight, with_labels, 1, out_pair_batch, out_n_pairs, out_n_keys);
+}
+
+// One pair batch with n_levels levels: level l holds the dictionary ids of the keys
+// (l_u, l_v, d) built from the WL labels of level l (level 0 = the input labels), so that
+// gk_features_build(pair_batch, n_levels, ...) + gk_gram give sum_l K_SP(level l) -- the WL
+// framework over the ShortestPath base kernel (weisfeiler_lehman.py:260-270).  Distances are
+// computed once.
+extern "C" int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_labels,
+                                  int n_levels, gk_batch** out_pair_batch, int64_t* out_n_pairs,
+                                  int64_t* out_n_keys) {
     GK_ARG(ctx && b && out_pair_batch, "gk_sp_build: null argument");
     GK_ARG(!b->is_pair_batch, "gk_sp_build: needs a graph batch");
+    GK_ARG(n_levels >= 1, "gk_sp_build_levels: n_levels must be >= 1");
+    GK_ARG(n_levels == 1 || n_levels <= b->n_levels,
+           "gk_sp_build_levels: levels not computed (call gk_wl_relabel first)");
     GK_HIP_CHECK(hipSetDevice(ctx->device));
     ProfScope prof(ctx, "sp");
-    const i64 N = b->n_graphs;
+    const i64 N = b->n_graphs, V = b->n_nodes;
     SpDist s(ctx);
     u64 total_sq = 0;
     GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq));
-    // pair offsets
     // pair offsets double as the pair batch's graph_ptr[N+1]
     Tmp<u32> ptotal(ctx);
     void* gpq = nullptr;
@@ -272,10 +285,7 @@ extern "C" int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     GK_HIP_CHECK(hipMemcpyAsync(&h_pairs, ptotal.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipMemcpyAsync(&h_maxd, s.maxd.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const u64 L = with_labels ? (u64)(b->n_labels0 > 0 ? b->n_labels0 : 1) : 1;
     const u64 d1 = (u64)h_maxd + 1;
-    GK_ARG(2 * bits_for64(L) + bits_for64(d1) <= 63, "ShortestPath: (label,label,distance) key exceeds 64 bits");
-    const int key_bits = bits_for64(d1 * L * L - 1);
     gk_batch* pb = new gk_batch();
     pb->ctx = ctx, pb->is_pair_batch = true;
     pb->n_graphs = N, pb->n_nodes = h_pairs, pb->n_edges = 0, pb->n_labels0 = 0;
@@ -289,30 +299,45 @@ extern "C" int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     const size_t np = h_pairs > 0 ? h_pairs : 1;
     if ((r = gk_dev_alloc(ctx, &q, np * 4))) return fail(r);
     pb->node_graph = (i32*)q;
-    if ((r = gk_dev_alloc(ctx, &q, np * 4))) return fail(r);
+    if ((r = gk_dev_alloc(ctx, &q, np * 4 * (size_t)n_levels))) return fail(r);
     pb->labels = (i32*)q;
-    if ((r = gk_dev_alloc(ctx, &q, np * 4))) return fail(r);
+    if ((r = gk_dev_alloc(ctx, &q, np * 4 * (size_t)n_levels))) return fail(r);
     pb->perm = (i32*)q;
-    pb->cap_levels = 1;
+    pb->cap_levels = n_levels;
     Tmp<u64> keys(ctx);
     Tmp<u32> nkeys(ctx);
-    if ((r = keys.alloc(np)) || (r = nkeys.alloc(1))) return fail(r);
-    sp_emit_kernel<<<dim3((unsigned)N), SP_THREADS, 0, ctx->stream>>>(
-        b->graph_ptr, b->labels /* level 0 */, s.dist_ptr.p, s.dist.p, pair_base, keys.p, pb->node_graph,
-        L, d1, with_labels ? 1 : 0);
-    if ((r = gk_dictionary_from_keys(ctx, keys.p, h_pairs, key_bits, pb->labels, pb->perm, nkeys.p)))
-        return fail(r);
-    u32 h_keys = 0;
-    if (hipMemcpyAsync(&h_keys, nkeys.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+    if ((r = keys.alloc(np)) || (r = nkeys.alloc((size_t)n_levels))) return fail(r);
+    for (int l = 0; l < n_levels; ++l) {
+        u64 L = 1;
+        if (with_labels) {
+            const i64 cnt = l == 0 ? (i64)b->n_labels0 : (i64)b->label_counts[l];
+            L = (u64)(cnt > 0 ? cnt : 1);
+            if (l == 0 && b->n_levels > 0 && (u64)b->label_counts[0] > L) L = (u64)b->label_counts[0];
+        }
+        if (2 * bits_for64(L) + bits_for64(d1) > 63) {
+            gk_set_error("ShortestPath: (label,label,distance) key exceeds 64 bits");
+            return fail(GK_ERR_ARG);
+        }
+        const int key_bits = bits_for64(d1 * L * L - 1);
+        sp_emit_kernel<<<dim3((unsigned)N), SP_THREADS, 0, ctx->stream>>>(
+            b->graph_ptr, b->labels + (size_t)l * V, s.dist_ptr.p, s.dist.p, pair_base, keys.p, pb->node_graph,
+            L, d1, with_labels ? 1 : 0);
+        if ((r = gk_dictionary_from_keys(ctx, keys.p, h_pairs, key_bits, pb->labels + (size_t)l * np,
+                                         pb->perm + (size_t)l * np, nkeys.p + l)))
+            return fail(r);
+    }
+    std::vector<u32> h_keys((size_t)n_levels, 0);
+    if (hipMemcpyAsync(h_keys.data(), nkeys.p, 4 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         gk_set_error("gk_sp_build: %s", hipGetErrorString(hipGetLastError()));
         return fail(GK_ERR_HIP);
     }
-    pb->n_levels = 1;
-    pb->label_counts.assign(1, h_keys);
+    pb->n_levels = n_levels;
+    pb->label_counts.assign(h_keys.begin(), h_keys.end());
     *out_pair_batch = pb;
     if (out_n_pairs) *out_n_pairs = h_pairs;
-    if (out_n_keys) *out_n_keys = h_keys;
+    if (out_n_keys)
+        for (int l = 0; l < n_levels; ++l) out_n_keys[l] = h_keys[l];
     return GK_OK;
 }
 

@@ -172,13 +172,15 @@ class Engine(object):
         return fl.value, ms.value
 
     # -- shortest paths -------------------------------------------------------------------------
-    def sp_build(self, db, edge_weight, with_labels):
+    def sp_build(self, db, edge_weight, with_labels, n_levels=1):
+        """Pair batch of the ShortestPath features; n_levels > 1 keys level l by the WL labels of
+        level l (``wl_relabel(db, n_levels - 1)`` first): the WL framework over the SP base kernel."""
         h = c_void_p()
-        npairs, nkeys = c_int64(), c_int64()
-        check(self.lib.gk_sp_build(self.handle, db.handle, _ptr(edge_weight), 1 if with_labels else 0,
-                                   byref(h), byref(npairs), byref(nkeys)))
+        npairs, nkeys = c_int64(), (c_int64 * int(n_levels))()
+        check(self.lib.gk_sp_build_levels(self.handle, db.handle, _ptr(edge_weight), 1 if with_labels else 0,
+                                          int(n_levels), byref(h), byref(npairs), nkeys))
         pb = DeviceBatch(self, h, db.n_graphs, npairs.value, 0)
-        pb.label_counts = [nkeys.value]
+        pb.label_counts = [int(k) for k in nkeys]
         return pb
 
     def sp_debug_apsp(self, db, edge_weight, graph, n):

@@ -3,8 +3,9 @@
 import numpy as np
 from sklearn.utils.validation import check_is_fitted
 
-from .batch import wl_batch_from_input
+from .batch import GraphBatch, sp_batch_from_input, wl_batch_from_input
 from .kernel import Kernel, NORM_NONE, NORM_NAN_TO_NUM
+from .shortest_path import ShortestPath
 from .vertex_histogram import VertexHistogram, FittedFeatures
 
 
@@ -12,7 +13,10 @@ class WeisfeilerLehman(Kernel):
     """Sum over WL levels 0..n_iter of the vertex-histogram kernel of the relabelled graphs.
 
     Parameters as the reference (weisfeiler_lehman.py:58-65): n_jobs, verbose, normalize,
-    n_iter=5, base_graph_kernel=VertexHistogram (the only base kernel on the accelerated path).
+    n_iter=5, base_graph_kernel=VertexHistogram.  Base kernels on the accelerated path:
+    ``VertexHistogram`` (the WL-subtree kernel) and ``ShortestPath`` (class or
+    ``(ShortestPath, {params})``): one APSP, then per level the pairs keyed by
+    that level's WL labels, all levels concatenated into one Gram product.
     """
 
     _graph_format = "dictionary"
@@ -47,10 +51,14 @@ class WeisfeilerLehman(Kernel):
                     raise ValueError('If the second argument of base kernel exists, it must be a '
                                      'dictionary between parameters names and values')
                 params.pop("normalize", None)
-            if base is not VertexHistogram:
+            if base is ShortestPath:
+                probe = ShortestPath(**{k: v for k, v in params.items() if k != "normalize"})
+                probe.initialize()                       # validates algorithm_type like the reference
+                self._sp_with_labels = bool(probe.with_labels)
+            elif base is not VertexHistogram:
                 raise NotImplementedError(
-                    'grakel_amd accelerates WeisfeilerLehman with the VertexHistogram base kernel '
-                    '(the WL-subtree kernel); other base kernels are outside the MI355X hot path')
+                    'grakel_amd accelerates WeisfeilerLehman with the VertexHistogram and '
+                    'ShortestPath base kernels; other base kernels are outside the MI355X hot path')
             params["normalize"] = False
             params["verbose"] = self.verbose
             params["n_jobs"] = None
@@ -65,11 +73,40 @@ class WeisfeilerLehman(Kernel):
 
     def _ingest(self, X, fitted):
         not_iter = TypeError if fitted is None else ValueError      # :143-144 vs :358-359
+        if self._base_graph_kernel is ShortestPath:
+            # the SP node set (every vertex of the graph object, with edge weights); WL itself
+            # always needs the labels, whatever the base kernel's with_labels says
+            return sp_batch_from_input(X, True, fitted, len_ok=lambda n: n >= 2, not_iterable=not_iter)
         return wl_batch_from_input(X, fitted, min_len=2, not_iterable=not_iter)
 
     def _prepare(self, engine, dbatch):
         engine.wl_relabel(dbatch, self._n_iter - 1)
+        if self._base_graph_kernel is ShortestPath:
+            w = self._cur_batch.edge_weight
+            if w is not None and (w.size == 0 or np.all(w == 1)):
+                w = None
+            pb = engine.sp_build(dbatch, w, self._sp_with_labels, n_levels=self._n_iter)
+            pb._parent = dbatch
+            pb.label_counts, pb.pair_key_counts = dbatch.label_counts, pb.label_counts
+            return pb, self._n_iter
         return dbatch, self._n_iter
+
+    def _gram_fit(self):
+        self._cur_batch = self._fit_batch
+        return super(WeisfeilerLehman, self)._gram_fit()
+
+    def _gram_transform(self, Y):
+        ybatch, _ = self._ingest(Y, self._label_map if self._label_map is not None else {})
+        self._ny = ybatch.n_graphs
+        self._cur_batch = GraphBatch.concat(self._fit_batch, ybatch)
+        eng = self._engine()
+        db = eng.upload(self._cur_batch)
+        fb, n_levels = self._prepare(eng, db)
+        feat = eng.features(fb, n_levels, n_fit=self._nx)
+        selfk = eng.selfk(feat)
+        self._X_diag = selfk[:self._nx]
+        self._Y_diag = selfk[self._nx:]
+        return eng, feat
 
     def _after_fit(self):
         self._inv_labels = {0: dict(self._label_map) if self._label_map is not None else {}}

@@ -159,6 +159,14 @@ int gk_gram_last_stats(gk_feat* f, double* out_flops, double* out_ms_event);
  * exposed as level 0 of a derived batch so that gk_features_build / gk_gram apply unchanged. */
 int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_labels,
                 gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys);
+/* The WL framework over the ShortestPath base kernel
+ * (WeisfeilerLehman(base_graph_kernel=ShortestPath): grakel/kernels/weisfeiler_lehman.py:77-109
+ * resolves the base class, :260-270 fits one base kernel per level on (graph, level labels) and
+ * sums their matrices).  After gk_wl_relabel(b, n_levels - 1): level l of the pair batch keys the
+ * pairs by the level-l WL labels (distances computed once), so gk_features_build(pair_batch,
+ * n_levels, ...) + gk_gram return sum_l K_SP(level l).  out_n_keys: int64[n_levels]. */
+int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_labels, int n_levels,
+                       gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys);
 /* Test hook: all-pairs distance matrix of one graph (n x n int32, -1 = unreachable). */
 int gk_sp_debug_apsp(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int64_t graph,
                      int32_t* out_dist);

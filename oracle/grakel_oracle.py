@@ -479,6 +479,36 @@ class SPOracle(object):
         return _normalize(K, self.y_diag, self.x_diag, False) if self.normalize else K
 
 
+class WLSPOracle(object):
+    """WeisfeilerLehman(base_graph_kernel=ShortestPath): the framework fits one base kernel per
+    level on ``(graph, level labels)`` and sums the matrices (weisfeiler_lehman.py:260-270,
+    transform :478-494); normalisation happens once, on the sum (:323-328)."""
+
+    def __init__(self, n_iter=5, normalize=False, with_labels=True):
+        self.n_iter, self.normalize, self.with_labels = n_iter, normalize, with_labels
+
+    def fit_transform(self, X):
+        els = _elements(X, lambda n: n >= 2, 'a list with at least a graph and node labels')
+        self.wl = WLOracle(self.n_iter)
+        self.wl.fit_transform(X, keep_levels=True)
+        self.sp, K = [], 0
+        for lev in self.wl.levels:
+            sp = SPOracle(with_labels=self.with_labels)
+            K = K + sp.fit_transform([[x[0], d] for x, d in zip(els, lev)])
+            self.sp.append(sp)
+        self.x_diag = np.diagonal(K).copy()
+        return _normalize(K, self.x_diag, self.x_diag, True) if self.normalize else K
+
+    def transform(self, Y):
+        els = _elements(Y, lambda n: n >= 2, 'a list with at least a graph and node labels')
+        self.wl.transform(Y, keep_levels=True)
+        K, self.y_diag = 0, 0
+        for sp, lev in zip(self.sp, self.wl.y_levels):
+            K = K + sp.transform([[y[0], d] for y, d in zip(els, lev)])
+            self.y_diag = self.y_diag + sp.y_diag
+        return _normalize(K, self.y_diag, self.x_diag, True) if self.normalize else K
+
+
 # --------------------------------------------------------------------------
 # Partition helper used by the parity tests ("bit-exact integer WL labels" ==
 # same partition of the nodes per level, SURVEY.md 8c)

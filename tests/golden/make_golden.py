@@ -102,6 +102,12 @@ def mutag():
     oan = WeisfeilerLehmanOptimalAssignment(n_iter=2, normalize=True)
     K_oa_norm = oan.fit_transform(G[:120])
     K_oa_norm_tr = oan.transform(G[120:])
+    wsp = WeisfeilerLehman(n_iter=2, base_graph_kernel=ShortestPath)
+    K_wlsp = as_int(wsp.fit_transform(G[:100]))
+    K_wlsp_tr = as_int(wsp.transform(G[100:140]))
+    wspn = WeisfeilerLehman(n_iter=1, normalize=True, base_graph_kernel=(ShortestPath, {"with_labels": True}))
+    K_wlspn = wspn.fit_transform(G[:100])
+    K_wlspn_tr = wspn.transform(G[100:140])
     eh = EdgeHistogram()
     K_eh = as_int(eh.fit_transform(G[:120]))
     K_eh_tr = as_int(eh.transform(G[120:]))
@@ -126,6 +132,8 @@ def mutag():
         node_label=np.array(labs, np.int32), edge_src=np.array(src, np.int32),
         edge_dst=np.array(dst, np.int32), edge_label=np.array(elab, np.int32),
         K_eh=K_eh.astype(np.int32), K_eh_tr=K_eh_tr.astype(np.int32), K_eh_norm=K_eh_norm,
+        K_wlsp2=K_wlsp.astype(np.int64), K_wlsp2_tr=K_wlsp_tr.astype(np.int64), K_wlsp1_norm=K_wlspn,
+        K_wlsp1_norm_tr=K_wlspn_tr,
         K_oa4=K_oa.astype(np.int32), K_oa4_tr=K_oa_tr.astype(np.int32), K_oa2_norm=K_oa_norm,
         K_oa2_norm_tr=K_oa_norm_tr,
         K_vh=K_vh.astype(np.int32), K_wl5=K_wl.astype(np.int32), K_sp=K_sp.astype(np.int64),
@@ -171,6 +179,9 @@ def small_sets():
             spu = ShortestPath(with_labels=False)
             out[name + "/spu_fit"] = as_int(spu.fit_transform(trs))
             out[name + "/spu_tr"] = as_int(spu.transform(tes))
+            wsp = WeisfeilerLehman(n_iter=2, base_graph_kernel=ShortestPath)
+            out[name + "/wlsp2_fit"] = as_int(wsp.fit_transform(trs))
+            out[name + "/wlsp2_tr"] = as_int(wsp.transform(tes))
         except KeyError as e:           # tuples sets can hit the Dijkstra sink-vertex bug
             print("  SP skipped for", name, "(reference KeyError %s)" % e)
     np.savez_compressed(os.path.join(HERE, "small_sets.npz"), **out)

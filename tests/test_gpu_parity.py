@@ -563,3 +563,52 @@ def test_wloa_error_behaviour(gk):
         oa.transform([[{0: [1], 1: [0]}]])                 # transform wants 2 or 3 elements (:327-337)
     with pytest.raises(ValueError):
         oa.transform(None)
+
+
+# ------------------------------------------------------------------------------------------
+# WL framework over the ShortestPath base kernel
+# ------------------------------------------------------------------------------------------
+def test_wl_with_shortest_path_base_against_reference_goldens(gk, mutag_graphs):
+    G, z = mutag_graphs
+    wsp = gk.WeisfeilerLehman(n_iter=2, base_graph_kernel=gk.ShortestPath)
+    assert np.array_equal(wsp.fit_transform(G[:100]), z["K_wlsp2"])
+    assert np.array_equal(wsp.diagonal(), np.diagonal(z["K_wlsp2"]))
+    assert np.array_equal(wsp.transform(G[100:140]), z["K_wlsp2_tr"])
+    wspn = gk.WeisfeilerLehman(n_iter=1, normalize=True,
+                               base_graph_kernel=(gk.ShortestPath, {"with_labels": True}))
+    assert np.allclose(wspn.fit_transform(G[:100]), z["K_wlsp1_norm"], rtol=REL_TOL, atol=0)
+    assert np.allclose(wspn.transform(G[100:140]), z["K_wlsp1_norm_tr"], rtol=REL_TOL, atol=0)
+    K = gk.GraphKernel(kernel=[{"name": "WL", "n_iter": 2}, {"name": "SP"}]).fit_transform(G[:100])
+    assert np.array_equal(K, z["K_wlsp2"])
+    with pytest.raises(ValueError):
+        gk.WeisfeilerLehman(base_graph_kernel=(gk.ShortestPath, {"algorithm_type": "bfs"})).fit(G[:3])
+    with pytest.raises(NotImplementedError):
+        gk.WeisfeilerLehman(base_graph_kernel=gk.EdgeHistogram).fit(G[:3])
+
+
+@pytest.mark.parametrize("name", ["dict_u", "adj_u", "adj_d", "tuples_d", "dense_big"])
+def test_wl_with_shortest_path_base_small_sets(gk, name):
+    z = load_golden("small_sets.npz")
+    if name + "/wlsp2_fit" not in z.files:
+        pytest.skip("the reference's ShortestPath raises on this set (Dijkstra sink-vertex KeyError)")
+    kw = dict(SMALL_SETS)[name]
+    tr, te = split(random_labelled_graphs(**kw))
+    trs, tes = sp_inputs(kw, tr), sp_inputs(kw, te)
+    wsp = gk.WeisfeilerLehman(n_iter=2, base_graph_kernel=gk.ShortestPath)
+    assert np.array_equal(wsp.fit_transform(trs), z[name + "/wlsp2_fit"])
+    assert np.array_equal(wsp.transform(tes), z[name + "/wlsp2_tr"])
+
+
+def test_wl_with_shortest_path_base_weighted_and_unlabelled_against_oracle(gk):
+    """NCI1-like graphs (distances up to ~25, 37 labels) incl. the with_labels=False base: every
+    level then carries the same distance histogram, K = (n_iter + 1) * K_SP."""
+    G = nci1_like(80, 5, as_adj=True)
+    want = O.WLSPOracle(n_iter=3)
+    Kw = want.fit_transform(G[:50])
+    wsp = gk.WeisfeilerLehman(n_iter=3, base_graph_kernel=gk.ShortestPath)
+    assert np.array_equal(wsp.fit_transform(G[:50]), Kw)
+    assert np.array_equal(wsp.transform(G[50:]), want.transform(G[50:]))
+    X_diag, Y_diag = wsp.diagonal()
+    assert np.array_equal(X_diag, want.x_diag) and np.array_equal(Y_diag, want.y_diag)
+    Ku = gk.WeisfeilerLehman(n_iter=2, base_graph_kernel=(gk.ShortestPath, {"with_labels": False})).fit_transform(G[:50])
+    assert np.array_equal(Ku, 3 * gk.ShortestPath(with_labels=False).fit_transform(G[:50]))

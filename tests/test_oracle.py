@@ -73,6 +73,12 @@ def test_mutag_against_reference(mutag_graphs):
     assert np.array_equal(eh.fit_transform(G[:120]), z["K_eh"])
     assert np.array_equal(eh.transform(G[120:]), z["K_eh_tr"])
     assert np.allclose(O.EHOracle(normalize=True).fit_transform(G), z["K_eh_norm"], rtol=1e-13, atol=0)
+    wsp = O.WLSPOracle(n_iter=2)                       # WL framework over the ShortestPath base kernel
+    assert np.array_equal(wsp.fit_transform(G[:100]), z["K_wlsp2"])
+    assert np.array_equal(wsp.transform(G[100:140]), z["K_wlsp2_tr"])
+    wspn = O.WLSPOracle(n_iter=1, normalize=True)
+    assert np.allclose(wspn.fit_transform(G[:100]), z["K_wlsp1_norm"], rtol=1e-13, atol=0)
+    assert np.allclose(wspn.transform(G[100:140]), z["K_wlsp1_norm_tr"], rtol=1e-13, atol=0)
     oa = O.WLOAOracle(n_iter=4)
     assert np.array_equal(oa.fit_transform(G[:120]), z["K_oa4"])
     assert np.array_equal(oa.transform(G[120:]), z["K_oa4_tr"])
@@ -116,6 +122,9 @@ def test_small_sets_against_reference(name):
         spu = O.SPOracle(with_labels=False)
         assert np.array_equal(spu.fit_transform(trs), z[name + "/spu_fit"])
         assert np.array_equal(spu.transform(tes), z[name + "/spu_tr"])
+        wsp = O.WLSPOracle(n_iter=2)
+        assert np.array_equal(wsp.fit_transform(trs), z[name + "/wlsp2_fit"])
+        assert np.array_equal(wsp.transform(tes), z[name + "/wlsp2_tr"])
 
 
 def test_er_n200_and_config2_against_reference():
