@@ -136,6 +136,9 @@ struct gk_batch {
     i32* labels = nullptr;             // [cap_levels][n_nodes]
     i32* perm = nullptr;               // [cap_levels][n_nodes] nodes grouped by label (stable)
     std::vector<i64> label_counts;     // per level
+    // per level: perm[level][0 .. n_sorted) holds every node that can share its label with another
+    // node (grouped by label); the nodes behind it carry labels of their own.  Empty = n_nodes.
+    std::vector<i64> n_sorted;
     // scratch kept between levels
     i32* nbr_sorted = nullptr;         // [n_edges] sorted neighbour labels of the level being built
     bool is_pair_batch = false;        // ShortestPath items: no CSR, level 0 only

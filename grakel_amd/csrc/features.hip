@@ -76,7 +76,8 @@ struct TripleEmit {
 __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __restrict__ tri_of,
                                   const i32* __restrict__ tri_pos, const i32* __restrict__ tri_run,
                                   i32* __restrict__ wide, int wide_above, u32* __restrict__ node_acc,
-                                  u32* __restrict__ meta, int level, int n_levels, i64 n, int kind) {
+                                  u32* __restrict__ meta, int level, int n_levels, i64 n, int kind,
+                                  const i32* __restrict__ node_graph, u32* __restrict__ covered) {
     __shared__ u32 wmax[4];
     i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 c = 0;
@@ -86,6 +87,9 @@ __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __res
         if ((int)c > wide_above) wide[tri_run[t]] = 1;       // benign race: all writers store 1
         i32 v = perm[k];
         node_acc[v] = (level == 0 ? 0u : node_acc[v]) + (kind ? 1u : c);   // min(c,c) summed == #nodes
+        // partial level (only the nodes that may share a label are listed): count them per graph,
+        // every other node of the graph owns its label and adds exactly 1 to the self similarity
+        if (covered) atomicAdd(&covered[node_graph[v]], 1u);
     }
     for (int off = 32; off > 0; off >>= 1) {
         u32 o = __shfl_down(c, off, 64);
@@ -124,14 +128,17 @@ __global__ void feat_runmax_kernel(const i32* __restrict__ tri_pos, const i32* _
 
 // one wave per graph: selfk[g] = sum of node_acc over the graph's (contiguous) nodes
 __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* __restrict__ node_acc,
-                                  u64* __restrict__ selfk, i64 n_graphs) {
+                                  u64* __restrict__ selfk, i64 n_graphs, const u32* __restrict__ covered,
+                                  int n_partial) {
     const i64 g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (g >= n_graphs) return;
     u64 s = 0;
     for (i32 v = graph_ptr[g] + lane; v < graph_ptr[g + 1]; v += 64) s += node_acc[v];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) selfk[g] = s;
+    // n_partial levels listed only `covered[g]` (summed) of the graph's nodes: the others add 1 each
+    if (lane == 0)
+        selfk[g] = s + (u64)n_partial * (u64)(graph_ptr[g + 1] - graph_ptr[g]) - (u64)(covered ? covered[g] : 0u);
 }
 
 // Column classes per label run, fused into the prefix sum:
@@ -166,7 +173,7 @@ struct ColumnIds {
 };
 
 __global__ void feat_colbase_kernel(u32* __restrict__ meta, const u64* __restrict__ total, int level, int n_levels) {
-    const u64 t = *total;
+    const u64 t = total ? *total : 0ull;      // null: a level without any shared label
     meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + (u32)(t & 0xffffffffull);
     meta[3 * n_levels + 1] += (u32)(t >> 32) & 0x7fffffffu;     // low columns over all levels
     meta[3 * n_levels + 4 + level] = (u32)(t >> 32) & 0x7fffffffu;   // ... and of this level
@@ -262,10 +269,19 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         return fail(GK_ERR_HIP);
     }
     Tmp<u64> flag(ctx);
-    Tmp<u32> cflag(ctx), node_acc(ctx);
+    Tmp<u32> cflag(ctx), node_acc(ctx), covered(ctx);
     Tmp<u64> ctotal64(ctx);
     if ((r = flag.alloc(V)) || (r = cflag.alloc(V)) || (r = ctotal64.alloc(1)) || (r = node_acc.alloc(V)))
         return fail(r);
+    // levels whose label-grouped order only lists the nodes that can share a label (active-set
+    // relabelling, wl.hip): the feature pass runs over that prefix alone
+    int n_partial = 0;
+    auto level_items = [&](int l) -> i64 { return (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V; };
+    for (int l = 0; l < n_levels; ++l) n_partial += level_items(l) < V ? 1 : 0;
+    if (n_partial > 0) {
+        if ((r = covered.alloc(N))) return fail(r);
+        if (gk_zero_async(ctx, covered.p, (size_t)N * 4) != GK_OK) return fail(GK_ERR_HIP);
+    }
     {
         const char* e = getenv("GK_LOW_DF");     // df threshold below which a column leaves the dense operand
         f->low_df = e ? atoi(e) : 32;
@@ -284,29 +300,36 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     const int wide_above = kind == GK_FEAT_MINSUM ? 0x7fffffff : (f->dtype == 0 ? 127 : -1);
     for (int l = 0; l < n_levels && V > 0; ++l) {
         LevelTriples& L = f->lev[l];
+        const i64 nl = level_items(l);       // items of this level's label-grouped order that matter
+        if (nl == 0) {                        // every node owns its label: no triples, no columns
+            feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, nullptr, l, n_levels);
+            continue;
+        }
         i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid, &L.low_runs, &L.wide};
         for (i32** a : arrs) {
-            if ((r = gk_dev_alloc(ctx, &q, (size_t)(V + 1) * 4))) return fail(r);
+            if ((r = gk_dev_alloc(ctx, &q, (size_t)(nl + 1) * 4))) return fail(r);
             *a = (i32*)q;
         }
         const i32* lab = b->labels + (size_t)l * V;
         const i32* perm = b->perm + (size_t)l * V;
-        feat_flags_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, lab, b->node_graph, flag.p, V);
+        feat_flags_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(perm, lab, b->node_graph, flag.p, nl);
         TripleEmit te{perm, b->node_graph, flag.p, L.tri_pos, L.tri_graph, L.tri_run, L.tstart, cflag.p,
-                      f->meta, l, V};
-        if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, V, nullptr))) return fail(r);
-        if (gk_zero_async(ctx, L.wide, (size_t)(V + 1) * 4) != GK_OK) return fail(GK_ERR_HIP);
-        feat_count_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, L.tri_run, L.wide, wide_above,
-                                                                     node_acc.p, f->meta, l, n_levels, V, kind);
+                      f->meta, l, nl};
+        if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, nl, nullptr))) return fail(r);
+        if (gk_zero_async(ctx, L.wide, (size_t)(nl + 1) * 4) != GK_OK) return fail(GK_ERR_HIP);
+        feat_count_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, L.tri_run, L.wide, wide_above,
+                                                                      node_acc.p, f->meta, l, n_levels, nl, kind,
+                                                                      b->node_graph, nl < V ? covered.p : nullptr);
         if (kind == GK_FEAT_MINSUM)
-            feat_runmax_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(L.tri_pos, L.tri_run, f->meta, l, L.wide);
+            feat_runmax_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(L.tri_pos, L.tri_run, f->meta, l, L.wide);
         ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df,
                      L.low_runs, L.wide, kind};
-        if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, V, ctotal64.p))) return fail(r);
+        if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, nl, ctotal64.p))) return fail(r);
         feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, ctotal64.p, l, n_levels);
     }
     if (V > 0)
-        feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, node_acc.p, f->selfk, N);
+        feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, node_acc.p, f->selfk, N,
+                                                                          n_partial > 0 ? covered.p : nullptr, n_partial);
     // one host sync: sizes of the dense operand
     std::vector<u32> h(n_meta);
     if (hipMemcpyAsync(h.data(), f->meta, n_meta * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -326,8 +349,9 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         Tmp<u32> wtotal(ctx);
         if ((r = wtotal.alloc(1))) return fail(r);
         for (int l = 0; l < n_levels; ++l) {
+            if (level_items(l) == 0) continue;
             ColumnIdsWide cw{f->lev[l].colid, f->meta, n_levels};
-            if ((r = gk_scan_fn<u32, ColumnIdsWide>(ctx, cw, V, wtotal.p))) return fail(r);
+            if ((r = gk_scan_fn<u32, ColumnIdsWide>(ctx, cw, level_items(l), wtotal.p))) return fail(r);
             feat_widebase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, wtotal.p, n_levels);
         }
         u32 hw = 0;

@@ -149,7 +149,15 @@ int gk_scan_u64(gk_ctx* ctx, const u64* in, u64* out, i64 n, bool exclusive, u64
 }
 
 // ---------------------------------------------------------------------------------------
-// Radix sort: 8-bit digits, per pass  histogram -> exclusive scan -> stable scatter.
+// Radix sort: 8-bit digits, stable.  A kernel boundary (~2.6 us back to back on MI355X) is the
+// cheapest device-wide synchronisation available -- measured: a global atomic barrier costs
+// ~0.14 us PER WORKGROUP and a cooperative launch +18 us (tools/micro/gridbar.hip) -- so the
+// passes are organised to need as few kernels as possible:
+//   n <= RS_SMALL_TILES tiles : ONE kernel per pass.  Every block re-counts the digits of the
+//       whole (L2-resident) key array -- split into "tiles before mine" and "the rest" -- instead
+//       of reading a histogram somebody else produced.
+//   larger n : three kernels per pass -- per-tile histogram, one block per digit scanning its
+//       row of tile counts, scatter (which prefix-sums the 256 digit totals itself).
 // A block owns a tile of RS_TILE consecutive keys and processes it in RS_ROUNDS rounds of
 // 256 keys (one per thread, in index order) so that stability only needs (a) the rank of a
 // key among equal digits inside its wave (ballot match) and (b) a per-digit running count
@@ -158,6 +166,7 @@ int gk_scan_u64(gk_ctx* ctx, const u64* in, u64* out, i64 n, bool exclusive, u64
 #define RS_THREADS 256
 #define RS_ROUNDS 8
 #define RS_TILE (RS_THREADS * RS_ROUNDS)
+#define RS_SMALL_TILES 32
 
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const u64* __restrict__ kin, i64 n,
                                                                 int shift, u32* __restrict__ hist,
@@ -179,36 +188,93 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const u64* __res
     hist[(i64)tid * nblk + blockIdx.x] = h[tid];
 }
 
+// block d: exclusive prefix of digit d's tile counts (in place) and the digit total
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(u32* __restrict__ hist, int nblk,
+                                                            u32* __restrict__ totals) {
+    __shared__ u32 wsum[4];
+    const int tid = threadIdx.x;
+    u32* row = hist + (i64)blockIdx.x * nblk;
+    u32 carry = 0;
+    for (int c0 = 0; c0 < nblk; c0 += 256) {
+        const int i = c0 + tid;
+        const u32 v = i < nblk ? row[i] : 0u;
+        const u32 inc = wave_incl_scan(v);
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < (tid >> 6); ++w) woff += wsum[w];
+        const u32 all = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (i < nblk) row[i] = carry + woff + inc - v;
+        carry += all;
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = carry;
+}
+
 // Stable scatter of one 2048-key tile.  Keys are taken in index order: round r, thread t holds
-// key tile0 + r*256 + t.  Phase 1: for every (round, wave) the lanes with equal digits find
-// each other with 8 ballots; the lowest lane of a group records the group size in
-// cnt[r][w][digit] and every lane keeps its rank inside the group.  Phase 2: thread d turns the
-// 32 counts of digit d into exclusive offsets in (round, wave) order -- exactly the order the
-// keys must keep.  Phase 3: position = global base[d] + offset[r][w][d] + rank.  Three barriers
-// per tile instead of four per round.
-__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+// key tile0 + r*256 + t.  Phase 0: thread d obtains the global base of digit d for this tile
+// (SMALL: by counting the whole array; else: row offset + prefix of the digit totals).
+// Phase 1: for every (round, wave) the lanes with equal digits find each other with 8 ballots;
+// the lowest lane of a group records the group size in cnt[r][w][digit] and every lane keeps its
+// rank inside the group.  Phase 2: thread d turns the 32 counts of digit d into exclusive offsets
+// in (round, wave) order -- exactly the order the keys must keep.  Phase 3: position = global
+// base[d] + offset[r][w][d] + rank.
+template <int THREADS, bool SMALL>
+__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
-    u32* __restrict__ vout, i64 n, int shift, const u32* __restrict__ offs, int nblk) {
-    constexpr int NWAVE = RS_THREADS / 64;
-    __shared__ u32 cnt[RS_ROUNDS * NWAVE * 256];     // 32 KiB
+    u32* __restrict__ vout, i64 n, int shift, const u32* __restrict__ offs,
+    const u32* __restrict__ totals, int nblk) {
+    constexpr int NWAVE = THREADS / 64, ROUNDS = RS_TILE / THREADS, NQ = ROUNDS * NWAVE;   // NQ == 32
+    __shared__ u32 cnt[NQ * 256];     // 32 KiB
+    __shared__ u32 dsum[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const i64 tile0 = (i64)blockIdx.x * RS_TILE;
-    u64 key[RS_ROUNDS];
-    u32 val[RS_ROUNDS], rank[RS_ROUNDS];
+    u64 key[ROUNDS];
+    u32 val[ROUNDS], rank[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < RS_ROUNDS; ++r) {
-        const i64 idx = tile0 + r * RS_THREADS + tid;
+    for (int r = 0; r < ROUNDS; ++r) {
+        const i64 idx = tile0 + r * THREADS + tid;
         const bool act = idx < n;
         key[r] = act ? kin[idx] : 0ull;
         val[r] = act ? (vin ? vin[idx] : (u32)idx) : 0u;
     }
+    u32 before = 0, total = 0;
+    if (SMALL) {
+        // cnt[0..255]: digits of the keys in tiles before this one, cnt[256..511]: all the others
+        if (tid < 512) cnt[tid] = 0;
+        __syncthreads();
+        for (i64 i0 = 0; i0 < n; i0 += 4 * THREADS) {
+            u64 k[4];
 #pragma unroll
-    for (int q = 0; q < RS_ROUNDS * NWAVE; ++q) cnt[q * 256 + tid] = 0;
+            for (int u = 0; u < 4; ++u) {
+                const i64 idx = i0 + u * THREADS + tid;
+                k[u] = idx < n ? kin[idx] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const i64 idx = i0 + u * THREADS + tid;
+                if (idx < n) atomicAdd(&cnt[(idx < tile0 ? 0u : 256u) + ((u32)(k[u] >> shift) & 255u)], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            before = cnt[tid];
+            total = before + cnt[256 + tid];
+        }
+        __syncthreads();
+    } else if (tid < 256) {
+        before = offs[(i64)tid * nblk + blockIdx.x];
+        total = totals[tid];
+    }
+    const u32 dincl = wave_incl_scan(total);
+    if (lane == 63 && w < 4) dsum[w] = dincl;
+#pragma unroll
+    for (int q = 0; q < NQ * 256 / THREADS; ++q) cnt[q * THREADS + tid] = 0;
     __syncthreads();
     const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < RS_ROUNDS; ++r) {
-        const bool act = tile0 + r * RS_THREADS + tid < n;
+    for (int r = 0; r < ROUNDS; ++r) {
+        const bool act = tile0 + r * THREADS + tid < n;
         const u32 d = (u32)(key[r] >> shift) & 255u;
         u64 m = __ballot(act);
 #pragma unroll
@@ -221,10 +287,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         if (act && rank[r] == 0) cnt[(r * NWAVE + w) * 256 + d] = (u32)__popcll(m);
     }
     __syncthreads();
-    {
-        u32 run = offs[(i64)tid * nblk + blockIdx.x];    // global base of digit `tid` for this tile
+    if (tid < 256) {
+        u32 run = dincl - total + before;    // keys with smaller digits + equal digits in earlier tiles
+        for (int q = 0; q < w; ++q) run += dsum[q];
 #pragma unroll
-        for (int q = 0; q < RS_ROUNDS * NWAVE; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const u32 c = cnt[q * 256 + tid];
             cnt[q * 256 + tid] = run;
             run += c;
@@ -232,8 +299,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ROUNDS; ++r) {
-        if (tile0 + r * RS_THREADS + tid < n) {
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (tile0 + r * THREADS + tid < n) {
             const u32 d = (u32)(key[r] >> shift) & 255u;
             const u32 pos = cnt[(r * NWAVE + w) * 256 + d] + rank[r];
             kout[pos] = key[r];
@@ -251,8 +318,10 @@ int gk_radix_sort_pairs(gk_ctx* ctx, u64* keys_in, u32* vals_in, u64* keys_out, 
     int passes = (key_bits + 7) / 8;
     if (passes == 0) passes = 1;   // nothing to distinguish: one (trivial) pass keeps the code paths uniform
     int nblk = (int)cdiv(n, RS_TILE);
+    const bool small = nblk <= RS_SMALL_TILES;
     Tmp<u32> hist(ctx);
-    GK_TRY(hist.alloc((size_t)256 * nblk));
+    if (!small) GK_TRY(hist.alloc((size_t)256 * nblk + 256));
+    u32* totals = small ? nullptr : hist.p + (size_t)256 * nblk;
     u64 *ks = keys_in, *kd = keys_out;
     u32 *vs = vals_in, *vd = vals_out;
     // vals_in may be null on entry: the values are then the indices 0..n-1 (implicit iota);
@@ -265,10 +334,16 @@ int gk_radix_sort_pairs(gk_ctx* ctx, u64* keys_in, u32* vals_in, u64* keys_out, 
     }
     for (int p = 0; p < passes; ++p) {
         int shift = p * 8;
-        radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, n, shift, hist.p, nblk);
-        GK_TRY(gk_scan_u32(ctx, hist.p, hist.p, (i64)256 * nblk, true, nullptr));
-        radix_scatter_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(
-            ks, (implicit_iota && p == 0) ? nullptr : vs, kd, vd, n, shift, hist.p, nblk);
+        const u32* vsrc = (implicit_iota && p == 0) ? nullptr : vs;
+        if (small) {
+            radix_scatter_kernel<1024, true><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
+                ks, vsrc, kd, vd, n, shift, nullptr, nullptr, nblk);
+        } else {
+            radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, n, shift, hist.p, nblk);
+            radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
+            radix_scatter_kernel<RS_THREADS, false><<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(
+                ks, vsrc, kd, vd, n, shift, hist.p, totals, nblk);
+        }
         u64* tk = ks; ks = kd; kd = tk;
         u32* tv = vs; vs = vd; vd = tv;
     }

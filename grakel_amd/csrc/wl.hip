@@ -502,8 +502,10 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     const u64 full_mask = hash_bits >= 64 ? ~0ull : ((1ull << hash_bits) - 1ull);
+    b->n_sorted[level] = V;
     if (n_act == 0) {
         // every class is a singleton: the partition cannot change any more
+        b->n_sorted[level] = 0;
         GK_HIP_CHECK(hipMemcpyAsync(cur, prev, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
         GK_HIP_CHECK(hipMemcpyAsync(perm, perm - V, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
         GK_HIP_CHECK(hipMemcpyAsync(count_dev, count_dev - 1, 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -511,6 +513,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     }
     if (!exact && (u64)n_act * 4 <= (u64)V) {
         // ---- active-set path: only the n_act active nodes are hashed, sorted and verified
+        b->n_sorted[level] = n_act;
         int bits = hash_bits;
         if (hash_bits >= 32) {   // default sizing rule applied to the active set (tests may force fewer bits)
             int lg = bits_for((u64)(n_act > 1 ? n_act - 1 : 1));
@@ -597,6 +600,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     GK_TRY(meta.alloc(2 * (size_t)n_levels));
     GK_TRY(gk_zero_async(ctx, meta.p, 8 * (size_t)n_levels));
     if (out_rounds) *out_rounds = 0;
+    b->n_sorted.assign((size_t)n_levels, V);
     RelabelState st(ctx);
     GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
     // level 0: group nodes by the given label ids
