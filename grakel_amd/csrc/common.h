@@ -190,8 +190,8 @@ int gk_scan_u64(gk_ctx* ctx, const u64* in, u64* out, i64 n, bool exclusive, u64
 // Stable LSD radix sort of (key,value) pairs on key bits [0,key_bits). Result in keys_out /
 // vals_out; keys_in/vals_in are clobbered (used as ping-pong buffers).
 // implicit_iota: the input values are 0..n-1 and are never read (vals_in is scratch only).
-int gk_radix_sort_pairs(gk_ctx* ctx, u64* keys_in, u32* vals_in, u64* keys_out, u32* vals_out,
-                        i64 n, int key_bits, bool implicit_iota = false);
+int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64* keys_out, u32* vals_out,
+                        i64 n, int key_bits);
 
 // ---- wl.hip ---------------------------------------------------------------------------
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);

@@ -31,9 +31,11 @@ static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(
 #define META_C(l) (3 * (l) + 2)
 
 __global__ void feat_flags_kernel(const i32* __restrict__ perm, const i32* __restrict__ lab,
-                                  const i32* __restrict__ node_graph, u64* __restrict__ flag, i64 n) {
+                                  const i32* __restrict__ node_graph, u64* __restrict__ flag, i64 n,
+                                  i32* __restrict__ wide) {
     i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
+    wide[k] = 0;      // per-run flag / maximum filled in by the count kernels (runs <= items)
     i32 v = perm[k];
     u64 f = 0x100000001ull;
     if (k > 0) {
@@ -264,7 +266,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     if ((r = gk_dev_alloc(ctx, &q, (size_t)N * 8))) return fail(r);
     f->selfk = (u64*)q;
     if (gk_zero_async(ctx, f->meta, n_meta * 4) != GK_OK ||
-        gk_zero_async(ctx, f->selfk, (size_t)N * 8) != GK_OK) {
+        (V == 0 && gk_zero_async(ctx, f->selfk, (size_t)N * 8) != GK_OK)) {   // V > 0: feat_selfk_kernel writes it all
         gk_set_error("gk_features_build: memset failed");
         return fail(GK_ERR_HIP);
     }
@@ -312,11 +314,10 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         }
         const i32* lab = b->labels + (size_t)l * V;
         const i32* perm = b->perm + (size_t)l * V;
-        feat_flags_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(perm, lab, b->node_graph, flag.p, nl);
+        feat_flags_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(perm, lab, b->node_graph, flag.p, nl, L.wide);
         TripleEmit te{perm, b->node_graph, flag.p, L.tri_pos, L.tri_graph, L.tri_run, L.tstart, cflag.p,
                       f->meta, l, nl};
         if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, nl, nullptr))) return fail(r);
-        if (gk_zero_async(ctx, L.wide, (size_t)(nl + 1) * 4) != GK_OK) return fail(GK_ERR_HIP);
         feat_count_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, L.tri_run, L.wide, wide_above,
                                                                       node_acc.p, f->meta, l, n_levels, nl, kind,
                                                                       b->node_graph, nl < V ? covered.p : nullptr);

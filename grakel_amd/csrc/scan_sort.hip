@@ -309,9 +309,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     }
 }
 
-int gk_radix_sort_pairs(gk_ctx* ctx, u64* keys_in, u32* vals_in, u64* keys_out, u32* vals_out,
-                        i64 n, int key_bits, bool implicit_iota) {
-    // Result always lands in keys_out/vals_out; keys_in/vals_in are scratch afterwards.
+int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64* keys_out, u32* vals_out,
+                        i64 n, int key_bits) {
+    // Stable sort by the low key_bits of the keys.  The inputs are only read (vals_in == nullptr:
+    // the values are the indices 0..n-1); the passes ping-pong between the out buffers and a
+    // temporary pair, ordered so that the last pass lands in keys_out / vals_out.
     if (n <= 0) return GK_OK;
     if (key_bits < 0) key_bits = 0;
     if (key_bits > 64) key_bits = 64;
@@ -319,33 +321,28 @@ int gk_radix_sort_pairs(gk_ctx* ctx, u64* keys_in, u32* vals_in, u64* keys_out, 
     if (passes == 0) passes = 1;   // nothing to distinguish: one (trivial) pass keeps the code paths uniform
     int nblk = (int)cdiv(n, RS_TILE);
     const bool small = nblk <= RS_SMALL_TILES;
-    Tmp<u32> hist(ctx);
+    Tmp<u32> hist(ctx), vtmp(ctx);
+    Tmp<u64> ktmp(ctx);
     if (!small) GK_TRY(hist.alloc((size_t)256 * nblk + 256));
+    if (passes > 1) { GK_TRY(ktmp.alloc(n)); GK_TRY(vtmp.alloc(n)); }
     u32* totals = small ? nullptr : hist.p + (size_t)256 * nblk;
-    u64 *ks = keys_in, *kd = keys_out;
-    u32 *vs = vals_in, *vd = vals_out;
-    // vals_in may be null on entry: the values are then the indices 0..n-1 (implicit iota);
-    // vals_scratch is the ping-pong partner of vals_out in that case
-    if ((passes & 1) == 0) {   // even number of passes: start from the out buffers
-        GK_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
-        if (vals_in && !implicit_iota)
-            GK_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
-        ks = keys_out, kd = keys_in, vs = vals_out, vd = vals_in;
-    }
+    const u64* ks = keys_in;
+    const u32* vs = vals_in;
     for (int p = 0; p < passes; ++p) {
+        const bool to_out = ((passes - 1 - p) & 1) == 0;
+        u64* kd = to_out ? keys_out : ktmp.p;
+        u32* vd = to_out ? vals_out : vtmp.p;
         int shift = p * 8;
-        const u32* vsrc = (implicit_iota && p == 0) ? nullptr : vs;
         if (small) {
             radix_scatter_kernel<1024, true><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
-                ks, vsrc, kd, vd, n, shift, nullptr, nullptr, nblk);
+                ks, vs, kd, vd, n, shift, nullptr, nullptr, nblk);
         } else {
             radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, n, shift, hist.p, nblk);
             radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
             radix_scatter_kernel<RS_THREADS, false><<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(
-                ks, vsrc, kd, vd, n, shift, hist.p, totals, nblk);
+                ks, vs, kd, vd, n, shift, hist.p, totals, nblk);
         }
-        u64* tk = ks; ks = kd; kd = tk;
-        u32* tv = vs; vs = vd; vd = tv;
+        ks = kd, vs = vd;
     }
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;

@@ -19,7 +19,7 @@
 #define SP_FW_MAX_N 200          // 200*201*4 B = 160.8 KB > 160 KiB? -> see sp_fw_cap()
 #define SP_ROW_MAX_N 32768
 
-int gk_dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32* lab, i32* perm, u32* count_dev);
+int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm, u32* count_dev);
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
 

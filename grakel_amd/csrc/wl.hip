@@ -451,23 +451,21 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
     return GK_OK;
 }
 
-// Sort (key,node) pairs, turn equal-key groups into dense ids. keys[] is clobbered.
+// Sort (key,node) pairs, turn equal-key groups into dense ids (keys[] and vals[] are only read).
 // Writes lab[node], perm[] (nodes in key order, ascending node inside a group), rep[id]
 // (may be null) and the number of groups to *count_dev.
-// vals == nullptr: the items are 0..n-1; otherwise vals[] (ascending node ids, clobbered) are
-// the items and lab/rep/frozen are indexed by item id, perm receives item ids.
-static int dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
-                                i32* rep, u32* count_dev, u32* vals = nullptr, u32* frozen = nullptr,
+// vals == nullptr: the items are 0..n-1; otherwise vals[] (ascending node ids) are the items and
+// lab/rep/frozen are indexed by item id, perm receives item ids.
+static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
+                                i32* rep, u32* count_dev, const u32* vals = nullptr, u32* frozen = nullptr,
                                 i64 rep_capacity = 0) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         return GK_OK;
     }
     Tmp<u64> ks(ctx);
-    Tmp<u32> vscratch(ctx);
     GK_TRY(ks.alloc(n));
-    if (!vals) GK_TRY(vscratch.alloc(n));
-    GK_TRY(gk_radix_sort_pairs(ctx, keys, vals ? vals : vscratch.p, ks.p, (u32*)perm, n, key_bits, vals == nullptr));
+    GK_TRY(gk_radix_sort_pairs(ctx, keys, vals, ks.p, (u32*)perm, n, key_bits));
     Tmp<i32> rep_tmp(ctx);
     if (!rep) { GK_TRY(rep_tmp.alloc(rep_capacity > n ? rep_capacity : n)); rep = rep_tmp.p; }
     HeadAssign ha{ks.p, (const u32*)perm, lab, rep, frozen, n};
@@ -476,7 +474,7 @@ static int dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32
 }
 
 // exported for sp.hip
-int gk_dictionary_from_keys(gk_ctx* ctx, u64* keys, i64 n, int key_bits, i32* lab, i32* perm, u32* count_dev) {
+int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm, u32* count_dev) {
     return dictionary_from_keys(ctx, keys, n, key_bits, lab, perm, nullptr, count_dev);
 }
 
@@ -534,14 +532,10 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                 b->big_nodes, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_node.p, seed, mask);
             gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act.p, n_act, b->row_ptr, hash_node.p, hash_act.p);
         }
-        // act[] is consumed by the sort (values ping-pong): keep a copy for verify
-        Tmp<u32> act_copy(ctx);
-        GK_TRY(act_copy.alloc(n_act));
-        GK_HIP_CHECK(hipMemcpyAsync(act_copy.p, st.act.p, (size_t)n_act * 4, hipMemcpyDeviceToDevice, ctx->stream));
         GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act.p, st.frozen.p));
         frozen_assign_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V);
-        GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
-        verify_list_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(act_copy.p, n_act, b->row_ptr, prev, b->nbr_sorted,
+        // *unresolved_dev is still zero here: gk_wl_relabel cleared it and this path runs once per level
+        verify_list_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act.p, n_act, b->row_ptr, prev, b->nbr_sorted,
                                                                            cur, rep.p, unresolved_dev);
         GK_HIP_CHECK(hipGetLastError());
         return GK_OK;
@@ -549,19 +543,19 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     // ---- full path
     Tmp<u64> hash(ctx), keys(ctx);
     Tmp<i32> rep(ctx);
-    GK_TRY(hash.alloc(V)); GK_TRY(keys.alloc(V)); GK_TRY(rep.alloc(V));
+    GK_TRY(hash.alloc(V)); GK_TRY(rep.alloc(V));
     for (int round = 0;; ++round) {
         GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), full_mask));
-        int bits;
-        if (round == 0) {
-            GK_HIP_CHECK(hipMemcpyAsync(keys.p, hash.p, V * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
-            bits = hash_bits;
-        } else {
+        int bits = hash_bits;
+        const u64* sort_keys = hash.p;           // round 0: the sort reads the hashes in place
+        if (round > 0) {
+            if (!keys.p) GK_TRY(keys.alloc(V));
             refine_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(cur, hash.p, keys.p, V);
-            bits = 64;
+            bits = 64, sort_keys = keys.p;
         }
-        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p));
-        GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
+        GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p));
+        // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
+        if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
         GK_HIP_CHECK(hipGetLastError());
         if (!exact) break;
