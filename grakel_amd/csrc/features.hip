@@ -70,6 +70,7 @@ struct TripleEmit {
             meta[META_R(level)] = (u32)(r + 1);
         }
     }
+    __device__ __forceinline__ void finish(u64) const {}
 };
 
 // per node: add the count of its (label,graph) triple to node_acc[v]; sum over the nodes of a
@@ -152,7 +153,7 @@ __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* 
 // scan value packs (low << 32 | dense) so one pass yields both running counts.
 struct ColumnIds {
     const i32* tstart; const i32* tri_graph; i32* colid; u32* meta; int level; int symmetric; i32 n_fit;
-    i32 low_df; i32* low_runs; const i32* wide; int kind;
+    i32 low_df; i32* low_runs; const i32* wide; int kind; int n_levels;
     __device__ __forceinline__ u64 value(i64 r) const {
         if (r >= (i64)meta[META_R(level)]) return 0ull;
         const i32 t0 = tstart[r], t1 = tstart[r + 1];
@@ -172,6 +173,12 @@ struct ColumnIds {
                          : ((v >> 63) ? -3 : (rare ? -2 : -1));
         if (rare) low_runs[((u32)(incl >> 32) & 0x7fffffffu) - 1] = (i32)r;   // compact list for gram_low_kernel
     }
+    // running column totals (emit only reads the PREVIOUS level's entry, so no block races with this)
+    __device__ __forceinline__ void finish(u64 t) const {
+        meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + (u32)(t & 0xffffffffull);
+        meta[3 * n_levels + 1] += (u32)(t >> 32) & 0x7fffffffu;           // low columns over all levels
+        meta[3 * n_levels + 4 + level] = (u32)(t >> 32) & 0x7fffffffu;     // ... and of this level
+    }
 };
 
 __global__ void feat_colbase_kernel(u32* __restrict__ meta, const u64* __restrict__ total, int level, int n_levels) {
@@ -188,6 +195,7 @@ struct ColumnIdsWide {
     __device__ __forceinline__ void emit(i64 r, u32 w, u32 incl) const {
         if (w) colid[r] = -4 - (i32)(meta[3 * n_levels + 2] + incl - 1);
     }
+    __device__ __forceinline__ void finish(u32) const {}     // feat_widebase_kernel: emit reads the base it would update
 };
 
 __global__ void feat_widebase_kernel(u32* __restrict__ meta, const u32* __restrict__ total, int n_levels) {
@@ -324,9 +332,8 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         if (kind == GK_FEAT_MINSUM)
             feat_runmax_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(L.tri_pos, L.tri_run, f->meta, l, L.wide);
         ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df,
-                     L.low_runs, L.wide, kind};
-        if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, nl, ctotal64.p))) return fail(r);
-        feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, ctotal64.p, l, n_levels);
+                     L.low_runs, L.wide, kind, n_levels};
+        if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, nl, nullptr))) return fail(r);
     }
     if (V > 0)
         feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, node_acc.p, f->selfk, N,

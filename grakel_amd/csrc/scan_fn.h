@@ -1,5 +1,6 @@
 // Prefix sum over values produced on the fly by a functor, with the consumer fused in:
-//     struct F { __device__ T value(i64 i) const;  __device__ void emit(i64 i, T v, T inclusive) const; };
+//     struct F { __device__ T value(i64 i) const;  __device__ void emit(i64 i, T v, T inclusive) const;
+//                __device__ void finish(T total) const; };     // one thread, after the last emit
 // Two kernels (tile sums, then apply-with-direct-offset as in scan_sort.hip); no flag / scan
 // arrays ever touch HBM.  Used for run-head -> label id, triple emission and column ids.
 #pragma once
@@ -75,7 +76,10 @@ __global__ __launch_bounds__(SF_THREADS) void scan_fn_apply_kernel(F f, const T*
         carry += row;
         __syncthreads();
     }
-    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = carry;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (total) *total = carry;
+        f.finish(carry);
+    }
 }
 
 // total (device, may be null) receives the grand total.  n == 0: total = 0.
@@ -88,7 +92,8 @@ static int gk_scan_fn(gk_ctx* ctx, const F& f, i64 n, T* total) {
     const i64 nblk = cdiv(n, SF_TILE);
     Tmp<T> partial(ctx);
     GK_TRY(partial.alloc(nblk));
-    scan_fn_sums_kernel<T, F><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n);
+    if (nblk > 1)      // a single tile has nothing before it (the apply kernel reads partial[0 .. blockIdx))
+        scan_fn_sums_kernel<T, F><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n);
     scan_fn_apply_kernel<T, F><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n, total);
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;

@@ -192,6 +192,7 @@ struct HeadAssign {
         if (head) rep[r] = (i32)v;
         if (frozen) frozen[v] = (head && (k == n - 1 || ks[k + 1] != ks[k])) ? 1u : 0u;
     }
+    __device__ __forceinline__ void finish(u32) const {}
 };
 
 // A node whose class is a singleton stays a singleton at every later level (classes only
@@ -204,6 +205,7 @@ struct ActiveScan {
         if (a) { act[incl - 1] = (u32)v; fidx[v] = 0xffffffffu; }
         else fidx[v] = (u32)v - incl;             // rank among the frozen nodes
     }
+    __device__ __forceinline__ void finish(u32) const {}
 };
 
 __global__ void frozen_assign_kernel(const u32* __restrict__ fidx, const u32* __restrict__ ra_dev,
