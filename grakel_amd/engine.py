@@ -183,6 +183,11 @@ class Engine(object):
         pb.label_counts = [int(k) for k in nkeys]
         return pb
 
+    def core_numbers(self, db):
+        out = np.empty(db.n_nodes, dtype=np.int32)
+        check(self.lib.gk_core_numbers(self.handle, db.handle, _ptr(out)))
+        return out
+
     def sp_debug_apsp(self, db, edge_weight, graph, n):
         out = np.empty((n, n), dtype=np.int32)
         check(self.lib.gk_sp_debug_apsp(self.handle, db.handle, _ptr(edge_weight), int(graph), _ptr(out)))

@@ -13,6 +13,7 @@ from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils.validation import check_is_fitted
 
 from .shortest_path import ShortestPath
+from .core_framework import CoreFramework
 from .vertex_histogram import VertexHistogram, EdgeHistogram
 from .weisfeiler_lehman import WeisfeilerLehman
 from .weisfeiler_lehman_optimal_assignment import WeisfeilerLehmanOptimalAssignment
@@ -27,7 +28,8 @@ _OTHER_BASE = ("random_walk", "RW", "graphlet_sampling", "GR",
                "neighborhood_subgraph_pairwise_distance", "NSPD", "odd_sth", "ODD", "propagation",
                "PR", "pyramid_match", "PM", "graph_hopper", "GH")
 _WLOA = ("weisfeiler_lehman_optimal_assignment", "WL-OA")
-_OTHER_FRAMEWORKS = ("hadamard_code", "HC", "core_framework", "CORE")
+_OTHER_FRAMEWORKS = ("hadamard_code", "HC")
+_CORE = ("core_framework", "CORE")
 
 
 class GraphKernel(BaseEstimator, TransformerMixin):
@@ -74,6 +76,10 @@ class GraphKernel(BaseEstimator, TransformerMixin):
             if len(kernel_list):
                 kernel["base_graph_kernel"] = self.make_kernel_(kernel_list, {})
             return WeisfeilerLehman, kernel
+        if name in _CORE:                       # graph_kernels.py:543-551: default base is SP
+            if len(kernel_list):
+                kernel["base_graph_kernel"] = self.make_kernel_(kernel_list, {})
+            return CoreFramework, kernel
         if name in _OTHER_BASE or name in _OTHER_FRAMEWORKS:
             raise NotImplementedError('kernel "%s" is outside the MI355X hot path (WL / VH / SP)' % name)
         raise ValueError("Unsupported kernel: " + str(name))

@@ -171,6 +171,13 @@ int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int
 int gk_sp_debug_apsp(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int64_t graph,
                      int32_t* out_dist);
 
+/* ---- Core framework ---------------------------------------------------------------------- */
+/* Replaces core_number() (grakel/kernels/core_framework.py:376-416): the k-core number of every
+ * vertex of every (undirected) graph of the batch, out_core int32[n_nodes] in batch order.  The
+ * framework itself (core_framework.py:95-234: one base kernel per core level on the induced
+ * subgraphs, matrices summed) runs the base-kernel entry points above on sub-batches. */
+int gk_core_numbers(gk_ctx* ctx, gk_batch* b, int32_t* out_core);
+
 #ifdef __cplusplus
 }
 #endif

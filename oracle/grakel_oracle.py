@@ -510,6 +510,101 @@ class WLSPOracle(object):
 
 
 # --------------------------------------------------------------------------
+# Core framework (grakel/kernels/core_framework.py)
+# --------------------------------------------------------------------------
+def core_numbers(A):
+    """k-core number of every vertex of the undirected graph with adjacency A
+    (core_framework.py:376-416 computes the same numbers with the bin walk)."""
+    n = A.shape[0]
+    nbrs = [set(np.nonzero(A[v] > 0)[0].tolist()) - {v} for v in range(n)]
+    deg = [len(x) for x in nbrs]
+    core, alive, k = [0] * n, set(range(n)), 0
+    while alive:
+        peel = [v for v in alive if deg[v] <= k]
+        if not peel:
+            k += 1
+            continue
+        for v in peel:
+            core[v] = k
+            alive.discard(v)
+            for u in nbrs[v]:
+                if u in alive:
+                    deg[u] -= 1
+    return core
+
+
+def _to_adjacency(x):
+    g = parse_graph(x[0], x[1] if len(x) > 1 else {})
+    if g.adjacency is not None:
+        return np.array(g.adjacency, dtype=float), dict(g.labels)
+    verts = list(g.vertices)
+    pos = {v: i for i, v in enumerate(verts)}
+    A = np.zeros((len(verts), len(verts)))
+    for a, d in g.edges.items():
+        for b, w in d.items():
+            A[pos[a], pos[b]] = w
+    return A, {pos[v]: l for v, l in g.labels.items()}
+
+
+class CoreOracle(object):
+    """CoreFramework: K = sum over core levels i of the base kernel on the subgraphs induced by
+    the vertices of core number >= i; graphs without such vertices sit out of level i
+    (core_framework.py:163-212).  ``make_base`` returns a fresh base oracle (fit_transform /
+    transform / x_diag / y_diag)."""
+
+    def __init__(self, make_base, normalize=False):
+        self.make_base, self.normalize = make_base, normalize
+
+    @staticmethod
+    def _levels(X):
+        els = _elements(X, lambda n: n >= 1, 'a list with at least a graph')
+        graphs = [_to_adjacency(x) for x in els]
+        cores = [core_numbers(A) for A, _ in graphs]
+        return graphs, cores, max(max(c) for c in cores)
+
+    @staticmethod
+    def _subgraphs(graphs, cores, i):
+        subs, idx = [], []
+        for j, ((A, lab), c) in enumerate(zip(graphs, cores)):
+            keep = [v for v in range(A.shape[0]) if c[v] >= i]
+            if keep:
+                subs.append([A[np.ix_(keep, keep)], {k: lab[v] for k, v in enumerate(keep)}])
+                idx.append(j)
+        return subs, np.array(idx, dtype=int)
+
+    def fit_transform(self, X):
+        graphs, cores, self.max_core = self._levels(X)
+        n = len(graphs)
+        K = np.zeros((n, n))
+        self.base, self.fit_idx = dict(), dict()
+        for i in range(self.max_core, -1, -1):
+            subs, idx = self._subgraphs(graphs, cores, i)
+            self.fit_idx[i] = idx
+            if len(idx):
+                self.base[i] = self.make_base()
+                K[np.ix_(idx, idx)] += self.base[i].fit_transform(subs)
+        self.x_diag = np.diagonal(K).copy()
+        return _normalize(K, self.x_diag, self.x_diag, True) if self.normalize else K
+
+    def transform(self, Y):
+        graphs, cores, t_max = self._levels(Y)
+        K = np.zeros((len(graphs), len(self.x_diag)))
+        self.y_diag = np.zeros(len(graphs))
+        for i in range(t_max, -1, -1):
+            subs, idx = self._subgraphs(graphs, cores, i)
+            if not len(idx):
+                continue
+            if self.max_core < i or not len(self.fit_idx[i]):
+                dummy = self.make_base()                              # :196-200: diagonal only
+                dummy.fit_transform(subs)
+                self.y_diag[idx] += dummy.x_diag
+            else:
+                K[np.ix_(idx, self.fit_idx[i])] += self.base[i].transform(subs)
+                self.y_diag[idx] += self.base[i].y_diag
+        return _normalize(K, self.y_diag, self.x_diag, True) if self.normalize else K
+
+
+# --------------------------------------------------------------------------
 # Partition helper used by the parity tests ("bit-exact integer WL labels" ==
 # same partition of the nodes per level, SURVEY.md 8c)
 # --------------------------------------------------------------------------

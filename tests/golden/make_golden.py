@@ -28,7 +28,7 @@ sys.path.insert(0, REF)
 
 import grakel  # noqa: E402  (the real reference)
 from grakel import WeisfeilerLehman, VertexHistogram, ShortestPath, EdgeHistogram  # noqa: E402
-from grakel import WeisfeilerLehmanOptimalAssignment  # noqa: E402
+from grakel import WeisfeilerLehmanOptimalAssignment, CoreFramework  # noqa: E402
 from grakel.datasets.base import read_data  # noqa: E402
 
 from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs  # noqa: E402
@@ -108,6 +108,14 @@ def mutag():
     wspn = WeisfeilerLehman(n_iter=1, normalize=True, base_graph_kernel=(ShortestPath, {"with_labels": True}))
     K_wlspn = wspn.fit_transform(G[:100])
     K_wlspn_tr = wspn.transform(G[100:140])
+    core = dict()
+    for tag, base in (("sp", None), ("vh", VertexHistogram), ("wl2", (WeisfeilerLehman, {"n_iter": 2}))):
+        cf = CoreFramework(base_graph_kernel=base)
+        core["K_core_%s" % tag] = as_int(cf.fit_transform(G[:100])).astype(np.int64)
+        core["K_core_%s_tr" % tag] = as_int(cf.transform(G[100:140])).astype(np.int64)
+    cfn = CoreFramework(normalize=True)
+    core["K_core_sp_norm"] = cfn.fit_transform(G[:100])
+    core["K_core_sp_norm_tr"] = cfn.transform(G[100:140])
     eh = EdgeHistogram()
     K_eh = as_int(eh.fit_transform(G[:120]))
     K_eh_tr = as_int(eh.transform(G[120:]))
@@ -134,7 +142,7 @@ def mutag():
         K_eh=K_eh.astype(np.int32), K_eh_tr=K_eh_tr.astype(np.int32), K_eh_norm=K_eh_norm,
         K_wlsp2=K_wlsp.astype(np.int64), K_wlsp2_tr=K_wlsp_tr.astype(np.int64), K_wlsp1_norm=K_wlspn,
         K_wlsp1_norm_tr=K_wlspn_tr,
-        K_oa4=K_oa.astype(np.int32), K_oa4_tr=K_oa_tr.astype(np.int32), K_oa2_norm=K_oa_norm,
+        K_oa4=K_oa.astype(np.int32), **core, K_oa4_tr=K_oa_tr.astype(np.int32), K_oa2_norm=K_oa_norm,
         K_oa2_norm_tr=K_oa_norm_tr,
         K_vh=K_vh.astype(np.int32), K_wl5=K_wl.astype(np.int32), K_sp=K_sp.astype(np.int64),
         K_wl3_tr=K_wl_tr.astype(np.int32), K_sp_tr=K_sp_tr.astype(np.int64),
@@ -182,6 +190,11 @@ def small_sets():
             wsp = WeisfeilerLehman(n_iter=2, base_graph_kernel=ShortestPath)
             out[name + "/wlsp2_fit"] = as_int(wsp.fit_transform(trs))
             out[name + "/wlsp2_tr"] = as_int(wsp.transform(tes))
+            if not kw["directed"]:        # core_number() needs symmetric neighbour lists
+                for tag, base in (("sp", None), ("vh", VertexHistogram)):
+                    cf = CoreFramework(base_graph_kernel=base)
+                    out[name + "/core_%s_fit" % tag] = as_int(cf.fit_transform(trs))
+                    out[name + "/core_%s_tr" % tag] = as_int(cf.transform(tes))
         except KeyError as e:           # tuples sets can hit the Dijkstra sink-vertex bug
             print("  SP skipped for", name, "(reference KeyError %s)" % e)
     np.savez_compressed(os.path.join(HERE, "small_sets.npz"), **out)

@@ -612,3 +612,62 @@ def test_wl_with_shortest_path_base_weighted_and_unlabelled_against_oracle(gk):
     assert np.array_equal(X_diag, want.x_diag) and np.array_equal(Y_diag, want.y_diag)
     Ku = gk.WeisfeilerLehman(n_iter=2, base_graph_kernel=(gk.ShortestPath, {"with_labels": False})).fit_transform(G[:50])
     assert np.array_equal(Ku, 3 * gk.ShortestPath(with_labels=False).fit_transform(G[:50]))
+
+
+# ------------------------------------------------------------------------------------------
+# Core framework
+# ------------------------------------------------------------------------------------------
+def test_core_numbers_match_the_oracle(gk):
+    from grakel_amd.batch import sp_batch_from_input
+    from grakel_amd.engine import get_engine
+    G = (random_labelled_graphs(40, 2, 60, 0.15, 3, 21, fmt="adj") +
+         random_labelled_graphs(6, 300, 700, 0.02, 2, 22, fmt="adj") +
+         [[np.zeros((3, 3)), {0: 0, 1: 0, 2: 1}], [np.ones((9, 9)) - np.eye(9), {i: 0 for i in range(9)}]])
+    gb, _ = sp_batch_from_input(G, True)
+    eng = get_engine()
+    got = eng.core_numbers(eng.upload(gb))
+    want = np.concatenate([O.core_numbers(np.asarray(g[0])) for g in G])
+    assert np.array_equal(got, want)
+    assert got[-9:].tolist() == [8] * 9 and got[-12:-9].tolist() == [0, 0, 0]
+
+
+def test_core_framework_against_reference_goldens(gk, mutag_graphs):
+    G, z = mutag_graphs
+    for tag, base in (("sp", None), ("vh", gk.VertexHistogram), ("wl2", (gk.WeisfeilerLehman, {"n_iter": 2}))):
+        cf = gk.CoreFramework(base_graph_kernel=base)
+        assert np.array_equal(cf.fit_transform(G[:100]), z["K_core_%s" % tag]), tag
+        assert np.array_equal(cf.diagonal(), np.diagonal(z["K_core_%s" % tag])), tag
+        assert np.array_equal(cf.transform(G[100:140]), z["K_core_%s_tr" % tag]), tag
+    cfn = gk.CoreFramework(normalize=True)
+    assert np.allclose(cfn.fit_transform(G[:100]), z["K_core_sp_norm"], rtol=REL_TOL, atol=0)
+    assert np.allclose(cfn.transform(G[100:140]), z["K_core_sp_norm_tr"], rtol=REL_TOL, atol=0)
+    K = gk.GraphKernel(kernel=[{"name": "CORE"}, {"name": "VH"}]).fit_transform(G[:100])
+    assert np.array_equal(K, z["K_core_vh"])
+    assert np.array_equal(gk.GraphKernel(kernel="core_framework").fit_transform(G[:100]), z["K_core_sp"])
+    fitted = gk.CoreFramework(base_graph_kernel=gk.VertexHistogram).fit(G[:100])     # fit, then transform
+    assert np.array_equal(fitted.transform(G[100:140]), z["K_core_vh_tr"])
+    with pytest.raises(NotImplementedError):
+        gk.CoreFramework(base_graph_kernel=gk.EdgeHistogram).fit(G[:3])
+
+
+@pytest.mark.parametrize("name", ["dict_u", "adj_u", "dense_big"])
+def test_core_framework_small_sets(gk, name):
+    """dense_big reaches core numbers around 20, so ~20 base-kernel levels; the targets of adj_u /
+    dict_u exercise levels the fitted graphs never reach (diagonal-only "dummy" levels)."""
+    z = load_golden("small_sets.npz")
+    kw = dict(SMALL_SETS)[name]
+    tr, te = split(random_labelled_graphs(**kw))
+    trs, tes = sp_inputs(kw, tr), sp_inputs(kw, te)
+    for tag, base, orc in (("sp", None, O.SPOracle), ("vh", gk.VertexHistogram, O.VHOracle)):
+        cf = gk.CoreFramework(base_graph_kernel=base)
+        assert np.array_equal(cf.fit_transform(trs), z[name + "/core_%s_fit" % tag]), tag
+        assert np.array_equal(cf.transform(tes), z[name + "/core_%s_tr" % tag]), tag
+        want = O.CoreOracle(orc)
+        want.fit_transform(trs), want.transform(tes)
+        X_diag, Y_diag = cf.diagonal()
+        assert np.array_equal(X_diag, want.x_diag) and np.array_equal(Y_diag, want.y_diag), tag
+    # swapped roles: sparse fit, dense targets -> levels above the fitted maximum
+    cf, want = gk.CoreFramework(base_graph_kernel=gk.VertexHistogram), O.CoreOracle(O.VHOracle)
+    assert np.array_equal(cf.fit_transform(tes[:3]), want.fit_transform(tes[:3]))
+    assert np.array_equal(cf.transform(trs), want.transform(trs))
+    assert np.array_equal(cf.diagonal()[1], want.y_diag)

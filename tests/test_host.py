@@ -205,7 +205,7 @@ def test_graph_kernel_dispatcher():
     g = GraphKernel(kernel={"name": "shortest_path", "with_labels": False})
     g.initialize()
     assert g.kernel_.with_labels is False
-    for bad in ("random_walk", "CORE", {"name": "SP", "as_attributes": True}):
+    for bad in ("random_walk", "HC", {"name": "SP", "as_attributes": True}):
         with pytest.raises(NotImplementedError):
             GraphKernel(kernel=bad).initialize()
     with pytest.raises(ValueError):
@@ -259,3 +259,27 @@ def test_wloa_ingestion_keeps_only_vertices_with_an_edge_dictionary_entry():
         wloa_batch_from_input([[A]], fitted_labels={}, fit=False)
     with pytest.raises(TypeError):
         wloa_batch_from_input([[A]])
+
+
+def test_induced_subbatch_and_core_framework_parameters():
+    from grakel_amd import CoreFramework, GraphKernel
+    from grakel_amd.batch import sp_batch_from_input
+    from grakel_amd.core_framework import induced_subbatch
+    A = np.array([[0, 2, 1, 0], [2, 0, 1, 0], [1, 1, 0, 3], [0, 0, 3, 0]])
+    gb, _ = sp_batch_from_input([[A, {0: 'a', 1: 'b', 2: 'a', 3: 'c'}], [np.zeros((2, 2)), {0: 'a', 1: 'a'}]], True)
+    sub, idx = induced_subbatch(gb, np.array([1, 1, 1, 0, 0, 0], bool))      # the triangle of graph 0
+    assert idx.tolist() == [0] and sub.graph_ptr.tolist() == [0, 3]
+    assert sub.row_ptr.tolist() == [0, 2, 4, 6] and sub.col_idx.tolist() == [1, 2, 0, 2, 0, 1]
+    assert sub.edge_weight.tolist() == [2, 1, 2, 1, 1, 1] and sub.node_label.tolist() == [0, 1, 0]
+    sub, idx = induced_subbatch(gb, np.ones(6, bool))
+    assert idx.tolist() == [0, 1] and sub.n_edges == gb.n_edges
+    cf = CoreFramework(min_core=3)
+    assert cf.min_core == -1                               # core_framework.py:48 ignores the argument
+    assert sorted(cf.get_params()) == ['base_graph_kernel', 'min_core', 'n_jobs', 'normalize', 'verbose']
+    cf.initialize()
+    assert cf.base_graph_kernel_ is ShortestPath           # default base (core_framework.py:61-62)
+    with pytest.raises(TypeError):
+        CoreFramework(base_graph_kernel=3).initialize()
+    g = GraphKernel(kernel=[{"name": "CORE"}, {"name": "WL", "n_iter": 2}])
+    g.initialize()
+    assert type(g.kernel_).__name__ == "CoreFramework" and g.kernel_.base_graph_kernel[0] is WeisfeilerLehman

@@ -79,6 +79,13 @@ def test_mutag_against_reference(mutag_graphs):
     wspn = O.WLSPOracle(n_iter=1, normalize=True)
     assert np.allclose(wspn.fit_transform(G[:100]), z["K_wlsp1_norm"], rtol=1e-13, atol=0)
     assert np.allclose(wspn.transform(G[100:140]), z["K_wlsp1_norm_tr"], rtol=1e-13, atol=0)
+    for tag, make in (("sp", O.SPOracle), ("vh", O.VHOracle), ("wl2", lambda: O.WLOracle(n_iter=2))):
+        cf = O.CoreOracle(make)                        # CoreFramework over three base kernels
+        assert np.array_equal(cf.fit_transform(G[:100]), z["K_core_%s" % tag]), tag
+        assert np.array_equal(cf.transform(G[100:140]), z["K_core_%s_tr" % tag]), tag
+    cfn = O.CoreOracle(O.SPOracle, normalize=True)
+    assert np.allclose(cfn.fit_transform(G[:100]), z["K_core_sp_norm"], rtol=1e-13, atol=0)
+    assert np.allclose(cfn.transform(G[100:140]), z["K_core_sp_norm_tr"], rtol=1e-13, atol=0)
     oa = O.WLOAOracle(n_iter=4)
     assert np.array_equal(oa.fit_transform(G[:120]), z["K_oa4"])
     assert np.array_equal(oa.transform(G[120:]), z["K_oa4_tr"])
@@ -125,6 +132,11 @@ def test_small_sets_against_reference(name):
         wsp = O.WLSPOracle(n_iter=2)
         assert np.array_equal(wsp.fit_transform(trs), z[name + "/wlsp2_fit"])
         assert np.array_equal(wsp.transform(tes), z[name + "/wlsp2_tr"])
+        if name + "/core_sp_fit" in z.files:
+            for tag, make in (("sp", O.SPOracle), ("vh", O.VHOracle)):
+                cf = O.CoreOracle(make)
+                assert np.array_equal(cf.fit_transform(trs), z[name + "/core_%s_fit" % tag]), tag
+                assert np.array_equal(cf.transform(tes), z[name + "/core_%s_tr" % tag]), tag
 
 
 def test_er_n200_and_config2_against_reference():
