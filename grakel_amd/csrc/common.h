@@ -159,6 +159,20 @@ struct LevelTriples {
     i64 n_low = 0;
 };
 
+// Up to GK_PACK_LEVELS levels handed to ONE kernel launch by value (per-level launches of
+// 5-20 us kernels cost more in launch latency than in work).
+#define GK_PACK_LEVELS 16
+struct LevelPack {
+    const i32* tri_pos[GK_PACK_LEVELS];
+    const i32* tri_graph[GK_PACK_LEVELS];
+    const i32* tri_run[GK_PACK_LEVELS];
+    const i32* tstart[GK_PACK_LEVELS];
+    const i32* colid[GK_PACK_LEVELS];
+    const i32* low_runs[GK_PACK_LEVELS];
+    i64 first[GK_PACK_LEVELS + 1];    // prefix of the per-level item counts
+    int n;
+};
+
 struct gk_feat {
     int kind = 0;               // GK_FEAT_DOT (0) | GK_FEAT_MINSUM (1), see gk_features_build_ex
     gk_ctx* ctx = nullptr;

@@ -202,14 +202,17 @@ __global__ void feat_widebase_kernel(u32* __restrict__ meta, const u32* __restri
     meta[3 * n_levels + 2] += *total;
 }
 
-__global__ void feat_scatter_mixed_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_graph,
-                                          const i32* __restrict__ tri_run, const i32* __restrict__ colid,
-                                          const u32* __restrict__ meta, int level, int8_t* __restrict__ phi,
-                                          i64 ld, double* __restrict__ phi_w, i64 ldw, int kind) {
-    const u32 Tn = meta[META_T(level)];
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Tn) return;
-    const i32 c = colid[tri_run[t]];
+// all levels in one launch: P.first = prefix of the per-level triple counts
+__global__ void feat_scatter_mixed_kernel(const LevelPack P, int8_t* __restrict__ phi, i64 ld,
+                                          double* __restrict__ phi_w, i64 ldw, int kind) {
+    i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.first[P.n]) return;
+    int l = 0;
+    while (t >= P.first[l + 1]) ++l;
+    t -= P.first[l];
+    const i32* __restrict__ tri_pos = P.tri_pos[l];
+    const i32* __restrict__ tri_graph = P.tri_graph[l];
+    const i32 c = P.colid[l][P.tri_run[l][t]];
     const i32 cnt = tri_pos[t + 1] - tri_pos[t];
     if (c >= 0 && kind) {
         int8_t* row = phi + (i64)tri_graph[t] * ld + c;
@@ -383,13 +386,20 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         f->phi_w = (double*)q;
         if (gk_zero_async(ctx, f->phi_w, wb) != GK_OK) return fail(GK_ERR_HIP);
     }
-    for (int l = 0; l < n_levels && V > 0; ++l) {
-        LevelTriples& L = f->lev[l];
-        u32 T = h[META_T(l)];
-        if (T == 0) continue;
-        feat_scatter_mixed_kernel<<<grid_for(T, 256), 256, 0, ctx->stream>>>(
-            L.tri_pos, L.tri_graph, L.tri_run, L.colid, f->meta, l, (int8_t*)f->phi, f->n_cols_pad,
-            f->phi_w, f->n_cols_wide_pad, kind);
+    for (int l0 = 0; l0 < n_levels && V > 0; l0 += GK_PACK_LEVELS) {
+        LevelPack P;
+        P.n = 0, P.first[0] = 0;
+        for (int l = l0; l < n_levels && l < l0 + GK_PACK_LEVELS; ++l) {
+            LevelTriples& L = f->lev[l];
+            if (h[META_T(l)] == 0 || !L.tri_pos) continue;
+            P.tri_pos[P.n] = L.tri_pos, P.tri_graph[P.n] = L.tri_graph, P.tri_run[P.n] = L.tri_run;
+            P.colid[P.n] = L.colid;
+            P.first[P.n + 1] = P.first[P.n] + h[META_T(l)];
+            ++P.n;
+        }
+        if (P.n == 0) continue;
+        feat_scatter_mixed_kernel<<<grid_for(P.first[P.n], 256), 256, 0, ctx->stream>>>(
+            P, (int8_t*)f->phi, f->n_cols_pad, f->phi_w, f->n_cols_wide_pad, kind);
     }
     if (hipGetLastError() != hipSuccess) {
         gk_set_error("gk_features_build: kernel launch failed");

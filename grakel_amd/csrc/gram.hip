@@ -355,14 +355,18 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
 // Rare columns (colid == -2): K[g_a][g_b] += c_a * c_b for every ordered pair of graphs that
 // share the label.  One wave per rare label run (df < 32 triples): lanes walk the df*df pairs.
 // Integer-valued float64 atomics: exact and order independent.
-__global__ void gram_low_kernel(const i32* __restrict__ low_runs, i64 n_low, const i32* __restrict__ tri_pos,
-                                const i32* __restrict__ tri_graph, const i32* __restrict__ tstart,
-                                double* __restrict__ K, i64 n_cols, i64 row_lo, i64 row_hi, int symmetric,
-                                i64 n_fit, int minsum) {
-    const i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ void gram_low_kernel(const LevelPack P, double* __restrict__ K, i64 n_cols, i64 row_lo, i64 row_hi,
+                                int symmetric, i64 n_fit, int minsum) {
+    i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (w >= n_low) return;
-    const i32 r = low_runs[w];
+    if (w >= P.first[P.n]) return;
+    int l = 0;
+    while (w >= P.first[l + 1]) ++l;          // wave-uniform: which level this rare run belongs to
+    w -= P.first[l];
+    const i32* __restrict__ tri_pos = P.tri_pos[l];
+    const i32* __restrict__ tri_graph = P.tri_graph[l];
+    const i32* __restrict__ tstart = P.tstart[l];
+    const i32 r = P.low_runs[l][w];
     const i32 t0 = tstart[r];
     const int m = tstart[r + 1] - t0;
     for (int p = lane; p < m * m; p += 64) {
@@ -431,12 +435,20 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
             f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, 0, tiles_n, 1);
     }
     if (has_low) {
-        for (int l = 0; l < f->n_levels; ++l) {
-            LevelTriples& L = f->lev[l];
-            if (!L.tri_pos || L.n_low == 0) continue;
-            gram_low_kernel<<<dim3((unsigned)cdiv(L.n_low * 64, 256)), dim3(256), 0, ctx->stream>>>(
-                L.low_runs, L.n_low, L.tri_pos, L.tri_graph, L.tstart, K, n_cols, row_lo, row_hi,
-                f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0);
+        for (int l0 = 0; l0 < f->n_levels; l0 += GK_PACK_LEVELS) {     // one launch per 16 levels
+            LevelPack P;
+            P.n = 0, P.first[0] = 0;
+            for (int l = l0; l < f->n_levels && l < l0 + GK_PACK_LEVELS; ++l) {
+                LevelTriples& L = f->lev[l];
+                if (!L.tri_pos || L.n_low == 0) continue;
+                P.tri_pos[P.n] = L.tri_pos, P.tri_graph[P.n] = L.tri_graph, P.tstart[P.n] = L.tstart;
+                P.low_runs[P.n] = L.low_runs;
+                P.first[P.n + 1] = P.first[P.n] + L.n_low;
+                ++P.n;
+            }
+            if (P.n == 0) continue;
+            gram_low_kernel<<<dim3((unsigned)cdiv(P.first[P.n] * 64, 256)), dim3(256), 0, ctx->stream>>>(
+                P, K, n_cols, row_lo, row_hi, f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0);
         }
     }
     if (has_low || has_wide) {
