@@ -180,7 +180,8 @@ struct gk_feat {
     int n_levels = 0;
     i64 n_graphs = 0, n_fit = 0, n_nodes = 0;
     bool symmetric = true;
-    std::vector<LevelTriples> lev;
+    std::vector<LevelTriples> lev;   // per-level VIEWS into the arena arrays below
+    std::vector<void*> arena;        // concatenated triple / run arrays of all levels (owned)
     u32* meta = nullptr;        // device: per level {T, R, ncols_cum}, then globals
     u64* selfk = nullptr;       // [n_graphs] exact integer self similarity
     i64 n_cols = 0, n_cols_pad = 0, nnz = 0, max_count = 0, n_low_cols = 0;

@@ -13,6 +13,13 @@
 //      rectangular job : present in a fit graph (< n_fit) AND a target graph (>= n_fit)
 // HBM-bound integer work: ~16 bytes per node per level.
 //
+// ALL LEVELS GO THROUGH EACH KERNEL TOGETHER: the items of level l (the first n_sorted[l]
+// positions of its perm: the nodes that can share a label, wl.hip) occupy the index range
+// [off[l], off[l] + n_l) of one concatenated item space, off[l] a multiple of the scan tile.  A
+// 6-level job is then 9 launches instead of ~45 -- at 1 M nodes every kernel of this file is
+// launch-latency bound (5-20 us), not bandwidth bound.  The triple scan restarts per level
+// (segmented), the column-id scan runs across the levels so that its prefix IS the column id.
+//
 // kind 1 (histogram intersection, K_ij = sum_l min(c_il, c_jl); WL-OA,
 // weisfeiler_lehman_optimal_assignment.py:268-279) stays on the same integer GEMM through the
 // UNARY expansion  min(a, b) = sum_{t>=1} [a >= t][b >= t]:  a dense label column whose largest
@@ -24,75 +31,113 @@
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
 
-// meta layout (u32): per level l: [3l+0]=T (triples) [3l+1]=R (label runs) [3l+2]=cols kept so far
-// (cumulative INCLUDING level l); globals at [3*n_levels + 0]=max count
+// meta layout (u32): per level l: [3l+0]=T (triples) [3l+1]=R (label runs) [3l+2]=dense columns
+// up to and including level l; globals at G = 3*n_levels: [G+0]=max count, [G+1]=rare columns,
+// [G+2]=float64 columns, [G+3]=dense columns, [G+4+l]=rare columns up to and including level l
 #define META_T(l) (3 * (l) + 0)
 #define META_R(l) (3 * (l) + 1)
 #define META_C(l) (3 * (l) + 2)
 
-__global__ void feat_flags_kernel(const i32* __restrict__ perm, const i32* __restrict__ lab,
-                                  const i32* __restrict__ node_graph, u64* __restrict__ flag, i64 n,
-                                  i32* __restrict__ wide) {
-    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    wide[k] = 0;      // per-run flag / maximum filled in by the count kernels (runs <= items)
-    i32 v = perm[k];
-    u64 f = 0x100000001ull;
-    if (k > 0) {
-        i32 p = perm[k - 1];
-        bool lh = lab[v] != lab[p];
-        bool sh = lh || node_graph[v] != node_graph[p];
-        f = ((u64)lh << 32) | (u64)sh;
+#define FEAT_MAX_LEVELS 48
+
+// the levels of one job, by value: level slot j covers items [off[j], off[j] + n[j])
+struct FeatLevels {
+    const i32* perm[FEAT_MAX_LEVELS];
+    const i32* lab[FEAT_MAX_LEVELS];
+    i64 n[FEAT_MAX_LEVELS];
+    i64 off[FEAT_MAX_LEVELS + 1];     // multiples of SF_TILE; off[L] = size of the item space
+    int level[FEAT_MAX_LEVELS];       // WL level of the slot (levels without shared labels are skipped)
+    int L;
+    __device__ __forceinline__ int slot_of(i64 i) const {
+        int j = 0;
+        while (i >= off[j + 1]) ++j;
+        return j;
     }
-    flag[k] = f;
+};
+
+// per-level views into the concatenated arrays: level slot j starts at element off[j] + j (one
+// sentinel entry of slack per level)
+struct FeatArrays {
+    i32 *tri_pos, *tri_graph, *tri_run, *tstart, *colid, *wide, *low_all;
+    __device__ __forceinline__ i64 base(const FeatLevels& P, int j) const { return P.off[j] + j; }
+};
+
+__global__ void feat_flags_kernel(const FeatLevels P, const FeatArrays A, const i32* __restrict__ node_graph,
+                                  u64* __restrict__ flag) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.off[P.L]) return;
+    const int j = P.slot_of(i);
+    const i64 k = i - P.off[j];
+    u64 f = 0;
+    if (k < P.n[j]) {
+        const i32* perm = P.perm[j];
+        const i32* lab = P.lab[j];
+        const i32 v = perm[k];
+        f = 0x100000001ull;
+        if (k > 0) {
+            const i32 p = perm[k - 1];
+            const bool lh = lab[v] != lab[p];
+            const bool sh = lh || node_graph[v] != node_graph[p];
+            f = ((u64)lh << 32) | (u64)sh;
+        }
+        A.wide[A.base(P, j) + k] = 0;     // per-run flag / maximum filled in by the count kernels (runs <= items)
+    }
+    flag[i] = f;
 }
 
 // packed (label-head, subrun-head) flags -> triple ids / run ids, triples emitted in the scan
 struct TripleEmit {
-    const i32* perm; const i32* node_graph; const u64* flag;
-    i32* tri_pos; i32* tri_graph; i32* tri_run; i32* tstart; u32* tri_of;   // tri_of[k] = triple of position k
-    u32* meta; int level; i64 n;
-    __device__ __forceinline__ u64 value(i64 k) const { return flag[k]; }
-    __device__ __forceinline__ void emit(i64 k, u64 f, u64 s) const {
+    FeatLevels P; FeatArrays A;
+    const i32* node_graph; const u64* flag; u32* tri_of;   // tri_of[i] = triple of item i
+    u32* meta;
+    __device__ __forceinline__ u64 value(i64 i) const { return flag[i]; }
+    __device__ __forceinline__ void emit(i64 i, u64 f, u64 s) const {
+        const int j = P.slot_of(i);
+        const i64 k = i - P.off[j];
+        if (k >= P.n[j]) return;
+        const i64 b = A.base(P, j);
         const i32 t = (i32)(u32)(s & 0xffffffffull) - 1;
         const i32 r = (i32)(u32)(s >> 32) - 1;
-        tri_of[k] = (u32)t;
+        tri_of[i] = (u32)t;
         if (f & 1ull) {
-            tri_pos[t] = (i32)k;
-            tri_graph[t] = node_graph[perm[k]];
-            tri_run[t] = r;
+            A.tri_pos[b + t] = (i32)k;
+            A.tri_graph[b + t] = node_graph[P.perm[j][k]];
+            A.tri_run[b + t] = r;
         }
-        if (f >> 32) tstart[r] = t;
-        if (k == n - 1) {   // sentinels + counts
-            tri_pos[t + 1] = (i32)n;
-            tstart[r + 1] = t + 1;
-            meta[META_T(level)] = (u32)(t + 1);
-            meta[META_R(level)] = (u32)(r + 1);
+        if (f >> 32) A.tstart[b + r] = t;
+        if (k == P.n[j] - 1) {   // sentinels + counts
+            A.tri_pos[b + t + 1] = (i32)P.n[j];
+            A.tstart[b + r + 1] = t + 1;
+            meta[META_T(P.level[j])] = (u32)(t + 1);
+            meta[META_R(P.level[j])] = (u32)(r + 1);
         }
     }
     __device__ __forceinline__ void finish(u64) const {}
+    __device__ __forceinline__ i64 seg_first_tile(i64 tile) const {
+        return P.off[P.slot_of(tile * SF_TILE)] / SF_TILE;
+    }
 };
 
-// per node: add the count of its (label,graph) triple to node_acc[v]; sum over the nodes of a
-// graph of these counts == sum over its triples of count^2, so the exact self similarity needs
-// no atomics (each node is written once per level).  Also tracks the largest count.
-__global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __restrict__ tri_of,
-                                  const i32* __restrict__ tri_pos, const i32* __restrict__ tri_run,
-                                  i32* __restrict__ wide, int wide_above, u32* __restrict__ node_acc,
-                                  u32* __restrict__ meta, int level, int n_levels, i64 n, int kind,
-                                  const i32* __restrict__ node_graph, u32* __restrict__ covered) {
+// per item: acc[level][v] = count of v's (label,graph) triple; the sum over the nodes of a graph
+// of these counts == sum over its triples of count^2, so the exact self similarity needs no
+// atomics.  Nodes a partial level does not list own their label: their slot was pre-set to 1.
+// Also tracks the largest count and flags runs whose counts leave the int8 range.
+__global__ void feat_count_kernel(const FeatLevels P, const FeatArrays A, const u32* __restrict__ tri_of,
+                                  int wide_above, u32* __restrict__ acc, i64 V, u32* __restrict__ meta,
+                                  int n_levels, int kind) {
     __shared__ u32 wmax[4];
-    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 c = 0;
-    if (k < n) {
-        const i32 t = (i32)tri_of[k];
-        c = (u32)(tri_pos[t + 1] - tri_pos[t]);
-        if ((int)c > wide_above) wide[tri_run[t]] = 1;       // benign race: all writers store 1
-        i32 v = perm[k];
-        node_acc[v] = (level == 0 ? 0u : node_acc[v]) + (kind ? 1u : c);   // min(c,c) summed == #nodes
-        // partial level (only the nodes that may share a label are listed): count them per graph,
-        // every other node of the graph owns its label and adds exactly 1 to the self similarity
-        if (covered) atomicAdd(&covered[node_graph[v]], 1u);
+    if (i < P.off[P.L]) {
+        const int j = P.slot_of(i);
+        const i64 k = i - P.off[j];
+        if (k < P.n[j]) {
+            const i64 b = A.base(P, j);
+            const i32 t = (i32)tri_of[i];
+            c = (u32)(A.tri_pos[b + t + 1] - A.tri_pos[b + t]);
+            if ((int)c > wide_above) A.wide[b + A.tri_run[b + t]] = 1;       // benign race: all writers store 1
+            acc[(i64)j * V + P.perm[j][k]] = kind ? 1u : c;                    // min(c,c) summed == #nodes
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         u32 o = __shfl_down(c, off, 64);
@@ -102,7 +147,7 @@ __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 m = wmax[0];
-        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = wmax[i] > m ? wmax[i] : m;
+        for (int q = 1; q < (int)(blockDim.x >> 6); ++q) m = wmax[q] > m ? wmax[q] : m;
         // plain read as a filter: once the maximum is established almost no block issues the atomic
         if (m > meta[3 * n_levels]) atomicMax(&meta[3 * n_levels], m);
     }
@@ -110,97 +155,116 @@ __global__ void feat_count_kernel(const i32* __restrict__ perm, const u32* __res
 
 // kind 1: wide[r] = largest count of label run r (the number of unary columns it expands to).
 // Triples are run-major, so a wave usually sees one run: one atomic per wave then.
-__global__ void feat_runmax_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_run,
-                                   const u32* __restrict__ meta, int level, i32* __restrict__ runmax) {
-    const u32 Tn = meta[META_T(level)];
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void feat_runmax_kernel(const FeatLevels P, const FeatArrays A, const u32* __restrict__ meta) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     i32 r = -1, c = 0;
-    if (t < Tn) r = tri_run[t], c = tri_pos[t + 1] - tri_pos[t];
+    i64 b = 0;
+    if (i < P.off[P.L]) {
+        const int j = P.slot_of(i);
+        const i64 t = i - P.off[j];
+        b = A.base(P, j);
+        if (t < (i64)meta[META_T(P.level[j])]) r = A.tri_run[b + t], c = A.tri_pos[b + t + 1] - A.tri_pos[b + t];
+    }
     const i32 r0 = __shfl(r, 0, 64);
-    if (__all(r == r0 || r < 0)) {
+    const i64 b0 = __shfl(b, 0, 64);
+    if (__all((r == r0 && b == b0) || r < 0)) {
         if (r0 < 0) return;
         for (int off = 32; off > 0; off >>= 1) {
             i32 o = __shfl_down(c, off, 64);
             c = o > c ? o : c;
         }
-        if ((threadIdx.x & 63) == 0) atomicMax(&runmax[r0], c);
+        if ((threadIdx.x & 63) == 0) atomicMax(&A.wide[b0 + r0], c);
     } else if (r >= 0) {
-        atomicMax(&runmax[r], c);
+        atomicMax(&A.wide[b + r], c);
     }
 }
 
-// one wave per graph: selfk[g] = sum of node_acc over the graph's (contiguous) nodes
-__global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* __restrict__ node_acc,
-                                  u64* __restrict__ selfk, i64 n_graphs, const u32* __restrict__ covered,
-                                  int n_partial) {
+// pre-set the accumulator slots of the partial levels (nodes outside the listed prefix count 1)
+__global__ void feat_fill_ones_kernel(u32* __restrict__ acc, i64 V, const FeatLevels P) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V * P.L) return;
+    const int j = (int)(i / V);
+    if (P.n[j] < V) acc[i] = 1u;
+}
+
+// one wave per graph: selfk[g] = sum over the listed levels of the graph's accumulator slots,
+// plus one per node for every level that lists nothing at all (n_unlisted such levels)
+__global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* __restrict__ acc, i64 V, int L,
+                                  u64* __restrict__ selfk, i64 n_graphs, int n_unlisted) {
     const i64 g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (g >= n_graphs) return;
+    const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
     u64 s = 0;
-    for (i32 v = graph_ptr[g] + lane; v < graph_ptr[g + 1]; v += 64) s += node_acc[v];
+    for (int j = 0; j < L; ++j)
+        for (i32 v = v0 + lane; v < v1; v += 64) s += acc[(i64)j * V + v];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    // n_partial levels listed only `covered[g]` (summed) of the graph's nodes: the others add 1 each
-    if (lane == 0)
-        selfk[g] = s + (u64)n_partial * (u64)(graph_ptr[g + 1] - graph_ptr[g]) - (u64)(covered ? covered[g] : 0u);
+    if (lane == 0) selfk[g] = s + (u64)n_unlisted * (u64)(v1 - v0);
 }
 
-// Column classes per label run, fused into the prefix sum:
+// Column classes per label run, fused into ONE prefix sum over the runs of all levels:
 //   dense (colid >= 0) : occurs in >= low_df graphs -> a column of the MFMA operand Phi_s
 //   low   (colid = -2) : useful but rare (df < low_df): its df*(df-1) pair products are added
 //                        to K by gram_low_kernel after the GEMM -- a column with df graphs
 //                        costs N^2 MACs in the dense product but only df^2 updates here
 //   dead  (colid = -1) : cannot touch an off-diagonal entry (graph-unique / one-sided)
-// scan value packs (low << 32 | dense) so one pass yields both running counts.
+// scan value packs (low << 32 | dense width) so one pass yields both running counts; the running
+// dense count is the column id itself (levels are concatenated along K).
 struct ColumnIds {
-    const i32* tstart; const i32* tri_graph; i32* colid; u32* meta; int level; int symmetric; i32 n_fit;
-    i32 low_df; i32* low_runs; const i32* wide; int kind; int n_levels;
-    __device__ __forceinline__ u64 value(i64 r) const {
-        if (r >= (i64)meta[META_R(level)]) return 0ull;
-        const i32 t0 = tstart[r], t1 = tstart[r + 1];
+    FeatLevels P; FeatArrays A;
+    u32* meta; int symmetric; i32 n_fit; i32 low_df; int kind; int n_levels;
+    __device__ __forceinline__ u64 value(i64 i) const {
+        const int j = P.slot_of(i);
+        const i64 r = i - P.off[j];
+        if (r >= (i64)meta[META_R(P.level[j])]) return 0ull;
+        const i64 b = A.base(P, j);
+        const i32 t0 = A.tstart[b + r], t1 = A.tstart[b + r + 1];
         bool useful;
         if (symmetric) useful = (t1 - t0) >= 2;
-        else useful = tri_graph[t0] < n_fit && tri_graph[t1 - 1] >= n_fit;
+        else useful = A.tri_graph[b + t0] < n_fit && A.tri_graph[b + t1 - 1] >= n_fit;
         if (!useful) return 0ull;
         if ((t1 - t0) < low_df) return 1ull << 32;
-        if (kind) return (u64)(u32)wide[r];       // unary expansion: one 0/1 column per count level
-        return wide[r] ? (1ull << 63) : 1ull;     // bit 63: dense but not int8-able (toggles only itself)
+        if (kind) return (u64)(u32)A.wide[b + r];       // unary expansion: one 0/1 column per count level
+        return A.wide[b + r] ? (1ull << 63) : 1ull;     // bit 63: dense but not int8-able (toggles only itself)
     }
-    __device__ __forceinline__ void emit(i64 r, u64 v, u64 incl) const {
-        const u32 base = level > 0 ? meta[META_C(level - 1)] : 0u;
+    __device__ __forceinline__ void emit(i64 i, u64 v, u64 incl) const {
+        const int j = P.slot_of(i);
+        const i64 r = i - P.off[j];
+        if (r >= P.n[j]) return;
+        const i64 b = A.base(P, j);
         const u32 rare = (u32)(v >> 32) & 0x7fffffffu;
         const u32 width = (u32)(v & 0xffffffffull);     // 1 (kind 0) or the run's largest count (kind 1)
-        colid[r] = width ? (i32)(base + (u32)(incl & 0xffffffffull) - width)
-                         : ((v >> 63) ? -3 : (rare ? -2 : -1));
-        if (rare) low_runs[((u32)(incl >> 32) & 0x7fffffffu) - 1] = (i32)r;   // compact list for gram_low_kernel
+        const u32 dense_incl = (u32)(incl & 0xffffffffull), rare_incl = (u32)(incl >> 32) & 0x7fffffffu;
+        A.colid[b + r] = width ? (i32)(dense_incl - width) : ((v >> 63) ? -3 : (rare ? -2 : -1));
+        if (rare) A.low_all[rare_incl - 1] = (i32)r;    // compact list for gram_low_kernel (level-local run id)
+        if (r == P.n[j] - 1) {                          // running totals at the end of the level
+            meta[META_C(P.level[j])] = dense_incl;
+            meta[3 * n_levels + 4 + P.level[j]] = rare_incl;
+        }
     }
-    // running column totals (emit only reads the PREVIOUS level's entry, so no block races with this)
     __device__ __forceinline__ void finish(u64 t) const {
-        meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + (u32)(t & 0xffffffffull);
-        meta[3 * n_levels + 1] += (u32)(t >> 32) & 0x7fffffffu;           // low columns over all levels
-        meta[3 * n_levels + 4 + level] = (u32)(t >> 32) & 0x7fffffffu;     // ... and of this level
+        meta[3 * n_levels + 3] = (u32)(t & 0xffffffffull);
+        meta[3 * n_levels + 1] = (u32)(t >> 32) & 0x7fffffffu;
     }
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
-
-__global__ void feat_colbase_kernel(u32* __restrict__ meta, const u64* __restrict__ total, int level, int n_levels) {
-    const u64 t = total ? *total : 0ull;      // null: a level without any shared label
-    meta[META_C(level)] = (level > 0 ? meta[META_C(level - 1)] : 0u) + (u32)(t & 0xffffffffull);
-    meta[3 * n_levels + 1] += (u32)(t >> 32) & 0x7fffffffu;     // low columns over all levels
-    meta[3 * n_levels + 4 + level] = (u32)(t >> 32) & 0x7fffffffu;   // ... and of this level
-}
 
 // second pass (only when some count exceeded 127): ids for the float64 side operand
 struct ColumnIdsWide {
-    i32* colid; u32* meta; int n_levels;
-    __device__ __forceinline__ u32 value(i64 r) const { return colid[r] == -3 ? 1u : 0u; }
-    __device__ __forceinline__ void emit(i64 r, u32 w, u32 incl) const {
-        if (w) colid[r] = -4 - (i32)(meta[3 * n_levels + 2] + incl - 1);
+    FeatLevels P; FeatArrays A; u32* meta; int n_levels;
+    __device__ __forceinline__ u32 value(i64 i) const {
+        const int j = P.slot_of(i);
+        const i64 r = i - P.off[j];
+        return (r < P.n[j] && A.colid[A.base(P, j) + r] == -3) ? 1u : 0u;
     }
-    __device__ __forceinline__ void finish(u32) const {}     // feat_widebase_kernel: emit reads the base it would update
+    __device__ __forceinline__ void emit(i64 i, u32 w, u32 incl) const {
+        if (!w) return;
+        const int j = P.slot_of(i);
+        A.colid[A.base(P, j) + (i - P.off[j])] = -4 - (i32)(incl - 1);
+    }
+    __device__ __forceinline__ void finish(u32 t) const { meta[3 * n_levels + 2] = t; }
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
-
-__global__ void feat_widebase_kernel(u32* __restrict__ meta, const u32* __restrict__ total, int n_levels) {
-    meta[3 * n_levels + 2] += *total;
-}
 
 // all levels in one launch: P.first = prefix of the per-level triple counts
 __global__ void feat_scatter_mixed_kernel(const LevelPack P, int8_t* __restrict__ phi, i64 ld,
@@ -221,26 +285,11 @@ __global__ void feat_scatter_mixed_kernel(const LevelPack P, int8_t* __restrict_
     else if (c <= -4) phi_w[(i64)tri_graph[t] * ldw + (-4 - c)] = (double)cnt;
 }
 
-template <typename T>
-__global__ void feat_scatter_kernel(const i32* __restrict__ tri_pos, const i32* __restrict__ tri_graph,
-                                    const i32* __restrict__ tri_run, const i32* __restrict__ colid,
-                                    const u32* __restrict__ meta, int level, T* __restrict__ phi, i64 ld) {
-    const u32 Tn = meta[META_T(level)];
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Tn) return;
-    i32 c = colid[tri_run[t]];
-    if (c < 0) return;
-    phi[(i64)tri_graph[t] * ld + c] = (T)(tri_pos[t + 1] - tri_pos[t]);
-}
-
 extern "C" int gk_features_destroy(gk_feat* f) {
     if (!f) return GK_OK;
     gk_ctx* ctx = f->ctx;
-    for (auto& L : f->lev) {
-        void* ptrs[] = {L.tri_pos, L.tri_graph, L.tri_run, L.tstart, L.colid, L.low_runs, L.wide};
-        for (void* p : ptrs)
-            if (p) gk_dev_free(ctx, p);
-    }
+    for (void* p : f->arena)
+        if (p) gk_dev_free(ctx, p);
     void* ptrs[] = {f->meta, f->selfk, f->phi, f->phi_w, f->K};
     for (void* p : ptrs)
         if (p) gk_dev_free(ctx, p);
@@ -258,6 +307,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     GK_ARG(kind == GK_FEAT_DOT || kind == GK_FEAT_MINSUM, "gk_features_build_ex: unknown kind");
     GK_ARG(n_levels >= 1 && n_levels <= (b->n_levels > 0 ? b->n_levels : 1),
            "gk_features_build: levels not computed (call gk_wl_relabel first)");
+    GK_ARG(n_levels <= FEAT_MAX_LEVELS, "gk_features_build: more than 48 levels are not supported");
     GK_ARG(n_fit >= 1 && n_fit <= b->n_graphs, "gk_features_build: bad n_fit");
     GK_ARG(b->n_levels > 0, "gk_features_build: batch has no label-grouped order (call gk_wl_relabel with n_iter>=0)");
     GK_HIP_CHECK(hipSetDevice(ctx->device));
@@ -281,20 +331,6 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         gk_set_error("gk_features_build: memset failed");
         return fail(GK_ERR_HIP);
     }
-    Tmp<u64> flag(ctx);
-    Tmp<u32> cflag(ctx), node_acc(ctx), covered(ctx);
-    Tmp<u64> ctotal64(ctx);
-    if ((r = flag.alloc(V)) || (r = cflag.alloc(V)) || (r = ctotal64.alloc(1)) || (r = node_acc.alloc(V)))
-        return fail(r);
-    // levels whose label-grouped order only lists the nodes that can share a label (active-set
-    // relabelling, wl.hip): the feature pass runs over that prefix alone
-    int n_partial = 0;
-    auto level_items = [&](int l) -> i64 { return (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V; };
-    for (int l = 0; l < n_levels; ++l) n_partial += level_items(l) < V ? 1 : 0;
-    if (n_partial > 0) {
-        if ((r = covered.alloc(N))) return fail(r);
-        if (gk_zero_async(ctx, covered.p, (size_t)N * 4) != GK_OK) return fail(GK_ERR_HIP);
-    }
     {
         const char* e = getenv("GK_LOW_DF");     // df threshold below which a column leaves the dense operand
         f->low_df = e ? atoi(e) : 32;
@@ -307,66 +343,89 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     // int8 operands need counts <= 127 and every Gram entry < 2^31:
     // K_ij <= sqrt(K_ii K_jj) <= n_levels * max_graph_nodes^2.  If the bound fails everything
     // dense goes to the float64 operand (wide_above = -1 flags every run).
-    const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
     // kind 1: operands are 0/1 and K_ij <= n_levels * max_graph_nodes, always int8-able.
+    const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
     f->dtype = (kind == GK_FEAT_MINSUM || bound < 2147483647.0) ? 0 : 1;
     const int wide_above = kind == GK_FEAT_MINSUM ? 0x7fffffff : (f->dtype == 0 ? 127 : -1);
+
+    // ---- the level slots: a level only lists the nodes that can share a label (wl.hip: active-set
+    // levels), a level that lists nothing adds one per node to the diagonal and nothing else
+    FeatLevels P;
+    P.L = 0, P.off[0] = 0;
+    int n_unlisted = 0;
+    std::vector<int> slot_of_level(n_levels, -1);
     for (int l = 0; l < n_levels && V > 0; ++l) {
-        LevelTriples& L = f->lev[l];
-        const i64 nl = level_items(l);       // items of this level's label-grouped order that matter
-        if (nl == 0) {                        // every node owns its label: no triples, no columns
-            feat_colbase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, nullptr, l, n_levels);
-            continue;
-        }
-        i32** arrs[] = {&L.tri_pos, &L.tri_graph, &L.tri_run, &L.tstart, &L.colid, &L.low_runs, &L.wide};
+        const i64 nl = (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V;
+        if (nl == 0) { ++n_unlisted; continue; }
+        const int j = P.L++;
+        slot_of_level[l] = j;
+        P.perm[j] = b->perm + (size_t)l * V, P.lab[j] = b->labels + (size_t)l * V;
+        P.n[j] = nl, P.level[j] = l;
+        P.off[j + 1] = P.off[j] + round_up(nl, SF_TILE);
+    }
+    const i64 total = P.off[P.L];
+    std::vector<u32> h(n_meta, 0);
+    FeatArrays A{};
+    if (total > 0) {
+        i32** arrs[] = {&A.tri_pos, &A.tri_graph, &A.tri_run, &A.tstart, &A.colid, &A.wide, &A.low_all};
         for (i32** a : arrs) {
-            if ((r = gk_dev_alloc(ctx, &q, (size_t)(nl + 1) * 4))) return fail(r);
+            if ((r = gk_dev_alloc(ctx, &q, (size_t)(total + P.L + 1) * 4))) return fail(r);
             *a = (i32*)q;
+            f->arena.push_back(q);
         }
-        const i32* lab = b->labels + (size_t)l * V;
-        const i32* perm = b->perm + (size_t)l * V;
-        feat_flags_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(perm, lab, b->node_graph, flag.p, nl, L.wide);
-        TripleEmit te{perm, b->node_graph, flag.p, L.tri_pos, L.tri_graph, L.tri_run, L.tstart, cflag.p,
-                      f->meta, l, nl};
-        if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, nl, nullptr))) return fail(r);
-        feat_count_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(perm, cflag.p, L.tri_pos, L.tri_run, L.wide, wide_above,
-                                                                      node_acc.p, f->meta, l, n_levels, nl, kind,
-                                                                      b->node_graph, nl < V ? covered.p : nullptr);
-        if (kind == GK_FEAT_MINSUM)
-            feat_runmax_kernel<<<grid_for(nl, 256), 256, 0, ctx->stream>>>(L.tri_pos, L.tri_run, f->meta, l, L.wide);
-        ColumnIds ci{L.tstart, L.tri_graph, L.colid, f->meta, l, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df,
-                     L.low_runs, L.wide, kind, n_levels};
-        if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, nl, nullptr))) return fail(r);
+        Tmp<u64> flag(ctx);
+        Tmp<u32> tri_of(ctx), acc(ctx);
+        if ((r = flag.alloc(total)) || (r = tri_of.alloc(total)) || (r = acc.alloc((size_t)P.L * V))) return fail(r);
+        bool any_partial = false;
+        for (int j = 0; j < P.L; ++j) any_partial |= P.n[j] < V;
+        if (any_partial) feat_fill_ones_kernel<<<grid_for(V * P.L, 256), 256, 0, ctx->stream>>>(acc.p, V, P);
+        feat_flags_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, b->node_graph, flag.p);
+        TripleEmit te{P, A, b->node_graph, flag.p, tri_of.p, f->meta};
+        if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, total, nullptr))) return fail(r);
+        feat_count_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, tri_of.p, wide_above, acc.p, V, f->meta,
+                                                                         n_levels, kind);
+        if (kind == GK_FEAT_MINSUM) feat_runmax_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, f->meta);
+        ColumnIds ci{P, A, f->meta, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df, kind, n_levels};
+        if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, total, nullptr))) return fail(r);
+        feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, acc.p, V, P.L, f->selfk, N,
+                                                                          n_unlisted);
+        // one host sync: sizes of the dense operand
+        if (hipMemcpyAsync(h.data(), f->meta, n_meta * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            gk_set_error("gk_features_build: %s", hipGetErrorString(hipGetLastError()));
+            return fail(GK_ERR_HIP);
+        }
+    } else if (V > 0) {      // every level unlisted (cannot happen: level 0 always lists all nodes)
+        gk_set_error("gk_features_build: no level lists any node");
+        return fail(GK_ERR_STATE);
     }
-    if (V > 0)
-        feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, node_acc.p, f->selfk, N,
-                                                                          n_partial > 0 ? covered.p : nullptr, n_partial);
-    // one host sync: sizes of the dense operand
-    std::vector<u32> h(n_meta);
-    if (hipMemcpyAsync(h.data(), f->meta, n_meta * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        gk_set_error("gk_features_build: %s", hipGetErrorString(hipGetLastError()));
-        return fail(GK_ERR_HIP);
-    }
+    const int G = 3 * n_levels;
     f->nnz = 0;
     for (int l = 0; l < n_levels; ++l) f->nnz += h[META_T(l)];
-    f->n_cols = V > 0 ? h[META_C(n_levels - 1)] : 0;
-    f->max_count = h[3 * n_levels];
-    f->n_low_cols = h[3 * n_levels + 1];
-    for (int l = 0; l < n_levels; ++l) f->lev[l].n_low = h[3 * n_levels + 4 + l];
+    f->n_cols = h[G + 3];
+    f->max_count = h[G];
+    f->n_low_cols = h[G + 1];
+    {   // per-level views for the Gram kernels
+        u32 low_before = 0;
+        for (int l = 0; l < n_levels; ++l) {
+            LevelTriples& L = f->lev[l];
+            const int j = slot_of_level[l];
+            if (j < 0) continue;
+            const i64 base = P.off[j] + j;
+            L.tri_pos = A.tri_pos + base, L.tri_graph = A.tri_graph + base, L.tri_run = A.tri_run + base;
+            L.tstart = A.tstart + base, L.colid = A.colid + base, L.wide = A.wide + base;
+            L.low_runs = A.low_all + low_before;
+            L.n_low = (i64)h[G + 4 + l] - (i64)low_before;
+            low_before = h[G + 4 + l];
+        }
+    }
     // ids of the float64 side operand (second pass, only when a dense column is too wide for int8)
     f->n_cols_wide = 0;
-    if (V > 0 && kind == GK_FEAT_DOT && (f->max_count > 127 || f->dtype == 1)) {
-        Tmp<u32> wtotal(ctx);
-        if ((r = wtotal.alloc(1))) return fail(r);
-        for (int l = 0; l < n_levels; ++l) {
-            if (level_items(l) == 0) continue;
-            ColumnIdsWide cw{f->lev[l].colid, f->meta, n_levels};
-            if ((r = gk_scan_fn<u32, ColumnIdsWide>(ctx, cw, level_items(l), wtotal.p))) return fail(r);
-            feat_widebase_kernel<<<1, 1, 0, ctx->stream>>>(f->meta, wtotal.p, n_levels);
-        }
+    if (total > 0 && kind == GK_FEAT_DOT && (f->max_count > 127 || f->dtype == 1)) {
+        ColumnIdsWide cw{P, A, f->meta, n_levels};
+        if ((r = gk_scan_fn<u32, ColumnIdsWide>(ctx, cw, total, nullptr))) return fail(r);
         u32 hw = 0;
-        if (hipMemcpyAsync(&hw, f->meta + 3 * n_levels + 2, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (hipMemcpyAsync(&hw, f->meta + G + 2, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             gk_set_error("gk_features_build: %s", hipGetErrorString(hipGetLastError()));
             return fail(GK_ERR_HIP);
@@ -387,19 +446,19 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         if (gk_zero_async(ctx, f->phi_w, wb) != GK_OK) return fail(GK_ERR_HIP);
     }
     for (int l0 = 0; l0 < n_levels && V > 0; l0 += GK_PACK_LEVELS) {
-        LevelPack P;
-        P.n = 0, P.first[0] = 0;
+        LevelPack S;
+        S.n = 0, S.first[0] = 0;
         for (int l = l0; l < n_levels && l < l0 + GK_PACK_LEVELS; ++l) {
             LevelTriples& L = f->lev[l];
             if (h[META_T(l)] == 0 || !L.tri_pos) continue;
-            P.tri_pos[P.n] = L.tri_pos, P.tri_graph[P.n] = L.tri_graph, P.tri_run[P.n] = L.tri_run;
-            P.colid[P.n] = L.colid;
-            P.first[P.n + 1] = P.first[P.n] + h[META_T(l)];
-            ++P.n;
+            S.tri_pos[S.n] = L.tri_pos, S.tri_graph[S.n] = L.tri_graph, S.tri_run[S.n] = L.tri_run;
+            S.colid[S.n] = L.colid;
+            S.first[S.n + 1] = S.first[S.n] + h[META_T(l)];
+            ++S.n;
         }
-        if (P.n == 0) continue;
-        feat_scatter_mixed_kernel<<<grid_for(P.first[P.n], 256), 256, 0, ctx->stream>>>(
-            P, (int8_t*)f->phi, f->n_cols_pad, f->phi_w, f->n_cols_wide_pad, kind);
+        if (S.n == 0) continue;
+        feat_scatter_mixed_kernel<<<grid_for(S.first[S.n], 256), 256, 0, ctx->stream>>>(
+            S, (int8_t*)f->phi, f->n_cols_pad, f->phi_w, f->n_cols_wide_pad, kind);
     }
     if (hipGetLastError() != hipSuccess) {
         gk_set_error("gk_features_build: kernel launch failed");

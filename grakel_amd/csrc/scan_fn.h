@@ -1,6 +1,9 @@
 // Prefix sum over values produced on the fly by a functor, with the consumer fused in:
 //     struct F { __device__ T value(i64 i) const;  __device__ void emit(i64 i, T v, T inclusive) const;
-//                __device__ void finish(T total) const; };     // one thread, after the last emit
+//                __device__ void finish(T total) const;        // one thread, after the last emit
+//                __device__ i64 seg_first_tile(i64 tile) const; };  // first tile of the tile's segment
+// Segments (e.g. one per WL level, each padded to whole tiles) restart the sum at zero; an
+// unsegmented functor returns 0.
 // Two kernels (tile sums, then apply-with-direct-offset as in scan_sort.hip); no flag / scan
 // arrays ever touch HBM.  Used for run-head -> label id, triple emission and column ids.
 #pragma once
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(SF_THREADS) void scan_fn_apply_kernel(F f, const T*
     __shared__ T bsum[SF_THREADS / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     T s = 0;
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SF_THREADS) s += partial[i];
+    for (int i = (int)f.seg_first_tile(blockIdx.x) + threadIdx.x; i < (int)blockIdx.x; i += SF_THREADS) s += partial[i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) bsum[w] = s;
     __syncthreads();

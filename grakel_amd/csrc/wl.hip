@@ -193,6 +193,7 @@ struct HeadAssign {
         if (frozen) frozen[v] = (head && (k == n - 1 || ks[k + 1] != ks[k])) ? 1u : 0u;
     }
     __device__ __forceinline__ void finish(u32) const {}
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
 
 // A node whose class is a singleton stays a singleton at every later level (classes only
@@ -206,6 +207,7 @@ struct ActiveScan {
         else fidx[v] = (u32)v - incl;             // rank among the frozen nodes
     }
     __device__ __forceinline__ void finish(u32) const {}
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
 
 __global__ void frozen_assign_kernel(const u32* __restrict__ fidx, const u32* __restrict__ ra_dev,
