@@ -417,7 +417,11 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
         const int tri = (f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
         const int patch = getenv("GK_GRAM_NO_PATCH") ? 0 : 1;
         const char* shape = getenv("GK_GRAM_TILE");
-        if ((shape && !strcmp(shape, "128")) || (!shape && f->n_cols_pad < 8192)) {
+        if (shape && !strcmp(shape, "128ns3")) {
+            GK_TRY((launch_glds<2, 2, 2, 2, 3>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
+        } else if (shape && !strcmp(shape, "128ns2")) {
+            GK_TRY((launch_glds<2, 2, 2, 2, 2>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
+        } else if ((shape && !strcmp(shape, "128")) || (!shape && f->n_cols_pad < 8192)) {
             // short K: the 128x128 tile runs two workgroups per CU, so one tile's float64 store
             // epilogue overlaps the other's MFMA loop (measured 0.36 vs 0.41 ms at K = 3968)
             GK_TRY((launch_glds<2, 2, 2, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));

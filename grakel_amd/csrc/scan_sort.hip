@@ -3,6 +3,7 @@
 // for the stable scatter.  Used by the WL dictionary (sort node signatures), the feature
 // builder (head flags -> run ids) and the ShortestPath pair dictionary.
 #include "common.h"
+#include <stdlib.h>
 
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
@@ -339,8 +340,13 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
         } else {
             radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, n, shift, hist.p, nblk);
             radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
-            radix_scatter_kernel<RS_THREADS, false><<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(
-                ks, vs, kd, vd, n, shift, hist.p, totals, nblk);
+            static const int big_threads = getenv("GK_RS_LARGE_THREADS") ? atoi(getenv("GK_RS_LARGE_THREADS")) : 1024;
+            if (big_threads == 1024)
+                radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
+                    ks, vs, kd, vd, n, shift, hist.p, totals, nblk);
+            else
+                radix_scatter_kernel<RS_THREADS, false><<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(
+                    ks, vs, kd, vd, n, shift, hist.p, totals, nblk);
         }
         ks = kd, vs = vd;
     }
