@@ -188,7 +188,10 @@ struct gk_feat {
     int low_df = 32;            // columns occurring in fewer graphs are applied as pair updates
     i64 n_rows_pad = 0;
     int dtype = 0;              // 0: int8 Phi, 1: f64 Phi
-    void* phi = nullptr;        // [n_rows_pad][n_cols_pad]
+    void* phi = nullptr;        // [n_rows_pad][n_cols_pad BYTES]: n_cols4 columns as 4-bit counts (two per
+                                // byte, k4_tiles K-steps of 64 B), then n_cols8 columns as int8 (k8_tiles)
+    i64 n_cols4 = 0, n_cols8 = 0;
+    int k4_tiles = 0, k8_tiles = 0;
     // dense columns holding a count > 127 cannot be int8 operands: they form a (usually
     // narrow) float64 side operand whose product is accumulated onto K after the int8 GEMM
     i64 n_cols_wide = 0, n_cols_wide_pad = 0;

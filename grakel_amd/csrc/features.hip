@@ -32,13 +32,15 @@
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
 
 // meta layout (u32): per level l: [3l+0]=T (triples) [3l+1]=R (label runs) [3l+2]=dense columns
-// up to and including level l; globals at G = 3*n_levels: [G+0]=max count, [G+1]=rare columns,
-// [G+2]=float64 columns, [G+3]=dense columns, [G+4+l]=rare columns up to and including level l
+// with counts <= 15 up to and including level l; globals at G = 3*n_levels: [G+0]=max count,
+// [G+1]=rare columns, [G+2]=float64 columns, [G+3]=4-bit dense columns, [G+4+l]=rare columns up to
+// and including level l, [4*n_levels+4]=int8 dense columns
 #define META_T(l) (3 * (l) + 0)
 #define META_R(l) (3 * (l) + 1)
 #define META_C(l) (3 * (l) + 2)
 
 #define FEAT_MAX_LEVELS 48
+#define COL_BYTE_BASE (1 << 30)   // colid >= this: column (colid - base) of the int8 region
 
 // the levels of one job, by value: level slot j covers items [off[j], off[j] + n[j])
 struct FeatLevels {
@@ -135,7 +137,16 @@ __global__ void feat_count_kernel(const FeatLevels P, const FeatArrays A, const 
             const i64 b = A.base(P, j);
             const i32 t = (i32)tri_of[i];
             c = (u32)(A.tri_pos[b + t + 1] - A.tri_pos[b + t]);
-            if ((int)c > wide_above) A.wide[b + A.tri_run[b + t]] = 1;       // benign race: all writers store 1
+            if (!kind && c > 15u) {
+                // operand class of the run: byte 0 set = some count needs int8, byte 1 set = needs the
+                // float64 side.  Plain byte stores of the same value from every such item: a hot run
+                // (level 0: a few labels, a million items) must not serialise on an atomic or a read
+                char* w = (char*)&A.wide[b + A.tri_run[b + t]];
+                w[0] = 1;
+                if ((int)c > wide_above) w[1] = 1;
+            } else if (!kind && wide_above < 0) {
+                ((char*)&A.wide[b + A.tri_run[b + t]])[1] = 1;      // float64-only job: every run
+            }
             acc[(i64)j * V + P.perm[j][k]] = kind ? 1u : c;                    // min(c,c) summed == #nodes
         }
     }
@@ -203,7 +214,8 @@ __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* 
 }
 
 // Column classes per label run, fused into ONE prefix sum over the runs of all levels:
-//   dense (colid >= 0) : occurs in >= low_df graphs -> a column of the MFMA operand Phi_s
+//   dense (colid >= 0) : occurs in >= low_df graphs -> a column of the MFMA operand Phi_s (4-bit
+//                        region when every count is <= 15, else numbered by ColumnIdsByteWide)
 //   low   (colid = -2) : useful but rare (df < low_df): its df*(df-1) pair products are added
 //                        to K by gram_low_kernel after the GEMM -- a column with df graphs
 //                        costs N^2 MACs in the dense product but only df^2 updates here
@@ -225,7 +237,7 @@ struct ColumnIds {
         if (!useful) return 0ull;
         if ((t1 - t0) < low_df) return 1ull << 32;
         if (kind) return (u64)(u32)A.wide[b + r];       // unary expansion: one 0/1 column per count level
-        return A.wide[b + r] ? (1ull << 63) : 1ull;     // bit 63: dense but not int8-able (toggles only itself)
+        return A.wide[b + r] ? (1ull << 63) : 1ull;     // bit 63: dense but not 4-bit-able (toggles only itself)
     }
     __device__ __forceinline__ void emit(i64 i, u64 v, u64 incl) const {
         const int j = P.slot_of(i);
@@ -249,25 +261,34 @@ struct ColumnIds {
     __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
 
-// second pass (only when some count exceeded 127): ids for the float64 side operand
-struct ColumnIdsWide {
+// second pass: dense columns holding a count > 15 -> ids in the int8 region (low half of the
+// packed sum) or in the float64 side operand (high half)
+struct ColumnIdsByteWide {
     FeatLevels P; FeatArrays A; u32* meta; int n_levels;
-    __device__ __forceinline__ u32 value(i64 i) const {
+    __device__ __forceinline__ u64 value(i64 i) const {
         const int j = P.slot_of(i);
         const i64 r = i - P.off[j];
-        return (r < P.n[j] && A.colid[A.base(P, j) + r] == -3) ? 1u : 0u;
+        const i64 b = A.base(P, j);
+        if (r >= P.n[j] || A.colid[b + r] != -3) return 0ull;
+        return (A.wide[b + r] & 0xff00) ? (1ull << 32) : 1ull;
     }
-    __device__ __forceinline__ void emit(i64 i, u32 w, u32 incl) const {
+    __device__ __forceinline__ void emit(i64 i, u64 w, u64 incl) const {
         if (!w) return;
         const int j = P.slot_of(i);
-        A.colid[A.base(P, j) + (i - P.off[j])] = -4 - (i32)(incl - 1);
+        i32* c = &A.colid[A.base(P, j) + (i - P.off[j])];
+        if (w >> 32) *c = -4 - (i32)((u32)(incl >> 32) - 1);
+        else *c = COL_BYTE_BASE + (i32)((u32)(incl & 0xffffffffull) - 1);
     }
-    __device__ __forceinline__ void finish(u32 t) const { meta[3 * n_levels + 2] = t; }
+    __device__ __forceinline__ void finish(u64 t) const {
+        meta[3 * n_levels + 2] = (u32)(t >> 32);
+        meta[4 * n_levels + 4] = (u32)(t & 0xffffffffull);
+    }
     __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
 
 // all levels in one launch: P.first = prefix of the per-level triple counts
-__global__ void feat_scatter_mixed_kernel(const LevelPack P, int8_t* __restrict__ phi, i64 ld,
+// phi: int8 staging image [rows][ld], 4-bit-class columns first, int8-class columns from byte_col0
+__global__ void feat_scatter_mixed_kernel(const LevelPack P, int8_t* __restrict__ phi, i64 ld, i64 byte_col0,
                                           double* __restrict__ phi_w, i64 ldw, int kind) {
     i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.first[P.n]) return;
@@ -281,8 +302,31 @@ __global__ void feat_scatter_mixed_kernel(const LevelPack P, int8_t* __restrict_
     if (c >= 0 && kind) {
         int8_t* row = phi + (i64)tri_graph[t] * ld + c;
         for (i32 q = 0; q < cnt; ++q) row[q] = 1;           // [count >= q+1]
-    } else if (c >= 0) phi[(i64)tri_graph[t] * ld + c] = (int8_t)cnt;
+    } else if (c >= COL_BYTE_BASE) phi[(i64)tri_graph[t] * ld + byte_col0 + (c - COL_BYTE_BASE)] = (int8_t)cnt;
+    else if (c >= 0) phi[(i64)tri_graph[t] * ld + c] = (int8_t)cnt;
     else if (c <= -4) phi_w[(i64)tri_graph[t] * ldw + (-4 - c)] = (double)cnt;
+}
+
+// staging image -> GEMM operand: the first n4p columns as nibbles (column 2q low, 2q+1 high of
+// byte q), the n8p int8 columns behind them.  One thread per 4 output bytes.
+__global__ void feat_pack_kernel(const int8_t* __restrict__ stage, i64 ld_stage, i64 n4p, i64 n8p,
+                                 int8_t* __restrict__ out, i64 ld_out, i64 n_rows) {
+    const i64 words = ld_out >> 2;
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * words) return;
+    const i64 row = idx / words, w = idx - row * words;
+    const int8_t* src = stage + row * ld_stage;
+    u32 o;
+    if (w * 8 < n4p) {
+        const u64 x = *(const u64*)(src + w * 8);
+        const u64 lo = x & 0x000f000f000f000full, hi = (x >> 4) & 0x00f000f000f000f0ull;
+        const u64 m = lo | hi;                       // byte pairs (b0 | b1<<4) at bits 0, 16, 32, 48
+        o = (u32)(m & 0xffull) | (u32)((m >> 8) & 0xff00ull) | (u32)((m >> 16) & 0xff0000ull) |
+            (u32)((m >> 24) & 0xff000000ull);
+    } else {
+        o = *(const u32*)(src + n4p + (w * 4 - n4p / 2));
+    }
+    *(u32*)(out + row * ld_out + w * 4) = o;
 }
 
 extern "C" int gk_features_destroy(gk_feat* f) {
@@ -321,7 +365,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     auto fail = [&](int r) { gk_features_destroy(f); return r; };
     int r;
     void* q = nullptr;
-    const size_t n_meta = 4 * (size_t)n_levels + 4;
+    const size_t n_meta = 4 * (size_t)n_levels + 5;
     if ((r = gk_dev_alloc(ctx, &q, n_meta * 4))) return fail(r);
     f->meta = (u32*)q;
     if ((r = gk_dev_alloc(ctx, &q, (size_t)N * 8))) return fail(r);
@@ -387,6 +431,10 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         if (kind == GK_FEAT_MINSUM) feat_runmax_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, f->meta);
         ColumnIds ci{P, A, f->meta, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df, kind, n_levels};
         if ((r = gk_scan_fn<u64, ColumnIds>(ctx, ci, total, nullptr))) return fail(r);
+        if (kind == GK_FEAT_DOT) {   // always queued (two launches) so that ONE read-back below sizes everything
+            ColumnIdsByteWide cw{P, A, f->meta, n_levels};
+            if ((r = gk_scan_fn<u64, ColumnIdsByteWide>(ctx, cw, total, nullptr))) return fail(r);
+        }
         feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, acc.p, V, P.L, f->selfk, N,
                                                                           n_unlisted);
         // one host sync: sizes of the dense operand
@@ -402,7 +450,10 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     const int G = 3 * n_levels;
     f->nnz = 0;
     for (int l = 0; l < n_levels; ++l) f->nnz += h[META_T(l)];
-    f->n_cols = h[G + 3];
+    f->n_cols4 = h[G + 3];
+    f->n_cols8 = h[4 * n_levels + 4];
+    f->n_cols = f->n_cols4 + f->n_cols8;
+    f->n_cols_wide = h[G + 2];
     f->max_count = h[G];
     f->n_low_cols = h[G + 1];
     {   // per-level views for the Gram kernels
@@ -419,25 +470,21 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
             low_before = h[G + 4 + l];
         }
     }
-    // ids of the float64 side operand (second pass, only when a dense column is too wide for int8)
-    f->n_cols_wide = 0;
-    if (total > 0 && kind == GK_FEAT_DOT && (f->max_count > 127 || f->dtype == 1)) {
-        ColumnIdsWide cw{P, A, f->meta, n_levels};
-        if ((r = gk_scan_fn<u32, ColumnIdsWide>(ctx, cw, total, nullptr))) return fail(r);
-        u32 hw = 0;
-        if (hipMemcpyAsync(&hw, f->meta + G + 2, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            gk_set_error("gk_features_build: %s", hipGetErrorString(hipGetLastError()));
-            return fail(GK_ERR_HIP);
-        }
-        f->n_cols_wide = hw;
-    }
-    f->n_cols_pad = round_up(f->n_cols > 0 ? f->n_cols : 1, 128);
+    // ---- operands: int8 staging image (plain byte stores, no two writers per byte), then packed:
+    // columns whose counts fit 4 bits travel as nibbles -- the Gram kernel is bound by the operand
+    // bytes it pulls through L2 -> LDS (gram.hip), so halving them is what counts
+    const i64 n4p = round_up(f->n_cols4, 128);
+    i64 n8p = round_up(f->n_cols8, 64);
+    if (n4p + n8p == 0) n8p = 64;             // at least one (all-zero) K-step
+    f->k4_tiles = (int)(n4p / 128), f->k8_tiles = (int)(n8p / 64);
+    f->n_cols_pad = n4p / 2 + n8p;            // BYTES per operand row
     f->n_rows_pad = round_up(N, 256) + 256;   // slack so that tile loads never need row guards
-    const size_t phi_bytes = (size_t)f->n_rows_pad * f->n_cols_pad;
-    if ((r = gk_dev_alloc(ctx, &q, phi_bytes))) return fail(r);
+    const i64 ld_stage = n4p + n8p;
+    Tmp<int8_t> stage(ctx);
+    if ((r = stage.alloc((size_t)f->n_rows_pad * ld_stage))) return fail(r);
+    if (gk_zero_async(ctx, stage.p, (size_t)f->n_rows_pad * ld_stage) != GK_OK) return fail(GK_ERR_HIP);
+    if ((r = gk_dev_alloc(ctx, &q, (size_t)f->n_rows_pad * f->n_cols_pad))) return fail(r);
     f->phi = q;
-    if (gk_zero_async(ctx, f->phi, phi_bytes) != GK_OK) return fail(GK_ERR_HIP);
     if (f->n_cols_wide > 0) {
         f->n_cols_wide_pad = round_up(f->n_cols_wide, 16);
         const size_t wb = (size_t)f->n_rows_pad * f->n_cols_wide_pad * 8;
@@ -458,8 +505,10 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         }
         if (S.n == 0) continue;
         feat_scatter_mixed_kernel<<<grid_for(S.first[S.n], 256), 256, 0, ctx->stream>>>(
-            S, (int8_t*)f->phi, f->n_cols_pad, f->phi_w, f->n_cols_wide_pad, kind);
+            S, stage.p, ld_stage, n4p, f->phi_w, f->n_cols_wide_pad, kind);
     }
+    feat_pack_kernel<<<grid_for(f->n_rows_pad * (f->n_cols_pad / 4), 256), 256, 0, ctx->stream>>>(
+        stage.p, ld_stage, n4p, n8p, (int8_t*)f->phi, f->n_cols_pad, f->n_rows_pad);
     if (hipGetLastError() != hipSuccess) {
         gk_set_error("gk_features_build: kernel launch failed");
         return fail(GK_ERR_HIP);
@@ -490,12 +539,16 @@ extern "C" int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk) {
 
 extern "C" int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi) {
     GK_ARG(ctx && f && out_phi, "gk_features_debug_phi: null argument");
-    const i64 N = f->n_graphs, D = f->n_cols, ld = f->n_cols_pad;
+    const i64 N = f->n_graphs, D = f->n_cols, ld = f->n_cols_pad, n4 = f->n_cols4;
+    const i64 byte0 = (i64)f->k4_tiles * 64;      // first byte of the int8 region
     std::vector<unsigned char> h((size_t)N * ld);
     GK_HIP_CHECK(hipMemcpyAsync(h.data(), f->phi, h.size(), hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (i64 i = 0; i < N; ++i)
-        for (i64 j = 0; j < D; ++j)
-            out_phi[i * D + j] = (double)((const int8_t*)h.data())[i * ld + j];
+        for (i64 j = 0; j < D; ++j) {
+            const unsigned char* row = h.data() + i * ld;
+            out_phi[i * D + j] = j < n4 ? (double)((row[j >> 1] >> (4 * (j & 1))) & 15)
+                                        : (double)((const int8_t*)row)[byte0 + (j - n4)];
+        }
     return GK_OK;
 }

@@ -102,7 +102,7 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 template <int WM, int WN, int TM, int TN, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
-    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles,
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles, int k4_tiles,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
     int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
@@ -165,6 +165,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
         for (int ks = 0; ks < 2; ++ks) offb[j][ks] = BM * 64 + rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
     }
 
+    // The first k4_tiles K-steps hold 4-bit counts, two columns per byte (features.hip): a 16-byte
+    // fragment then feeds TWO MFMA slices (low nibbles, high nibbles; A and B are unpacked alike,
+    // so the column order inside the dot product does not matter).  Half the bytes per column
+    // through L2 -> LDS -> VGPR, which is what bounds this kernel.
+#define GL_MFMA(FA, FB, PACKED)                                                              \
+    if (PACKED) {                                                                            \
+        v4i al[TM], ah[TM], bl[TN], bh[TN];                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) { al[i] = FA[i] & 0x0f0f0f0f; ah[i] = (FA[i] >> 4) & 0x0f0f0f0f; } \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) { bl[j] = FB[j] & 0x0f0f0f0f; bh[j] = (FB[j] >> 4) & 0x0f0f0f0f; } \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                   \
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al[i], bl[j], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                   \
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+    } else {                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                   \
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(FA[i], FB[j], acc[i][j], 0, 0, 0); \
+    }
+
     v4i fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     {   // own pieces of stage 0 landed: up to NS-1 later stages may stay in flight
         const int after = k_tiles - 1;
@@ -183,49 +204,45 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb0[j] = *(const v4i*)(st + offb[j][0]);
     }
-    for (int kt = 0; kt < k_tiles; ++kt) {
-        const int8_t* st = smem + (kt % NS) * STAGE;
-        // ---- phase A: read slice 1 of stage kt, multiply slice 0
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa1[i] = *(const v4i*)(st + offa[i][1]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb1[j] = *(const v4i*)(st + offb[j][1]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- stage hand-over: stage kt+1 must be complete, stage kt is fully read
-        if (kt + 1 < k_tiles) {
-            const int after = k_tiles - 1 - (kt + 1);          // stages after kt+1 may stay in flight
-            const int fly = after < NS - 2 ? after : NS - 2;
-            if (fly >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PPW) : "memory");
-            else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
-            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS < k_tiles) GL_ISSUE(kt + NS);       // overwrites the buffer of stage kt
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase B: read slice 0 of stage kt+1, multiply slice 1
-        if (kt + 1 < k_tiles) {
-            const int8_t* sn = smem + ((kt + 1) % NS) * STAGE;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa0[i] = *(const v4i*)(sn + offa[i][0]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb0[j] = *(const v4i*)(sn + offb[j][0]);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    // two copies of the K-step, specialised at compile time (a run-time "packed" flag inside one
+    // loop makes the compiler keep two accumulator sets: 128 AGPRs, one wave per SIMD)
+#define GL_STEP(PACKED)                                                                      \
+    {                                                                                        \
+        const int8_t* st = smem + (kt % NS) * STAGE;                                         \
+        /* ---- phase A: read slice 1 of stage kt, multiply slice 0 */                        \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa1[i] = *(const v4i*)(st + offa[i][1]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb1[j] = *(const v4i*)(st + offb[j][1]); \
+        GL_MFMA(fa0, fb0, PACKED)                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        /* ---- stage hand-over: stage kt+1 must be complete, stage kt is fully read */       \
+        if (kt + 1 < k_tiles) {                                                              \
+            const int after = k_tiles - 1 - (kt + 1);   /* stages after kt+1 may stay in flight */ \
+            const int fly = after < NS - 2 ? after : NS - 2;                                 \
+            if (fly >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PPW) : "memory"); \
+            else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory"); \
+            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                 \
+        } else {                                                                             \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        }                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                        \
+        if (kt + NS < k_tiles) GL_ISSUE(kt + NS);       /* overwrites the buffer of stage kt */ \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        /* ---- phase B: read slice 0 of stage kt+1, multiply slice 1 */                      \
+        if (kt + 1 < k_tiles) {                                                              \
+            const int8_t* sn = smem + ((kt + 1) % NS) * STAGE;                               \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) fa0[i] = *(const v4i*)(sn + offa[i][0]); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) fb0[j] = *(const v4i*)(sn + offb[j][0]); \
+        }                                                                                    \
+        GL_MFMA(fa1, fb1, PACKED)                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
     }
+    int kt = 0;
+    for (; kt < k4_tiles; ++kt) GL_STEP(true)
+    for (; kt < k_tiles; ++kt) GL_STEP(false)
+#undef GL_STEP
 #undef GL_ISSUE
+#undef GL_MFMA
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool mirror = tri && bm != bn;     // off-diagonal tile of a symmetric job: also write K^T
@@ -274,7 +291,7 @@ static int launch_glds(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b
     auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
     GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
-        a, b, f->n_cols_pad, (int)(f->n_cols_pad / GI_BK), f->selfk, K, M, n_cols, row_lo,
+        a, b, f->n_cols_pad, f->k4_tiles + f->k8_tiles, f->k4_tiles, f->selfk, K, M, n_cols, row_lo,
         f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0);
     *tiles_done = tri ? (double)tiles_m * (tiles_m + 1) / 2 * BM * BN : (double)M * n_cols;
     return GK_OK;
@@ -468,7 +485,7 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     (void)hipEventDestroy(e1);
     f->last_ms = ms;
     // work actually executed: symmetric jobs only run the tiles on/above the diagonal
-    f->last_flops = 2.0 * tiles_done * (double)f->n_cols;
+    f->last_flops = 2.0 * tiles_done * (double)f->n_cols;     // columns actually holding a label (padding excluded)
     return GK_OK;
 }
 
