@@ -224,7 +224,7 @@ template <int THREADS, bool SMALL>
 __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
     u32* __restrict__ vout, i64 n, int shift, const u32* __restrict__ offs,
-    const u32* __restrict__ totals, int nblk) {
+    const u32* __restrict__ totals, int nblk, u32* __restrict__ totals_out, u32* __restrict__ max_out) {
     constexpr int NWAVE = THREADS / 64, ROUNDS = RS_TILE / THREADS, NQ = ROUNDS * NWAVE;   // NQ == 32
     __shared__ u32 cnt[NQ * 256];     // 32 KiB
     __shared__ u32 dsum[4];
@@ -269,6 +269,14 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     }
     const u32 dincl = wave_incl_scan(total);
     if (lane == 63 && w < 4) dsum[w] = dincl;
+    if (blockIdx.x == 0 && (totals_out || max_out)) {      // digit statistics of this pass (one block reports)
+        if (totals_out && tid < 256) totals_out[tid] = total;
+        if (max_out && w < 4) {
+            u32 m = total;
+            for (int off = 32; off > 0; off >>= 1) { const u32 o = __shfl_down(m, off, 64); m = o > m ? o : m; }
+            if (lane == 0) atomicMax(max_out, m);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < NQ * 256 / THREADS; ++q) cnt[q * THREADS + tid] = 0;
     __syncthreads();
@@ -310,11 +318,123 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Bucket finish: after ONE stable pass on the TOP digit the array is 256 contiguous buckets; a
+// workgroup then owns a bucket and runs every remaining (low to high) digit pass on it by itself,
+// ping-ponging between the two global buffers with only workgroup barriers in between.  Six
+// passes over 1 M keys become 4 launches instead of 18.  Correct for any bucket size; fast when
+// the buckets are balanced, which the caller judges from the class sizes of the previous level.
+// ---------------------------------------------------------------------------------------
+#define BK_THREADS 1024
+__global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
+    u64* __restrict__ ka, u32* __restrict__ va, u64* __restrict__ kb, u32* __restrict__ vb,
+    const u32* __restrict__ totals, int n_passes) {
+    constexpr int NWAVE = BK_THREADS / 64, ROUNDS = RS_TILE / BK_THREADS, NQ = ROUNDS * NWAVE;   // 32
+    __shared__ u32 cnt[NQ * 256];
+    __shared__ u32 base[256];
+    __shared__ u32 dsum[4];
+    __shared__ u32 bstart;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // bucket range: exclusive prefix of the digit totals
+    {
+        const u32 t = tid < 256 ? totals[tid] : 0u;
+        const u32 inc = wave_incl_scan(t);
+        if (lane == 63 && w < 4) dsum[w] = inc;
+        __syncthreads();
+        if (tid == (int)blockIdx.x) {
+            u32 off = inc - t;
+            for (int q = 0; q < w; ++q) off += dsum[q];
+            bstart = off;
+        }
+        __syncthreads();
+    }
+    const u32 size = totals[blockIdx.x];
+    if (size == 0) return;
+    const i64 start = bstart;
+    const u64 lt = (1ull << lane) - 1ull;
+    u64* ks = ka; u32* vs = va; u64* kd = kb; u32* vd = vb;
+    for (int p = 0; p < n_passes; ++p) {
+        const int shift = 8 * p;
+        if (tid < 256) base[tid] = 0;
+        __syncthreads();
+        for (u32 i = tid; i < size; i += BK_THREADS) atomicAdd(&base[(u32)(ks[start + i] >> shift) & 255u], 1u);
+        __syncthreads();
+        {
+            const u32 t = tid < 256 ? base[tid] : 0u;
+            const u32 inc = wave_incl_scan(t);
+            if (lane == 63 && w < 4) dsum[w] = inc;
+            __syncthreads();
+            if (tid < 256) {
+                u32 off = inc - t;
+                for (int q = 0; q < w; ++q) off += dsum[q];
+                base[tid] = off;
+            }
+        }
+        for (u32 tile0 = 0; tile0 < size; tile0 += RS_TILE) {
+            u64 key[ROUNDS];
+            u32 val[ROUNDS], rank[ROUNDS];
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const u32 i = tile0 + r * BK_THREADS + tid;
+                const bool act = i < size;
+                key[r] = act ? ks[start + i] : 0ull;
+                val[r] = act ? vs[start + i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ * 256 / BK_THREADS; ++q) cnt[q * BK_THREADS + tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const bool act = tile0 + r * BK_THREADS + tid < size;
+                const u32 d = (u32)(key[r] >> shift) & 255u;
+                u64 m = __ballot(act);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const u64 bb = __ballot(act && bit);
+                    m &= bit ? bb : ~bb;
+                }
+                rank[r] = (u32)__popcll(m & lt);
+                if (act && rank[r] == 0) cnt[(r * NWAVE + w) * 256 + d] = (u32)__popcll(m);
+            }
+            __syncthreads();
+            if (tid < 256) {
+                u32 run = base[tid];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const u32 c = cnt[q * 256 + tid];
+                    cnt[q * 256 + tid] = run;
+                    run += c;
+                }
+                base[tid] = run;      // carried into the bucket's next tile
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                if (tile0 + r * BK_THREADS + tid < size) {
+                    const u32 d = (u32)(key[r] >> shift) & 255u;
+                    const u32 pos = cnt[(r * NWAVE + w) * 256 + d] + rank[r];
+                    kd[start + pos] = key[r];
+                    vd[start + pos] = val[r];
+                }
+            }
+            __syncthreads();
+        }
+        // the bucket's next pass reads what this workgroup just wrote (same CU, workgroup scope)
+        __threadfence_block();
+        __syncthreads();
+        u64* tk = ks; ks = kd; kd = tk;
+        u32* tv = vs; vs = vd; vd = tv;
+    }
+}
+
 int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64* keys_out, u32* vals_out,
-                        i64 n, int key_bits) {
+                        i64 n, int key_bits, bool use_buckets, u32* top_digit_max) {
     // Stable sort by the low key_bits of the keys.  The inputs are only read (vals_in == nullptr:
     // the values are the indices 0..n-1); the passes ping-pong between the out buffers and a
     // temporary pair, ordered so that the last pass lands in keys_out / vals_out.
+    // top_digit_max (device, may be null) receives the size of the largest top-digit bucket.
+    if (top_digit_max) GK_TRY(gk_zero_async(ctx, top_digit_max, 4));
     if (n <= 0) return GK_OK;
     if (key_bits < 0) key_bits = 0;
     if (key_bits > 64) key_bits = 64;
@@ -324,9 +444,29 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
     const bool small = nblk <= RS_SMALL_TILES;
     Tmp<u32> hist(ctx), vtmp(ctx);
     Tmp<u64> ktmp(ctx);
-    if (!small) GK_TRY(hist.alloc((size_t)256 * nblk + 256));
+    GK_TRY(hist.alloc((small ? 0 : (size_t)256 * nblk) + 512));
     if (passes > 1) { GK_TRY(ktmp.alloc(n)); GK_TRY(vtmp.alloc(n)); }
-    u32* totals = small ? nullptr : hist.p + (size_t)256 * nblk;
+    u32* totals = hist.p + (small ? 0 : (size_t)256 * nblk);
+    u32* bucket_totals = totals + 256;
+    if (use_buckets && passes >= 3) {
+        // top digit first (stable), then every bucket finishes on its own
+        const int inner = passes - 1, shift = 8 * inner;
+        const bool msd_to_out = (inner & 1) == 0;      // inner passes alternate; the last one must land in out
+        u64* kx = msd_to_out ? keys_out : ktmp.p;  u32* vx = msd_to_out ? vals_out : vtmp.p;
+        u64* ky = msd_to_out ? ktmp.p : keys_out;  u32* vy = msd_to_out ? vtmp.p : vals_out;
+        if (small) {
+            radix_scatter_kernel<1024, true><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
+                keys_in, vals_in, kx, vx, n, shift, nullptr, nullptr, nblk, bucket_totals, top_digit_max);
+        } else {
+            radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(keys_in, n, shift, hist.p, nblk);
+            radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
+            radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
+                keys_in, vals_in, kx, vx, n, shift, hist.p, totals, nblk, bucket_totals, top_digit_max);
+        }
+        radix_bucket_kernel<<<dim3(256), dim3(BK_THREADS), 0, ctx->stream>>>(kx, vx, ky, vy, bucket_totals, inner);
+        GK_HIP_CHECK(hipGetLastError());
+        return GK_OK;
+    }
     const u64* ks = keys_in;
     const u32* vs = vals_in;
     for (int p = 0; p < passes; ++p) {
@@ -334,19 +474,15 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
         u64* kd = to_out ? keys_out : ktmp.p;
         u32* vd = to_out ? vals_out : vtmp.p;
         int shift = p * 8;
+        u32* mx = p == passes - 1 ? top_digit_max : nullptr;
         if (small) {
             radix_scatter_kernel<1024, true><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
-                ks, vs, kd, vd, n, shift, nullptr, nullptr, nblk);
+                ks, vs, kd, vd, n, shift, nullptr, nullptr, nblk, nullptr, mx);
         } else {
             radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(ks, n, shift, hist.p, nblk);
             radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
-            static const int big_threads = getenv("GK_RS_LARGE_THREADS") ? atoi(getenv("GK_RS_LARGE_THREADS")) : 1024;
-            if (big_threads == 1024)
-                radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
-                    ks, vs, kd, vd, n, shift, hist.p, totals, nblk);
-            else
-                radix_scatter_kernel<RS_THREADS, false><<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(
-                    ks, vs, kd, vd, n, shift, hist.p, totals, nblk);
+            radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
+                ks, vs, kd, vd, n, shift, hist.p, totals, nblk, nullptr, mx);
         }
         ks = kd, vs = vd;
     }

@@ -462,14 +462,14 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
 // lab/rep/frozen are indexed by item id, perm receives item ids.
 static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
                                 i32* rep, u32* count_dev, const u32* vals = nullptr, u32* frozen = nullptr,
-                                i64 rep_capacity = 0) {
+                                i64 rep_capacity = 0, bool use_buckets = false, u32* top_digit_max = nullptr) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         return GK_OK;
     }
     Tmp<u64> ks(ctx);
     GK_TRY(ks.alloc(n));
-    GK_TRY(gk_radix_sort_pairs(ctx, keys, vals, ks.p, (u32*)perm, n, key_bits));
+    GK_TRY(gk_radix_sort_pairs(ctx, keys, vals, ks.p, (u32*)perm, n, key_bits, use_buckets, top_digit_max));
     Tmp<i32> rep_tmp(ctx);
     if (!rep) { GK_TRY(rep_tmp.alloc(rep_capacity > n ? rep_capacity : n)); rep = rep_tmp.p; }
     HeadAssign ha{ks.p, (const u32*)perm, lab, rep, frozen, n};
@@ -482,8 +482,20 @@ int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i
     return dictionary_from_keys(ctx, keys, n, key_bits, lab, perm, nullptr, count_dev);
 }
 
+// The bucket finish of the sort (scan_sort.hip) pays when no top-digit bucket is much larger than
+// the average.  Classes only split from level to level, so the largest bucket of the PREVIOUS
+// level's sort bounds this level's largest class; it is read back together with n_active.
+#define SORT_BUCKET_MAX_KEYS 6144
+static bool sort_buckets_ok(u32 prev_top_max, i64 n, bool exact) {
+    static const char* e = getenv("GK_SORT_BUCKETS");       // "0" never, "1" always (tests), unset: decide
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    return !exact && prev_top_max > 0 && prev_top_max <= SORT_BUCKET_MAX_KEYS && n / 256 <= SORT_BUCKET_MAX_KEYS;
+}
+
 struct RelabelState {
-    Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active
+    u32 prev_top_max = 0;                  // largest top-digit bucket of the previous level's sort
+    Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active, [2] = top-digit max
     i64 n_frozen_levels = 0;
     explicit RelabelState(gk_ctx* c) : frozen(c), act(c), fidx(c), scratch(c) {}
 };
@@ -500,8 +512,12 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     if (!exact && !getenv("GK_WL_NO_ACTIVE_SET")) {
         ActiveScan as{st.frozen.p, st.act.p, st.fidx.p};
         GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, st.scratch.p + 1)));
-        GK_HIP_CHECK(hipMemcpyAsync(&n_act, st.scratch.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        u32 back[2] = {0, 0};
+        GK_HIP_CHECK(hipMemcpyAsync(back, st.scratch.p + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        n_act = back[0], st.prev_top_max = back[1];
+    } else {
+        st.prev_top_max = 0;
     }
     const u64 full_mask = hash_bits >= 64 ? ~0ull : ((1ull << hash_bits) - 1ull);
     b->n_sorted[level] = V;
@@ -536,7 +552,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                 b->big_nodes, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_node.p, seed, mask);
             gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act.p, n_act, b->row_ptr, hash_node.p, hash_act.p);
         }
-        GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act.p, st.frozen.p));
+        GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act.p, st.frozen.p, 0,
+                                    sort_buckets_ok(st.prev_top_max, n_act, exact), st.scratch.p + 2));
         frozen_assign_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V);
         // *unresolved_dev is still zero here: gk_wl_relabel cleared it and this path runs once per level
         verify_list_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act.p, n_act, b->row_ptr, prev, b->nbr_sorted,
@@ -557,7 +574,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             refine_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(cur, hash.p, keys.p, V);
             bits = 64, sort_keys = keys.p;
         }
-        GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p));
+        GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
+                                    round == 0 && sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2));
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
@@ -608,7 +626,8 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         GK_TRY(keys.alloc(V)); GK_TRY(lab_tmp.alloc(V));
         if (V > 0) labels_to_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels, keys.p, V);
         int bits = bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0);
-        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p));
+        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p, 0,
+                                    false, st.scratch.p + 2));
     }
     std::vector<u32> h(2 * (size_t)n_levels);
     int first_bad = -1;
