@@ -200,7 +200,7 @@ def main():
                     "achieved": (alg_flops / ((phases or {}).get("gram") * 1e-3) / 1e12) if phases else None},
                 "note": "achieved = integer ops EXECUTED by the MFMA kernel per launch / its avg HIP-event "
                         "duration (1 GPU: only the tiles on/above the diagonal, mirrored on store; "
-                        "only the dense columns -- label columns present in < 32 graphs are applied as exact "
+                        "only the dense columns -- label columns present in < 24 graphs are applied as exact "
                         "pair updates by gram_low_kernel, inside gram_phase_ms; columns whose counts fit 4 bits "
                         "travel as nibbles and are unpacked in registers, the MFMA itself is int8). The kernel "
                         "also writes the whole float64 K (N^2*8 B), which bounds it at ~0.13 ms by HBM."},

@@ -185,7 +185,7 @@ struct gk_feat {
     u32* meta = nullptr;        // device: per level {T, R, ncols_cum}, then globals
     u64* selfk = nullptr;       // [n_graphs] exact integer self similarity
     i64 n_cols = 0, n_cols_pad = 0, nnz = 0, max_count = 0, n_low_cols = 0;
-    int low_df = 32;            // columns occurring in fewer graphs are applied as pair updates
+    int low_df = 24;            // columns occurring in fewer graphs are applied as pair updates
     i64 n_rows_pad = 0;
     int dtype = 0;              // 0: int8 Phi, 1: f64 Phi
     void* phi = nullptr;        // [n_rows_pad][n_cols_pad BYTES]: n_cols4 columns as 4-bit counts (two per

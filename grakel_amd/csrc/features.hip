@@ -377,7 +377,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     }
     {
         const char* e = getenv("GK_LOW_DF");     // df threshold below which a column leaves the dense operand
-        f->low_df = e ? atoi(e) : 32;
+        f->low_df = e ? atoi(e) : 24;
         if (f->low_df < 2) f->low_df = 2;        // 2 == everything useful is dense
     }
     if (!b->graph_ptr) {

@@ -9,7 +9,7 @@
 //   2. gram_f64_kernel     : dense columns holding a count > 127 (typical for ShortestPath
 //                            histograms) form a narrow float64 side operand,
 //                            v_mfma_f64_16x16x4_f64, accumulated onto K (exact while K < 2^53).
-//   3. gram_low_kernel     : useful columns present in < 32 graphs never enter a dense operand;
+//   3. gram_low_kernel     : useful columns present in < 24 graphs (GK_LOW_DF) never enter a dense operand;
 //                            their df*(df-1) pair products are added as float64 atomics.
 //   4. gram_normalize_kernel, only when 2. or 3. ran and normalisation was requested.
 // Histogram-intersection features (kind 1) arrive unary-expanded (features.hip), so step 1 computes
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
 }
 
 // Rare columns (colid == -2): K[g_a][g_b] += c_a * c_b for every ordered pair of graphs that
-// share the label.  One wave per rare label run (df < 32 triples): lanes walk the df*df pairs.
+// share the label.  One wave per rare label run (df < GK_LOW_DF triples): lanes walk the df*df pairs.
 // Integer-valued float64 atomics: exact and order independent.
 __global__ void gram_low_kernel(const LevelPack P, double* __restrict__ K, i64 n_cols, i64 row_lo, i64 row_hi,
                                 int symmetric, i64 n_fit, int minsum) {

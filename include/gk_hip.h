@@ -121,7 +121,7 @@ int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, gk_
 int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, int kind, gk_feat** out);
 int gk_features_destroy(gk_feat* f);
 /* n_cols_kept: width of the dense MFMA operand Phi_s; n_cols_low: useful but rare columns
- * (fewer than GK_LOW_DF=32 graphs) that are applied as exact pair updates after the GEMM instead;
+ * (fewer than GK_LOW_DF=24 graphs) that are applied as exact pair updates after the GEMM instead;
  * nnz: number of (label,graph) triples over all levels; max_count: largest single count;
  * dtype: 0 = int8 Phi / i32 MFMA, 1 = f64 Phi / f64 MFMA. */
 int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* n_cols_low, int64_t* nnz,
