@@ -14,6 +14,7 @@
 //                        groups with re-seeded hashes until no mismatch is left.
 // HBM-bound integer work: algorithmic bytes per level 8E + 12V.
 #include "common.h"
+#include <stdio.h>
 #include "scan_fn.h"
 #include <stdlib.h>
 
@@ -485,7 +486,7 @@ int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i
 // The bucket finish of the sort (scan_sort.hip) pays when no top-digit bucket is much larger than
 // the average.  Classes only split from level to level, so the largest bucket of the PREVIOUS
 // level's sort bounds this level's largest class; it is read back together with n_active.
-#define SORT_BUCKET_MAX_KEYS 6144
+#define SORT_BUCKET_MAX_KEYS 16384
 static bool sort_buckets_ok(u32 prev_top_max, i64 n, bool exact) {
     static const char* e = getenv("GK_SORT_BUCKETS");       // "0" never, "1" always (tests), unset: decide
     if (e && e[0] == '0') return false;
@@ -516,6 +517,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         GK_HIP_CHECK(hipMemcpyAsync(back, st.scratch.p + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         n_act = back[0], st.prev_top_max = back[1];
+        static const bool dbg = getenv("GK_WL_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[gk] level %d: active %u of %lld, previous top-digit bucket max %u\n", level, n_act, (long long)V, back[1]);
     } else {
         st.prev_top_max = 0;
     }
