@@ -209,7 +209,7 @@ int gk_scan_u64(gk_ctx* ctx, const u64* in, u64* out, i64 n, bool exclusive, u64
 // vals_out; keys_in/vals_in are clobbered (used as ping-pong buffers).
 // implicit_iota: the input values are 0..n-1 and are never read (vals_in is scratch only).
 int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64* keys_out, u32* vals_out,
-                        i64 n, int key_bits, bool use_buckets = false, u32* top_digit_max = nullptr);
+                        i64 n, int key_bits, int use_buckets = 0, u32* top_digit_max = nullptr);
 
 // ---- wl.hip ---------------------------------------------------------------------------
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);

@@ -20,6 +20,21 @@ __device__ __forceinline__ T wave_incl_scan(T x) {
     return x;
 }
 
+// Digit histogram without same-address pile-ups: the lanes of a wave that hold the same digit find
+// each other with 8 ballots and their leader adds the group size once.  Equal keys (a WL class of
+// thousands of nodes has ONE hash) would otherwise serialise thousands of LDS atomics on one counter.
+__device__ __forceinline__ void wave_digit_add(u32* __restrict__ counters, bool act, u32 d) {
+    u64 m = __ballot(act);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const u64 bb = __ballot(act && bit);
+        m &= bit ? bb : ~bb;
+    }
+    const u64 lt = (1ull << (threadIdx.x & 63)) - 1ull;
+    if (act && (m & lt) == 0ull) atomicAdd(&counters[d], (u32)__popcll(m));
+}
+
 template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums_kernel(const T* __restrict__ in,
                                                                        T* __restrict__ partial,
@@ -179,11 +194,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const u64* __res
     const i64 tile0 = (i64)blockIdx.x * RS_TILE;
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
-        i64 idx = tile0 + r * RS_THREADS + tid;
-        if (idx < n) {
-            u32 d = (u32)(kin[idx] >> shift) & 255u;
-            atomicAdd(&h[d], 1u);
-        }
+        const i64 idx = tile0 + r * RS_THREADS + tid;
+        if (idx < n) atomicAdd(&h[(u32)(kin[idx] >> shift) & 255u], 1u);
     }
     __syncthreads();
     hist[(i64)tid * nblk + blockIdx.x] = h[tid];
@@ -357,7 +369,11 @@ __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
         const int shift = 8 * p;
         if (tid < 256) base[tid] = 0;
         __syncthreads();
-        for (u32 i = tid; i < size; i += BK_THREADS) atomicAdd(&base[(u32)(ks[start + i] >> shift) & 255u], 1u);
+        for (u32 i0 = 0; i0 < size; i0 += BK_THREADS) {
+            const u32 i = i0 + tid;
+            const bool act = i < size;
+            wave_digit_add(base, act, act ? (u32)(ks[start + i] >> shift) & 255u : 0u);
+        }
         __syncthreads();
         {
             const u32 t = tid < 256 ? base[tid] : 0u;
@@ -429,7 +445,10 @@ __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
 }
 
 int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64* keys_out, u32* vals_out,
-                        i64 n, int key_bits, bool use_buckets, u32* top_digit_max) {
+                        i64 n, int key_bits, int use_buckets, u32* top_digit_max) {
+    // use_buckets: 0 pass by pass, 1 bucket finish, 2 probe -- histogram the top digit, read the
+    // 256 bucket sizes back (one host sync) and take the bucket finish when the largest bucket is
+    // at most `probe_limit` keys; only worth it on large arrays (the sync costs about one pass).
     // Stable sort by the low key_bits of the keys.  The inputs are only read (vals_in == nullptr:
     // the values are the indices 0..n-1); the passes ping-pong between the out buffers and a
     // temporary pair, ordered so that the last pass lands in keys_out / vals_out.
@@ -448,6 +467,21 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
     if (passes > 1) { GK_TRY(ktmp.alloc(n)); GK_TRY(vtmp.alloc(n)); }
     u32* totals = hist.p + (small ? 0 : (size_t)256 * nblk);
     u32* bucket_totals = totals + 256;
+    bool probed = false;
+    if (use_buckets == 2) {
+        use_buckets = 0;
+        if (passes >= 4 && !small && nblk >= 128) {
+            const int shift = 8 * (passes - 1);
+            radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(keys_in, n, shift, hist.p, nblk);
+            radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
+            u32 h_tot[256];
+            GK_HIP_CHECK(hipMemcpyAsync(h_tot, totals, sizeof(h_tot), hipMemcpyDeviceToHost, ctx->stream));
+            GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            u32 mx = 0;
+            for (int d = 0; d < 256; ++d) mx = h_tot[d] > mx ? h_tot[d] : mx;
+            if (mx <= 16384) use_buckets = 1, probed = true;     // the histogram is reused below
+        }
+    }
     if (use_buckets && passes >= 3) {
         // top digit first (stable), then every bucket finishes on its own
         const int inner = passes - 1, shift = 8 * inner;
@@ -458,8 +492,10 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
             radix_scatter_kernel<1024, true><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
                 keys_in, vals_in, kx, vx, n, shift, nullptr, nullptr, nblk, bucket_totals, top_digit_max);
         } else {
-            radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(keys_in, n, shift, hist.p, nblk);
-            radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
+            if (!probed) {
+                radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(keys_in, n, shift, hist.p, nblk);
+                radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
+            }
             radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
                 keys_in, vals_in, kx, vx, n, shift, hist.p, totals, nblk, bucket_totals, top_digit_max);
         }

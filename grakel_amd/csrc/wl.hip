@@ -463,7 +463,7 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
 // lab/rep/frozen are indexed by item id, perm receives item ids.
 static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
                                 i32* rep, u32* count_dev, const u32* vals = nullptr, u32* frozen = nullptr,
-                                i64 rep_capacity = 0, bool use_buckets = false, u32* top_digit_max = nullptr) {
+                                i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         return GK_OK;
@@ -487,11 +487,13 @@ int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i
 // the average.  Classes only split from level to level, so the largest bucket of the PREVIOUS
 // level's sort bounds this level's largest class; it is read back together with n_active.
 #define SORT_BUCKET_MAX_KEYS 16384
-static bool sort_buckets_ok(u32 prev_top_max, i64 n, bool exact) {
+static int sort_buckets_ok(u32 prev_top_max, i64 n, bool exact) {
     static const char* e = getenv("GK_SORT_BUCKETS");       // "0" never, "1" always (tests), unset: decide
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
-    return !exact && prev_top_max > 0 && prev_top_max <= SORT_BUCKET_MAX_KEYS && n / 256 <= SORT_BUCKET_MAX_KEYS;
+    if (e && e[0] == '0') return 0;
+    if (e && e[0] == '1') return 1;
+    if (exact || n / 256 > SORT_BUCKET_MAX_KEYS) return 0;
+    if (prev_top_max > 0 && prev_top_max <= SORT_BUCKET_MAX_KEYS) return 1;
+    return 2;       // no bound from the previous level (e.g. level 1 after a few input labels): let the sort probe
 }
 
 struct RelabelState {
@@ -578,7 +580,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             bits = 64, sort_keys = keys.p;
         }
         GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
-                                    round == 0 && sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2));
+                                    round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2));
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
@@ -630,7 +632,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         if (V > 0) labels_to_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels, keys.p, V);
         int bits = bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0);
         GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p, 0,
-                                    false, st.scratch.p + 2));
+                                    0, st.scratch.p + 2));
     }
     std::vector<u32> h(2 * (size_t)n_levels);
     int first_bad = -1;
