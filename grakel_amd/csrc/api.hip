@@ -1,5 +1,8 @@
 // Context, error reporting, allocation and timing entry points of libgk_hip.so.
 #include "common.h"
+#include <chrono>
+#include <stdlib.h>
+#include <string.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -46,6 +49,18 @@ extern "C" int gk_create(int device_id, gk_ctx** out) {
     GK_HIP_CHECK(hipEventCreate(&ctx->ev1));
     GK_HIP_CHECK(hipEventCreate(&ctx->pv0));
     GK_HIP_CHECK(hipEventCreate(&ctx->pv1));
+    if (!getenv("GK_NO_MAILBOX")) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, GK_MBOX_WORDS * 4, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+            hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            memset(h, 0, GK_MBOX_WORDS * 4);
+            ctx->mbox_host = (u32*)h, ctx->mbox_dev = (u32*)d;
+        } else {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+        }
+    }
     *out = ctx;
     return GK_OK;
 }
@@ -58,10 +73,56 @@ extern "C" int gk_destroy(gk_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->pv0);
     (void)hipEventDestroy(ctx->pv1);
+    if (ctx->mbox_host) (void)hipHostFree(ctx->mbox_host);
     cache_release_all(ctx);
     for (auto& kv : ctx->cache.live) (void)hipFree(kv.first);   // leaked by the caller: reclaim
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+    return GK_OK;
+}
+
+// ---- small read-backs ---------------------------------------------------------------------
+// A hipMemcpyAsync(D2H) + hipStreamSynchronize pair costs a staging-copy kernel plus a stream drain
+// (~25 us of idle GPU each; a WL job needs one per level).  Instead one tiny kernel stores the words
+// into mapped pinned host memory and then releases a sequence number the host spins on.
+__global__ void mbox_post_kernel(const u32* __restrict__ src, int n_words, u32* __restrict__ mbox, u32 seq) {
+    for (int i = threadIdx.x; i < n_words; i += blockDim.x)
+        __hip_atomic_store(&mbox[1 + i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();        // every thread: its words are visible to the host before the barrier
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words) {
+    if (n_words <= 0) return GK_OK;
+    if (!ctx->mbox_host || n_words > GK_MBOX_WORDS - 1) {
+        GK_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, (size_t)n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return GK_OK;
+    }
+    const u32 seq = ++ctx->mbox_seq ? ctx->mbox_seq : ++ctx->mbox_seq;     // never 0
+    mbox_post_kernel<<<1, 256, 0, ctx->stream>>>(src_dev, n_words, ctx->mbox_dev, seq);
+    GK_HIP_CHECK(hipGetLastError());
+    volatile u32* box = ctx->mbox_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    u64 spins = 0;
+    while (__atomic_load_n(&box[0], __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xfffff) == 0) {
+            // very slow or failed kernel: fall back to a real synchronisation (reports the error, if any)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (__atomic_load_n(&box[0], __ATOMIC_ACQUIRE) != seq) {
+                    gk_set_error("gk_readback: the device never posted its values");
+                    return GK_ERR_HIP;
+                }
+                break;
+            }
+        }
+    }
+    for (int i = 0; i < n_words; ++i) dst_host[i] = box[1 + i];
     return GK_OK;
 }
 

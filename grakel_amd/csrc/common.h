@@ -67,7 +67,17 @@ struct gk_ctx {
     hipEvent_t pv0 = nullptr, pv1 = nullptr;   // profile timer
     bool profile = false;
     std::map<std::string, ProfSlot> prof;
+    // small device -> host read-backs (see gk_readback): mapped pinned host memory the device
+    // writes into, then a sequence word the host spins on -- no staging copy, no stream drain
+    u32* mbox_host = nullptr;
+    u32* mbox_dev = nullptr;
+    u32 mbox_seq = 0;
 };
+#define GK_MBOX_WORDS 512
+
+// Read n_words (<= GK_MBOX_WORDS - 1) u32 values at device address src back to dst_host, ordered after
+// everything queued on the context's stream so far.  Returns when the values have arrived.
+int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words);
 
 // Device allocation through the context's block cache (stream-ordered reuse on ctx->stream).
 int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes);

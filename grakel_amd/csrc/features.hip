@@ -438,11 +438,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, acc.p, V, P.L, f->selfk, N,
                                                                           n_unlisted);
         // one host sync: sizes of the dense operand
-        if (hipMemcpyAsync(h.data(), f->meta, n_meta * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            gk_set_error("gk_features_build: %s", hipGetErrorString(hipGetLastError()));
-            return fail(GK_ERR_HIP);
-        }
+        if ((r = gk_readback(ctx, f->meta, h.data(), (int)n_meta))) return fail(r);
     } else if (V > 0) {      // every level unlisted (cannot happen: level 0 always lists all nodes)
         gk_set_error("gk_features_build: no level lists any node");
         return fail(GK_ERR_STATE);

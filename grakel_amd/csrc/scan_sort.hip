@@ -475,8 +475,7 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
             radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(keys_in, n, shift, hist.p, nblk);
             radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
             u32 h_tot[256];
-            GK_HIP_CHECK(hipMemcpyAsync(h_tot, totals, sizeof(h_tot), hipMemcpyDeviceToHost, ctx->stream));
-            GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            GK_TRY(gk_readback(ctx, totals, h_tot, 256));
             u32 mx = 0;
             for (int d = 0; d < 256; ++d) mx = h_tot[d] > mx ? h_tot[d] : mx;
             if (mx <= 16384) use_buckets = 1, probed = true;     // the histogram is reused below

@@ -516,8 +516,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         ActiveScan as{st.frozen.p, st.act.p, st.fidx.p};
         GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, st.scratch.p + 1)));
         u32 back[2] = {0, 0};
-        GK_HIP_CHECK(hipMemcpyAsync(back, st.scratch.p + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        GK_TRY(gk_readback(ctx, st.scratch.p + 1, back, 2));
         n_act = back[0], st.prev_top_max = back[1];
         static const bool dbg = getenv("GK_WL_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "[gk] level %d: active %u of %lld, previous top-digit bucket max %u\n", level, n_act, (long long)V, back[1]);
@@ -638,8 +637,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     int first_bad = -1;
     for (int lvl = 1; lvl < n_levels; ++lvl)
         GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, st, meta.p + lvl, meta.p + n_levels + lvl, nullptr));
-    GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 8 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    GK_TRY(gk_readback(ctx, meta.p, h.data(), 2 * n_levels));
     for (int lvl = 1; lvl < n_levels; ++lvl)
         if (h[n_levels + lvl] != 0) { first_bad = lvl; break; }
     if (first_bad > 0) {   // a hash collision was detected: redo from that level, exactly
