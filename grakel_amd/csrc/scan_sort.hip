@@ -338,12 +338,28 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 // the buckets are balanced, which the caller judges from the class sizes of the previous level.
 // ---------------------------------------------------------------------------------------
 #define BK_THREADS 1024
+#define BK_ROUNDS 12
+#define BK_SUB 4                                // rounds ranked per sub-step (bounds the counter array)
+#define BK_CAP (BK_THREADS * BK_ROUNDS)        // bucket size the in-LDS path takes (12288 keys)
+#define BK_IDX_BITS 14
+#define BK_LDS_BYTES (BK_CAP * 8 + BK_SUB * (BK_THREADS / 64) * 256 * 2 + 4 * 256 * 4)
+
+// One workgroup per top-digit bucket of (ks, vs); the sorted bucket lands in (kd, vd).
+//  * bucket <= 12288 keys and <= 6 remaining digits: everything happens in LDS.  An element is
+//    (remaining key bits << 14 | position in the bucket), up to 12 per thread in registers in index
+//    order.  A pass (a) finds each element's rank inside its (round, wave) group with 8 ballots
+//    and adds the group sizes to the digit totals, (b) prefix-sums the totals, (c) four rounds at
+//    a time turns the group sizes (u16 counters) into offsets and scatters the elements into the
+//    LDS array, (d) reads them back in index order.  Work is proportional to the rounds in use.
+//    Keys and values are gathered from the (untouched) source by position at the very end.
+//  * anything else: the passes ping-pong through the two global buffers (workgroup barriers
+//    only); correct for any size, slow for a big bucket -- the caller avoids that case.
 __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
-    u64* __restrict__ ka, u32* __restrict__ va, u64* __restrict__ kb, u32* __restrict__ vb,
+    u64* __restrict__ ks, u32* __restrict__ vs, u64* __restrict__ kd, u32* __restrict__ vd,
     const u32* __restrict__ totals, int n_passes) {
-    constexpr int NWAVE = BK_THREADS / 64, ROUNDS = RS_TILE / BK_THREADS, NQ = ROUNDS * NWAVE;   // 32
-    __shared__ u32 cnt[NQ * 256];
-    __shared__ u32 base[256];
+    constexpr int NWAVE = BK_THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bk_lds[];
+    __shared__ u32 base[2][256];
     __shared__ u32 dsum[4];
     __shared__ u32 bstart;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -364,26 +380,161 @@ __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
     if (size == 0) return;
     const i64 start = bstart;
     const u64 lt = (1ull << lane) - 1ull;
-    u64* ks = ka; u32* vs = va; u64* kd = kb; u32* vd = vb;
+
+    if (size <= 256 && n_passes <= 6) {
+        // tiny bucket (the active levels of a WL job): rank every element against all others --
+        // (key bits, position) is a strict total order, so the rank is the output position.
+        // size broadcast reads from LDS per thread instead of n_passes barrier-laden passes.
+        u64* elems = (u64*)bk_lds;
+        const u64 keymask = (1ull << (n_passes * 8)) - 1ull;
+        u64 mine = ~0ull;
+        if ((u32)tid < size) {
+            mine = ((ks[start + tid] & keymask) << BK_IDX_BITS) | (u64)tid;
+            elems[tid] = mine;
+        }
+        __syncthreads();
+        if ((u32)tid < size) {
+            u32 rnk = 0;
+            for (u32 j = 0; j < size; ++j) rnk += elems[j] < mine ? 1u : 0u;
+            kd[start + rnk] = ks[start + tid];
+            vd[start + rnk] = vs[start + tid];
+        }
+        return;
+    }
+    if (size <= BK_CAP && n_passes <= 6) {
+        u64* elems = (u64*)bk_lds;                                         // [BK_CAP]
+        unsigned short* cnt16 = (unsigned short*)(bk_lds + BK_CAP * 8);    // [BK_SUB][NWAVE][256]
+        u32* qsum = (u32*)(bk_lds + BK_CAP * 8 + BK_SUB * NWAVE * 256 * 2);   // [4][256]
+        const int nr = (int)((size + BK_THREADS - 1) / BK_THREADS);        // rounds in use (block-uniform)
+        const u64 keymask = (1ull << (n_passes * 8)) - 1ull;
+        u64 e[BK_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < BK_ROUNDS; ++r) {
+            const u32 i = r * BK_THREADS + tid;
+            e[r] = (r < nr && i < size) ? (((ks[start + i] & keymask) << BK_IDX_BITS) | (u64)i) : ~0ull;
+        }
+        int cur = 0;
+        for (int p = 0; p < n_passes; ++p) {
+            const int shift = BK_IDX_BITS + 8 * p;
+            if (tid < 256) base[cur][tid] = 0;
+            __syncthreads();
+            // (a) rank inside the (round, wave) group; the group leader keeps the group size
+            u32 rank[BK_ROUNDS], gsz[BK_ROUNDS];
+#pragma unroll
+            for (int r = 0; r < BK_ROUNDS; ++r) {
+                rank[r] = 0, gsz[r] = 0;
+                if (r < nr) {
+                    const bool act = (u32)(r * BK_THREADS + tid) < size;
+                    const u32 d = (u32)(e[r] >> shift) & 255u;
+                    u64 m = __ballot(act);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const bool bit = (d >> b) & 1u;
+                        const u64 bb = __ballot(act && bit);
+                        m &= bit ? bb : ~bb;
+                    }
+                    rank[r] = (u32)__popcll(m & lt);
+                    if (act && rank[r] == 0) {
+                        gsz[r] = (u32)__popcll(m);
+                        atomicAdd(&base[cur][d], gsz[r]);
+                    }
+                }
+            }
+            __syncthreads();
+            // (b) digit offsets
+            {
+                const u32 t = tid < 256 ? base[cur][tid] : 0u;
+                const u32 inc = wave_incl_scan(t);
+                if (lane == 63 && w < 4) dsum[w] = inc;
+                __syncthreads();
+                if (tid < 256) {
+                    u32 off = inc - t;
+                    for (int q = 0; q < w; ++q) off += dsum[q];
+                    base[cur][tid] = off;
+                }
+            }
+            // (c) BK_SUB rounds at a time: group sizes -> offsets -> scatter
+            for (int r0 = 0; r0 < nr; r0 += BK_SUB) {
+                const int rs = nr - r0 < BK_SUB ? nr - r0 : BK_SUB;          // rounds of this sub-step
+                {
+                    uint4* z = (uint4*)cnt16;
+                    for (int q = tid; q < rs * NWAVE * 256 * 2 / 16; q += BK_THREADS) z[q] = make_uint4(0, 0, 0, 0);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < BK_ROUNDS; ++r)
+                    if (r >= r0 && r < r0 + rs && gsz[r])
+                        cnt16[((r - r0) * NWAVE + w) * 256 + ((u32)(e[r] >> shift) & 255u)] = (unsigned short)gsz[r];
+                __syncthreads();
+                {   // four threads per digit, each a contiguous quarter of the rs*16 groups
+                    const int d = tid & 255, qt = tid >> 8;
+                    const int per = rs * NWAVE / 4, g0 = qt * per;
+                    u32 ssum = 0;
+                    for (int g = 0; g < per; ++g) ssum += cnt16[(g0 + g) * 256 + d];
+                    qsum[qt * 256 + d] = ssum;
+                    __syncthreads();
+                    u32 run = base[cur][d];
+                    for (int q = 0; q < qt; ++q) run += qsum[q * 256 + d];
+                    for (int g = 0; g < per; ++g) {
+                        const u32 c = cnt16[(g0 + g) * 256 + d];
+                        cnt16[(g0 + g) * 256 + d] = (unsigned short)run;
+                        run += c;
+                    }
+                    if (qt == 3) base[cur ^ 1][d] = run;       // digit offsets for the next sub-step
+                }
+                __syncthreads();
+                cur ^= 1;
+#pragma unroll
+                for (int r = 0; r < BK_ROUNDS; ++r)
+                    if (r >= r0 && r < r0 + rs && (u32)(r * BK_THREADS + tid) < size) {
+                        const u32 d = (u32)(e[r] >> shift) & 255u;
+                        elems[(u32)cnt16[((r - r0) * NWAVE + w) * 256 + d] + rank[r]] = e[r];
+                    }
+                __syncthreads();
+            }
+            // (d) back into registers in index order
+#pragma unroll
+            for (int r = 0; r < BK_ROUNDS; ++r) {
+                const u32 i = r * BK_THREADS + tid;
+                if (r < nr && i < size) e[r] = elems[i];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < BK_ROUNDS; ++r) {
+            const u32 i = r * BK_THREADS + tid;
+            if (r < nr && i < size) {
+                const u32 src = (u32)(e[r] & (u64)((1u << BK_IDX_BITS) - 1));
+                kd[start + i] = ks[start + src];
+                vd[start + i] = vs[start + src];
+            }
+        }
+        return;
+    }
+
+    // ---- general path: ping-pong through global memory
+    constexpr int ROUNDS = RS_TILE / BK_THREADS, NQ = ROUNDS * NWAVE;   // 32 groups per tile
+    u32* cnt = (u32*)bk_lds;                                            // [NQ * 256]
+    u64* ka = ks; u32* va = vs; u64* kb = kd; u32* vb = vd;
     for (int p = 0; p < n_passes; ++p) {
         const int shift = 8 * p;
-        if (tid < 256) base[tid] = 0;
+        if (tid < 256) base[0][tid] = 0;
         __syncthreads();
         for (u32 i0 = 0; i0 < size; i0 += BK_THREADS) {
             const u32 i = i0 + tid;
             const bool act = i < size;
-            wave_digit_add(base, act, act ? (u32)(ks[start + i] >> shift) & 255u : 0u);
+            wave_digit_add(base[0], act, act ? (u32)(ka[start + i] >> shift) & 255u : 0u);
         }
         __syncthreads();
         {
-            const u32 t = tid < 256 ? base[tid] : 0u;
+            const u32 t = tid < 256 ? base[0][tid] : 0u;
             const u32 inc = wave_incl_scan(t);
             if (lane == 63 && w < 4) dsum[w] = inc;
             __syncthreads();
             if (tid < 256) {
                 u32 off = inc - t;
                 for (int q = 0; q < w; ++q) off += dsum[q];
-                base[tid] = off;
+                base[0][tid] = off;
             }
         }
         for (u32 tile0 = 0; tile0 < size; tile0 += RS_TILE) {
@@ -393,8 +544,8 @@ __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
             for (int r = 0; r < ROUNDS; ++r) {
                 const u32 i = tile0 + r * BK_THREADS + tid;
                 const bool act = i < size;
-                key[r] = act ? ks[start + i] : 0ull;
-                val[r] = act ? vs[start + i] : 0u;
+                key[r] = act ? ka[start + i] : 0ull;
+                val[r] = act ? va[start + i] : 0u;
             }
 #pragma unroll
             for (int q = 0; q < NQ * 256 / BK_THREADS; ++q) cnt[q * BK_THREADS + tid] = 0;
@@ -415,14 +566,14 @@ __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
             }
             __syncthreads();
             if (tid < 256) {
-                u32 run = base[tid];
+                u32 run = base[0][tid];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const u32 c = cnt[q * 256 + tid];
                     cnt[q * 256 + tid] = run;
                     run += c;
                 }
-                base[tid] = run;      // carried into the bucket's next tile
+                base[0][tid] = run;      // carried into the bucket's next tile
             }
             __syncthreads();
 #pragma unroll
@@ -430,8 +581,8 @@ __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
                 if (tile0 + r * BK_THREADS + tid < size) {
                     const u32 d = (u32)(key[r] >> shift) & 255u;
                     const u32 pos = cnt[(r * NWAVE + w) * 256 + d] + rank[r];
-                    kd[start + pos] = key[r];
-                    vd[start + pos] = val[r];
+                    kb[start + pos] = key[r];
+                    vb[start + pos] = val[r];
                 }
             }
             __syncthreads();
@@ -439,8 +590,14 @@ __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
         // the bucket's next pass reads what this workgroup just wrote (same CU, workgroup scope)
         __threadfence_block();
         __syncthreads();
-        u64* tk = ks; ks = kd; kd = tk;
-        u32* tv = vs; vs = vd; vd = tv;
+        u64* tk = ka; ka = kb; kb = tk;
+        u32* tv = va; va = vb; vb = tv;
+    }
+    if (ka != kd) {       // an even number of passes ended in the source buffer: move the bucket over
+        for (u32 i = tid; i < size; i += BK_THREADS) {
+            kd[start + i] = ka[start + i];
+            vd[start + i] = va[start + i];
+        }
     }
 }
 
@@ -478,15 +635,14 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
             GK_TRY(gk_readback(ctx, totals, h_tot, 256));
             u32 mx = 0;
             for (int d = 0; d < 256; ++d) mx = h_tot[d] > mx ? h_tot[d] : mx;
-            if (mx <= 16384) use_buckets = 1, probed = true;     // the histogram is reused below
+            if (mx <= BK_CAP) use_buckets = 1, probed = true;     // the histogram is reused below
         }
     }
     if (use_buckets && passes >= 3) {
         // top digit first (stable), then every bucket finishes on its own
         const int inner = passes - 1, shift = 8 * inner;
-        const bool msd_to_out = (inner & 1) == 0;      // inner passes alternate; the last one must land in out
-        u64* kx = msd_to_out ? keys_out : ktmp.p;  u32* vx = msd_to_out ? vals_out : vtmp.p;
-        u64* ky = msd_to_out ? ktmp.p : keys_out;  u32* vy = msd_to_out ? vtmp.p : vals_out;
+        u64* kx = ktmp.p;  u32* vx = vtmp.p;         // top-digit pass: in -> tmp; buckets: tmp -> out
+        u64* ky = keys_out;  u32* vy = vals_out;
         if (small) {
             radix_scatter_kernel<1024, true><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
                 keys_in, vals_in, kx, vx, n, shift, nullptr, nullptr, nblk, bucket_totals, top_digit_max);
@@ -498,7 +654,15 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
             radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
                 keys_in, vals_in, kx, vx, n, shift, hist.p, totals, nblk, bucket_totals, top_digit_max);
         }
-        radix_bucket_kernel<<<dim3(256), dim3(BK_THREADS), 0, ctx->stream>>>(kx, vx, ky, vy, bucket_totals, inner);
+        static bool attr_set = false;
+        if (!attr_set) {
+            GK_HIP_CHECK(hipFuncSetAttribute((const void*)radix_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             BK_LDS_BYTES));
+            attr_set = true;
+        }
+        static const int dbg_passes = getenv("GK_BK_DEBUG_PASSES") ? atoi(getenv("GK_BK_DEBUG_PASSES")) : -1;
+        radix_bucket_kernel<<<dim3(256), dim3(BK_THREADS), BK_LDS_BYTES, ctx->stream>>>(kx, vx, ky, vy, bucket_totals,
+                                                                                      dbg_passes >= 0 ? dbg_passes : inner);
         GK_HIP_CHECK(hipGetLastError());
         return GK_OK;
     }

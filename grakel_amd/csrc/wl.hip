@@ -486,7 +486,7 @@ int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i
 // The bucket finish of the sort (scan_sort.hip) pays when no top-digit bucket is much larger than
 // the average.  Classes only split from level to level, so the largest bucket of the PREVIOUS
 // level's sort bounds this level's largest class; it is read back together with n_active.
-#define SORT_BUCKET_MAX_KEYS 16384
+#define SORT_BUCKET_MAX_KEYS 12288     // what one workgroup sorts entirely in LDS (scan_sort.hip: BK_CAP)
 static int sort_buckets_ok(u32 prev_top_max, i64 n, bool exact) {
     static const char* e = getenv("GK_SORT_BUCKETS");       // "0" never, "1" always (tests), unset: decide
     if (e && e[0] == '0') return 0;
