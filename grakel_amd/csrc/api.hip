@@ -96,16 +96,16 @@ __global__ void mbox_post_kernel(const u32* __restrict__ src, int n_words, u32* 
     }
 }
 
-int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words) {
-    if (n_words <= 0) return GK_OK;
-    if (!ctx->mbox_host || n_words > GK_MBOX_WORDS - 1) {
-        GK_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, (size_t)n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        return GK_OK;
-    }
-    const u32 seq = ++ctx->mbox_seq ? ctx->mbox_seq : ++ctx->mbox_seq;     // never 0
-    mbox_post_kernel<<<1, 256, 0, ctx->stream>>>(src_dev, n_words, ctx->mbox_dev, seq);
-    GK_HIP_CHECK(hipGetLastError());
+// A kernel that can post by itself (e.g. the finish hook of a scan) takes gk_mbox_begin()'s sequence
+// number and ctx->mbox_dev, stores its words at mbox[1..] and then releases mbox[0] = seq at system
+// scope; the host collects them with gk_mbox_wait().  Returns 0 when the mailbox is unavailable.
+u32 gk_mbox_begin(gk_ctx* ctx) {
+    if (!ctx->mbox_host) return 0;
+    if (++ctx->mbox_seq == 0) ++ctx->mbox_seq;     // never 0
+    return ctx->mbox_seq;
+}
+
+int gk_mbox_wait(gk_ctx* ctx, u32 seq, u32* dst_host, int n_words) {
     volatile u32* box = ctx->mbox_host;
     const auto t0 = std::chrono::steady_clock::now();
     u64 spins = 0;
@@ -115,7 +115,7 @@ int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
                 GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
                 if (__atomic_load_n(&box[0], __ATOMIC_ACQUIRE) != seq) {
-                    gk_set_error("gk_readback: the device never posted its values");
+                    gk_set_error("gk_mbox_wait: the device never posted its values");
                     return GK_ERR_HIP;
                 }
                 break;
@@ -124,6 +124,19 @@ int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words) {
     }
     for (int i = 0; i < n_words; ++i) dst_host[i] = box[1 + i];
     return GK_OK;
+}
+
+int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words) {
+    if (n_words <= 0) return GK_OK;
+    const u32 seq = n_words <= GK_MBOX_WORDS - 1 ? gk_mbox_begin(ctx) : 0;
+    if (!seq) {
+        GK_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, (size_t)n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return GK_OK;
+    }
+    mbox_post_kernel<<<1, 256, 0, ctx->stream>>>(src_dev, n_words, ctx->mbox_dev, seq);
+    GK_HIP_CHECK(hipGetLastError());
+    return gk_mbox_wait(ctx, seq, dst_host, n_words);
 }
 
 extern "C" int gk_set_stream(gk_ctx* ctx, void* hip_stream) {

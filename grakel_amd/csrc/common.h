@@ -78,6 +78,8 @@ struct gk_ctx {
 // Read n_words (<= GK_MBOX_WORDS - 1) u32 values at device address src back to dst_host, ordered after
 // everything queued on the context's stream so far.  Returns when the values have arrived.
 int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words);
+u32 gk_mbox_begin(gk_ctx* ctx);                                     // 0: no mailbox, use gk_readback
+int gk_mbox_wait(gk_ctx* ctx, u32 seq, u32* dst_host, int n_words);
 
 // Device allocation through the context's block cache (stream-ordered reuse on ctx->stream).
 int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes);

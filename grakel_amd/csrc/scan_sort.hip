@@ -240,6 +240,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     constexpr int NWAVE = THREADS / 64, ROUNDS = RS_TILE / THREADS, NQ = ROUNDS * NWAVE;   // NQ == 32
     __shared__ u32 cnt[NQ * 256];     // 32 KiB
     __shared__ u32 dsum[4];
+    __shared__ u32 dmaxv[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const i64 tile0 = (i64)blockIdx.x * RS_TILE;
     u64 key[ROUNDS];
@@ -283,15 +284,20 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     if (lane == 63 && w < 4) dsum[w] = dincl;
     if (blockIdx.x == 0 && (totals_out || max_out)) {      // digit statistics of this pass (one block reports)
         if (totals_out && tid < 256) totals_out[tid] = total;
-        if (max_out && w < 4) {
+        if (max_out && w < 4) {     // plain store by the last of the four digit waves to arrive (no zeroing launch)
             u32 m = total;
             for (int off = 32; off > 0; off >>= 1) { const u32 o = __shfl_down(m, off, 64); m = o > m ? o : m; }
-            if (lane == 0) atomicMax(max_out, m);
+            if (lane == 0) dmaxv[w] = m;
         }
     }
 #pragma unroll
     for (int q = 0; q < NQ * 256 / THREADS; ++q) cnt[q * THREADS + tid] = 0;
     __syncthreads();
+    if (max_out && blockIdx.x == 0 && tid == 0) {
+        u32 m = dmaxv[0];
+        for (int q = 1; q < 4; ++q) m = dmaxv[q] > m ? dmaxv[q] : m;
+        *max_out = m;
+    }
     const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -610,8 +616,10 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
     // the values are the indices 0..n-1); the passes ping-pong between the out buffers and a
     // temporary pair, ordered so that the last pass lands in keys_out / vals_out.
     // top_digit_max (device, may be null) receives the size of the largest top-digit bucket.
-    if (top_digit_max) GK_TRY(gk_zero_async(ctx, top_digit_max, 4));
-    if (n <= 0) return GK_OK;
+    if (n <= 0) {
+        if (top_digit_max) GK_TRY(gk_zero_async(ctx, top_digit_max, 4));
+        return GK_OK;
+    }
     if (key_bits < 0) key_bits = 0;
     if (key_bits > 64) key_bits = 64;
     int passes = (key_bits + 7) / 8;

@@ -202,12 +202,24 @@ struct HeadAssign {
 // fresh id.  ActiveScan compacts the still-active nodes (ascending) and numbers the frozen.
 struct ActiveScan {
     const u32* frozen; u32* act; u32* fidx;
+    u32* total_out;            // device copy of the active count
+    const u32* extra;          // one more word to report (largest top-digit bucket of the last sort)
+    u32* mbox; u32 seq;        // host mailbox (null: the host reads total_out / extra back itself)
     __device__ __forceinline__ u32 value(i64 v) const { return frozen[v] ? 0u : 1u; }
     __device__ __forceinline__ void emit(i64 v, u32 a, u32 incl) const {
         if (a) { act[incl - 1] = (u32)v; fidx[v] = 0xffffffffu; }
         else fidx[v] = (u32)v - incl;             // rank among the frozen nodes
     }
-    __device__ __forceinline__ void finish(u32) const {}
+    // the totals are final before any emit ran, so the host can be told right away
+    __device__ __forceinline__ void finish(u32 total) const {
+        *total_out = total;
+        if (mbox) {
+            __hip_atomic_store(&mbox[1], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mbox[2], *extra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
 
@@ -264,6 +276,36 @@ __global__ void verify_list_kernel(const u32* __restrict__ act, i64 n_act, const
     const i32 v = (i32)act[j];
     const i32 r = rep[lab[v]];
     if (r == v) return;
+    bool ok = lab_prev[v] == lab_prev[r];
+    const i32 s = row_ptr[v], sr = row_ptr[r];
+    const int d = row_ptr[v + 1] - s;
+    ok = ok && (d == row_ptr[r + 1] - sr);
+    if (ok)
+        for (int k = 0; k < d; ++k)
+            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+    if (!ok) atomicAdd(unresolved, 1u);
+}
+
+// active-set level, one pass over the nodes: a frozen node receives its fresh id and its place
+// behind the sorted prefix; an active node is verified against its class representative
+__global__ void frozen_assign_verify_kernel(const u32* __restrict__ fidx, const u32* __restrict__ ra_dev,
+                                            i32* __restrict__ lab, i32* __restrict__ perm,
+                                            u32* __restrict__ count_out, u32 n_active, i64 n,
+                                            const u32* __restrict__ /*act*/, const i32* __restrict__ row_ptr,
+                                            const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
+                                            const i32* __restrict__ rep, u32* __restrict__ unresolved) {
+    const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 ra = *ra_dev;
+    if (v == 0) *count_out = ra + (u32)(n - n_active);
+    if (v >= n) return;
+    const u32 f = fidx[v];
+    if (f != 0xffffffffu) {
+        lab[v] = (i32)(ra + f);
+        perm[n_active + f] = (i32)v;
+        return;
+    }
+    const i32 r = rep[lab[v]];
+    if (r == (i32)v) return;
     bool ok = lab_prev[v] == lab_prev[r];
     const i32 s = row_ptr[v], sr = row_ptr[r];
     const int d = row_ptr[v + 1] - s;
@@ -513,10 +555,12 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     // ---- how many nodes still sit in classes of size >= 2 ? (one 4-byte read-back per level)
     u32 n_act = (u32)V;
     if (!exact && !getenv("GK_WL_NO_ACTIVE_SET")) {
-        ActiveScan as{st.frozen.p, st.act.p, st.fidx.p};
-        GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, st.scratch.p + 1)));
+        const u32 seq = gk_mbox_begin(ctx);
+        ActiveScan as{st.frozen.p, st.act.p, st.fidx.p, st.scratch.p + 1, st.scratch.p + 2, seq ? ctx->mbox_dev : nullptr, seq};
+        GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, nullptr)));
         u32 back[2] = {0, 0};
-        GK_TRY(gk_readback(ctx, st.scratch.p + 1, back, 2));
+        if (seq) GK_TRY(gk_mbox_wait(ctx, seq, back, 2));
+        else GK_TRY(gk_readback(ctx, st.scratch.p + 1, back, 2));
         n_act = back[0], st.prev_top_max = back[1];
         static const bool dbg = getenv("GK_WL_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "[gk] level %d: active %u of %lld, previous top-digit bucket max %u\n", level, n_act, (long long)V, back[1]);
@@ -558,10 +602,10 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         }
         GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act.p, st.frozen.p, 0,
                                     sort_buckets_ok(st.prev_top_max, n_act, exact), st.scratch.p + 2));
-        frozen_assign_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V);
         // *unresolved_dev is still zero here: gk_wl_relabel cleared it and this path runs once per level
-        verify_list_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act.p, n_act, b->row_ptr, prev, b->nbr_sorted,
-                                                                           cur, rep.p, unresolved_dev);
+        frozen_assign_verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(
+            st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V, st.act.p, b->row_ptr, prev, b->nbr_sorted, rep.p,
+            unresolved_dev);
         GK_HIP_CHECK(hipGetLastError());
         return GK_OK;
     }
