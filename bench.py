@@ -29,13 +29,13 @@ sys.path.insert(0, ROOT)
 WORKLOAD = dict(N=10000, n=100, p=0.05, L=5, seed=0, n_iter=5)
 I8_DENSE_PEAK_TOPS = 5000.0      # int8 MFMA dense = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6
-# HBM-side bytes per launch of the MFMA Gram kernel on this exact workload (config 3, 3 937 dense
-# columns -- 3 932 as 4-bit nibbles + 5 as int8 --, 128x128 tiles), from the PMC passes committed in
-# profiles/r01j_pmc_hbm_bytes.csv
+# HBM-side bytes per launch of the MFMA Gram kernel on this exact workload (config 3, 4 623 dense
+# columns at the rare-column threshold of 24 -- all but 5 as 4-bit nibbles --, 128x128 tiles), from the
+# PMC passes committed in profiles/r01p_pmc_hbm_bytes.csv
 # (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs): 2 x FETCH_SIZE (gfx950 reports
 # half of a wide coalesced read, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.
-# Algorithmic floor: read Phi_s once (21 MB packed) + write the float64 K once (800 MB).
-GRAM_PMC_TRAFFIC_BYTES = {(10000, "i8"): (2 * 146185.837 + 791986.4) * 1024}
+# Algorithmic floor: read Phi_s once (24 MB packed) + write the float64 K once (800 MB).
+GRAM_PMC_TRAFFIC_BYTES = {(10000, "i8"): (2 * 175819.625 + 795023.325) * 1024}
 
 def cpu_baseline(sample_graphs, cfg):
     """The CPU oracle (a literal restatement of the reference's algorithm) on a bounded sample
@@ -165,8 +165,8 @@ def main():
                             "frac_of_8TBps": rb / (phases["relabel"] * 1e-3) / 8e12},
                 "features": {"algorithmic_bytes": fb, "GB_per_s": fb / (phases["features"] * 1e-3) / 1e9,
                              "frac_of_8TBps": fb / (phases["features"] * 1e-3) / 8e12},
-                "note": "about 130 dependent launches of 4-50 us over 1 M-element arrays per step: "
-                        "latency/launch bound, not bandwidth bound (DESIGN.md 4)"}
+                "note": "about 70 dependent launches of 4-60 us over 1 M-element arrays per step, six device->host "
+                        "read-backs: launch/latency bound, not bandwidth bound (DESIGN.md 4)"}
         out = {
             "metric": "graph-pairs/sec for NxN WL-subtree(h=%d) fit_transform" % h,
             "value": N * N / (dt / a.steps),
