@@ -55,6 +55,7 @@ SIGNATURES = {
     "gk_gram_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "gk_gram_last_stats": (c_int, [c_void_p, _f64p, _f64p]),
     "gk_sp_build": (c_int, [c_void_p, c_void_p, c_void_p, c_int, _vpp, _i64p, _i64p]),
+    "gk_batch_from_shards": (c_int, [c_void_p, c_int, _i64p, c_int64, c_int64, c_int64, c_void_p, c_int, _vpp]),
     "gk_core_numbers": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gk_sp_build_levels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, _vpp, _i64p, _i64p]),
     "gk_sp_debug_apsp": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -345,9 +345,12 @@ __global__ void node_graph_kernel(const i32* __restrict__ graph_ptr, i32* __rest
     node_graph[v] = (i32)lo;
 }
 
-__global__ void batch_stats_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr,
+// per-block maxima (largest graph, largest degree) into part[2*block..]: thousands of blocks
+// hammering one counter -- even just reading it -- serialise on a single L2 channel
+__global__ __launch_bounds__(256) void batch_stats_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr,
                                    i64 n_graphs, i64 n_nodes, u32* __restrict__ big_flag,
-                                   i32* __restrict__ stats /* [0]=max graph nodes [1]=max degree */) {
+                                   i32* __restrict__ part) {
+    __shared__ int sg[4], sd[4];
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     int gn = 0, d = 0;
     if (i < n_graphs) gn = graph_ptr[i + 1] - graph_ptr[i];
@@ -355,13 +358,36 @@ __global__ void batch_stats_kernel(const i32* __restrict__ graph_ptr, const i32*
         d = row_ptr[i + 1] - row_ptr[i];
         big_flag[i] = d > WL_DEG_SMALL ? 1u : 0u;
     }
-    for (int off = 32; off > 0; off >>= 1) {     // one atomic per wave, and only when it can win
+    for (int off = 32; off > 0; off >>= 1) {
         int o = __shfl_down(gn, off, 64); gn = o > gn ? o : gn;
         o = __shfl_down(d, off, 64); d = o > d ? o : d;
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (gn > stats[0]) atomicMax(&stats[0], gn);
-        if (d > stats[1]) atomicMax(&stats[1], d);
+    if ((threadIdx.x & 63) == 0) sg[threadIdx.x >> 6] = gn, sd[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q) { gn = sg[q] > gn ? sg[q] : gn; d = sd[q] > d ? sd[q] : d; }
+        part[2 * blockIdx.x] = gn, part[2 * blockIdx.x + 1] = d;
+    }
+}
+
+// one block: stats[0] = max graph nodes, stats[1] = max degree
+__global__ __launch_bounds__(1024) void batch_stats_reduce_kernel(const i32* __restrict__ part, int nblk,
+                                                                  i32* __restrict__ stats) {
+    __shared__ int sg[16], sd[16];
+    int gn = 0, d = 0;
+    for (int i = threadIdx.x; i < nblk; i += 1024) {
+        const int a = part[2 * i], b = part[2 * i + 1];
+        gn = a > gn ? a : gn, d = b > d ? b : d;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_down(gn, off, 64); gn = o > gn ? o : gn;
+        o = __shfl_down(d, off, 64); d = o > d ? o : d;
+    }
+    if ((threadIdx.x & 63) == 0) sg[threadIdx.x >> 6] = gn, sd[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 16; ++q) { gn = sg[q] > gn ? sg[q] : gn; d = sd[q] > d ? sd[q] : d; }
+        stats[0] = gn, stats[1] = d;
     }
 }
 
@@ -376,6 +402,49 @@ static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+// node -> graph map, size statistics and the list of high-degree nodes of a batch whose
+// graph_ptr / row_ptr / col_idx / labels are already in place on the device
+static int batch_finish(gk_ctx* ctx, gk_batch* b) {
+    const i64 n_graphs = b->n_graphs, n_nodes = b->n_nodes;
+    if (n_nodes > 0)
+        node_graph_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->node_graph, n_graphs, n_nodes);
+    Tmp<u32> flag(ctx), excl(ctx), total(ctx);
+    Tmp<i32> stats(ctx), part(ctx);
+    const i64 m = n_graphs > n_nodes ? n_graphs : n_nodes;
+    const int nblk = (int)cdiv(m > 0 ? m : 1, 256);
+    GK_TRY(flag.alloc(n_nodes)); GK_TRY(excl.alloc(n_nodes)); GK_TRY(total.alloc(1));
+    GK_TRY(stats.alloc(3)); GK_TRY(part.alloc(2 * (size_t)nblk));
+    batch_stats_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, n_graphs, n_nodes, flag.p, part.p);
+    batch_stats_reduce_kernel<<<1, 1024, 0, ctx->stream>>>(part.p, nblk, stats.p);
+    GK_TRY(gk_scan_u32(ctx, flag.p, excl.p, n_nodes, true, (u32*)stats.p + 2));
+    u32 h[3] = {0, 0, 0};
+    GK_TRY(gk_readback(ctx, (const u32*)stats.p, h, 3));
+    b->max_graph_nodes = (i32)h[0], b->max_degree = (i32)h[1], b->n_big = h[2];
+    {
+        void* q = nullptr;
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)(b->n_big > 0 ? b->n_big : 1) * 4));
+        b->big_nodes = (i32*)q;
+    }
+    if (b->n_big > 0)
+        compact_big_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(flag.p, excl.p, b->big_nodes, n_nodes);
+    GK_HIP_CHECK(hipGetLastError());
+    b->n_levels = 0;
+    b->label_counts.assign(1, b->n_labels0);
+    return GK_OK;
+}
+
+static int batch_alloc(gk_ctx* ctx, gk_batch* b) {
+    i32** arrs[] = {&b->graph_ptr, &b->row_ptr, &b->col_idx, &b->node_graph, &b->nbr_sorted, &b->labels, &b->perm};
+    const i64 sizes[] = {b->n_graphs + 1, b->n_nodes + 1, b->n_edges, b->n_nodes, b->n_edges, b->n_nodes, b->n_nodes};
+    for (int k = 0; k < 7; ++k) {
+        void* q = nullptr;
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)(sizes[k] > 0 ? sizes[k] : 1) * 4));
+        *arrs[k] = (i32*)q;
+    }
+    b->cap_levels = 1;
+    return GK_OK;
+}
+
 extern "C" int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, int64_t n_edges,
                                const int32_t* graph_ptr, const int32_t* row_ptr,
                                const int32_t* col_idx, const int32_t* node_label,
@@ -390,52 +459,107 @@ extern "C" int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, i
     b->n_graphs = n_graphs, b->n_nodes = n_nodes, b->n_edges = n_edges, b->n_labels0 = n_labels0;
     hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     auto fail = [&](int r) { gk_batch_destroy(b); return r; };
-#define B_ALLOC(ptr, n) { void* q = nullptr; int r = gk_dev_alloc(ctx, &q, (size_t)((n) > 0 ? (n) : 1) * 4); if (r) return fail(r); ptr = (i32*)q; }
-    B_ALLOC(b->graph_ptr, n_graphs + 1);
-    B_ALLOC(b->row_ptr, n_nodes + 1);
-    B_ALLOC(b->col_idx, n_edges);
-    B_ALLOC(b->node_graph, n_nodes);
-    B_ALLOC(b->nbr_sorted, n_edges);
-    b->cap_levels = 1;
-    B_ALLOC(b->labels, n_nodes);
-    B_ALLOC(b->perm, n_nodes);
+    int r;
+    if ((r = batch_alloc(ctx, b))) return fail(r);
 #define B_COPY(dst, src, n) if ((n) > 0 && hipMemcpyAsync(dst, src, (size_t)(n) * 4, kind, ctx->stream) != hipSuccess) { gk_set_error("gk_batch_create: copy failed"); return fail(GK_ERR_HIP); }
     B_COPY(b->graph_ptr, graph_ptr, n_graphs + 1);
     B_COPY(b->row_ptr, row_ptr, n_nodes + 1);
     B_COPY(b->col_idx, col_idx, n_edges);
     B_COPY(b->labels, node_label, n_nodes);
 #undef B_COPY
-    if (n_nodes > 0) {
-        node_graph_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->node_graph, n_graphs, n_nodes);
-    }
-    // statistics + list of high-degree nodes
-    Tmp<u32> flag(ctx), excl(ctx), total(ctx);
-    Tmp<i32> stats(ctx);
-    int r;
-    if ((r = flag.alloc(n_nodes)) || (r = excl.alloc(n_nodes)) || (r = total.alloc(1)) || (r = stats.alloc(2))) return fail(r);
-    if (gk_zero_async(ctx, stats.p, 8) != GK_OK) return fail(GK_ERR_HIP);
-    i64 m = n_graphs > n_nodes ? n_graphs : n_nodes;
-    batch_stats_kernel<<<grid_for(m, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, n_graphs, n_nodes, flag.p, stats.p);
-    if ((r = gk_scan_u32(ctx, flag.p, excl.p, n_nodes, true, total.p))) return fail(r);
-    i32 hstats[2] = {0, 0};
-    u32 hbig = 0;
-    if (hipMemcpyAsync(hstats, stats.p, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(&hbig, total.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        gk_set_error("gk_batch_create: stats readback failed: %s", hipGetErrorString(hipGetLastError()));
-        return fail(GK_ERR_HIP);
-    }
-    b->max_graph_nodes = hstats[0], b->max_degree = hstats[1], b->n_big = hbig;
-    B_ALLOC(b->big_nodes, b->n_big);
-#undef B_ALLOC
-    if (b->n_big > 0)
-        compact_big_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(flag.p, excl.p, b->big_nodes, n_nodes);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if ((r = batch_finish(ctx, b))) return fail(r);
+    if (!src_on_device && hipStreamSynchronize(ctx->stream) != hipSuccess) {     // the host arrays may go away
         gk_set_error("gk_batch_create: %s", hipGetErrorString(hipGetLastError()));
         return fail(GK_ERR_HIP);
     }
-    b->n_levels = 0;
-    b->label_counts.assign(1, n_labels0);
+    *out = b;
+    return GK_OK;
+}
+
+// ---- multi-GPU: the global batch straight from the all-gathered shard messages ----------------
+// Rank r's message (msg_stride int32 words, as grakel_amd/dist.py packs it) is
+//   [graph sizes, padded to mg | node degrees, padded to mv | node labels, padded to mv | col_idx (LOCAL node ids), padded to me]
+// The shards are concatenated in rank order; col_idx is shifted to global node ids.
+#define GK_MAX_RANKS 64
+struct ShardMap {
+    int R;
+    i64 g0[GK_MAX_RANKS + 1], v0[GK_MAX_RANKS + 1], e0[GK_MAX_RANKS + 1];   // prefix sums of the shard sizes
+    i64 stride, mg, mv;
+    const i32* msg;
+    __device__ __forceinline__ int rank_of(const i64* p, i64 i) const {
+        int r = 0;
+        while (i >= p[r + 1]) ++r;
+        return r;
+    }
+};
+
+struct ShardGraphPtr {     // exclusive prefix of the graph sizes -> graph_ptr
+    ShardMap M; i32* graph_ptr; i64 n;
+    __device__ __forceinline__ u32 value(i64 g) const {
+        const int r = M.rank_of(M.g0, g);
+        return (u32)M.msg[r * M.stride + (g - M.g0[r])];
+    }
+    __device__ __forceinline__ void emit(i64 g, u32, u32 incl) const {
+        if (g == 0) graph_ptr[0] = 0;
+        graph_ptr[g + 1] = (i32)incl;
+    }
+    __device__ __forceinline__ void finish(u32) const {}
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
+};
+
+struct ShardRowPtr {       // exclusive prefix of the node degrees -> row_ptr; labels ride along
+    ShardMap M; i32* row_ptr; i32* labels; i64 n;
+    __device__ __forceinline__ u32 value(i64 v) const {
+        const int r = M.rank_of(M.v0, v);
+        return (u32)M.msg[r * M.stride + M.mg + (v - M.v0[r])];
+    }
+    __device__ __forceinline__ void emit(i64 v, u32, u32 incl) const {
+        const int r = M.rank_of(M.v0, v);
+        if (v == 0) row_ptr[0] = 0;
+        row_ptr[v + 1] = (i32)incl;
+        labels[v] = M.msg[r * M.stride + M.mg + M.mv + (v - M.v0[r])];
+    }
+    __device__ __forceinline__ void finish(u32) const {}
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
+};
+
+__global__ void shard_col_idx_kernel(const ShardMap M, i32* __restrict__ col_idx, i64 n_edges) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const int r = M.rank_of(M.e0, e);
+    col_idx[e] = M.msg[r * M.stride + M.mg + 2 * M.mv + (e - M.e0[r])] + (i32)M.v0[r];
+}
+
+extern "C" int gk_batch_from_shards(gk_ctx* ctx, int n_ranks, const int64_t* shard_sizes, int64_t mg, int64_t mv,
+                                    int64_t me, const int32_t* gathered_dev, int32_t n_labels0, gk_batch** out) {
+    GK_ARG(ctx && shard_sizes && gathered_dev && out, "gk_batch_from_shards: null argument");
+    GK_ARG(n_ranks >= 1 && n_ranks <= GK_MAX_RANKS, "gk_batch_from_shards: 1..64 ranks");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    ShardMap M;
+    M.R = n_ranks, M.stride = mg + 2 * mv + me, M.mg = mg, M.mv = mv, M.msg = gathered_dev;
+    M.g0[0] = M.v0[0] = M.e0[0] = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        const int64_t ng = shard_sizes[3 * r], nv = shard_sizes[3 * r + 1], ne = shard_sizes[3 * r + 2];
+        GK_ARG(ng >= 0 && nv >= 0 && ne >= 0 && ng <= mg && nv <= mv && ne <= me, "gk_batch_from_shards: shard larger than its padding");
+        M.g0[r + 1] = M.g0[r] + ng, M.v0[r + 1] = M.v0[r] + nv, M.e0[r + 1] = M.e0[r] + ne;
+    }
+    const i64 N = M.g0[n_ranks], V = M.v0[n_ranks], E = M.e0[n_ranks];
+    GK_ARG(N > 0, "gk_batch_from_shards: no graphs");
+    GK_ARG(V < (1ll << 31) - 1 && E < (1ll << 31) - 1, "gk_batch_from_shards: int32 index overflow");
+    gk_batch* b = new gk_batch();
+    b->ctx = ctx;
+    b->n_graphs = N, b->n_nodes = V, b->n_edges = E, b->n_labels0 = n_labels0;
+    auto fail = [&](int r) { gk_batch_destroy(b); return r; };
+    int r;
+    if ((r = batch_alloc(ctx, b))) return fail(r);
+    ShardGraphPtr sg{M, b->graph_ptr, N};
+    if ((r = gk_scan_fn<u32, ShardGraphPtr>(ctx, sg, N, nullptr))) return fail(r);
+    if (V > 0) {
+        ShardRowPtr sr{M, b->row_ptr, b->labels, V};
+        if ((r = gk_scan_fn<u32, ShardRowPtr>(ctx, sr, V, nullptr))) return fail(r);
+    } else if ((r = gk_zero_async(ctx, b->row_ptr, 4))) return fail(r);
+    if (E > 0) shard_col_idx_kernel<<<grid_for(E, 256), 256, 0, ctx->stream>>>(M, b->col_idx, E);
+    if ((r = batch_finish(ctx, b))) return fail(r);
     *out = b;
     return GK_OK;
 }

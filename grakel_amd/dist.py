@@ -69,6 +69,17 @@ class ShardExchange(object):
         for r in range(self.ws):
             self.bounds.append(self.bounds[-1] + int(a[r, 0]))
         self.zero = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.flat = None
+
+    def gather_flat(self):
+        """ONE collective into a preallocated buffer: the ws messages back to back (what
+        ``gk_batch_from_shards`` consumes on the device)."""
+        import torch
+        import torch.distributed as dist
+        if self.flat is None:
+            self.flat = torch.empty(self.ws * self.msg.shape[0], dtype=self.msg.dtype, device=self.dev)
+        dist.all_gather_into_tensor(self.flat, self.msg, group=self.group)
+        return self.flat
 
     def gather(self):
         import torch
@@ -116,6 +127,15 @@ class ShardedWL(object):
     def __init__(self, engine, n_iter=5, normalize=False, group=None):
         self.engine, self.n_iter, self.normalize, self.group = engine, n_iter, normalize, group
         self._exchange, self._local = None, None
+        self._stream_shared = False
+
+    def _share_stream(self, dev):
+        """The library works on torch's current stream of this device, so the all-gather and the
+        kernels that consume it are stream-ordered without a host synchronisation."""
+        import torch
+        if not self._stream_shared:
+            self.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            self._stream_shared = True
 
     def step(self, local_batch, to_host=False):
         """One fit_transform: returns (row block [n_local x N] or None, info dict)."""
@@ -125,12 +145,13 @@ class ShardedWL(object):
         dev = torch.device("cuda", self.engine.device)
         if self._local is not local_batch:           # shard sizes are exchanged once per local shard
             self._exchange, self._local = ShardExchange(local_batch, self.group, dev), local_batch
-        gp, rp, ci, lab = self._exchange.gather()
-        n_labels, bounds = self._exchange.n_labels, self._exchange.bounds
-        torch.cuda.current_stream(dev).synchronize()
+        self._share_stream(dev)
+        ex = self._exchange
+        flat = ex.gather_flat()
+        n_labels, bounds = ex.n_labels, ex.bounds
         eng = self.engine
-        db = eng.upload_from_device(gp.shape[0] - 1, lab.shape[0], ci.shape[0], gp.data_ptr(),
-                                    rp.data_ptr(), ci.data_ptr(), lab.data_ptr(), n_labels)
+        # the global CSR is rebuilt from the gathered messages by the library (two scans + one copy kernel)
+        db = eng.batch_from_shards(ex.all_sizes[:, :3], ex.mg, ex.mv, ex.me, flat.data_ptr(), n_labels)
         counts = eng.wl_relabel(db, self.n_iter)
         feat = eng.features(db, self.n_iter + 1)
         rows = (bounds[rank], bounds[rank + 1])

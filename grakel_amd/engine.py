@@ -120,6 +120,15 @@ class Engine(object):
                                        n_labels, 1, byref(h)))
         return DeviceBatch(self, h, n_graphs, n_nodes, n_edges)
 
+    def batch_from_shards(self, shard_sizes, mg, mv, me, gathered_ptr, n_labels):
+        """shard_sizes: int64 [n_ranks, 3] (graphs, nodes, edges); gathered_ptr: device address of the
+        all-gathered int32 messages (grakel_amd.dist.ShardExchange layout)."""
+        sizes = np.ascontiguousarray(shard_sizes, dtype=np.int64)
+        h = c_void_p()
+        check(self.lib.gk_batch_from_shards(self.handle, int(sizes.shape[0]), sizes.ctypes.data_as(ctypes.POINTER(c_int64)),
+                                            int(mg), int(mv), int(me), c_void_p(int(gathered_ptr)), int(n_labels), byref(h)))
+        return DeviceBatch(self, h, int(sizes[:, 0].sum()), int(sizes[:, 1].sum()), int(sizes[:, 2].sum()))
+
     # -- WL ---------------------------------------------------------------------------------
     def wl_relabel(self, db, n_iter, hash_bits=0):
         counts = (c_int64 * (n_iter + 1))()

@@ -72,6 +72,14 @@ int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, int64_t n_ed
                     const int32_t* graph_ptr, const int32_t* row_ptr, const int32_t* col_idx,
                     const int32_t* node_label, int32_t n_labels0, int src_on_device,
                     gk_batch** out);
+/* Multi-GPU ingestion (grakel_amd/dist.py): the global batch straight from the all-gathered shard
+ * messages, without a host round trip.  Rank r's message is msg_stride = mg + 2*mv + me int32 words:
+ * [graph sizes | node degrees | node labels | col_idx with LOCAL node ids], each part zero padded to
+ * the largest shard (mg graphs, mv nodes, me edges).  shard_sizes = int64[n_ranks][3] (graphs,
+ * nodes, edges) on the host; gathered_dev = the n_ranks messages back to back on the device (what
+ * ncclAllGather leaves).  Shards are concatenated in rank order. */
+int gk_batch_from_shards(gk_ctx* ctx, int n_ranks, const int64_t* shard_sizes, int64_t mg, int64_t mv,
+                         int64_t me, const int32_t* gathered_dev, int32_t n_labels0, gk_batch** out);
 int gk_batch_destroy(gk_batch* b);
 int gk_batch_info(gk_batch* b, int64_t* n_graphs, int64_t* n_nodes, int64_t* n_edges);
 

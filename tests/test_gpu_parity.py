@@ -321,7 +321,7 @@ def test_errors_match_reference(gk):
 
 def test_sharded_path_single_rank_matches_plain_path(gk):
     """grakel_amd/dist.py end to end on one GPU: a 1-rank RCCL group exercises the all-gather,
-    the device-side CSR rebuild, gk_batch_create(src_on_device=1) and gk_gram_rows."""
+    the device-side CSR rebuild (gk_batch_from_shards) and gk_gram_rows."""
     import torch
     import torch.distributed as dist
     from grakel_amd.batch import wl_batch_from_input
@@ -481,6 +481,42 @@ def test_edge_histogram_against_reference_goldens(gk, mutag_graphs):
     assert np.array_equal(gk.GraphKernel(kernel="EH").fit_transform(G[:120]), z["K_eh"])
     with pytest.raises(TypeError):
         gk.EdgeHistogram().fit_transform([[g[0], g[1]] for g in G[:3]])      # needs edge labels
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_batch_from_shards_rebuilds_the_global_batch(gk, world):
+    """What every rank of a `world`-rank job does after the all-gather, on one GPU: the messages
+    are packed per shard exactly as ShardExchange packs them (ragged shards, incl. graphs without
+    edges), laid out back to back as ncclAllGather leaves them, and gk_batch_from_shards must give
+    the same Gram rows as the plain path on the whole batch."""
+    import torch
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.dist import shard_bounds
+    from grakel_amd.engine import get_engine
+    X = er_dataset(203, 25, 0.08, 4, 17) + [[{0: [], 1: []}, {0: 1, 1: 2}]] * 2
+    gb, _ = wl_batch_from_input(X)
+    K = gk.WeisfeilerLehman(n_iter=3).fit_transform(gb)
+    b = shard_bounds(gb.n_graphs, world)
+    shards = [gb.slice_graphs(b[r], b[r + 1]) for r in range(world)]
+    sizes = np.array([[s.n_graphs, s.n_nodes, s.n_edges] for s in shards], np.int64)
+    mg, mv, me = (int(x) for x in sizes.max(axis=0))
+    msgs = []
+    for s in shards:
+        m = np.zeros(mg + 2 * mv + me, np.int32)
+        m[:s.n_graphs] = np.diff(s.graph_ptr)
+        m[mg:mg + s.n_nodes] = np.diff(s.row_ptr)
+        m[mg + mv:mg + mv + s.n_nodes] = s.node_label
+        m[mg + 2 * mv:mg + 2 * mv + s.n_edges] = s.col_idx          # local node ids
+        msgs.append(m)
+    flat = torch.from_numpy(np.concatenate(msgs)).cuda()
+    torch.cuda.synchronize()
+    eng = get_engine()
+    db = eng.batch_from_shards(sizes, mg, mv, me, flat.data_ptr(), gb.n_labels)
+    assert (db.n_graphs, db.n_nodes, db.n_edges) == (gb.n_graphs, gb.n_nodes, gb.n_edges)
+    eng.wl_relabel(db, 3)
+    feat = eng.features(db, 4)
+    for r in range(world):
+        assert np.array_equal(eng.gram(feat, 0, rows=(b[r], b[r + 1])), K[b[r]:b[r + 1]])
 
 
 # ------------------------------------------------------------------------------------------
