@@ -159,8 +159,9 @@ __global__ void feat_count_kernel(const FeatLevels P, const FeatArrays A, const 
     if (threadIdx.x == 0) {
         u32 m = wmax[0];
         for (int q = 1; q < (int)(blockDim.x >> 6); ++q) m = wmax[q] > m ? wmax[q] : m;
-        // plain read as a filter: once the maximum is established almost no block issues the atomic
-        if (m > meta[3 * n_levels]) atomicMax(&meta[3 * n_levels], m);
+        // 64 slots instead of one counter (the host takes their maximum): tens of thousands of
+        // blocks reading or updating ONE address serialise on a single L2 channel
+        if (m) atomicMax(&meta[4 * n_levels + 5 + (blockIdx.x & 63)], m);
     }
 }
 
@@ -365,7 +366,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     auto fail = [&](int r) { gk_features_destroy(f); return r; };
     int r;
     void* q = nullptr;
-    const size_t n_meta = 4 * (size_t)n_levels + 5;
+    const size_t n_meta = 4 * (size_t)n_levels + 5 + 64;      // ... + 64 partial maxima of the counts
     if ((r = gk_dev_alloc(ctx, &q, n_meta * 4))) return fail(r);
     f->meta = (u32*)q;
     if ((r = gk_dev_alloc(ctx, &q, (size_t)N * 8))) return fail(r);
@@ -450,7 +451,8 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     f->n_cols8 = h[4 * n_levels + 4];
     f->n_cols = f->n_cols4 + f->n_cols8;
     f->n_cols_wide = h[G + 2];
-    f->max_count = h[G];
+    f->max_count = 0;
+    for (int q = 0; q < 64; ++q) f->max_count = std::max<i64>(f->max_count, h[4 * n_levels + 5 + q]);
     f->n_low_cols = h[G + 1];
     {   // per-level views for the Gram kernels
         u32 low_before = 0;
