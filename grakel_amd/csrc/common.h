@@ -211,6 +211,7 @@ struct gk_feat {
     double* K = nullptr;        // last Gram output (device)
     i64 K_rows = 0, K_cols = 0;
     double last_flops = 0, last_ms = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the MFMA kernel of the last gk_gram* call
 };
 
 // ---- primitives (scan_sort.hip) -------------------------------------------------------

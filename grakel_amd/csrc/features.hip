@@ -333,6 +333,8 @@ __global__ void feat_pack_kernel(const int8_t* __restrict__ stage, i64 ld_stage,
 extern "C" int gk_features_destroy(gk_feat* f) {
     if (!f) return GK_OK;
     gk_ctx* ctx = f->ctx;
+    if (f->ev0) (void)hipEventDestroy(f->ev0);
+    if (f->ev1) (void)hipEventDestroy(f->ev1);
     for (void* p : f->arena)
         if (p) gk_dev_free(ctx, p);
     void* ptrs[] = {f->meta, f->selfk, f->phi, f->phi_w, f->K};

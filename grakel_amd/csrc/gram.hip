@@ -419,9 +419,13 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     const i64 M = row_hi - row_lo;
     if (M <= 0) return GK_OK;
     const i64 first_row_graph = (f->symmetric ? 0 : f->n_fit) + row_lo;   // row of Phi
-    hipEvent_t e0, e1;
-    GK_HIP_CHECK(hipEventCreate(&e0));
-    GK_HIP_CHECK(hipEventCreate(&e1));
+    // the MFMA kernel is bracketed by two events that are only READ in gk_gram_last_stats: the call
+    // returns as soon as everything is queued, so the host can already queue the next job
+    if (!f->ev0) {
+        GK_HIP_CHECK(hipEventCreate(&f->ev0));
+        GK_HIP_CHECK(hipEventCreate(&f->ev1));
+    }
+    hipEvent_t e0 = f->ev0, e1 = f->ev1;
     GK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
     double tiles_done = (double)M * n_cols;
     const int normalize_req = normalize;
@@ -478,12 +482,7 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
                 K, f->selfk, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize_req);
         GK_HIP_CHECK(hipGetLastError());
     }
-    GK_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    GK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    f->last_ms = ms;
+    f->last_ms = -1.0;      // not read yet
     // work actually executed: symmetric jobs only run the tiles on/above the diagonal
     f->last_flops = 2.0 * tiles_done * (double)f->n_cols;     // columns actually holding a label (padding excluded)
     return GK_OK;
@@ -527,6 +526,12 @@ extern "C" int gk_gram_dev_ptr(gk_feat* f, void** out_dev_ptr, int64_t* n_rows, 
 
 extern "C" int gk_gram_last_stats(gk_feat* f, double* out_flops, double* out_ms_event) {
     GK_ARG(f, "gk_gram_last_stats: null");
+    if (f->last_ms < 0 && f->ev0) {
+        GK_HIP_CHECK(hipEventSynchronize(f->ev1));
+        float ms = 0;
+        GK_HIP_CHECK(hipEventElapsedTime(&ms, f->ev0, f->ev1));
+        f->last_ms = ms;
+    }
     if (out_flops) *out_flops = f->last_flops;
     if (out_ms_event) *out_ms_event = f->last_ms;
     return GK_OK;
