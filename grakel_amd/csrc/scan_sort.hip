@@ -628,14 +628,16 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
     const bool small = nblk <= RS_SMALL_TILES;
     Tmp<u32> hist(ctx), vtmp(ctx);
     Tmp<u64> ktmp(ctx);
-    GK_TRY(hist.alloc((small ? 0 : (size_t)256 * nblk) + 512));
+    GK_TRY(hist.alloc((size_t)256 * nblk + 512));
     if (passes > 1) { GK_TRY(ktmp.alloc(n)); GK_TRY(vtmp.alloc(n)); }
-    u32* totals = hist.p + (small ? 0 : (size_t)256 * nblk);
+    u32* totals = hist.p + (size_t)256 * nblk;
     u32* bucket_totals = totals + 256;
     bool probed = false;
     if (use_buckets == 2) {
         use_buckets = 0;
-        if (passes >= 4 && !small && nblk >= 128) {
+        if (n <= BK_CAP) {
+            use_buckets = 1;                   // no bucket can exceed what the LDS path holds
+        } else if (passes >= 4) {
             const int shift = 8 * (passes - 1);
             radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(keys_in, n, shift, hist.p, nblk);
             radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
@@ -643,7 +645,7 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
             GK_TRY(gk_readback(ctx, totals, h_tot, 256));
             u32 mx = 0;
             for (int d = 0; d < 256; ++d) mx = h_tot[d] > mx ? h_tot[d] : mx;
-            if (mx <= BK_CAP) use_buckets = 1, probed = true;     // the histogram is reused below
+            if (mx <= BK_CAP) use_buckets = 1, probed = !small;     // large arrays reuse the histogram below
         }
     }
     if (use_buckets && passes >= 3) {

@@ -678,7 +678,10 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     if (V == 0) return GK_OK;
     // ---- how many nodes still sit in classes of size >= 2 ? (one 4-byte read-back per level)
     u32 n_act = (u32)V;
-    if (!exact && !getenv("GK_WL_NO_ACTIVE_SET")) {
+    // level 1 always takes the full path: a singleton class among the INPUT labels is rare, treating
+    // it as active is still correct (freezing is an optimisation), and skipping the scan saves two
+    // launches and a read-back; the sort probes its buckets instead of using the previous level's bound
+    if (!exact && !getenv("GK_WL_NO_ACTIVE_SET") && level >= 2) {
         const u32 seq = gk_mbox_begin(ctx);
         ActiveScan as{st.frozen.p, st.act.p, st.fidx.p, st.scratch.p + 1, st.scratch.p + 2, seq ? ctx->mbox_dev : nullptr, seq};
         GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, nullptr)));
