@@ -4,7 +4,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
-#include <string.h>
 
 static thread_local char g_err[1024] = "";
 static void cache_release_all(gk_ctx* ctx);

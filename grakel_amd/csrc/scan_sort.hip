@@ -1,6 +1,6 @@
-// Device-wide prefix sums and a stable LSD radix sort for (u64 key, u32 value) pairs.
+// Device-wide prefix sums and a stable radix sort for (u64 key, u32 value) pairs.
 // Hand-written for gfx950: 64-lane wave scans via DPP shuffles, wave-ballot digit matching
-// for the stable scatter.  Used by the WL dictionary (sort node signatures), the feature
+// for the stable scatter, an in-LDS finish per top-digit bucket.  Used by the WL dictionary (sort node signatures), the feature
 // builder (head flags -> run ids) and the ShortestPath pair dictionary.
 #include "common.h"
 #include <stdlib.h>
@@ -670,9 +670,7 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
                                              BK_LDS_BYTES));
             attr_set = true;
         }
-        static const int dbg_passes = getenv("GK_BK_DEBUG_PASSES") ? atoi(getenv("GK_BK_DEBUG_PASSES")) : -1;
-        radix_bucket_kernel<<<dim3(256), dim3(BK_THREADS), BK_LDS_BYTES, ctx->stream>>>(kx, vx, ky, vy, bucket_totals,
-                                                                                      dbg_passes >= 0 ? dbg_passes : inner);
+        radix_bucket_kernel<<<dim3(256), dim3(BK_THREADS), BK_LDS_BYTES, ctx->stream>>>(kx, vx, ky, vy, bucket_totals, inner);
         GK_HIP_CHECK(hipGetLastError());
         return GK_OK;
     }

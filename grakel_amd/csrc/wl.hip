@@ -5,17 +5,21 @@
 //                        col_idx stream, LDS-staged), sort them, write the sorted list to
 //                        nbr_sorted[] and form a 64-bit multiset hash of (own, degree, list).
 //   2. radix sort       : (hash, node) pairs, stable -> equal signatures become adjacent and
-//                        keep ascending node order inside a group.
+//                        keep ascending node order inside a group (scan_sort.hip: pass by pass,
+//                        or top digit + one workgroup per bucket when the classes are small).
 //   3. heads + scan     : group index = new dense label id; first node = representative.
 //   4. verify           : every node compares its FULL signature (own label, degree, sorted
 //                        list) with its group's representative -> the dictionary is exact, the
 //                        hash only proposes groups.  Any mismatch (a 64-bit collision) is
 //                        counted; the host then re-runs that level in "exact" mode, refining
 //                        groups with re-seeded hashes until no mismatch is left.
+// From level 2 on only the ACTIVE nodes go through 1-4: a node whose class is a singleton keeps a
+// class of its own for ever (ActiveScan / frozen_assign_verify_kernel).  The per-level sizes reach
+// the host through the mailbox of api.hip, not through a stream synchronisation.
 // HBM-bound integer work: algorithmic bytes per level 8E + 12V.
 #include "common.h"
-#include <stdio.h>
 #include "scan_fn.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 #define WL_DEG_SMALL 32       // nodes up to this degree: one thread sorts its list in LDS
@@ -160,10 +164,6 @@ __global__ __launch_bounds__(BIG_THREADS) void wl_signature_big_kernel(
     }
 }
 
-__global__ void iota_u32_kernel(u32* __restrict__ p, i64 n) {
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (u32)i;
-}
 
 __global__ void labels_to_keys_kernel(const i32* __restrict__ lab, u64* __restrict__ keys, i64 n) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -223,20 +223,6 @@ struct ActiveScan {
     __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
 
-__global__ void frozen_assign_kernel(const u32* __restrict__ fidx, const u32* __restrict__ ra_dev,
-                                     i32* __restrict__ lab, i32* __restrict__ perm,
-                                     u32* __restrict__ count_out, u32 n_active, i64 n) {
-    i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 ra = *ra_dev;
-    if (v < n) {
-        const u32 f = fidx[v];
-        if (f != 0xffffffffu) {
-            lab[v] = (i32)(ra + f);
-            perm[n_active + f] = (i32)v;
-        }
-    }
-    if (v == 0) *count_out = ra + (u32)(n - n_active);
-}
 
 // signature of the listed (active, degree <= WL_DEG_SMALL) nodes: one thread per node, the
 // neighbour list is gathered and sorted in the global scratch (few nodes: not worth staging)
@@ -267,24 +253,6 @@ __global__ void gather_big_hash_kernel(const u32* __restrict__ act, i64 n_act, c
     if (row_ptr[v + 1] - row_ptr[v] > WL_DEG_SMALL) hash_out[j] = hash_node[v];
 }
 
-__global__ void verify_list_kernel(const u32* __restrict__ act, i64 n_act, const i32* __restrict__ row_ptr,
-                                   const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
-                                   const i32* __restrict__ lab, const i32* __restrict__ rep,
-                                   u32* __restrict__ unresolved) {
-    i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_act) return;
-    const i32 v = (i32)act[j];
-    const i32 r = rep[lab[v]];
-    if (r == v) return;
-    bool ok = lab_prev[v] == lab_prev[r];
-    const i32 s = row_ptr[v], sr = row_ptr[r];
-    const int d = row_ptr[v + 1] - s;
-    ok = ok && (d == row_ptr[r + 1] - sr);
-    if (ok)
-        for (int k = 0; k < d; ++k)
-            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
-    if (!ok) atomicAdd(unresolved, 1u);
-}
 
 // active-set level, one pass over the nodes: a frozen node receives its fresh id and its place
 // behind the sorted prefix; an active node is verified against its class representative
