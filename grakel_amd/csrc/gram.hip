@@ -290,8 +290,14 @@ static int launch_glds(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b
     const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch ? patch_sz : 0);
     auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
     GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    int kt_all = f->k4_tiles + f->k8_tiles, kt4 = f->k4_tiles;
+    i64 M_store = M;
+    if (const char* abl = getenv("GK_GRAM_ABL")) {     // timing ablations (tools/gram_only.py): WRONG results
+        if (!strcmp(abl, "nostore")) M_store = 0;       // K loop only: every store is predicated off
+        if (!strcmp(abl, "nok")) kt_all = 0, kt4 = 0;   // epilogue only
+    }
     kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
-        a, b, f->n_cols_pad, f->k4_tiles + f->k8_tiles, f->k4_tiles, f->selfk, K, M, n_cols, row_lo,
+        a, b, f->n_cols_pad, kt_all, kt4, f->selfk, K, M_store, n_cols, row_lo,
         f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0);
     *tiles_done = tri ? (double)tiles_m * (tiles_m + 1) / 2 * BM * BN : (double)M * n_cols;
     return GK_OK;
@@ -438,7 +444,9 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
         const int tri = (f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
         const int patch = getenv("GK_GRAM_NO_PATCH") ? 0 : 1;
         const char* shape = getenv("GK_GRAM_TILE");
-        if (shape && !strcmp(shape, "128ns3")) {
+        if (shape && !strcmp(shape, "256")) {
+            GK_TRY((launch_glds<2, 4, 4, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
+        } else if (shape && !strcmp(shape, "128ns3")) {
             GK_TRY((launch_glds<2, 2, 2, 2, 3>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
         } else if (shape && !strcmp(shape, "128ns2")) {
             GK_TRY((launch_glds<2, 2, 2, 2, 2>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));

@@ -127,15 +127,24 @@ class ShardedWL(object):
     def __init__(self, engine, n_iter=5, normalize=False, group=None):
         self.engine, self.n_iter, self.normalize, self.group = engine, n_iter, normalize, group
         self._exchange, self._local = None, None
-        self._stream_shared = False
+        self._stream = None
 
-    def _share_stream(self, dev):
-        """The library works on torch's current stream of this device, so the all-gather and the
-        kernels that consume it are stream-ordered without a host synchronisation."""
+    def _shared_stream(self, dev):
+        """One torch side stream carries both the collective and the library's kernels, so the
+        all-gather and its consumers are stream-ordered without a host synchronisation.  It has to be
+        a real stream: torch's default stream has the handle 0, which ``gk_set_stream`` reads as
+        "use the context's own stream" -- and that stream is not ordered against the collective."""
         import torch
-        if not self._stream_shared:
-            self.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-            self._stream_shared = True
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(dev)
+            self.engine.set_stream(self._stream.cuda_stream)
+        return self._stream
+
+    def close(self):
+        """Give the engine its own stream back (the engine is process-wide)."""
+        if self._stream is not None:
+            self.engine.set_stream(0)
+            self._stream = None
 
     def step(self, local_batch, to_host=False):
         """One fit_transform: returns (row block [n_local x N] or None, info dict)."""
@@ -145,19 +154,22 @@ class ShardedWL(object):
         dev = torch.device("cuda", self.engine.device)
         if self._local is not local_batch:           # shard sizes are exchanged once per local shard
             self._exchange, self._local = ShardExchange(local_batch, self.group, dev), local_batch
-        self._share_stream(dev)
+        s = self._shared_stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))   # the shard message was built on the caller's stream
         ex = self._exchange
-        flat = ex.gather_flat()
-        n_labels, bounds = ex.n_labels, ex.bounds
         eng = self.engine
-        # the global CSR is rebuilt from the gathered messages by the library (two scans + one copy kernel)
-        db = eng.batch_from_shards(ex.all_sizes[:, :3], ex.mg, ex.mv, ex.me, flat.data_ptr(), n_labels)
-        counts = eng.wl_relabel(db, self.n_iter)
-        feat = eng.features(db, self.n_iter + 1)
-        rows = (bounds[rank], bounds[rank + 1])
-        K = eng.gram(feat, 2 if self.normalize else 0, rows=rows, to_host=to_host)
-        info = dict(label_counts=counts, n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, rows=rows, n_graphs=db.n_graphs,
-                    gram=eng.gram_stats(feat), dtype=feat.dtype)
-        feat.close()
-        db.close()
+        with torch.cuda.stream(s):
+            flat = ex.gather_flat()
+            n_labels, bounds = ex.n_labels, ex.bounds
+            # the global CSR is rebuilt from the gathered messages by the library (two scans + one copy kernel)
+            db = eng.batch_from_shards(ex.all_sizes[:, :3], ex.mg, ex.mv, ex.me, flat.data_ptr(), n_labels)
+            counts = eng.wl_relabel(db, self.n_iter)
+            feat = eng.features(db, self.n_iter + 1)
+            rows = (bounds[rank], bounds[rank + 1])
+            K = eng.gram(feat, 2 if self.normalize else 0, rows=rows, to_host=to_host)
+            info = dict(label_counts=counts, n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, rows=rows,
+                        n_graphs=db.n_graphs, gram=eng.gram_stats(feat), dtype=feat.dtype)
+            feat.close()
+            db.close()
+        torch.cuda.current_stream(dev).wait_stream(s)
         return K, info

@@ -336,8 +336,11 @@ def test_sharded_path_single_rank_matches_plain_path(gk):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         gb, _ = wl_batch_from_input(X)
-        Kr, info = ShardedWL(get_engine(), n_iter=3).step(gb, to_host=True)
-        assert info["rows"] == (0, 300) and np.array_equal(Kr, K)
+        sw = ShardedWL(get_engine(), n_iter=3)
+        for _ in range(3):                           # repeated steps reuse the gather buffer and the side stream
+            Kr, info = sw.step(gb, to_host=True)
+            assert info["rows"] == (0, 300) and np.array_equal(Kr, K)
+        sw.close()
         # a row block (what rank r of R computes) equals the same rows of the full matrix
         eng = get_engine()
         db = eng.upload(gb)
