@@ -348,6 +348,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 #define BK_SUB 4                                // rounds ranked per sub-step (bounds the counter array)
 #define BK_CAP (BK_THREADS * BK_ROUNDS)        // bucket size the in-LDS path takes (12288 keys)
 #define BK_IDX_BITS 14
+#define BK_SMALL 512                             // buckets up to this size are ranked by comparison
 #define BK_LDS_BYTES (BK_CAP * 8 + BK_SUB * (BK_THREADS / 64) * 256 * 2 + 4 * 256 * 4)
 
 // One workgroup per top-digit bucket of (ks, vs); the sorted bucket lands in (kd, vd).
@@ -387,21 +388,38 @@ __global__ __launch_bounds__(BK_THREADS) void radix_bucket_kernel(
     const i64 start = bstart;
     const u64 lt = (1ull << lane) - 1ull;
 
-    if (size <= 256 && n_passes <= 6) {
-        // tiny bucket (the active levels of a WL job): rank every element against all others --
+    if (size <= BK_SMALL && n_passes <= 6) {
+        // small bucket (the active levels of a WL job): rank every element against all others --
         // (key bits, position) is a strict total order, so the rank is the output position.
-        // size broadcast reads from LDS per thread instead of n_passes barrier-laden passes.
-        u64* elems = (u64*)bk_lds;
+        // All 1024 threads take part: an element is served by 1024/S2 threads (S2 = 256 or 512
+        // element slots), each counting the smaller elements in its share of the bucket with
+        // broadcast 16-byte LDS reads; the partial ranks meet in an LDS counter.
+        u64* elems = (u64*)bk_lds;                              // [BK_SMALL], padded with the largest value
+        u32* rk = (u32*)(bk_lds + BK_SMALL * 8);                // [BK_SMALL]
         const u64 keymask = (1ull << (n_passes * 8)) - 1ull;
-        u64 mine = ~0ull;
-        if ((u32)tid < size) {
-            mine = ((ks[start + tid] & keymask) << BK_IDX_BITS) | (u64)tid;
-            elems[tid] = mine;
+        if (tid < BK_SMALL) {
+            elems[tid] = (u32)tid < size ? (((ks[start + tid] & keymask) << BK_IDX_BITS) | (u64)tid) : ~0ull;
+            rk[tid] = 0;
+        }
+        __syncthreads();
+        const u32 S2 = size <= 256 ? 256u : 512u;
+        const u32 e = (u32)tid & (S2 - 1u), part = (u32)tid / S2, parts = BK_THREADS / S2;
+        const u32 per = (((size + parts - 1u) / parts) + 1u) & ~1u;      // even: 16-byte reads
+        if (e < size) {
+            const u64 mine = elems[e];
+            u32 j = part * per;
+            const u32 j1 = j + per < (u32)BK_SMALL ? j + per : (u32)BK_SMALL;
+            u32 r = 0;
+#pragma unroll 8
+            for (; j < j1; j += 2) {
+                const ulonglong2 ab = *(const ulonglong2*)(elems + j);
+                r += (ab.x < mine ? 1u : 0u) + (ab.y < mine ? 1u : 0u);
+            }
+            if (r) atomicAdd(&rk[e], r);
         }
         __syncthreads();
         if ((u32)tid < size) {
-            u32 rnk = 0;
-            for (u32 j = 0; j < size; ++j) rnk += elems[j] < mine ? 1u : 0u;
+            const u32 rnk = rk[tid];
             kd[start + rnk] = ks[start + tid];
             vd[start + rnk] = vs[start + tid];
         }
