@@ -205,10 +205,15 @@ struct ActiveScan {
     u32* total_out;            // device copy of the active count
     const u32* extra;          // one more word to report (largest top-digit bucket of the last sort)
     u32* mbox; u32 seq;        // host mailbox (null: the host reads total_out / extra back itself)
-    __device__ __forceinline__ u32 value(i64 v) const { return frozen[v] ? 0u : 1u; }
+    const i32* iso_info;       // gk_batch::iso_info (null: no isolated vertices): those are carried, never active
+    __device__ __forceinline__ u32 value(i64 v) const {
+        return (frozen[v] || (iso_info && iso_info[v] < 0)) ? 0u : 1u;
+    }
     __device__ __forceinline__ void emit(i64 v, u32 a, u32 incl) const {
-        if (a) { act[incl - 1] = (u32)v; fidx[v] = 0xffffffffu; }
-        else fidx[v] = (u32)v - incl;             // rank among the frozen nodes
+        if (a) { act[incl - 1] = (u32)v; fidx[v] = 0xffffffffu; return; }
+        const i32 info = iso_info ? iso_info[v] : 0;
+        if (info < 0) fidx[v] = 0x80000000u | (u32)(-1 - info);   // carried: slot in the carried list
+        else fidx[v] = (u32)v - incl - (u32)info;                  // rank among the frozen nodes
     }
     // the totals are final before any emit ran, so the host can be told right away
     __device__ __forceinline__ void finish(u32 total) const {
@@ -255,21 +260,30 @@ __global__ void gather_big_hash_kernel(const u32* __restrict__ act, i64 n_act, c
 
 
 // active-set level, one pass over the nodes: a frozen node receives its fresh id and its place
-// behind the sorted prefix; an active node is verified against its class representative
+// behind the listed prefix; a carried (isolated) node keeps its class -- ids ra .. ra + n_car_classes
+// - 1, listed right behind the sorted active nodes in carried-list order; an active node is verified
+// against its class representative.  perm = [sorted active | carried | frozen].
 __global__ void frozen_assign_verify_kernel(const u32* __restrict__ fidx, const u32* __restrict__ ra_dev,
                                             i32* __restrict__ lab, i32* __restrict__ perm,
                                             u32* __restrict__ count_out, u32 n_active, i64 n,
-                                            const u32* __restrict__ /*act*/, const i32* __restrict__ row_ptr,
+                                            u32 n_car, u32 n_car_classes, const i32* __restrict__ car_class,
+                                            const i32* __restrict__ row_ptr,
                                             const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
                                             const i32* __restrict__ rep, u32* __restrict__ unresolved) {
     const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 ra = *ra_dev;
-    if (v == 0) *count_out = ra + (u32)(n - n_active);
+    if (v == 0) *count_out = ra + n_car_classes + (u32)(n - n_active - n_car);
     if (v >= n) return;
     const u32 f = fidx[v];
     if (f != 0xffffffffu) {
-        lab[v] = (i32)(ra + f);
-        perm[n_active + f] = (i32)v;
+        if (f & 0x80000000u) {
+            const u32 slot = f & 0x7fffffffu;
+            lab[v] = (i32)(ra + (u32)car_class[slot]);
+            perm[n_active + slot] = (i32)v;
+        } else {
+            lab[v] = (i32)(ra + n_car_classes + f);
+            perm[n_active + n_car + f] = (i32)v;
+        }
         return;
     }
     const i32 r = rep[lab[v]];
@@ -317,7 +331,7 @@ __global__ void node_graph_kernel(const i32* __restrict__ graph_ptr, i32* __rest
 // hammering one counter -- even just reading it -- serialise on a single L2 channel
 __global__ __launch_bounds__(256) void batch_stats_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr,
                                    i64 n_graphs, i64 n_nodes, u32* __restrict__ big_flag,
-                                   i32* __restrict__ part) {
+                                   u32* __restrict__ iso_flag, i32* __restrict__ part) {
     __shared__ int sg[4], sd[4];
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     int gn = 0, d = 0;
@@ -325,6 +339,7 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const i32* __restrict_
     if (i < n_nodes) {
         d = row_ptr[i + 1] - row_ptr[i];
         big_flag[i] = d > WL_DEG_SMALL ? 1u : 0u;
+        iso_flag[i] = d == 0 ? 1u : 0u;
     }
     for (int off = 32; off > 0; off >>= 1) {
         int o = __shfl_down(gn, off, 64); gn = o > gn ? o : gn;
@@ -365,7 +380,36 @@ __global__ void compact_big_kernel(const u32* __restrict__ big_flag, const u32* 
     if (i < n && big_flag[i]) big_nodes[excl[i]] = (i32)i;
 }
 
+// isolated vertices: sort key = input label, list of the vertices; everybody else learns how many
+// isolated vertices precede it
+__global__ void iso_keys_kernel(const u32* __restrict__ iso_flag, const u32* __restrict__ iso_excl,
+                                const i32* __restrict__ labels0, u64* __restrict__ keys,
+                                i32* __restrict__ iso_nodes, i32* __restrict__ iso_info, i64 n) {
+    const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const u32 before = iso_excl[v];
+    if (iso_flag[v]) {
+        keys[before] = (u64)(u32)labels0[v];
+        iso_nodes[before] = (i32)v;
+    } else {
+        iso_info[v] = (i32)before;
+    }
+}
+
+// carried list = isolated vertices grouped by input label (stable: ascending vertex inside a group)
+__global__ void iso_slots_kernel(const i32* __restrict__ order, const i32* __restrict__ cls,
+                                 const i32* __restrict__ iso_nodes, i32* __restrict__ iso_info,
+                                 i32* __restrict__ car_class, i64 n_iso) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_iso) return;
+    const i32 item = order[k];
+    iso_info[iso_nodes[item]] = -1 - (i32)k;
+    car_class[k] = cls[item];
+}
+
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
+static int bits_for(u64 max_value);
+int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm, u32* count_dev);
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -376,18 +420,43 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
     const i64 n_graphs = b->n_graphs, n_nodes = b->n_nodes;
     if (n_nodes > 0)
         node_graph_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->node_graph, n_graphs, n_nodes);
-    Tmp<u32> flag(ctx), excl(ctx), total(ctx);
+    Tmp<u32> flag(ctx), excl(ctx), total(ctx), iso_flag(ctx), iso_excl(ctx);
     Tmp<i32> stats(ctx), part(ctx);
     const i64 m = n_graphs > n_nodes ? n_graphs : n_nodes;
     const int nblk = (int)cdiv(m > 0 ? m : 1, 256);
     GK_TRY(flag.alloc(n_nodes)); GK_TRY(excl.alloc(n_nodes)); GK_TRY(total.alloc(1));
-    GK_TRY(stats.alloc(3)); GK_TRY(part.alloc(2 * (size_t)nblk));
-    batch_stats_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, n_graphs, n_nodes, flag.p, part.p);
+    GK_TRY(iso_flag.alloc(n_nodes)); GK_TRY(iso_excl.alloc(n_nodes));
+    GK_TRY(stats.alloc(5)); GK_TRY(part.alloc(2 * (size_t)nblk));
+    batch_stats_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, n_graphs, n_nodes, flag.p,
+                                                             iso_flag.p, part.p);
     batch_stats_reduce_kernel<<<1, 1024, 0, ctx->stream>>>(part.p, nblk, stats.p);
     GK_TRY(gk_scan_u32(ctx, flag.p, excl.p, n_nodes, true, (u32*)stats.p + 2));
-    u32 h[3] = {0, 0, 0};
-    GK_TRY(gk_readback(ctx, (const u32*)stats.p, h, 3));
+    GK_TRY(gk_scan_u32(ctx, iso_flag.p, iso_excl.p, n_nodes, true, (u32*)stats.p + 3));
+    u32 h[4] = {0, 0, 0, 0};
+    GK_TRY(gk_readback(ctx, (const u32*)stats.p, h, 4));
     b->max_graph_nodes = (i32)h[0], b->max_degree = (i32)h[1], b->n_big = h[2];
+    b->n_iso = 0, b->n_iso_classes = 0;
+    if (h[3] > 0 && !getenv("GK_WL_NO_ISO")) {
+        // the carried list of the isolated vertices (see gk_batch::iso_info)
+        const i64 n_iso = h[3];
+        void* q = nullptr;
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)n_nodes * 4));
+        b->iso_info = (i32*)q;
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)n_iso * 4));
+        b->car_class = (i32*)q;
+        Tmp<u64> keys(ctx);
+        Tmp<i32> iso_nodes(ctx), cls(ctx), order(ctx);
+        GK_TRY(keys.alloc(n_iso)); GK_TRY(iso_nodes.alloc(n_iso)); GK_TRY(cls.alloc(n_iso)); GK_TRY(order.alloc(n_iso));
+        iso_keys_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(iso_flag.p, iso_excl.p, b->labels, keys.p,
+                                                                          iso_nodes.p, b->iso_info, n_nodes);
+        GK_TRY(gk_dictionary_from_keys(ctx, keys.p, n_iso, bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0),
+                                       cls.p, order.p, (u32*)stats.p + 4));
+        iso_slots_kernel<<<grid_for(n_iso, 256), 256, 0, ctx->stream>>>(order.p, cls.p, iso_nodes.p, b->iso_info,
+                                                                         b->car_class, n_iso);
+        u32 n_cls = 0;
+        GK_TRY(gk_readback(ctx, (const u32*)stats.p + 4, &n_cls, 1));
+        b->n_iso = n_iso, b->n_iso_classes = n_cls;
+    }
     {
         void* q = nullptr;
         GK_TRY(gk_dev_alloc(ctx, &q, (size_t)(b->n_big > 0 ? b->n_big : 1) * 4));
@@ -536,7 +605,7 @@ extern "C" int gk_batch_destroy(gk_batch* b) {
     if (!b) return GK_OK;
     gk_ctx* ctx = b->ctx;
     void* ptrs[] = {b->graph_ptr, b->row_ptr, b->col_idx, b->node_graph, b->big_nodes,
-                    b->labels, b->perm, b->nbr_sorted};
+                    b->labels, b->perm, b->nbr_sorted, b->iso_info, b->car_class};
     for (void* p : ptrs)
         if (p) gk_dev_free(ctx, p);
     delete b;
@@ -644,6 +713,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     i32* cur = b->labels + (size_t)level * V;
     i32* perm = b->perm + (size_t)level * V;
     if (V == 0) return GK_OK;
+    const i64 n_car = b->iso_info ? b->n_iso : 0;      // isolated vertices: carried along, never active
     // ---- how many nodes still sit in classes of size >= 2 ? (one 4-byte read-back per level)
     u32 n_act = (u32)V;
     // level 1 always takes the full path: a singleton class among the INPUT labels is rare, treating
@@ -651,7 +721,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     // launches and a read-back; the sort probes its buckets instead of using the previous level's bound
     if (!exact && !getenv("GK_WL_NO_ACTIVE_SET") && level >= 2) {
         const u32 seq = gk_mbox_begin(ctx);
-        ActiveScan as{st.frozen.p, st.act.p, st.fidx.p, st.scratch.p + 1, st.scratch.p + 2, seq ? ctx->mbox_dev : nullptr, seq};
+        ActiveScan as{st.frozen.p, st.act.p, st.fidx.p, st.scratch.p + 1, st.scratch.p + 2, seq ? ctx->mbox_dev : nullptr, seq,
+                      n_car > 0 ? b->iso_info : nullptr};
         GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, nullptr)));
         u32 back[2] = {0, 0};
         if (seq) GK_TRY(gk_mbox_wait(ctx, seq, back, 2));
@@ -664,7 +735,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     }
     const u64 full_mask = hash_bits >= 64 ? ~0ull : ((1ull << hash_bits) - 1ull);
     b->n_sorted[level] = V;
-    if (n_act == 0) {
+    if (n_act == 0 && n_car == 0) {
         // every class is a singleton: the partition cannot change any more
         b->n_sorted[level] = 0;
         GK_HIP_CHECK(hipMemcpyAsync(cur, prev, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -673,8 +744,9 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         return GK_OK;
     }
     if (!exact && (u64)n_act * 4 <= (u64)V) {
-        // ---- active-set path: only the n_act active nodes are hashed, sorted and verified
-        b->n_sorted[level] = n_act;
+        // ---- active-set path: only the n_act active nodes are hashed, sorted and verified; the
+        // carried classes of the isolated vertices are listed behind them
+        b->n_sorted[level] = (i64)n_act + n_car;
         int bits = hash_bits;
         if (hash_bits >= 32) {   // default sizing rule applied to the active set (tests may force fewer bits)
             int lg = bits_for((u64)(n_act > 1 ? n_act - 1 : 1));
@@ -699,8 +771,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                                     sort_buckets_ok(st.prev_top_max, n_act, exact), st.scratch.p + 2));
         // *unresolved_dev is still zero here: gk_wl_relabel cleared it and this path runs once per level
         frozen_assign_verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(
-            st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V, st.act.p, b->row_ptr, prev, b->nbr_sorted, rep.p,
-            unresolved_dev);
+            st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V, (u32)n_car, (u32)b->n_iso_classes, b->car_class,
+            b->row_ptr, prev, b->nbr_sorted, rep.p, unresolved_dev);
         GK_HIP_CHECK(hipGetLastError());
         return GK_OK;
     }
