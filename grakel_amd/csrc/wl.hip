@@ -249,6 +249,42 @@ __global__ void wl_signature_list_kernel(const u32* __restrict__ act, i64 n_act,
     hash_out[j] = mix64(acc) & mask;
 }
 
+// Few labels and small degrees (level 1 of a job with a handful of input labels): the signature
+// (own label, multiset of neighbour labels) has an EXACT integer code
+//     own * R^L + sum over neighbours of R^label,   R = max degree + 1, L = number of labels
+// (the sum is the mixed-radix number of the label counts: no digit reaches R, so no carries).
+// When L * R^L < 2^32 the code, scrambled by a bijection of the 32-bit integers so that the sort's
+// top digit stays balanced, replaces the 48-bit hash: 4 digit passes instead of 6, no sorted
+// neighbour lists, and nothing to verify -- equal keys ARE equal signatures.
+__global__ __launch_bounds__(256) void wl_signature_exact_kernel(
+    const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+    u64* __restrict__ hash, i64 n, int L, u64 R, u32* __restrict__ unresolved) {
+    __shared__ u64 pw[20];
+    if ((int)threadIdx.x <= L) {
+        u64 p = 1;
+        for (int i = 0; i < (int)threadIdx.x; ++i) p *= R;
+        pw[threadIdx.x] = p;
+    }
+    __syncthreads();
+    const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const i32 s = row_ptr[v], e = row_ptr[v + 1];
+    const u32 own = (u32)lab_prev[v];
+    bool in_range = own < (u32)L;
+    u64 key = (u64)own * pw[L];
+    for (i32 k = s; k < e; ++k) {
+        const u32 l = (u32)lab_prev[col_idx[k]];
+        in_range = in_range && l < (u32)L;
+        key += pw[l < (u32)L ? l : 0];
+    }
+    if (!in_range) atomicAdd(unresolved, 1u);      // ids beyond the declared label count: redo with hashes
+    u32 x = (u32)key;                    // bijective scramble (every step is invertible mod 2^32)
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    hash[v] = (u64)x;
+}
+
 // hubs write their hash indexed by node: move it to the active-list slot
 __global__ void gather_big_hash_kernel(const u32* __restrict__ act, i64 n_act, const i32* __restrict__ row_ptr,
                                        const u64* __restrict__ hash_node, u64* __restrict__ hash_out) {
@@ -701,6 +737,7 @@ static int sort_buckets_ok(u32 prev_top_max, i64 n, bool exact) {
 
 struct RelabelState {
     u32 prev_top_max = 0;                  // largest top-digit bucket of the previous level's sort
+    bool default_bits = true;              // the caller did not force a hash width (tests do, to provoke collisions)
     Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active, [2] = top-digit max
     i64 n_frozen_levels = 0;
     explicit RelabelState(gk_ctx* c) : frozen(c), act(c), fidx(c), scratch(c) {}
@@ -780,7 +817,23 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     Tmp<u64> hash(ctx), keys(ctx);
     Tmp<i32> rep(ctx);
     GK_TRY(hash.alloc(V)); GK_TRY(rep.alloc(V));
+    // level 1 of a job with few input labels: exact 32-bit signature codes (wl_signature_exact_kernel)
+    bool exact_code = false;
+    u64 code_R = (u64)b->max_degree + 1;
+    if (level == 1 && !exact && st.default_bits && b->n_labels0 >= 1 && b->n_labels0 <= 16 && !getenv("GK_WL_NO_EXACT1")) {
+        double span = (double)b->n_labels0;
+        for (int i = 0; i < b->n_labels0; ++i) span *= (double)code_R;
+        exact_code = span < 4294967296.0;
+    }
     for (int round = 0;; ++round) {
+        if (exact_code) {
+            wl_signature_exact_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, b->col_idx, prev, hash.p, V,
+                                                                                 (int)b->n_labels0, code_R, unresolved_dev);
+            GK_TRY(dictionary_from_keys(ctx, hash.p, V, 32, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
+                                        sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2));
+            GK_HIP_CHECK(hipGetLastError());
+            break;
+        }
         GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), full_mask));
         int bits = hash_bits;
         const u64* sort_keys = hash.p;           // round 0: the sort reads the hashes in place
@@ -814,6 +867,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     GK_ARG(ctx && b, "gk_wl_relabel: null ctx/batch");
     GK_ARG(!b->is_pair_batch, "gk_wl_relabel: pair batches have no adjacency");
     GK_ARG(n_iter >= 0 && n_iter < 4096, "gk_wl_relabel: bad n_iter");
+    const bool default_bits = hash_bits <= 0 || hash_bits > 64;
     if (hash_bits <= 0 || hash_bits > 64) {
         // default: 2*log2(V) + 8 bits (multiple of the 8-bit radix digit, at least 32): a colliding
         // pair then shows up in ~1/256 of the levels and is resolved exactly by the refine loop
@@ -833,6 +887,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     if (out_rounds) *out_rounds = 0;
     b->n_sorted.assign((size_t)n_levels, V);
     RelabelState st(ctx);
+    st.default_bits = default_bits;
     GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
     // level 0: group nodes by the given label ids
     {

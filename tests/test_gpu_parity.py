@@ -107,6 +107,57 @@ def test_wl_label_partitions_match_oracle(gk, name):
         assert same_partition(eng.wl_labels(db, lvl), levels[lvl]), "level %d" % lvl
 
 
+def _graphs_with_isolated_vertices(kind, seed):
+    """Graphs whose connected part freezes quickly while many isolated vertices keep sharing labels:
+    the active-set levels then carry the isolated classes (gk_batch::iso_info) instead of sorting them."""
+    rs = np.random.RandomState(seed)
+    X = []
+    for g in range(60):
+        if kind == "paths":            # a path with pairwise distinct labels: every class is a singleton at once
+            m = int(rs.randint(3, 9))
+            ed = {i: [j for j in (i - 1, i + 1) if 0 <= j < m] for i in range(m)}
+            lab = {i: 100 * g + i for i in range(m)}
+        else:                          # a small random connected-ish part with few labels (classes keep splitting)
+            m = int(rs.randint(4, 10))
+            ed = {i: [] for i in range(m)}
+            for i in range(1, m):
+                j = int(rs.randint(0, i))
+                ed[i].append(j), ed[j].append(i)
+            lab = {i: int(rs.randint(0, 2)) for i in range(m)}
+        for q in range(int(rs.randint(15, 40))):      # isolated vertices: 3 shared labels + a few unique ones
+            v = m + q
+            ed[v] = []
+            lab[v] = int(rs.randint(0, 3)) if rs.rand() < 0.9 else 10 ** 6 + 1000 * g + q
+        X.append([ed, lab])
+    return X
+
+
+@pytest.mark.parametrize("kind", ["paths", "trees"])
+def test_isolated_vertices_are_carried_through_active_set_levels(gk, kind):
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    X = _graphs_with_isolated_vertices(kind, 3)
+    wl, K, levels = _oracle_levels(X, 5)
+    gb, _ = wl_batch_from_input(X)
+    assert int((np.diff(gb.row_ptr) == 0).sum()) * 4 > 3 * gb.n_nodes      # mostly isolated: the active path runs
+    eng = get_engine()
+    db = eng.upload(gb)
+    counts = eng.wl_relabel(db, 5)
+    assert counts == wl.label_counts
+    for lvl in range(6):
+        assert same_partition(eng.wl_labels(db, lvl), levels[lvl]), "level %d" % lvl
+    feat = eng.features(db, 6)
+    assert np.array_equal(eng.gram(feat), K)
+    est = gk.WeisfeilerLehman(n_iter=5, normalize=True)
+    Kn = est.fit_transform(X)
+    Kref = O.WLOracle(n_iter=5, normalize=True)
+    assert np.allclose(Kn, Kref.fit_transform(X), rtol=REL_TOL, atol=0)
+    Y = _graphs_with_isolated_vertices(kind, 4)[:17]
+    assert np.allclose(est.transform(Y), Kref.transform(Y), rtol=REL_TOL, atol=0)
+    oa = gk.WeisfeilerLehmanOptimalAssignment(n_iter=4)
+    assert np.array_equal(oa.fit_transform(X), O.WLOAOracle(n_iter=4).fit_transform(X))
+
+
 @pytest.mark.parametrize("bits", [3, 6, 10])
 def test_forced_hash_collisions_are_resolved_exactly(gk, bits):
     """Truncated hashes collide massively; the verify + refine loop must still be exact."""
