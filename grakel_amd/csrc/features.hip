@@ -442,9 +442,9 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
                                                                           n_unlisted);
         // one host sync: sizes of the dense operand
         if ((r = gk_readback(ctx, f->meta, h.data(), (int)n_meta))) return fail(r);
-    } else if (V > 0) {      // every level unlisted (cannot happen: level 0 always lists all nodes)
-        gk_set_error("gk_features_build: no level lists any node");
-        return fail(GK_ERR_STATE);
+    } else if (V > 0) {      // no two nodes share a label at any level: K is its diagonal, n_levels per node
+        feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, nullptr, V, 0, f->selfk, N,
+                                                                          n_unlisted);
     }
     const int G = 3 * n_levels;
     f->nnz = 0;

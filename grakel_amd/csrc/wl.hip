@@ -197,6 +197,43 @@ struct HeadAssign {
     __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
 
+// The same for a level that sorts EVERY node, with the label-grouped order split on the way: nodes
+// of classes with two or more members first (still grouped by label, ascending node inside a group),
+// the singletons behind them from the end.  Only the first *ns_out positions can share a label, so
+// the label-count features of the level (features.hip) read those and nothing else -- at the
+// third level of a 1 M-node job that is 5 % of the nodes.  Packed scan: heads low, listed nodes high.
+struct HeadAssignSplit {
+    const u64* ks;       // sorted keys
+    const u32* sorted;   // node at each sorted position
+    i32* lab; i32* rep; u32* frozen;
+    i32* perm_out;       // out: [nodes of shared classes | singletons]
+    u32* ns_out;         // out: number of nodes of shared classes
+    u32* count_out;      // out: number of classes
+    i64 n;
+    __device__ __forceinline__ bool head(i64 k) const { return k == 0 || ks[k] != ks[k - 1]; }
+    __device__ __forceinline__ u64 value(i64 k) const {
+        const bool h = head(k);
+        const bool single = h && (k == n - 1 || ks[k + 1] != ks[k]);
+        return (u64)(h ? 1u : 0u) | ((u64)(single ? 0u : 1u) << 32);
+    }
+    __device__ __forceinline__ void emit(i64 k, u64 val, u64 incl) const {
+        const u32 v = sorted[k];
+        const bool h = (val & 1ull) != 0, single = (val >> 32) == 0;
+        const i32 r = (i32)(u32)(incl & 0xffffffffull) - 1;
+        const i64 listed = (i64)(incl >> 32);            // listed nodes up to and including k
+        lab[v] = r;
+        if (h) rep[r] = (i32)v;
+        if (frozen) frozen[v] = single ? 1u : 0u;
+        if (single) perm_out[n - 1 - (k - listed)] = (i32)v;
+        else perm_out[listed - 1] = (i32)v;
+    }
+    __device__ __forceinline__ void finish(u64 total) const {
+        *ns_out = (u32)(total >> 32);
+        *count_out = (u32)(total & 0xffffffffull);
+    }
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
+};
+
 // A node whose class is a singleton stays a singleton at every later level (classes only
 // split), so it needs no signature, no sort and no verification any more: it just receives a
 // fresh id.  ActiveScan compacts the still-active nodes (ascending) and numbers the frozen.
@@ -700,18 +737,30 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
 // (may be null) and the number of groups to *count_dev.
 // vals == nullptr: the items are 0..n-1; otherwise vals[] (ascending node ids) are the items and
 // lab/rep/frozen are indexed by item id, perm receives item ids.
+// listed_dev (device, may be null; needs vals == nullptr): perm receives the split order of
+// HeadAssignSplit and *listed_dev the number of nodes in classes of two or more.
 static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
                                 i32* rep, u32* count_dev, const u32* vals = nullptr, u32* frozen = nullptr,
-                                i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr) {
+                                i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr,
+                                u32* listed_dev = nullptr) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
+        if (listed_dev) GK_TRY(gk_zero_async(ctx, listed_dev, 4));
         return GK_OK;
     }
     Tmp<u64> ks(ctx);
     GK_TRY(ks.alloc(n));
-    GK_TRY(gk_radix_sort_pairs(ctx, keys, vals, ks.p, (u32*)perm, n, key_bits, use_buckets, top_digit_max));
     Tmp<i32> rep_tmp(ctx);
     if (!rep) { GK_TRY(rep_tmp.alloc(rep_capacity > n ? rep_capacity : n)); rep = rep_tmp.p; }
+    if (listed_dev && !vals) {
+        Tmp<u32> sorted(ctx);
+        GK_TRY(sorted.alloc(n));
+        GK_TRY(gk_radix_sort_pairs(ctx, keys, vals, ks.p, sorted.p, n, key_bits, use_buckets, top_digit_max));
+        HeadAssignSplit ha{ks.p, sorted.p, lab, rep, frozen, perm, listed_dev, count_dev, n};
+        GK_TRY((gk_scan_fn<u64, HeadAssignSplit>(ctx, ha, n, nullptr)));
+        return GK_OK;
+    }
+    GK_TRY(gk_radix_sort_pairs(ctx, keys, vals, ks.p, (u32*)perm, n, key_bits, use_buckets, top_digit_max));
     HeadAssign ha{ks.p, (const u32*)perm, lab, rep, frozen, n};
     GK_TRY((gk_scan_fn<u32, HeadAssign>(ctx, ha, n, count_dev)));
     return GK_OK;
@@ -738,13 +787,15 @@ static int sort_buckets_ok(u32 prev_top_max, i64 n, bool exact) {
 struct RelabelState {
     u32 prev_top_max = 0;                  // largest top-digit bucket of the previous level's sort
     bool default_bits = true;              // the caller did not force a hash width (tests do, to provoke collisions)
+    std::vector<char> full_level;          // levels that sorted every node (their perm is split: shared classes first)
+    bool split = true;                     // GK_WL_NO_SPLIT: keep the plain label-grouped order
     Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active, [2] = top-digit max
     i64 n_frozen_levels = 0;
     explicit RelabelState(gk_ctx* c) : frozen(c), act(c), fidx(c), scratch(c) {}
 };
 
 static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, bool exact, RelabelState& st,
-                         u32* count_dev, u32* unresolved_dev, int* rounds) {
+                         u32* count_dev, u32* unresolved_dev, u32* listed_dev, int* rounds) {
     const i64 V = b->n_nodes;
     const i32* prev = b->labels + (size_t)(level - 1) * V;
     i32* cur = b->labels + (size_t)level * V;
@@ -814,6 +865,9 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         return GK_OK;
     }
     // ---- full path
+    if (!st.split) listed_dev = nullptr;
+    st.full_level[level] = listed_dev ? 1 : 0;
+    b->n_sorted[level] = V;
     Tmp<u64> hash(ctx), keys(ctx);
     Tmp<i32> rep(ctx);
     GK_TRY(hash.alloc(V)); GK_TRY(rep.alloc(V));
@@ -830,7 +884,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             wl_signature_exact_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, b->col_idx, prev, hash.p, V,
                                                                                  (int)b->n_labels0, code_R, unresolved_dev);
             GK_TRY(dictionary_from_keys(ctx, hash.p, V, 32, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
-                                        sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2));
+                                        sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2, listed_dev));
             GK_HIP_CHECK(hipGetLastError());
             break;
         }
@@ -843,7 +897,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             bits = 64, sort_keys = keys.p;
         }
         GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
-                                    round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2));
+                                    round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev));
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
@@ -881,13 +935,15 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     const int n_levels = n_iter + 1;
     const i64 V = b->n_nodes;
     GK_TRY(gk_batch_ensure_levels(b, n_levels));
-    Tmp<u32> meta(ctx);   // [n_levels] counts, [n_levels] unresolved
-    GK_TRY(meta.alloc(2 * (size_t)n_levels));
-    GK_TRY(gk_zero_async(ctx, meta.p, 8 * (size_t)n_levels));
+    Tmp<u32> meta(ctx);   // [n_levels] counts, [n_levels] unresolved, [n_levels] nodes of shared classes (full levels)
+    GK_TRY(meta.alloc(3 * (size_t)n_levels));
+    GK_TRY(gk_zero_async(ctx, meta.p, 12 * (size_t)n_levels));
     if (out_rounds) *out_rounds = 0;
     b->n_sorted.assign((size_t)n_levels, V);
     RelabelState st(ctx);
     st.default_bits = default_bits;
+    st.split = getenv("GK_WL_NO_SPLIT") == nullptr;
+    st.full_level.assign((size_t)n_levels, 0);
     GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
     // level 0: group nodes by the given label ids
     {
@@ -896,24 +952,29 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         GK_TRY(keys.alloc(V)); GK_TRY(lab_tmp.alloc(V));
         if (V > 0) labels_to_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels, keys.p, V);
         int bits = bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0);
+        st.full_level[0] = st.split ? 1 : 0;
         GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p, 0,
-                                    0, st.scratch.p + 2));
+                                    0, st.scratch.p + 2, st.split ? meta.p + 2 * n_levels : nullptr));
     }
-    std::vector<u32> h(2 * (size_t)n_levels);
+    std::vector<u32> h(3 * (size_t)n_levels);
     int first_bad = -1;
     for (int lvl = 1; lvl < n_levels; ++lvl)
-        GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, st, meta.p + lvl, meta.p + n_levels + lvl, nullptr));
-    GK_TRY(gk_readback(ctx, meta.p, h.data(), 2 * n_levels));
+        GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, st, meta.p + lvl, meta.p + n_levels + lvl,
+                             meta.p + 2 * n_levels + lvl, nullptr));
+    GK_TRY(gk_readback(ctx, meta.p, h.data(), 3 * n_levels));
     for (int lvl = 1; lvl < n_levels; ++lvl)
         if (h[n_levels + lvl] != 0) { first_bad = lvl; break; }
     if (first_bad > 0) {   // a hash collision was detected: redo from that level, exactly
         for (int lvl = first_bad; lvl < n_levels; ++lvl)
-            GK_TRY(relabel_level(ctx, b, lvl, hash_bits, true, st, meta.p + lvl, meta.p + n_levels + lvl, out_rounds));
-        GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 8 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
+            GK_TRY(relabel_level(ctx, b, lvl, hash_bits, true, st, meta.p + lvl, meta.p + n_levels + lvl,
+                                 meta.p + 2 * n_levels + lvl, out_rounds));
+        GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 12 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     b->n_levels = n_levels;
     b->label_counts.resize(n_levels);
+    for (int lvl = 0; lvl < n_levels && V > 0; ++lvl)       // full levels only list the nodes of shared classes
+        if (st.full_level[lvl]) b->n_sorted[lvl] = h[2 * n_levels + lvl];
     for (int lvl = 0; lvl < n_levels; ++lvl) {
         b->label_counts[lvl] = h[lvl];
         if (out_label_counts) out_label_counts[lvl] = h[lvl];
