@@ -210,6 +210,8 @@ struct HeadAssignSplit {
     u32* ns_out;         // out: number of nodes of shared classes
     u32* count_out;      // out: number of classes
     i64 n;
+    u32* mbox; u32 seq;  // host mailbox (may be null): the host learns {listed nodes, *extra} without a scan of its own
+    const u32* extra;    // largest top-digit bucket of the sort that produced ks
     __device__ __forceinline__ bool head(i64 k) const { return k == 0 || ks[k] != ks[k - 1]; }
     __device__ __forceinline__ u64 value(i64 k) const {
         const bool h = head(k);
@@ -230,6 +232,12 @@ struct HeadAssignSplit {
     __device__ __forceinline__ void finish(u64 total) const {
         *ns_out = (u32)(total >> 32);
         *count_out = (u32)(total & 0xffffffffull);
+        if (mbox) {
+            __hip_atomic_store(&mbox[1], (u32)(total >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mbox[2], extra ? *extra : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
@@ -742,7 +750,7 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
 static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
                                 i32* rep, u32* count_dev, const u32* vals = nullptr, u32* frozen = nullptr,
                                 i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr,
-                                u32* listed_dev = nullptr) {
+                                u32* listed_dev = nullptr, u32* posted_seq = nullptr) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         if (listed_dev) GK_TRY(gk_zero_async(ctx, listed_dev, 4));
@@ -756,7 +764,12 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
         Tmp<u32> sorted(ctx);
         GK_TRY(sorted.alloc(n));
         GK_TRY(gk_radix_sort_pairs(ctx, keys, vals, ks.p, sorted.p, n, key_bits, use_buckets, top_digit_max));
-        HeadAssignSplit ha{ks.p, sorted.p, lab, rep, frozen, perm, listed_dev, count_dev, n};
+        // posted_seq (may be null): the finish hook also posts {listed nodes, largest top-digit bucket}
+        // to the host mailbox; *posted_seq receives the sequence number to wait for (0: not posted)
+        const u32 seq = posted_seq ? gk_mbox_begin(ctx) : 0u;
+        if (posted_seq) *posted_seq = seq;
+        HeadAssignSplit ha{ks.p, sorted.p, lab, rep, frozen, perm, listed_dev, count_dev, n,
+                           seq ? ctx->mbox_dev : nullptr, seq, top_digit_max};
         GK_TRY((gk_scan_fn<u64, HeadAssignSplit>(ctx, ha, n, nullptr)));
         return GK_OK;
     }
@@ -789,6 +802,7 @@ struct RelabelState {
     bool default_bits = true;              // the caller did not force a hash width (tests do, to provoke collisions)
     std::vector<char> full_level;          // levels that sorted every node (their perm is split: shared classes first)
     bool split = true;                     // GK_WL_NO_SPLIT: keep the plain label-grouped order
+    u32 posted_seq = 0;                    // mailbox message {listed nodes, top-digit max} of the previous (full) level
     Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active, [2] = top-digit max
     i64 n_frozen_levels = 0;
     explicit RelabelState(gk_ctx* c) : frozen(c), act(c), fidx(c), scratch(c) {}
@@ -807,7 +821,20 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     // level 1 always takes the full path: a singleton class among the INPUT labels is rare, treating
     // it as active is still correct (freezing is an optimisation), and skipping the scan saves two
     // launches and a read-back; the sort probes its buckets instead of using the previous level's bound
-    if (!exact && !getenv("GK_WL_NO_ACTIVE_SET") && level >= 2) {
+    bool decided = false;
+    if (!exact && st.posted_seq && level >= 2) {
+        // the previous level sorted every node and told the host how many nodes sit in shared classes:
+        // when even without the isolated ones they are more than a quarter of the batch this level takes
+        // the full path again, and the active-set scan (two launches over all nodes) is not needed
+        u32 back[2] = {0, 0};
+        GK_TRY(gk_mbox_wait(ctx, st.posted_seq, back, 2));
+        if (((i64)back[0] - n_car) * 4 > V && !getenv("GK_WL_NO_ACTIVE_SET")) {
+            n_act = back[0], st.prev_top_max = back[1], decided = true;
+        }
+    }
+    st.posted_seq = 0;
+    if (decided) {
+    } else if (!exact && !getenv("GK_WL_NO_ACTIVE_SET") && level >= 2) {
         const u32 seq = gk_mbox_begin(ctx);
         ActiveScan as{st.frozen.p, st.act.p, st.fidx.p, st.scratch.p + 1, st.scratch.p + 2, seq ? ctx->mbox_dev : nullptr, seq,
                       n_car > 0 ? b->iso_info : nullptr};
@@ -884,7 +911,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             wl_signature_exact_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, b->col_idx, prev, hash.p, V,
                                                                                  (int)b->n_labels0, code_R, unresolved_dev);
             GK_TRY(dictionary_from_keys(ctx, hash.p, V, 32, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
-                                        sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2, listed_dev));
+                                        sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2, listed_dev,
+                                        listed_dev ? &st.posted_seq : nullptr));
             GK_HIP_CHECK(hipGetLastError());
             break;
         }
@@ -897,7 +925,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             bits = 64, sort_keys = keys.p;
         }
         GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
-                                    round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev));
+                                    round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev,
+                                    (listed_dev && !exact) ? &st.posted_seq : nullptr));
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
