@@ -247,14 +247,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool mirror = tri && bm != bn;     // off-diagonal tile of a symmetric job: also write K^T
     const bool even = (N & 1) == 0;
+    // The transposed copy of a 128x128 tile goes through LDS (the operand ring is free after the last
+    // K-step): the int32 accumulators are written column-major with a 4-word pad per column
+    // (conflict-free 16-byte writes), then every wave streams whole columns back -- 128 consecutive
+    // K^T entries, 1 KiB of float64 per store instruction -- instead of 16-byte pieces scattered over
+    // 32 rows.  Plain counts only (normalised epilogues keep the register path).
+    constexpr bool LDS_MIRROR = (BM == 128 && BN == 128);
+    constexpr int LDT = BM + 4;
+    const bool lds_mirror = LDS_MIRROR && mirror && normalize == 0 && even;
+    int* tsm = (int*)smem;
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
-            const i64 col = (i64)bn * BN + (wn * TN + nt) * 32 + (lane & 31);
+            const int ctile = (wn * TN + nt) * 32 + (lane & 31);
+            const i64 col = (i64)bn * BN + ctile;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const i64 row0 = (i64)bm * BM + (wm * TM + mt) * 32 + 8 * q + 4 * (lane >> 5);
+                const int rtile = (wm * TM + mt) * 32 + 8 * q + 4 * (lane >> 5);
+                const i64 row0 = (i64)bm * BM + rtile;
                 double v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -266,7 +277,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
                         K[row * N + col] = v[j];           // 32 lanes -> 256 contiguous bytes
                     }
                 }
-                if (mirror && col < N) {                    // K[col][row0..row0+3]: 32 B per lane
+                if (lds_mirror) {
+                    v4i t;
+                    t[0] = acc[mt][nt][4 * q], t[1] = acc[mt][nt][4 * q + 1];
+                    t[2] = acc[mt][nt][4 * q + 2], t[3] = acc[mt][nt][4 * q + 3];
+                    *(v4i*)(tsm + ctile * LDT + rtile) = t;
+                } else if (mirror && col < N) {             // K[col][row0..row0+3]: 32 B per lane
                     double* dst = K + col * N + row0;
                     if (even && row0 + 3 < M) {
                         *(double2*)(dst) = make_double2(v[0], v[1]);
@@ -279,13 +295,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
                 }
             }
         }
+    if (LDS_MIRROR && lds_mirror) {          // block-uniform
+        __syncthreads();
+        const i64 r = (i64)bm * BM + 2 * lane;              // two consecutive entries of K^T's row per lane
+        for (int c = wave; c < BN; c += NW) {
+            const i64 krow = (i64)bn * BN + c;
+            if (krow >= N) break;
+            const int2 t = *(const int2*)(tsm + c * LDT + 2 * lane);
+            double* dst = K + krow * N + r;
+            if (r + 1 < M) *(double2*)dst = make_double2((double)t.x, (double)t.y);
+            else if (r < M) dst[0] = (double)t.x;
+        }
+    }
 }
 
 template <int WM, int WN, int TM, int TN, int NS>
 static int launch_glds(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
                        i64 row_lo, int normalize, double* K, int tri, int patch, int patch_sz, double* tiles_done) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LDS = NS * (BM + BN) * 64;
+    constexpr int LDS_RING = NS * (BM + BN) * 64;
+    constexpr int LDS_T = (BM == 128 && BN == 128) ? BN * (BM + 4) * 4 : 0;     // transposed tile of the epilogue
+    constexpr int LDS = LDS_RING > LDS_T ? LDS_RING : LDS_T;
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(n_cols, BN);
     const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch ? patch_sz : 0);
     auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
