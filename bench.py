@@ -29,13 +29,33 @@ sys.path.insert(0, ROOT)
 WORKLOAD = dict(N=10000, n=100, p=0.05, L=5, seed=0, n_iter=5)
 I8_DENSE_PEAK_TOPS = 5000.0      # int8 MFMA dense = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6
-# HBM-side bytes per launch of the MFMA Gram kernel on this exact workload (config 3, 4 623 dense
-# columns at the rare-column threshold of 24 -- all but 5 as 4-bit nibbles --, 128x128 tiles), from the
-# PMC passes committed in profiles/r01p_pmc_hbm_bytes.csv
-# (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs): 2 x FETCH_SIZE (gfx950 reports
-# half of a wide coalesced read, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.
+# HBM-side bytes per launch of the MFMA Gram kernel on this exact workload (config 3), from the PMC
+# passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of
+# this script, summarised by tools/pmc_summary.py): 2 x FETCH_SIZE (gfx950 reports half of a wide
+# coalesced read, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.
 # Algorithmic floor: read Phi_s once (24 MB packed) + write the float64 K once (800 MB).
-GRAM_PMC_TRAFFIC_BYTES = {(10000, "i8"): (2 * 175819.625 + 795023.325) * 1024}
+PMC_FILE = os.path.join(ROOT, "profiles", "r01s_pmc_hbm_bytes.csv")
+
+
+def gram_pmc_traffic_bytes(n_graphs, dtype):
+    """Per-launch HBM bytes of the int8 MFMA Gram kernel from the committed PMC summary, or None
+    when the workload is not the profiled one (config 3) or the file is absent."""
+    if n_graphs != WORKLOAD["N"] or dtype != "i8" or not os.path.exists(PMC_FILE):
+        return None
+    fetch = write = None
+    with open(PMC_FILE) as f:
+        for line in f:
+            if "gram_i8_glds_kernel" not in line:
+                continue
+            parts = line.rstrip().rsplit(",", 3)          # "kernel",counter,launches,avg
+            if parts[1] == "FETCH_SIZE":
+                fetch = float(parts[3])
+            elif parts[1] == "WRITE_SIZE":
+                write = float(parts[3])
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
 
 def cpu_baseline(sample_graphs, cfg):
     """The CPU oracle (a literal restatement of the reference's algorithm) on a bounded sample
@@ -183,7 +203,7 @@ def main():
                             "frac_of_8TBps": rb / (phases["relabel"] * 1e-3) / 8e12},
                 "features": {"algorithmic_bytes": fb, "GB_per_s": fb / (phases["features"] * 1e-3) / 1e9,
                              "frac_of_8TBps": fb / (phases["features"] * 1e-3) / 8e12},
-                "note": "about 70 dependent launches of 4-60 us over 1 M-element arrays per step, six device->host "
+                "note": "about 60 dependent launches of 3-60 us over 1 M-element arrays per step, six device->host "
                         "read-backs: launch/latency bound, not bandwidth bound (DESIGN.md 4)"}
         out = {
             "metric": "graph-pairs/sec for NxN WL-subtree(h=%d) fit_transform" % h,
@@ -208,7 +228,8 @@ def main():
                            else "gram_i8_glds_kernel<2,4,4,2,4> (256x256 tile)"),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": GRAM_PMC_TRAFFIC_BYTES.get((N, dtype)) if world == 1 else None,
+                "traffic": gram_pmc_traffic_bytes(N, dtype) if world == 1 else None,
+                "traffic_source": "profiles/r01s_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE, KiB)",
                 "executed_flops_per_launch": flops, "avg_launch_ms": gram_avg_ms,
                 "algorithmic": {
                     # 2*N_rows*N_cols*D_eff with D_eff = label columns occurring in
