@@ -146,10 +146,11 @@ struct gk_batch {
     // label" at every level >= 1 and never splits, so active-set levels carry these classes along
     // instead of hashing and sorting them again (wl.hip).  iso_info[v] >= 0: number of isolated
     // vertices before v; < 0: v is isolated and -1 - iso_info[v] is its slot in the carried list
-    // (grouped by input label, ascending node inside a group); car_class[slot] = dense class id.
+    // (grouped by input label, ascending node inside a group); car_class[slot] = dense class id,
+    // car_class[n_iso] = number of carried classes.
     i32* iso_info = nullptr;    // [n_nodes], null when the batch has no isolated vertex
-    i32* car_class = nullptr;   // [n_iso]
-    i64 n_iso = 0, n_iso_classes = 0;
+    i32* car_class = nullptr;   // [n_iso + 1]
+    i64 n_iso = 0;
     // levels
     int n_levels = 0;                  // levels currently valid (0 = only level-0 labels)
     int cap_levels = 0;

@@ -347,12 +347,14 @@ __global__ void gather_big_hash_kernel(const u32* __restrict__ act, i64 n_act, c
 __global__ void frozen_assign_verify_kernel(const u32* __restrict__ fidx, const u32* __restrict__ ra_dev,
                                             i32* __restrict__ lab, i32* __restrict__ perm,
                                             u32* __restrict__ count_out, u32 n_active, i64 n,
-                                            u32 n_car, u32 n_car_classes, const i32* __restrict__ car_class,
+                                            u32 n_car, const u32* __restrict__ n_car_classes_dev,
+                                            const i32* __restrict__ car_class,
                                             const i32* __restrict__ row_ptr,
                                             const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
                                             const i32* __restrict__ rep, u32* __restrict__ unresolved) {
     const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 ra = *ra_dev;
+    const u32 n_car_classes = n_car ? *n_car_classes_dev : 0u;
     if (v == 0) *count_out = ra + n_car_classes + (u32)(n - n_active - n_car);
     if (v >= n) return;
     const u32 f = fidx[v];
@@ -516,14 +518,14 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
     u32 h[4] = {0, 0, 0, 0};
     GK_TRY(gk_readback(ctx, (const u32*)stats.p, h, 4));
     b->max_graph_nodes = (i32)h[0], b->max_degree = (i32)h[1], b->n_big = h[2];
-    b->n_iso = 0, b->n_iso_classes = 0;
+    b->n_iso = 0;
     if (h[3] > 0 && !getenv("GK_WL_NO_ISO")) {
         // the carried list of the isolated vertices (see gk_batch::iso_info)
         const i64 n_iso = h[3];
         void* q = nullptr;
         GK_TRY(gk_dev_alloc(ctx, &q, (size_t)n_nodes * 4));
         b->iso_info = (i32*)q;
-        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)n_iso * 4));
+        GK_TRY(gk_dev_alloc(ctx, &q, ((size_t)n_iso + 1) * 4));      // [n_iso] class per slot, then the class count
         b->car_class = (i32*)q;
         Tmp<u64> keys(ctx);
         Tmp<i32> iso_nodes(ctx), cls(ctx), order(ctx);
@@ -531,12 +533,10 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
         iso_keys_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(iso_flag.p, iso_excl.p, b->labels, keys.p,
                                                                           iso_nodes.p, b->iso_info, n_nodes);
         GK_TRY(gk_dictionary_from_keys(ctx, keys.p, n_iso, bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0),
-                                       cls.p, order.p, (u32*)stats.p + 4));
+                                       cls.p, order.p, (u32*)b->car_class + n_iso));
         iso_slots_kernel<<<grid_for(n_iso, 256), 256, 0, ctx->stream>>>(order.p, cls.p, iso_nodes.p, b->iso_info,
                                                                          b->car_class, n_iso);
-        u32 n_cls = 0;
-        GK_TRY(gk_readback(ctx, (const u32*)stats.p + 4, &n_cls, 1));
-        b->n_iso = n_iso, b->n_iso_classes = n_cls;
+        b->n_iso = n_iso;      // the class count stays on the device (car_class[n_iso]): no second read-back
     }
     {
         void* q = nullptr;
@@ -886,7 +886,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                                     sort_buckets_ok(st.prev_top_max, n_act, exact), st.scratch.p + 2));
         // *unresolved_dev is still zero here: gk_wl_relabel cleared it and this path runs once per level
         frozen_assign_verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(
-            st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V, (u32)n_car, (u32)b->n_iso_classes, b->car_class,
+            st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V, (u32)n_car,
+            n_car > 0 ? (const u32*)b->car_class + n_car : nullptr, b->car_class,
             b->row_ptr, prev, b->nbr_sorted, rep.p, unresolved_dev);
         GK_HIP_CHECK(hipGetLastError());
         return GK_OK;

@@ -70,6 +70,7 @@ class ShardExchange(object):
             self.bounds.append(self.bounds[-1] + int(a[r, 0]))
         self.zero = torch.zeros(1, dtype=torch.int32, device=dev)
         self.flat = None
+        self._into_tensor = True
 
     def gather_flat(self):
         """ONE collective into a preallocated buffer: the ws messages back to back (what
@@ -78,7 +79,13 @@ class ShardExchange(object):
         import torch.distributed as dist
         if self.flat is None:
             self.flat = torch.empty(self.ws * self.msg.shape[0], dtype=self.msg.dtype, device=self.dev)
-        dist.all_gather_into_tensor(self.flat, self.msg, group=self.group)
+        if self._into_tensor:
+            try:
+                dist.all_gather_into_tensor(self.flat, self.msg, group=self.group)
+                return self.flat
+            except (RuntimeError, NotImplementedError):      # a backend without the fused form (some gloo builds)
+                self._into_tensor = False
+        dist.all_gather(list(self.flat.view(self.ws, -1).unbind(0)), self.msg, group=self.group)
         return self.flat
 
     def gather(self):

@@ -32,6 +32,24 @@ def _worker(rank, world, port, out_dir):
         g = tensors_to_batch(gp, rp, ci, lab, n_labels)
         ok = (np.array_equal(g.graph_ptr, full.graph_ptr) and np.array_equal(g.row_ptr, full.row_ptr)
               and np.array_equal(g.col_idx, full.col_idx) and np.array_equal(g.node_label, full.node_label))
+        # the fused form the GPU path uses: ONE buffer holding the ranks' messages back to back
+        # ([graph sizes | degrees | labels | col_idx], each padded to the largest shard) -- rebuilt here
+        # with numpy exactly as gk_batch_from_shards does on the device
+        from grakel_amd.dist import ShardExchange
+        ex = ShardExchange(local)
+        flat = ex.gather_flat().numpy()
+        stride = ex.mg + 2 * ex.mv + ex.me
+        gs, dg, lb, cc, v0 = [], [], [], [], 0
+        for r in range(world):
+            ng, nv, ne = (int(x) for x in ex.all_sizes[r, :3])
+            m = flat[r * stride:(r + 1) * stride]
+            gs.append(m[:ng]), dg.append(m[ex.mg:ex.mg + nv]), lb.append(m[ex.mg + ex.mv:ex.mg + ex.mv + nv])
+            cc.append(m[ex.mg + 2 * ex.mv:ex.mg + 2 * ex.mv + ne] + v0)
+            v0 += nv
+        ok = ok and (np.array_equal(np.concatenate([[0], np.cumsum(np.concatenate(gs))]), full.graph_ptr)
+                     and np.array_equal(np.concatenate([[0], np.cumsum(np.concatenate(dg))]), full.row_ptr)
+                     and np.array_equal(np.concatenate(lb), full.node_label)
+                     and np.array_equal(np.concatenate(cc), full.col_idx))
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([int(ok), b[rank], b[rank + 1]]))
     finally:
         dist.destroy_process_group()

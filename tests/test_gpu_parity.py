@@ -158,6 +158,45 @@ def test_isolated_vertices_are_carried_through_active_set_levels(gk, kind):
     assert np.array_equal(oa.fit_transform(X), O.WLOAOracle(n_iter=4).fit_transform(X))
 
 
+def _cycle_and_path_graphs(n_labels, seed, with_isolated):
+    rs = np.random.RandomState(seed)
+    X = []
+    for g in range(80):
+        m = int(rs.randint(3, 12))
+        cyc = rs.rand() < 0.5
+        ed = {i: [j for j in ((i - 1) % m if cyc else i - 1, (i + 1) % m if cyc else i + 1) if 0 <= j < m and j != i]
+              for i in range(m)}
+        ed = {i: sorted(set(v)) for i, v in ed.items()}
+        lab = {i: int(rs.randint(0, n_labels)) for i in range(m)}
+        if with_isolated:
+            for q in range(int(rs.randint(0, 4))):
+                ed[m + q] = []
+                lab[m + q] = int(rs.randint(0, n_labels))
+        X.append([ed, lab])
+    return X
+
+
+@pytest.mark.parametrize("n_labels,with_isolated", [(16, False), (16, True), (17, True), (2, True)])
+def test_level1_exact_signature_codes_and_their_limits(gk, n_labels, with_isolated):
+    """Max degree 2: 16 labels still fit the exact 32-bit level-1 code (16 * 3^16 < 2^32), 17 do not
+    (the library then hashes); both must give the reference partition.  n_iter 0 and 1 included."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    X = _cycle_and_path_graphs(n_labels, 11, with_isolated)
+    gb, _ = wl_batch_from_input(X)
+    eng = get_engine()
+    for h in (0, 1, 4):
+        wl, K, levels = _oracle_levels(X, h)
+        db = eng.upload(gb)
+        assert eng.wl_relabel(db, h) == wl.label_counts
+        for lvl in range(h + 1):
+            assert same_partition(eng.wl_labels(db, lvl), levels[lvl]), "h %d level %d" % (h, lvl)
+        assert np.array_equal(eng.gram(eng.features(db, h + 1)), K)
+    only_isolated = [[{i: [] for i in range(5)}, {i: i % 3 for i in range(5)}] for _ in range(7)]
+    assert np.array_equal(gk.WeisfeilerLehman(n_iter=3).fit_transform(only_isolated),
+                          O.WLOracle(n_iter=3).fit_transform(only_isolated))
+
+
 @pytest.mark.parametrize("bits", [3, 6, 10])
 def test_forced_hash_collisions_are_resolved_exactly(gk, bits):
     """Truncated hashes collide massively; the verify + refine loop must still be exact."""
@@ -403,6 +442,45 @@ def test_sharded_path_single_rank_matches_plain_path(gk):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    """One of two processes sharing cuda:0 (gloo moves the shard messages; RCCL needs one GPU per rank)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.dist import ShardedWL, shard_bounds
+    from grakel_amd.engine import get_engine
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full, _ = wl_batch_from_input(er_dataset(301, 30, 0.1, 4, 5))      # 301 graphs: ragged over 2 ranks
+        b = shard_bounds(full.n_graphs, world)
+        local = full.slice_graphs(b[rank], b[rank + 1])                     # this rank only holds its shard
+        sw = ShardedWL(get_engine(0), n_iter=3)
+        for _ in range(2):                                                  # the second step reuses the exchange
+            K, info = sw.step(local, to_host=True)
+        assert info["rows"] == (b[rank], b[rank + 1]) and info["n_graphs"] == 301
+        np.save(os.path.join(out_dir, "K_%d.npy" % rank), K)
+        sw.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_path_two_processes_on_one_gpu(gk, tmp_path):
+    """The multi-GPU step end to end with TWO ranks (shard -> all-gather -> gk_batch_from_shards ->
+    relabel -> features -> gk_gram_rows of the rank's rows): both processes use cuda:0 and the gloo
+    backend, so everything except RCCL itself is what runs on an 8-GPU node."""
+    import torch.multiprocessing as mp
+    K = gk.WeisfeilerLehman(n_iter=3).fit_transform(er_dataset(301, 30, 0.1, 4, 5))
+    port = 29000 + (os.getpid() % 2000)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    blocks = [np.load(os.path.join(str(tmp_path), "K_%d.npy" % r)) for r in range(2)]
+    assert blocks[0].shape == (151, 301) and blocks[1].shape == (150, 301)
+    assert np.array_equal(np.vstack(blocks), K)
 
 
 # ------------------------------------------------------------------------------------------
