@@ -352,6 +352,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 #define BK_LDS_BYTES (BK_CAP * 8 + BK_SUB * (BK_THREADS / 64) * 256 * 2 + 4 * 256 * 4)
 
 // One workgroup per top-digit bucket of (ks, vs); the sorted bucket lands in (kd, vd).
+//  * bucket <= 512 keys: every element is ranked against all others (no passes at all).
 //  * bucket <= 12288 keys and <= 6 remaining digits: everything happens in LDS.  An element is
 //    (remaining key bits << 14 | position in the bucket), up to 12 per thread in registers in index
 //    order.  A pass (a) finds each element's rank inside its (round, wave) group with 8 ballots

@@ -91,7 +91,12 @@ int gk_batch_info(gk_batch* b, int64_t* n_graphs, int64_t* n_nodes, int64_t* n_e
  * (own previous label, sorted multiset of out-neighbour previous labels) are equal.
  * Exact: 64-bit multiset hashes are only used to group candidates, every node's full
  * signature is compared with its group representative, and groups that fail are refined
- * with re-seeded hashes until none fails.
+ * with re-seeded hashes until none fails.  Level 1 of a job with few input labels and small
+ * degrees uses exact integer signature codes instead (no hash, nothing to verify).  Work that
+ * cannot change the result is skipped: singleton classes are frozen, the classes of the
+ * isolated vertices (one per input label) are carried along without being sorted again.
+ * Label ids are an arbitrary bijection per level; the listed order (nodes of shared classes
+ * grouped by label) that gk_features_build consumes stays inside the batch.
  *   out_label_counts[n_iter+1] : number of distinct labels per level (host)
  *   hash_bits : 0 = default (64); tests pass small values to force collisions
  *   out_rounds : total extra refinement rounds that were needed (0 in practice), may be NULL */
