@@ -72,6 +72,43 @@ def cpu_baseline(sample_graphs, cfg):
                        % (sample_graphs, cfg["n"], cfg["p"], cfg["n_iter"], dt, int(K.sum()))), K, X
 
 
+def end_to_end(eng, full, cfg):
+    """What a caller of the estimator sees (never `value`): (a) packed CSR on the host -> float64 K on the
+    host (upload, step, 8 N^2 bytes over PCIe into pageable memory), (b) the estimator on Python
+    objects (SURVEY.md 8d asks for both walls).  One run each, after one warm-up of (a)."""
+    import grakel_amd
+    from grakel_amd.synthetic import er_dataset
+    N, h = cfg["N"], cfg["n_iter"]
+
+    def packed():
+        t0 = time.perf_counter()
+        db = eng.upload(full)
+        eng.wl_relabel(db, h)
+        feat = eng.features(db, h + 1)
+        K = eng.gram(feat, 0, to_host=True)
+        dt = time.perf_counter() - t0
+        feat.close()
+        db.close()
+        return dt, K
+
+    packed()
+    dt_packed, K = packed()
+    X = er_dataset(N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])      # {u: [v, ...]} + {u: label} per graph
+    from grakel_amd.batch import wl_batch_from_input
+    t0 = time.perf_counter()
+    wl_batch_from_input(X)
+    dt_ingest = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Kobj = grakel_amd.WeisfeilerLehman(n_iter=h).fit_transform(X)
+    dt_obj = time.perf_counter() - t0
+    return {"packed_csr_host_to_host_ms": dt_packed * 1e3, "packed_csr_graph_pairs_per_s": N * N / dt_packed,
+            "python_objects_s": dt_obj, "python_objects_graph_pairs_per_s": N * N / dt_obj,
+            "of_which_host_ingestion_s": dt_ingest, "same_matrix": bool(np.array_equal(K, Kobj)),
+            "note": "packed: H2D of the CSR + step + D2H of the %d MB float64 K into pageable memory; "
+                    "objects: grakel_amd.WeisfeilerLehman(n_iter=%d).fit_transform on %d dict graphs"
+                    % (N * N * 8 // 1000000, h, N)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +286,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             cb, Kcpu, X = cpu_baseline(min(a.cpu_sample, N), cfg)
             out["cpu_baseline"] = cb
+            out["end_to_end"] = end_to_end(eng, full, cfg)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

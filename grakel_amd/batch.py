@@ -21,6 +21,11 @@ from itertools import chain
 import numpy as np
 from scipy.sparse import issparse
 
+try:                                   # optional C fast path of the dict-of-lists / dict-of-dicts walk
+    from . import _gk_ingest           # (csrc/ingest.c, built by `make -C grakel_amd/csrc`); host logic only
+except ImportError:                    # not built: the Python path below does everything
+    _gk_ingest = None
+
 
 class GraphBatch(object):
     """A set of graphs packed as CSR (int32), the unit the HIP library consumes.
@@ -337,6 +342,19 @@ def wl_batch_from_input(X, fitted_labels=None, min_len=2, not_iterable=TypeError
     """Ingest the WL / VH input -> (GraphBatch, label mapping)."""
     if isinstance(X, GraphBatch):
         return X, None
+    if _gk_ingest is not None and type(X) in (list, tuple):
+        # plain `[edge dict, label dict, ...]` elements: the same walk in C; anything it does not
+        # recognise makes it return None and the Python path below takes the whole input
+        r = _gk_ingest.wl_ingest(X, int(min_len))
+        if r is not None:
+            sizes, row_ptr, col, values = r
+            ids, mapping = compress_labels(values, fitted_labels)
+            n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
+            sizes = np.frombuffer(sizes, dtype=np.int32)
+            graph_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+            np.cumsum(sizes, out=graph_ptr[1:])
+            return GraphBatch(graph_ptr, np.frombuffer(row_ptr, dtype=np.int32), np.frombuffer(col, dtype=np.int32),
+                              ids, max(n_labels, 1)), mapping
     msg = ('each element of X must be either a graph object or a list with at least a graph '
            'like object and node labels dict \n')
     sizes, srcs, dsts, values = [], [], [], []

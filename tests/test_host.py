@@ -75,6 +75,74 @@ def test_all_edge_dictionary_forms_give_the_same_batch():
         wl_batch_from_input([["nonsense", {0: 'a'}]])
 
 
+def _both_paths(X, **kw):
+    """wl_batch_from_input through the C fast path (csrc/ingest.c) and through the Python path."""
+    from grakel_amd import batch as B
+    if B._gk_ingest is None:                        # fresh checkout: build the optional module (gcc + Python.h)
+        import importlib
+        import subprocess
+        subprocess.call(["make", "-C", os.path.join(ROOT, "grakel_amd", "csrc"), "ingest"])
+        try:
+            B._gk_ingest = importlib.import_module("grakel_amd._gk_ingest")
+        except ImportError:
+            pytest.skip("the C ingestion module cannot be built here (no Python.h?)")
+
+    def run():
+        try:
+            gb, m = B.wl_batch_from_input(X, **kw)
+            return ("ok", gb.graph_ptr.tolist(), gb.row_ptr.tolist(), gb.col_idx.tolist(), gb.node_label.tolist(),
+                    gb.n_labels, m)
+        except Exception as e:                      # noqa: BLE001 -- the two paths must raise alike
+            return ("raise", type(e), e.args)
+    fast = run()
+    saved, B._gk_ingest = B._gk_ingest, None
+    try:
+        slow = run()
+    finally:
+        B._gk_ingest = saved
+    return fast, slow
+
+
+def test_c_ingestion_fast_path_equals_the_python_path():
+    rs = np.random.RandomState(5)
+    cases = {}
+    for name, kw in SMALL_SETS:
+        cases[name] = random_labelled_graphs(**kw)
+    cases["er"] = er_dataset(40, 30, 0.15, 5, 3)                       # identity numbering, lists
+    X = er_dataset(25, 12, 0.3, 3, 9)
+    cases["dict_of_dicts"] = [[{u: {v: 1.0 for v in nb} for u, nb in g.items()}, lab] for g, lab in X]
+    sym = [[{"v%d" % u: ["v%d" % v for v in nb] for u, nb in g.items()}, {"v%d" % u: l for u, l in lab.items()}]
+           for g, lab in X]
+    cases["string_vertices"] = sym
+    cases["shuffled_label_order"] = [[g, dict(sorted(lab.items(), key=lambda kv: -kv[0]))] for g, lab in X]
+    cases["duplicates_and_hubs"] = [[{0: [1, 1, 2] + list(range(3, 60)) * 2, **{i: [0, 0] for i in range(1, 60)}},
+                                     {i: int(rs.randint(0, 4)) for i in range(60)}]]
+    cases["unlabelled_source_is_ignored"] = [[{0: [1], 1: [0], 9: [0]}, {0: 'a', 1: 'b'}]]
+    cases["vertex_without_entry"] = [[{0: [1], 1: [0]}, {0: 'a', 1: 'b', 2: 'c'}]]
+    cases["extras_and_tuples"] = [(g, lab, {}, "extra") for g, lab in X]
+    cases["mixed_forms_decline"] = X[:3] + [[np.eye(3), {0: 1, 1: 1, 2: 2}]] + sym[:2]
+    cases["numpy_int_neighbours"] = [[{0: [np.int64(1)], 1: [np.int64(0)]}, {0: 'a', 1: 'b'}]]
+    cases["float_neighbours"] = [[{0: [1.0], 1: [0.0]}, {0: 'a', 1: 'b'}]]
+    cases["bool_weights"] = [[{0: {1: True}, 1: {0: True}}, {0: 'a', 1: 'b'}]]
+    cases["unlabelled_neighbour"] = [[{0: [1, 7], 1: [0]}, {0: 'a', 1: 'b'}]]
+    cases["unlabelled_neighbour_symbols"] = [[{'a': ['b', 'zz'], 'b': ['a']}, {'a': 1, 'b': 2}]]
+    cases["empty_labels"] = [[{0: [1], 1: [0]}, {}]]
+    cases["empty_element"] = [[{0: [1], 1: [0]}, {0: 1, 1: 2}], []]
+    cases["labels_not_a_dict"] = [[{0: [1], 1: [0]}, [1, 2]]]
+    cases["negative_neighbour"] = [[{0: [-1], 1: [0]}, {0: 'a', 1: 'b'}]]
+    import warnings
+    for name, X in cases.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fast, slow = _both_paths(X)
+        assert fast == slow, name
+    fitted = {'a': 0, 'b': 1}
+    fast, slow = _both_paths(cases["unlabelled_source_is_ignored"] + [[{0: [1], 1: [0]}, {0: 'b', 1: 'q'}]],
+                             fitted_labels=fitted)
+    assert fast == slow and fast[0] == "ok"
+    assert _both_paths(cases["unlabelled_neighbour"])[0][:2] == ("raise", KeyError)
+
+
 def test_label_compression_fit_and_transform():
     ids, m = compress_labels(['b', 'a', 'c', 'a'])
     assert ids.tolist() == [1, 0, 2, 0] and m == {'a': 0, 'b': 1, 'c': 2}
