@@ -96,11 +96,11 @@ def end_to_end(eng, full, cfg):
     X = er_dataset(N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])      # {u: [v, ...]} + {u: label} per graph
     from grakel_amd.batch import wl_batch_from_input
     t0 = time.perf_counter()
-    wl_batch_from_input(X)
-    dt_ingest = time.perf_counter() - t0
-    t0 = time.perf_counter()
     Kobj = grakel_amd.WeisfeilerLehman(n_iter=h).fit_transform(X)
     dt_obj = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    wl_batch_from_input(X)                       # the ingestion part alone, same (now warm) objects
+    dt_ingest = time.perf_counter() - t0
     return {"packed_csr_host_to_host_ms": dt_packed * 1e3, "packed_csr_graph_pairs_per_s": N * N / dt_packed,
             "python_objects_s": dt_obj, "python_objects_graph_pairs_per_s": N * N / dt_obj,
             "of_which_host_ingestion_s": dt_ingest, "same_matrix": bool(np.array_equal(K, Kobj)),
