@@ -150,6 +150,7 @@ struct gk_batch {
     // car_class[n_iso] = number of carried classes.
     i32* iso_info = nullptr;    // [n_nodes], null when the batch has no isolated vertex
     i32* car_class = nullptr;   // [n_iso + 1]
+    i32* car_nodes = nullptr;   // [n_iso] the carried list itself: vertex at each slot
     i64 n_iso = 0;
     // levels
     int n_levels = 0;                  // levels currently valid (0 = only level-0 labels)

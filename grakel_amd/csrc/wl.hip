@@ -185,11 +185,13 @@ struct HeadAssign {
     i32* rep;          // out: rep[run]  = first node of the run
     u32* frozen;       // out (may be null): 1 when the node's class is a singleton
     i64 n;
+    u32 base;              // ids start at base + *base_dev (active-set levels: behind the frozen and carried ids)
+    const u32* base_dev;   // may be null
     __device__ __forceinline__ u32 value(i64 k) const { return (k == 0 || ks[k] != ks[k - 1]) ? 1u : 0u; }
     __device__ __forceinline__ void emit(i64 k, u32 head, u32 incl) const {
         const u32 v = perm[k];
         const i32 r = (i32)incl - 1;
-        lab[v] = r;
+        lab[v] = (i32)(base + (base_dev ? *base_dev : 0u)) + r;
         if (head) rep[r] = (i32)v;
         if (frozen) frozen[v] = (head && (k == n - 1 || ks[k + 1] != ks[k])) ? 1u : 0u;
     }
@@ -340,10 +342,203 @@ __global__ void gather_big_hash_kernel(const u32* __restrict__ act, i64 n_act, c
 }
 
 
-// active-set level, one pass over the nodes: a frozen node receives its fresh id and its place
-// behind the listed prefix; a carried (isolated) node keeps its class -- ids ra .. ra + n_car_classes
-// - 1, listed right behind the sorted active nodes in carried-list order; an active node is verified
-// against its class representative.  perm = [sorted active | carried | frozen].
+// The active list of a level from the active list of the level before (both ascending node ids): a
+// node of the old list either stays active or has just become a singleton.  Frozen nodes keep their
+// id for good -- ids of an active-set level are [frozen | carried classes | active classes], the frozen
+// ones numbered in the order they froze -- so a level starts as a copy of the previous level's labels
+// and the nodes that froze last get the next free frozen ids here.  O(previous active nodes), where
+// ActiveScan + frozen_assign_verify_kernel walk all nodes.
+struct ActiveFromList {
+    const u32* frozen; const u32* act_prev; u32* act_new;
+    i32* lab;                  // this level's labels (already a copy of the previous level's)
+    u32 n_frozen_prev;         // frozen nodes of the previous level = first free frozen id
+    u32* total_out; const u32* extra; u32* mbox; u32 seq;     // as in ActiveScan
+    __device__ __forceinline__ u32 value(i64 i) const { return frozen[act_prev[i]] ? 0u : 1u; }
+    __device__ __forceinline__ void emit(i64 i, u32 a, u32 incl) const {
+        const u32 v = act_prev[i];
+        if (a) act_new[incl - 1] = v;
+        else lab[v] = (i32)(n_frozen_prev + ((u32)i - incl));
+    }
+    __device__ __forceinline__ void finish(u32 total) const {
+        *total_out = total;
+        if (mbox) {
+            __hip_atomic_store(&mbox[1], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mbox[2], *extra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
+};
+
+// ... and the end of such a level: carried classes get their ids and their place behind the sorted
+// active nodes, active nodes are verified against their class representative.  O(active + carried).
+__global__ void active_finish_kernel(const u32* __restrict__ act, u32 n_active,
+                                     const i32* __restrict__ car_nodes, const i32* __restrict__ car_class, u32 n_car,
+                                     u32 n_frozen, const u32* __restrict__ n_car_classes_dev,
+                                     const u32* __restrict__ ra_dev, i32* __restrict__ lab, i32* __restrict__ perm,
+                                     u32* __restrict__ count_out, const i32* __restrict__ row_ptr,
+                                     const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
+                                     const i32* __restrict__ rep, u32* __restrict__ unresolved) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 n_cc = n_car ? *n_car_classes_dev : 0u;
+    if (j == 0) *count_out = n_frozen + n_cc + *ra_dev;
+    if (j < n_car) {
+        const i32 v = car_nodes[j];
+        lab[v] = (i32)(n_frozen + (u32)car_class[j]);
+        perm[n_active + j] = v;
+    }
+    if (j >= n_active) return;
+    const i32 v = (i32)act[j];
+    const i32 r = rep[lab[v] - (i32)(n_frozen + n_cc)];
+    if (r == v) return;
+    bool ok = lab_prev[v] == lab_prev[r];
+    const i32 s = row_ptr[v], sr = row_ptr[r];
+    const int d = row_ptr[v + 1] - s;
+    ok = ok && (d == row_ptr[r + 1] - sr);
+    if (ok)
+        for (int k = 0; k < d; ++k)
+            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+    if (!ok) atomicAdd(unresolved, 1u);
+}
+
+// A whole active-set level in ONE workgroup, for the tail of a job where a few hundred nodes are still
+// active: eight launches of 3-5 us kernels plus a host read-back cost ~55 us per level, this kernel
+// ~15 us and no read-back (the host learns the active counts with the final read-back of the job).
+//   do_scan: the active list is first derived from the previous level's list (ActiveFromList above),
+//            otherwise act_cur / *n_act_io already describe this level.
+//   then   : signatures of the active nodes (as wl_signature_list_kernel), (key, list position) ranked
+//            against each other in LDS (a strict total order: stable), run heads -> class ids behind
+//            the frozen and carried ids, singleton flags for the next level, verification against the
+//            class representative, carried classes (as active_finish_kernel).
+#define TINY_MAX 1024
+__device__ __forceinline__ u32 tiny_block_scan(u32 x, u32* wsum, u32* total) {     // inclusive, 1024 threads
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 inc = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
+    }
+    __syncthreads();                      // wsum may still be read from the previous scan
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < TINY_MAX / 64; ++q) {
+        const u32 t = wsum[q];
+        if (q < w) before += t;
+        all += t;
+    }
+    *total = all;
+    return inc + before;
+}
+
+__global__ __launch_bounds__(TINY_MAX) void wl_tiny_level_kernel(
+    const u32* __restrict__ act_prev, u32* __restrict__ act_cur, u32* __restrict__ n_act_io, int do_scan,
+    u32* __restrict__ frozen, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
+    const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted, i32* __restrict__ lab, i32* __restrict__ perm,
+    u64 seed, u64 mask, const i32* __restrict__ car_nodes, const i32* __restrict__ car_class, u32 n_car,
+    const u32* __restrict__ n_car_classes_dev, i64 V, u32* __restrict__ count_out, u32* __restrict__ n_act_out,
+    u32* __restrict__ unresolved) {
+    __shared__ u32 act_s[TINY_MAX];
+    __shared__ __attribute__((aligned(16))) u64 elem_s[TINY_MAX];
+    __shared__ u64 skey[TINY_MAX];
+    __shared__ u32 sidx[TINY_MAX];
+    __shared__ i32 rep_s[TINY_MAX];
+    __shared__ u32 wsum[TINY_MAX / 64];
+    const u32 j = threadIdx.x;
+    const u32 n_in = *n_act_io;                       // every thread reads it before thread 0 overwrites it below
+    u32 n_act = n_in;
+    if (do_scan) {
+        u32 a = 0, v = 0;
+        if (j < n_in) { v = act_prev[j]; a = frozen[v] ? 0u : 1u; }
+        const u32 incl = tiny_block_scan(a, wsum, &n_act);
+        if (j < n_in) {
+            if (a) { act_s[incl - 1] = v; act_cur[incl - 1] = v; }
+            else lab[v] = (i32)((u32)(V - (i64)n_in - (i64)n_car) + (j - incl));      // next free frozen ids
+        }
+    } else if (j < n_in) {
+        act_s[j] = act_cur[j];
+    }
+    __syncthreads();
+    const u32 n_cc = n_car ? *n_car_classes_dev : 0u;
+    const u32 n_frozen = (u32)(V - (i64)n_act - (i64)n_car);
+    const u32 base = n_frozen + n_cc;
+    // ---- signatures
+    u64 key = ~0ull;
+    if (j < n_act) {
+        const u32 v = act_s[j];
+        const i32 s = row_ptr[v];
+        const int d = row_ptr[v + 1] - s;
+        i32* x = nbr_sorted + s;
+        for (int k = 0; k < d; ++k) x[k] = lab_prev[col_idx[s + k]];
+        insertion_sort(x, d);
+        u64 acc = sig_head((u32)lab_prev[v], (u32)d, seed);
+        for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+        key = mix64(acc) & mask;
+    }
+    elem_s[j] = j < n_act ? ((key << 10) | (u64)j) : ~0ull;
+    __syncthreads();
+    // ---- rank against all others (elements are distinct): the rank is the sorted position
+    if (j < n_act) {
+        const u64 mine = elem_s[j];
+        const u32 n_even = (n_act + 1u) & ~1u;
+        u32 r = 0;
+#pragma unroll 4
+        for (u32 i = 0; i < n_even; i += 2) {
+            const ulonglong2 ab = *(const ulonglong2*)(elem_s + i);
+            r += (ab.x < mine ? 1u : 0u) + (ab.y < mine ? 1u : 0u);
+        }
+        skey[r] = key;
+        sidx[r] = j;
+    }
+    __syncthreads();
+    // ---- run heads -> class ids, singleton flags, representatives
+    bool head = false, single = false;
+    if (j < n_act) {
+        head = j == 0 || skey[j] != skey[j - 1];
+        single = head && (j + 1 == n_act || skey[j + 1] != skey[j]);
+    }
+    u32 ra = 0;
+    const u32 incl = tiny_block_scan(head ? 1u : 0u, wsum, &ra);
+    i32 v = 0;
+    if (j < n_act) {
+        v = (i32)act_s[sidx[j]];
+        lab[v] = (i32)(base + incl - 1u);
+        perm[j] = v;
+        frozen[v] = single ? 1u : 0u;
+        if (head) rep_s[incl - 1] = v;
+    }
+    __syncthreads();
+    if (j < n_act && !head) {           // same full signature as the class representative?
+        const i32 r = rep_s[incl - 1];
+        bool ok = lab_prev[v] == lab_prev[r];
+        const i32 s = row_ptr[v], sr = row_ptr[r];
+        const int d = row_ptr[v + 1] - s;
+        ok = ok && (d == row_ptr[r + 1] - sr);
+        if (ok)
+            for (int k = 0; k < d; ++k)
+                if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+        if (!ok) atomicAdd(unresolved, 1u);
+    }
+    for (u32 c = j; c < n_car; c += TINY_MAX) {
+        const i32 cv = car_nodes[c];
+        lab[cv] = (i32)(n_frozen + (u32)car_class[c]);
+        perm[n_act + c] = cv;
+    }
+    if (j == 0) {
+        *count_out = base + ra;
+        *n_act_io = n_act;
+        *n_act_out = n_act;
+    }
+}
+
+// FIRST active-set level (the level before sorted every node), one pass over the nodes: a frozen node
+// receives its permanent id (its rank among the frozen nodes); a carried (isolated) node keeps its
+// class, listed right behind the sorted active nodes in carried-list order; an active node is verified
+// against its class representative.  ids = [frozen | carried classes | active classes],
+// perm = [sorted active | carried | (unlisted: nobody reads behind n_sorted)].
 __global__ void frozen_assign_verify_kernel(const u32* __restrict__ fidx, const u32* __restrict__ ra_dev,
                                             i32* __restrict__ lab, i32* __restrict__ perm,
                                             u32* __restrict__ count_out, u32 n_active, i64 n,
@@ -355,21 +550,21 @@ __global__ void frozen_assign_verify_kernel(const u32* __restrict__ fidx, const 
     const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 ra = *ra_dev;
     const u32 n_car_classes = n_car ? *n_car_classes_dev : 0u;
-    if (v == 0) *count_out = ra + n_car_classes + (u32)(n - n_active - n_car);
+    const u32 n_frozen = (u32)(n - n_active - n_car);
+    if (v == 0) *count_out = n_frozen + n_car_classes + ra;
     if (v >= n) return;
     const u32 f = fidx[v];
     if (f != 0xffffffffu) {
         if (f & 0x80000000u) {
             const u32 slot = f & 0x7fffffffu;
-            lab[v] = (i32)(ra + (u32)car_class[slot]);
+            lab[v] = (i32)(n_frozen + (u32)car_class[slot]);
             perm[n_active + slot] = (i32)v;
         } else {
-            lab[v] = (i32)(ra + n_car_classes + f);
-            perm[n_active + n_car + f] = (i32)v;
+            lab[v] = (i32)f;               // frozen ids come first and never change again (ActiveFromList)
         }
         return;
     }
-    const i32 r = rep[lab[v]];
+    const i32 r = rep[lab[v] - (i32)(n_frozen + n_car_classes)];
     if (r == (i32)v) return;
     bool ok = lab_prev[v] == lab_prev[r];
     const i32 s = row_ptr[v], sr = row_ptr[r];
@@ -482,12 +677,14 @@ __global__ void iso_keys_kernel(const u32* __restrict__ iso_flag, const u32* __r
 // carried list = isolated vertices grouped by input label (stable: ascending vertex inside a group)
 __global__ void iso_slots_kernel(const i32* __restrict__ order, const i32* __restrict__ cls,
                                  const i32* __restrict__ iso_nodes, i32* __restrict__ iso_info,
-                                 i32* __restrict__ car_class, i64 n_iso) {
+                                 i32* __restrict__ car_class, i32* __restrict__ car_nodes, i64 n_iso) {
     const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_iso) return;
     const i32 item = order[k];
-    iso_info[iso_nodes[item]] = -1 - (i32)k;
+    const i32 v = iso_nodes[item];
+    iso_info[v] = -1 - (i32)k;
     car_class[k] = cls[item];
+    car_nodes[k] = v;
 }
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
@@ -527,6 +724,8 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
         b->iso_info = (i32*)q;
         GK_TRY(gk_dev_alloc(ctx, &q, ((size_t)n_iso + 1) * 4));      // [n_iso] class per slot, then the class count
         b->car_class = (i32*)q;
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)n_iso * 4));
+        b->car_nodes = (i32*)q;
         Tmp<u64> keys(ctx);
         Tmp<i32> iso_nodes(ctx), cls(ctx), order(ctx);
         GK_TRY(keys.alloc(n_iso)); GK_TRY(iso_nodes.alloc(n_iso)); GK_TRY(cls.alloc(n_iso)); GK_TRY(order.alloc(n_iso));
@@ -535,7 +734,7 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
         GK_TRY(gk_dictionary_from_keys(ctx, keys.p, n_iso, bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0),
                                        cls.p, order.p, (u32*)b->car_class + n_iso));
         iso_slots_kernel<<<grid_for(n_iso, 256), 256, 0, ctx->stream>>>(order.p, cls.p, iso_nodes.p, b->iso_info,
-                                                                         b->car_class, n_iso);
+                                                                         b->car_class, b->car_nodes, n_iso);
         b->n_iso = n_iso;      // the class count stays on the device (car_class[n_iso]): no second read-back
     }
     {
@@ -686,7 +885,7 @@ extern "C" int gk_batch_destroy(gk_batch* b) {
     if (!b) return GK_OK;
     gk_ctx* ctx = b->ctx;
     void* ptrs[] = {b->graph_ptr, b->row_ptr, b->col_idx, b->node_graph, b->big_nodes,
-                    b->labels, b->perm, b->nbr_sorted, b->iso_info, b->car_class};
+                    b->labels, b->perm, b->nbr_sorted, b->iso_info, b->car_class, b->car_nodes};
     for (void* p : ptrs)
         if (p) gk_dev_free(ctx, p);
     delete b;
@@ -750,7 +949,8 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
 static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm,
                                 i32* rep, u32* count_dev, const u32* vals = nullptr, u32* frozen = nullptr,
                                 i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr,
-                                u32* listed_dev = nullptr, u32* posted_seq = nullptr) {
+                                u32* listed_dev = nullptr, u32* posted_seq = nullptr, u32 lab_base = 0,
+                                const u32* lab_base_dev = nullptr) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         if (listed_dev) GK_TRY(gk_zero_async(ctx, listed_dev, 4));
@@ -774,7 +974,7 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
         return GK_OK;
     }
     GK_TRY(gk_radix_sort_pairs(ctx, keys, vals, ks.p, (u32*)perm, n, key_bits, use_buckets, top_digit_max));
-    HeadAssign ha{ks.p, (const u32*)perm, lab, rep, frozen, n};
+    HeadAssign ha{ks.p, (const u32*)perm, lab, rep, frozen, n, lab_base, lab_base_dev};
     GK_TRY((gk_scan_fn<u32, HeadAssign>(ctx, ha, n, count_dev)));
     return GK_OK;
 }
@@ -804,12 +1004,40 @@ struct RelabelState {
     bool split = true;                     // GK_WL_NO_SPLIT: keep the plain label-grouped order
     u32 posted_seq = 0;                    // mailbox message {listed nodes, top-digit max} of the previous (full) level
     Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active, [2] = top-digit max
+    Tmp<u32> act2;                         // second active list (the list of a level is built from the previous level's)
+    u32* act_cur = nullptr;                // the current level's active list (act or act2)
+    bool prev_active = false;              // the previous level took the active-set path (its list is act_cur)
+    u32 n_act_prev = 0;
+    bool list_scan = true;                 // GK_WL_NO_LISTSCAN: always rebuild the active list from all nodes
+    bool tiny = true;                      // GK_WL_NO_TINY: never run a level in the single-workgroup kernel
+    std::vector<char> tiny_level;          // levels run by wl_tiny_level_kernel (n_act_prev is then only a bound)
     i64 n_frozen_levels = 0;
-    explicit RelabelState(gk_ctx* c) : frozen(c), act(c), fidx(c), scratch(c) {}
+    explicit RelabelState(gk_ctx* c) : frozen(c), act(c), fidx(c), scratch(c), act2(c) {}
 };
 
+// one launch of wl_tiny_level_kernel for `level` (labels of the level already hold a copy of the
+// previous level's); st.n_act_prev bounds the number of active nodes
+static int launch_tiny_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, RelabelState& st, int do_scan,
+                             const u32* act_prev, u32* act_cur, i32* cur, i32* perm, const i32* prev,
+                             u32* count_dev, u32* tiny_dev, u32* unresolved_dev) {
+    const i64 V = b->n_nodes;
+    const i64 n_car = b->iso_info ? b->n_iso : 0;
+    int bits = hash_bits;
+    if (hash_bits >= 32) bits = 32;        // 2 * log2(1024) + 8 = 28 bits, rounded up to whole digits; (key << 10 | position) fits 64 bits
+    const u64 mask = (1ull << bits) - 1ull;
+    wl_tiny_level_kernel<<<1, TINY_MAX, 0, ctx->stream>>>(
+        act_prev, act_cur, st.scratch.p + 1, do_scan, st.frozen.p, b->row_ptr, b->col_idx, prev, b->nbr_sorted, cur, perm,
+        level_seed(level, 0), mask, b->car_nodes, b->car_class, (u32)n_car,
+        n_car > 0 ? (const u32*)b->car_class + n_car : nullptr, V, count_dev, tiny_dev, unresolved_dev);
+    GK_HIP_CHECK(hipGetLastError());
+    st.tiny_level[level] = 1;
+    st.prev_active = true;
+    b->n_sorted[level] = n_car;            // + the active count, known after the job's final read-back
+    return GK_OK;
+}
+
 static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, bool exact, RelabelState& st,
-                         u32* count_dev, u32* unresolved_dev, u32* listed_dev, int* rounds) {
+                         u32* count_dev, u32* unresolved_dev, u32* listed_dev, u32* tiny_dev, int* rounds) {
     const i64 V = b->n_nodes;
     const i32* prev = b->labels + (size_t)(level - 1) * V;
     i32* cur = b->labels + (size_t)level * V;
@@ -833,18 +1061,48 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         }
     }
     st.posted_seq = 0;
+    bool list_based = false;               // this level's active list came from the previous level's list
     if (decided) {
     } else if (!exact && !getenv("GK_WL_NO_ACTIVE_SET") && level >= 2) {
-        const u32 seq = gk_mbox_begin(ctx);
-        ActiveScan as{st.frozen.p, st.act.p, st.fidx.p, st.scratch.p + 1, st.scratch.p + 2, seq ? ctx->mbox_dev : nullptr, seq,
-                      n_car > 0 ? b->iso_info : nullptr};
-        GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, nullptr)));
         u32 back[2] = {0, 0};
-        if (seq) GK_TRY(gk_mbox_wait(ctx, seq, back, 2));
-        else GK_TRY(gk_readback(ctx, st.scratch.p + 1, back, 2));
+        if (st.prev_active && st.list_scan) {
+            // the previous level took the active-set path: frozen ids are permanent, so this level's labels
+            // start as a copy and only the previous active list (st.act_cur) is scanned
+            list_based = true;
+            GK_HIP_CHECK(hipMemcpyAsync(cur, prev, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            if (st.tiny && b->n_big == 0 && st.n_act_prev <= TINY_MAX) {
+                // a few hundred active nodes at most: the whole level in one workgroup, no read-back
+                // (st.n_act_prev stays an upper bound; the exact count lives in st.scratch[1])
+                u32* act_new = st.act_cur == st.act.p ? st.act2.p : st.act.p;
+                GK_TRY(launch_tiny_level(ctx, b, level, hash_bits, st, 1, st.act_cur, act_new, cur, perm, prev, count_dev,
+                                         tiny_dev, unresolved_dev));
+                st.act_cur = act_new;
+                return GK_OK;
+            }
+            if (st.n_act_prev > 0) {
+                const u32 seq = gk_mbox_begin(ctx);
+                u32* act_new = st.act_cur == st.act.p ? st.act2.p : st.act.p;
+                const u32 n_frozen_prev = (u32)(V - (i64)st.n_act_prev - n_car);
+                ActiveFromList af{st.frozen.p, st.act_cur, act_new, cur, n_frozen_prev, st.scratch.p + 1, st.scratch.p + 2,
+                                  seq ? ctx->mbox_dev : nullptr, seq};
+                GK_TRY((gk_scan_fn<u32, ActiveFromList>(ctx, af, (i64)st.n_act_prev, nullptr)));
+                if (seq) GK_TRY(gk_mbox_wait(ctx, seq, back, 2));
+                else GK_TRY(gk_readback(ctx, st.scratch.p + 1, back, 2));
+                st.act_cur = act_new;
+            }
+        } else {
+            const u32 seq = gk_mbox_begin(ctx);
+            ActiveScan as{st.frozen.p, st.act.p, st.fidx.p, st.scratch.p + 1, st.scratch.p + 2, seq ? ctx->mbox_dev : nullptr, seq,
+                          n_car > 0 ? b->iso_info : nullptr};
+            GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, nullptr)));
+            if (seq) GK_TRY(gk_mbox_wait(ctx, seq, back, 2));
+            else GK_TRY(gk_readback(ctx, st.scratch.p + 1, back, 2));
+            st.act_cur = st.act.p;
+        }
         n_act = back[0], st.prev_top_max = back[1];
         static const bool dbg = getenv("GK_WL_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[gk] level %d: active %u of %lld, previous top-digit bucket max %u\n", level, n_act, (long long)V, back[1]);
+        if (dbg) fprintf(stderr, "[gk] level %d: active %u of %lld%s, previous top-digit bucket max %u\n", level, n_act,
+                         (long long)V, list_based ? " (from the previous list)" : "", back[1]);
     } else {
         st.prev_top_max = 0;
     }
@@ -856,12 +1114,16 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         GK_HIP_CHECK(hipMemcpyAsync(cur, prev, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
         GK_HIP_CHECK(hipMemcpyAsync(perm, perm - V, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
         GK_HIP_CHECK(hipMemcpyAsync(count_dev, count_dev - 1, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        st.prev_active = true, st.n_act_prev = 0;       // nothing left to scan at the following levels either
         return GK_OK;
     }
     if (!exact && (u64)n_act * 4 <= (u64)V) {
         // ---- active-set path: only the n_act active nodes are hashed, sorted and verified; the
-        // carried classes of the isolated vertices are listed behind them
+        // carried classes of the isolated vertices are listed behind them.
+        // ids of the level: [frozen nodes | carried classes | classes of the active nodes]
         b->n_sorted[level] = (i64)n_act + n_car;
+        const u32 n_frozen = (u32)(V - (i64)n_act - n_car);
+        const u32* n_cc_dev = n_car > 0 ? (const u32*)b->car_class + n_car : nullptr;
         int bits = hash_bits;
         if (hash_bits >= 32) {   // default sizing rule applied to the active set (tests may force fewer bits)
             int lg = bits_for((u64)(n_act > 1 ? n_act - 1 : 1));
@@ -870,31 +1132,46 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             if (bits > hash_bits) bits = hash_bits;
         }
         const u64 mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+        if (list_based && st.tiny && b->n_big == 0 && n_act <= TINY_MAX) {
+            st.n_act_prev = n_act;
+            return launch_tiny_level(ctx, b, level, hash_bits, st, 0, nullptr, st.act_cur, cur, perm, prev, count_dev,
+                                     tiny_dev, unresolved_dev);
+        }
         Tmp<u64> hash_act(ctx), hash_node(ctx);
         Tmp<i32> rep(ctx);
         GK_TRY(hash_act.alloc(n_act)); GK_TRY(rep.alloc(n_act));
         const u64 seed = level_seed(level, 0);
         wl_signature_list_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(
-            st.act.p, n_act, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_act.p, seed, mask);
+            st.act_cur, n_act, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_act.p, seed, mask);
         if (b->n_big > 0) {
             GK_TRY(hash_node.alloc(V));
             wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
                 b->big_nodes, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_node.p, seed, mask);
-            gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act.p, n_act, b->row_ptr, hash_node.p, hash_act.p);
+            gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act_cur, n_act, b->row_ptr, hash_node.p, hash_act.p);
         }
-        GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act.p, st.frozen.p, 0,
-                                    sort_buckets_ok(st.prev_top_max, n_act, exact), st.scratch.p + 2));
+        GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act_cur, st.frozen.p, 0,
+                                    sort_buckets_ok(st.prev_top_max, n_act, exact), st.scratch.p + 2, nullptr, nullptr,
+                                    n_frozen, n_cc_dev));
         // *unresolved_dev is still zero here: gk_wl_relabel cleared it and this path runs once per level
-        frozen_assign_verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(
-            st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V, (u32)n_car,
-            n_car > 0 ? (const u32*)b->car_class + n_car : nullptr, b->car_class,
-            b->row_ptr, prev, b->nbr_sorted, rep.p, unresolved_dev);
+        if (list_based) {
+            const i64 m = (i64)n_act > n_car ? (i64)n_act : n_car;
+            active_finish_kernel<<<grid_for(m, 256), 256, 0, ctx->stream>>>(
+                st.act_cur, n_act, b->car_nodes, b->car_class, (u32)n_car, n_frozen, n_cc_dev, st.scratch.p, cur, perm,
+                count_dev, b->row_ptr, prev, b->nbr_sorted, rep.p, unresolved_dev);
+        } else {
+            frozen_assign_verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(
+                st.fidx.p, st.scratch.p, cur, perm, count_dev, n_act, V, (u32)n_car, n_cc_dev, b->car_class,
+                b->row_ptr, prev, b->nbr_sorted, rep.p, unresolved_dev);
+        }
         GK_HIP_CHECK(hipGetLastError());
+        st.prev_active = true, st.n_act_prev = n_act;
         return GK_OK;
     }
+    st.prev_active = false;
     // ---- full path
     if (!st.split) listed_dev = nullptr;
     st.full_level[level] = listed_dev ? 1 : 0;
+    st.tiny_level[level] = 0;
     b->n_sorted[level] = V;
     Tmp<u64> hash(ctx), keys(ctx);
     Tmp<i32> rep(ctx);
@@ -966,15 +1243,19 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     const i64 V = b->n_nodes;
     GK_TRY(gk_batch_ensure_levels(b, n_levels));
     Tmp<u32> meta(ctx);   // [n_levels] counts, [n_levels] unresolved, [n_levels] nodes of shared classes (full levels)
-    GK_TRY(meta.alloc(3 * (size_t)n_levels));
-    GK_TRY(gk_zero_async(ctx, meta.p, 12 * (size_t)n_levels));
+    GK_TRY(meta.alloc(4 * (size_t)n_levels));     // ... and [n_levels] active nodes of the levels run by the tiny kernel
+    GK_TRY(gk_zero_async(ctx, meta.p, 16 * (size_t)n_levels));
     if (out_rounds) *out_rounds = 0;
     b->n_sorted.assign((size_t)n_levels, V);
     RelabelState st(ctx);
     st.default_bits = default_bits;
     st.split = getenv("GK_WL_NO_SPLIT") == nullptr;
     st.full_level.assign((size_t)n_levels, 0);
+    st.list_scan = getenv("GK_WL_NO_LISTSCAN") == nullptr;
+    st.tiny = getenv("GK_WL_NO_TINY") == nullptr;
+    st.tiny_level.assign((size_t)n_levels, 0);
     GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
+    GK_TRY(st.act2.alloc(V / 4 + 1));      // active-set levels hold at most V/4 active nodes
     // level 0: group nodes by the given label ids
     {
         Tmp<u64> keys(ctx);
@@ -986,25 +1267,27 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p, 0,
                                     0, st.scratch.p + 2, st.split ? meta.p + 2 * n_levels : nullptr));
     }
-    std::vector<u32> h(3 * (size_t)n_levels);
+    std::vector<u32> h(4 * (size_t)n_levels);
     int first_bad = -1;
     for (int lvl = 1; lvl < n_levels; ++lvl)
         GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, st, meta.p + lvl, meta.p + n_levels + lvl,
-                             meta.p + 2 * n_levels + lvl, nullptr));
-    GK_TRY(gk_readback(ctx, meta.p, h.data(), 3 * n_levels));
+                             meta.p + 2 * n_levels + lvl, meta.p + 3 * n_levels + lvl, nullptr));
+    GK_TRY(gk_readback(ctx, meta.p, h.data(), 4 * n_levels));
     for (int lvl = 1; lvl < n_levels; ++lvl)
         if (h[n_levels + lvl] != 0) { first_bad = lvl; break; }
     if (first_bad > 0) {   // a hash collision was detected: redo from that level, exactly
         for (int lvl = first_bad; lvl < n_levels; ++lvl)
             GK_TRY(relabel_level(ctx, b, lvl, hash_bits, true, st, meta.p + lvl, meta.p + n_levels + lvl,
-                                 meta.p + 2 * n_levels + lvl, out_rounds));
-        GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 12 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
+                                 meta.p + 2 * n_levels + lvl, meta.p + 3 * n_levels + lvl, out_rounds));
+        GK_HIP_CHECK(hipMemcpyAsync(h.data(), meta.p, 16 * (size_t)n_levels, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     b->n_levels = n_levels;
     b->label_counts.resize(n_levels);
-    for (int lvl = 0; lvl < n_levels && V > 0; ++lvl)       // full levels only list the nodes of shared classes
+    for (int lvl = 0; lvl < n_levels && V > 0; ++lvl) {     // full levels only list the nodes of shared classes
         if (st.full_level[lvl]) b->n_sorted[lvl] = h[2 * n_levels + lvl];
+        else if (st.tiny_level[lvl]) b->n_sorted[lvl] += h[3 * n_levels + lvl];      // carried + active
+    }
     for (int lvl = 0; lvl < n_levels; ++lvl) {
         b->label_counts[lvl] = h[lvl];
         if (out_label_counts) out_label_counts[lvl] = h[lvl];

@@ -197,6 +197,27 @@ def test_level1_exact_signature_codes_and_their_limits(gk, n_labels, with_isolat
                           O.WLOracle(n_iter=3).fit_transform(only_isolated))
 
 
+@pytest.mark.parametrize("switch", ["", "GK_WL_NO_TINY", "GK_WL_NO_LISTSCAN", "GK_WL_NO_ISO", "GK_WL_NO_SPLIT",
+                                    "GK_WL_NO_EXACT1", "GK_WL_NO_ACTIVE_SET"])
+def test_every_relabel_path_gives_the_reference_partition(gk, switch, monkeypatch):
+    """The relabel loop picks among several equivalent routes per level (single-workgroup tail levels,
+    active list from the previous list or from all nodes, carried isolated classes, split listing, exact
+    level-1 codes, active sets at all); each switch removes one of them, the result must not move."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    X = er_dataset(500, 40, 0.07, 3, 17)          # sparse: isolated vertices, and the refinement needs ~6 levels
+    wl, K, levels = _oracle_levels(X, 7)
+    gb, _ = wl_batch_from_input(X)
+    eng = get_engine()
+    db = eng.upload(gb)
+    assert eng.wl_relabel(db, 7) == wl.label_counts
+    for lvl in range(8):
+        assert same_partition(eng.wl_labels(db, lvl), levels[lvl]), "level %d" % lvl
+    assert np.array_equal(eng.gram(eng.features(db, 8)), K)
+
+
 @pytest.mark.parametrize("bits", [3, 6, 10])
 def test_forced_hash_collisions_are_resolved_exactly(gk, bits):
     """Truncated hashes collide massively; the verify + refine loop must still be exact."""
