@@ -13,10 +13,23 @@
 //                        hash only proposes groups.  Any mismatch (a 64-bit collision) is
 //                        counted; the host then re-runs that level in "exact" mode, refining
 //                        groups with re-seeded hashes until no mismatch is left.
-// From level 2 on only the ACTIVE nodes go through 1-4: a node whose class is a singleton keeps a
-// class of its own for ever (ActiveScan / frozen_assign_verify_kernel).  The per-level sizes reach
-// the host through the mailbox of api.hip, not through a stream synchronisation.
-// HBM-bound integer work: algorithmic bytes per level 8E + 12V.
+// Work that cannot change the partition is not done (every switch below has a GK_WL_NO_* override,
+// tests/test_gpu_parity.py runs the job through each combination's removal):
+//   * level 1 with few input labels and small degrees: exact 32-bit signature codes instead of
+//     hashes -- no sorted lists, fewer digit passes, nothing to verify (wl_signature_exact_kernel);
+//   * a level that sorts every node splits its label-grouped order: nodes of classes >= 2 first
+//     (HeadAssignSplit); only those are "listed" for the label-count features;
+//   * from level 2 on only the ACTIVE nodes go through 1-4 once they are at most a quarter of the
+//     batch: a node whose class is a singleton keeps a class of its own for ever -- it is frozen, with
+//     a permanent id ([frozen | carried | active] id layout), so a level starts as a copy of the
+//     previous level's labels; the first such level finds the active nodes among all nodes
+//     (ActiveScan, frozen_assign_verify_kernel), the following ones compact the previous list
+//     (ActiveFromList, active_finish_kernel);
+//   * isolated vertices form one class per input label for ever: carried, never sorted again;
+//   * at most 1024 active nodes: the whole level is one single-workgroup launch
+//     (wl_tiny_level_kernel), no host read-back.
+// The per-level sizes reach the host through the mailbox of api.hip, not through a stream
+// synchronisation.  HBM-bound integer work: algorithmic bytes per level 8E + 12V.
 #include "common.h"
 #include "scan_fn.h"
 #include <stdio.h>
