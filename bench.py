@@ -134,12 +134,20 @@ def main():
         import __graft_entry__
         __graft_entry__.build()
     assert torch.cuda.is_available() and _lib.device_count() > 0, "bench.py needs MI355X GPUs"
+    # test hook (tests the N > 1 code path of this script on a ONE-GPU box): GK_BENCH_BACKEND=gloo puts
+    # every rank on device GK_BENCH_DEVICE and moves the shard messages with gloo; never set by the driver
+    backend = os.environ.get("GK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = int(os.environ.get("GK_BENCH_DEVICE", "0"))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(WORKLOAD)
     cfg["N"] = a.graphs

@@ -504,6 +504,32 @@ def test_sharded_path_two_processes_on_one_gpu(gk, tmp_path):
     assert np.array_equal(np.vstack(blocks), K)
 
 
+def test_bench_two_rank_code_path_on_one_gpu(gk):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), here
+    with both ranks on cuda:0 over gloo (GK_BENCH_BACKEND test hook): the script's sharded branch, its
+    max-over-ranks timing and its JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GK_BENCH_BACKEND="gloo", GK_BENCH_DEVICE="0")
+    port = 29100 + (os.getpid() % 800)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--graphs", "600"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["cpu_baseline"] is None and d["roofline"]["traffic"] is None
+    from grakel_amd import GraphBatch
+    from grakel_amd.engine import get_engine
+    eng = get_engine()
+    db = eng.upload(GraphBatch(*er_dataset_csr(600, 100, 0.05, 5, 0), 5))
+    assert d["config"]["label_counts"] == eng.wl_relabel(db, 5)
+
+
 # ------------------------------------------------------------------------------------------
 # edge cases (ragged / degenerate inputs), each against the CPU oracle
 # ------------------------------------------------------------------------------------------
