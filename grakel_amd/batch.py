@@ -457,6 +457,22 @@ def _sp_graph_arrays(gobj, labels, with_labels):
 def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_iterable=TypeError):
     if isinstance(X, GraphBatch):
         return X, None
+    if _gk_ingest is not None and len_ok is None and type(X) in (list, tuple) and hasattr(_gk_ingest, "sp_ingest"):
+        # adjacency arrays / int-keyed edge dictionaries with integer weights: the same walk in C
+        # (csrc/ingest.c); None = not recognised, the Python path below takes the whole input
+        r = _gk_ingest.sp_ingest(X, bool(with_labels), 2 if with_labels else 1, 3)
+        if r is not None:
+            sizes, row_ptr, col, w, values = r
+            sizes = np.frombuffer(sizes, dtype=np.int32)
+            graph_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+            np.cumsum(sizes, out=graph_ptr[1:])
+            if with_labels:
+                ids, mapping = compress_labels(values, fitted_labels)
+                n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
+            else:
+                ids, mapping, n_labels = np.zeros(int(graph_ptr[-1]), np.int32), {}, 1
+            return GraphBatch(graph_ptr, np.frombuffer(row_ptr, dtype=np.int32), np.frombuffer(col, dtype=np.int32), ids,
+                              max(n_labels, 1), edge_weight=np.frombuffer(w, dtype=np.int32)), mapping
     msg = 'each element of X must have at least one and at most 3 elements\n'
     ok = (lambda n: n in (2, 3)) if with_labels else (lambda n: n in (1, 2, 3))
     if len_ok is not None:

@@ -67,14 +67,28 @@ static size_t sort_unique(int32_t* row, size_t m) {
 
 enum { ST_OK = 0, ST_DECLINE = 1, ST_ERROR = 2 };
 
+/* integer value of an exact int, or of anything with __index__ (numpy integer scalars, bool): such
+ * objects hash and compare like the int, so dictionary semantics are unchanged.  ST_DECLINE otherwise. */
+static int int_value(PyObject* o, long long* out) {
+    int overflow = 0;
+    if (PyLong_CheckExact(o)) {
+        *out = PyLong_AsLongLongAndOverflow(o, &overflow);
+        return overflow ? ST_DECLINE : ST_OK;
+    }
+    if (!PyIndex_Check(o) || PyFloat_Check(o)) return ST_DECLINE;
+    PyObject* i = PyNumber_Index(o);
+    if (!i) { PyErr_Clear(); return ST_DECLINE; }
+    *out = PyLong_AsLongLongAndOverflow(i, &overflow);
+    Py_DECREF(i);
+    return overflow ? ST_DECLINE : ST_OK;
+}
+
 /* index of neighbour `nb` among the n labelled vertices of the current graph */
 static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* pos, Py_ssize_t* out) {
     if (identity) {
-        if (!PyLong_CheckExact(nb)) return ST_DECLINE;
-        int overflow = 0;
-        long long j = PyLong_AsLongLongAndOverflow(nb, &overflow);
-        if (overflow || j < 0 || j >= (long long)n) {
-            if (!overflow && j == -1 && PyErr_Occurred()) return ST_ERROR;
+        long long j;
+        if (int_value(nb, &j) != ST_OK) return ST_DECLINE;
+        if (j < 0 || j >= (long long)n) {
             PyErr_SetObject(PyExc_KeyError, nb);          /* unlabelled neighbour */
             return ST_ERROR;
         }
@@ -218,7 +232,275 @@ done:;
     return result;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * ShortestPath ingestion (batch.py: sp_batch_from_input / _sp_graph_arrays).  Nodes are ALL vertices
+ * of the graph: 0..n-1 for an adjacency matrix (graph.py:912-981), the sorted vertex symbols for an
+ * edge dictionary (graph.py:894-907) -- handled here only when every symbol is an exact int.
+ *   sp_ingest(X, with_labels, min_len, max_len) -> None | (sizes, row_ptr, col_idx, weight, values)
+ * Weights must be positive integers below 2^20 (what the device path supports); anything else is
+ * declined so that the Python path raises what it raises.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int64_t key; int32_t w; } edge_t;      /* key = src * n + dst (local indices) */
+
+static int cmp_edge(const void* a, const void* b) {
+    int64_t x = ((const edge_t*)a)->key, y = ((const edge_t*)b)->key;
+    return (x > y) - (x < y);
+}
+static int cmp64(const void* a, const void* b) {
+    int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+    return (x > y) - (x < y);
+}
+static Py_ssize_t find64(const int64_t* a, Py_ssize_t n, int64_t x) {
+    Py_ssize_t lo = 0, hi = n;
+    while (lo < hi) { Py_ssize_t m = (lo + hi) >> 1; if (a[m] < x) lo = m + 1; else hi = m; }
+    return lo;      /* present by construction */
+}
+
+/* exact int -> int64, or decline */
+static int as_i64(PyObject* o, int64_t* out) {
+    long long v;
+    if (int_value(o, &v) != ST_OK) return ST_DECLINE;
+    *out = (int64_t)v;
+    return ST_OK;
+}
+
+/* a weight the device path takes: positive integer < 2^20 (int, or float with an integer value) */
+static int as_weight(PyObject* o, int32_t* out) {
+    double d;
+    if (PyLong_CheckExact(o)) {
+        int overflow = 0;
+        long long v = PyLong_AsLongLongAndOverflow(o, &overflow);
+        if (overflow || v <= 0 || v >= (1 << 20)) return ST_DECLINE;
+        *out = (int32_t)v;
+        return ST_OK;
+    }
+    if (!PyFloat_CheckExact(o)) return ST_DECLINE;
+    d = PyFloat_AS_DOUBLE(o);
+    if (!(d > 0.0) || d >= 1048576.0 || d != (double)(int32_t)d) return ST_DECLINE;
+    *out = (int32_t)d;
+    return ST_OK;
+}
+
+typedef struct { int64_t* p; size_t n, cap; } vec64;
+typedef struct { edge_t* p; size_t n, cap; } vecE;
+static int v64_push(vec64* v, int64_t x) {
+    if (v->n == v->cap) {
+        size_t nc = v->cap ? v->cap * 2 : 1024;
+        int64_t* q = (int64_t*)realloc(v->p, nc * sizeof(int64_t));
+        if (!q) return -1;
+        v->p = q, v->cap = nc;
+    }
+    v->p[v->n++] = x;
+    return 0;
+}
+static int vE_push(vecE* v, int64_t key, int32_t w) {
+    if (v->n == v->cap) {
+        size_t nc = v->cap ? v->cap * 2 : 1024;
+        edge_t* q = (edge_t*)realloc(v->p, nc * sizeof(edge_t));
+        if (!q) return -1;
+        v->p = q, v->cap = nc;
+    }
+    v->p[v->n].key = key, v->p[v->n].w = w;
+    ++v->n;
+    return 0;
+}
+
+static PyObject* sp_ingest(PyObject* self, PyObject* args) {
+    PyObject* X;
+    int with_labels = 1;
+    Py_ssize_t min_len = 1, max_len = 3;
+    if (!PyArg_ParseTuple(args, "Op|nn", &X, &with_labels, &min_len, &max_len)) return NULL;
+    if (!PyList_CheckExact(X) && !PyTuple_CheckExact(X)) Py_RETURN_NONE;
+    const Py_ssize_t n_el = PySequence_Fast_GET_SIZE(X);
+    if (n_el == 0) Py_RETURN_NONE;
+
+    vec32 sizes = {0}, rowp = {0}, col = {0}, wts = {0};
+    vec64 verts = {0};
+    vecE edges = {0};
+    PyObject* values = PyList_New(0);
+    int status = ST_OK;
+    int64_t V = 0;
+    if (!values || vec_push(&rowp, 0)) { status = ST_ERROR; PyErr_NoMemory(); goto done; }
+
+    for (Py_ssize_t e = 0; e < n_el && status == ST_OK; ++e) {
+        PyObject* x = PySequence_Fast_GET_ITEM(X, e);
+        if (!PyList_CheckExact(x) && !PyTuple_CheckExact(x)) { status = ST_DECLINE; break; }
+        const Py_ssize_t xl = PySequence_Fast_GET_SIZE(x);
+        if (xl < min_len || xl < 1 || (max_len > 0 && xl > max_len)) { status = ST_DECLINE; break; }
+        PyObject* g = PySequence_Fast_GET_ITEM(x, 0);
+        PyObject* labels = xl > 1 ? PySequence_Fast_GET_ITEM(x, 1) : NULL;
+        if (with_labels && !(labels && PyDict_CheckExact(labels) && PyDict_GET_SIZE(labels) > 0)) { status = ST_DECLINE; break; }
+        Py_ssize_t n = 0;
+        edges.n = 0, verts.n = 0;
+        int is_matrix = 0;
+
+        if (PyDict_CheckExact(g)) {
+            if (PyDict_GET_SIZE(g) == 0) { status = ST_DECLINE; break; }
+            int all_list = 1, all_dict = 1;
+            Py_ssize_t it = 0;
+            PyObject *k, *d;
+            while (PyDict_Next(g, &it, &k, &d)) {
+                if (!PyList_CheckExact(d)) all_list = 0;
+                if (!PyDict_CheckExact(d)) all_dict = 0;
+                if (!all_list && !all_dict) break;
+            }
+            if (!all_list && !all_dict) { status = ST_DECLINE; break; }
+            /* pass 1: vertex symbols */
+            it = 0;
+            while (PyDict_Next(g, &it, &k, &d) && status == ST_OK) {
+                int64_t a;
+                if ((status = as_i64(k, &a)) != ST_OK) break;
+                if (v64_push(&verts, a)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                if (all_list) {
+                    for (Py_ssize_t q = 0; q < PyList_GET_SIZE(d); ++q) {
+                        int64_t bnb;
+                        if ((status = as_i64(PyList_GET_ITEM(d, q), &bnb)) != ST_OK) break;
+                        if (v64_push(&verts, bnb)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                    }
+                } else {
+                    Py_ssize_t it2 = 0;
+                    PyObject *nb, *w;
+                    while (PyDict_Next(d, &it2, &nb, &w)) {
+                        int64_t bnb;
+                        if ((status = as_i64(nb, &bnb)) != ST_OK) break;
+                        if (v64_push(&verts, bnb)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                    }
+                }
+            }
+            if (status != ST_OK) break;
+            qsort(verts.p, verts.n, sizeof(int64_t), cmp64);
+            {
+                size_t w = 0;
+                for (size_t i = 0; i < verts.n; ++i)
+                    if (w == 0 || verts.p[i] != verts.p[w - 1]) verts.p[w++] = verts.p[i];
+                verts.n = w;
+            }
+            n = (Py_ssize_t)verts.n;
+            /* pass 2: edges with local indices */
+            it = 0;
+            while (PyDict_Next(g, &it, &k, &d) && status == ST_OK) {
+                int64_t a = 0;
+                as_i64(k, &a);
+                const int64_t ia = find64(verts.p, n, a);
+                if (all_list) {
+                    for (Py_ssize_t q = 0; q < PyList_GET_SIZE(d); ++q) {
+                        int64_t bnb = 0;
+                        as_i64(PyList_GET_ITEM(d, q), &bnb);
+                        if (vE_push(&edges, ia * n + find64(verts.p, n, bnb), 1)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                    }
+                } else {
+                    Py_ssize_t it2 = 0;
+                    PyObject *nb, *w;
+                    while (PyDict_Next(d, &it2, &nb, &w)) {
+                        int64_t bnb = 0;
+                        int32_t wi;
+                        as_i64(nb, &bnb);
+                        if ((status = as_weight(w, &wi)) != ST_OK) break;
+                        if (vE_push(&edges, ia * n + find64(verts.p, n, bnb), wi)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                    }
+                }
+            }
+            if (status != ST_OK) break;
+            qsort(edges.p, edges.n, sizeof(edge_t), cmp_edge);
+            {   /* duplicates only arise from repeated list entries (all weight 1): keep one */
+                size_t w = 0;
+                for (size_t i = 0; i < edges.n; ++i)
+                    if (w == 0 || edges.p[i].key != edges.p[w - 1].key) edges.p[w++] = edges.p[i];
+                edges.n = w;
+            }
+        } else {
+            /* adjacency matrix through the buffer protocol: 2-D, C-contiguous, a plain numeric type */
+            Py_buffer view;
+            if (!PyObject_CheckBuffer(g) || PyDict_Check(g) || PyBytes_Check(g) || PyByteArray_Check(g)) { status = ST_DECLINE; break; }
+            if (PyObject_GetBuffer(g, &view, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS | PyBUF_ND) != 0) { PyErr_Clear(); status = ST_DECLINE; break; }
+            const char* f = view.format ? view.format : "B";
+            if (*f == '@' || *f == '=' || *f == '<') ++f;
+            const char code = f[0];
+            const int known = f[1] == 0 && ((code == 'l' && view.itemsize == 8) || (code == 'q' && view.itemsize == 8) ||
+                                            (code == 'i' && view.itemsize == 4) || (code == 'd' && view.itemsize == 8) ||
+                                            (code == 'B' && view.itemsize == 1) || (code == '?' && view.itemsize == 1));
+            if (view.ndim != 2 || view.shape[0] != view.shape[1] || !known || view.shape[0] == 0) {
+                PyBuffer_Release(&view);
+                status = ST_DECLINE;
+                break;
+            }
+            n = view.shape[0];
+            is_matrix = 1;
+            const char* base = (const char*)view.buf;
+            for (Py_ssize_t i = 0; i < n && status == ST_OK; ++i)
+                for (Py_ssize_t jx = 0; jx < n; ++jx) {
+                    const char* p = base + (i * n + jx) * view.itemsize;
+                    double d;
+                    if (code == 'l' || code == 'q') d = (double)*(const int64_t*)p;
+                    else if (code == 'i') d = (double)*(const int32_t*)p;
+                    else if (code == 'd') d = *(const double*)p;
+                    else d = (double)*(const unsigned char*)p;
+                    if (d == 0.0) continue;
+                    if (!(d > 0.0) || d >= 1048576.0 || d != (double)(int32_t)d) { status = ST_DECLINE; break; }
+                    if (vE_push(&edges, (int64_t)i * n + jx, (int32_t)d)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                }
+            PyBuffer_Release(&view);
+            if (status != ST_OK) break;
+        }
+        if (V + n >= 2147483647LL || col.n + edges.n >= 2147483647ULL) { status = ST_DECLINE; break; }
+
+        /* labels in vertex order: labels[v] for v in verts (KeyError like the reference) */
+        if (with_labels) {
+            for (Py_ssize_t i = 0; i < n; ++i) {
+                PyObject* key = PyLong_FromLongLong(is_matrix ? (long long)i : (long long)verts.p[i]);
+                if (!key) { status = ST_ERROR; break; }
+                PyObject* lv = PyDict_GetItemWithError(labels, key);
+                if (!lv) {
+                    if (!PyErr_Occurred()) PyErr_SetObject(PyExc_KeyError, key);
+                    Py_DECREF(key);
+                    status = ST_ERROR;
+                    break;
+                }
+                Py_DECREF(key);
+                if (PyList_Append(values, lv)) { status = ST_ERROR; break; }
+            }
+            if (status != ST_OK) break;
+        }
+        /* CSR rows of this graph */
+        {
+            size_t q = 0;
+            for (Py_ssize_t i = 0; i < n && status == ST_OK; ++i) {
+                while (q < edges.n && edges.p[q].key / n == i) {
+                    if (vec_push(&col, (int32_t)(V + edges.p[q].key % n)) || vec_push(&wts, edges.p[q].w)) {
+                        status = ST_ERROR; PyErr_NoMemory(); break;
+                    }
+                    ++q;
+                }
+                if (status == ST_OK && vec_push(&rowp, (int32_t)col.n)) { status = ST_ERROR; PyErr_NoMemory(); }
+            }
+        }
+        if (status != ST_OK) break;
+        if (vec_push(&sizes, (int32_t)n)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+        V += n;
+    }
+
+done:;
+    PyObject* result = NULL;
+    if (status == ST_OK) {
+        PyObject* a = PyByteArray_FromStringAndSize((const char*)sizes.p, (Py_ssize_t)(sizes.n * 4));
+        PyObject* b = PyByteArray_FromStringAndSize((const char*)rowp.p, (Py_ssize_t)(rowp.n * 4));
+        PyObject* c = PyByteArray_FromStringAndSize((const char*)col.p, (Py_ssize_t)(col.n * 4));
+        PyObject* d = PyByteArray_FromStringAndSize((const char*)wts.p, (Py_ssize_t)(wts.n * 4));
+        if (a && b && c && d) result = PyTuple_Pack(5, a, b, c, d, values);
+        Py_XDECREF(a); Py_XDECREF(b); Py_XDECREF(c); Py_XDECREF(d);
+    } else if (status == ST_DECLINE) {
+        if (PyErr_Occurred()) PyErr_Clear();
+        result = Py_None;
+        Py_INCREF(result);
+    }
+    Py_XDECREF(values);
+    free(sizes.p); free(rowp.p); free(col.p); free(wts.p); free(verts.p); free(edges.p);
+    return result;
+}
+
 static PyMethodDef methods[] = {
+    {"sp_ingest", sp_ingest, METH_VARARGS,
+     "sp_ingest(X, with_labels, min_len=1, max_len=3) -> None | (sizes, row_ptr, col_idx, weight, values)"},
     {"wl_ingest", wl_ingest, METH_VARARGS,
      "wl_ingest(X, min_len=2) -> None | (sizes, row_ptr, col_idx, values): see grakel_amd/csrc/ingest.c"},
     {NULL, NULL, 0, NULL}};

@@ -143,6 +143,71 @@ def test_c_ingestion_fast_path_equals_the_python_path():
     assert _both_paths(cases["unlabelled_neighbour"])[0][:2] == ("raise", KeyError)
 
 
+def test_c_sp_ingestion_fast_path_equals_the_python_path():
+    from grakel_amd import batch as B
+    from grakel_amd.synthetic import nci1_like
+    _both_paths([[{0: [1], 1: [0]}, {0: 1, 1: 2}]])            # builds / loads the C module if needed
+
+    def run(X, with_labels, **kw):
+        try:
+            gb, m = B.sp_batch_from_input(X, with_labels, **kw)
+            return ("ok", gb.graph_ptr.tolist(), gb.row_ptr.tolist(), gb.col_idx.tolist(), gb.node_label.tolist(),
+                    gb.edge_weight.tolist(), gb.n_labels, m)
+        except Exception as e:                      # noqa: BLE001
+            return ("raise", type(e), e.args)
+
+    def both(X, with_labels=True, **kw):
+        fast = run(X, with_labels, **kw)
+        saved, B._gk_ingest = B._gk_ingest, None
+        try:
+            slow = run(X, with_labels, **kw)
+        finally:
+            B._gk_ingest = saved
+        return fast, slow
+    rs = np.random.RandomState(2)
+    A = (rs.rand(6, 6) < 0.4).astype(np.int64)
+    np.fill_diagonal(A, 0)
+    lab6 = {i: "abc"[i % 3] for i in range(6)}
+    cases = {
+        "nci1_adjacency": nci1_like(60, 0, as_adj=True),
+        "nci1_dicts": nci1_like(60, 0, as_adj=False),
+        "weights_int64": [[A * 3, lab6]],
+        "weights_float64_integral": [[(A * 2).astype(np.float64), lab6]],
+        "bool_matrix": [[A.astype(bool), lab6]],
+        "uint8_int32": [[A.astype(np.uint8), lab6], [A.astype(np.int32), lab6]],
+        "float32_declines": [[A.astype(np.float32), lab6]],
+        "fortran_order_declines": [[np.asfortranarray(A), lab6]],
+        "non_square": [[np.ones((2, 3), np.int64), {0: 1, 1: 2}]],
+        "negative_weight": [[-A, lab6]],
+        "fractional_weight": [[A * 0.5, lab6]],
+        "huge_weight": [[A * (2 ** 20), lab6]],
+        "dict_of_dicts_weights": [[{5: {9: 2, 7: 3.0}, 9: {5: 2}, 7: {}}, {5: 'x', 7: 'y', 9: 'x'}]],
+        "zero_weight_in_dict": [[{0: {1: 0}, 1: {0: 1}}, {0: 1, 1: 1}]],
+        "float_weight_in_dict": [[{0: {1: 0.5}, 1: {0: 1}}, {0: 1, 1: 1}]],
+        "vertex_only_as_neighbour": [[{3: [8, 8, 1]}, {1: 'a', 3: 'b', 8: 'c'}]],
+        "missing_label": [[{0: [1], 1: [0]}, {0: 'a'}]],
+        "missing_label_matrix": [[A, {0: 'a'}]],
+        "empty_labels": [[A, {}]],
+        "string_vertices_decline": [[{'a': ['b'], 'b': ['a']}, {'a': 1, 'b': 2}]],
+        "tuple_keys_decline": [[{(0, 1): 1, (1, 0): 1}, {0: 1, 1: 2}]],
+        "list_of_lists_declines": [[A.tolist(), lab6]],
+        "extras": [(A, lab6, {}), (A * 2, lab6)],
+        "too_long": [(A, lab6, {}, "x")],
+        "mixed": nci1_like(5, 1, as_adj=True) + nci1_like(5, 2, as_adj=False),
+    }
+    for name, X in cases.items():
+        fast, slow = both(X)
+        assert fast == slow, name
+    for name in ("nci1_adjacency", "nci1_dicts", "missing_label_matrix", "empty_labels"):
+        X = [[x[0]] for x in cases[name]]                     # unlabelled: one-element inputs are fine
+        assert both(X, False)[0] == both(X, False)[1], name
+        assert both(cases[name], False)[0] == both(cases[name], False)[1], name
+    assert both(cases["nci1_adjacency"], True, fitted_labels={0: 0, 1: 1})[0][0] == "ok"
+    fast, slow = both(cases["nci1_dicts"], True, fitted_labels={0: 0, 1: 1})
+    assert fast == slow
+    assert both(cases["missing_label"])[0][:2] == ("raise", KeyError)
+
+
 def test_label_compression_fit_and_transform():
     ids, m = compress_labels(['b', 'a', 'c', 'a'])
     assert ids.tolist() == [1, 0, 2, 0] and m == {'a': 0, 'b': 1, 'c': 2}
