@@ -208,6 +208,59 @@ def test_c_sp_ingestion_fast_path_equals_the_python_path():
     assert both(cases["missing_label"])[0][:2] == ("raise", KeyError)
 
 
+def test_c_ingestion_never_diverges_from_the_python_path_on_random_inputs():
+    """Property test: whatever mixture of vertex symbols, edge-dictionary forms, weights and label
+    dictionaries, the C helper either declines or produces exactly what the Python path produces --
+    the same batch or the same exception."""
+    hyp = pytest.importorskip("hypothesis")
+    st = hyp.strategies
+    import warnings
+    from grakel_amd import batch as B
+    _both_paths([[{0: [1], 1: [0]}, {0: 1, 1: 2}]])            # builds / loads the C module if needed
+    symbols = st.sampled_from([0, 1, 2, 3, 4, 7, -1, 10 ** 12, True, 1.0, 2.5, "a", "b", (1, 2), np.int64(3), np.int32(1)])
+    weights = st.sampled_from([1, 2, 3, 2.0, 1.0, 0, 0.5, -1, 2 ** 20, True, 7])
+    labels_v = st.sampled_from([0, 1, 2, "x", "y", (1,), 3.5])
+
+    @st.composite
+    def element(draw):
+        verts = draw(st.lists(symbols, min_size=1, max_size=6, unique_by=lambda v: (hash(v), v == v)))
+        form = draw(st.sampled_from(["lists", "dicts"]))
+        g = {}
+        for v in draw(st.lists(st.sampled_from(verts), max_size=6)):
+            nbrs = draw(st.lists(st.sampled_from(verts + [99]), max_size=4))
+            g[v] = list(nbrs) if form == "lists" else {nb: draw(weights) for nb in nbrs}
+        if draw(st.booleans()) and all(isinstance(v, int) and not isinstance(v, bool) and 0 <= v < 8 for v in verts):
+            lab = {i: draw(labels_v) for i in range(max(verts) + 1)}      # identity numbering 0..n-1
+        else:
+            lab = {v: draw(labels_v) for v in draw(st.lists(st.sampled_from(verts + [99]), max_size=7))}
+        extra = draw(st.sampled_from([(), ({},), ({}, "z")]))
+        return draw(st.sampled_from([list, tuple]))((g, lab) + extra)
+
+    def sp_run(X, with_labels):
+        try:
+            gb, m = B.sp_batch_from_input(X, with_labels)
+            return ("ok", gb.graph_ptr.tolist(), gb.row_ptr.tolist(), gb.col_idx.tolist(), gb.node_label.tolist(),
+                    gb.edge_weight.tolist(), gb.n_labels, m)
+        except Exception as e:                      # noqa: BLE001
+            return ("raise", type(e), e.args)
+
+    @hyp.settings(max_examples=300, deadline=None, suppress_health_check=list(hyp.HealthCheck))
+    @hyp.given(st.lists(element(), min_size=1, max_size=4), st.booleans())
+    def check(X, with_labels):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fast, slow = _both_paths(X)
+            assert fast == slow
+            fast = sp_run(X, with_labels)
+            saved, B._gk_ingest = B._gk_ingest, None
+            try:
+                slow = sp_run(X, with_labels)
+            finally:
+                B._gk_ingest = saved
+            assert fast == slow
+    check()
+
+
 def test_label_compression_fit_and_transform():
     ids, m = compress_labels(['b', 'a', 'c', 'a'])
     assert ids.tolist() == [1, 0, 2, 0] and m == {'a': 0, 'b': 1, 'c': 2}
