@@ -65,6 +65,14 @@ static size_t sort_unique(int32_t* row, size_t m) {
     return w;
 }
 
+/* raise KeyError(key) -- PyErr_SetObject alone would unpack a tuple key into the exception's args */
+static void set_key_error(PyObject* key) {
+    PyObject* t = PyTuple_Pack(1, key);
+    if (!t) return;
+    PyErr_SetObject(PyExc_KeyError, t);
+    Py_DECREF(t);
+}
+
 enum { ST_OK = 0, ST_DECLINE = 1, ST_ERROR = 2 };
 
 /* integer value of an exact int, or of anything with __index__ (numpy integer scalars, bool): such
@@ -89,7 +97,7 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
         long long j;
         if (int_value(nb, &j) != ST_OK) return ST_DECLINE;
         if (j < 0 || j >= (long long)n) {
-            PyErr_SetObject(PyExc_KeyError, nb);          /* unlabelled neighbour */
+            set_key_error(nb);          /* unlabelled neighbour */
             return ST_ERROR;
         }
         *out = (Py_ssize_t)j;
@@ -98,7 +106,7 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
     PyObject* idx = PyDict_GetItemWithError(pos, nb);     /* borrowed */
     if (!idx) {
         if (PyErr_Occurred()) { PyErr_Clear(); return ST_DECLINE; }   /* unhashable symbol: let Python decide */
-        PyErr_SetObject(PyExc_KeyError, nb);
+        set_key_error(nb);
         return ST_ERROR;
     }
     *out = PyLong_AsSsize_t(idx);
@@ -451,7 +459,7 @@ static PyObject* sp_ingest(PyObject* self, PyObject* args) {
                 if (!key) { status = ST_ERROR; break; }
                 PyObject* lv = PyDict_GetItemWithError(labels, key);
                 if (!lv) {
-                    if (!PyErr_Occurred()) PyErr_SetObject(PyExc_KeyError, key);
+                    if (!PyErr_Occurred()) set_key_error(key);
                     Py_DECREF(key);
                     status = ST_ERROR;
                     break;

@@ -244,7 +244,7 @@ def test_c_ingestion_never_diverges_from_the_python_path_on_random_inputs():
         except Exception as e:                      # noqa: BLE001
             return ("raise", type(e), e.args)
 
-    @hyp.settings(max_examples=300, deadline=None, suppress_health_check=list(hyp.HealthCheck))
+    @hyp.settings(max_examples=400, deadline=None, suppress_health_check=list(hyp.HealthCheck))
     @hyp.given(st.lists(element(), min_size=1, max_size=4), st.booleans())
     def check(X, with_labels):
         with warnings.catch_warnings():
