@@ -254,6 +254,28 @@ def wloa_batch_from_input(X, fitted_labels=None, fit=True):
     taken as adjacency-style input: every vertex owns an entry."""
     if isinstance(X, GraphBatch):
         return X, None
+    if _gk_ingest is not None and type(X) in (list, tuple):
+        # plain `[edge dict, label dict, ...]` elements: the walk and the entry flags in C (csrc/ingest.c);
+        # the restriction to the vertices with an entry is then one vectorised pass over the batch
+        r = _gk_ingest.wl_ingest(X, 2, True, 0 if fit else 3)
+        if r is not None:
+            sizes, row_ptr, col, values, mask = r
+            ids, mapping = compress_labels(values, fitted_labels)
+            n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
+            sizes = np.frombuffer(sizes, dtype=np.int32)
+            row_ptr = np.frombuffer(row_ptr, dtype=np.int32)
+            col = np.frombuffer(col, dtype=np.int32)
+            mask = np.frombuffer(mask, dtype=np.uint8).astype(bool)
+            graph_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+            np.cumsum(sizes, out=graph_ptr[1:])
+            if not mask.all():
+                new = np.cumsum(mask, dtype=np.int64) - 1
+                src = np.repeat(np.arange(len(mask), dtype=np.int64), np.diff(row_ptr))
+                kept = np.concatenate([[0], np.cumsum(mask, dtype=np.int64)])
+                graph_ptr = kept[graph_ptr]                     # vertices with an entry before each graph
+                row_ptr, col, _ = _csr_from_global(int(graph_ptr[-1]), new[src], new[col.astype(np.int64)])
+                ids = ids[mask]
+            return GraphBatch(graph_ptr, row_ptr, col, np.ascontiguousarray(ids), max(n_labels, 1)), mapping
     if fit:
         len_ok, err = (lambda n: n >= 2), TypeError
         msg = ('each element of X must be either a graph object or a list with at least a graph '
@@ -322,6 +344,12 @@ def _pack_csr(n_nodes_per_graph, srcs, dsts, weights=None):
     src = (np.concatenate(srcs) if srcs else np.zeros(0, np.int64)) + offs
     dst = (np.concatenate(dsts) if dsts else np.zeros(0, np.int64)) + offs
     w = np.concatenate(weights) if weights is not None and weights else None
+    row_ptr, dst, w = _csr_from_global(V, src, dst, w)
+    return graph_ptr, row_ptr, dst, w
+
+
+def _csr_from_global(V, src, dst, w=None):
+    """Global (src, dst[, w]) edge arrays over V nodes -> (row_ptr, col_idx, w), sorted and de-duplicated."""
     key = src * np.int64(V if V > 0 else 1) + dst
     if key.size and not np.all(key[1:] > key[:-1]):
         # not already (src,dst)-sorted & unique: sort and collapse duplicates (dict semantics:
@@ -335,7 +363,7 @@ def _pack_csr(n_nodes_per_graph, srcs, dsts, weights=None):
             w = w[order][last]
     row_ptr = np.zeros(V + 1, dtype=np.int64)
     np.cumsum(np.bincount(src, minlength=V), out=row_ptr[1:])
-    return graph_ptr, row_ptr, dst, w
+    return row_ptr, dst, w
 
 
 def wl_batch_from_input(X, fitted_labels=None, min_len=2, not_iterable=TypeError):

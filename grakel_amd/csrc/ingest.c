@@ -11,7 +11,7 @@
  * error the reference raises -- handles the whole input.  tests/test_host.py checks that both
  * paths produce identical batches.
  *
- *   wl_ingest(X: list, min_len: int) -> None | (sizes, row_ptr, col_idx, values)
+ *   wl_ingest(X: list, min_len: int, want_mask=False, max_len=0) -> None | (sizes, row_ptr, col_idx, values[, mask])
  *       sizes   bytearray of int32[n_graphs]     nodes per graph (= labelled vertices)
  *       row_ptr bytearray of int32[V + 1]
  *       col_idx bytearray of int32[E]            GLOBAL node ids, ascending and unique per row
@@ -115,14 +115,21 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
 
 static PyObject* wl_ingest(PyObject* self, PyObject* args) {
     PyObject* X;
-    Py_ssize_t min_len = 2;
-    if (!PyArg_ParseTuple(args, "O|n", &X, &min_len)) return NULL;
+    Py_ssize_t min_len = 2, max_len = 0;
+    int want_mask = 0;
+    if (!PyArg_ParseTuple(args, "O|npn", &X, &min_len, &want_mask, &max_len)) return NULL;
     if (!PyList_CheckExact(X) && !PyTuple_CheckExact(X)) Py_RETURN_NONE;
     const Py_ssize_t n_el = PySequence_Fast_GET_SIZE(X);
     if (n_el == 0) Py_RETURN_NONE;
     if (min_len < 2) min_len = 2;
 
     vec32 sizes = {0}, rowp = {0}, col = {0}, tmp = {0};
+    /* want_mask (WL-OA, weisfeiler_lehman_optimal_assignment.py:176): per labelled vertex, does it own an
+     * entry in the reference's edge dictionary?  dict of lists: a key with a non-empty list, or a vertex
+     * that only occurs as a neighbour; dict of dicts: any key or neighbour (batch.py: _edge_lists).
+     * flag bits per vertex: 1 = key of g, 2 = key with out-edges, 4 = somebody's neighbour */
+    unsigned char* flag = NULL;
+    size_t flag_cap = 0;
     PyObject* values = PyList_New(0);
     PyObject* pos = NULL;
     int status = ST_OK;
@@ -133,6 +140,7 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
         PyObject* x = PySequence_Fast_GET_ITEM(X, e);
         if (!PyList_CheckExact(x) && !PyTuple_CheckExact(x)) { status = ST_DECLINE; break; }
         if (PySequence_Fast_GET_SIZE(x) < min_len) { status = ST_DECLINE; break; }
+        if (max_len > 0 && PySequence_Fast_GET_SIZE(x) > max_len) { status = ST_DECLINE; break; }
         PyObject* g = PySequence_Fast_GET_ITEM(x, 0);
         PyObject* labels = PySequence_Fast_GET_ITEM(x, 1);
         if (!PyDict_CheckExact(g) || !PyDict_CheckExact(labels)) { status = ST_DECLINE; break; }
@@ -142,16 +150,28 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
 
         /* form of the edge dictionary: all values lists, or all values dicts (graph.py:1640-1690) */
         int all_list = 1, all_dict = 1;
+        Py_ssize_t g_nonempty = 0;                 /* keys of g with out-edges */
         {
             Py_ssize_t it = 0;
             PyObject *k, *d;
             while (PyDict_Next(g, &it, &k, &d)) {
-                if (!PyList_CheckExact(d)) all_list = 0;
-                if (!PyDict_CheckExact(d)) all_dict = 0;
+                if (!PyList_CheckExact(d)) all_list = 0; else if (PyList_GET_SIZE(d) > 0) ++g_nonempty;
+                if (!PyDict_CheckExact(d)) all_dict = 0; else if (PyDict_GET_SIZE(d) > 0) ++g_nonempty;
                 if (!all_list && !all_dict) break;
             }
         }
         if (!all_list && !all_dict) { status = ST_DECLINE; break; }
+        if (want_mask) {
+            if ((size_t)(V + n) > flag_cap) {
+                size_t nc = flag_cap ? flag_cap * 2 : 65536;
+                while (nc < (size_t)(V + n)) nc *= 2;
+                unsigned char* q = (unsigned char*)realloc(flag, nc);
+                if (!q) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                flag = q, flag_cap = nc;
+            }
+            memset(flag + V, 0, (size_t)n);
+        }
+        Py_ssize_t lab_in_g = 0, lab_nonempty = 0;  /* the same counts over the LABELLED keys */
 
         /* identity numbering: the label keys are exactly 0, 1, ..., n-1 in this order */
         int identity = 1;
@@ -190,6 +210,12 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
             PyObject* d = PyDict_GetItemWithError(g, k);          /* borrowed; absent: no out-edges */
             if (!d && PyErr_Occurred()) { PyErr_Clear(); status = ST_DECLINE; break; }
             tmp.n = 0;
+            if (d) {
+                const int has = all_list ? PyList_GET_SIZE(d) > 0 : PyDict_GET_SIZE(d) > 0;
+                ++lab_in_g;
+                lab_nonempty += has;
+                if (want_mask) flag[rowp.n - 1] |= (unsigned char)(1 | (has ? 2 : 0));     /* rowp.n - 1 == this vertex */
+            }
             if (d && all_list) {
                 const Py_ssize_t m = PyList_GET_SIZE(d);
                 for (Py_ssize_t q = 0; q < m; ++q) {
@@ -211,12 +237,23 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
             }
             if (status != ST_OK) break;
             const size_t m = sort_unique(tmp.p, tmp.n);
-            for (size_t q = 0; q < m; ++q)
+            for (size_t q = 0; q < m; ++q) {
+                if (want_mask) flag[tmp.p[q]] |= 4;
                 if (vec_push(&col, tmp.p[q])) { status = ST_ERROR; PyErr_NoMemory(); break; }
+            }
             if (col.n >= 2147483647ULL) { status = ST_DECLINE; break; }
             if (status == ST_OK && vec_push(&rowp, (int32_t)col.n)) { status = ST_ERROR; PyErr_NoMemory(); }
         }
         if (status != ST_OK) break;
+        if (want_mask) {
+            /* an entry vertex without a label is the reference's KeyError: which one it names depends on
+             * set order, so let the Python path raise it */
+            if (all_list ? lab_nonempty != g_nonempty : lab_in_g != PyDict_GET_SIZE(g)) { status = ST_DECLINE; break; }
+            for (Py_ssize_t i = 0; i < n; ++i) {
+                const unsigned char f = flag[V + i];
+                flag[V + i] = all_list ? ((f & 2) || (!(f & 1) && (f & 4))) : ((f & 1) || (f & 4));
+            }
+        }
         if (vec_push(&sizes, (int32_t)n)) { status = ST_ERROR; PyErr_NoMemory(); break; }
         V += n;
     }
@@ -227,7 +264,11 @@ done:;
         PyObject* a = PyByteArray_FromStringAndSize((const char*)sizes.p, (Py_ssize_t)(sizes.n * 4));
         PyObject* b = PyByteArray_FromStringAndSize((const char*)rowp.p, (Py_ssize_t)(rowp.n * 4));
         PyObject* c = PyByteArray_FromStringAndSize((const char*)col.p, (Py_ssize_t)(col.n * 4));
-        if (a && b && c) result = PyTuple_Pack(4, a, b, c, values);
+        if (a && b && c && want_mask) {
+            PyObject* mk = PyByteArray_FromStringAndSize((const char*)flag, (Py_ssize_t)V);
+            if (mk) result = PyTuple_Pack(5, a, b, c, values, mk);
+            Py_XDECREF(mk);
+        } else if (a && b && c) result = PyTuple_Pack(4, a, b, c, values);
         Py_XDECREF(a); Py_XDECREF(b); Py_XDECREF(c);
     } else if (status == ST_DECLINE) {
         if (PyErr_Occurred()) PyErr_Clear();
@@ -236,7 +277,7 @@ done:;
     }
     Py_XDECREF(values);
     Py_XDECREF(pos);
-    free(sizes.p); free(rowp.p); free(col.p); free(tmp.p);
+    free(sizes.p); free(rowp.p); free(col.p); free(tmp.p); free(flag);
     return result;
 }
 
@@ -510,7 +551,7 @@ static PyMethodDef methods[] = {
     {"sp_ingest", sp_ingest, METH_VARARGS,
      "sp_ingest(X, with_labels, min_len=1, max_len=3) -> None | (sizes, row_ptr, col_idx, weight, values)"},
     {"wl_ingest", wl_ingest, METH_VARARGS,
-     "wl_ingest(X, min_len=2) -> None | (sizes, row_ptr, col_idx, values): see grakel_amd/csrc/ingest.c"},
+     "wl_ingest(X, min_len=2, want_mask=False, max_len=0) -> None | (sizes, row_ptr, col_idx, values[, mask])"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_gk_ingest", "C fast path of grakel_amd.batch", -1, methods};

@@ -131,11 +131,26 @@ def test_c_ingestion_fast_path_equals_the_python_path():
     cases["labels_not_a_dict"] = [[{0: [1], 1: [0]}, [1, 2]]]
     cases["negative_neighbour"] = [[{0: [-1], 1: [0]}, {0: 'a', 1: 'b'}]]
     import warnings
+    from grakel_amd import batch as B
+
+    def oa(X):
+        try:
+            gb, m = B.wloa_batch_from_input(X)
+            return ("ok", gb.graph_ptr.tolist(), gb.row_ptr.tolist(), gb.col_idx.tolist(), gb.node_label.tolist(), gb.n_labels, m)
+        except Exception as e:                      # noqa: BLE001
+            return ("raise", type(e), e.args)
     for name, X in cases.items():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             fast, slow = _both_paths(X)
-        assert fast == slow, name
+            assert fast == slow, name
+            fast = oa(X)                            # WL-OA: same walk + the entry mask
+            saved, B._gk_ingest = B._gk_ingest, None
+            try:
+                slow = oa(X)
+            finally:
+                B._gk_ingest = saved
+            assert fast == slow, "wloa " + name
     fitted = {'a': 0, 'b': 1}
     fast, slow = _both_paths(cases["unlabelled_source_is_ignored"] + [[{0: [1], 1: [0]}, {0: 'b', 1: 'q'}]],
                              fitted_labels=fitted)
@@ -244,6 +259,14 @@ def test_c_ingestion_never_diverges_from_the_python_path_on_random_inputs():
         except Exception as e:                      # noqa: BLE001
             return ("raise", type(e), e.args)
 
+    def oa_run(X, fit):
+        try:
+            gb, m = B.wloa_batch_from_input(X, fitted_labels=None if fit else {0: 0, "x": 1}, fit=fit)
+            return ("ok", gb.graph_ptr.tolist(), gb.row_ptr.tolist(), gb.col_idx.tolist(), gb.node_label.tolist(),
+                    gb.n_labels, m)
+        except Exception as e:                      # noqa: BLE001
+            return ("raise", type(e), e.args)
+
     @hyp.settings(max_examples=400, deadline=None, suppress_health_check=list(hyp.HealthCheck))
     @hyp.given(st.lists(element(), min_size=1, max_size=4), st.booleans())
     def check(X, with_labels):
@@ -258,6 +281,14 @@ def test_c_ingestion_never_diverges_from_the_python_path_on_random_inputs():
             finally:
                 B._gk_ingest = saved
             assert fast == slow
+            for fit in (True, False):                      # WL-OA: the batch restricted to the vertices with an entry
+                fast = oa_run(X, fit)
+                saved, B._gk_ingest = B._gk_ingest, None
+                try:
+                    slow = oa_run(X, fit)
+                finally:
+                    B._gk_ingest = saved
+                assert fast == slow
     check()
 
 
