@@ -210,10 +210,14 @@ struct gk_feat {
     int low_df = 24;            // columns occurring in fewer graphs are applied as pair updates
     i64 n_rows_pad = 0;
     int dtype = 0;              // 0: int8 Phi, 1: f64 Phi
-    void* phi = nullptr;        // [n_rows_pad][n_cols_pad BYTES]: n_cols4 columns as 4-bit counts (two per
-                                // byte, k4_tiles K-steps of 64 B), then n_cols8 columns as int8 (k8_tiles)
-    i64 n_cols4 = 0, n_cols8 = 0;
-    int k4_tiles = 0, k8_tiles = 0;
+    // Dense MFMA operand, [n_rows_pad][n_cols_pad BYTES], K-steps of 128 B per row:
+    //   [secondary: n_cols8 int8 columns, k8_steps steps]  -- only when the primary region is fp4: counts 5..127
+    //   [primary: n_cols1 columns, k1_steps steps]          -- phi_fp4: two columns per byte as MX fp4 (e2m1) codes of
+    //                                                          the counts 0..4 (256 columns per step); else int8 (128 per step)
+    void* phi = nullptr;
+    i64 n_cols1 = 0, n_cols8 = 0;
+    int k1_steps = 0, k8_steps = 0;
+    bool phi_fp4 = false;       // counts <= 4 travel as fp4 (needs every Gram entry < 2^24: f32 accumulation stays exact)
     // dense columns holding a count > 127 cannot be int8 operands: they form a (usually
     // narrow) float64 side operand whose product is accumulated onto K after the int8 GEMM
     i64 n_cols_wide = 0, n_cols_wide_pad = 0;

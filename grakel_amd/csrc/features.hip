@@ -123,9 +123,9 @@ struct TripleEmit {
 // per item: acc[level][v] = count of v's (label,graph) triple; the sum over the nodes of a graph
 // of these counts == sum over its triples of count^2, so the exact self similarity needs no
 // atomics.  Nodes a partial level does not list own their label: their slot was pre-set to 1.
-// Also tracks the largest count and flags runs whose counts leave the int8 range.
+// Also tracks the largest count and flags runs whose counts leave the primary / the int8 range.
 __global__ void feat_count_kernel(const FeatLevels P, const FeatArrays A, const u32* __restrict__ tri_of,
-                                  int wide_above, u32* __restrict__ acc, i64 V, u32* __restrict__ meta,
+                                  int prim_max, int wide_above, u32* __restrict__ acc, i64 V, u32* __restrict__ meta,
                                   int n_levels, int kind) {
     __shared__ u32 wmax[4];
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,15 +137,14 @@ __global__ void feat_count_kernel(const FeatLevels P, const FeatArrays A, const 
             const i64 b = A.base(P, j);
             const i32 t = (i32)tri_of[i];
             c = (u32)(A.tri_pos[b + t + 1] - A.tri_pos[b + t]);
-            if (!kind && c > 15u) {
-                // operand class of the run: byte 0 set = some count needs int8, byte 1 set = needs the
-                // float64 side.  Plain byte stores of the same value from every such item: a hot run
-                // (level 0: a few labels, a million items) must not serialise on an atomic or a read
+            if (!kind) {
+                // operand class of the run: byte 0 set = some count exceeds what the primary region holds
+                // (fp4: 4), byte 1 set = needs the float64 side.  Plain byte stores of the same value from
+                // every such item: a hot run (level 0: a few labels, a million items) must not serialise
+                // on an atomic or a read
                 char* w = (char*)&A.wide[b + A.tri_run[b + t]];
-                w[0] = 1;
+                if ((int)c > prim_max) w[0] = 1;
                 if ((int)c > wide_above) w[1] = 1;
-            } else if (!kind && wide_above < 0) {
-                ((char*)&A.wide[b + A.tri_run[b + t]])[1] = 1;      // float64-only job: every run
             }
             acc[(i64)j * V + P.perm[j][k]] = kind ? 1u : c;                    // min(c,c) summed == #nodes
         }
@@ -215,8 +214,8 @@ __global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* 
 }
 
 // Column classes per label run, fused into ONE prefix sum over the runs of all levels:
-//   dense (colid >= 0) : occurs in >= low_df graphs -> a column of the MFMA operand Phi_s (4-bit
-//                        region when every count is <= 15, else numbered by ColumnIdsByteWide)
+//   dense (colid >= 0) : occurs in >= low_df graphs -> a column of the MFMA operand Phi_s (primary
+//                        region when every count fits it, else numbered by ColumnIdsByteWide)
 //   low   (colid = -2) : useful but rare (df < low_df): its df*(df-1) pair products are added
 //                        to K by gram_low_kernel after the GEMM -- a column with df graphs
 //                        costs N^2 MACs in the dense product but only df^2 updates here
@@ -238,7 +237,7 @@ struct ColumnIds {
         if (!useful) return 0ull;
         if ((t1 - t0) < low_df) return 1ull << 32;
         if (kind) return (u64)(u32)A.wide[b + r];       // unary expansion: one 0/1 column per count level
-        return A.wide[b + r] ? (1ull << 63) : 1ull;     // bit 63: dense but not 4-bit-able (toggles only itself)
+        return A.wide[b + r] ? (1ull << 63) : 1ull;     // bit 63: dense but not primary (toggles only itself)
     }
     __device__ __forceinline__ void emit(i64 i, u64 v, u64 incl) const {
         const int j = P.slot_of(i);
@@ -262,8 +261,8 @@ struct ColumnIds {
     __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
 };
 
-// second pass: dense columns holding a count > 15 -> ids in the int8 region (low half of the
-// packed sum) or in the float64 side operand (high half)
+// second pass: dense columns that do not fit the primary region -> ids in the secondary int8 region
+// (low half of the packed sum) or in the float64 side operand (high half)
 struct ColumnIdsByteWide {
     FeatLevels P; FeatArrays A; u32* meta; int n_levels;
     __device__ __forceinline__ u64 value(i64 i) const {
@@ -288,9 +287,12 @@ struct ColumnIdsByteWide {
 };
 
 // all levels in one launch: P.first = prefix of the per-level triple counts
-// phi: int8 staging image [rows][ld], 4-bit-class columns first, int8-class columns from byte_col0
+// phi: byte staging image [rows][ld], primary-class columns first, secondary int8 columns from byte_col0.
+// fp4: the primary region receives the MX fp4 (e2m1) CODE of the count (0,1,2,3,4 -> 0,2,4,5,6), which
+// feat_pack_kernel then only has to pack two per byte.
+__device__ __forceinline__ int8_t fp4_code(i32 c) { return (int8_t)((0x65420 >> (4 * c)) & 15); }
 __global__ void feat_scatter_mixed_kernel(const LevelPack P, int8_t* __restrict__ phi, i64 ld, i64 byte_col0,
-                                          double* __restrict__ phi_w, i64 ldw, int kind) {
+                                          double* __restrict__ phi_w, i64 ldw, int kind, int fp4) {
     i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.first[P.n]) return;
     int l = 0;
@@ -302,15 +304,17 @@ __global__ void feat_scatter_mixed_kernel(const LevelPack P, int8_t* __restrict_
     const i32 cnt = tri_pos[t + 1] - tri_pos[t];
     if (c >= 0 && kind) {
         int8_t* row = phi + (i64)tri_graph[t] * ld + c;
-        for (i32 q = 0; q < cnt; ++q) row[q] = 1;           // [count >= q+1]
+        const int8_t one = fp4 ? 2 : 1;
+        for (i32 q = 0; q < cnt; ++q) row[q] = one;         // [count >= q+1]
     } else if (c >= COL_BYTE_BASE) phi[(i64)tri_graph[t] * ld + byte_col0 + (c - COL_BYTE_BASE)] = (int8_t)cnt;
-    else if (c >= 0) phi[(i64)tri_graph[t] * ld + c] = (int8_t)cnt;
+    else if (c >= 0) phi[(i64)tri_graph[t] * ld + c] = fp4 ? fp4_code(cnt) : (int8_t)cnt;
     else if (c <= -4) phi_w[(i64)tri_graph[t] * ldw + (-4 - c)] = (double)cnt;
 }
 
-// staging image -> GEMM operand: the first n4p columns as nibbles (column 2q low, 2q+1 high of
-// byte q), the n8p int8 columns behind them.  One thread per 4 output bytes.
-__global__ void feat_pack_kernel(const int8_t* __restrict__ stage, i64 ld_stage, i64 n4p, i64 n8p,
+// staging image -> GEMM operand row [n8p secondary bytes | primary]: fp4 primary = the n1p staged codes
+// packed two per byte (column 2q low, 2q+1 high nibble of byte q), else the n1p bytes as they are.
+// One thread per 4 output bytes.
+__global__ void feat_pack_kernel(const int8_t* __restrict__ stage, i64 ld_stage, i64 n1p, i64 n8p, int fp4,
                                  int8_t* __restrict__ out, i64 ld_out, i64 n_rows) {
     const i64 words = ld_out >> 2;
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,14 +322,16 @@ __global__ void feat_pack_kernel(const int8_t* __restrict__ stage, i64 ld_stage,
     const i64 row = idx / words, w = idx - row * words;
     const int8_t* src = stage + row * ld_stage;
     u32 o;
-    if (w * 8 < n4p) {
-        const u64 x = *(const u64*)(src + w * 8);
+    if (w * 4 < n8p) {
+        o = *(const u32*)(src + n1p + w * 4);
+    } else if (fp4) {
+        const u64 x = *(const u64*)(src + (w * 4 - n8p) * 2);
         const u64 lo = x & 0x000f000f000f000full, hi = (x >> 4) & 0x00f000f000f000f0ull;
         const u64 m = lo | hi;                       // byte pairs (b0 | b1<<4) at bits 0, 16, 32, 48
         o = (u32)(m & 0xffull) | (u32)((m >> 8) & 0xff00ull) | (u32)((m >> 16) & 0xff0000ull) |
             (u32)((m >> 24) & 0xff000000ull);
     } else {
-        o = *(const u32*)(src + n4p + (w * 4 - n4p / 2));
+        o = *(const u32*)(src + (w * 4 - n8p));
     }
     *(u32*)(out + row * ld_out + w * 4) = o;
 }
@@ -389,12 +395,18 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     }
     // int8 operands need counts <= 127 and every Gram entry < 2^31:
     // K_ij <= sqrt(K_ii K_jj) <= n_levels * max_graph_nodes^2.  If the bound fails everything
-    // dense goes to the float64 operand (wide_above = -1 flags every run).
-    // kind 1: operands are 0/1 and K_ij <= n_levels * max_graph_nodes, always int8-able.
-    const double bound = (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
+    // dense goes to the float64 operand (wide_above = -1 flags every run).  Below 2^24 float32
+    // accumulation is exact as well, so counts 0..4 may travel as MX fp4 (e2m1) operands: half the
+    // operand bytes and twice the MFMA rate of int8 (gram.hip); counts 5..127 then form a secondary
+    // int8 region.
+    // kind 1: operands are 0/1 and K_ij <= n_levels * max_graph_nodes.
+    const double bound = kind == GK_FEAT_MINSUM
+                             ? (double)n_levels * (double)b->max_graph_nodes
+                             : (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
     f->dtype = (kind == GK_FEAT_MINSUM || bound < 2147483647.0) ? 0 : 1;
+    f->phi_fp4 = f->dtype == 0 && bound < 16777216.0 && !getenv("GK_GRAM_NO_FP4");
     const int wide_above = kind == GK_FEAT_MINSUM ? 0x7fffffff : (f->dtype == 0 ? 127 : -1);
-
+    const int prim_max = f->dtype != 0 ? -1 : (f->phi_fp4 ? 4 : 127);
     // ---- the level slots: a level only lists the nodes that can share a label (wl.hip: active-set
     // levels), a level that lists nothing adds one per node to the diagonal and nothing else
     FeatLevels P;
@@ -429,7 +441,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         feat_flags_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, b->node_graph, flag.p);
         TripleEmit te{P, A, b->node_graph, flag.p, tri_of.p, f->meta};
         if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, total, nullptr))) return fail(r);
-        feat_count_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, tri_of.p, wide_above, acc.p, V, f->meta,
+        feat_count_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, tri_of.p, prim_max, wide_above, acc.p, V, f->meta,
                                                                          n_levels, kind);
         if (kind == GK_FEAT_MINSUM) feat_runmax_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, f->meta);
         ColumnIds ci{P, A, f->meta, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df, kind, n_levels};
@@ -449,9 +461,9 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     const int G = 3 * n_levels;
     f->nnz = 0;
     for (int l = 0; l < n_levels; ++l) f->nnz += h[META_T(l)];
-    f->n_cols4 = h[G + 3];
+    f->n_cols1 = h[G + 3];
     f->n_cols8 = h[4 * n_levels + 4];
-    f->n_cols = f->n_cols4 + f->n_cols8;
+    f->n_cols = f->n_cols1 + f->n_cols8;
     f->n_cols_wide = h[G + 2];
     f->max_count = 0;
     for (int q = 0; q < 64; ++q) f->max_count = std::max<i64>(f->max_count, h[4 * n_levels + 5 + q]);
@@ -470,16 +482,17 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
             low_before = h[G + 4 + l];
         }
     }
-    // ---- operands: int8 staging image (plain byte stores, no two writers per byte), then packed:
-    // columns whose counts fit 4 bits travel as nibbles -- the Gram kernel is bound by the operand
-    // bytes it pulls through L2 -> LDS (gram.hip), so halving them is what counts
-    const i64 n4p = round_up(f->n_cols4, 128);
-    i64 n8p = round_up(f->n_cols8, 64);
-    if (n4p + n8p == 0) n8p = 64;             // at least one (all-zero) K-step
-    f->k4_tiles = (int)(n4p / 128), f->k8_tiles = (int)(n8p / 64);
-    f->n_cols_pad = n4p / 2 + n8p;            // BYTES per operand row
+    // ---- operands: byte staging image (plain byte stores, no two writers per byte), then packed into
+    // K-steps of 128 B per row: the Gram kernel is bound by the operand bytes it pulls through
+    // L2 -> LDS (gram.hip), whole 128-byte lines per row move ~1.6x faster than half lines
+    // (tools/micro/l2lds.hip), and fp4 halves the bytes per column
+    const i64 n1p = round_up(f->n_cols1, f->phi_fp4 ? 256 : 128);
+    i64 n8p = round_up(f->n_cols8, 128);
+    if (n1p + n8p == 0) n8p = 128;            // at least one (all-zero) K-step
+    f->k1_steps = (int)(n1p / (f->phi_fp4 ? 256 : 128)), f->k8_steps = (int)(n8p / 128);
+    f->n_cols_pad = (f->phi_fp4 ? n1p / 2 : n1p) + n8p;     // BYTES per operand row
     f->n_rows_pad = round_up(N, 256) + 256;   // slack so that tile loads never need row guards
-    const i64 ld_stage = n4p + n8p;
+    const i64 ld_stage = n1p + n8p;
     Tmp<int8_t> stage(ctx);
     if ((r = stage.alloc((size_t)f->n_rows_pad * ld_stage))) return fail(r);
     if (gk_zero_async(ctx, stage.p, (size_t)f->n_rows_pad * ld_stage) != GK_OK) return fail(GK_ERR_HIP);
@@ -505,10 +518,10 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         }
         if (S.n == 0) continue;
         feat_scatter_mixed_kernel<<<grid_for(S.first[S.n], 256), 256, 0, ctx->stream>>>(
-            S, stage.p, ld_stage, n4p, f->phi_w, f->n_cols_wide_pad, kind);
+            S, stage.p, ld_stage, n1p, f->phi_w, f->n_cols_wide_pad, kind, f->phi_fp4 ? 1 : 0);
     }
     feat_pack_kernel<<<grid_for(f->n_rows_pad * (f->n_cols_pad / 4), 256), 256, 0, ctx->stream>>>(
-        stage.p, ld_stage, n4p, n8p, (int8_t*)f->phi, f->n_cols_pad, f->n_rows_pad);
+        stage.p, ld_stage, n1p, n8p, f->phi_fp4 ? 1 : 0, (int8_t*)f->phi, f->n_cols_pad, f->n_rows_pad);
     if (hipGetLastError() != hipSuccess) {
         gk_set_error("gk_features_build: kernel launch failed");
         return fail(GK_ERR_HIP);
@@ -539,16 +552,18 @@ extern "C" int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk) {
 
 extern "C" int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi) {
     GK_ARG(ctx && f && out_phi, "gk_features_debug_phi: null argument");
-    const i64 N = f->n_graphs, D = f->n_cols, ld = f->n_cols_pad, n4 = f->n_cols4;
-    const i64 byte0 = (i64)f->k4_tiles * 64;      // first byte of the int8 region
+    const i64 N = f->n_graphs, D = f->n_cols, ld = f->n_cols_pad, n1 = f->n_cols1;
+    const i64 prim0 = (i64)f->k8_steps * 128;      // first byte of the primary region
+    static const double fp4_value[16] = {0, 0.5, 1, 1.5, 2, 3, 4, 6, -0.0, -0.5, -1, -1.5, -2, -3, -4, -6};
     std::vector<unsigned char> h((size_t)N * ld);
     GK_HIP_CHECK(hipMemcpyAsync(h.data(), f->phi, h.size(), hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (i64 i = 0; i < N; ++i)
-        for (i64 j = 0; j < D; ++j) {
+        for (i64 j = 0; j < D; ++j) {       // columns: primary class first, then the secondary int8 class
             const unsigned char* row = h.data() + i * ld;
-            out_phi[i * D + j] = j < n4 ? (double)((row[j >> 1] >> (4 * (j & 1))) & 15)
-                                        : (double)((const int8_t*)row)[byte0 + (j - n4)];
+            if (j >= n1) out_phi[i * D + j] = (double)((const int8_t*)row)[j - n1];
+            else if (f->phi_fp4) out_phi[i * D + j] = fp4_value[(row[prim0 + (j >> 1)] >> (4 * (j & 1))) & 15];
+            else out_phi[i * D + j] = (double)((const int8_t*)row)[prim0 + j];
         }
     return GK_OK;
 }

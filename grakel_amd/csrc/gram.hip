@@ -2,10 +2,13 @@
 //
 // Label counts are small non-negative integers, so the product is EXACT integer arithmetic.
 // A launch sequence (gk_gram_launch) is:
-//   1. gram_i8_glds_kernel : dense columns with counts <= 127 as int8 operands,
-//                            v_mfma_i32_32x32x32_i8, int32 accumulate (K < 2^31 is checked when the
-//                            features are built): 2x the bf16 MFMA rate, bit-exact versus the
-//                            reference's float64 result.  Writes every entry of K (float64).
+//   1. gram_ws_kernel      : dense columns as MFMA operands -- counts 0..4 as MX fp4 codes
+//                            (v_mfma_scale_f32_32x32x64_f8f6f4, exact), counts 5..127 as int8
+//                            (v_mfma_i32_32x32x32_i8); features.hip only allows fp4 when every entry stays
+//                            below 2^24 (exact float32 accumulation) and int8 below 2^31: bit-exact versus
+//                            the reference's float64 result.  Persistent, warp-specialised: four waves
+//                            multiply, four waves write K (float64) under the next tile's K loop.
+//                            gram_tile_kernel is the plain one-tile-per-workgroup form (GK_GRAM_NO_WS=1).
 //   2. gram_f64_kernel     : dense columns holding a count > 127 (typical for ShortestPath
 //                            histograms) form a narrow float64 side operand,
 //                            v_mfma_f64_16x16x4_f64, accumulated onto K (exact while K < 2^53).
@@ -14,7 +17,7 @@
 //   4. gram_normalize_kernel, only when 2. or 3. ran and normalisation was requested.
 // Histogram-intersection features (kind 1) arrive unary-expanded (features.hip), so step 1 computes
 // sum_l min(c_il, c_jl) exactly; step 2 never applies and step 3 adds min(c_a, c_b) per pair.
-// The int8 epilogue fuses what the reference does in three extra N^2 passes: the per-level sum
+// The store epilogue fuses what the reference does in three extra N^2 passes: the per-level sum
 // (all levels are concatenated along K), the diagonal (graph-unique label columns are not in
 // Phi_s; K_ii is written from the exact selfk vector instead) and -- when no extra term
 // follows -- the normalisation K_ij / sqrt(K_ii K_jj) (weisfeiler_lehman.py:323-328,
@@ -42,8 +45,6 @@ __device__ __forceinline__ double finish_entry(double val, i64 grow, i64 gcol, b
     }
     return val;
 }
-
-#define GI_BK 64     // K-step in bytes (two 32-deep MFMA slices)
 
 // Block -> output tile.  Workgroup b is observed to run on XCD b % 8 (speed assumption only),
 // so consecutive ids of ONE XCD (b>>3) walk 8x8-tile patches: the ~128 tiles resident on an
@@ -85,177 +86,160 @@ static inline i64 gram_grid_blocks(int tiles_m, int tiles_n, int sym, int patch)
 }
 
 // ---------------------------------------------------------------------------------------
-// int8 path, pipelined.  Operand tiles go L2 -> LDS directly (global_load_lds_dwordx4: no VGPR
-// round trip, no ds_write) into a ring of NS stages, NS-1 K-steps in flight across the per-step
-// barrier (counted s_waitcnt vmcnt, raw s_barrier).  The LDS image is linear per wave
-// instruction (16 rows x 64 B = 1 KiB), so the bank-conflict-free layout comes from
-// XOR-swizzling the 16-byte chunk index on the SOURCE address and on the fragment read:
-//      physical chunk = logical chunk ^ ((row >> 2) & 3)
-// which spreads every 16-lane ds_read_b128 group over all 16 slots of the 256-B bank row.
-// Measured: the L2->LDS path sustains ~11-14 TB/s chip-wide, so the operand bytes per MAC set
-// the ceiling -> the 256x256 tile (8 waves, 128x64 per wave) halves them versus 128x128.
-//   <WM,WN,TM,TN>: waves_m x waves_n, MFMA 32x32 tiles per wave; BM = WM*TM*32, BN = WN*TN*32.
-// Each wave stages (BM+BN)/(16*waves) = 4 sixteen-row pieces per K-step in both shapes.
+// Dense path: 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave = 2x2 MFMA
+// 32x32 tiles), two workgroups per CU so that one tile's float64 store epilogue overlaps the other's
+// K loop.  What bounds it, in this order: the float64 store of K (HBM), the operand
+// bytes pulled through L2 -> LDS, then the MFMA pipe.  Hence:
+//   * operand K-steps are 128 B per row -- whole cache lines: tools/micro/l2lds.hip measures 26 TB/s
+//     chip-wide for 128-B row pieces against 16-17 TB/s for 64-B pieces;
+//   * counts 0..4 travel as MX fp4 (e2m1) codes with unit block scales, two columns per byte:
+//     v_mfma_scale_f32_32x32x64_f8f6f4 multiplies them exactly (tools/micro/mfma_rate.hip) at twice
+//     the int8 rate and half the bytes; float32 accumulation is exact because features.hip only
+//     chooses fp4 when every Gram entry stays below 2^24.  The few columns with counts 5..127 form a
+//     leading int8 region (v_mfma_i32_32x32x32_i8 on the same registers, converted once);
+//   * tiles go L2 -> LDS directly (global_load_lds_dwordx4: no VGPR round trip) into a 2-stage ring,
+//     one s_barrier per K-step.  The LDS image is linear per wave instruction (8 rows x 128 B =
+//     1 KiB), so the bank-conflict-free layout comes from XOR-swizzling the 16-byte chunk index on
+//     the SOURCE address and on the fragment read:  physical chunk = logical chunk ^ ((row >> 1) & 7),
+//     which spreads every 16-lane ds_read_b128 group over all 16 slots of the 256-B bank row.
 // ---------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int TM, int TN, int NS>
-__global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
-    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_tiles, int k4_tiles,
+#define GT_BM 128
+#define GT_BK 128                                   // operand bytes per row per K-step
+#define GT_STAGE (2 * GT_BM * GT_BK)                // A rows then B rows: 32 KiB
+#define GT_LDT (GT_BM + 4)                          // padded column of the transposed tile (epilogue)
+#define GT_LDS_BYTES (GT_BM * GT_LDT * 4 > 2 * GT_STAGE ? GT_BM * GT_LDT * 4 : 2 * GT_STAGE)
+
+// by value: __builtin_bit_cast applied directly to a vector ELEMENT expression reads element 0 (clang, ROCm 7.2)
+__device__ __forceinline__ int gt_bits(float x) { return __builtin_bit_cast(int, x); }
+
+template <bool FP4>
+__global__ __launch_bounds__(256) void gram_tile_kernel(
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
     int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
-    constexpr int STAGE = (BM + BN) * 64;
-    constexpr int PPW = (BM + BN) / 16 / NW;                 // 1-KiB pieces per wave per stage
-    static_assert((BM + BN) % (16 * NW) == 0, "pieces must divide evenly over the waves");
-    extern __shared__ __attribute__((aligned(16))) int8_t smem[];   // NS * STAGE, ONE array
+    constexpr int BM = GT_BM, BN = GT_BM, TM = 2, TN = 2, PPW = 8;
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave >> 1, wn = wave & 1;
     int bm, bn;
     if (!gram_map_tile(blockIdx.x, tiles_m, tiles_n, tri, patch, bm, bn)) return;
 
-    // staging: piece q of this wave covers rows [16*(wave*PPW+q), +16) of the (A rows, B rows) list
-    const int srow = lane >> 2;                              // row inside the piece
-    const int schunk = (lane & 3) ^ ((srow >> 2) & 3);       // logical chunk this lane fetches
+    // staging: wave w fills stage rows [64w, 64w + 64) (waves 0,1: the A rows, 2,3: the B rows), eight
+    // 1-KiB pieces of 8 rows; lane -> (row lane>>3, physical chunk lane&7) fetches the logical chunk
+    // physical ^ ((stage row >> 1) & 7)
     const int8_t* gsrc[PPW];
-    int sdst[PPW];
+    {
+        const int srow = lane >> 3, pch = lane & 7;
+        const int8_t* base = wave < 2 ? A + ((i64)bm * BM + wave * 64) * ld : B + ((i64)bn * BN + (wave - 2) * 64) * ld;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-        const int r0 = (wave * PPW + q) * 16;
-        if (r0 < BM) gsrc[q] = A + ((i64)bm * BM + r0 + srow) * ld + schunk * 16;
-        else gsrc[q] = B + ((i64)bn * BN + (r0 - BM) + srow) * ld + schunk * 16;
-        sdst[q] = r0 * 64;
+        for (int q = 0; q < PPW; ++q) {
+            const int r = q * 8 + srow;                           // row inside the wave's 64 (64w is a multiple of 16)
+            gsrc[q] = base + (i64)r * ld + ((pch ^ ((r >> 1) & 7)) << 4);
+        }
+    }
+#define GT_ISSUE(KT)                                                                          \
+    {                                                                                         \
+        const i64 go = (i64)(KT) * GT_BK;                                                     \
+        int8_t* st = smem + ((KT) & 1) * GT_STAGE + wave * (64 * GT_BK);                      \
+        _Pragma("unroll") for (int q = 0; q < PPW; ++q)                                       \
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc[q] + go), (lds_void_t*)(st + q * 1024), 16, 0, 0); \
     }
 
-    v16i acc[TM][TN];
+    // fragment addresses: row rr of the stage, slice s (32 B = one MFMA K-slice), half fh = lane >> 5
+    const int fr = lane & 31, fh = lane >> 5;
+    int offa[TM][4], offb[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rr = wm * 64 + i * 32 + fr;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) offa[i][sl] = rr * GT_BK + (((2 * sl + fh) ^ ((rr >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int rr = BM + wn * 64 + j * 32 + fr;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) offb[j][sl] = rr * GT_BK + (((2 * sl + fh) ^ ((rr >> 1) & 7)) << 4);
+    }
+
+    // one register set for both accumulator types: int32 while the int8 region runs, float32 after
+    v16f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;       // bit pattern 0 == int32 0
 
-#define GL_ISSUE(KT)                                                                        \
-    {                                                                                       \
-        const i64 go = (i64)(KT) * GI_BK;                                                   \
-        int8_t* st = smem + ((KT) % NS) * STAGE;                                            \
-        _Pragma("unroll") for (int q = 0; q < PPW; ++q)                                     \
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc[q] + go), (lds_void_t*)(st + sdst[q]), 16, 0, 0); \
+#define GT_MFMA(FA, FB, AS_FP4)                                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                      \
+            if (AS_FP4) {                                                                     \
+                const v8i xa = {FA[i][0], FA[i][1], FA[i][2], FA[i][3], 0, 0, 0, 0};          \
+                const v8i xb = {FB[j][0], FB[j][1], FB[j][2], FB[j][3], 0, 0, 0, 0};          \
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, xb, acc[i][j], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+            } else {                                                                          \
+                acc[i][j] = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(   \
+                    FA[i], FB[j], __builtin_bit_cast(v16i, acc[i][j]), 0, 0, 0));             \
+            }                                                                                 \
+        }
+    // K-step: wait for the stage, one barrier (everybody also finished reading the other buffer), queue the
+    // next stage into that buffer, then four K-slices with the fragments of slice s+1 in flight while
+    // the MFMAs of slice s run
+#define GT_STEP(AS_FP4)                                                                       \
+    {                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        __builtin_amdgcn_s_barrier();                                                         \
+        if (kt + 1 < k_steps) GT_ISSUE(kt + 1);                                               \
+        const int8_t* st = smem + (kt & 1) * GT_STAGE;                                        \
+        v4i fa[2][TM], fb[2][TN];                                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *(const v4i*)(st + offa[i][0]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *(const v4i*)(st + offb[j][0]); \
+        _Pragma("unroll") for (int sl = 0; sl < 4; ++sl) {                                    \
+            if (sl < 3) {                                                                     \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[(sl + 1) & 1][i] = *(const v4i*)(st + offa[i][(sl + 1) & 3]); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[(sl + 1) & 1][j] = *(const v4i*)(st + offb[j][(sl + 1) & 3]); \
+            }                                                                                 \
+            GT_MFMA(fa[sl & 1], fb[sl & 1], AS_FP4)                                           \
+        }                                                                                     \
     }
-
-    // Software pipeline inside the K-step: while the MFMAs of one 32-deep K-slice run, the
-    // fragments of the next slice are already being read from LDS, so the LDS phase and the
-    // MFMA phase of the 8 barrier-synchronised waves overlap instead of alternating.
-    for (int p = 0; p < NS; ++p)
-        if (p < k_tiles) GL_ISSUE(p);
-
-    const int fr = lane & 31, fh = lane >> 5;
-    int offa[TM][2], offb[TN][2];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int rr = wm * TM * 32 + i * 32 + fr;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) offa[i][ks] = rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int rr = wn * TN * 32 + j * 32 + fr;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) offb[j][ks] = BM * 64 + rr * 64 + (((2 * ks + fh) ^ ((rr >> 2) & 3)) << 4);
-    }
-
-    // The first k4_tiles K-steps hold 4-bit counts, two columns per byte (features.hip): a 16-byte
-    // fragment then feeds TWO MFMA slices (low nibbles, high nibbles; A and B are unpacked alike,
-    // so the column order inside the dot product does not matter).  Half the bytes per column
-    // through L2 -> LDS -> VGPR, which is what bounds this kernel.
-#define GL_MFMA(FA, FB, PACKED)                                                              \
-    if (PACKED) {                                                                            \
-        v4i al[TM], ah[TM], bl[TN], bh[TN];                                                  \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) { al[i] = FA[i] & 0x0f0f0f0f; ah[i] = (FA[i] >> 4) & 0x0f0f0f0f; } \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) { bl[j] = FB[j] & 0x0f0f0f0f; bh[j] = (FB[j] >> 4) & 0x0f0f0f0f; } \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                   \
-                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al[i], bl[j], acc[i][j], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                   \
-                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah[i], bh[j], acc[i][j], 0, 0, 0); \
-    } else {                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                   \
-                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(FA[i], FB[j], acc[i][j], 0, 0, 0); \
-    }
-
-    v4i fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    {   // own pieces of stage 0 landed: up to NS-1 later stages may stay in flight
-        const int after = k_tiles - 1;
-        const int fly = after < NS - 1 ? after : NS - 1;
-        if (fly >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory");
-        else if (fly == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
-        else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    {
-        const int8_t* st = smem;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa0[i] = *(const v4i*)(st + offa[i][0]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb0[j] = *(const v4i*)(st + offb[j][0]);
-    }
-    // two copies of the K-step, specialised at compile time (a run-time "packed" flag inside one
-    // loop makes the compiler keep two accumulator sets: 128 AGPRs, one wave per SIMD)
-#define GL_STEP(PACKED)                                                                      \
-    {                                                                                        \
-        const int8_t* st = smem + (kt % NS) * STAGE;                                         \
-        /* ---- phase A: read slice 1 of stage kt, multiply slice 0 */                        \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa1[i] = *(const v4i*)(st + offa[i][1]); \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb1[j] = *(const v4i*)(st + offb[j][1]); \
-        GL_MFMA(fa0, fb0, PACKED)                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        /* ---- stage hand-over: stage kt+1 must be complete, stage kt is fully read */       \
-        if (kt + 1 < k_tiles) {                                                              \
-            const int after = k_tiles - 1 - (kt + 1);   /* stages after kt+1 may stay in flight */ \
-            const int fly = after < NS - 2 ? after : NS - 2;                                 \
-            if (fly >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PPW) : "memory"); \
-            else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory"); \
-            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory"); \
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                 \
-        } else {                                                                             \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-        }                                                                                    \
-        __builtin_amdgcn_s_barrier();                                                        \
-        if (kt + NS < k_tiles) GL_ISSUE(kt + NS);       /* overwrites the buffer of stage kt */ \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        /* ---- phase B: read slice 0 of stage kt+1, multiply slice 1 */                      \
-        if (kt + 1 < k_tiles) {                                                              \
-            const int8_t* sn = smem + ((kt + 1) % NS) * STAGE;                               \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) fa0[i] = *(const v4i*)(sn + offa[i][0]); \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) fb0[j] = *(const v4i*)(sn + offb[j][0]); \
-        }                                                                                    \
-        GL_MFMA(fa1, fb1, PACKED)                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-    }
+    GT_ISSUE(0);
     int kt = 0;
-    for (; kt < k4_tiles; ++kt) GL_STEP(true)
-    for (; kt < k_tiles; ++kt) GL_STEP(false)
-#undef GL_STEP
-#undef GL_ISSUE
-#undef GL_MFMA
+    if (FP4) {
+        for (; kt < k8_steps; ++kt) GT_STEP(false)
+        if (k8_steps > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = (float)gt_bits(acc[i][j][r]);
+        }
+        for (; kt < k_steps; ++kt) GT_STEP(true)
+    } else {
+        for (; kt < k_steps; ++kt) GT_STEP(false)
+    }
+#undef GT_STEP
+#undef GT_ISSUE
+#undef GT_MFMA
+#define GT_VAL(X) (FP4 ? (double)(X) : (double)gt_bits(X))
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool mirror = tri && bm != bn;     // off-diagonal tile of a symmetric job: also write K^T
     const bool even = (N & 1) == 0;
-    // The transposed copy of a 128x128 tile goes through LDS (the operand ring is free after the last
-    // K-step): the int32 accumulators are written column-major with a 4-word pad per column
-    // (conflict-free 16-byte writes), then every wave streams whole columns back -- 128 consecutive
-    // K^T entries, 1 KiB of float64 per store instruction -- instead of 16-byte pieces scattered over
-    // 32 rows.  Plain counts only (normalised epilogues keep the register path).
-    constexpr bool LDS_MIRROR = (BM == 128 && BN == 128);
-    constexpr int LDT = BM + 4;
-    const bool lds_mirror = LDS_MIRROR && mirror && normalize == 0 && even;
-    int* tsm = (int*)smem;
+    // The transposed copy goes through LDS (the operand ring is free after the last K-step): the 32-bit
+    // accumulators are written column-major with a 4-word pad per column (conflict-free 16-byte
+    // writes), then every wave streams whole columns back -- 128 consecutive K^T entries, 1 KiB of
+    // float64 per store instruction -- instead of 16-byte pieces scattered over 32 rows.  Plain counts
+    // only (normalised epilogues keep the register path).
+    constexpr int LDT = GT_LDT;
+    const bool lds_mirror = mirror && normalize == 0 && even;
+    float* tsm = (float*)smem;
+    if (lds_mirror) __syncthreads();          // the last K-step's fragment reads are done (block-uniform)
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -272,16 +256,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
                     const i64 row = row0 + j;
                     v[j] = 0.0;
                     if (row < M && col < N) {
-                        v[j] = finish_entry((double)acc[mt][nt][4 * q + j], row_base + row, col,
+                        v[j] = finish_entry(GT_VAL(acc[mt][nt][4 * q + j]), row_base + row, col,
                                             symmetric != 0, selfk, n_fit, normalize);
                         K[row * N + col] = v[j];           // 32 lanes -> 256 contiguous bytes
                     }
                 }
                 if (lds_mirror) {
-                    v4i t;
-                    t[0] = acc[mt][nt][4 * q], t[1] = acc[mt][nt][4 * q + 1];
-                    t[2] = acc[mt][nt][4 * q + 2], t[3] = acc[mt][nt][4 * q + 3];
-                    *(v4i*)(tsm + ctile * LDT + rtile) = t;
+                    float4 t;
+                    t.x = acc[mt][nt][4 * q], t.y = acc[mt][nt][4 * q + 1];
+                    t.z = acc[mt][nt][4 * q + 2], t.w = acc[mt][nt][4 * q + 3];
+                    *(float4*)(tsm + ctile * LDT + rtile) = t;
                 } else if (mirror && col < N) {             // K[col][row0..row0+3]: 32 B per lane
                     double* dst = K + col * N + row0;
                     if (even && row0 + 3 < M) {
@@ -295,41 +279,421 @@ __global__ __launch_bounds__(64 * WM * WN) void gram_i8_glds_kernel(
                 }
             }
         }
-    if (LDS_MIRROR && lds_mirror) {          // block-uniform
+    if (lds_mirror) {          // block-uniform
         __syncthreads();
         const i64 r = (i64)bm * BM + 2 * lane;              // two consecutive entries of K^T's row per lane
-        for (int c = wave; c < BN; c += NW) {
+        for (int c = wave; c < BN; c += 4) {
             const i64 krow = (i64)bn * BN + c;
             if (krow >= N) break;
-            const int2 t = *(const int2*)(tsm + c * LDT + 2 * lane);
+            const float2 t = *(const float2*)(tsm + c * LDT + 2 * lane);
             double* dst = K + krow * N + r;
-            if (r + 1 < M) *(double2*)dst = make_double2((double)t.x, (double)t.y);
-            else if (r < M) dst[0] = (double)t.x;
+            if (r + 1 < M) *(double2*)dst = make_double2(GT_VAL(t.x), GT_VAL(t.y));
+            else if (r < M) dst[0] = GT_VAL(t.x);
         }
     }
+#undef GT_VAL
 }
 
-template <int WM, int WN, int TM, int TN, int NS>
-static int launch_glds(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
-                       i64 row_lo, int normalize, double* K, int tri, int patch, int patch_sz, double* tiles_done) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LDS_RING = NS * (BM + BN) * 64;
-    constexpr int LDS_T = (BM == 128 && BN == 128) ? BN * (BM + 4) * 4 : 0;     // transposed tile of the epilogue
-    constexpr int LDS = LDS_RING > LDS_T ? LDS_RING : LDS_T;
-    const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(n_cols, BN);
-    const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch ? patch_sz : 0);
-    auto kern = gram_i8_glds_kernel<WM, WN, TM, TN, NS>;
-    GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    int kt_all = f->k4_tiles + f->k8_tiles, kt4 = f->k4_tiles;
-    i64 M_store = M;
-    if (const char* abl = getenv("GK_GRAM_ABL")) {     // timing ablations (tools/gram_only.py): WRONG results
-        if (!strcmp(abl, "nostore")) M_store = 0;       // K loop only: every store is predicated off
-        if (!strcmp(abl, "nok")) kt_all = 0, kt4 = 0;   // epilogue only
+// ---------------------------------------------------------------------------------------
+// Warp-specialised persistent form of the same tile product (the default): ONE 512-thread workgroup
+// per CU walks a strided sequence of tiles.  Waves 0-3 only run K loops; waves 4-7 only write K.  A
+// finished tile's 32-bit accumulators are parked in a 64-KiB LDS buffer (column-major, XOR-swizzled)
+// and the store waves stream them out -- rows of the tile and, for an off-diagonal tile of a
+// symmetric job, rows of its transpose, 1 KiB of float64 per store instruction -- a few rows per
+// K-step of the NEXT tile, in lockstep with the compute waves' one barrier per K-step.  So the
+// float64 store of K (the HBM roof of this kernel) runs under the K loops instead of after them,
+// the operand ring can be three stages deep (two K-steps = 64 KiB in flight per CU; the L2 -> LDS
+// path needs that much to stream), and the load pipeline does not drain between tiles.
+//   LDS: ring 3 x 32 KiB | parked tile 64 KiB = 160 KiB (all of it).
+// ---------------------------------------------------------------------------------------
+#define WS_RING 3
+#define WS_OUT_OFF (WS_RING * GT_STAGE)
+#define WS_LDS_BYTES (WS_OUT_OFF + GT_BM * GT_BM * 4)
+
+struct WsTile { int id, bm, bn, ok; };
+
+__device__ __forceinline__ WsTile ws_next_tile(int id, int stride, int n_ids, int tiles_m, int tiles_n, int tri, int patch) {
+    WsTile t;
+    t.ok = 0, t.bm = 0, t.bn = 0;
+    for (id += stride; id < n_ids; id += stride)
+        if (gram_map_tile(id, tiles_m, tiles_n, tri, patch, t.bm, t.bn)) { t.ok = 1; break; }
+    t.id = id;
+    return t;
+}
+
+// parked tile: entry (row, col) of the 128x128 tile as a 32-bit word at
+__device__ __forceinline__ int ws_out_addr(int row, int col) {
+    return col * (GT_BM * 4) + ((((row >> 2) ^ (col & 31)) << 4) | ((row & 3) << 2));
+}
+
+template <bool FP4, int ABL>
+__global__ __launch_bounds__(512) void gram_ws_kernel(
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
+    const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
+    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int n_ids, i64 M_store, unsigned* __restrict__ xcc_ticket) {
+    constexpr int BM = GT_BM, BN = GT_BM, TM = 2, TN = 2, PPW = 8;
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: scalar branches, scalar tile walk
+    const bool is_compute = wave < 4;                       // wave-uniform role
+    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
+
+    // ---- compute role state -------------------------------------------------------------
+    // staging (as gram_tile_kernel): compute wave w fills stage rows [64w, 64w + 64)
+    i64 roff[PPW];
+    {
+        const int srow = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int r = q * 8 + srow;
+            roff[q] = (i64)r * ld + ((pch ^ ((r >> 1) & 7)) << 4);
+        }
     }
-    kern<<<dim3((unsigned)blocks), dim3(64 * WM * WN), LDS, ctx->stream>>>(
-        a, b, f->n_cols_pad, kt_all, kt4, f->selfk, K, M_store, n_cols, row_lo,
-        f->symmetric ? 1 : 0, f->n_fit, normalize, tiles_m, tiles_n, tri, patch ? patch_sz : 0);
-    *tiles_done = tri ? (double)tiles_m * (tiles_m + 1) / 2 * BM * BN : (double)M * n_cols;
+    const int fr = lane & 31, fh = lane >> 5;
+    int offa[TM][4], offb[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rr = wm * 64 + i * 32 + fr;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) offa[i][sl] = rr * GT_BK + (((2 * sl + fh) ^ ((rr >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int rr = BM + wn * 64 + j * 32 + fr;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) offb[j][sl] = rr * GT_BK + (((2 * sl + fh) ^ ((rr >> 1) & 7)) << 4);
+    }
+    v16f acc[TM][TN];
+#define WS_ZERO_ACC()                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    WS_ZERO_ACC()
+
+    // ---- the tile sequences: `cur` is being multiplied, `ldt` is being loaded (at most one tile ahead),
+    // `prv` is being written out by the store waves
+    const int stride = gridDim.x;
+    int first_id = (int)blockIdx.x;
+    if (xcc_ticket) {          // experiment: identity from the XCD this workgroup really runs on
+        int& s_first = *(int*)(smem + WS_OUT_OFF);      // the parked-tile buffer is idle at start
+        if (tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            const unsigned slot = atomicAdd(&xcc_ticket[xcc], 1u);
+            s_first = (int)((slot << 3) | xcc);
+        }
+        __syncthreads();
+        first_id = __builtin_amdgcn_readfirstlane(s_first);
+    }
+    WsTile cur = ws_next_tile(first_id - stride, stride, n_ids, tiles_m, tiles_n, tri, patch);
+    WsTile ldt = cur, prv;
+    prv.ok = 0, prv.bm = prv.bn = 0, prv.id = 0;
+    int kt_ld = 0, buf_ld = 0, buf_cp = 0, ahead = 0;       // ahead: stages issued and not yet consumed
+    const int8_t* src_base = nullptr;
+#define WS_SRC_BASE()                                                                          \
+    src_base = cw < 2 ? A + ((i64)ldt.bm * BM + cw * 64) * ld : B + ((i64)ldt.bn * BN + (cw - 2) * 64) * ld;
+#define WS_ISSUE_NEXT()                                                                        \
+    if (ldt.ok) {                                                                              \
+        const int8_t* gp = src_base + (i64)kt_ld * GT_BK;                                      \
+        int8_t* st = smem + buf_ld * GT_STAGE + cw * (64 * GT_BK);                             \
+        if (ABL == 0 || ABL == 2 || ABL == 6) {                                                          \
+            _Pragma("unroll") for (int q = 0; q < PPW; ++q)                                    \
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gp + roff[q]), (lds_void_t*)(st + q * 1024), 16, 0, 0); \
+        }                                                                                      \
+        buf_ld = buf_ld == WS_RING - 1 ? 0 : buf_ld + 1;                                       \
+        ++ahead;                                                                               \
+        if (++kt_ld == k_steps) {                                                              \
+            kt_ld = 0;                                                                         \
+            ldt = ws_next_tile(ldt.id, stride, n_ids, tiles_m, tiles_n, tri, patch);           \
+            WS_SRC_BASE()                                                                      \
+        }                                                                                      \
+    }
+    if (is_compute) {
+        WS_SRC_BASE()
+        WS_ISSUE_NEXT()
+        WS_ISSUE_NEXT()
+    }
+
+#define WS_MFMA(FA, FB, AS_FP4)                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+            if (AS_FP4) {                                                                      \
+                const v8i xa = {FA[i][0], FA[i][1], FA[i][2], FA[i][3], 0, 0, 0, 0};           \
+                const v8i xb = {FB[j][0], FB[j][1], FB[j][2], FB[j][3], 0, 0, 0, 0};           \
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, xb, acc[i][j], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+            } else {                                                                           \
+                acc[i][j] = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(    \
+                    FA[i], FB[j], __builtin_bit_cast(v16i, acc[i][j]), 0, 0, 0));              \
+            }                                                                                  \
+        }
+// K-step = 4 K-slices.  One compute wave per SIMD has nobody to hide its LDS latency behind, so the
+// fragment reads run two slices ahead of the MFMAs: R0 R1 | R2 M0 | R3 M1 | M2 | M3 (sched_barrier keeps
+// the groups apart; the waits the compiler inserts are counted lgkmcnt, LDS returns in order).
+#define WS_READ(SL, BUF)                                                                       \
+    if (ABL != 3 && ABL != 5) {                                                                \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[BUF][i] = *(const v4i*)(st + offa[i][SL]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[BUF][j] = *(const v4i*)(st + offb[j][SL]); \
+    } else {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[BUF][i] = (v4i){offa[i][SL], buf_cp, kt_ld, SL};  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[BUF][j] = (v4i){offb[j][SL], buf_cp, kt_ld, SL};  \
+    }
+#define WS_COMPUTE(AS_FP4)                                                                     \
+    {                                                                                          \
+        const int8_t* st = smem + buf_cp * GT_STAGE;                                           \
+        v4i fa[3][TM], fb[3][TN];                                                              \
+        WS_READ(0, 0) WS_READ(1, 1)                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        /* the buffer computed in the previous step is free now: queue the stage after next (its */ \
+        /* issue time hides the latency of the reads above) */                                 \
+        WS_ISSUE_NEXT()                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        WS_READ(2, 2) WS_MFMA(fa[0], fb[0], AS_FP4)                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        WS_READ(3, 0) WS_MFMA(fa[1], fb[1], AS_FP4)                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        WS_MFMA(fa[2], fb[2], AS_FP4)                                                          \
+        WS_MFMA(fa[0], fb[0], AS_FP4)                                                          \
+    }
+
+    // ---- store role: the parked tile `prv` goes out in k_steps chunks, one per K-step of `cur`.
+    // Store wave s owns tile rows [32s, 32s+32) (units 0..31) and, for a mirrored tile, the rows
+    // [32s, 32s+32) of the transposed tile (units 32..63).  A unit is one 1-KiB row: lane l holds the
+    // entries 2l, 2l+1.
+    const int sw = wave - 4;
+    const bool even = (N & 1) == 0;
+    int8_t* const outb = smem + WS_OUT_OFF;
+#define WS_VAL(X) (FP4 ? (double)(X) : (double)gt_bits(X))
+    auto store_units = [&](int u0, int u1) __attribute__((always_inline)) {
+        const bool mirror = tri && prv.bm != prv.bn;
+        const int n_units = mirror ? 64 : 32;
+        // the plain path has no global load, so the store waves never wait on their own stores (loads and
+        // stores share vmcnt and retire in order)
+        const i64 d0 = row_base + (i64)prv.bm * BM - (i64)prv.bn * BN;      // job row - column at the tile origin
+        const bool slow = normalize != 0 || (symmetric && d0 > -BM && d0 < BN);
+        if (u1 > n_units) u1 = n_units;
+        for (int u = u0; u < u1; ++u) {
+            const bool tr = u >= 32;                       // a row of the transposed tile
+            const int r = sw * 32 + (u & 31);              // row of the (transposed) tile
+            // global position of the 128-entry row: K[grow][gcol0 + 0..127]
+            const i64 grow = (tr ? (i64)prv.bn * BN : (i64)prv.bm * BM) + r;
+            const i64 gcol0 = tr ? (i64)prv.bm * BM : (i64)prv.bn * BN;
+            const i64 lim_r = tr ? N : M_store, lim_c = tr ? M_store : N;     // transposed rows only exist when M == N
+            if (grow >= lim_r) continue;
+            const int e = 2 * lane;
+            float x0, x1;
+            if (tr) {
+                const float2 t = *(const float2*)(outb + ws_out_addr(e, r));      // tile entries (row e, col r), (e+1, r)
+                x0 = t.x, x1 = t.y;
+            } else {
+                x0 = *(const float*)(outb + ws_out_addr(r, e));
+                x1 = *(const float*)(outb + ws_out_addr(r, e + 1));
+            }
+            const i64 gc = gcol0 + e;
+            double v0 = WS_VAL(x0), v1 = WS_VAL(x1);
+            if (slow) {       // tiles that touch the diagonal, normalised jobs: selfk look-ups (global loads)
+                // tile coordinates for finish_entry: rows index the job's rows, cols its columns
+                const i64 jr0 = tr ? gc : grow, jc0 = tr ? grow : gc, jr1 = tr ? gc + 1 : grow, jc1 = tr ? grow : gc + 1;
+                if (gc < lim_c) v0 = finish_entry(v0, row_base + jr0, jc0, symmetric != 0, selfk, n_fit, normalize);
+                if (gc + 1 < lim_c) v1 = finish_entry(v1, row_base + jr1, jc1, symmetric != 0, selfk, n_fit, normalize);
+            }
+            double* dst = K + grow * N + gc;
+            if (even && gc + 1 < lim_c) *(double2*)dst = make_double2(v0, v1);
+            else {
+                if (gc < lim_c) dst[0] = v0;
+                if (gc + 1 < lim_c) dst[1] = v1;
+            }
+        }
+    };
+    // Fast form for interior tiles of plain jobs (no selfk look-up, even N).  The LDS reads are inline
+    // asm: in a kernel that also uses LDS-DMA the compiler puts s_waitcnt vmcnt(0) in front of every LDS
+    // read, i.e. the store waves would wait for their own stores every row.  Four rows per batch,
+    // 16-byte non-temporal stores.
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const unsigned out_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int8_t*)outb;
+    auto store_units_fast = [&](int u0, int u1) __attribute__((always_inline)) {
+        const bool mirror = tri && prv.bm != prv.bn;
+        const int n_units = mirror ? 64 : 32;
+        if (u1 > n_units) u1 = n_units;
+        const int e = 2 * lane;
+        double* const dst_rows = K + ((i64)prv.bm * BM + sw * 32) * N + (i64)prv.bn * BN + e;     // row-major rows
+        double* const dst_cols = K + ((i64)prv.bn * BN + sw * 32) * N + (i64)prv.bm * BM + e;     // rows of the transpose
+        for (int ub = u0; ub < u1; ub += 4) {
+            float2 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = ub + q;
+                if (u < u1) {                      // wave-uniform
+                    const int r = sw * 32 + (u & 31);
+                    if (u >= 32) {                 // tile entries (e, r), (e + 1, r): 8 contiguous bytes
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(x[q]) : "v"(out_lds + (unsigned)ws_out_addr(e, r)));
+                    } else {                       // tile entries (r, e), (r, e + 1)
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(x[q].x) : "v"(out_lds + (unsigned)ws_out_addr(r, e)));
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(x[q].y) : "v"(out_lds + (unsigned)ws_out_addr(r, e + 1)));
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = ub + q;
+                if (u < u1) {
+                    const v2d v = {WS_VAL(x[q].x), WS_VAL(x[q].y)};
+                    double* dst = (u >= 32 ? dst_cols : dst_rows) + (i64)(u & 31) * N;
+                    if (ABL == 0) __builtin_nontemporal_store(v, (v2d*)dst);
+                    else if (v.x == 1.2345e300) dst[0] = v.y;
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](int u0, int u1) __attribute__((always_inline)) {
+        const i64 d0 = row_base + (i64)prv.bm * BM - (i64)prv.bn * BN;
+        const bool plain = normalize == 0 && !(symmetric && d0 > -BM && d0 < BN) && even &&
+                           ((i64)prv.bm + 1) * BM <= M_store && ((i64)prv.bn + 1) * BN <= N &&
+                           (!(tri && prv.bm != prv.bn) || (((i64)prv.bn + 1) * BN <= M_store && ((i64)prv.bm + 1) * BM <= N));
+        if (plain) store_units_fast(u0, u1);
+        else store_units(u0, u1);
+    };
+    const int upc = k_steps > 0 ? (64 + k_steps - 1) / k_steps : 64;           // units per chunk (a mirrored tile has 64 per wave)
+
+    // ---- main loops: one per role, with the same barrier sequence (k_steps + 1 per tile, one at the end).
+    // Separate loop nests keep the accumulators of the compute role in one straight-line K loop.
+    if (is_compute) {
+#define WS_STEP(AS_FP4)                                                                        \
+    {                                                                                          \
+        /* this stage has landed; the one behind it may stay in flight */                      \
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");             \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
+        if (ABL < 4) __builtin_amdgcn_s_barrier();                                             \
+        --ahead;                                                                               \
+        if (ABL != 2) WS_COMPUTE(AS_FP4) else WS_ISSUE_NEXT()                                  \
+        buf_cp = buf_cp == WS_RING - 1 ? 0 : buf_cp + 1;                                       \
+    }
+        while (cur.ok) {
+            int kt = 0;
+            if (FP4) {
+                for (; kt < k8_steps; ++kt) WS_STEP(false)
+                if (k8_steps > 0) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = (float)gt_bits(acc[i][j][r]);
+                }
+                for (; kt < k_steps; ++kt) WS_STEP(true)
+            } else {
+                for (; kt < k_steps; ++kt) WS_STEP(false)
+            }
+            // hand-over: the store waves have read the parked tile completely, park this one
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int ctile = (wn * TN + nt) * 32 + (lane & 31);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rtile = (wm * TM + mt) * 32 + 8 * q + 4 * (lane >> 5);
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        const v4f t = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                        // asm: a plain LDS store would make the compiler drain the LDS-DMA prefetch (vmcnt(0)) first
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(out_lds + (unsigned)ws_out_addr(rtile, ctile)), "v"(t) : "memory");
+                    }
+                }
+            WS_ZERO_ACC()
+            // every stage of this tile has been queued, so the load cursor already stands on the next tile
+            // (with a single K-step per tile it may stand two tiles ahead: walk then)
+            if (k_steps >= 2) cur = ldt;
+            else cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#undef WS_STEP
+    } else {
+        while (cur.ok) {
+            for (int kt = 0; kt < k_steps; ++kt) {
+                if (ABL < 4) __builtin_amdgcn_s_barrier();
+                if (prv.ok && ABL != 5) store_chunk(kt * upc, (kt + 1) * upc);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            prv = cur;
+            cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+        }
+        // drain: the last parked tile
+        __builtin_amdgcn_s_barrier();
+        if (prv.ok) store_chunk(0, 64);
+    }
+#undef WS_VAL
+#undef WS_COMPUTE
+#undef WS_READ
+#undef WS_MFMA
+#undef WS_ISSUE_NEXT
+#undef WS_SRC_BASE
+#undef WS_ZERO_ACC
+}
+
+static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
+                        i64 row_lo, int normalize, double* K, int tri, int patch, double* entries_done) {
+    const int tiles_m = (int)cdiv(M, GT_BM), tiles_n = (int)cdiv(n_cols, GT_BM);
+    const int patch_sz = patch ? GI_PATCH : 0;
+    const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch_sz);
+    int k_all = f->k1_steps + f->k8_steps, k8 = f->k8_steps;
+    i64 M_store = M;
+    int abl_bits = 0;
+    if (const char* abl = getenv("GK_GRAM_ABL")) {     // timing ablations (tools/gram_only.py): WRONG results
+        if (!strcmp(abl, "nostore")) M_store = 0, abl_bits = 6;       // K loop only: every store is predicated off
+        if (!strcmp(abl, "nok")) k_all = 0, k8 = 0;     // epilogue only
+        if (!strcmp(abl, "noload")) abl_bits = 1;      // persistent kernel: MFMA + LDS reads only
+        if (!strcmp(abl, "nomfma")) abl_bits = 2;      // persistent kernel: operand streaming only
+        if (!strcmp(abl, "mfmaonly")) abl_bits = 3;    // no loads, no LDS reads
+        if (!strcmp(abl, "nobarrier")) abl_bits = 4;   // no loads, no per-step barrier
+        if (!strcmp(abl, "puremfma")) abl_bits = 5;    // compute waves: MFMA only, store waves idle, no barriers
+    }
+    const bool use_ws = getenv("GK_GRAM_NO_WS") == nullptr;
+    if (use_ws) {
+        int n_cu = 256;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        }
+        const i64 grid = blocks < n_cu ? blocks : n_cu;
+        unsigned* ticket = nullptr;
+        Tmp<unsigned> ticket_buf(ctx);
+        if (getenv("GK_GRAM_XCC")) {
+            GK_TRY(ticket_buf.alloc(8));
+            GK_TRY(gk_zero_async(ctx, ticket_buf.p, 32));
+            ticket = ticket_buf.p;
+        }
+        void (*kern)(const int8_t*, const int8_t*, i64, int, int, const u64*, double*, i64, i64, i64, int, i64, int, int, int,
+                     int, int, int, i64, unsigned*) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
+        if (abl_bits == 1) kern = gram_ws_kernel<true, 1>;
+        if (abl_bits == 2) kern = gram_ws_kernel<true, 2>;
+        if (abl_bits == 3) kern = gram_ws_kernel<true, 3>;
+        if (abl_bits == 4) kern = gram_ws_kernel<true, 4>;
+        if (abl_bits == 5) kern = gram_ws_kernel<true, 5>;
+        if (abl_bits == 6) kern = gram_ws_kernel<true, 6>, M_store = M;
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+        kern<<<dim3((unsigned)grid), dim3(512), WS_LDS_BYTES, ctx->stream>>>(
+            a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
+            normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket);
+    } else if (f->phi_fp4) {
+        auto kern = gram_tile_kernel<true>;
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES));
+        kern<<<dim3((unsigned)blocks), dim3(256), GT_LDS_BYTES, ctx->stream>>>(
+            a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M_store, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
+            normalize, tiles_m, tiles_n, tri, patch_sz);
+    } else {
+        auto kern = gram_tile_kernel<false>;
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES));
+        kern<<<dim3((unsigned)blocks), dim3(256), GT_LDS_BYTES, ctx->stream>>>(
+            a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M_store, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
+            normalize, tiles_m, tiles_n, tri, patch_sz);
+    }
+    // entries actually multiplied (real rows and columns; the zero padding of edge tiles is not work)
+    *entries_done = tri ? (double)M * (M + 1) / 2 : (double)M * n_cols;
     return GK_OK;
 }
 
@@ -473,20 +837,7 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
         // full symmetric job: only tiles on/above the diagonal are computed, each written twice
         const int tri = (f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
         const int patch = getenv("GK_GRAM_NO_PATCH") ? 0 : 1;
-        const char* shape = getenv("GK_GRAM_TILE");
-        if (shape && !strcmp(shape, "256")) {
-            GK_TRY((launch_glds<2, 4, 4, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
-        } else if (shape && !strcmp(shape, "128ns3")) {
-            GK_TRY((launch_glds<2, 2, 2, 2, 3>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
-        } else if (shape && !strcmp(shape, "128ns2")) {
-            GK_TRY((launch_glds<2, 2, 2, 2, 2>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
-        } else if ((shape && !strcmp(shape, "128")) || (!shape && f->n_cols_pad < 8192)) {
-            // short K: the 128x128 tile runs two workgroups per CU, so one tile's float64 store
-            // epilogue overlaps the other's MFMA loop (measured 0.36 vs 0.41 ms at K = 3968)
-            GK_TRY((launch_glds<2, 2, 2, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 8, &tiles_done)));
-        } else {
-            GK_TRY((launch_glds<2, 4, 4, 2, 4>(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, 4, &tiles_done)));
-        }
+        GK_TRY(launch_tiles(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, &tiles_done));
     }
     GK_HIP_CHECK(hipGetLastError());
     GK_HIP_CHECK(hipEventRecord(e1, ctx->stream));

@@ -17,10 +17,11 @@ variants = [dict()]
 variants += [dict(x.split("=") for x in v.split(",")) for v in sys.argv[2:]]
 for env in variants:
     for k in list(os.environ):
-        if k.startswith("GK_GRAM"): del os.environ[k]
+        if k.startswith("GK_GRAM") or k == "GK_LOW_DF": del os.environ[k]
     os.environ.update(env)
-    if any(k in env for k in ("GK_LOW_DF",)):
+    if any(k in env for k in ("GK_LOW_DF", "GK_GRAM_NO_FP4")) or getattr(feat, "_special", False):
         feat.close(); feat = eng.features(db, 6)
+        feat._special = any(k in env for k in ("GK_LOW_DF", "GK_GRAM_NO_FP4"))
         print("   features: dense cols", feat.n_cols, "low_df", env.get("GK_LOW_DF"))
     ms, tot = [], []
     for it in range(6):
