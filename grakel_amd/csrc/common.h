@@ -74,6 +74,7 @@ struct gk_ctx {
     u32 mbox_seq = 0;
 };
 #define GK_MBOX_WORDS 512
+#define GK_HIST0_MAX_LABELS 256
 
 // Read n_words (<= GK_MBOX_WORDS - 1) u32 values at device address src back to dst_host, ordered after
 // everything queued on the context's stream so far.  Returns when the values have arrived.
@@ -164,6 +165,10 @@ struct gk_batch {
     // scratch kept between levels
     i32* nbr_sorted = nullptr;         // [n_edges] sorted neighbour labels of the level being built
     bool is_pair_batch = false;        // ShortestPath items: no CSR, level 0 only
+    // level 0 of a batch with at most GK_HIST0_MAX_LABELS input labels is never sorted: the label-count
+    // features of that level come from one LDS histogram per graph (features.hip), perm[0] stays unused
+    bool level0_hist = false;
+    i32 n_labels0_present = 0;         // distinct level-0 label ids that occur (valid when n_labels0 <= GK_HIST0_MAX_LABELS)
 };
 
 // ---------------------------------------------------------------------------------------

@@ -49,6 +49,8 @@ struct FeatLevels {
     i64 n[FEAT_MAX_LEVELS];
     i64 off[FEAT_MAX_LEVELS + 1];     // multiples of SF_TILE; off[L] = size of the item space
     int level[FEAT_MAX_LEVELS];       // WL level of the slot (levels without shared labels are skipped)
+    int synth;                        // slot whose triple / run arrays come from the level-0 histogram (-1: none):
+                                      // the per-item kernels skip it
     int L;
     __device__ __forceinline__ int slot_of(i64 i) const {
         int j = 0;
@@ -74,9 +76,10 @@ __global__ void feat_flags_kernel(const FeatLevels P, const FeatArrays A, const 
     if (k < P.n[j]) {
         const i32* perm = P.perm[j];
         const i32* lab = P.lab[j];
-        const i32 v = perm[k];
+        const i32 v = j == P.synth ? 0 : perm[k];
         f = 0x100000001ull;
-        if (k > 0) {
+        if (j == P.synth) f = 0;
+        else if (k > 0) {
             const i32 p = perm[k - 1];
             const bool lh = lab[v] != lab[p];
             const bool sh = lh || node_graph[v] != node_graph[p];
@@ -96,7 +99,7 @@ struct TripleEmit {
     __device__ __forceinline__ void emit(i64 i, u64 f, u64 s) const {
         const int j = P.slot_of(i);
         const i64 k = i - P.off[j];
-        if (k >= P.n[j]) return;
+        if (k >= P.n[j] || j == P.synth) return;
         const i64 b = A.base(P, j);
         const i32 t = (i32)(u32)(s & 0xffffffffull) - 1;
         const i32 r = (i32)(u32)(s >> 32) - 1;
@@ -120,12 +123,11 @@ struct TripleEmit {
     }
 };
 
-// per item: acc[level][v] = count of v's (label,graph) triple; the sum over the nodes of a graph
-// of these counts == sum over its triples of count^2, so the exact self similarity needs no
-// atomics.  Nodes a partial level does not list own their label: their slot was pre-set to 1.
+// per item: the count of its (label,graph) triple -> exact self similarity (see below), largest count,
+// operand class of the run.
 // Also tracks the largest count and flags runs whose counts leave the primary / the int8 range.
 __global__ void feat_count_kernel(const FeatLevels P, const FeatArrays A, const u32* __restrict__ tri_of,
-                                  int prim_max, int wide_above, u32* __restrict__ acc, i64 V, u32* __restrict__ meta,
+                                  int prim_max, int wide_above, u64* __restrict__ selfk, u32* __restrict__ meta,
                                   int n_levels, int kind) {
     __shared__ u32 wmax[4];
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,7 +135,7 @@ __global__ void feat_count_kernel(const FeatLevels P, const FeatArrays A, const 
     if (i < P.off[P.L]) {
         const int j = P.slot_of(i);
         const i64 k = i - P.off[j];
-        if (k < P.n[j]) {
+        if (k < P.n[j] && j != P.synth) {
             const i64 b = A.base(P, j);
             const i32 t = (i32)tri_of[i];
             c = (u32)(A.tri_pos[b + t + 1] - A.tri_pos[b + t]);
@@ -146,7 +148,11 @@ __global__ void feat_count_kernel(const FeatLevels P, const FeatArrays A, const 
                 if ((int)c > prim_max) w[0] = 1;
                 if ((int)c > wide_above) w[1] = 1;
             }
-            acc[(i64)j * V + P.perm[j][k]] = kind ? 1u : c;                    // min(c,c) summed == #nodes
+            // exact self similarity: every node counts 1 per level (feat_selfk_init_kernel), a triple of
+            // count c adds the remaining c^2 - c once (integer atomics: exact, order independent; kind 1
+            // sums min(c, c) = c per triple, i.e. nothing beyond the baseline)
+            if (!kind && c >= 2u && k == (i64)A.tri_pos[b + t])
+                atomicAdd((unsigned long long*)&selfk[A.tri_graph[b + t]], (unsigned long long)c * c - c);
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -190,27 +196,142 @@ __global__ void feat_runmax_kernel(const FeatLevels P, const FeatArrays A, const
     }
 }
 
-// pre-set the accumulator slots of the partial levels (nodes outside the listed prefix count 1)
-__global__ void feat_fill_ones_kernel(u32* __restrict__ acc, i64 V, const FeatLevels P) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V * P.L) return;
-    const int j = (int)(i / V);
-    if (P.n[j] < V) acc[i] = 1u;
+// selfk[g] = nodes of g x (levels whose triples go through feat_count_kernel or that list nothing) + the
+// level-0 histogram's own sum (extra, may be null); feat_count_kernel adds c^2 - c per triple.
+__global__ void feat_selfk_init_kernel(const i32* __restrict__ graph_ptr, u64* __restrict__ selfk, i64 n_graphs,
+                                       int n_levels_plain, const u64* __restrict__ extra) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_graphs) return;
+    selfk[g] = (u64)(graph_ptr[g + 1] - graph_ptr[g]) * (u64)n_levels_plain + (extra ? extra[g] : 0ull);
 }
 
-// one wave per graph: selfk[g] = sum over the listed levels of the graph's accumulator slots,
-// plus one per node for every level that lists nothing at all (n_unlisted such levels)
-__global__ void feat_selfk_kernel(const i32* __restrict__ graph_ptr, const u32* __restrict__ acc, i64 V, int L,
-                                  u64* __restrict__ selfk, i64 n_graphs, int n_unlisted) {
-    const i64 g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+// ---- level 0 with a small label alphabet (wl.hip: gk_batch::level0_hist): no label-grouped order exists.
+// hist0: one wave per graph counts its labels in LDS -> C0T[label][graph] and the graph's sum of
+// squared counts (kind 1: its node count).  hist0_rows: one workgroup per label reduces its row to
+// (graphs containing it, nodes carrying it).  hist0_synth: one workgroup per label writes that label's
+// triples (tri_graph, tri_pos as the running node count, tri_run), its run entry (tstart, operand-class
+// flags) and workgroup 0 the sentinels and the level's triple / run counts -- exactly the arrays
+// TripleEmit and feat_count_kernel produce for a sorted level, at L0 * N items instead of V.
+__global__ __launch_bounds__(256) void feat_hist0_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ lab0,
+                                                         i64 n_graphs, int L0, u32* __restrict__ c0t,
+                                                         u64* __restrict__ extra, int kind) {
+    __shared__ u32 h[4][GK_HIST0_MAX_LABELS];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const i64 g = (i64)blockIdx.x * 4 + w;
+    for (int l = lane; l < L0; l += 64) h[w][l] = 0;
+    __syncthreads();
+    if (g < n_graphs) {
+        const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
+        for (i32 v = v0 + lane; v < v1; v += 64) atomicAdd(&h[w][lab0[v]], 1u);
+    }
+    __syncthreads();
     if (g >= n_graphs) return;
-    const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
     u64 s = 0;
-    for (int j = 0; j < L; ++j)
-        for (i32 v = v0 + lane; v < v1; v += 64) s += acc[(i64)j * V + v];
+    for (int l = lane; l < L0; l += 64) {
+        const u32 c = h[w][l];
+        c0t[(i64)l * n_graphs + g] = c;
+        s += kind ? (u64)c : (u64)c * c;
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) selfk[g] = s + (u64)n_unlisted * (u64)(v1 - v0);
+    if (lane == 0) extra[g] = s;
+}
+
+__device__ __forceinline__ u32 hist0_block_sum(u32 x, u32* red) {       // 1024 threads
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    u32 t = 0;
+    for (int q = 0; q < 16; ++q) t += red[q];
+    return t;
+}
+
+// chunk = 1024 consecutive graphs of one label's row; rows[(l * n_chunks + ch) * 2 + {0,1}] = graphs containing
+// the label / nodes carrying it inside the chunk
+__global__ __launch_bounds__(1024) void feat_hist0_rows_kernel(const u32* __restrict__ c0t, i64 n_graphs, int n_chunks,
+                                                               u32* __restrict__ rows) {
+    __shared__ u32 red[16];
+    const int l = blockIdx.x / n_chunks, ch = blockIdx.x % n_chunks;
+    const i64 g = (i64)ch * 1024 + threadIdx.x;
+    const u32 c = g < n_graphs ? c0t[(i64)l * n_graphs + g] : 0u;
+    const u32 df = hist0_block_sum(c ? 1u : 0u, red);
+    const u32 sz = hist0_block_sum(c, red);
+    if (threadIdx.x == 0) rows[2 * (i64)blockIdx.x] = df, rows[2 * (i64)blockIdx.x + 1] = sz;
+}
+
+__global__ __launch_bounds__(1024) void feat_hist0_synth_kernel(const u32* __restrict__ c0t, const u32* __restrict__ rows,
+                                                                i64 n_graphs, int n_chunks, int L0, const FeatArrays A, i64 base,
+                                                                u32* __restrict__ meta, int level, int n_levels, int prim_max,
+                                                                int wide_above, int kind) {
+    __shared__ u32 red[16];
+    __shared__ u32 wsum_t[16], wsum_p[16];
+    __shared__ u32 sh[8];
+    const int l = blockIdx.x / n_chunks, ch = blockIdx.x % n_chunks, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // triples / nodes before this chunk (earlier labels, earlier chunks of this label), non-empty labels before
+    // this label, the label's own totals, and the totals of the level: sums over the (label, chunk) cells
+    u32 tb = 0, pb = 0, tt = 0, pt = 0, mine = 0;
+    const int cells = L0 * n_chunks;
+    for (int q = tid; q < cells; q += 1024) {
+        const u32 d = rows[2 * q], z = rows[2 * q + 1];
+        if (q < (int)blockIdx.x) tb += d, pb += z;
+        if (q / n_chunks == l) mine += d;
+        tt += d, pt += z;
+    }
+    tb = hist0_block_sum(tb, red), pb = hist0_block_sum(pb, red), tt = hist0_block_sum(tt, red);
+    pt = hist0_block_sum(pt, red), mine = hist0_block_sum(mine, red);
+    // non-empty labels before l / in total: thread q < L0 sums label q's chunks
+    u32 ne_before = 0, ne_all = 0;
+    if (tid < L0) {
+        u32 d = 0;
+        for (int c2 = 0; c2 < n_chunks; ++c2) d += rows[2 * (tid * n_chunks + c2)];
+        ne_all = d ? 1u : 0u;
+        ne_before = (d && tid < l) ? 1u : 0u;
+    }
+    const u32 rb = hist0_block_sum(ne_before, red), rt = hist0_block_sum(ne_all, red);
+    if (blockIdx.x == 0 && tid == 0) {   // sentinels and counts of the level
+        A.tri_pos[base + tt] = (i32)pt;
+        A.tstart[base + rt] = (i32)tt;
+        meta[META_T(level)] = tt;
+        meta[META_R(level)] = rt;
+    }
+    if (mine == 0) return;
+    if (ch == 0 && tid == 0) A.tstart[base + rb] = (i32)tb;
+    const i64 g = (i64)ch * 1024 + tid;
+    const u32 c = g < n_graphs ? c0t[(i64)l * n_graphs + g] : 0u;
+    const u32 has = c ? 1u : 0u;
+    u32 it = has, ip = c;                         // inclusive scans over the 1024 graphs of the chunk
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 yt = __shfl_up(it, off, 64), yp = __shfl_up(ip, off, 64);
+        if (lane >= off) it += yt, ip += yp;
+    }
+    __syncthreads();
+    if (lane == 63) wsum_t[w] = it, wsum_p[w] = ip;
+    __syncthreads();
+    u32 bt = 0, bp = 0;
+    for (int q = 0; q < w; ++q) bt += wsum_t[q], bp += wsum_p[q];
+    if (has) {
+        const i64 t = base + tb + bt + it - 1;
+        A.tri_graph[t] = (i32)g;
+        A.tri_pos[t] = (i32)(pb + bp + ip - c);
+        A.tri_run[t] = (i32)rb;
+    }
+    // largest count of the chunk: operand class of the label's run (OR / max from every chunk), the job's largest count
+    u32 cmax = c;
+    for (int off = 32; off > 0; off >>= 1) { const u32 o = __shfl_down(cmax, off, 64); cmax = o > cmax ? o : cmax; }
+    __syncthreads();
+    if (lane == 0) red[w] = cmax;
+    __syncthreads();
+    if (tid == 0) {
+        u32 m = 0;
+        for (int q = 0; q < 16; ++q) m = red[q] > m ? red[q] : m;
+        if (kind) atomicMax(&A.wide[base + rb], (i32)m);        // unary width of the run
+        else {
+            const i32 fl = ((int)m > prim_max ? 1 : 0) | ((int)m > wide_above ? 0x100 : 0);
+            if (fl) atomicOr(&A.wide[base + rb], fl);
+        }
+        atomicMax(&meta[4 * n_levels + 5 + (blockIdx.x & 63)], m);
+    }
+    (void)sh;
 }
 
 // Column classes per label run, fused into ONE prefix sum over the runs of all levels:
@@ -410,16 +531,20 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     // ---- the level slots: a level only lists the nodes that can share a label (wl.hip: active-set
     // levels), a level that lists nothing adds one per node to the diagonal and nothing else
     FeatLevels P;
-    P.L = 0, P.off[0] = 0;
+    P.L = 0, P.off[0] = 0, P.synth = -1;
     int n_unlisted = 0;
     std::vector<int> slot_of_level(n_levels, -1);
+    const bool hist0 = b->level0_hist && !b->is_pair_batch && V > 0;
+    const i64 L0 = b->n_labels0;
     for (int l = 0; l < n_levels && V > 0; ++l) {
-        const i64 nl = (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V;
+        i64 nl = (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V;
+        if (l == 0 && hist0) nl = L0 * N;           // items of the synthesized slot: (label, graph) cells
         if (nl == 0) { ++n_unlisted; continue; }
         const int j = P.L++;
         slot_of_level[l] = j;
         P.perm[j] = b->perm + (size_t)l * V, P.lab[j] = b->labels + (size_t)l * V;
         P.n[j] = nl, P.level[j] = l;
+        if (l == 0 && hist0) P.synth = j;
         P.off[j + 1] = P.off[j] + round_up(nl, SF_TILE);
     }
     const i64 total = P.off[P.L];
@@ -433,15 +558,26 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
             f->arena.push_back(q);
         }
         Tmp<u64> flag(ctx);
-        Tmp<u32> tri_of(ctx), acc(ctx);
-        if ((r = flag.alloc(total)) || (r = tri_of.alloc(total)) || (r = acc.alloc((size_t)P.L * V))) return fail(r);
-        bool any_partial = false;
-        for (int j = 0; j < P.L; ++j) any_partial |= P.n[j] < V;
-        if (any_partial) feat_fill_ones_kernel<<<grid_for(V * P.L, 256), 256, 0, ctx->stream>>>(acc.p, V, P);
+        Tmp<u32> tri_of(ctx);
+        if ((r = flag.alloc(total)) || (r = tri_of.alloc(total))) return fail(r);
         feat_flags_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, b->node_graph, flag.p);
+        Tmp<u32> c0t(ctx), rows0(ctx);
+        Tmp<u64> extra0(ctx);
+        if (P.synth >= 0) {
+            const int n_chunks = (int)cdiv(N, 1024);
+            if ((r = c0t.alloc((size_t)(L0 * N))) || (r = rows0.alloc((size_t)(2 * L0 * n_chunks))) || (r = extra0.alloc((size_t)N))) return fail(r);
+            feat_hist0_kernel<<<grid_for(N, 4), 256, 0, ctx->stream>>>(b->graph_ptr, b->labels, N, (int)L0, c0t.p, extra0.p, kind);
+            feat_hist0_rows_kernel<<<dim3((unsigned)(L0 * n_chunks)), 1024, 0, ctx->stream>>>(c0t.p, N, n_chunks, rows0.p);
+            feat_hist0_synth_kernel<<<dim3((unsigned)(L0 * n_chunks)), 1024, 0, ctx->stream>>>(
+                c0t.p, rows0.p, N, n_chunks, (int)L0, A, P.off[P.synth] + P.synth, f->meta, P.level[P.synth], n_levels, prim_max,
+                wide_above, kind);
+        }
+        feat_selfk_init_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, f->selfk, N,
+                                                                          n_levels - (P.synth >= 0 ? 1 : 0),
+                                                                          P.synth >= 0 ? extra0.p : nullptr);
         TripleEmit te{P, A, b->node_graph, flag.p, tri_of.p, f->meta};
         if ((r = gk_scan_fn<u64, TripleEmit>(ctx, te, total, nullptr))) return fail(r);
-        feat_count_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, tri_of.p, prim_max, wide_above, acc.p, V, f->meta,
+        feat_count_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, tri_of.p, prim_max, wide_above, f->selfk, f->meta,
                                                                          n_levels, kind);
         if (kind == GK_FEAT_MINSUM) feat_runmax_kernel<<<grid_for(total, 256), 256, 0, ctx->stream>>>(P, A, f->meta);
         ColumnIds ci{P, A, f->meta, f->symmetric ? 1 : 0, (i32)n_fit, (i32)f->low_df, kind, n_levels};
@@ -450,13 +586,10 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
             ColumnIdsByteWide cw{P, A, f->meta, n_levels};
             if ((r = gk_scan_fn<u64, ColumnIdsByteWide>(ctx, cw, total, nullptr))) return fail(r);
         }
-        feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, acc.p, V, P.L, f->selfk, N,
-                                                                          n_unlisted);
         // one host sync: sizes of the dense operand
         if ((r = gk_readback(ctx, f->meta, h.data(), (int)n_meta))) return fail(r);
     } else if (V > 0) {      // no two nodes share a label at any level: K is its diagonal, n_levels per node
-        feat_selfk_kernel<<<grid_for(N * 64, 256), 256, 0, ctx->stream>>>(b->graph_ptr, nullptr, V, 0, f->selfk, N,
-                                                                          n_unlisted);
+        feat_selfk_init_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, f->selfk, N, n_levels, nullptr);
     }
     const int G = 3 * n_levels;
     f->nnz = 0;

@@ -644,10 +644,46 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const i32* __restrict_
     }
 }
 
-// one block: stats[0] = max graph nodes, stats[1] = max degree
+// Input validation (the C ABI does not trust its caller: a malformed CSR must become GK_ERR_ARG, not an
+// out-of-bounds gather in the signature kernels) and the set of level-0 label ids that occur.
+//   err bits: 1 graph_ptr not a monotone cover of [0, n_nodes], 2 row_ptr not a monotone cover of
+//   [0, n_edges], 4 label id outside [0, n_labels0), 8 neighbour outside the node range of its graph
+__global__ void batch_check_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr,
+                                   const i32* __restrict__ col_idx, const i32* __restrict__ node_graph,
+                                   const i32* __restrict__ labels, i64 n_graphs, i64 n_nodes, i64 n_edges,
+                                   i32 n_labels0, u32* __restrict__ pres, u32* __restrict__ err) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 e = 0;
+    if (i < n_graphs) {
+        const i64 a = graph_ptr[i], b = graph_ptr[i + 1];
+        if (a < 0 || a > b || b > n_nodes || (i == 0 && a != 0) || (i == n_graphs - 1 && b != n_nodes)) e |= 1u;
+    }
+    if (i < n_nodes) {
+        const i64 r0 = row_ptr[i], r1 = row_ptr[i + 1];
+        if (r0 < 0 || r0 > r1 || r1 > n_edges || (i == 0 && r0 != 0) || (i == n_nodes - 1 && r1 != n_edges)) e |= 2u;
+        const i32 l = labels[i];
+        if (l < 0 || l >= n_labels0) e |= 4u;
+        else if (pres && !pres[l]) pres[l] = 1u;          // same value from every writer
+        if (!(e & 2u)) {
+            const i32 g = node_graph[i];
+            const i32 lo = graph_ptr[g], hi = graph_ptr[g + 1];
+            for (i64 k = r0; k < r1; ++k) {
+                const i32 c = col_idx[k];
+                if (c < lo || c >= hi) { e |= 8u; break; }
+            }
+        }
+    }
+    if (e) atomicOr(err, e);
+}
+
+// one block: stats[0] = max graph nodes, stats[1] = max degree, stats[4] = level-0 label ids that occur
 __global__ __launch_bounds__(1024) void batch_stats_reduce_kernel(const i32* __restrict__ part, int nblk,
-                                                                  i32* __restrict__ stats) {
+                                                                  i32* __restrict__ stats, const u32* __restrict__ pres, int n_pres) {
     __shared__ int sg[16], sd[16];
+    __shared__ int spres;
+    if (threadIdx.x == 0) spres = 0;
+    __syncthreads();
+    if (pres && (int)threadIdx.x < n_pres && pres[threadIdx.x]) atomicAdd(&spres, 1);
     int gn = 0, d = 0;
     for (int i = threadIdx.x; i < nblk; i += 1024) {
         const int a = part[2 * i], b = part[2 * i + 1];
@@ -661,7 +697,7 @@ __global__ __launch_bounds__(1024) void batch_stats_reduce_kernel(const i32* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int q = 1; q < 16; ++q) { gn = sg[q] > gn ? sg[q] : gn; d = sd[q] > d ? sd[q] : d; }
-        stats[0] = gn, stats[1] = d;
+        stats[0] = gn, stats[1] = d, stats[4] = spres;
     }
 }
 
@@ -719,15 +755,31 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
     const int nblk = (int)cdiv(m > 0 ? m : 1, 256);
     GK_TRY(flag.alloc(n_nodes)); GK_TRY(excl.alloc(n_nodes)); GK_TRY(total.alloc(1));
     GK_TRY(iso_flag.alloc(n_nodes)); GK_TRY(iso_excl.alloc(n_nodes));
-    GK_TRY(stats.alloc(5)); GK_TRY(part.alloc(2 * (size_t)nblk));
+    Tmp<u32> pres(ctx);
+    const bool few_labels = b->n_labels0 >= 1 && b->n_labels0 <= GK_HIST0_MAX_LABELS;
+    GK_TRY(stats.alloc(8)); GK_TRY(part.alloc(2 * (size_t)nblk)); GK_TRY(pres.alloc(GK_HIST0_MAX_LABELS));
+    GK_TRY(gk_zero_async(ctx, stats.p, 32));
+    GK_TRY(gk_zero_async(ctx, pres.p, GK_HIST0_MAX_LABELS * 4));
+    batch_check_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, b->node_graph, b->labels,
+                                                             n_graphs, n_nodes, b->n_edges, b->n_labels0,
+                                                             few_labels ? pres.p : nullptr, (u32*)stats.p + 5);
     batch_stats_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, n_graphs, n_nodes, flag.p,
                                                              iso_flag.p, part.p);
-    batch_stats_reduce_kernel<<<1, 1024, 0, ctx->stream>>>(part.p, nblk, stats.p);
+    batch_stats_reduce_kernel<<<1, 1024, 0, ctx->stream>>>(part.p, nblk, stats.p, few_labels ? pres.p : nullptr,
+                                                            (int)b->n_labels0);
     GK_TRY(gk_scan_u32(ctx, flag.p, excl.p, n_nodes, true, (u32*)stats.p + 2));
     GK_TRY(gk_scan_u32(ctx, iso_flag.p, iso_excl.p, n_nodes, true, (u32*)stats.p + 3));
-    u32 h[4] = {0, 0, 0, 0};
-    GK_TRY(gk_readback(ctx, (const u32*)stats.p, h, 4));
+    u32 h[6] = {0, 0, 0, 0, 0, 0};
+    GK_TRY(gk_readback(ctx, (const u32*)stats.p, h, 6));
+    if (h[5]) {
+        gk_set_error("gk_batch_create: malformed batch (%s%s%s%s)", (h[5] & 1u) ? "graph_ptr is not a monotone cover of the nodes; " : "",
+                     (h[5] & 2u) ? "row_ptr is not a monotone cover of the edges; " : "",
+                     (h[5] & 4u) ? "node_label outside [0, n_labels0); " : "",
+                     (h[5] & 8u) ? "col_idx leaves the node range of its graph" : "");
+        return GK_ERR_ARG;
+    }
     b->max_graph_nodes = (i32)h[0], b->max_degree = (i32)h[1], b->n_big = h[2];
+    b->n_labels0_present = few_labels ? (i32)h[4] : 0;
     b->n_iso = 0;
     if (h[3] > 0 && !getenv("GK_WL_NO_ISO")) {
         // the carried list of the isolated vertices (see gk_batch::iso_info)
@@ -1269,8 +1321,12 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     st.tiny_level.assign((size_t)n_levels, 0);
     GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
     GK_TRY(st.act2.alloc(V / 4 + 1));      // active-set levels hold at most V/4 active nodes
-    // level 0: group nodes by the given label ids
-    {
+    // level 0: group nodes by the given label ids -- unless there are only a few of them: then nothing of
+    // level 0 needs an order (level 1 always takes the full path and never reads the singleton flags, the
+    // label-count features of level 0 come from one LDS histogram per graph, features.hip)
+    const bool hist0 = V > 0 && b->n_labels0 >= 1 && b->n_labels0 <= GK_HIST0_MAX_LABELS && !getenv("GK_WL_NO_HIST0");
+    b->level0_hist = hist0;
+    if (!hist0) {
         Tmp<u64> keys(ctx);
         Tmp<i32> lab_tmp(ctx);
         GK_TRY(keys.alloc(V)); GK_TRY(lab_tmp.alloc(V));
@@ -1301,6 +1357,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         if (st.full_level[lvl]) b->n_sorted[lvl] = h[2 * n_levels + lvl];
         else if (st.tiny_level[lvl]) b->n_sorted[lvl] += h[3 * n_levels + lvl];      // carried + active
     }
+    if (hist0) h[0] = (u32)b->n_labels0_present;
     for (int lvl = 0; lvl < n_levels; ++lvl) {
         b->label_counts[lvl] = h[lvl];
         if (out_label_counts) out_label_counts[lvl] = h[lvl];
