@@ -37,6 +37,8 @@ SIGNATURES = {
     "gk_profile_enable": (c_int, [c_void_p, c_int]),
     "gk_profile_reset": (c_int, [c_void_p]),
     "gk_profile_get": (c_int, [c_void_p, c_char_p, _f64p, _i64p]),
+    "gk_host_alloc": (c_int, [ctypes.c_uint64, _vpp]),
+    "gk_host_free": (c_int, [c_void_p]),
     "gk_batch_create": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int32, c_int, _vpp]),
     "gk_batch_destroy": (c_int, [c_void_p]),
@@ -54,6 +56,7 @@ SIGNATURES = {
     "gk_gram_dev_ptr": (c_int, [c_void_p, _vpp, _i64p, _i64p]),
     "gk_gram_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "gk_gram_last_stats": (c_int, [c_void_p, _f64p, _f64p]),
+    "gk_gram_checksum": (c_int, [c_void_p, c_void_p, _f64p, _f64p, _f64p]),
     "gk_sp_build": (c_int, [c_void_p, c_void_p, c_void_p, c_int, _vpp, _i64p, _i64p]),
     "gk_batch_from_shards": (c_int, [c_void_p, c_int, _i64p, c_int64, c_int64, c_int64, c_void_p, c_int, _vpp]),
     "gk_core_numbers": (c_int, [c_void_p, c_void_p, c_void_p]),

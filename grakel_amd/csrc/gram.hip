@@ -913,6 +913,81 @@ extern "C" int gk_gram_dev_ptr(gk_feat* f, void** out_dev_ptr, int64_t* n_rows, 
     return GK_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Checksums of the Gram output that is still on the device (bench.py asserts the timed matrix without the
+// 8 N^2-byte copy; the 50 000-graph parity test checks symmetry of a 20 GB matrix in place):
+// sum of all entries, trace and max |K_ij - K_ji| (square outputs), 32x32 tiles transposed through LDS.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_checksum_kernel(const double* __restrict__ K, i64 M, i64 N, int square,
+                                                            double* __restrict__ out /* sum, trace, max asym */) {
+    __shared__ double ta[32][33], tb[32][33];
+    __shared__ double red[3][4];
+    const i64 tiles_n = (N + 31) / 32;
+    const i64 ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
+    double s = 0.0, tr = 0.0, as = 0.0;
+    if (!square || tj >= ti) {
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 8 rows per pass
+        for (int r = ty; r < 32; r += 8) {
+            const i64 i = ti * 32 + r, j = tj * 32 + tx;
+            ta[r][tx] = (i < M && j < N) ? K[i * N + j] : 0.0;
+            if (square) {
+                const i64 i2 = tj * 32 + r, j2 = ti * 32 + tx;
+                tb[r][tx] = (i2 < M && j2 < N) ? K[i2 * N + j2] : 0.0;
+            }
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const i64 i = ti * 32 + r, j = tj * 32 + tx;
+            if (i < M && j < N) {
+                const double a = ta[r][tx];
+                if (!square) s += a;
+                else {
+                    const double b = tb[tx][r];            // K[j][i]
+                    if (tj > ti) s += a + b;
+                    else s += a;                           // diagonal tile: every entry once
+                    const double d = a > b ? a - b : b - a;
+                    as = d > as ? d : as;
+                    if (i == j) tr += a;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64), tr += __shfl_down(tr, off, 64);
+        const double o = __shfl_down(as, off, 64);
+        as = o > as ? o : as;
+    }
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s, red[1][threadIdx.x >> 6] = tr, red[2][threadIdx.x >> 6] = as;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0, T = 0, A = 0;
+        for (int q = 0; q < 4; ++q) { S += red[0][q], T += red[1][q]; A = red[2][q] > A ? red[2][q] : A; }
+        if (S != 0.0) atomicAdd(&out[0], S);
+        if (T != 0.0) atomicAdd(&out[1], T);
+        if (A > 0.0) atomicMax((unsigned long long*)&out[2], (unsigned long long)__double_as_longlong(A));   // A >= 0: bit order == value order
+    }
+}
+
+extern "C" int gk_gram_checksum(gk_ctx* ctx, gk_feat* f, double* out_sum, double* out_trace, double* out_max_asym) {
+    GK_ARG(ctx && f && f->K, "gk_gram_checksum: no Gram output on the device (call gk_gram first)");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    const i64 M = f->K_rows, N = f->K_cols;
+    const int square = M == N ? 1 : 0;
+    Tmp<double> out(ctx);
+    GK_TRY(out.alloc(3));
+    GK_TRY(gk_zero_async(ctx, out.p, 24));
+    const i64 blocks = ((M + 31) / 32) * ((N + 31) / 32);
+    GK_ARG(blocks < (1ll << 31), "gk_gram_checksum: matrix too large");
+    if (blocks > 0) gram_checksum_kernel<<<dim3((unsigned)blocks), 256, 0, ctx->stream>>>(f->K, M, N, square, out.p);
+    double h[3] = {0, 0, 0};
+    GK_HIP_CHECK(hipMemcpyAsync(h, out.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (out_sum) *out_sum = h[0];
+    if (out_trace) *out_trace = square ? h[1] : 0.0;
+    if (out_max_asym) *out_max_asym = square ? h[2] : 0.0;
+    return GK_OK;
+}
+
 extern "C" int gk_gram_last_stats(gk_feat* f, double* out_flops, double* out_ms_event) {
     GK_ARG(f, "gk_gram_last_stats: null");
     if (f->last_ms < 0 && f->ev0) {

@@ -3,7 +3,12 @@
 The path shards naturally with ONE exchange step: rank r owns the graphs
 [lo_r, hi_r) -- it ingests/packs only those and holds only their CSR shard in HBM -- but WL
 labels are a *global* dictionary, so before relabelling every rank needs every graph's
-level-0 features (labels + adjacency).  The exchange is therefore a single RCCL
+level-0 features (labels + adjacency).  The level-0 ids must mean the same label on every rank:
+a shard cut out of a globally ingested batch (``GraphBatch.slice_graphs``) already has global ids; a
+shard ingested on its own (``wl_batch_from_input`` on the rank's graphs) has shard-local ids and MUST be
+passed together with its ``label_map`` -- the ranks then exchange their distinct label values once and
+remap to the ids of the sorted union, exactly the reference's ``sorted(distinct_values)`` numbering
+(weisfeiler_lehman.py:199-210).  The exchange is therefore a single RCCL
 ``all_gather`` of the packed shards over xGMI (config 3: ~25 MB in total, i.e. ~3 MB per
 rank; a direct all-gather at ~153 GB/s per link takes tens of microseconds), after which
 
@@ -28,6 +33,25 @@ def shard_bounds(n_graphs, world_size):
     return b
 
 
+def reconcile_label_ids(local, label_map, group=None):
+    """Shard-local level-0 ids -> ids of the sorted union of every rank's label values.
+
+    ``label_map`` is the ``{label value: local id}`` dictionary ``wl_batch_from_input`` returned for this
+    rank's shard.  Returns (node_label int32 with global ids, number of global labels).  One
+    ``all_gather_object`` of the distinct values (a few hundred python objects at most)."""
+    import torch.distributed as dist
+    ws = dist.get_world_size(group)
+    mine = sorted(label_map, key=lambda v: label_map[v])           # local id order == sorted order
+    everyone = [None] * ws
+    dist.all_gather_object(everyone, mine, group=group)
+    union = sorted(set(v for part in everyone for v in part))
+    gid = {v: i for i, v in enumerate(union)}
+    lut = np.zeros(max(len(mine), 1), dtype=np.int32)
+    for v, i in label_map.items():
+        lut[i] = gid[v]
+    return lut[local.node_label], len(union)
+
+
 def _pad_to(t, n, torch):
     if t.shape[0] == n:
         return t
@@ -41,10 +65,13 @@ class ShardExchange(object):
     every later call is ONE fused all_gather of [graph sizes | degrees | labels | col_idx] plus
     the pointer rebuild (two cumsums) on the device."""
 
-    def __init__(self, local, group=None, device=None):
+    def __init__(self, local, group=None, device=None, label_map=None):
         import torch
         import torch.distributed as dist
         self.group, self.ws = group, dist.get_world_size(group)
+        if label_map is not None:          # the shard was ingested on its own: make the level-0 ids global
+            ids, n_labels = reconcile_label_ids(local, label_map, group)
+            local = GraphBatch(local.graph_ptr, local.row_ptr, local.col_idx, ids, n_labels, local.edge_weight)
         self.dev = torch.device("cpu") if device is None else device
         dev = self.dev
 
@@ -111,14 +138,15 @@ class ShardExchange(object):
         return graph_ptr.contiguous(), row_ptr.contiguous(), col_idx.contiguous(), labels.contiguous()
 
 
-def all_gather_batch(local, group=None, device=None):
+def all_gather_batch(local, group=None, device=None, label_map=None):
     """All-gather CSR shards -> the global batch as int32 torch tensors on ``device``.
 
-    ``local`` is this rank's ``GraphBatch`` (local node numbering).  Returns
+    ``local`` is this rank's ``GraphBatch`` (local node numbering); ``label_map`` as in ``ShardExchange``
+    (None: the level-0 ids are already global).  Returns
     (graph_ptr, row_ptr, col_idx, node_label, n_labels, shard_graph_bounds) where the four
     arrays describe ALL graphs in rank order with global node numbering.
     """
-    ex = ShardExchange(local, group, device)
+    ex = ShardExchange(local, group, device, label_map)
     gp, rp, ci, lab = ex.gather()
     return gp, rp, ci, lab, ex.n_labels, ex.bounds
 
@@ -153,14 +181,16 @@ class ShardedWL(object):
             self.engine.set_stream(0)
             self._stream = None
 
-    def step(self, local_batch, to_host=False):
-        """One fit_transform: returns (row block [n_local x N] or None, info dict)."""
+    def step(self, local_batch, to_host=False, label_map=None, keep=False):
+        """One fit_transform: returns (row block [n_local x N] or None, info dict).  ``label_map``: see
+        ``ShardExchange`` (needed when the shard was ingested on its own).  ``keep``: leave the features (and
+        with them the rank's row block in HBM) alive as info["feat"] / info["batch"]; the caller closes them."""
         import torch
         import torch.distributed as dist
         rank = dist.get_rank(self.group)
         dev = torch.device("cuda", self.engine.device)
         if self._local is not local_batch:           # shard sizes are exchanged once per local shard
-            self._exchange, self._local = ShardExchange(local_batch, self.group, dev), local_batch
+            self._exchange, self._local = ShardExchange(local_batch, self.group, dev, label_map), local_batch
         s = self._shared_stream(dev)
         s.wait_stream(torch.cuda.current_stream(dev))   # the shard message was built on the caller's stream
         ex = self._exchange
@@ -176,7 +206,10 @@ class ShardedWL(object):
             K = eng.gram(feat, 2 if self.normalize else 0, rows=rows, to_host=to_host)
             info = dict(label_counts=counts, n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, rows=rows,
                         n_graphs=db.n_graphs, gram=eng.gram_stats(feat), dtype=feat.dtype)
-            feat.close()
-            db.close()
+            if keep:
+                info["feat"], info["batch"] = feat, db
+            else:
+                feat.close()
+                db.close()
         torch.cuda.current_stream(dev).wait_stream(s)
         return K, info

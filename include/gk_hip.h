@@ -63,6 +63,13 @@ int gk_profile_reset(gk_ctx* ctx);
 /* names: "relabel", "features", "gram".  Returns total ms and launch count. */
 int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_launches);
 
+/* Pinned (page-locked) host memory for the outputs of gk_gram / gk_gram_rows: the device -> host copy of the
+ * float64 matrix (8 N^2 bytes; the reference returns it as a host ndarray, kernel.py:167-204) then runs at the
+ * PCIe rate instead of the pageable-copy rate (measured 57 vs 12-18 GB/s).  Any host pointer is accepted
+ * as out_host; this pair only makes the fast path available to callers without a HIP binding. */
+int gk_host_alloc(uint64_t bytes, void** out);
+int gk_host_free(void* p);
+
 /* ---- batches ------------------------------------------------------------------------ */
 /* Replaces the per-graph Python containers built by WeisfeilerLehman.parse_input
  * (grakel/kernels/weisfeiler_lehman.py:142-194: Gs_ed / L dictionaries) and
@@ -160,6 +167,11 @@ int gk_gram_dev_ptr(gk_feat* f, void** out_dev_ptr, int64_t* n_rows, int64_t* n_
  * out_host is [(row_hi-row_lo) x n_cols]. */
 int gk_gram_rows(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_hi, int normalize,
                  double* out_host);
+/* Checksums of the matrix the last gk_gram* call left on the device, computed in place: sum of all entries,
+ * trace and max |K_ij - K_ji| (the last two 0 for a non-square output).  What bench.py asserts on the
+ * timed matrix and what the 50 000-graph parity test (a 20 GB matrix) checks without a host copy; the
+ * reference has no counterpart (it holds K as one host ndarray, kernel.py:167-204). */
+int gk_gram_checksum(gk_ctx* ctx, gk_feat* f, double* out_sum, double* out_trace, double* out_max_asym);
 /* Algorithmic work of the last gk_gram* call, for the roofline: MACs = rows*cols*kept cols. */
 int gk_gram_last_stats(gk_feat* f, double* out_flops, double* out_ms_event);
 

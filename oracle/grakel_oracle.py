@@ -256,6 +256,20 @@ class WLOracle(object):
         self.x_diag = np.diagonal(K).copy()
         return _normalize(K, self.x_diag, self.x_diag, True) if self.normalize else K
 
+    def label_counts_only(self, X):
+        """The relabel loop alone (weisfeiler_lehman.py:199-258), for inputs whose N x N matrices do not fit
+        (config 5: the reference itself cannot run it): number of distinct labels per level."""
+        eds, L = _wl_ingest(X)
+        inv0 = {dv: i for i, dv in enumerate(sorted({l for d in L for l in d.values()}))}
+        counts = [len(inv0)]
+        L = [{k: inv0[v] for k, v in d.items()} for d in L]
+        for i in range(1, self.n_iter + 1):
+            creds = [{v: _credential(Lj, ed, v) for v in Lj} for Lj, ed in zip(L, eds)]
+            inv = {c: j for j, c in enumerate(sorted({c for d in creds for c in d.values()}))}
+            L = [{v: inv[c] for v, c in d.items()} for d in creds]
+            counts.append(len(inv))
+        return counts
+
     def transform(self, Y, keep_levels=False):
         eds, L = _wl_ingest(Y)
         inv0 = self.inv_labels[0]

@@ -55,6 +55,43 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_own_ingestion(rank, world, port, out_dir):
+    """Each rank ingests ONLY its own graphs (shard-local level-0 ids, different label sets per rank)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.dist import all_gather_batch, shard_bounds, tensors_to_batch
+    from grakel_amd.synthetic import random_labelled_graphs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = random_labelled_graphs(16, 3, 9, 0.4, 6, 5)
+        for i, x in enumerate(X):                        # label values that only occur in one half
+            x[1] = {v: "shared" if l % 3 == 0 else ("a%d" % l if i < 8 else "b%d" % (l % 2)) for v, l in x[1].items()}
+        full, full_map = wl_batch_from_input(X)
+        b = shard_bounds(len(X), world)
+        local, local_map = wl_batch_from_input(X[b[rank]:b[rank + 1]])
+        assert len(local_map) < len(full_map)            # the shard does not see every label
+        gp, rp, ci, lab, n_labels, _ = all_gather_batch(local, None, None, label_map=local_map)
+        g = tensors_to_batch(gp, rp, ci, lab, n_labels)
+        ok = (n_labels == len(full_map) and np.array_equal(g.node_label, full.node_label)
+              and np.array_equal(g.col_idx, full.col_idx) and np.array_equal(g.graph_ptr, full.graph_ptr))
+        # without the map the ids collide: the same call must NOT reproduce the global labels
+        _, _, _, lab_bad, _, _ = all_gather_batch(local, None, None)
+        ok = ok and not np.array_equal(lab_bad.numpy(), full.node_label)
+        np.save(os.path.join(out_dir, "own_%d.npy" % rank), np.array([int(ok)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_independently_ingested_shards_get_global_label_ids_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = 31000 + (os.getpid() % 2000)
+    mp.spawn(_worker_own_ingestion, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(os.path.join(str(tmp_path), "own_%d.npy" % r)).tolist() == [1]
+
+
 def test_shard_bounds():
     from grakel_amd.dist import shard_bounds
     assert shard_bounds(10, 4) == [0, 3, 6, 8, 10]

@@ -886,3 +886,166 @@ def test_core_framework_small_sets(gk, name):
     assert np.array_equal(cf.fit_transform(tes[:3]), want.fit_transform(tes[:3]))
     assert np.array_equal(cf.transform(trs), want.transform(trs))
     assert np.array_equal(cf.diagonal()[1], want.y_diag)
+
+
+# ------------------------------------------------------------------------------------------
+# config 5 (BASELINE.json: 50 000 synthetic n=30 graphs, WL h=5).  The reference cannot run it (six dense
+# 50k x 50k float64 matrices, weisfeiler_lehman.py:269-270), so parity is block-wise: a WL kernel value
+# only depends on the two graphs, hence K[block, block] of the big job must equal the oracle run on the
+# block alone, and K[i, j] the oracle run on the pair.
+# ------------------------------------------------------------------------------------------
+CONFIG5 = dict(N=50000, n=30, p=0.1, L=5, seed=0, h=5)
+CONFIG5_LABEL_COUNTS = [5, 6987, 1106456, 1386518, 1408511, 1408933]     # oracle.WLOracle.label_counts_only
+
+
+def _config5_parts():
+    from grakel_amd import GraphBatch
+    c = CONFIG5
+    gp, rp, ci, lab = er_dataset_csr(c["N"], c["n"], c["p"], c["L"], c["seed"])
+    return GraphBatch(gp, rp, ci, lab, c["L"])
+
+
+def _graphs_from_batch(gb, idx):
+    """grakel input form [edge dict, labels] of the listed graphs of a packed batch."""
+    out = []
+    for g in idx:
+        v0, v1 = int(gb.graph_ptr[g]), int(gb.graph_ptr[g + 1])
+        ed = {v - v0: (gb.col_idx[gb.row_ptr[v]:gb.row_ptr[v + 1]] - v0).tolist() for v in range(v0, v1)}
+        out.append([ed, {v - v0: int(gb.node_label[v]) for v in range(v0, v1)}])
+    return out
+
+
+def test_config5_full_size_blockwise_against_the_oracle(gk):
+    from grakel_amd.engine import get_engine
+    c = CONFIG5
+    N, h = c["N"], c["h"]
+    gb = _config5_parts()
+    eng = get_engine()
+    db = eng.upload(gb)
+    assert eng.wl_relabel(db, h) == CONFIG5_LABEL_COUNTS
+    feat = eng.features(db, h + 1)
+    eng.gram(feat, 0, to_host=False)                      # the 20 GB float64 matrix stays in HBM
+    total, trace, asym = eng.gram_checksum(feat)
+    selfk = eng.selfk(feat)
+    assert asym == 0.0                                    # K == K.T, checked in place
+    assert trace == selfk.sum()                           # diag(K) sums to the exact self similarities
+    rs = np.random.RandomState(11)
+    # (a) eight disjoint 500-graph diagonal blocks, every entry against the oracle on the block alone
+    row_sum_all = 0.0
+    for b0 in (0, 3500, 9000, 17500, 24000, 31000, 42500, 49500):
+        rows = eng.gram(feat, 0, rows=(b0, b0 + 500))     # [500 x N] row block, recomputed by gk_gram_rows
+        Kref = O.WLOracle(n_iter=h).fit_transform(_graphs_from_batch(gb, range(b0, b0 + 500)))
+        assert np.array_equal(rows[:, b0:b0 + 500], Kref), "diagonal block at %d" % b0
+        assert np.array_equal(np.diagonal(rows[:, b0:b0 + 500]), selfk[b0:b0 + 500])
+        # (b) off-diagonal entries of these rows against the pairwise oracle
+        for _ in range(260):
+            i, j = b0 + int(rs.randint(0, 500)), int(rs.randint(0, N))
+            if b0 <= j < b0 + 500:
+                continue
+            want = O.WLOracle(n_iter=h).fit_transform(_graphs_from_batch(gb, [i, j]))[0, 1]
+            assert rows[i - b0, j] == want, (i, j)
+        row_sum_all += rows.sum()
+    # (c) the row blocks recomputed by gk_gram_rows and the in-place matrix agree on the symmetric counterpart
+    eng.gram(feat, 0, to_host=False)
+    assert eng.gram_checksum(feat)[0] == total
+    cols = eng.gram(feat, 0, rows=(12345, 12346))[0]
+    blk = eng.gram(feat, 0, rows=(3500, 4000))
+    assert np.array_equal(blk[:, 12345], cols[3500:4000])
+
+
+def _config5_rank_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grakel_amd.dist import ShardedWL, shard_bounds
+    from grakel_amd.engine import get_engine
+    torch.cuda.set_device(0)
+    full = _config5_parts()
+    b = shard_bounds(full.n_graphs, world)
+    eng = get_engine(0)
+    sw = ShardedWL(eng, n_iter=CONFIG5["h"])
+    _, info = sw.step(full.slice_graphs(b[rank], b[rank + 1]), keep=True)
+    s, _, _ = eng.gram_checksum(info["feat"])             # this rank's [N/2 x N] row block, in HBM
+    rows = eng.gram(info["feat"], 0, rows=(b[rank] + 7, b[rank] + 8))
+    np.save(os.path.join(outdir, "c5_%d.npy" % rank), np.concatenate([[s], rows[0]]))
+    sw.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config5_row_sharded_over_two_processes(gk, tmp_path):
+    """Config 5 with the Gram rows sharded over two ranks (both on cuda:0, gloo): each rank holds a 10 GB row
+    block; the blocks' sums add up to the single-process matrix and a row of each block equals the row the
+    single process computes."""
+    import torch.multiprocessing as mp
+    from grakel_amd.engine import get_engine
+    c = CONFIG5
+    eng = get_engine()
+    db = eng.upload(_config5_parts())
+    eng.wl_relabel(db, c["h"])
+    feat = eng.features(db, c["h"] + 1)
+    eng.gram(feat, 0, to_host=False)
+    total = eng.gram_checksum(feat)[0]
+    want = {r: eng.gram(feat, 0, rows=(lo + 7, lo + 8))[0] for r, lo in ((0, 0), (1, c["N"] // 2))}
+    feat.close()
+    db.close()
+    port = 29300 + (os.getpid() % 500)
+    mp.spawn(_config5_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [np.load(os.path.join(str(tmp_path), "c5_%d.npy" % r)) for r in range(2)]
+    assert got[0][0] + got[1][0] == total
+    for r in range(2):
+        assert np.array_equal(got[r][1:], want[r])
+
+
+# ------------------------------------------------------------------------------------------
+# the dense kernel against the host product of its own operand, every operand form and both kernel forms
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env", [dict(), dict(GK_GRAM_NO_FP4="1"), dict(GK_GRAM_NO_WS="1"),
+                                 dict(GK_GRAM_NO_WS="1", GK_GRAM_NO_FP4="1")])
+@pytest.mark.parametrize("N,n", [(40, 20), (300, 20), (1001, 12)])
+def test_dense_gram_equals_the_product_of_its_own_operand(gk, monkeypatch, env, N, n):
+    from grakel_amd import GraphBatch
+    from grakel_amd.engine import get_engine
+    monkeypatch.setenv("GK_LOW_DF", "2")                   # every useful column is dense
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng = get_engine()
+    db = eng.upload(GraphBatch(*er_dataset_csr(N, n, 0.15, 3, 0), 3))
+    eng.wl_relabel(db, 2)
+    feat = eng.features(db, 3)
+    assert feat.n_cols_low == 0 and feat.max_count > 4     # counts 5..127 exist: the secondary int8 region is in use
+    phi = eng.debug_phi(feat)
+    K = eng.gram(feat, 0)
+    R = phi @ phi.T
+    np.fill_diagonal(R, eng.selfk(feat))
+    assert np.array_equal(K, R)
+    s, t, a = eng.gram_checksum(feat)
+    assert (s, t, a) == (K.sum(), np.trace(K), 0.0)
+
+
+def test_malformed_batches_are_rejected_at_the_c_abi(gk):
+    """gk_batch_create validates the CSR on the device: a malformed batch is GK_ERR_ARG, not an out-of-bounds gather."""
+    from grakel_amd import GraphBatch
+    from grakel_amd._lib import GkError
+    from grakel_amd.engine import get_engine
+    eng = get_engine()
+    gp, rp, ci, lab = er_dataset_csr(50, 12, 0.3, 3, 1)
+
+    def bad(**kw):
+        a = dict(gp=gp.copy(), rp=rp.copy(), ci=ci.copy(), lab=lab.copy())
+        for k, f in kw.items():
+            f(a[k])
+        gb = GraphBatch.__new__(GraphBatch)                # bypass the host-side checks: this is the C ABI's job
+        gb.graph_ptr, gb.row_ptr, gb.col_idx, gb.node_label = a["gp"], a["rp"], a["ci"], a["lab"]
+        gb.n_labels, gb.edge_weight = 3, None
+        with pytest.raises(GkError, match="malformed batch"):
+            eng.upload(gb)
+
+    def swap_rows(r): r[5], r[6] = r[6] + 1, r[5]
+    def far_col(c): c[3] = len(rp) - 2                    # a neighbour in another graph
+    def neg_col(c): c[0] = -1
+    def big_label(l): l[7] = 3
+    def swap_graphs(g): g[3] = g[5]
+    bad(rp=swap_rows), bad(ci=far_col), bad(ci=neg_col), bad(lab=big_label), bad(gp=swap_graphs)
+    assert eng.upload(GraphBatch(gp, rp, ci, lab, 3)).n_graphs == 50
