@@ -46,6 +46,13 @@ class GraphBatch(object):
             raise ValueError("GraphBatch: row_ptr must have n_nodes+1 entries")
         if int(self.graph_ptr[-1]) != self.n_nodes or int(self.row_ptr[-1]) != self.n_edges:
             raise ValueError("GraphBatch: inconsistent pointer arrays")
+        # O(V) sanity of what the kernels index with (the neighbour ranges are checked on the device,
+        # gk_batch_create -> GK_ERR_ARG): monotone pointers from 0, label ids inside [0, n_labels)
+        if self.graph_ptr[0] != 0 or self.row_ptr[0] != 0 or np.any(np.diff(self.graph_ptr) < 0) \
+                or np.any(np.diff(self.row_ptr) < 0):
+            raise ValueError("GraphBatch: graph_ptr / row_ptr must start at 0 and never decrease")
+        if self.n_nodes and (int(self.node_label.min()) < 0 or int(self.node_label.max()) >= max(self.n_labels, 1)):
+            raise ValueError("GraphBatch: node_label ids must lie in [0, n_labels)")
 
     n_graphs = property(lambda self: self.graph_ptr.shape[0] - 1)
     n_nodes = property(lambda self: self.node_label.shape[0])

@@ -269,6 +269,21 @@ extern "C" int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_
     GK_HIP_CHECK(hipSetDevice(ctx->device));
     ProfScope prof(ctx, "sp");
     const i64 N = b->n_graphs, V = b->n_nodes;
+    {   // distances are int32 sums below SP_INF: the longest simple path must stay under it, otherwise a
+        // finite distance would silently count as "unreachable"
+        i64 wmax = 1;
+        if (edge_weight)
+            for (i64 e = 0; e < b->n_edges; ++e) {
+                GK_ARG(edge_weight[e] > 0, "ShortestPath: edge weights must be positive integers");
+                if (edge_weight[e] > wmax) wmax = edge_weight[e];
+            }
+        const i64 longest = (i64)(b->max_graph_nodes > 1 ? b->max_graph_nodes - 1 : 0) * wmax;
+        if (longest >= (i64)SP_INF) {
+            gk_set_error("ShortestPath: a path of %d vertices with edge weight %lld can exceed the int32 distance range",
+                         b->max_graph_nodes, (long long)wmax);
+            return GK_ERR_UNSUPPORTED;
+        }
+    }
     SpDist s(ctx);
     u64 total_sq = 0;
     GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq));

@@ -9,18 +9,57 @@ from .batch import sp_batch_from_input
 from .kernel import Kernel, NORM_NONE, NORM_PLAIN
 
 
-class _EnumStub(object):
-    """Stand-in for the reference's ``_enum`` ((l_u,l_v,d) -> column) dictionary: the
-    dictionary lives on the device; the host keeps its size."""
+class _LazyDict(dict):
+    """A dictionary of the reference's fitted state (``_enum``, ``X``, ``_Y_enum``) that is rebuilt from the
+    device's all-pairs distances the first time it is read; ``len`` of ``_enum`` is known without that."""
 
-    def __init__(self, n):
-        self._n = int(n)
+    def __init__(self, fill, known_len=None):
+        dict.__init__(self)
+        self._fill, self._known_len = fill, known_len
+
+    def _ensure(self):
+        f, self._fill = self._fill, None
+        if f is not None:
+            dict.update(self, f())
 
     def __len__(self):
-        return self._n
+        if self._fill is not None and self._known_len is not None:
+            return self._known_len
+        self._ensure()
+        return dict.__len__(self)
 
-    def __repr__(self):
-        return "<%d shortest-path features on device>" % self._n
+    def __missing__(self, key):
+        if self._fill is None:
+            raise KeyError(key)
+        self._ensure()
+        return dict.__getitem__(self, key)
+
+    def __iter__(self):
+        self._ensure()
+        return dict.__iter__(self)
+
+    def __contains__(self, key):
+        self._ensure()
+        return dict.__contains__(self, key)
+
+    def keys(self):
+        self._ensure()
+        return dict.keys(self)
+
+    def items(self):
+        self._ensure()
+        return dict.items(self)
+
+    def values(self):
+        self._ensure()
+        return dict.values(self)
+
+    def get(self, key, default=None):
+        self._ensure()
+        return dict.get(self, key, default)
+
+    def __reduce__(self):          # pickles as what has been rebuilt so far (ShortestPath.__setstate__ re-arms it)
+        return (dict, (dict(dict.items(self)),))
 
 
 class ShortestPath(Kernel):
@@ -72,8 +111,9 @@ class ShortestPath(Kernel):
 
     def _gram_transform(self, Y):
         from .batch import GraphBatch
-        ybatch, _ = self._ingest(Y, self._label_map if self._label_map is not None else {})
+        ybatch, ymap = self._ingest(Y, self._label_map if self._label_map is not None else {})
         self._ny = ybatch.n_graphs
+        self._cur_y_batch, self._cur_y_map = ybatch, ymap
         self._cur_batch = GraphBatch.concat(self._fit_batch, ybatch)
         eng = self._engine()
         db = eng.upload(self._cur_batch)
@@ -92,16 +132,123 @@ class ShortestPath(Kernel):
         if X is None:
             raise ValueError('`fit` input cannot be None')
         self._fit_host(X)
-        self.X = {i: None for i in range(self._nx)}
-        self._enum = _EnumStub(0)
+        self.__dict__.pop("_state", None)
+        self._arm_lazy_state()
         return self
+
+    def _arm_lazy_state(self):
+        self.X = _LazyDict(lambda: self._fitted_state()["X"], self._nx)
+        self._enum = _LazyDict(lambda: self._fitted_state()["enum"])
+
+    def __setstate__(self, state):
+        super(ShortestPath, self).__setstate__(state)
+        if "_fit_batch" in self.__dict__ and not isinstance(self.__dict__.get("_enum"), _LazyDict):
+            filled_enum, filled_X = self.__dict__.get("_enum") or {}, self.__dict__.get("X") or {}
+            if filled_enum and filled_X:
+                self._state = dict(enum=dict(filled_enum), X=dict(filled_X))
+            self._arm_lazy_state()
+
+    # ---- the reference's fitted state (shortest_path.py:396-406,412-499), rebuilt on demand ------------
+    def _pair_features(self, gb, n_first, enum, new_enum):
+        """(l_u, l_v, d) counts of the graphs of ``gb`` in the reference's enumeration order: graph after
+        graph, u then v in vertex order; keys not in ``enum`` are appended to ``new_enum`` (first seen
+        first).  Distances come from the device (gk_sp_debug_apsp), labels are the original values."""
+        eng = self._engine()
+        db = eng.upload(gb)
+        w = gb.edge_weight
+        if w is not None and (w.size == 0 or np.all(w == 1)):
+            w = None
+        inv = None
+        if self.with_labels and self._label_map is not None:
+            inv = {i: k for k, i in self._all_label_ids.items()}
+        counts = dict()
+        for g in range(gb.n_graphs):
+            v0, v1 = int(gb.graph_ptr[g]), int(gb.graph_ptr[g + 1])
+            n = v1 - v0
+            S = eng.sp_debug_apsp(db, w, g, n) if n > 0 else np.zeros((0, 0), np.int32)
+            lab = gb.node_label[v0:v1].tolist()
+            row = dict()
+            us, vs = np.nonzero((S >= 0) & ~np.eye(n, dtype=bool))
+            for u, v, d in zip(us.tolist(), vs.tolist(), S[us, vs].tolist()):
+                if self.with_labels:
+                    key = (inv[lab[u]], inv[lab[v]], float(d)) if inv is not None else (lab[u], lab[v], float(d))
+                else:
+                    key = float(d)
+                idx = enum.get(key)
+                if idx is None:
+                    idx = new_enum.get(key)
+                    if idx is None:
+                        idx = n_first + len(new_enum)
+                        new_enum[key] = idx
+                row[idx] = row.get(idx, 0) + 1
+            counts[g] = row
+        db.close()
+        return counts
+
+    def _fitted_state(self):
+        st = self.__dict__.get("_state")
+        if st is None:
+            self._all_label_ids = dict(self._label_map) if self._label_map is not None else {}
+            enum = dict()
+            counts = self._pair_features(self._fit_batch, 0, dict(), enum)
+            st = self._state = dict(enum=enum, X=counts)
+        return st
+
+    @staticmethod
+    def _dense(counts, n_rows, n_cols):
+        phi = np.zeros((n_rows, n_cols))
+        for i, row in counts.items():
+            for j, c in row.items():
+                phi[i, j] = c
+        return phi
+
+    def _transform_state(self):
+        """Counts and the extension ``_Y_enum`` of the last transform's targets (shortest_path.py:472-489)."""
+        if "_Y_batch" not in self.__dict__:
+            raise AttributeError("no transform has been called")
+        ys = self.__dict__.get("_Y_state")
+        if ys is None:
+            st = self._fitted_state()
+            self._all_label_ids = dict(self._label_map) if self._label_map is not None else {}
+            self._all_label_ids.update(self._cur_y_map or {})
+            y_enum = dict()
+            counts = self._pair_features(self._Y_batch, len(st["enum"]), st["enum"], y_enum)
+            ys = self._Y_state = dict(enum=y_enum, X=counts)
+        return ys
+
+    @property
+    def _phi_X(self):
+        """shortest_path.py:396-403 (fit_transform) / :292-301 (as wide as ``_enum`` + ``_Y_enum`` after a transform)."""
+        if "_fit_batch" not in self.__dict__:
+            raise AttributeError("_phi_X")
+        st = self._fitted_state()
+        width = len(st["enum"])
+        if getattr(self, "_is_transformed", False):
+            width += len(self._transform_state()["enum"])
+        return self._dense(st["X"], self._nx, width)
+
+    @property
+    def _phi_Y(self):
+        """shortest_path.py:292-301 of the last transform."""
+        ys = self._transform_state()
+        return self._dense(ys["X"], self._ny, len(self._fitted_state()["enum"]) + len(ys["enum"]))
+
+    @property
+    def _Y_enum(self):
+        return self._transform_state()["enum"]
+
+    def __getstate__(self):
+        state = super(ShortestPath, self).__getstate__()
+        for k in ("_state", "_Y_state", "_cur_y_batch", "_all_label_ids"):
+            state.pop(k, None)
+        return state
 
     def fit_transform(self, X, y=None):
         """shortest_path.py:370-410 (normalisation divides silently, :407-408)."""
         self._method_calling = 2
         self.fit(X)
         eng, feat = self._gram_fit()
-        self._enum = _EnumStub(self._last_info["label_counts"][0])
+        self._enum._known_len = self._last_info["label_counts"][0]
         with np.errstate(divide='ignore', invalid='ignore'):
             return eng.gram(feat, NORM_PLAIN if self.normalize else NORM_NONE)
 
@@ -113,4 +260,6 @@ class ShortestPath(Kernel):
             raise ValueError('transform input cannot be None')
         eng, feat = self._gram_transform(X)
         self._is_transformed = True
+        self.__dict__.pop("_Y_state", None)
+        self._Y_batch = self._cur_y_batch
         return eng.gram(feat, NORM_PLAIN if self.normalize else NORM_NONE)

@@ -7,15 +7,63 @@ from .batch import vh_batch_from_input
 from .kernel import Kernel, NORM_NONE, NORM_PLAIN
 
 
-class FittedFeatures(object):
-    """Stand-in for the reference's fitted ``X`` (the N x D label-count matrix): the matrix
-    itself lives column-compacted in HBM; the host keeps its shape only."""
+def count_matrix(node_graph, node_col, n_graphs, n_cols):
+    """scipy CSR [n_graphs x n_cols] of how often column id ``node_col[v]`` occurs in graph ``node_graph[v]``
+    (vertex_histogram.py:118-137: the reference's fitted ``X``)."""
+    from scipy.sparse import csr_matrix
+    keep = node_col >= 0
+    key = node_graph[keep].astype(np.int64) * max(int(n_cols), 1) + node_col[keep]
+    uniq, cnt = np.unique(key, return_counts=True)
+    rows, cols = uniq // max(int(n_cols), 1), uniq % max(int(n_cols), 1)
+    return csr_matrix((cnt.astype(np.float64), (rows, cols)), shape=(int(n_graphs), int(n_cols)))
 
-    def __init__(self, n_graphs, n_labels):
+
+def first_seen_columns(ids):
+    """{id: column} in first-seen order over the nodes (graph after graph, vertex after vertex): the
+    reference's ``_labels`` enumeration (vertex_histogram.py:109-116)."""
+    uniq, first = np.unique(ids, return_index=True)
+    order = np.argsort(first, kind="stable")
+    return {int(uniq[i]): c for c, i in enumerate(order)}
+
+
+class FittedFeatures(object):
+    """The reference's fitted ``X`` (the N x D label-count matrix, vertex_histogram.py:118-137) without its
+    cost: the device works on its own column-compacted operand, so the host matrix is only built when
+    somebody reads it.  ``shape`` is free; any other attribute (``toarray``, ``dot``, ``nnz``, indexing ...)
+    materialises a ``scipy.sparse.csr_matrix`` once and forwards to it."""
+
+    def __init__(self, n_graphs, n_labels, build=None):
         self.shape = (n_graphs, n_labels)
+        self._build, self._m = build, None
+
+    def materialize(self):
+        if self._m is None:
+            if self._build is None:
+                raise AttributeError("this fitted feature matrix was not kept (no builder)")
+            self._m = self._build()
+            self.shape = self._m.shape
+        return self._m
+
+    def __getattr__(self, name):
+        if name.startswith("__") or name in ("_build", "_m", "shape"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialize().toarray()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getstate__(self):
+        return dict(shape=self.shape, _build=None, _m=self._m)
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
 
     def __repr__(self):
-        return "FittedFeatures(shape=%r, on_device)" % (self.shape,)
+        return "FittedFeatures(shape=%r, %s)" % (self.shape, "lazy" if self._m is None else "materialized")
 
 
 class VertexHistogram(Kernel):
@@ -45,15 +93,23 @@ class VertexHistogram(Kernel):
         if X is None:
             raise ValueError('`fit` input cannot be None')
         self._fit_host(X)
+        gb = self._fit_batch
+        cols = first_seen_columns(gb.node_label)                    # vertex_histogram.py:109-116
         if self._label_map is not None:
-            # first-seen column order like vertex_histogram.py:109-116
-            ids = self._fit_batch.node_label
-            _, first = np.unique(ids, return_index=True)
-            order = np.argsort(first, kind="stable")
             inv = {i: k for k, i in self._label_map.items()}
-            self._labels = {inv[int(i)]: c for c, i in enumerate(order)}
+            self._labels = {inv[i]: c for i, c in cols.items()}
+        else:                                                       # packed input: the ids are the labels
+            self._labels = dict(cols)
         self.sparse_ = bool(self.sparse) if self.sparse != 'auto' else True
-        self.X = FittedFeatures(self._nx, self._fit_batch.n_labels)
+
+        def build(gb=gb, cols=cols):
+            lut = np.full(gb.n_labels, -1, np.int64)
+            for i, c in cols.items():
+                lut[i] = c
+            node_graph = np.repeat(np.arange(gb.n_graphs), np.diff(gb.graph_ptr))
+            return count_matrix(node_graph, lut[gb.node_label], gb.n_graphs, len(cols))
+
+        self.X = FittedFeatures(self._nx, len(cols), build)
         return self
 
     def fit_transform(self, X, y=None):

@@ -6,7 +6,105 @@ from sklearn.utils.validation import check_is_fitted
 from .batch import GraphBatch, sp_batch_from_input, wl_batch_from_input
 from .kernel import Kernel, NORM_NONE, NORM_NAN_TO_NUM
 from .shortest_path import ShortestPath
-from .vertex_histogram import VertexHistogram, FittedFeatures
+from .vertex_histogram import VertexHistogram, FittedFeatures, count_matrix, first_seen_columns
+
+
+MAX_LEVELS = 48        # FEAT_MAX_LEVELS of csrc/features.hip
+
+
+def _accelerated(base):
+    """The reference's own ``grakel.VertexHistogram`` / ``grakel.ShortestPath`` classes (callers that only
+    swapped the WeisfeilerLehman import) map to the accelerated classes of the same name."""
+    if type(base) is type and getattr(base, "__module__", "").split(".")[0] == "grakel":
+        return {"VertexHistogram": VertexHistogram, "ShortestPath": ShortestPath}.get(base.__name__, base)
+    return base
+
+
+class _LazyInvLabels(dict):
+    """``_inv_labels`` (weisfeiler_lehman.py:199-210,257).  Level 0 -- the input label map -- is there from
+    ``fit`` on; the dictionaries of the levels >= 1 hold the reference's credential strings, which only the
+    host pass ``WeisfeilerLehman.inv_labels()`` can rebuild, so they are filled in the first time anything but
+    level 0 is looked at.  Pickles as a plain dict of what is filled in."""
+
+    def __init__(self, level0, fill):
+        dict.__init__(self, {0: level0})
+        self._fill = fill
+
+    def _ensure(self):
+        f, self._fill = self._fill, None
+        if f is not None:
+            for k, v in f().items():
+                dict.__setitem__(self, k, v)
+
+    def __missing__(self, key):
+        self._ensure()
+        return dict.__getitem__(self, key)
+
+    def __len__(self):
+        self._ensure()
+        return dict.__len__(self)
+
+    def __iter__(self):
+        self._ensure()
+        return dict.__iter__(self)
+
+    def __contains__(self, key):
+        if key != 0:
+            self._ensure()
+        return dict.__contains__(self, key)
+
+    def keys(self):
+        self._ensure()
+        return dict.keys(self)
+
+    def items(self):
+        self._ensure()
+        return dict.items(self)
+
+    def values(self):
+        self._ensure()
+        return dict.values(self)
+
+    def __reduce__(self):
+        return (dict, (dict(dict.items(self)),))
+
+
+class FittedLevel(object):
+    """``WeisfeilerLehman.X[i]``: the base kernel the reference fits on level i (weisfeiler_lehman.py:260-285).
+    ``X`` (graphs x labels of the level) and ``_labels`` ({reference label id: column}, first seen first) are
+    rebuilt on the host from the reference-identical label ids when somebody reads them."""
+
+    def __init__(self, owner, level, n_graphs, n_labels):
+        self._owner, self._level = owner, level
+        self.X = FittedFeatures(n_graphs, n_labels, self._build_X)
+        self.sparse_ = True
+        self._cols = None
+
+    def _columns(self):
+        if self._cols is None:
+            self._cols = first_seen_columns(self._owner._level_reference_ids(self._level))
+        return self._cols
+
+    @property
+    def _labels(self):
+        return dict(self._columns())
+
+    def _build_X(self):
+        gb = self._owner._fit_batch
+        ids = self._owner._level_reference_ids(self._level)
+        cols = self._columns()
+        uniq = np.fromiter(cols.keys(), np.int64, len(cols))
+        col_of = np.fromiter(cols.values(), np.int64, len(cols))
+        order = np.argsort(uniq)
+        pos = np.searchsorted(uniq[order], ids)
+        node_graph = np.repeat(np.arange(gb.n_graphs), np.diff(gb.graph_ptr))
+        return count_matrix(node_graph, col_of[order][pos], gb.n_graphs, len(cols))
+
+    def __getstate__(self):
+        return dict(_owner=None, _level=self._level, X=self.X, sparse_=True, _cols=self._cols)
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
 
 
 class WeisfeilerLehman(Kernel):
@@ -37,14 +135,15 @@ class WeisfeilerLehman(Kernel):
             base = self.base_graph_kernel
             if base is None:
                 base, params = VertexHistogram, dict()
-            elif type(base) is type and issubclass(base, Kernel):
-                params = dict()
+            elif type(base) is type and issubclass(_accelerated(base), Kernel):
+                base, params = _accelerated(base), dict()
             else:
                 try:
                     base, params = base
                 except Exception:
                     raise TypeError('Base kernel was not formulated in the correct way. '
                                     'Check documentation.')
+                base = _accelerated(base)
                 if not (type(base) is type and issubclass(base, Kernel)):
                     raise TypeError('The first argument must be a valid grakel.kernel.kernel Object')
                 if type(params) is not dict:
@@ -68,6 +167,9 @@ class WeisfeilerLehman(Kernel):
         if not self._initialized["n_iter"]:
             if type(self.n_iter) is not int or self.n_iter <= 0:
                 raise TypeError("'n_iter' must be a positive integer")
+            if self.n_iter + 1 > MAX_LEVELS:
+                raise NotImplementedError("grakel_amd builds the features of at most %d WL levels in one job "
+                                          "(n_iter <= %d)" % (MAX_LEVELS, MAX_LEVELS - 1))
             self._n_iter = self.n_iter + 1
             self._initialized["n_iter"] = True
 
@@ -109,8 +211,33 @@ class WeisfeilerLehman(Kernel):
         return eng, feat
 
     def _after_fit(self):
-        self._inv_labels = {0: dict(self._label_map) if self._label_map is not None else {}}
-        self.X = {i: FittedFeatures(self._nx, None) for i in range(self._n_iter)}
+        self.__dict__.pop("_reference_labels", None)
+        lvl0 = dict(self._label_map) if self._label_map is not None else \
+            {int(i): int(i) for i in np.unique(self._fit_batch.node_label).tolist()}
+        self._inv_labels = _LazyInvLabels(lvl0, self._all_inv_labels)
+        self.X = {i: FittedLevel(self, i, self._nx, None) for i in range(self._n_iter)}
+
+    def __setstate__(self, state):
+        super(WeisfeilerLehman, self).__setstate__(state)
+        d = self.__dict__.get("_inv_labels")
+        if isinstance(d, dict) and not isinstance(d, _LazyInvLabels):      # pickled as a plain dict
+            lazy = _LazyInvLabels(d.get(0, {}), self._all_inv_labels if len(d) <= 1 else None)
+            for k, v in d.items():
+                dict.__setitem__(lazy, k, v)
+            self._inv_labels = lazy
+        if isinstance(self.__dict__.get("X"), dict):
+            for lvl in self.X.values():
+                if isinstance(lvl, FittedLevel):
+                    lvl._owner = self
+
+    def _level_reference_ids(self, level):
+        """Reference label id of every node of the fit batch at ``level`` (the values the reference's
+        level-``level`` base kernel sees as labels)."""
+        if "_reference_labels" not in self.__dict__:
+            self._inv_labels._ensure()
+        if "_reference_labels" not in self.__dict__:      # the dictionaries came from a pickle: replay
+            self._all_inv_labels()
+        return self._reference_labels[level]
 
     def fit(self, X, y=None):
         """kernel.py:86-121 with weisfeiler_lehman.py:117-290 as parse_input."""
@@ -133,7 +260,8 @@ class WeisfeilerLehman(Kernel):
         self._fit_host(X)
         self._after_fit()
         eng, feat = self._gram_fit()
-        self.X = {i: FittedFeatures(self._nx, c) for i, c in enumerate(self._last_info["label_counts"])}
+        for i, c in enumerate(self._last_info["label_counts"]):
+            self.X[i].X.shape = (self._nx, c)
         return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
 
     def transform(self, X):
@@ -141,14 +269,14 @@ class WeisfeilerLehman(Kernel):
         graphs: the WL partition of the union restricted to the fitted graphs is the fitted
         partition, so K[targets, fitted] equals the reference's dictionary look-up path."""
         self._method_calling = 3
-        check_is_fitted(self, ['X', '_nx', '_inv_labels'])
+        check_is_fitted(self, ['X', '_nx'])
         if X is None:
             raise ValueError('transform input cannot be None')
         eng, feat = self._gram_transform(X)
         self._is_transformed = True
         return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
 
-    def inv_labels(self):
+    def _all_inv_labels(self):
         """Reference-identical ``_inv_labels`` for every level.
 
         The device uses arbitrary dense ids per level (the Gram matrix does not depend on
@@ -158,13 +286,13 @@ class WeisfeilerLehman(Kernel):
         that from one representative node per device label: cost O(#labels * degree) in Python,
         so it is on demand only.  Returns the dict and stores it in ``self._inv_labels``.
         """
-        check_is_fitted(self, ['X', '_nx', '_inv_labels'])
+        check_is_fitted(self, ['X', '_nx'])
         gb = self._fit_batch
         eng = self._engine()
         db = eng.upload(gb)
         eng.wl_relabel(db, self._n_iter - 1)
         ref_prev = gb.node_label.astype(np.int64)          # level-0 ids are already the reference's
-        out = {0: dict(self._inv_labels[0])}
+        out = {0: dict(dict.__getitem__(self._inv_labels, 0))}
         count = len(out[0])
         self._reference_labels = [ref_prev]
         for i in range(1, self._n_iter):
@@ -184,5 +312,11 @@ class WeisfeilerLehman(Kernel):
             ref_prev = ids[dev]
             self._reference_labels.append(ref_prev)
         db.close()
-        self._inv_labels = out
         return out
+
+    def inv_labels(self):
+        """Reference-identical ``_inv_labels`` for every level, as a plain dict (also what reading
+        ``self._inv_labels[i]`` for i >= 1 triggers)."""
+        check_is_fitted(self, ['X', '_nx'])
+        self._inv_labels._ensure()
+        return dict(dict.items(self._inv_labels))

@@ -152,6 +152,43 @@ def mutag():
           np.trace(K_vh), np.trace(K_wl), np.trace(K_sp))
 
 
+def mutag_state(n_graphs=60):
+    """Fitted state a consumer may read on the first graphs of MUTAG: VertexHistogram ``X`` /
+    ``_labels``; WeisfeilerLehman ``_inv_labels`` and per level ``X[i].X`` / ``X[i]._labels``; ShortestPath
+    ``_enum`` / ``_phi_X`` / ``X``."""
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "grakel", "tests", "data"))
+    try:
+        G = read_data('MUTAG', with_classes=True).data[:n_graphs]
+    finally:
+        os.chdir(cwd)
+
+    def dense(X):
+        return np.asarray(X.todense() if hasattr(X, "todense") else X)
+
+    vh = VertexHistogram()
+    vh.fit(G)
+    out = dict(n_graphs=n_graphs, vh_X=dense(vh.X).astype(np.int32),
+               vh_labels=json.dumps(sorted([[int(k), int(v)] for k, v in vh._labels.items()])))
+    wl = WeisfeilerLehman(n_iter=3)
+    wl.fit(G)
+    out["wl_inv_labels"] = json.dumps({str(i): {str(k): int(v) for k, v in d.items()} for i, d in wl._inv_labels.items()})
+    for i in range(4):
+        out["wl_X%d" % i] = dense(wl.X[i].X).astype(np.int32)
+        out["wl_labels%d" % i] = json.dumps(sorted([[int(k), int(v)] for k, v in wl.X[i]._labels.items()]))
+    sp = ShortestPath()
+    sp.fit_transform(G)
+    enum = sorted(sp._enum.items(), key=lambda kv: kv[1])
+    out["sp_enum"] = np.array([[int(k[0]), int(k[1]), int(k[2])] for k, _ in enum], np.int64)
+    assert [v for _, v in enum] == list(range(len(enum)))
+    out["sp_phi_X"] = sp._phi_X.astype(np.int32)
+    out["sp_X_graph0"] = json.dumps(sorted([[int(k), int(v)] for k, v in sp.X[0].items()]))
+    sp.transform(G[:7])
+    out["sp_phi_Y_shape"] = np.array(sp._phi_Y.shape, np.int64)
+    np.savez_compressed(os.path.join(HERE, "mutag_state.npz"), **out)
+    print("MUTAG fitted state:", {k: (v.shape if hasattr(v, "shape") else len(v)) for k, v in out.items() if k != "n_graphs"})
+
+
 def small_sets():
     out = {}
     for name, kw in SMALL_SETS:
@@ -253,8 +290,12 @@ def nci1_sp(N):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip config 3 (~100 s) and NCI1-4110")
+    ap.add_argument("--only-state", action="store_true", help="only the fitted-state fixture (mutag_state.npz)")
     a = ap.parse_args()
     print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
+    mutag_state()
+    if a.only_state:
+        sys.exit(0)
     doc_goldens()
     mutag()
     small_sets()

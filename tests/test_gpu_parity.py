@@ -1049,3 +1049,55 @@ def test_malformed_batches_are_rejected_at_the_c_abi(gk):
     def swap_graphs(g): g[3] = g[5]
     bad(rp=swap_rows), bad(ci=far_col), bad(ci=neg_col), bad(lab=big_label), bad(gp=swap_graphs)
     assert eng.upload(GraphBatch(gp, rp, ci, lab, 3)).n_graphs == 50
+
+
+# ------------------------------------------------------------------------------------------
+# fitted state a consumer may read, against the real reference on MUTAG
+# (tests/golden/make_golden.py: mutag_state)
+# ------------------------------------------------------------------------------------------
+def test_fitted_state_equals_the_reference(gk, mutag_graphs):
+    import json
+    G, _ = mutag_graphs
+    z = load_golden("mutag_state.npz")
+    G = G[:int(z["n_graphs"])]
+    # VertexHistogram: X (graphs x labels, first-seen columns), _labels
+    vh = gk.VertexHistogram().fit(G)
+    assert sorted([int(k), int(v)] for k, v in vh._labels.items()) == json.loads(str(z["vh_labels"]))
+    assert vh.X.shape == z["vh_X"].shape and np.array_equal(vh.X.toarray(), z["vh_X"])
+    assert np.array_equal(np.asarray(vh.X), z["vh_X"]) and vh.sparse_ is True
+    # WeisfeilerLehman: _inv_labels (filled by reading it), X[i].X, X[i]._labels
+    wl = gk.WeisfeilerLehman(n_iter=3).fit(G)
+    want = {int(i): {k: int(v) for k, v in d.items()} for i, d in json.loads(str(z["wl_inv_labels"])).items()}
+    assert {str(k): v for k, v in wl._inv_labels[0].items()} == {str(k): v for k, v in want[0].items()}
+    for i in (1, 2, 3):
+        assert wl._inv_labels[i] == want[i]
+    assert sorted(wl._inv_labels.keys()) == [0, 1, 2, 3] and wl._nx == len(G)
+    for i in range(4):
+        assert sorted([int(k), int(v)] for k, v in wl.X[i]._labels.items()) == json.loads(str(z["wl_labels%d" % i]))
+        assert np.array_equal(wl.X[i].X.toarray(), z["wl_X%d" % i])
+    wl2 = pickle.loads(pickle.dumps(wl))                    # the state survives a pickle round trip
+    assert wl2._inv_labels[2] == want[2] and np.array_equal(wl2.X[3].X.toarray(), z["wl_X3"])
+    # ShortestPath: _enum ((l_u, l_v, d) -> column, first seen first), X (count dicts), _phi_X, _phi_Y
+    sp = gk.ShortestPath()
+    K = sp.fit_transform(G)
+    assert len(sp._enum) == z["sp_enum"].shape[0]           # known without rebuilding the dictionary
+    enum = sorted(sp._enum.items(), key=lambda kv: kv[1])
+    assert [[int(k[0]), int(k[1]), int(k[2])] for k, _ in enum] == z["sp_enum"].tolist()
+    assert np.array_equal(sp._phi_X, z["sp_phi_X"]) and np.array_equal(sp._phi_X @ sp._phi_X.T, K)
+    assert sorted([int(k), int(v)] for k, v in sp.X[0].items()) == json.loads(str(z["sp_X_graph0"]))
+    Kt = sp.transform(G[:7])
+    assert sp._phi_Y.shape == tuple(z["sp_phi_Y_shape"].tolist()) and len(sp._Y_enum) == 0
+    assert np.array_equal(sp._phi_Y @ sp._phi_X.T, Kt)
+    sp2 = pickle.loads(pickle.dumps(sp))
+    assert np.array_equal(sp2._phi_X[:, :len(enum)], z["sp_phi_X"])
+
+
+def test_shortest_path_distance_range_is_checked(gk):
+    """A chain whose end-to-end distance leaves the int32 distance range must raise, not count as unreachable."""
+    from grakel_amd._lib import GkError
+    n = 1200
+    w = 1000000 - 1                                           # below the host's per-edge cap, (n-1)*w > 2^30
+    ed = {(i, i + 1): w for i in range(n - 1)}
+    ed.update({(i + 1, i): w for i in range(n - 1)})
+    with pytest.raises((GkError, NotImplementedError)):
+        gk.ShortestPath().fit_transform([[ed, {i: 0 for i in range(n)}]])

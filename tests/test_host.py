@@ -500,3 +500,32 @@ def test_induced_subbatch_and_core_framework_parameters():
     g = GraphKernel(kernel=[{"name": "CORE"}, {"name": "WL", "n_iter": 2}])
     g.initialize()
     assert type(g.kernel_).__name__ == "CoreFramework" and g.kernel_.base_graph_kernel[0] is WeisfeilerLehman
+
+
+def test_limits_fail_early_and_reference_base_classes_are_accepted():
+    """n_iter beyond what one feature job holds fails in initialize(), not deep inside fit_transform; a malformed
+    packed batch fails in GraphBatch; the reference's own base-kernel classes map to the accelerated ones."""
+    from grakel_amd import GraphBatch
+    from grakel_amd.weisfeiler_lehman_optimal_assignment import WeisfeilerLehmanOptimalAssignment
+    with pytest.raises(NotImplementedError):
+        WeisfeilerLehman(n_iter=48).initialize()
+    with pytest.raises(NotImplementedError):
+        WeisfeilerLehmanOptimalAssignment(n_iter=60).initialize()
+    WeisfeilerLehman(n_iter=47).initialize()
+    gp, rp, ci, lab = np.array([0, 2, 3]), np.array([0, 1, 2, 2]), np.array([1, 0]), np.array([0, 1, 0])
+    assert GraphBatch(gp, rp, ci, lab, 2).n_graphs == 2
+    for bad in (dict(rp=np.array([0, 2, 1, 2])), dict(gp=np.array([0, 3, 3])[[0, 2, 1]]), dict(lab=np.array([0, 2, 0])),
+                dict(lab=np.array([0, -1, 0]))):
+        a = dict(gp=gp, rp=rp, ci=ci, lab=lab)
+        a.update(bad)
+        with pytest.raises(ValueError):
+            GraphBatch(a["gp"], a["rp"], a["ci"], a["lab"], 2)
+    # a class that only LOOKS like the reference's (module "grakel....", same name) is enough for the mapping
+    fake = type("VertexHistogram", (object,), {"__module__": "grakel.kernels.vertex_histogram"})
+    wl = WeisfeilerLehman(base_graph_kernel=fake)
+    wl.initialize()
+    assert wl._base_graph_kernel is VertexHistogram
+    fake_sp = type("ShortestPath", (object,), {"__module__": "grakel.kernels.shortest_path"})
+    wl = WeisfeilerLehman(base_graph_kernel=(fake_sp, {"with_labels": True}))
+    wl.initialize()
+    assert wl._base_graph_kernel is ShortestPath
