@@ -514,7 +514,7 @@ def test_limits_fail_early_and_reference_base_classes_are_accepted():
     WeisfeilerLehman(n_iter=47).initialize()
     gp, rp, ci, lab = np.array([0, 2, 3]), np.array([0, 1, 2, 2]), np.array([1, 0]), np.array([0, 1, 0])
     assert GraphBatch(gp, rp, ci, lab, 2).n_graphs == 2
-    for bad in (dict(rp=np.array([0, 2, 1, 2])), dict(gp=np.array([0, 3, 3])[[0, 2, 1]]), dict(lab=np.array([0, 2, 0])),
+    for bad in (dict(rp=np.array([0, 2, 1, 2])), dict(gp=np.array([0, 4, 3])), dict(lab=np.array([0, 2, 0])),
                 dict(lab=np.array([0, -1, 0]))):
         a = dict(gp=gp, rp=rp, ci=ci, lab=lab)
         a.update(bad)
