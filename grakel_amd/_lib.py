@@ -41,6 +41,7 @@ SIGNATURES = {
     "gk_host_free": (c_int, [c_void_p]),
     "gk_batch_create": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int32, c_int, _vpp]),
+    "gk_batch_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, _vpp]),
     "gk_batch_destroy": (c_int, [c_void_p]),
     "gk_batch_info": (c_int, [c_void_p, _i64p, _i64p, _i64p]),
     "gk_wl_relabel": (c_int, [c_void_p, c_void_p, c_int, c_int, _i64p, POINTER(c_int)]),

@@ -946,6 +946,47 @@ extern "C" int gk_batch_from_shards(gk_ctx* ctx, int n_ranks, const int64_t* sha
     return GK_OK;
 }
 
+// out[i] = in[i] + delta (pointer / index arrays of the second batch of a union)
+__global__ void shift_copy_kernel(const i32* __restrict__ in, i32* __restrict__ out, i64 n, i32 delta) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + delta;
+}
+
+// Union batch on the device: graphs of `a` first, then the graphs of `b` (transform = fitted graphs +
+// targets, weisfeiler_lehman.py:330-500 relabels the targets against the fitted dictionaries; here the
+// union is relabelled jointly).  `a` typically is the fitted batch kept resident between calls, so a
+// transform only uploads its targets.  Both inputs stay valid.
+extern "C" int gk_batch_concat(gk_ctx* ctx, gk_batch* a, gk_batch* b, int32_t n_labels0, gk_batch** out) {
+    GK_ARG(ctx && a && b && out, "gk_batch_concat: null argument");
+    GK_ARG(!a->is_pair_batch && !b->is_pair_batch, "gk_batch_concat: needs graph batches");
+    GK_ARG(a->ctx == ctx && b->ctx == ctx, "gk_batch_concat: batches of another context");
+    const i64 N = a->n_graphs + b->n_graphs, V = a->n_nodes + b->n_nodes, E = a->n_edges + b->n_edges;
+    GK_ARG(V < (1ll << 31) - 1 && E < (1ll << 31) - 1, "gk_batch_concat: int32 index overflow");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    gk_batch* u = new gk_batch();
+    u->ctx = ctx;
+    u->n_graphs = N, u->n_nodes = V, u->n_edges = E, u->n_labels0 = n_labels0;
+    auto fail = [&](int r) { gk_batch_destroy(u); return r; };
+    int r;
+    if ((r = batch_alloc(ctx, u))) return fail(r);
+    hipStream_t st = ctx->stream;
+#define U_COPY(dst, src, n) if ((n) > 0 && hipMemcpyAsync(dst, src, (size_t)(n) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { gk_set_error("gk_batch_concat: copy failed"); return fail(GK_ERR_HIP); }
+    U_COPY(u->graph_ptr, a->graph_ptr, a->n_graphs + 1);
+    U_COPY(u->row_ptr, a->row_ptr, a->n_nodes + 1);
+    U_COPY(u->col_idx, a->col_idx, a->n_edges);
+    U_COPY(u->labels, a->labels, a->n_nodes);          // level-0 labels: the first n_nodes entries
+    U_COPY(u->labels + a->n_nodes, b->labels, b->n_nodes);
+#undef U_COPY
+    shift_copy_kernel<<<grid_for(b->n_graphs, 256), 256, 0, st>>>(b->graph_ptr + 1, u->graph_ptr + a->n_graphs + 1, b->n_graphs, (i32)a->n_nodes);
+    if (b->n_nodes > 0)
+        shift_copy_kernel<<<grid_for(b->n_nodes, 256), 256, 0, st>>>(b->row_ptr + 1, u->row_ptr + a->n_nodes + 1, b->n_nodes, (i32)a->n_edges);
+    if (b->n_edges > 0)
+        shift_copy_kernel<<<grid_for(b->n_edges, 256), 256, 0, st>>>(b->col_idx, u->col_idx + a->n_edges, b->n_edges, (i32)a->n_nodes);
+    if ((r = batch_finish(ctx, u))) return fail(r);
+    *out = u;
+    return GK_OK;
+}
+
 extern "C" int gk_batch_destroy(gk_batch* b) {
     if (!b) return GK_OK;
     gk_ctx* ctx = b->ctx;

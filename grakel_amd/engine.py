@@ -166,6 +166,12 @@ class Engine(object):
                                        _ptr(gb.node_label), gb.n_labels, 0, byref(h)))
         return DeviceBatch(self, h, gb.n_graphs, gb.n_nodes, gb.n_edges)
 
+    def concat(self, a, b, n_labels):
+        """Union batch on the device (graphs of ``a`` first); ``a`` and ``b`` stay valid."""
+        h = c_void_p()
+        check(self.lib.gk_batch_concat(self.handle, a.handle, b.handle, int(n_labels), byref(h)))
+        return DeviceBatch(self, h, a.n_graphs + b.n_graphs, a.n_nodes + b.n_nodes, a.n_edges + b.n_edges)
+
     def upload_from_device(self, n_graphs, n_nodes, n_edges, graph_ptr, row_ptr, col_idx, node_label,
                            n_labels):
         """Arrays are raw device pointers (ints), e.g. torch tensors' ``data_ptr()``."""

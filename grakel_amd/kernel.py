@@ -101,9 +101,25 @@ class Kernel(BaseEstimator, TransformerMixin):
                 delattr(self, attr)
         self._is_transformed = False
 
+    def _fitted_on_device(self, eng):
+        """The fitted batch in HBM, uploaded once and kept between ``fit_transform`` / ``transform`` /
+        ``diagonal`` calls (never pickled).  Relabelling adds level arrays to it, the CSR itself is immutable."""
+        d = self.__dict__.get("_dev_fit")
+        if d is None or d.handle is None or d.engine is not eng or d.engine.handle is None:
+            d = self._dev_fit = eng.upload(self._fit_batch)
+        return d
+
+    def _union_on_device(self, eng, ybatch):
+        """Fitted graphs + targets as one device batch; only the targets are uploaded."""
+        yb = eng.upload(ybatch)
+        try:
+            return eng.concat(self._fitted_on_device(eng), yb, max(self._fit_batch.n_labels, ybatch.n_labels))
+        finally:
+            yb.close()
+
     def _gram_fit(self):
         eng = self._engine()
-        db = eng.upload(self._fit_batch)
+        db = self._fitted_on_device(eng)
         fb, n_levels = self._prepare(eng, db)
         feat = eng.features(fb, n_levels, kind=self._feature_kind)
         self._X_diag = eng.selfk(feat)
@@ -114,9 +130,8 @@ class Kernel(BaseEstimator, TransformerMixin):
     def _gram_transform(self, Y):
         ybatch, _ = self._ingest(Y, self._label_map if self._label_map is not None else {})
         self._ny = ybatch.n_graphs
-        union = GraphBatch.concat(self._fit_batch, ybatch)
         eng = self._engine()
-        db = eng.upload(union)
+        db = self._union_on_device(eng, ybatch)
         fb, n_levels = self._prepare(eng, db)
         feat = eng.features(fb, n_levels, n_fit=self._nx, kind=self._feature_kind)
         selfk = eng.selfk(feat)

@@ -200,9 +200,12 @@ class WeisfeilerLehman(Kernel):
     def _gram_transform(self, Y):
         ybatch, _ = self._ingest(Y, self._label_map if self._label_map is not None else {})
         self._ny = ybatch.n_graphs
-        self._cur_batch = GraphBatch.concat(self._fit_batch, ybatch)
         eng = self._engine()
-        db = eng.upload(self._cur_batch)
+        if self._base_graph_kernel is ShortestPath:        # edge weights travel with the host batch
+            self._cur_batch = GraphBatch.concat(self._fit_batch, ybatch)
+            db = eng.upload(self._cur_batch)
+        else:
+            db = self._union_on_device(eng, ybatch)
         fb, n_levels = self._prepare(eng, db)
         feat = eng.features(fb, n_levels, n_fit=self._nx)
         selfk = eng.selfk(feat)

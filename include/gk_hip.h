@@ -87,6 +87,10 @@ int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, int64_t n_ed
  * ncclAllGather leaves).  Shards are concatenated in rank order. */
 int gk_batch_from_shards(gk_ctx* ctx, int n_ranks, const int64_t* shard_sizes, int64_t mg, int64_t mv,
                          int64_t me, const int32_t* gathered_dev, int32_t n_labels0, gk_batch** out);
+/* Union batch on the device, graphs of `a` first: what a transform relabels (fitted graphs + targets;
+ * weisfeiler_lehman.py:330-500, vertex_histogram.py:57-154 with the fitted label columns).  `a` usually is the
+ * fitted batch kept in HBM between calls, so only the targets cross PCIe.  Both inputs stay valid. */
+int gk_batch_concat(gk_ctx* ctx, gk_batch* a, gk_batch* b, int32_t n_labels0, gk_batch** out);
 int gk_batch_destroy(gk_batch* b);
 int gk_batch_info(gk_batch* b, int64_t* n_graphs, int64_t* n_nodes, int64_t* n_edges);
 

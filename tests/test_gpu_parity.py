@@ -246,7 +246,7 @@ def test_small_sets_against_reference_goldens(gk, name):
         wl = gk.WeisfeilerLehman(n_iter=h)
         assert np.array_equal(wl.fit_transform(tr), z["%s/wl%d_fit" % (name, h)])
         assert np.array_equal(wl.transform(te), z["%s/wl%d_tr" % (name, h)])
-        assert [x.shape[1] for x in wl.X.values()] == z["%s/wl%d_counts" % (name, h)].tolist()
+        assert [x.X.shape[1] for x in wl.X.values()] == z["%s/wl%d_counts" % (name, h)].tolist()
     wln = gk.WeisfeilerLehman(n_iter=2, normalize=True)
     assert np.allclose(wln.fit_transform(tr), z[name + "/wl2n_fit"], rtol=REL_TOL, atol=0)
     assert np.allclose(wln.transform(te), z[name + "/wl2n_tr"], rtol=REL_TOL, atol=0)
@@ -292,7 +292,7 @@ def test_mutag_against_reference_goldens(gk, mutag_graphs):
     wl = gk.WeisfeilerLehman(n_iter=5)
     K = wl.fit_transform(G)
     assert np.array_equal(K, z["K_wl5"])
-    assert [x.shape[1] for x in wl.X.values()] == z["wl5_label_counts"].tolist()
+    assert [x.X.shape[1] for x in wl.X.values()] == z["wl5_label_counts"].tolist()
     assert np.array_equal(wl.diagonal(), np.diagonal(z["K_wl5"]))
     assert np.linalg.eigvalsh(K).min() > -1e-5            # grakel/tests/test_kernels.py:516-520
     assert np.array_equal(gk.ShortestPath().fit_transform(G), z["K_sp"])
@@ -328,7 +328,7 @@ def test_er_sets_against_reference_goldens(gk):
         p = float(z["p"][0])
         wl = gk.WeisfeilerLehman(n_iter=h)
         K = wl.fit_transform(er_dataset(N, n, p, L, seed))
-        assert [x.shape[1] for x in wl.X.values()] == z["label_counts"].tolist()
+        assert [x.X.shape[1] for x in wl.X.values()] == z["label_counts"].tolist()
         assert int(K.sum()) == int(z["K_sum"][0]) and int(np.trace(K)) == int(z["K_trace"][0])
         assert np.array_equal(K[:64, :64], z["K_block"])
         assert np.array_equal(K[z["samp_i"], z["samp_j"]], z["samp_v"])
@@ -351,7 +351,7 @@ def test_config3_full_size_against_reference_checksums(gk):
     gp, rp, ci, lab = er_dataset_csr(N, n, float(z["p"][0]), L, seed)
     wl = gk.WeisfeilerLehman(n_iter=h)
     K = wl.fit_transform(gk.GraphBatch(gp, rp, ci, lab, L))
-    assert [x.shape[1] for x in wl.X.values()] == z["label_counts"].tolist()
+    assert [x.X.shape[1] for x in wl.X.values()] == z["label_counts"].tolist()
     assert int(K.sum()) == int(z["K_sum"][0])
     assert int(np.trace(K)) == int(z["K_trace"][0]) and int(K.max()) == int(z["K_max"][0])
     assert np.array_equal(np.diagonal(K), z["diag"])
