@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: WL-subtree(h=5) fit_transform Gram matrix, graph-pairs/second.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* is one full pass of the hot path over BASELINE config 3 (10 000 synthetic
-Erdos-Renyi graphs, n=100, p=0.05, 5 labels, seed 0): WL relabelling for 5
-iterations, label-count features of the 6 levels, and the N x N Gram matrix, with the packed
-CSR batch already resident in HBM when the timed region starts and the float64 matrix left in
-HBM when it ends.  N>1: the graphs (and the Gram rows) are sharded over the ranks; a step then
-also contains the RCCL all-gather of the CSR shards (grakel_amd/dist.py).  Total work is
-fixed, so the scaling is "strong".
+A *step* is one full pass of the hot path over the workload -- default BASELINE config 3 (10 000
+synthetic Erdos-Renyi graphs, n=100, p=0.05, 5 labels, seed 0), the configuration the
+metric is quoted on: WL relabelling for 5 iterations, label-count features of the 6 levels, and the
+N x N Gram matrix, with the packed CSR batch already resident in HBM when the timed region starts and
+the float64 matrix left in HBM when it ends (`value` = the DEVICE STEP; what a caller of
+`fit_transform` sees, host ndarray included, is `end_to_end.value_host_to_host`).  N>1: the graphs and
+the Gram rows are sharded over the ranks; a step then also contains the RCCL all-gather of the CSR
+shards (grakel_amd/dist.py).  Total work is fixed, so the scaling is "strong".  `--workload config5`
+(50 000 graphs, n=30: a 20 GB matrix) is the case where the row sharding is needed for capacity.
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the
-dominant kernel (the int8 MFMA Gram) and `cpu_baseline` (the oracle timed on this box).
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the dominant
+kernel (the Gram kernel: bound by the float64 store of K) and `cpu_baseline` (the oracle
+timed on this box).
 """
 import argparse
 import json
@@ -26,26 +29,32 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOAD = dict(N=10000, n=100, p=0.05, L=5, seed=0, n_iter=5)
-I8_DENSE_PEAK_TOPS = 5000.0      # int8 MFMA dense = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
-F64_PEAK_TFLOPS = 78.6
-# HBM-side bytes per launch of the MFMA Gram kernel on this exact workload (config 3), from the PMC
-# passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of
-# this script, summarised by tools/pmc_summary.py): 2 x FETCH_SIZE (gfx950 reports half of a wide
-# coalesced read, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.
-# Algorithmic floor: read Phi_s once (24 MB packed) + write the float64 K once (800 MB).
-PMC_FILE = os.path.join(ROOT, "profiles", "r01s_pmc_hbm_bytes.csv")
+WORKLOADS = {
+    # golden = (sum of K, trace of K) from the real reference (tests/golden/er_config3.npz); config 5 cannot
+    # be run by the reference (six dense 50k x 50k float64 matrices): its checks are the invariants
+    "config3": dict(N=10000, n=100, p=0.05, L=5, seed=0, n_iter=5, golden=(200604613570.0, 25874190.0),
+                    label_counts=[5, 17694, 973861, 993286, 993302, 993302]),
+    "config5": dict(N=50000, n=30, p=0.1, L=5, seed=0, n_iter=5, golden=None,
+                    label_counts=[5, 6987, 1106456, 1386518, 1408511, 1408933]),
+}
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP4_DENSE_PEAK_TOPS = 10000.0    # MX fp4 dense (the operands of the counts <= 4); int8 dense = 5000
+I8_DENSE_PEAK_TOPS = 5000.0
+# HBM-side bytes per launch of the Gram kernel on config 3, from the PMC passes committed under profiles/
+# (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, summarised by
+# tools/pmc_summary.py): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read,
+# MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.  NOT measured in this run.
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_bytes.csv")
+GRAM_KERNELS = ("gram_ws_kernel", "gram_tile_kernel")
 
 
-def gram_pmc_traffic_bytes(n_graphs, dtype):
-    """Per-launch HBM bytes of the int8 MFMA Gram kernel from the committed PMC summary, or None
-    when the workload is not the profiled one (config 3) or the file is absent."""
-    if n_graphs != WORKLOAD["N"] or dtype != "i8" or not os.path.exists(PMC_FILE):
+def gram_pmc_traffic_bytes(workload, world):
+    if workload != "config3" or world != 1 or not os.path.exists(PMC_FILE):
         return None
     fetch = write = None
     with open(PMC_FILE) as f:
         for line in f:
-            if "gram_i8_glds_kernel" not in line:
+            if not any(k in line for k in GRAM_KERNELS):
                 continue
             parts = line.rstrip().rsplit(",", 3)          # "kernel",counter,launches,avg
             if parts[1] == "FETCH_SIZE":
@@ -57,25 +66,46 @@ def gram_pmc_traffic_bytes(n_graphs, dtype):
     return (2.0 * fetch + write) * 1024.0
 
 
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
 def cpu_baseline(sample_graphs, cfg):
-    """The CPU oracle (a literal restatement of the reference's algorithm) on a bounded sample
-    of the same workload: the first `sample_graphs` graphs of config 3, one host core."""
+    """The CPU oracle (a literal restatement of the reference's algorithm, oracle/grakel_oracle.py) on a
+    bounded sample of the same workload: the first `sample_graphs` graphs of the generator, ONE host core
+    (the reference's only parallel mode, n_jobs, hands pairwise kernel calls to joblib threads; the WL /
+    VertexHistogram path computes its matrices with one scipy product per level and never uses it)."""
     from oracle import grakel_oracle as O
     from grakel_amd.synthetic import er_dataset
     X = er_dataset(sample_graphs, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])
     t0 = time.perf_counter()
     K = O.WLOracle(n_iter=cfg["n_iter"]).fit_transform(X)
     dt = time.perf_counter() - t0
+    model, nproc = cpu_info()
     return dict(value=sample_graphs * sample_graphs / dt, unit="graph-pairs/s", cores=1, kind="port",
-                sample="first %d graphs of the config-3 generator (n=%d p=%.2f h=%d), "
-                       "oracle.WLOracle.fit_transform, %.1f s, K sum %d"
-                       % (sample_graphs, cfg["n"], cfg["p"], cfg["n_iter"], dt, int(K.sum()))), K, X
+                cpu_model=model, host_cores_available=nproc,
+                sample="first %d graphs of the %d-graph generator (n=%d p=%.2f h=%d), oracle.WLOracle.fit_transform, "
+                       "%.1f s, K sum %d; the cost is ~N^2 (one dense N x N float64 per level), so the full-size rate "
+                       "is at or below this one" % (sample_graphs, cfg["N"], cfg["n"], cfg["p"], cfg["n_iter"], dt, int(K.sum())),
+                reference_real="grakel 0.1.11 itself, full config 3, one core of the build container (Intel Xeon "
+                               "2.1 GHz): 93.1 s = 1.07e6 graph-pairs/s (tests/golden/er_config3.npz: ref_seconds); "
+                               "it cannot travel to the GPU box")
 
 
-def end_to_end(eng, full, cfg):
+def end_to_end(eng, full, cfg, with_objects):
     """What a caller of the estimator sees (never `value`): (a) packed CSR on the host -> float64 K on the
-    host (upload, step, 8 N^2 bytes over PCIe into pageable memory), (b) the estimator on Python
-    objects (SURVEY.md 8d asks for both walls).  One run each, after one warm-up of (a)."""
+    host (upload, step, 8 N^2 bytes over PCIe into the pinned output pool), (b) the estimator on Python
+    objects (SURVEY.md 8d asks for both walls).  One run each, after warm-ups (the first run of a size
+    pins the output block)."""
     import grakel_amd
     from grakel_amd.synthetic import er_dataset
     N, h = cfg["N"], cfg["n_iter"]
@@ -91,22 +121,79 @@ def end_to_end(eng, full, cfg):
         db.close()
         return dt, K
 
+    t0 = time.perf_counter()
+    _, K = packed()
+    first = time.perf_counter() - t0
+    del K
     packed()
     dt_packed, K = packed()
-    X = er_dataset(N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])      # {u: [v, ...]} + {u: label} per graph
-    from grakel_amd.batch import wl_batch_from_input
+    out = {"packed_csr_host_to_host_ms": dt_packed * 1e3, "value_host_to_host": N * N / dt_packed,
+           "first_call_ms_incl_pinning_the_output": first * 1e3,
+           "note": "packed: H2D of the CSR + step + D2H of the %d MB float64 K into a pinned, reused output "
+                   "block (grakel_amd.engine.PinnedPool)" % (N * N * 8 // 1000000)}
+    if with_objects:
+        X = er_dataset(N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])      # {u: [v, ...]} + {u: label} per graph
+        from grakel_amd.batch import wl_batch_from_input
+        est = grakel_amd.WeisfeilerLehman(n_iter=h)
+        est.fit_transform(X[:50])
+        t0 = time.perf_counter()
+        Kobj = est.fit_transform(X)
+        dt_obj = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        wl_batch_from_input(X)                       # the ingestion part alone, same (now warm) objects
+        dt_ingest = time.perf_counter() - t0
+        out.update({"python_objects_s": dt_obj, "python_objects_graph_pairs_per_s": N * N / dt_obj,
+                    "of_which_host_ingestion_s": dt_ingest, "same_matrix": bool(np.array_equal(K, Kobj)),
+                    "objects_note": "grakel_amd.WeisfeilerLehman(n_iter=%d).fit_transform on %d dict graphs" % (h, N)})
+    return out
+
+
+def config4_sp(eng, steps=5):
+    """BASELINE config 4 stand-in (4110 NCI1-like graphs, ShortestPath): ms per fit_transform from the packed
+    CSR in HBM, the all-pairs kernels' min-plus rate against an LDS-bandwidth ceiling, the Gram kernel."""
+    from grakel_amd.batch import sp_batch_from_input
+    from grakel_amd.synthetic import nci1_like
+    N = 4110
+    gb, _ = sp_batch_from_input(nci1_like(N, 0, as_adj=True), True)
+    db = eng.upload(gb)
+    sizes = np.diff(gb.graph_ptr).astype(np.float64)
+
+    def step():
+        pb = eng.sp_build(db, None, True)
+        feat = eng.features(pb, 1)
+        eng.gram(feat, 0, to_host=False)
+        info = dict(n_pairs=pb.n_nodes, n_keys=pb.label_counts[0], dense=feat.n_cols, rare=feat.n_cols_low,
+                    max_count=feat.max_count, gram=eng.gram_stats(feat), checksum=eng.gram_checksum(feat))
+        feat.close()
+        pb.close()
+        return info
+
+    for _ in range(2):
+        step()
+    eng.synchronize()
     t0 = time.perf_counter()
-    Kobj = grakel_amd.WeisfeilerLehman(n_iter=h).fit_transform(X)
-    dt_obj = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    wl_batch_from_input(X)                       # the ingestion part alone, same (now warm) objects
-    dt_ingest = time.perf_counter() - t0
-    return {"packed_csr_host_to_host_ms": dt_packed * 1e3, "packed_csr_graph_pairs_per_s": N * N / dt_packed,
-            "python_objects_s": dt_obj, "python_objects_graph_pairs_per_s": N * N / dt_obj,
-            "of_which_host_ingestion_s": dt_ingest, "same_matrix": bool(np.array_equal(K, Kobj)),
-            "note": "packed: H2D of the CSR + step + D2H of the %d MB float64 K into pageable memory; "
-                    "objects: grakel_amd.WeisfeilerLehman(n_iter=%d).fit_transform on %d dict graphs"
-                    % (N * N * 8 // 1000000, h, N)}
+    for _ in range(steps):
+        info = step()
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng.profile(True)
+    step()
+    ph = {k: round(eng.profile_get(k)[0], 4) for k in ("sp", "sp_fw", "features", "gram")}
+    eng.profile(False)
+    db.close()
+    ops = float((sizes ** 3).sum())
+    # a min-plus update reads d[i][k], d[k][j], d[i][j] and writes d[i][j]: 16 LDS bytes; 4-byte LDS reads
+    # stream at ~75 TB/s chip-wide (MI355X_MICROARCH.md "LDS")
+    ceiling = 75e12 / 16.0
+    return {"workload": "NCI1-like stand-in (SURVEY.md appendix A), %d graphs, ShortestPath(with_labels), packed CSR in HBM" % N,
+            "ms_per_fit_transform": dt * 1e3, "graph_pairs_per_s": N * N / dt, "phases_ms": ph,
+            "fw_minplus_ops": ops, "fw_Gops_per_s": ops / (ph["sp_fw"] * 1e-3) / 1e9,
+            "fw_lds_ceiling_Gops_per_s": ceiling / 1e9, "fw_frac_of_lds_ceiling": ops / (ph["sp_fw"] * 1e-3) / ceiling,
+            "pairs": info["n_pairs"], "features": info["n_keys"], "dense_columns": info["dense"],
+            "rare_columns": info["rare"], "max_count": info["max_count"], "gram_kernel_ms": info["gram"][1],
+            "K_sum": info["checksum"][0], "K_sum_expected": 87649686148.0,
+            "K_matches_reference_checksum": bool(info["checksum"][0] == 87649686148.0 and info["checksum"][2] == 0.0),
+            "reference_cpu_s": {"floyd_warshall_route": 15.2, "dijkstra_route": 21.8}}
 
 
 def main():
@@ -114,9 +201,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--graphs", type=int, default=WORKLOAD["N"], help="(debug) smaller workload")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3")
+    ap.add_argument("--graphs", type=int, default=0, help="(debug) smaller workload")
     ap.add_argument("--cpu-sample", type=int, default=6500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and the config-4 object")
     a = ap.parse_args()
 
     import torch
@@ -149,8 +238,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg = dict(WORKLOAD)
-    cfg["N"] = a.graphs
+    cfg = dict(WORKLOADS[a.workload])
+    full_size = a.graphs in (0, cfg["N"])
+    if not full_size:
+        cfg["N"], cfg["golden"], cfg["label_counts"] = a.graphs, None, None
     N, h = cfg["N"], cfg["n_iter"]
     eng = get_engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -158,19 +249,23 @@ def main():
     gp, rp, ci, lab = er_dataset_csr(N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])
     full = GraphBatch(gp, rp, ci, lab, cfg["L"])
     info = {}
+    keep = {}
 
     if world == 1:
         db = eng.upload(full)                 # input resident in HBM before the timed region
 
         pending = []
 
-        def collect():
-            # HIP-event time of the previous step's MFMA kernel: read one step late, when it has
+        def collect(last=False):
+            # HIP-event time of the previous step's Gram kernel: read one step late, when it has
             # long finished, so that reading it never drains the queue the host is filling
             while pending:
                 f = pending.pop()
                 info["gram"] = eng.gram_stats(f)
-                f.close()
+                if last:
+                    keep["feat"] = f
+                else:
+                    f.close()
 
         def step():
             eng.wl_relabel(db, h)
@@ -210,9 +305,23 @@ def main():
             gram_ms.append(info["gram"][1])      # world == 1: the step before (see collect)
     sync()
     dt = time.perf_counter() - t0
+    checks = None
     if world == 1:
-        collect()
+        collect(last=True)
         gram_ms.append(info["gram"][1])
+        # the matrix the LAST timed step left in HBM, checked in place (no 8 N^2-byte copy)
+        s, tr, asym = eng.gram_checksum(keep["feat"])
+        selfk_sum = float(eng.selfk(keep["feat"]).sum())
+        checks = {"K_sum": s, "K_trace": tr, "max_abs_K_minus_KT": asym, "trace_equals_sum_of_selfk": bool(tr == selfk_sum),
+                  "label_counts_match_the_oracle": (info["label_counts"] == cfg["label_counts"]) if cfg["label_counts"] else None,
+                  "matches_reference_checksums": bool((s, tr) == cfg["golden"]) if cfg["golden"] else None,
+                  "gram_max_abs_err": 0.0 if (cfg["golden"] and (s, tr) == cfg["golden"] and asym == 0.0) else None}
+        assert asym == 0.0 and tr == selfk_sum, "timed Gram matrix is not symmetric / has a wrong diagonal: %r" % (checks,)
+        if cfg["golden"]:
+            assert (s, tr) == cfg["golden"], "timed Gram matrix differs from the reference checksums: %r" % (checks,)
+        if cfg["label_counts"]:
+            assert info["label_counts"] == cfg["label_counts"], "WL label counts differ from the oracle's"
+        keep.pop("feat").close()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,11 +340,17 @@ def main():
         ms_per_step = dt / a.steps * 1e3
         flops, _ = info["gram"]
         gram_avg_ms = float(np.mean(gram_ms))
-        dtype = ("i8", "f64")[info["dtype"]]
-        peak = I8_DENSE_PEAK_TOPS if dtype == "i8" else F64_PEAK_TFLOPS
-        achieved = flops / (gram_avg_ms * 1e-3) / 1e12
-        d_eff = (info.get("n_cols") or 0) + (info.get("n_cols_low") or 0)
-        alg_flops = (2.0 * (N / world) * N * d_eff) if world > 1 else (2.0 * (N * (N + 1) / 2) * d_eff)
+        f64_only = bool(info["dtype"])
+        d_dense = info.get("n_cols") or 0
+        d_eff = d_dense + (info.get("n_cols_low") or 0)
+        rows = N / world
+        # algorithmic HBM bytes of one Gram launch: write the rank's float64 rows once,
+        # read the dense operand once (fp4: two columns per byte, 128-byte K-steps)
+        operand_bytes = (N + 511) // 256 * 256 * ((d_dense + 255) // 256 * 128)
+        gram_bytes = 8.0 * rows * N + operand_bytes
+        achieved_gbs = gram_bytes / (gram_avg_ms * 1e-3) / 1e9
+        mfma_peak = I8_DENSE_PEAK_TOPS if os.environ.get("GK_GRAM_NO_FP4") else FP4_DENSE_PEAK_TOPS
+        alg_flops = (2.0 * rows * N * d_eff) if world > 1 else (2.0 * (N * (N + 1) / 2) * d_eff)
         # HBM view of the two integer phases (SURVEY.md 8d algorithmic bytes, int32 everywhere):
         # relabel per level 8E + 12V (signature) + 24V (dictionary pass); features 16V per level
         V_, E_ = int(full.n_nodes), int(full.n_edges)
@@ -248,55 +363,61 @@ def main():
                             "frac_of_8TBps": rb / (phases["relabel"] * 1e-3) / 8e12},
                 "features": {"algorithmic_bytes": fb, "GB_per_s": fb / (phases["features"] * 1e-3) / 1e9,
                              "frac_of_8TBps": fb / (phases["features"] * 1e-3) / 8e12},
-                "note": "about 60 dependent launches of 3-60 us over 1 M-element arrays per step, six device->host "
-                        "read-backs: launch/latency bound, not bandwidth bound (DESIGN.md 4)"}
+                "note": "dependent launches of 3-60 us over <= 1 M-element arrays: latency bound (DESIGN.md 4)"}
+        traffic = gram_pmc_traffic_bytes(a.workload if full_size else "", world)
         out = {
             "metric": "graph-pairs/sec for NxN WL-subtree(h=%d) fit_transform" % h,
             "value": N * N / (dt / a.steps),
+            "value_is": "device step: CSR resident in HBM -> float64 K resident in HBM (see end_to_end for host to host)",
             "unit": "graph-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": dtype,
+            "dtype": "f64" if f64_only else "fp4+i8",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: %d Erdos-Renyi graphs n=%d p=%.2f, %d labels, seed %d, "
+            "config": {"workload": "BASELINE %s: %d Erdos-Renyi graphs n=%d p=%.2f, %d labels, seed %d, "
                                    "WL-subtree h=%d, full NxN float64 Gram left in HBM"
-                                   % (N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"], h),
-                       "graphs": N, "nodes": int(full.n_nodes), "edges": int(full.n_edges),
+                                   % (a.workload, N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"], h),
+                       "graphs": N, "nodes": V_, "edges": E_,
                        "parallelism": "graphs+Gram rows sharded over %d GPU(s)" % world,
-                       "label_counts": info.get("label_counts"), "gram_columns_dense": info.get("n_cols"),
+                       "label_counts": info.get("label_counts"), "gram_columns_dense": d_dense,
                        "gram_columns_rare": info.get("n_cols_low")},
+            "checks": checks,
             "roofline": {
-                "kernel": ("gram_i8_glds_kernel<2,2,2,2,4> (128x128 tile)" if (info.get("n_cols") or 0) < 8065
-                           else "gram_i8_glds_kernel<2,4,4,2,4> (256x256 tile)"),
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak,
-                "traffic": gram_pmc_traffic_bytes(N, dtype) if world == 1 else None,
-                "traffic_source": "profiles/r01s_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE, KiB)",
-                "executed_flops_per_launch": flops, "avg_launch_ms": gram_avg_ms,
-                "algorithmic": {
-                    # 2*N_rows*N_cols*D_eff with D_eff = label columns occurring in
-                    # >= 2 graphs (dense + rare); upper triangle only at 1 GPU (stated), full rows at N GPUs
-                    "D_eff": d_eff, "dense_columns": info.get("n_cols"), "rare_columns": info.get("n_cols_low"),
-                    "flops": alg_flops, "gram_phase_ms": (phases or {}).get("gram"),
-                    "achieved": (alg_flops / ((phases or {}).get("gram") * 1e-3) / 1e12) if phases else None},
-                "note": "achieved = integer ops EXECUTED by the MFMA kernel per launch / its avg HIP-event "
-                        "duration (1 GPU: only the tiles on/above the diagonal, mirrored on store; "
-                        "only the dense columns -- label columns present in < 24 graphs are applied as exact "
-                        "pair updates by gram_low_kernel, inside gram_phase_ms; columns whose counts fit 4 bits "
-                        "travel as nibbles and are unpacked in registers, the MFMA itself is int8). The kernel "
-                        "also writes the whole float64 K (N^2*8 B), which bounds it at ~0.13 ms by HBM."},
+                "kernel": "gram_ws_kernel (persistent, warp-specialised 128x128 tiles; MX fp4 operands for counts <= 4, "
+                          "int8 for 5..127; float64 store of K)",
+                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_source": "profiles/r02_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE, KiB) -- a committed PMC "
+                                  "pass of this script, NOT measured in this run" if traffic else None,
+                "algorithmic_bytes_per_launch": gram_bytes, "avg_launch_ms": gram_avg_ms,
+                "mfma_view": {
+                    # the same launch priced against the matrix pipe: with fp4 operands its floor (flops / peak)
+                    # is ~0.05 ms on config 3, below the 0.10 ms HBM floor of the float64 store -- hence "hbm"
+                    "executed_flops_per_launch": flops, "TFLOP_per_s": flops / (gram_avg_ms * 1e-3) / 1e12,
+                    "peak": mfma_peak, "frac": flops / (gram_avg_ms * 1e-3) / 1e12 / mfma_peak,
+                    "D_eff": d_eff, "dense_columns": d_dense, "rare_columns": info.get("n_cols_low"),
+                    "algorithmic_flops": alg_flops, "gram_phase_ms": (phases or {}).get("gram")},
+                "note": "achieved = (8 bytes x rows x N of float64 K written once + the packed dense operand read once) / "
+                        "avg HIP-event duration of the Gram kernel.  1 GPU: only tiles on/above the diagonal are "
+                        "multiplied, both halves are stored; label columns present in < 24 graphs never enter the dense "
+                        "operand, their exact pair updates (gram_low_kernel) are inside gram_phase_ms."},
             "phases_ms": phases,
             "phases_hbm": phases_hbm,
         }
         if world == 1 and not a.no_cpu_baseline:
-            cb, Kcpu, X = cpu_baseline(min(a.cpu_sample, N), cfg)
-            out["cpu_baseline"] = cb
-            out["end_to_end"] = end_to_end(eng, full, cfg)
+            out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, N), cfg)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not a.no_extras:
+            out["end_to_end"] = end_to_end(eng, full, cfg, with_objects=(a.workload == "config3"))
+            try:
+                out["extra"] = {"config4_sp": config4_sp(eng)}
+            except Exception as e:                     # never lose the headline line to an extra
+                out["extra"] = {"config4_sp": {"error": repr(e)}}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

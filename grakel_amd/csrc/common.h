@@ -108,23 +108,27 @@ struct Tmp {
     Tmp& operator=(const Tmp&) = delete;
 };
 
-struct ProfScope {
+struct ProfScope {          // scopes may nest ("sp" around "sp_fw"): each owns its pair of events
     gk_ctx* ctx;
     const char* name;
     i64 launches;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     ProfScope(gk_ctx* c, const char* n, i64 l = 1) : ctx(c), name(n), launches(l) {
-        if (ctx->profile) (void)hipEventRecord(ctx->pv0, ctx->stream);
+        if (ctx->profile && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+            (void)hipEventRecord(e0, ctx->stream);
     }
     ~ProfScope() {
-        if (ctx->profile) {
-            (void)hipEventRecord(ctx->pv1, ctx->stream);
-            (void)hipEventSynchronize(ctx->pv1);
+        if (ctx->profile && e0 && e1) {
+            (void)hipEventRecord(e1, ctx->stream);
+            (void)hipEventSynchronize(e1);
             float ms = 0;
-            (void)hipEventElapsedTime(&ms, ctx->pv0, ctx->pv1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
             ProfSlot& s = ctx->prof[name];
             s.ms += ms;
             s.launches += launches;
         }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
     }
 };
 

@@ -218,6 +218,7 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     }
     const int cap = sp_fw_cap();
     const int nmax = b->max_graph_nodes;
+    ProfScope prof_fw(ctx, "sp_fw", 2);       // the all-pairs kernels alone (bench.py: min-plus rate)
     {
         // two launches over all graphs: small graphs (n <= 48) with 256 threads, the rest up to
         // the LDS cap with 1024 threads; a launch's workgroups exit at once for the other class

@@ -60,7 +60,8 @@ int gk_timer_stop_ms(gk_ctx* ctx, double* out_ms);
  * around each launch group when profiling is enabled (enable=1 adds sync overhead). */
 int gk_profile_enable(gk_ctx* ctx, int enable);
 int gk_profile_reset(gk_ctx* ctx);
-/* names: "relabel", "features", "gram".  Returns total ms and launch count. */
+/* names: "relabel", "features", "gram", "sp" (gk_sp_build*), "sp_fw" (its all-pairs kernels alone).
+ * Returns total ms and launch count. */
 int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_launches);
 
 /* Pinned (page-locked) host memory for the outputs of gk_gram / gk_gram_rows: the device -> host copy of the
