@@ -1101,3 +1101,27 @@ def test_shortest_path_distance_range_is_checked(gk):
     ed.update({(i + 1, i): w for i in range(n - 1)})
     with pytest.raises((GkError, NotImplementedError)):
         gk.ShortestPath().fit_transform([[ed, {i: 0 for i in range(n)}]])
+
+
+def test_integration_md_ctypes_stub_runs_verbatim(gk, mutag_graphs):
+    """INTEGRATION.md section B is the binding a GraKeL maintainer would paste: execute that code block exactly
+    as printed (only the library path is resolved) and compare with the reference's MUTAG WL(h=5) matrix."""
+    import re
+    from grakel_amd import _lib
+    from grakel_amd.batch import wl_batch_from_input
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, re.S)
+    stub = [b for b in blocks if "def wl_gram(" in b]
+    assert len(stub) == 1
+    code = stub[0].replace('C.CDLL("libgk_hip.so")', 'C.CDLL(%r)' % _lib.LIB_PATH)
+    assert code != stub[0]
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    G, z = mutag_graphs
+    gb, _ = wl_batch_from_input(G)
+    K, counts = ns["wl_gram"](gb.graph_ptr, gb.row_ptr, gb.col_idx, gb.node_label, gb.n_labels, 5, False)
+    assert np.array_equal(K, z["K_wl5"]) and counts == z["wl5_label_counts"].tolist()
+    Kn, _ = ns["wl_gram"](gb.graph_ptr, gb.row_ptr, gb.col_idx, gb.node_label, gb.n_labels, 5, True)
+    d = np.sqrt(np.diagonal(K))
+    assert np.allclose(Kn, K / np.outer(d, d), rtol=REL_TOL, atol=0)
