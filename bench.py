@@ -283,6 +283,7 @@ def main():
 
         def step():
             _, i = sw.step(local)
+            i.pop("K_dev", None)                 # the rank's row block (a torch tensor) is released with the step
             info.update(i)
 
     def sync():
@@ -322,10 +323,14 @@ def main():
         if cfg["label_counts"]:
             assert info["label_counts"] == cfg["label_counts"], "WL label counts differ from the oracle's"
         keep.pop("feat").close()
+    sharded_ms = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ev = getattr(sw, "last_events", None)
+        if ev is not None:                       # the last step's Gram part on this rank (rank 0 reports its own)
+            sharded_ms = {"block_products_ms": ev[0].elapsed_time(ev[1]), "exchange_and_placement_ms": ev[1].elapsed_time(ev[2])}
 
     # per-phase device times (one extra, untimed, profiled step; single GPU only)
     phases = None
@@ -340,17 +345,20 @@ def main():
         ms_per_step = dt / a.steps * 1e3
         flops, _ = info["gram"]
         gram_avg_ms = float(np.mean(gram_ms))
+        if sharded_ms is not None:               # N > 1: all block products of the rank (HIP events on the shared stream)
+            gram_avg_ms = sharded_ms["block_products_ms"]
         f64_only = bool(info["dtype"])
         d_dense = info.get("n_cols") or 0
         d_eff = d_dense + (info.get("n_cols_low") or 0)
         rows = N / world
-        # algorithmic HBM bytes of one Gram launch: write the rank's float64 rows once,
-        # read the dense operand once (fp4: two columns per byte, 128-byte K-steps)
+        # algorithmic HBM bytes of one Gram launch: write the float64 entries the rank produces
+        # once (1 GPU: all of K; N GPUs: the blocks of its symmetric plan, ~half of its row block), read the
+        # dense operand once (fp4: two columns per byte, 128-byte K-steps)
         operand_bytes = (N + 511) // 256 * 256 * ((d_dense + 255) // 256 * 128)
-        gram_bytes = 8.0 * rows * N + operand_bytes
+        gram_bytes = 8.0 * rows * N * (1.0 if world == 1 else 0.5 * (1.0 + 1.0 / world)) + operand_bytes
         achieved_gbs = gram_bytes / (gram_avg_ms * 1e-3) / 1e9
         mfma_peak = I8_DENSE_PEAK_TOPS if os.environ.get("GK_GRAM_NO_FP4") else FP4_DENSE_PEAK_TOPS
-        alg_flops = (2.0 * rows * N * d_eff) if world > 1 else (2.0 * (N * (N + 1) / 2) * d_eff)
+        alg_flops = 2.0 * (N * (N + 1) / 2) * d_eff / world
         # HBM view of the two integer phases (SURVEY.md 8d algorithmic bytes, int32 everywhere):
         # relabel per level 8E + 12V (signature) + 24V (dictionary pass); features 16V per level
         V_, E_ = int(full.n_nodes), int(full.n_edges)
@@ -381,7 +389,10 @@ def main():
                                    "WL-subtree h=%d, full NxN float64 Gram left in HBM"
                                    % (a.workload, N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"], h),
                        "graphs": N, "nodes": V_, "edges": E_,
-                       "parallelism": "graphs+Gram rows sharded over %d GPU(s)" % world,
+                       "parallelism": "graphs+Gram rows sharded over %d GPU(s)%s" % (
+                           world, "" if world == 1 else "; every rank multiplies 1/%d of the upper triangle and ships the "
+                                                        "mirrored blocks point to point (grakel_amd.dist.symmetric_plan)" % world),
+                       "sharded_gram_ms": sharded_ms,
                        "label_counts": info.get("label_counts"), "gram_columns_dense": d_dense,
                        "gram_columns_rare": info.get("n_cols_low")},
             "checks": checks,

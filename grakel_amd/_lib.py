@@ -57,6 +57,10 @@ SIGNATURES = {
     "gk_gram_dev_ptr": (c_int, [c_void_p, _vpp, _i64p, _i64p]),
     "gk_gram_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "gk_gram_last_stats": (c_int, [c_void_p, _f64p, _f64p]),
+    "gk_gram_block": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64]),
+    "gk_gram_reset_stats": (c_int, [c_void_p]),
+    "gk_block_copy": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
+    "gk_gram_normalize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int]),
     "gk_gram_checksum": (c_int, [c_void_p, c_void_p, _f64p, _f64p, _f64p]),
     "gk_sp_build": (c_int, [c_void_p, c_void_p, c_void_p, c_int, _vpp, _i64p, _i64p]),
     "gk_batch_from_shards": (c_int, [c_void_p, c_int, _i64p, c_int64, c_int64, c_int64, c_void_p, c_int, _vpp]),

@@ -121,7 +121,10 @@ template <bool FP4>
 __global__ __launch_bounds__(256) void gram_tile_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
-    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch) {
+    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, i64 ldk, i64 col_base,
+    int even) {
+    // K points at the job's entry (0, 0); ldk = elements between two of its rows; (row_base, col_base) = the
+    // job's origin in the whole matrix (diagonal / normalisation look-ups)
     constexpr int BM = GT_BM, BN = GT_BM, TM = 2, TN = 2, PPW = 8;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -230,7 +233,6 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool mirror = tri && bm != bn;     // off-diagonal tile of a symmetric job: also write K^T
-    const bool even = (N & 1) == 0;
     // The transposed copy goes through LDS (the operand ring is free after the last K-step): the 32-bit
     // accumulators are written column-major with a 4-word pad per column (conflict-free 16-byte
     // writes), then every wave streams whole columns back -- 128 consecutive K^T entries, 1 KiB of
@@ -256,9 +258,9 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(
                     const i64 row = row0 + j;
                     v[j] = 0.0;
                     if (row < M && col < N) {
-                        v[j] = finish_entry(GT_VAL(acc[mt][nt][4 * q + j]), row_base + row, col,
+                        v[j] = finish_entry(GT_VAL(acc[mt][nt][4 * q + j]), row_base + row, col_base + col,
                                             symmetric != 0, selfk, n_fit, normalize);
-                        K[row * N + col] = v[j];           // 32 lanes -> 256 contiguous bytes
+                        K[row * ldk + col] = v[j];         // 32 lanes -> 256 contiguous bytes
                     }
                 }
                 if (lds_mirror) {
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(
                     t.z = acc[mt][nt][4 * q + 2], t.w = acc[mt][nt][4 * q + 3];
                     *(float4*)(tsm + ctile * LDT + rtile) = t;
                 } else if (mirror && col < N) {             // K[col][row0..row0+3]: 32 B per lane
-                    double* dst = K + col * N + row0;
+                    double* dst = K + col * ldk + row0;
                     if (even && row0 + 3 < M) {
                         *(double2*)(dst) = make_double2(v[0], v[1]);
                         *(double2*)(dst + 2) = make_double2(v[2], v[3]);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(
             const i64 krow = (i64)bn * BN + c;
             if (krow >= N) break;
             const float2 t = *(const float2*)(tsm + c * LDT + 2 * lane);
-            double* dst = K + krow * N + r;
+            double* dst = K + krow * ldk + r;
             if (r + 1 < M) *(double2*)dst = make_double2(GT_VAL(t.x), GT_VAL(t.y));
             else if (r < M) dst[0] = GT_VAL(t.x);
         }
@@ -330,7 +332,8 @@ template <bool FP4, int ABL>
 __global__ __launch_bounds__(512) void gram_ws_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
-    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int n_ids, i64 M_store, unsigned* __restrict__ xcc_ticket) {
+    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int n_ids, i64 M_store, unsigned* __restrict__ xcc_ticket,
+    i64 ldk, i64 col_base, int even_in) {
     constexpr int BM = GT_BM, BN = GT_BM, TM = 2, TN = 2, PPW = 8;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
     // [32s, 32s+32) of the transposed tile (units 32..63).  A unit is one 1-KiB row: lane l holds the
     // entries 2l, 2l+1.
     const int sw = wave - 4;
-    const bool even = (N & 1) == 0;
+    const bool even = even_in != 0;
     int8_t* const outb = smem + WS_OUT_OFF;
 #define WS_VAL(X) (FP4 ? (double)(X) : (double)gt_bits(X))
     auto store_units = [&](int u0, int u1) __attribute__((always_inline)) {
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
         const int n_units = mirror ? 64 : 32;
         // the plain path has no global load, so the store waves never wait on their own stores (loads and
         // stores share vmcnt and retire in order)
-        const i64 d0 = row_base + (i64)prv.bm * BM - (i64)prv.bn * BN;      // job row - column at the tile origin
+        const i64 d0 = row_base + (i64)prv.bm * BM - col_base - (i64)prv.bn * BN;      // matrix row - column at the tile origin
         const bool slow = normalize != 0 || (symmetric && d0 > -BM && d0 < BN);
         if (u1 > n_units) u1 = n_units;
         for (int u = u0; u < u1; ++u) {
@@ -494,10 +497,10 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
             if (slow) {       // tiles that touch the diagonal, normalised jobs: selfk look-ups (global loads)
                 // tile coordinates for finish_entry: rows index the job's rows, cols its columns
                 const i64 jr0 = tr ? gc : grow, jc0 = tr ? grow : gc, jr1 = tr ? gc + 1 : grow, jc1 = tr ? grow : gc + 1;
-                if (gc < lim_c) v0 = finish_entry(v0, row_base + jr0, jc0, symmetric != 0, selfk, n_fit, normalize);
-                if (gc + 1 < lim_c) v1 = finish_entry(v1, row_base + jr1, jc1, symmetric != 0, selfk, n_fit, normalize);
+                if (gc < lim_c) v0 = finish_entry(v0, row_base + jr0, col_base + jc0, symmetric != 0, selfk, n_fit, normalize);
+                if (gc + 1 < lim_c) v1 = finish_entry(v1, row_base + jr1, col_base + jc1, symmetric != 0, selfk, n_fit, normalize);
             }
-            double* dst = K + grow * N + gc;
+            double* dst = K + grow * ldk + gc;
             if (even && gc + 1 < lim_c) *(double2*)dst = make_double2(v0, v1);
             else {
                 if (gc < lim_c) dst[0] = v0;
@@ -516,8 +519,8 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
         const int n_units = mirror ? 64 : 32;
         if (u1 > n_units) u1 = n_units;
         const int e = 2 * lane;
-        double* const dst_rows = K + ((i64)prv.bm * BM + sw * 32) * N + (i64)prv.bn * BN + e;     // row-major rows
-        double* const dst_cols = K + ((i64)prv.bn * BN + sw * 32) * N + (i64)prv.bm * BM + e;     // rows of the transpose
+        double* const dst_rows = K + ((i64)prv.bm * BM + sw * 32) * ldk + (i64)prv.bn * BN + e;     // row-major rows
+        double* const dst_cols = K + ((i64)prv.bn * BN + sw * 32) * ldk + (i64)prv.bm * BM + e;     // rows of the transpose
         for (int ub = u0; ub < u1; ub += 4) {
             float2 x[4];
 #pragma unroll
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
                 const int u = ub + q;
                 if (u < u1) {
                     const v2d v = {WS_VAL(x[q].x), WS_VAL(x[q].y)};
-                    double* dst = (u >= 32 ? dst_cols : dst_rows) + (i64)(u & 31) * N;
+                    double* dst = (u >= 32 ? dst_cols : dst_rows) + (i64)(u & 31) * ldk;
                     if (ABL == 0) __builtin_nontemporal_store(v, (v2d*)dst);
                     else if (v.x == 1.2345e300) dst[0] = v.y;
                 }
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
         }
     };
     auto store_chunk = [&](int u0, int u1) __attribute__((always_inline)) {
-        const i64 d0 = row_base + (i64)prv.bm * BM - (i64)prv.bn * BN;
+        const i64 d0 = row_base + (i64)prv.bm * BM - col_base - (i64)prv.bn * BN;
         const bool plain = normalize == 0 && !(symmetric && d0 > -BM && d0 < BN) && even &&
                            ((i64)prv.bm + 1) * BM <= M_store && ((i64)prv.bn + 1) * BN <= N &&
                            (!(tri && prv.bm != prv.bn) || (((i64)prv.bn + 1) * BN <= M_store && ((i64)prv.bm + 1) * BM <= N));
@@ -636,7 +639,9 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
 }
 
 static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
-                        i64 row_lo, int normalize, double* K, int tri, int patch, double* entries_done) {
+                        i64 row_lo, int normalize, double* K, int tri, int patch, double* entries_done, i64 ldk, i64 col_lo) {
+    // a / b: operand rows of the job's first row / first column; K: the job's entry (0, 0)
+    const int even = ((uintptr_t)K % 16 == 0 && ldk % 2 == 0) ? 1 : 0;      // 16-byte stores of two float64
     const int tiles_m = (int)cdiv(M, GT_BM), tiles_n = (int)cdiv(n_cols, GT_BM);
     const int patch_sz = patch ? GI_PATCH : 0;
     const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch_sz);
@@ -668,7 +673,7 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
             ticket = ticket_buf.p;
         }
         void (*kern)(const int8_t*, const int8_t*, i64, int, int, const u64*, double*, i64, i64, i64, int, i64, int, int, int,
-                     int, int, int, i64, unsigned*) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
+                     int, int, int, i64, unsigned*, i64, i64, int) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
         if (abl_bits == 1) kern = gram_ws_kernel<true, 1>;
         if (abl_bits == 2) kern = gram_ws_kernel<true, 2>;
         if (abl_bits == 3) kern = gram_ws_kernel<true, 3>;
@@ -678,19 +683,19 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
         GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
         kern<<<dim3((unsigned)grid), dim3(512), WS_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
-            normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket);
+            normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket, ldk, col_lo, even);
     } else if (f->phi_fp4) {
         auto kern = gram_tile_kernel<true>;
         GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES));
         kern<<<dim3((unsigned)blocks), dim3(256), GT_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M_store, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
-            normalize, tiles_m, tiles_n, tri, patch_sz);
+            normalize, tiles_m, tiles_n, tri, patch_sz, ldk, col_lo, even);
     } else {
         auto kern = gram_tile_kernel<false>;
         GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES));
         kern<<<dim3((unsigned)blocks), dim3(256), GT_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M_store, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
-            normalize, tiles_m, tiles_n, tri, patch_sz);
+            normalize, tiles_m, tiles_n, tri, patch_sz, ldk, col_lo, even);
     }
     // entries actually multiplied (real rows and columns; the zero padding of edge tiles is not work)
     *entries_done = tri ? (double)M * (M + 1) / 2 : (double)M * n_cols;
@@ -710,7 +715,7 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
 __global__ __launch_bounds__(256) void gram_f64_kernel(
     const double* __restrict__ A, const double* __restrict__ B, i64 ld, int k_tiles,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
-    int symmetric, i64 n_fit, int normalize, int tiles_n, int accumulate) {
+    int symmetric, i64 n_fit, int normalize, int tiles_n, int accumulate, i64 ldk, i64 col_base) {
     __shared__ double sA[GD_BM * GD_LD];
     __shared__ double sB[GD_BN * GD_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -759,9 +764,9 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
                 const i64 row = (i64)bm * GD_BM + wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
                 if (row < M && col < N) {
                     if (accumulate) {       // K already holds the int8 product (and selfk on the diagonal)
-                        if (!(symmetric && row_base + row == col)) K[row * N + col] += acc[mt][nt][r];
+                        if (!(symmetric && row_base + row == col_base + col)) K[row * ldk + col] += acc[mt][nt][r];
                     } else {
-                        K[row * N + col] = finish_entry(acc[mt][nt][r], row_base + row, col, symmetric != 0,
+                        K[row * ldk + col] = finish_entry(acc[mt][nt][r], row_base + row, col_base + col, symmetric != 0,
                                                         selfk, n_fit, normalize);
                     }
                 }
@@ -772,8 +777,8 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
 // Rare columns (colid == -2): K[g_a][g_b] += c_a * c_b for every ordered pair of graphs that
 // share the label.  One wave per rare label run (df < GK_LOW_DF triples): lanes walk the df*df pairs.
 // Integer-valued float64 atomics: exact and order independent.
-__global__ void gram_low_kernel(const LevelPack P, double* __restrict__ K, i64 n_cols, i64 row_lo, i64 row_hi,
-                                int symmetric, i64 n_fit, int minsum) {
+__global__ void gram_low_kernel(const LevelPack P, double* __restrict__ K, i64 ldk, i64 row_lo, i64 row_hi,
+                                int symmetric, i64 n_fit, int minsum, i64 col_lo, i64 col_hi) {
     i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (w >= P.first[P.n]) return;
@@ -791,10 +796,10 @@ __global__ void gram_low_kernel(const LevelPack P, double* __restrict__ K, i64 n
         const i32 a = t0 + ia, b = t0 + ib;
         const i64 ga = tri_graph[a], gb = tri_graph[b];
         const i64 row = symmetric ? ga : ga - n_fit;       // rectangular job: rows are the target graphs
-        if (row < row_lo || row >= row_hi) continue;
+        if (row < row_lo || row >= row_hi || gb < col_lo || gb >= col_hi) continue;
         if (symmetric ? (ia == ib) : (gb >= n_fit)) continue;
         const i32 ca = tri_pos[a + 1] - tri_pos[a], cb = tri_pos[b + 1] - tri_pos[b];
-        atomicAdd(&K[(row - row_lo) * n_cols + gb], minsum ? (double)(ca < cb ? ca : cb) : (double)ca * (double)cb);
+        atomicAdd(&K[(row - row_lo) * ldk + (gb - col_lo)], minsum ? (double)(ca < cb ? ca : cb) : (double)ca * (double)cb);
     }
 }
 
@@ -813,11 +818,14 @@ __global__ void gram_normalize_kernel(double* __restrict__ K, const u64* __restr
     K[idx] = val;
 }
 
-// rows [row_lo,row_hi) of the job's Gram matrix into K ([row_hi-row_lo] x n_cols, row major)
-int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normalize, double* K) {
-    const i64 n_cols = f->symmetric ? f->n_graphs : f->n_fit;
-    const i64 M = row_hi - row_lo;
-    if (M <= 0) return GK_OK;
+// Block [row_lo,row_hi) x [col_lo,col_hi) of the job's Gram matrix into K (the block's entry (0,0); ldk elements
+// between rows).  Every term is included (dense MFMA product, float64 side operand, rare-column pair updates).
+// A block on the diagonal of a symmetric job (same row and column range) only multiplies the tiles on/above
+// its diagonal and stores both halves.
+static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i64 col_lo, i64 col_hi, int normalize,
+                             double* K, i64 ldk, bool accumulate_stats) {
+    const i64 M = row_hi - row_lo, NC = col_hi - col_lo;
+    if (M <= 0 || NC <= 0) return GK_OK;
     const i64 first_row_graph = (f->symmetric ? 0 : f->n_fit) + row_lo;   // row of Phi
     // the MFMA kernel is bracketed by two events that are only READ in gk_gram_last_stats: the call
     // returns as soon as everything is queued, so the host can already queue the next job
@@ -827,26 +835,27 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
     }
     hipEvent_t e0 = f->ev0, e1 = f->ev1;
     GK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
-    double tiles_done = (double)M * n_cols;
+    double entries_done = (double)M * NC;
     const int normalize_req = normalize;
     const bool has_low = f->n_low_cols > 0, has_wide = f->n_cols_wide > 0;
     if (has_low || has_wide) normalize = 0;   // normalise after the extra terms instead of in the epilogue
     {
         const int8_t* phi = (const int8_t*)f->phi;
         const int8_t* pa = phi + first_row_graph * f->n_cols_pad;
-        // full symmetric job: only tiles on/above the diagonal are computed, each written twice
-        const int tri = (f->symmetric && row_lo == 0 && M == n_cols && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
+        const int8_t* pb = phi + col_lo * f->n_cols_pad;
+        const int tri = (f->symmetric && row_lo == col_lo && row_hi == col_hi && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
         const int patch = getenv("GK_GRAM_NO_PATCH") ? 0 : 1;
-        GK_TRY(launch_tiles(ctx, f, pa, phi, M, n_cols, row_lo, normalize, K, tri, patch, &tiles_done));
+        GK_TRY(launch_tiles(ctx, f, pa, pb, M, NC, row_lo, normalize, K, tri, patch, &entries_done, ldk, col_lo));
     }
     GK_HIP_CHECK(hipGetLastError());
     GK_HIP_CHECK(hipEventRecord(e1, ctx->stream));
     if (has_wide) {   // float64 side operand: K += Phi_w . Phi_w^T (diagonal excluded: it is selfk)
         const double* pw = f->phi_w;
-        const int tiles_m = (int)cdiv(M, GD_BM), tiles_n = (int)cdiv(n_cols, GD_BN);
+        const int tiles_m = (int)cdiv(M, GD_BM), tiles_n = (int)cdiv(NC, GD_BN);
         gram_f64_kernel<<<dim3((unsigned)(tiles_m * (i64)tiles_n)), dim3(256), 0, ctx->stream>>>(
-            pw + first_row_graph * f->n_cols_wide_pad, pw, f->n_cols_wide_pad, (int)(f->n_cols_wide_pad / GD_BK),
-            f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, 0, tiles_n, 1);
+            pw + first_row_graph * f->n_cols_wide_pad, pw + col_lo * f->n_cols_wide_pad, f->n_cols_wide_pad,
+            (int)(f->n_cols_wide_pad / GD_BK), f->selfk, K, M, NC, row_lo, f->symmetric ? 1 : 0, f->n_fit, 0, tiles_n, 1,
+            ldk, col_lo);
     }
     if (has_low) {
         for (int l0 = 0; l0 < f->n_levels; l0 += GK_PACK_LEVELS) {     // one launch per 16 levels
@@ -862,18 +871,96 @@ int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normaliz
             }
             if (P.n == 0) continue;
             gram_low_kernel<<<dim3((unsigned)cdiv(P.first[P.n] * 64, 256)), dim3(256), 0, ctx->stream>>>(
-                P, K, n_cols, row_lo, row_hi, f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0);
+                P, K, ldk, row_lo, row_hi, f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0, col_lo, col_hi);
         }
     }
     if (has_low || has_wide) {
-        if (normalize_req)
-            gram_normalize_kernel<<<dim3((unsigned)cdiv(M * n_cols, 256)), dim3(256), 0, ctx->stream>>>(
-                K, f->selfk, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize_req);
+        if (normalize_req) {
+            GK_ARG(col_lo == 0 && ldk == NC, "gram: normalisation of a column block is applied by gk_gram_normalize_rows");
+            gram_normalize_kernel<<<dim3((unsigned)cdiv(M * NC, 256)), dim3(256), 0, ctx->stream>>>(
+                K, f->selfk, M, NC, row_lo, f->symmetric ? 1 : 0, f->n_fit, normalize_req);
+        }
         GK_HIP_CHECK(hipGetLastError());
     }
     f->last_ms = -1.0;      // not read yet
-    // work actually executed: symmetric jobs only run the tiles on/above the diagonal
-    f->last_flops = 2.0 * tiles_done * (double)f->n_cols;     // columns actually holding a label (padding excluded)
+    // work actually executed: a diagonal block only runs the tiles on/above its diagonal
+    const double fl = 2.0 * entries_done * (double)f->n_cols;     // columns actually holding a label (padding excluded)
+    f->last_flops = accumulate_stats ? f->last_flops + fl : fl;
+    return GK_OK;
+}
+
+// rows [row_lo,row_hi) of the job's Gram matrix into K ([row_hi-row_lo] x n_cols, row major)
+int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normalize, double* K) {
+    const i64 n_cols = f->symmetric ? f->n_graphs : f->n_fit;
+    return gram_block_launch(ctx, f, row_lo, row_hi, 0, n_cols, normalize, K, n_cols, false);
+}
+
+// ---- block-wise entry points of the multi-GPU path (grakel_amd/dist.py): a rank computes some blocks of
+// its row block, ships them to the ranks owning the mirrored blocks, and places what it receives transposed
+extern "C" int gk_gram_block(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_hi, int64_t col_lo, int64_t col_hi,
+                             double* out_dev, int64_t ld) {
+    GK_ARG(ctx && f && out_dev, "gk_gram_block: null argument");
+    const i64 n_rows = f->symmetric ? f->n_graphs : f->n_graphs - f->n_fit;
+    const i64 n_cols = f->symmetric ? f->n_graphs : f->n_fit;
+    GK_ARG(row_lo >= 0 && row_hi <= n_rows && row_lo <= row_hi && col_lo >= 0 && col_hi <= n_cols && col_lo <= col_hi,
+           "gk_gram_block: bad block");
+    GK_ARG(ld >= col_hi - col_lo, "gk_gram_block: leading dimension smaller than the block");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    ProfScope prof(ctx, "gram");
+    return gram_block_launch(ctx, f, row_lo, row_hi, col_lo, col_hi, 0, out_dev, ld, true);
+}
+
+extern "C" int gk_gram_reset_stats(gk_feat* f) {
+    GK_ARG(f, "gk_gram_reset_stats: null");
+    f->last_flops = 0.0;
+    return GK_OK;
+}
+
+// dst[i][j] = src[i][j] (transpose == 0, rows x cols) or dst[j][i] = src[i][j] (transpose != 0): 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void block_copy_kernel(const double* __restrict__ src, i64 rows, i64 cols, i64 ld_src,
+                                                         double* __restrict__ dst, i64 ld_dst, int transpose) {
+    __shared__ double t[32][33];
+    const i64 tiles_c = (cols + 31) / 32;
+    const i64 ti = blockIdx.x / tiles_c, tj = blockIdx.x % tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const i64 i = ti * 32 + r, j = tj * 32 + tx;
+        if (i < rows && j < cols) t[r][tx] = src[i * ld_src + j];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        if (!transpose) {
+            const i64 i = ti * 32 + r, j = tj * 32 + tx;
+            if (i < rows && j < cols) dst[i * ld_dst + j] = t[r][tx];
+        } else {
+            const i64 j = tj * 32 + r, i = ti * 32 + tx;       // dst row j, dst column i
+            if (i < rows && j < cols) dst[j * ld_dst + i] = t[tx][r];
+        }
+    }
+}
+
+extern "C" int gk_block_copy(gk_ctx* ctx, const double* src_dev, int64_t rows, int64_t cols, int64_t ld_src,
+                             double* dst_dev, int64_t ld_dst, int transpose) {
+    GK_ARG(ctx && src_dev && dst_dev && rows >= 0 && cols >= 0, "gk_block_copy: bad argument");
+    if (rows == 0 || cols == 0) return GK_OK;
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    const i64 blocks = ((rows + 31) / 32) * ((cols + 31) / 32);
+    GK_ARG(blocks < (1ll << 31), "gk_block_copy: block too large");
+    block_copy_kernel<<<dim3((unsigned)blocks), 256, 0, ctx->stream>>>(src_dev, rows, cols, ld_src, dst_dev, ld_dst, transpose);
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
+}
+
+// K[row_hi-row_lo x n_cols] (device, leading dimension n_cols) /= sqrt(selfk_row selfk_col); mode as gk_gram
+extern "C" int gk_gram_normalize_rows(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_hi, double* K_dev, int mode) {
+    GK_ARG(ctx && f && K_dev && (mode == 1 || mode == 2), "gk_gram_normalize_rows: bad argument");
+    const i64 n_cols = f->symmetric ? f->n_graphs : f->n_fit;
+    const i64 M = row_hi - row_lo;
+    if (M <= 0) return GK_OK;
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    gram_normalize_kernel<<<dim3((unsigned)cdiv(M * n_cols, 256)), dim3(256), 0, ctx->stream>>>(
+        K_dev, f->selfk, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit, mode);
+    GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }
 

@@ -12,11 +12,16 @@ remap to the ids of the sorted union, exactly the reference's ``sorted(distinct_
 ``all_gather`` of the packed shards over xGMI (config 3: ~25 MB in total, i.e. ~3 MB per
 rank; a direct all-gather at ~153 GB/s per link takes tens of microseconds), after which
 
-    relabel + label-count features : replicated on every rank (HBM-bound, ~1 ms)
-    Gram                           : rank r computes rows [lo_r, hi_r) x all columns
+    relabel + label-count features : replicated on every rank (latency-bound, well under 1 ms)
+    Gram                           : rank r OWNS rows [lo_r, hi_r) x all columns, but only multiplies half of
+                                     them: K is symmetric, so of every pair of blocks (K[B_p, B_q], K[B_q, B_p])
+                                     one rank computes one block and ships it to the owner of the mirrored block,
+                                     which stores it transposed (``symmetric_plan``).  R ranks together do the MACs
+                                     one GPU does alone (tiles on/above the diagonal), each 1/R of them.
 
-so the N x N matrix never needs to exist on one device; each rank returns its row block.
-No other collective touches the data path.  ``torch.distributed`` is plumbing only: backend
+so the N x N matrix never needs to exist on one device; each rank returns its row block.  The block
+exchange is point-to-point (``batch_isend_irecv``: xGMI links are point-to-point, every rank talks to
+about half of its peers with one message each); no other collective touches the data path.  ``torch.distributed`` is plumbing only: backend
 "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests of the shard/gather/rebuild logic.
 """
 import numpy as np
@@ -31,6 +36,41 @@ def shard_bounds(n_graphs, world_size):
     for r in range(world_size):
         b.append(b[-1] + base + (1 if r < rem else 0))
     return b
+
+
+def symmetric_plan(bounds, rank):
+    """Which blocks of its row block rank ``rank`` multiplies itself ("symmetry can halve work").
+
+    ``bounds``: row-block bounds of the R ranks.  Returns (compute, recv):
+      compute = [(row_lo, row_hi, col_lo, col_hi, peer)]  blocks rank ``rank`` computes; ``peer`` is the rank that
+                owns the mirrored block and receives a copy (-1: the diagonal block, mirrored in place);
+      recv    = [(peer, row_lo, row_hi, col_lo, col_hi)]  blocks computed by ``peer`` -- rows inside ITS row block,
+                columns inside this rank's -- that arrive here and are stored transposed.
+    Rank r takes the diagonal block, the full blocks towards the next ceil(R/2)-1 ranks (cyclically) and, for
+    even R, half of the block towards the rank R/2 away (the lower rank the first half of the columns, the
+    higher rank the second half of its rows): every unordered pair of blocks is multiplied exactly once and
+    every rank multiplies (N/R)^2 * R/2 entries -- 1/R of the upper triangle."""
+    R = len(bounds) - 1
+
+    def jobs(r):
+        lo, hi = bounds[r], bounds[r + 1]
+        out = [(lo, hi, lo, hi, -1)]
+        for d in range(1, (R + 1) // 2):
+            q = (r + d) % R
+            out.append((lo, hi, bounds[q], bounds[q + 1], q))
+        if R % 2 == 0 and R > 1:
+            q = (r + R // 2) % R
+            a, b = min(r, q), max(r, q)
+            half = bounds[b] + (bounds[b + 1] - bounds[b]) // 2
+            if r == a:        # all rows of a  x  first half of b's columns
+                out.append((lo, hi, bounds[b], half, b))
+            else:             # second half of b's rows  x  all columns of a
+                out.append((half, hi, bounds[a], bounds[a + 1], a))
+        return [j for j in out if j[1] > j[0] and j[3] > j[2]]
+
+    compute = jobs(rank)
+    recv = [(p, j[0], j[1], j[2], j[3]) for p in range(R) if p != rank for j in jobs(p) if j[4] == rank]
+    return compute, recv
 
 
 def reconcile_label_ids(local, label_map, group=None):
@@ -159,10 +199,57 @@ def tensors_to_batch(graph_ptr, row_ptr, col_idx, labels, n_labels):
 class ShardedWL(object):
     """WL-subtree Gram with graphs and Gram rows sharded over the ranks of ``group``."""
 
-    def __init__(self, engine, n_iter=5, normalize=False, group=None):
+    def __init__(self, engine, n_iter=5, normalize=False, group=None, symmetric=True):
+        import torch.distributed as dist
         self.engine, self.n_iter, self.normalize, self.group = engine, n_iter, normalize, group
+        self.symmetric = symmetric          # False: every rank multiplies its full row block (no exchange)
+        self.ws = dist.get_world_size(group)
         self._exchange, self._local = None, None
         self._stream = None
+
+    def _symmetric_rows(self, eng, feat, bounds, rank, N, dev):
+        """This rank's row block [n_local x N] (a torch tensor: device memory for the point-to-point exchange):
+        multiply the blocks of ``symmetric_plan``, ship the off-diagonal ones to the owners of the mirrored
+        blocks, store the received ones transposed."""
+        import torch
+        import torch.distributed as dist
+        lo, hi = bounds[rank], bounds[rank + 1]
+        K = torch.empty((hi - lo, N), dtype=torch.float64, device=dev)
+        base = K.data_ptr()
+        compute, recv = symmetric_plan(bounds, rank)
+        eng.gram_reset_stats(feat)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # block products | exchange + placement
+        ev[0].record()
+        # gloo (the CPU-side test backend) has no device-to-device send / recv: stage through the host there
+        on_host = dist.get_backend(self.group) == "gloo"
+        ops, keepalive = [], []
+        for (r0, r1, c0, c1, peer) in compute:
+            eng.gram_block(feat, (r0, r1), (c0, c1), base + ((r0 - lo) * N + c0) * 8, N)
+            if peer >= 0:        # contiguous copy of the block for the wire
+                buf = torch.empty((r1 - r0, c1 - c0), dtype=torch.float64, device=dev)
+                eng.block_copy(base + ((r0 - lo) * N + c0) * 8, r1 - r0, c1 - c0, N, buf.data_ptr(), c1 - c0)
+                if on_host:
+                    torch.cuda.current_stream(dev).synchronize()
+                    buf = buf.cpu()
+                ops.append(dist.P2POp(dist.isend, buf, peer, group=self.group))
+                keepalive.append(buf)
+        ev[1].record()
+        landed = []
+        for (peer, r0, r1, c0, c1) in recv:          # rows [r0,r1) of the peer, columns [c0,c1) of this rank
+            buf = torch.empty((r1 - r0, c1 - c0), dtype=torch.float64, device="cpu" if on_host else dev)
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group=self.group))
+            landed.append((buf, r0, r1, c0, c1))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for (buf, r0, r1, c0, c1) in landed:         # K[c0:c1, r0:r1] = buf^T
+            if on_host:
+                buf = buf.to(dev)
+                keepalive.append(buf)
+            eng.block_copy(buf.data_ptr(), r1 - r0, c1 - c0, c1 - c0, base + ((c0 - lo) * N + r0) * 8, N, transpose=True)
+        ev[2].record()
+        self.last_events = ev        # elapsed_time(ev[0], ev[1]) = block products + packing, (ev[1], ev[2]) = exchange + placement
+        return K
 
     def _shared_stream(self, dev):
         """One torch side stream carries both the collective and the library's kernels, so the
@@ -203,9 +290,18 @@ class ShardedWL(object):
             counts = eng.wl_relabel(db, self.n_iter)
             feat = eng.features(db, self.n_iter + 1)
             rows = (bounds[rank], bounds[rank + 1])
-            K = eng.gram(feat, 2 if self.normalize else 0, rows=rows, to_host=to_host)
-            info = dict(label_counts=counts, n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, rows=rows,
-                        n_graphs=db.n_graphs, gram=eng.gram_stats(feat), dtype=feat.dtype)
+            N = db.n_graphs
+            if self.symmetric and self.ws > 1:
+                Kdev = self._symmetric_rows(eng, feat, bounds, rank, N, dev)
+                if self.normalize:
+                    eng.gram_normalize_rows(feat, rows, Kdev.data_ptr(), 2)
+                K = Kdev.cpu().numpy() if to_host else None
+                info = dict(K_dev=Kdev)
+            else:
+                K = eng.gram(feat, 2 if self.normalize else 0, rows=rows, to_host=to_host)
+                info = dict()
+            info.update(label_counts=counts, n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, rows=rows,
+                        n_graphs=N, gram=eng.gram_stats(feat), dtype=feat.dtype)
             if keep:
                 info["feat"], info["batch"] = feat, db
             else:

@@ -236,6 +236,21 @@ class Engine(object):
         check(self.lib.gk_gram_rows(self.handle, feat.handle, lo, hi, int(normalize), _ptr(out)))
         return out
 
+    # -- block-wise Gram (multi-GPU path): caller-owned device memory, addresses as ints -------------------
+    def gram_block(self, feat, rows, cols, out_ptr, ld):
+        check(self.lib.gk_gram_block(self.handle, feat.handle, int(rows[0]), int(rows[1]), int(cols[0]), int(cols[1]),
+                                     c_void_p(int(out_ptr)), int(ld)))
+
+    def gram_reset_stats(self, feat):
+        check(self.lib.gk_gram_reset_stats(feat.handle))
+
+    def block_copy(self, src_ptr, rows, cols, ld_src, dst_ptr, ld_dst, transpose=False):
+        check(self.lib.gk_block_copy(self.handle, c_void_p(int(src_ptr)), int(rows), int(cols), int(ld_src),
+                                     c_void_p(int(dst_ptr)), int(ld_dst), 1 if transpose else 0))
+
+    def gram_normalize_rows(self, feat, rows, k_ptr, mode):
+        check(self.lib.gk_gram_normalize_rows(self.handle, feat.handle, int(rows[0]), int(rows[1]), c_void_p(int(k_ptr)), int(mode)))
+
     def gram_checksum(self, feat):
         """(sum, trace, max |K - K^T|) of the matrix the last ``gram`` call left on the device."""
         a, b, c = c_double(), c_double(), c_double()

@@ -172,6 +172,19 @@ int gk_gram_dev_ptr(gk_feat* f, void** out_dev_ptr, int64_t* n_rows, int64_t* n_
  * out_host is [(row_hi-row_lo) x n_cols]. */
 int gk_gram_rows(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_hi, int normalize,
                  double* out_host);
+/* Block-wise form for the multi-GPU path (grakel_amd/dist.py; SURVEY.md 8e "symmetry can halve work"): the block
+ * [row_lo,row_hi) x [col_lo,col_hi) of the job's matrix, every term included, un-normalised, into CALLER-owned
+ * device memory (out_dev = the block's entry (0,0), ld elements between rows).  A diagonal block of a symmetric
+ * job only multiplies the tiles on/above its diagonal.  gk_gram_last_stats then reports the flops of all blocks
+ * since gk_gram_reset_stats.  gk_block_copy moves a block between device buffers, optionally transposed (the
+ * mirrored half a rank receives from its peer); gk_gram_normalize_rows applies gk_gram's normalisation to a
+ * finished row block. */
+int gk_gram_block(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_hi, int64_t col_lo, int64_t col_hi,
+                  double* out_dev, int64_t ld);
+int gk_gram_reset_stats(gk_feat* f);
+int gk_block_copy(gk_ctx* ctx, const double* src_dev, int64_t rows, int64_t cols, int64_t ld_src,
+                  double* dst_dev, int64_t ld_dst, int transpose);
+int gk_gram_normalize_rows(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_hi, double* K_dev, int mode);
 /* Checksums of the matrix the last gk_gram* call left on the device, computed in place: sum of all entries,
  * trace and max |K_ij - K_ji| (the last two 0 for a non-square output).  What bench.py asserts on the
  * timed matrix and what the 50 000-graph parity test (a 20 GB matrix) checks without a host copy; the

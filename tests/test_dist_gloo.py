@@ -92,6 +92,43 @@ def test_independently_ingested_shards_get_global_label_ids_world2(tmp_path):
         assert np.load(os.path.join(str(tmp_path), "own_%d.npy" % r)).tolist() == [1]
 
 
+def test_symmetric_plan_covers_every_entry_exactly_once():
+    """Blocks a rank multiplies + mirrored blocks it receives tile its row block exactly; every unordered pair of
+    row blocks is multiplied once; the multiplied entries are balanced (1/R of the upper triangle each)."""
+    from grakel_amd.dist import shard_bounds, symmetric_plan
+    for R in range(1, 10):
+        for N in (R, 37, 100, 257):
+            if N < R:
+                continue
+            b = shard_bounds(N, R)
+            owner_count = np.zeros((N, N), np.int32)          # how often entry (i, j) is produced for row i's owner
+            multiplied = np.zeros((N, N), np.int32)
+            work = []
+            for r in range(R):
+                compute, recv = symmetric_plan(b, r)
+                w = 0
+                for (r0, r1, c0, c1, peer) in compute:
+                    assert b[r] <= r0 <= r1 <= b[r + 1]      # rows inside the rank's own block
+                    owner_count[r0:r1, c0:c1] += 1
+                    if peer < 0:                              # diagonal block: tiles on/above the diagonal only
+                        multiplied[r0:r1, c0:c1] += np.triu(np.ones((r1 - r0, c1 - c0), np.int32))
+                    else:
+                        multiplied[r0:r1, c0:c1] += 1
+                    w += (r1 - r0) * (r1 - r0 + 1) // 2 if peer < 0 else (r1 - r0) * (c1 - c0)
+                    if peer >= 0:
+                        assert (r, r0, r1, c0, c1) in symmetric_plan(b, peer)[1]   # the peer expects exactly this block
+                for (peer, r0, r1, c0, c1) in recv:           # stored transposed: rows c0:c1 (mine), columns r0:r1
+                    assert b[r] <= c0 <= c1 <= b[r + 1]
+                    owner_count[c0:c1, r0:r1] += 1
+                work.append(w)
+            assert np.all(owner_count == 1)
+            sym = multiplied + multiplied.T
+            np.fill_diagonal(sym, np.diagonal(multiplied))
+            assert np.all(sym == 1)                           # each unordered pair of graphs multiplied once
+            if N % (2 * R) == 0:
+                assert max(work) - min(work) <= N // R        # balanced up to a block edge
+
+
 def test_shard_bounds():
     from grakel_amd.dist import shard_bounds
     assert shard_bounds(10, 4) == [0, 3, 6, 8, 10]

@@ -486,7 +486,16 @@ def _two_rank_worker(rank, world, port, out_dir):
             K, info = sw.step(local, to_host=True)
         assert info["rows"] == (b[rank], b[rank + 1]) and info["n_graphs"] == 301
         np.save(os.path.join(out_dir, "K_%d.npy" % rank), K)
-        sw.close()
+        np.save(os.path.join(out_dir, "flops_%d.npy" % rank), np.array([info["gram"][0], info["n_cols"]]))
+        # the same step with every rank multiplying its full row block (no exchange) gives the same rows
+        sw.symmetric = False
+        K_full, info_full = sw.step(local, to_host=True)
+        assert np.array_equal(K_full, K) and info_full["gram"][0] > 1.8 * info["gram"][0]
+        swn = ShardedWL(get_engine(0), n_iter=3, normalize=True)
+        swn._stream, sw._stream = sw._stream, None
+        Kn, _ = swn.step(local, to_host=True)
+        np.save(os.path.join(out_dir, "Kn_%d.npy" % rank), Kn)
+        swn.close()
     finally:
         dist.destroy_process_group()
 
@@ -502,6 +511,15 @@ def test_sharded_path_two_processes_on_one_gpu(gk, tmp_path):
     blocks = [np.load(os.path.join(str(tmp_path), "K_%d.npy" % r)) for r in range(2)]
     assert blocks[0].shape == (151, 301) and blocks[1].shape == (150, 301)
     assert np.array_equal(np.vstack(blocks), K)
+    # symmetric sharding: the two ranks TOGETHER multiply what one GPU multiplies alone (entries on/above the
+    # diagonal x dense columns), each about half of it
+    fl = [np.load(os.path.join(str(tmp_path), "flops_%d.npy" % r)) for r in range(2)]
+    one_gpu = 2.0 * (301 * 302 / 2) * fl[0][1]
+    assert fl[0][0] + fl[1][0] == one_gpu
+    assert abs(fl[0][0] - fl[1][0]) < 0.02 * one_gpu
+    Kn = np.vstack([np.load(os.path.join(str(tmp_path), "Kn_%d.npy" % r)) for r in range(2)])
+    d = np.sqrt(np.diagonal(K))
+    assert np.allclose(Kn, K / np.outer(d, d), rtol=REL_TOL, atol=0)
 
 
 def test_bench_two_rank_code_path_on_one_gpu(gk):
@@ -965,10 +983,11 @@ def _config5_rank_worker(rank, world, port, outdir):
     b = shard_bounds(full.n_graphs, world)
     eng = get_engine(0)
     sw = ShardedWL(eng, n_iter=CONFIG5["h"])
-    _, info = sw.step(full.slice_graphs(b[rank], b[rank + 1]), keep=True)
-    s, _, _ = eng.gram_checksum(info["feat"])             # this rank's [N/2 x N] row block, in HBM
-    rows = eng.gram(info["feat"], 0, rows=(b[rank] + 7, b[rank] + 8))
-    np.save(os.path.join(outdir, "c5_%d.npy" % rank), np.concatenate([[s], rows[0]]))
+    _, info = sw.step(full.slice_graphs(b[rank], b[rank + 1]))
+    Kd = info["K_dev"]                                     # this rank's [N/2 x N] row block, a 10 GB torch tensor in HBM
+    s = float(Kd.sum().item())
+    np.save(os.path.join(outdir, "c5_%d.npy" % rank), np.concatenate([[s, info["gram"][0], info["n_cols"]], Kd[7].cpu().numpy()]))
+    del Kd, info
     sw.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -995,7 +1014,10 @@ def test_config5_row_sharded_over_two_processes(gk, tmp_path):
     got = [np.load(os.path.join(str(tmp_path), "c5_%d.npy" % r)) for r in range(2)]
     assert got[0][0] + got[1][0] == total
     for r in range(2):
-        assert np.array_equal(got[r][1:], want[r])
+        assert np.array_equal(got[r][3:], want[r])
+    # each rank multiplied half of what one GPU multiplies (entries on/above the diagonal x dense columns)
+    one_gpu = 2.0 * (c["N"] * (c["N"] + 1) / 2) * got[0][2]
+    assert got[0][1] + got[1][1] == one_gpu and abs(got[0][1] - got[1][1]) < 0.01 * one_gpu
 
 
 # ------------------------------------------------------------------------------------------
