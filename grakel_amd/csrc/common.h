@@ -166,6 +166,9 @@ struct gk_batch {
     // per level: perm[level][0 .. n_sorted) holds every node that can share its label with another
     // node (grouped by label); the nodes behind it carry labels of their own.  Empty = n_nodes.
     std::vector<i64> n_sorted;
+    // per level: 1 when the ids follow the active-set layout [frozen singletons | carried classes | active classes]:
+    // a node can share its label iff its id >= n_nodes - n_sorted[level] (features.hip, graph-major path)
+    std::vector<char> active_layout;
     // scratch kept between levels
     i32* nbr_sorted = nullptr;         // [n_edges] sorted neighbour labels of the level being built
     bool is_pair_batch = false;        // ShortestPath items: no CSR, level 0 only
@@ -231,6 +234,12 @@ struct gk_feat {
     // narrow) float64 side operand whose product is accumulated onto K after the int8 GEMM
     i64 n_cols_wide = 0, n_cols_wide_pad = 0;
     double* phi_w = nullptr;    // [n_rows_pad][n_cols_wide_pad]
+    // graph-major builder (features_gm.hip): the rare labels as lists instead of label-major triples
+    bool gm = false;
+    i32* gm_low_q = nullptr;    // [n_low_cols] label index of each rare label
+    u32* gm_roff = nullptr;     // per label index: first entry of its list
+    u32* gm_df = nullptr;       // per label index: entries (graphs) of its list
+    i32* gm_low_graph = nullptr, *gm_low_cnt = nullptr;    // the lists: graph, count
     double* K = nullptr;        // last Gram output (device)
     i64 K_rows = 0, K_cols = 0;
     double last_flops = 0, last_ms = 0;

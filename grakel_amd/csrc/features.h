@@ -1,0 +1,28 @@
+// Definitions shared by the two feature builders (features.hip: label-major, features_gm.hip: graph-major).
+#pragma once
+#include "common.h"
+
+// label-major builder: meta layout (u32): per level l: [3l+0]=T (triples) [3l+1]=R (label runs) [3l+2]=dense columns
+// with counts that fit the primary region up to and including level l; globals at G = 3*n_levels: [G+0]=max count,
+// [G+1]=rare columns, [G+2]=float64 columns, [G+3]=primary dense columns, [G+4+l]=rare columns up to
+// and including level l, [4*n_levels+4]=int8 dense columns, then 64 partial maxima of the counts
+#define META_T(l) (3 * (l) + 0)
+#define META_R(l) (3 * (l) + 1)
+#define META_C(l) (3 * (l) + 2)
+
+#define FEAT_MAX_LEVELS 48
+#define COL_BYTE_BASE (1 << 30)   // colid >= this: column (colid - base) of the int8 region
+
+// graph-major builder: meta layout
+#define GM_META_PRIM 0
+#define GM_META_INT8 1
+#define GM_META_F64 2
+#define GM_META_RARE 3
+#define GM_META_RARE_ENTRIES 4
+#define GM_META_MAXC 8            // 64 partial maxima
+#define GM_META_NNZ 72            // 64 partial sums
+#define GM_META_WORDS 136
+#define GM_MAX_NODES 1024         // largest graph a wave stages in LDS
+#define GM_ROW_LDS_MAX 65536      // widest operand row (bytes) assembled in LDS
+
+int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int prim_max, int wide_above);

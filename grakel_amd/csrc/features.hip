@@ -27,20 +27,10 @@
 // exactly, on the int8 MFMA path; selfk[g] = sum of counts (= nodes x levels).
 #include "common.h"
 #include "scan_fn.h"
+#include "features.h"
 #include <stdlib.h>
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
-
-// meta layout (u32): per level l: [3l+0]=T (triples) [3l+1]=R (label runs) [3l+2]=dense columns
-// with counts <= 15 up to and including level l; globals at G = 3*n_levels: [G+0]=max count,
-// [G+1]=rare columns, [G+2]=float64 columns, [G+3]=4-bit dense columns, [G+4+l]=rare columns up to
-// and including level l, [4*n_levels+4]=int8 dense columns
-#define META_T(l) (3 * (l) + 0)
-#define META_R(l) (3 * (l) + 1)
-#define META_C(l) (3 * (l) + 2)
-
-#define FEAT_MAX_LEVELS 48
-#define COL_BYTE_BASE (1 << 30)   // colid >= this: column (colid - base) of the int8 region
 
 // the levels of one job, by value: level slot j covers items [off[j], off[j] + n[j])
 struct FeatLevels {
@@ -495,7 +485,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     auto fail = [&](int r) { gk_features_destroy(f); return r; };
     int r;
     void* q = nullptr;
-    const size_t n_meta = 4 * (size_t)n_levels + 5 + 64;      // ... + 64 partial maxima of the counts
+    const size_t n_meta = std::max<size_t>(4 * (size_t)n_levels + 5 + 64, GM_META_WORDS);      // ... + 64 partial maxima of the counts
     if ((r = gk_dev_alloc(ctx, &q, n_meta * 4))) return fail(r);
     f->meta = (u32*)q;
     if ((r = gk_dev_alloc(ctx, &q, (size_t)N * 8))) return fail(r);
@@ -528,6 +518,18 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     f->phi_fp4 = f->dtype == 0 && bound < 16777216.0 && !getenv("GK_GRAM_NO_FP4");
     const int wide_above = kind == GK_FEAT_MINSUM ? 0x7fffffff : (f->dtype == 0 ? 127 : -1);
     const int prim_max = f->dtype != 0 ? -1 : (f->phi_fp4 ? 4 : 127);
+    // ---- graph batches with small graphs: the graph-major builder (features_gm.hip); it declines (row wider
+    // than its LDS image) with GK_ERR_UNSUPPORTED and this builder takes over
+    if (!b->is_pair_batch && V > 0 && b->max_graph_nodes <= GM_MAX_NODES && !getenv("GK_FEAT_NO_GM")) {
+        r = gk_features_build_gm(ctx, b, f, n_levels, prim_max, wide_above);
+        if (r == GK_OK) { *out = f; return GK_OK; }
+        if (r != GK_ERR_UNSUPPORTED) return fail(r);
+        for (void* p : f->arena)
+            if (p) gk_dev_free(ctx, p);
+        f->arena.clear();
+        f->gm = false;
+        if (gk_zero_async(ctx, f->meta, n_meta * 4) != GK_OK) return fail(GK_ERR_HIP);
+    }
     // ---- the level slots: a level only lists the nodes that can share a label (wl.hip: active-set
     // levels), a level that lists nothing adds one per node to the diagonal and nothing else
     FeatLevels P;

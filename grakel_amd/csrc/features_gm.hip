@@ -1,0 +1,527 @@
+// Label-count features, GRAPH-MAJOR form (the default for graph batches): no label-grouped node order is
+// needed, so the relabel sort's by-product (perm[]) is not read at all and the per-item passes of
+// features.hip (flags, triple scan, counts: ~16 bytes x items x 4 passes) disappear.
+//
+// A graph is small (n <= 111 in every config), so one WAVE owns a graph:
+//   gm_pairs_kernel  per level, the wave stages the graph's labels in LDS; node v counts the nodes of
+//                    its graph carrying its label (c) and learns whether it is the first of them.  The first
+//                    one is the graph's (label, graph, c) entry: cnt[level][v] = c (0 for everybody else),
+//                    df[label] += 1, cmax[label] = max(c), exact self similarity
+//                    selfk[g] = n_g x levels + sum over entries of (c^2 - c)  -- no atomics, no triples.
+//                    Only nodes whose class has at least two members take part (ids of an active-set level
+//                    say so themselves, wl.hip; full levels pass a flag array).
+//   GmColumns scan   over the labels that can be shared (all levels concatenated): df / cmax -> column
+//                    class exactly as features.hip (dense primary / int8 / float64 / rare / dead), dense
+//                    column ids and the offsets of the rare labels' (graph, count) lists in ONE prefix sum.
+//   gm_rows_kernel   the wave assembles its graph's whole operand row in LDS (fp4 codes OR-ed into place,
+//                    int8 counts stored) and writes it once, coalesced: no zeroed staging image, no pack
+//                    pass; rare entries go to their label's list (cursor atomics, order irrelevant).
+// Results are identical to features.hip's (same classes, same K); column ORDER differs, which no consumer
+// can observe.  Falls back to features.hip for pair batches (ShortestPath) and graphs above GM_MAX_NODES.
+#include "common.h"
+#include "scan_fn.h"
+#include "features.h"
+#include <stdlib.h>
+
+static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
+
+struct GmLevels {
+    const i32* lab[FEAT_MAX_LEVELS];      // level labels
+    const unsigned char* flag[FEAT_MAX_LEVELS];   // 1 = the node's class has >= 2 members (null: decided by id_base alone)
+    i32 id_base[FEAT_MAX_LEVELS];         // ids below it are singletons for good (active-set layout), else 0
+    i64 off[FEAT_MAX_LEVELS + 1];         // start of the level's labels [id_base, count) in the concatenated label space
+    int level[FEAT_MAX_LEVELS];
+    int L;
+    __device__ __forceinline__ int slot_of(i64 q) const {
+        int j = 0;
+        while (q >= off[j + 1]) ++j;
+        return j;
+    }
+};
+
+// per shareable label q: df (graphs containing it), cmax (largest count), side flags (rectangular jobs)
+struct GmLabelArrays {
+    u32* df; u32* cmax; unsigned char* side;      // side: bit 0 = occurs in a fitted graph, bit 1 = in a target graph
+    i32* colid; u32* roff; u32* cursor; i32* low_q;
+};
+
+#define GM_WAVES 16
+
+// One wave per graph (persistent workgroups: a wave walks graphs w, w + stride, ...), all levels.  Per level the
+// wave counts its graph's labels in a small open-addressing table in LDS (T slots, T >= 2 x the largest
+// graph): a node inserts its label (compare-and-swap on the key, add one to the slot's counter); the lane
+// whose insertion claimed the slot owns the (label, graph) entry.  O(n) LDS atomics per level.
+//
+// df / count class per label: a million (label, graph) entries are a million RANDOM L2 transactions when they
+// go straight to global counters (measured 230 us, thousands of them piling onto the few hot labels).  Levels
+// with a small label space (level 0, level 1, the active-set levels: P.priv_off[j] >= 0) therefore count in
+// a workgroup-private LDS histogram -- 16 bits per label: graphs seen by this workgroup (12 bits), fitted /
+// target side (2 bits), "a count exceeds the primary / the int8 range" (2 bits) -- written out once per
+// workgroup and summed by gm_reduce_kernel.  The other levels (few entries: most of their nodes own their
+// label) keep the guarded global atomics.
+#define GM_PRIV_COUNT_MASK 0x0fffu
+#define GM_PRIV_SIDE_SHIFT 12
+#define GM_PRIV_BIG1 0x4000u          // some count > prim_max
+#define GM_PRIV_BIG2 0x8000u          // some count > wide_above
+
+struct GmPriv {
+    i32 off[FEAT_MAX_LEVELS];         // first private bin of the slot, -1: global atomics
+    int bins;                         // private bins in total (even)
+};
+
+__global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+                                                                const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
+                                                                u32* __restrict__ cnt, u64* __restrict__ selfk,
+                                                                u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
+                                                                int rectangular, u32 df_cap, int T, int prim_max,
+                                                                int wide_above, u32* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private histogram | per wave: keys[T] | count + owner << 16 [T]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32* priv = (u32*)gm_lds;                                          // two 16-bit bins per word
+    const int priv_words = R.bins / 2;
+    for (int t = threadIdx.x; t < priv_words; t += blockDim.x) priv[t] = 0;
+    __syncthreads();
+    i32* keys = gm_lds + priv_words + (size_t)w * 2 * T;
+    u32* co = (u32*)(keys + T);
+    const u32 tmask = (u32)T - 1u;
+    u32 maxc = 0, entries = 0;
+    for (i64 g = (i64)blockIdx.x * GM_WAVES + w; g < n_graphs; g += (i64)gridDim.x * GM_WAVES) {
+        const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
+        const int n = v1 - v0;
+        u64 extra = 0;
+        const u32 side_bit = g < n_fit ? 1u : 2u;
+        for (int j = 0; j < P.L; ++j) {
+            const i32* __restrict__ lab = P.lab[j];
+            const unsigned char* __restrict__ fl = P.flag[j];
+            const i32 base = P.id_base[j];
+            for (int t = lane; t < T; t += 64) keys[t] = -1, co[t] = 0;
+            __builtin_amdgcn_wave_barrier();
+            // insert: only nodes whose class has at least two members take part
+            for (int i = lane; i < n; i += 64) {
+                const i32 x = lab[v0 + i];
+                if (x < base || (fl && !fl[v0 + i])) continue;
+                u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+                for (;;) {
+                    const i32 old = atomicCAS(&keys[h], -1, x);
+                    if (old == -1) { atomicAdd(&co[h], ((u32)i << 16) | 1u); break; }     // claimed the slot: owner of the entry
+                    if (old == x) { atomicAdd(&co[h], 1u); break; }
+                    h = (h + 1u) & tmask;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the owner of a slot emits the entry
+            const i32 poff = R.off[j];
+            for (int i = lane; i < n; i += 64) {
+                const i32 x = lab[v0 + i];
+                u32 c = 0;
+                if (x >= base && (!fl || fl[v0 + i])) {
+                    u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+                    while (keys[h] != x) h = (h + 1u) & tmask;
+                    const u32 e = co[h];
+                    if ((e >> 16) == (u32)i) c = e & 0xffffu;
+                }
+                cnt[(i64)j * V + v0 + i] = c;
+                if (!c) continue;
+                if (poff >= 0) {
+                    const u32 bin = (u32)poff + (u32)(x - base);
+                    const int sh = 16 * (bin & 1u);
+                    u32 add = 1u;
+                    if (rectangular) add |= side_bit << GM_PRIV_SIDE_SHIFT;
+                    if ((int)c > prim_max) add |= GM_PRIV_BIG1;
+                    if ((int)c > wide_above) add |= GM_PRIV_BIG2;
+                    const u32 cur = (priv[bin >> 1] >> sh) & 0xffffu;
+                    const u32 flags = add & ~cur & 0xf000u;                 // flag bits not set yet
+                    if (flags) atomicOr(&priv[bin >> 1], flags << sh);
+                    atomicAdd(&priv[bin >> 1], 1u << sh);
+                } else {
+                    const i64 q = P.off[j] + (x - base);
+                    // guarded global atomics: look first (L2-coherent load), add only while it still counts
+                    if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
+                    if (c >= 2u && __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) atomicMax(&A.cmax[q], c);
+                    if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
+                }
+                if (!kind) extra += (u64)c * c - c;
+                maxc = c > maxc ? c : maxc;
+                ++entries;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        for (int off = 32; off > 0; off >>= 1) extra += __shfl_down(extra, off, 64);
+        if (lane == 0) selfk[g] = (u64)n * (u64)n_levels + extra;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        entries += __shfl_down(entries, off, 64);
+        const u32 o = __shfl_down(maxc, off, 64);
+        maxc = o > maxc ? o : maxc;
+    }
+    if (lane == 0) {
+        if (maxc) atomicMax(&meta[GM_META_MAXC + (blockIdx.x & 63)], maxc);
+        if (entries) atomicAdd(&meta[GM_META_NNZ + (blockIdx.x & 63)], entries);
+    }
+    __syncthreads();
+    u32* mine = part + (size_t)blockIdx.x * priv_words;
+    for (int t = threadIdx.x; t < priv_words; t += blockDim.x) mine[t] = priv[t];
+}
+
+// sum the workgroups' private histograms: df (saturating at what the column scan distinguishes), the count class as
+// a representative cmax (1, prim_max + 1 or wide_above + 1), the side bits
+__global__ __launch_bounds__(1024) void gm_reduce_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+                                                         const u32* __restrict__ part, int n_wg, int prim_max, int wide_above,
+                                                         int rectangular) {
+    // block = 64 consecutive words x 16 row groups (wave w sums the workgroups w, w + 16, ...), combined in LDS
+    __shared__ u32 sc0[16][64], sc1[16][64], sf[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int words = R.bins / 2;
+    const int t = blockIdx.x * 64 + lane;
+    u32 c0 = 0, c1 = 0, fl = 0;
+    if (t < words)
+        for (int g = w; g < n_wg; g += 16) {
+            const u32 x = part[(size_t)g * words + t];
+            c0 += x & GM_PRIV_COUNT_MASK, c1 += (x >> 16) & GM_PRIV_COUNT_MASK;
+            fl |= (x & 0xf000u) | ((x >> 16 & 0xf000u) << 16);
+        }
+    sc0[w][lane] = c0, sc1[w][lane] = c1, sf[w][lane] = fl;
+    __syncthreads();
+    if (w != 0 || t >= words) return;
+    for (int k = 1; k < 16; ++k) c0 += sc0[k][lane], c1 += sc1[k][lane], fl |= sf[k][lane];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const u32 bin = 2u * (u32)t + (u32)k, c = k ? c1 : c0, f = k ? (fl >> 16) : (fl & 0xffffu);
+        int j = -1;
+        for (int s = 0; s < P.L; ++s)
+            if (R.off[s] >= 0 && (i64)bin >= R.off[s] && (i64)bin < R.off[s] + (P.off[s + 1] - P.off[s])) j = s;
+        if (j < 0) continue;                                   // padding bin
+        const i64 q = P.off[j] + (bin - (u32)R.off[j]);
+        A.df[q] = c;
+        A.cmax[q] = (f & GM_PRIV_BIG2) ? (u32)wide_above + 1u : ((f & GM_PRIV_BIG1) ? (u32)prim_max + 1u : (c ? 1u : 0u));
+        if (rectangular) A.side[q] = (unsigned char)((f >> GM_PRIV_SIDE_SHIFT) & 3u);
+    }
+}
+
+// listed prefix of a full level's label-grouped order -> flag array (the relabel sort leaves the nodes of
+// shared classes in perm[0 .. n_sorted))
+__global__ void gm_flags_kernel(const i32* __restrict__ perm, i64 n_listed, unsigned char* __restrict__ flag) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_listed) flag[perm[k]] = 1;
+}
+
+// Column classes per shareable label, one prefix sum for everything:
+//   a = primary dense columns (low 32) | secondary int8 columns (high 32)
+//   b = float64 columns (low 32) | rare labels (high 32)
+//   c = rare (graph, count) entries before this label
+struct Gm3 {
+    u64 a, b, c;
+    __device__ __forceinline__ Gm3& operator+=(const Gm3& o) { a += o.a, b += o.b, c += o.c; return *this; }
+};
+__device__ __forceinline__ Gm3 gm3_shfl_up(const Gm3& x, int off) {
+    Gm3 y;
+    y.a = __shfl_up(x.a, off, 64), y.b = __shfl_up(x.b, off, 64), y.c = __shfl_up(x.c, off, 64);
+    return y;
+}
+__device__ __forceinline__ Gm3 gm3_shfl_down(const Gm3& x, int off) {
+    Gm3 y;
+    y.a = __shfl_down(x.a, off, 64), y.b = __shfl_down(x.b, off, 64), y.c = __shfl_down(x.c, off, 64);
+    return y;
+}
+
+struct GmColumns {
+    GmLabelArrays A; i64 Q; int symmetric; int low_df; int kind; int prim_max; int wide_above; u32* meta;
+    __device__ __forceinline__ Gm3 value(i64 q) const {
+        Gm3 v{0, 0, 0};
+        const u32 df = A.df[q];
+        if (df == 0) return v;
+        const bool useful = symmetric ? df >= 2u : A.side[q] == 3;
+        if (!useful) return v;
+        if ((int)df < low_df) { v.b = 1ull << 32, v.c = df; return v; }
+        const u32 m = A.cmax[q] ? A.cmax[q] : 1u;
+        if (kind) v.a = m;                                   // unary expansion: one 0/1 column per count level
+        else if ((int)m <= prim_max) v.a = 1;
+        else if ((int)m <= wide_above) v.a = 1ull << 32;
+        else v.b = 1;
+        return v;
+    }
+    __device__ __forceinline__ void emit(i64 q, const Gm3& v, const Gm3& incl) const {
+        i32 c = -1;                                          // dead
+        if (v.b >> 32) {                                     // rare
+            c = -2;
+            A.roff[q] = (u32)(incl.c - v.c);
+            A.low_q[(u32)(incl.b >> 32) - 1] = (i32)q;
+        } else if (v.a & 0xffffffffull) c = (i32)((u32)(incl.a & 0xffffffffull) - (u32)(v.a & 0xffffffffull));
+        else if (v.a >> 32) c = COL_BYTE_BASE + (i32)((u32)(incl.a >> 32) - 1);
+        else if (v.b & 0xffffffffull) c = -4 - (i32)((u32)(incl.b & 0xffffffffull) - 1);
+        A.colid[q] = c;
+    }
+    __device__ __forceinline__ void finish(const Gm3& t) const {
+        meta[GM_META_PRIM] = (u32)(t.a & 0xffffffffull), meta[GM_META_INT8] = (u32)(t.a >> 32);
+        meta[GM_META_F64] = (u32)(t.b & 0xffffffffull), meta[GM_META_RARE] = (u32)(t.b >> 32);
+        meta[GM_META_RARE_ENTRIES] = (u32)t.c;
+    }
+};
+
+// scan_fn.h specialised to the three-word sum (its templates need arithmetic shuffles of T)
+#define G3_THREADS 256
+#define G3_ITEMS 4
+#define G3_TILE (G3_THREADS * G3_ITEMS)
+__global__ __launch_bounds__(G3_THREADS) void gm_scan_sums_kernel(const GmColumns f, Gm3* __restrict__ partial) {
+    __shared__ Gm3 wsum[G3_THREADS / 64];
+    const i64 base = (i64)blockIdx.x * G3_TILE;
+    Gm3 s{0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < G3_ITEMS; ++i) {
+        const i64 idx = base + (i64)i * G3_THREADS + threadIdx.x;
+        if (idx < f.Q) s += f.value(idx);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += gm3_shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Gm3 t{0, 0, 0};
+        for (int i = 0; i < G3_THREADS / 64; ++i) t += wsum[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColumns f, const Gm3* __restrict__ partial) {
+    __shared__ Gm3 wsum[G3_THREADS / 64];
+    __shared__ Gm3 bsum[G3_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    Gm3 s{0, 0, 0};
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += G3_THREADS) s += partial[i];
+    for (int off = 32; off > 0; off >>= 1) s += gm3_shfl_down(s, off);
+    if (lane == 0) bsum[w] = s;
+    __syncthreads();
+    Gm3 carry{0, 0, 0};
+    for (int q = 0; q < G3_THREADS / 64; ++q) carry += bsum[q];
+    const i64 tile0 = (i64)blockIdx.x * G3_TILE;
+#pragma unroll
+    for (int i = 0; i < G3_ITEMS; ++i) {
+        const i64 idx = tile0 + (i64)i * G3_THREADS + threadIdx.x;
+        Gm3 v{0, 0, 0};
+        if (idx < f.Q) v = f.value(idx);
+        Gm3 inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const Gm3 y = gm3_shfl_up(inc, off);
+            if (lane >= off) inc += y;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        Gm3 woff{0, 0, 0}, row{0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < G3_THREADS / 64; ++q) {
+            if (q < w) woff += wsum[q];
+            row += wsum[q];
+        }
+        if (idx < f.Q) {
+            Gm3 incl = carry;
+            incl += woff;
+            incl += inc;
+            f.emit(idx, v, incl);
+        }
+        carry += row;
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) f.finish(carry);
+}
+
+// one workgroup per graph: the operand row in LDS (row_bytes <= GM_ROW_LDS_MAX), written once
+__global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const GmLabelArrays A,
+                                                      const i32* __restrict__ graph_ptr, i64 V, const u32* __restrict__ cnt,
+                                                      int8_t* __restrict__ phi, i64 ld, i64 prim0 /* first byte of the primary region */,
+                                                      int fp4, int kind, double* __restrict__ phi_w, i64 ldw,
+                                                      i32* __restrict__ low_graph, i32* __restrict__ low_cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char row[];
+    const i64 g = blockIdx.x;
+    const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
+    for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) ((uint4*)row)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int n = v1 - v0;
+    for (int t = threadIdx.x; t < n * P.L; t += blockDim.x) {
+        const int j = t / n, i = t - j * n;
+        const u32 c = cnt[(i64)j * V + v0 + i];
+        if (!c) continue;
+        const i64 q = P.off[j] + (P.lab[j][v0 + i] - P.id_base[j]);
+        const i32 col = A.colid[q];
+        if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;          // secondary int8 region: bytes [0, prim0)
+        else if (col >= 0) {
+            if (kind) {                                                                 // unary run of ones
+                for (u32 x = 0; x < c; ++x) {
+                    const i64 cc = col + x;
+                    if (fp4) atomicOr((u32*)(row + prim0 + ((cc >> 1) & ~3ll)), 2u << (8 * ((cc >> 1) & 3) + 4 * (cc & 1)));
+                    else row[prim0 + cc] = 1;
+                }
+            } else if (fp4) {
+                const u32 code = (0x65420u >> (4 * c)) & 15u;
+                atomicOr((u32*)(row + prim0 + ((col >> 1) & ~3)), code << (8 * ((col >> 1) & 3) + 4 * (col & 1)));
+            } else row[prim0 + col] = (unsigned char)c;
+        } else if (col <= -4) phi_w[g * ldw + (-4 - col)] = (double)c;
+        else if (col == -2) {
+            const u32 pos = A.roff[q] + atomicAdd(&A.cursor[q], 1u);
+            low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c;
+        }
+    }
+    __syncthreads();
+    uint4* dst = (uint4*)(phi + g * ld);
+    for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) dst[i] = ((const uint4*)row)[i];
+}
+
+// rows [n_graphs, n_rows_pad) of the operand: zero
+__global__ void gm_pad_rows_kernel(int8_t* __restrict__ phi, i64 bytes) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bytes / 16) ((uint4*)phi)[i] = make_uint4(0, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int prim_max, int wide_above) {
+    const i64 V = b->n_nodes, N = b->n_graphs;
+    const int kind = f->kind;
+    void* q = nullptr;
+    // ---- level slots
+    GmLevels P;
+    P.L = 0, P.off[0] = 0;
+    std::vector<const i32*> perm_of;
+    std::vector<i64> listed_of;
+    for (int l = 0; l < n_levels; ++l) {
+        const i64 nl = (l == 0 && b->level0_hist) ? V : ((size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V);
+        if (nl == 0) continue;                                // nothing shared: baseline only
+        const int j = P.L++;
+        const bool act = (size_t)l < b->active_layout.size() && b->active_layout[l];
+        const i64 count = l == 0 ? (i64)b->n_labels0 : b->label_counts[l];     // level 0 keeps the input ids
+        P.lab[j] = b->labels + (size_t)l * V, P.level[j] = l;
+        P.id_base[j] = act ? (i32)(V - nl) : 0;
+        P.flag[j] = nullptr;
+        P.off[j + 1] = P.off[j] + (count - P.id_base[j]);
+        perm_of.push_back((!act && nl < V) ? b->perm + (size_t)l * V : nullptr);     // full level with a listed prefix
+        listed_of.push_back(nl);
+    }
+    const i64 Q = P.off[P.L];
+    GK_ARG(Q < (1ll << 31), "gk_features_build: label space too large");
+    // ---- per-label arrays (zeroed in one go), flags of the full levels, counts
+    const size_t qa = (size_t)round_up(Q > 0 ? Q : 1, 64);
+    Tmp<u32> zeroed(ctx);                     // [df | cmax | cursor | side (bytes) | flags (bytes, V per flagged level)]
+    size_t n_flag_levels = 0;
+    for (const i32* pp : perm_of) n_flag_levels += pp ? 1 : 0;
+    const size_t zero_words = 3 * qa + qa / 4 + n_flag_levels * (size_t)round_up(V, 64) / 4;
+    GK_TRY(zeroed.alloc(zero_words));
+    GK_TRY(gk_zero_async(ctx, zeroed.p, zero_words * 4));
+    GmLabelArrays A;
+    A.df = zeroed.p, A.cmax = zeroed.p + qa, A.cursor = zeroed.p + 2 * qa;
+    A.side = (unsigned char*)(zeroed.p + 3 * qa);
+    unsigned char* flag_mem = A.side + qa;
+    {
+        size_t k = 0;
+        for (int j = 0; j < P.L; ++j)
+            if (perm_of[j]) {
+                unsigned char* fl = flag_mem + (k++) * (size_t)round_up(V, 64);
+                P.flag[j] = fl;
+                gm_flags_kernel<<<grid_for(listed_of[j], 256), 256, 0, ctx->stream>>>(perm_of[j], listed_of[j], fl);
+            }
+    }
+    i32** keep[] = {&A.colid, (i32**)&A.roff, &A.low_q};
+    for (i32** a : keep) {
+        GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));
+        *a = (i32*)q;
+        f->arena.push_back(q);
+    }
+    Tmp<u32> cnt(ctx);
+    GK_TRY(cnt.alloc((size_t)(P.L > 0 ? P.L : 1) * (size_t)(V > 0 ? V : 1)));
+    const int rectangular = f->symmetric ? 0 : 1;
+    int T = 64;
+    while (T < 2 * b->max_graph_nodes) T <<= 1;
+    // ---- which levels count in workgroup-private histograms (small label spaces first come, 32 K bins in all)
+    int n_cu = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    }
+    i64 grid = cdiv(N, GM_WAVES);
+    if (grid > 2 * (i64)n_cu) grid = 2 * (i64)n_cu;
+    // two 1024-thread workgroups per CU: 160 KiB / 2 = private histogram + 16 counting tables
+    const i64 priv_budget = std::max<i64>(0, (80 * 1024 - 1024 - (i64)GM_WAVES * 2 * T * 4) / 2);
+    GmPriv R;
+    R.bins = 0;
+    const bool priv_ok = kind == GK_FEAT_DOT && !getenv("GK_GM_NO_PRIV") && cdiv(N, grid * GM_WAVES) + 1 < (i64)GM_PRIV_COUNT_MASK;
+    for (int j = 0; j < FEAT_MAX_LEVELS; ++j) R.off[j] = -1;
+    for (int j = 0; j < P.L; ++j) {
+        const i64 ids = P.off[j + 1] - P.off[j];
+        if (priv_ok && ids > 0 && R.bins + ids <= priv_budget) R.off[j] = R.bins, R.bins += (int)ids;
+    }
+    R.bins = (R.bins + 1) & ~1;
+    const size_t pairs_lds = (size_t)R.bins * 2 + (size_t)GM_WAVES * 2 * T * 4;
+    GK_ARG(pairs_lds <= 160 * 1024, "gk_features_build: graph too large for the graph-major builder");
+    if (pairs_lds > 48 * 1024)
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
+    Tmp<u32> part(ctx);
+    GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
+    gm_pairs_kernel<<<dim3((unsigned)grid), 64 * GM_WAVES, pairs_lds, ctx->stream>>>(
+        P, A, R, b->graph_ptr, N, V, cnt.p, f->selfk, f->meta, n_levels, kind, f->n_fit, rectangular,
+        (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p);
+    if (R.bins > 0)
+        gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(P, A, R, part.p, (int)grid, prim_max, wide_above, rectangular);
+    std::vector<u32> h(GM_META_WORDS, 0);
+    if (Q > 0) {
+        GmColumns gc{A, Q, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta};
+        const i64 nblk = cdiv(Q, G3_TILE);
+        Tmp<Gm3> partial(ctx);
+        GK_TRY(partial.alloc((size_t)nblk));
+        if (nblk > 1) gm_scan_sums_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
+        gm_scan_apply_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
+    }
+    GK_TRY(gk_readback(ctx, f->meta, h.data(), GM_META_WORDS));     // one host sync: sizes of the operand
+    f->n_cols1 = h[GM_META_PRIM], f->n_cols8 = h[GM_META_INT8], f->n_cols = f->n_cols1 + f->n_cols8;
+    f->n_cols_wide = h[GM_META_F64], f->n_low_cols = h[GM_META_RARE];
+    f->max_count = 0, f->nnz = 0;
+    for (int k = 0; k < 64; ++k) {
+        f->max_count = std::max<i64>(f->max_count, h[GM_META_MAXC + k]);
+        f->nnz += h[GM_META_NNZ + k];
+    }
+    const i64 rare_entries = h[GM_META_RARE_ENTRIES];
+    // ---- operand: [secondary int8 | primary], 128-byte K-steps (features.hip has the rationale)
+    const i64 n1p = round_up(f->n_cols1, f->phi_fp4 ? 256 : 128);
+    i64 n8p = round_up(f->n_cols8, 128);
+    if (n1p + n8p == 0) n8p = 128;
+    f->k1_steps = (int)(n1p / (f->phi_fp4 ? 256 : 128)), f->k8_steps = (int)(n8p / 128);
+    f->n_cols_pad = (f->phi_fp4 ? n1p / 2 : n1p) + n8p;
+    f->n_rows_pad = round_up(N, 256) + 256;
+    if (f->n_cols_pad > GM_ROW_LDS_MAX) return GK_ERR_UNSUPPORTED;            // caller falls back to features.hip
+    GK_TRY(gk_dev_alloc(ctx, &q, (size_t)f->n_rows_pad * f->n_cols_pad));
+    f->phi = q;
+    if (f->n_cols_wide > 0) {
+        f->n_cols_wide_pad = round_up(f->n_cols_wide, 16);
+        const size_t wb = (size_t)f->n_rows_pad * f->n_cols_wide_pad * 8;
+        GK_TRY(gk_dev_alloc(ctx, &q, wb));
+        f->phi_w = (double*)q;
+        GK_TRY(gk_zero_async(ctx, f->phi_w, wb));
+    }
+    i32* lg = nullptr;
+    i32* lc = nullptr;
+    if (rare_entries > 0) {
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
+        lg = (i32*)q, f->arena.push_back(q);
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
+        lc = (i32*)q, f->arena.push_back(q);
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GM_ROW_LDS_MAX));
+        attr_set = true;
+    }
+    gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
+        P, A, b->graph_ptr, V, cnt.p, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
+        f->n_cols_wide_pad, lg, lc);
+    const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
+    gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
+    GK_HIP_CHECK(hipGetLastError());
+    // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries
+    f->gm = true;
+    f->gm_low_q = A.low_q, f->gm_roff = A.roff, f->gm_low_graph = lg, f->gm_low_cnt = lc;
+    // df is read by the pair-update kernel: keep it (moves out of the zeroed temporary)
+    {
+        GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));
+        GK_HIP_CHECK(hipMemcpyAsync(q, A.df, qa * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        f->gm_df = (u32*)q, f->arena.push_back(q);
+    }
+    return GK_OK;
+}

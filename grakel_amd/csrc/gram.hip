@@ -803,6 +803,28 @@ __global__ void gram_low_kernel(const LevelPack P, double* __restrict__ K, i64 l
     }
 }
 
+// the same for the graph-major feature builder: a rare label's entries are a (graph, count) list
+__global__ void gram_low_gm_kernel(const i32* __restrict__ low_q, i64 n_low, const u32* __restrict__ roff,
+                                   const u32* __restrict__ df, const i32* __restrict__ lgraph, const i32* __restrict__ lcnt,
+                                   double* __restrict__ K, i64 ldk, i64 row_lo, i64 row_hi, int symmetric, i64 n_fit,
+                                   int minsum, i64 col_lo, i64 col_hi) {
+    const i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_low) return;
+    const i32 q = low_q[w];
+    const u32 t0 = roff[q];
+    const int m = (int)df[q];
+    for (int p = lane; p < m * m; p += 64) {
+        const int ia = p / m, ib = p - ia * m;
+        const i64 ga = lgraph[t0 + ia], gb = lgraph[t0 + ib];
+        const i64 row = symmetric ? ga : ga - n_fit;       // rectangular job: rows are the target graphs
+        if (row < row_lo || row >= row_hi || gb < col_lo || gb >= col_hi) continue;
+        if (symmetric ? (ia == ib) : (gb >= n_fit)) continue;
+        const i32 ca = lcnt[t0 + ia], cb = lcnt[t0 + ib];
+        atomicAdd(&K[(row - row_lo) * ldk + (gb - col_lo)], minsum ? (double)(ca < cb ? ca : cb) : (double)ca * (double)cb);
+    }
+}
+
 __global__ void gram_normalize_kernel(double* __restrict__ K, const u64* __restrict__ selfk, i64 M, i64 n_cols,
                                       i64 row_lo, int symmetric, i64 n_fit, int normalize) {
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -857,7 +879,11 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
             (int)(f->n_cols_wide_pad / GD_BK), f->selfk, K, M, NC, row_lo, f->symmetric ? 1 : 0, f->n_fit, 0, tiles_n, 1,
             ldk, col_lo);
     }
-    if (has_low) {
+    if (has_low && f->gm) {
+        gram_low_gm_kernel<<<dim3((unsigned)cdiv(f->n_low_cols * 64, 256)), dim3(256), 0, ctx->stream>>>(
+            f->gm_low_q, f->n_low_cols, f->gm_roff, f->gm_df, f->gm_low_graph, f->gm_low_cnt, K, ldk, row_lo, row_hi,
+            f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0, col_lo, col_hi);
+    } else if (has_low) {
         for (int l0 = 0; l0 < f->n_levels; l0 += GK_PACK_LEVELS) {     // one launch per 16 levels
             LevelPack P;
             P.n = 0, P.first[0] = 0;

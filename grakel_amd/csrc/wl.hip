@@ -1137,6 +1137,7 @@ static int launch_tiny_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits,
         n_car > 0 ? (const u32*)b->car_class + n_car : nullptr, V, count_dev, tiny_dev, unresolved_dev);
     GK_HIP_CHECK(hipGetLastError());
     st.tiny_level[level] = 1;
+    b->active_layout[level] = 1;
     st.prev_active = true;
     b->n_sorted[level] = n_car;            // + the active count, known after the job's final read-back
     return GK_OK;
@@ -1217,6 +1218,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     if (n_act == 0 && n_car == 0) {
         // every class is a singleton: the partition cannot change any more
         b->n_sorted[level] = 0;
+        b->active_layout[level] = 1;
         GK_HIP_CHECK(hipMemcpyAsync(cur, prev, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
         GK_HIP_CHECK(hipMemcpyAsync(perm, perm - V, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
         GK_HIP_CHECK(hipMemcpyAsync(count_dev, count_dev - 1, 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1228,6 +1230,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         // carried classes of the isolated vertices are listed behind them.
         // ids of the level: [frozen nodes | carried classes | classes of the active nodes]
         b->n_sorted[level] = (i64)n_act + n_car;
+        b->active_layout[level] = 1;
         const u32 n_frozen = (u32)(V - (i64)n_act - n_car);
         const u32* n_cc_dev = n_car > 0 ? (const u32*)b->car_class + n_car : nullptr;
         int bits = hash_bits;
@@ -1274,6 +1277,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         return GK_OK;
     }
     st.prev_active = false;
+    b->active_layout[level] = 0;
     // ---- full path
     if (!st.split) listed_dev = nullptr;
     st.full_level[level] = listed_dev ? 1 : 0;
@@ -1353,6 +1357,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     GK_TRY(gk_zero_async(ctx, meta.p, 16 * (size_t)n_levels));
     if (out_rounds) *out_rounds = 0;
     b->n_sorted.assign((size_t)n_levels, V);
+    b->active_layout.assign((size_t)n_levels, 0);
     RelabelState st(ctx);
     st.default_bits = default_bits;
     st.split = getenv("GK_WL_NO_SPLIT") == nullptr;
