@@ -162,6 +162,7 @@ struct gk_batch {
     int cap_levels = 0;
     i32* labels = nullptr;             // [cap_levels][n_nodes]
     i32* perm = nullptr;               // [cap_levels][n_nodes] nodes grouped by label (stable)
+    unsigned char* shared_flag = nullptr;   // [cap_levels][n_nodes] full levels: 1 = the node's class has >= 2 members
     std::vector<i64> label_counts;     // per level
     // per level: perm[level][0 .. n_sorted) holds every node that can share its label with another
     // node (grouped by label); the nodes behind it carry labels of their own.  Empty = n_nodes.

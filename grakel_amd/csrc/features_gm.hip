@@ -393,7 +393,9 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         P.id_base[j] = act ? (i32)(V - nl) : 0;
         P.flag[j] = nullptr;
         P.off[j + 1] = P.off[j] + (count - P.id_base[j]);
-        perm_of.push_back((!act && nl < V) ? b->perm + (size_t)l * V : nullptr);     // full level with a listed prefix
+        // full level with a listed prefix: the relabel left per-node flags (wl.hip: HeadAssignSplit)
+        if (!act && nl < V && b->shared_flag) P.flag[j] = b->shared_flag + (size_t)l * V;
+        perm_of.push_back(nullptr);
         listed_of.push_back(nl);
     }
     const i64 Q = P.off[P.L];

@@ -227,6 +227,7 @@ struct HeadAssignSplit {
     i64 n;
     u32* mbox; u32 seq;  // host mailbox (may be null): the host learns {listed nodes, *extra} without a scan of its own
     const u32* extra;    // largest top-digit bucket of the sort that produced ks
+    unsigned char* shared_out;   // out (may be null): 1 when the node's class has two or more members (features_gm.hip)
     __device__ __forceinline__ bool head(i64 k) const { return k == 0 || ks[k] != ks[k - 1]; }
     __device__ __forceinline__ u64 value(i64 k) const {
         const bool h = head(k);
@@ -241,6 +242,7 @@ struct HeadAssignSplit {
         lab[v] = r;
         if (h) rep[r] = (i32)v;
         if (frozen) frozen[v] = single ? 1u : 0u;
+        if (shared_out) shared_out[v] = single ? 0 : 1;
         if (single) perm_out[n - 1 - (k - listed)] = (i32)v;
         else perm_out[listed - 1] = (i32)v;
     }
@@ -823,6 +825,11 @@ static int batch_alloc(gk_ctx* ctx, gk_batch* b) {
         GK_TRY(gk_dev_alloc(ctx, &q, (size_t)(sizes[k] > 0 ? sizes[k] : 1) * 4));
         *arrs[k] = (i32*)q;
     }
+    {
+        void* q = nullptr;
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)(b->n_nodes > 0 ? b->n_nodes : 1)));
+        b->shared_flag = (unsigned char*)q;
+    }
     b->cap_levels = 1;
     return GK_OK;
 }
@@ -991,7 +998,7 @@ extern "C" int gk_batch_destroy(gk_batch* b) {
     if (!b) return GK_OK;
     gk_ctx* ctx = b->ctx;
     void* ptrs[] = {b->graph_ptr, b->row_ptr, b->col_idx, b->node_graph, b->big_nodes,
-                    b->labels, b->perm, b->nbr_sorted, b->iso_info, b->car_class, b->car_nodes};
+                    b->labels, b->perm, b->nbr_sorted, b->iso_info, b->car_class, b->car_nodes, b->shared_flag};
     for (void* p : ptrs)
         if (p) gk_dev_free(ctx, p);
     delete b;
@@ -1017,6 +1024,12 @@ int gk_batch_ensure_levels(gk_batch* b, int n_levels) {
     GK_HIP_CHECK(hipMemcpyAsync(np, b->perm, per * b->cap_levels, hipMemcpyDeviceToDevice, ctx->stream));
     gk_dev_free(ctx, b->labels);
     gk_dev_free(ctx, b->perm);
+    {   // the flags of earlier runs are recomputed by every relabel call: no copy
+        void* nf = nullptr;
+        GK_TRY(gk_dev_alloc(ctx, &nf, (per / 4) * n_levels));
+        gk_dev_free(ctx, b->shared_flag);
+        b->shared_flag = (unsigned char*)nf;
+    }
     b->labels = (i32*)nl, b->perm = (i32*)np, b->cap_levels = n_levels;
     return GK_OK;
 }
@@ -1056,7 +1069,7 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
                                 i32* rep, u32* count_dev, const u32* vals = nullptr, u32* frozen = nullptr,
                                 i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr,
                                 u32* listed_dev = nullptr, u32* posted_seq = nullptr, u32 lab_base = 0,
-                                const u32* lab_base_dev = nullptr) {
+                                const u32* lab_base_dev = nullptr, unsigned char* shared_out = nullptr) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         if (listed_dev) GK_TRY(gk_zero_async(ctx, listed_dev, 4));
@@ -1075,7 +1088,7 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
         const u32 seq = posted_seq ? gk_mbox_begin(ctx) : 0u;
         if (posted_seq) *posted_seq = seq;
         HeadAssignSplit ha{ks.p, sorted.p, lab, rep, frozen, perm, listed_dev, count_dev, n,
-                           seq ? ctx->mbox_dev : nullptr, seq, top_digit_max};
+                           seq ? ctx->mbox_dev : nullptr, seq, top_digit_max, shared_out};
         GK_TRY((gk_scan_fn<u64, HeadAssignSplit>(ctx, ha, n, nullptr)));
         return GK_OK;
     }
@@ -1300,7 +1313,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                                                                                  (int)b->n_labels0, code_R, unresolved_dev);
             GK_TRY(dictionary_from_keys(ctx, hash.p, V, 32, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
                                         sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2, listed_dev,
-                                        listed_dev ? &st.posted_seq : nullptr));
+                                        listed_dev ? &st.posted_seq : nullptr, 0, nullptr, b->shared_flag + (size_t)level * V));
             GK_HIP_CHECK(hipGetLastError());
             break;
         }
@@ -1314,7 +1327,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         }
         GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
                                     round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev,
-                                    (listed_dev && !exact) ? &st.posted_seq : nullptr));
+                                    (listed_dev && !exact) ? &st.posted_seq : nullptr, 0, nullptr,
+                                    b->shared_flag + (size_t)level * V));
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
@@ -1380,7 +1394,8 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         int bits = bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0);
         st.full_level[0] = st.split ? 1 : 0;
         GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p, 0,
-                                    0, st.scratch.p + 2, st.split ? meta.p + 2 * n_levels : nullptr));
+                                    0, st.scratch.p + 2, st.split ? meta.p + 2 * n_levels : nullptr, nullptr, 0, nullptr,
+                                    b->shared_flag));
     }
     std::vector<u32> h(4 * (size_t)n_levels);
     int first_bad = -1;
