@@ -42,6 +42,10 @@ extern "C" int gk_create(int device_id, gk_ctx** out) {
     GK_HIP_CHECK(hipSetDevice(device_id));
     gk_ctx* ctx = new gk_ctx();
     ctx->device = device_id;
+    {
+        hipDeviceProp_t prop;
+        ctx->n_cu = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
     GK_HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     GK_HIP_CHECK(hipEventCreate(&ctx->ev0));

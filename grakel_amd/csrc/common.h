@@ -72,6 +72,7 @@ struct gk_ctx {
     u32* mbox_host = nullptr;
     u32* mbox_dev = nullptr;
     u32 mbox_seq = 0;
+    int n_cu = 0;                              // compute units of the device (persistent-kernel grids)
 };
 #define GK_MBOX_WORDS 512
 #define GK_HIST0_MAX_LABELS 256
@@ -170,6 +171,7 @@ struct gk_batch {
     // per level: 1 when the ids follow the active-set layout [frozen singletons | carried classes | active classes]:
     // a node can share its label iff its id >= n_nodes - n_sorted[level] (features.hip, graph-major path)
     std::vector<char> active_layout;
+    std::vector<char> perm_valid;      // per level: 0 when the relabel skipped the label-grouped order (sort-free dictionary)
     // scratch kept between levels
     i32* nbr_sorted = nullptr;         // [n_edges] sorted neighbour labels of the level being built
     bool is_pair_batch = false;        // ShortestPath items: no CSR, level 0 only
@@ -256,6 +258,11 @@ int gk_scan_u64(gk_ctx* ctx, const u64* in, u64* out, i64 n, bool exclusive, u64
 // implicit_iota: the input values are 0..n-1 and are never read (vals_in is scratch only).
 int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64* keys_out, u32* vals_out,
                         i64 n, int key_bits, int use_buckets = 0, u32* top_digit_max = nullptr);
+
+// Dictionary without a sort (full WL levels whose label-grouped order nobody reads): see scan_sort.hip
+int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* rep, u32* frozen,
+                         unsigned char* shared_out, u32* count_dev, u32* listed_dev, u32* top_digit_max, u32* overflow,
+                         u32* mbox, u32 seq);
 
 // ---- wl.hip ---------------------------------------------------------------------------
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);

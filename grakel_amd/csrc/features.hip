@@ -542,6 +542,11 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         i64 nl = (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V;
         if (l == 0 && hist0) nl = L0 * N;           // items of the synthesized slot: (label, graph) cells
         if (nl == 0) { ++n_unlisted; continue; }
+        if (!(l == 0 && hist0) && (size_t)l < b->perm_valid.size() && !b->perm_valid[l]) {
+            gk_set_error("gk_features_build: this batch was relabelled without label-grouped orders (graph-major features); "
+                         "set GK_WL_NO_BUCKET_DICT=1 to use the label-major builder");
+            return fail(GK_ERR_STATE);
+        }
         const int j = P.L++;
         slot_of_level[l] = j;
         P.perm[j] = b->perm + (size_t)l * V, P.lab[j] = b->labels + (size_t)l * V;

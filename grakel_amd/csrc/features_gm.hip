@@ -433,11 +433,7 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     int T = 64;
     while (T < 2 * b->max_graph_nodes) T <<= 1;
     // ---- which levels count in workgroup-private histograms (small label spaces first come, 32 K bins in all)
-    int n_cu = 256;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     i64 grid = cdiv(N, GM_WAVES);
     if (grid > 2 * (i64)n_cu) grid = 2 * (i64)n_cu;
     // two 1024-thread workgroups per CU: 160 KiB / 2 = private histogram + 16 counting tables
@@ -453,8 +449,11 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     R.bins = (R.bins + 1) & ~1;
     const size_t pairs_lds = (size_t)R.bins * 2 + (size_t)GM_WAVES * 2 * T * 4;
     GK_ARG(pairs_lds <= 160 * 1024, "gk_features_build: graph too large for the graph-major builder");
-    if (pairs_lds > 48 * 1024)
+    static size_t pairs_lds_set = 0;
+    if (pairs_lds > 48 * 1024 && pairs_lds > pairs_lds_set) {
         GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
+        pairs_lds_set = pairs_lds;
+    }
     Tmp<u32> part(ctx);
     GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
     gm_pairs_kernel<<<dim3((unsigned)grid), 64 * GM_WAVES, pairs_lds, ctx->stream>>>(

@@ -659,11 +659,7 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
     }
     const bool use_ws = getenv("GK_GRAM_NO_WS") == nullptr;
     if (use_ws) {
-        int n_cu = 256;
-        {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-        }
+        const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
         const i64 grid = blocks < n_cu ? blocks : n_cu;
         unsigned* ticket = nullptr;
         Tmp<unsigned> ticket_buf(ctx);
@@ -680,7 +676,11 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
         if (abl_bits == 4) kern = gram_ws_kernel<true, 4>;
         if (abl_bits == 5) kern = gram_ws_kernel<true, 5>;
         if (abl_bits == 6) kern = gram_ws_kernel<true, 6>, M_store = M;
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+        static std::map<const void*, bool> attr_done;      // once per kernel instance
+        if (!attr_done[(const void*)kern]) {
+            GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+            attr_done[(const void*)kern] = true;
+        }
         kern<<<dim3((unsigned)grid), dim3(512), WS_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
             normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket, ldk, col_lo, even);

@@ -715,3 +715,226 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Dictionary WITHOUT a sort (full WL levels of graph batches, wl.hip): equal keys only have to MEET, no
+// consumer needs them in order once the label-count features are built graph-major (features_gm.hip).
+// One stable pass on the top digit (as above) leaves 256 buckets; a workgroup then owns a bucket and
+// runs an open-addressing table in LDS over the remaining key bits: an item claims a slot with a
+// compare-and-swap or finds its key there and bumps the slot's counter.  Slots in use, ranked by a
+// workgroup prefix sum, are the bucket's classes; bucket offsets (a 256-entry prefix) make the ids dense.
+// Replaces the remaining 3-5 digit passes of the bucket finish AND the run-head scan over the sorted array.
+//   slot word: bits 0-13 owner item + 1 (0 = empty) | bits 14-27 members, later the slot's rank | bit 28 singleton
+//   per item (bucket_dict_kernel -> bucket_assign_kernel): bits 0-13 rank of its class in the bucket,
+//   bit 30 the item owns the class (its node becomes the representative), bit 31 singleton
+// A bucket above the capacity is not handled: the kernel raises BD_OVERFLOW in *overflow (and keeps the
+// outputs memory-safe); the caller redoes the level with the sorting path.
+// ---------------------------------------------------------------------------------------
+#define BD_SLOTS 16384
+#define BD_CAP32 12288          // keys of <= 32 remaining bits: 48 KiB of keys + 64 KiB of slots
+#define BD_CAP64 8192           // wider keys: 64 KiB + 64 KiB
+
+template <typename K, int CAP>
+__global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict__ kx, const u32* __restrict__ totals,
+                                                           int shift, u32* __restrict__ item_out, u32* __restrict__ nd,
+                                                           u32* __restrict__ overflow, unsigned long long* __restrict__ ticket) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bd_lds[];
+    K* key_s = (K*)bd_lds;                                   // [CAP]
+    u32* slot_s = (u32*)(bd_lds + (size_t)CAP * sizeof(K));  // [BD_SLOTS]
+    __shared__ u32 dsum[4];
+    __shared__ u32 wsum[16];
+    __shared__ u32 bstart;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) *ticket = 0;           // bucket_assign_kernel's arrival counter
+    {   // bucket range: exclusive prefix of the digit totals
+        const u32 t = tid < 256 ? totals[tid] : 0u;
+        const u32 inc = wave_incl_scan(t);
+        if (lane == 63 && w < 4) dsum[w] = inc;
+        __syncthreads();
+        if (tid == (int)blockIdx.x) {
+            u32 off = inc - t;
+            for (int q = 0; q < w; ++q) off += dsum[q];
+            bstart = off;
+        }
+        __syncthreads();
+    }
+    const u32 size = totals[blockIdx.x];
+    const i64 start = bstart;
+    if (size == 0) { if (tid == 0) nd[blockIdx.x] = 0; return; }
+    if (size > (u32)CAP) {              // not handled here: one class for the whole bucket (memory-safe), level redone by the caller
+        for (u32 i = tid; i < size; i += 1024) item_out[start + i] = i == 0 ? (1u << 30) : 0u;
+        if (tid == 0) { nd[blockIdx.x] = 1; atomicOr(overflow, 0x80000000u); }
+        return;
+    }
+    const u64 kmask = shift >= 64 ? ~0ull : ((1ull << shift) - 1ull);
+    for (u32 i = tid; i < size; i += 1024) key_s[i] = (K)(kx[start + i] & kmask);
+    for (int t = tid; t < BD_SLOTS; t += 1024) slot_s[t] = 0;
+    __syncthreads();
+    // ---- insert
+    for (u32 i = tid; i < size; i += 1024) {
+        const K k = key_s[i];
+        u32 h = (u32)(((u64)k * 0x9E3779B97F4A7C15ull) >> 50);       // 14 bits
+        for (;;) {
+            u32 v = slot_s[h];
+            if (v == 0) {
+                v = atomicCAS(&slot_s[h], 0u, (i + 1u) | (1u << 14));
+                if (v == 0) break;                                   // claimed: owner, one member
+            }
+            if (key_s[(v & 0x3fffu) - 1u] == k) { atomicAdd(&slot_s[h], 1u << 14); break; }
+            h = (h + 1u) & (BD_SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    // ---- rank the slots in use: thread t owns slots [16t, 16t + 16)
+    u32 mine = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mine += slot_s[16 * tid + q] ? 1u : 0u;
+    const u32 inc = wave_incl_scan(mine);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 before = inc - mine, all = 0;
+    for (int q = 0; q < 16; ++q) {
+        if (q < w) before += wsum[q];
+        all += wsum[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const u32 v = slot_s[16 * tid + q];
+        if (v) {
+            const u32 members = (v >> 14) & 0x3fffu;
+            slot_s[16 * tid + q] = (v & 0x3fffu) | (before << 14) | (members == 1u ? 1u << 28 : 0u);
+            ++before;
+        }
+    }
+    if (tid == 0) nd[blockIdx.x] = all;
+    __syncthreads();
+    // ---- every item looks its class up again
+    for (u32 i = tid; i < size; i += 1024) {
+        const K k = key_s[i];
+        u32 h = (u32)(((u64)k * 0x9E3779B97F4A7C15ull) >> 50);
+        u32 v;
+        for (;;) {
+            v = slot_s[h];
+            if (key_s[(v & 0x3fffu) - 1u] == k) break;
+            h = (h + 1u) & (BD_SLOTS - 1);
+        }
+        item_out[start + i] = ((v >> 14) & 0x3fffu) | ((v & 0x3fffu) == i + 1u ? 1u << 30 : 0u) | ((v >> 28) & 1u) << 31;
+    }
+}
+
+// second half: dense ids = bucket offset + rank; labels, representatives, singleton / shared flags, the level's
+// class count and number of nodes in shared classes; the last workgroup to finish posts {listed, *extra} to the
+// host mailbox (as HeadAssignSplit's finish hook does on the sorting path)
+__global__ __launch_bounds__(1024) void bucket_assign_kernel(const u32* __restrict__ vx, const u32* __restrict__ item_in,
+                                                             const u32* __restrict__ totals, const u32* __restrict__ nd,
+                                                             i32* __restrict__ lab, i32* __restrict__ rep, u32* __restrict__ frozen,
+                                                             unsigned char* __restrict__ shared_out, u32* __restrict__ listed_out,
+                                                             u32* __restrict__ count_out, unsigned long long* __restrict__ ticket,
+                                                             u32* __restrict__ mbox, u32 seq, const u32* __restrict__ extra, i64 n) {
+    // one item per thread (the scattered stores need many workgroups in flight); the bucket of an item is found
+    // in the two 256-entry prefixes every workgroup rebuilds in LDS
+    __shared__ u32 starts[257], bases[257];
+    __shared__ u32 dsum[4], esum[4];
+    __shared__ u32 red[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    {
+        const u32 t = tid < 256 ? totals[tid] : 0u, e = tid < 256 ? nd[tid] : 0u;
+        const u32 inct = wave_incl_scan(t), ince = wave_incl_scan(e);
+        if (lane == 63 && w < 4) dsum[w] = inct, esum[w] = ince;
+        __syncthreads();
+        if (tid < 256) {
+            u32 off = inct, base = ince;
+            for (int q = 0; q < w; ++q) off += dsum[q], base += esum[q];
+            starts[tid + 1] = off, bases[tid + 1] = base;            // inclusive -> entry tid + 1
+        }
+        if (tid == 0) starts[0] = 0, bases[0] = 0;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && tid == 0) *count_out = bases[256];
+    const i64 i = (i64)blockIdx.x * 1024 + tid;
+    u32 listed = 0;
+    if (i < n) {
+        int lo = 0, hi = 256;                                       // largest b with starts[b] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((i64)starts[mid] <= i) lo = mid; else hi = mid;
+        }
+        const u32 node = vx[i], t = item_in[i];
+        const u32 id = bases[lo] + (t & 0x3fffu);
+        const u32 single = t >> 31;
+        lab[node] = (i32)id;
+        if (frozen) frozen[node] = single;
+        if (shared_out) shared_out[node] = single ? 0 : 1;
+        if ((t >> 30) & 1u) rep[id] = (i32)node;
+        listed = single ? 0u : 1u;
+    }
+    for (int off = 32; off > 0; off >>= 1) listed += __shfl_down(listed, off, 64);
+    if (lane == 0) red[w] = listed;
+    __syncthreads();
+    if (tid == 0) {
+        u32 s = 0;
+        for (int q = 0; q < 16; ++q) s += red[q];
+        // count and arrival in ONE 64-bit atomic: no fence between two atomics (a device-scope fence writes the
+        // XCD's dirty L2 lines back -- all the scattered stores above -- once per workgroup: measured 3x the kernel)
+        const unsigned long long old = atomicAdd(ticket, ((unsigned long long)s << 32) | 1ull);
+        if ((u32)old == gridDim.x - 1) {                    // last arrival: everybody's count is in
+            const u32 total = (u32)(old >> 32) + s;
+            *listed_out = total;
+            if (!mbox) return;
+            __hip_atomic_store(&mbox[1], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mbox[2], extra ? *extra : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// keys[i] belongs to item i (0..n-1).  lab / frozen / shared_out are indexed by item, rep by class id.
+// *overflow gets 0x80000000 or-ed in when a bucket did not fit.
+int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* rep, u32* frozen,
+                         unsigned char* shared_out, u32* count_dev, u32* listed_dev, u32* top_digit_max, u32* overflow,
+                         u32* mbox, u32 seq) {
+    if (key_bits > 64) key_bits = 64;
+    const int passes = (key_bits + 7) / 8;
+    const int shift = 8 * (passes - 1);
+    const int nblk = (int)cdiv(n, RS_TILE);
+    Tmp<u32> hist(ctx), vx(ctx), item(ctx), nd(ctx);
+    Tmp<u64> kx(ctx);
+    GK_TRY(hist.alloc((size_t)256 * nblk + 768)); GK_TRY(vx.alloc(n)); GK_TRY(item.alloc(n)); GK_TRY(nd.alloc(256));
+    GK_TRY(kx.alloc(n));
+    u32* totals = hist.p + (size_t)256 * nblk;
+    u32* bucket_totals = totals + 256;
+    unsigned long long* ticket = (unsigned long long*)(totals + 512);      // 8-byte aligned: 256 * nblk + 512 words in
+    if (nblk <= RS_SMALL_TILES) {
+        radix_scatter_kernel<1024, true><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
+            keys, nullptr, kx.p, vx.p, n, shift, nullptr, nullptr, nblk, bucket_totals, top_digit_max);
+    } else {
+        radix_hist_kernel<<<dim3(nblk), dim3(RS_THREADS), 0, ctx->stream>>>(keys, n, shift, hist.p, nblk);
+        radix_rowscan_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(hist.p, nblk, totals);
+        radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
+            keys, nullptr, kx.p, vx.p, n, shift, hist.p, totals, nblk, bucket_totals, top_digit_max);
+    }
+    if (shift <= 32) {
+        auto kern = bucket_dict_kernel<u32, BD_CAP32>;
+        const int lds = BD_CAP32 * 4 + BD_SLOTS * 4;
+        static bool attr32 = false;
+        if (!attr32) {
+            GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr32 = true;
+        }
+        kern<<<dim3(256), dim3(1024), lds, ctx->stream>>>(kx.p, bucket_totals, shift, item.p, nd.p, overflow, ticket);
+    } else {
+        auto kern = bucket_dict_kernel<u64, BD_CAP64>;
+        const int lds = BD_CAP64 * 8 + BD_SLOTS * 4;
+        static bool attr64 = false;
+        if (!attr64) {
+            GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr64 = true;
+        }
+        kern<<<dim3(256), dim3(1024), lds, ctx->stream>>>(kx.p, bucket_totals, shift, item.p, nd.p, overflow, ticket);
+    }
+    bucket_assign_kernel<<<dim3((unsigned)cdiv(n, 1024)), dim3(1024), 0, ctx->stream>>>(
+        vx.p, item.p, bucket_totals, nd.p, lab, rep, frozen, shared_out, listed_dev, count_dev, ticket, mbox, seq, top_digit_max, n);
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
+}

@@ -1069,7 +1069,8 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
                                 i32* rep, u32* count_dev, const u32* vals = nullptr, u32* frozen = nullptr,
                                 i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr,
                                 u32* listed_dev = nullptr, u32* posted_seq = nullptr, u32 lab_base = 0,
-                                const u32* lab_base_dev = nullptr, unsigned char* shared_out = nullptr) {
+                                const u32* lab_base_dev = nullptr, unsigned char* shared_out = nullptr,
+                                u32* no_order_overflow = nullptr) {
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         if (listed_dev) GK_TRY(gk_zero_async(ctx, listed_dev, 4));
@@ -1079,6 +1080,16 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
     GK_TRY(ks.alloc(n));
     Tmp<i32> rep_tmp(ctx);
     if (!rep) { GK_TRY(rep_tmp.alloc(rep_capacity > n ? rep_capacity : n)); rep = rep_tmp.p; }
+    if (listed_dev && !vals && no_order_overflow && key_bits >= 24) {
+        // nobody reads this level's label-grouped order (graph-major features): equal keys only have to meet --
+        // top-digit partition + one LDS table per bucket instead of the remaining digit passes and the
+        // run-head scan (scan_sort.hip); a bucket that does not fit raises a flag in *no_order_overflow and
+        // the level is redone by the sorting path (gk_wl_relabel)
+        const u32 seq = posted_seq ? gk_mbox_begin(ctx) : 0u;
+        if (posted_seq) *posted_seq = seq;
+        return gk_bucket_dictionary(ctx, keys, n, key_bits, lab, rep, frozen, shared_out, count_dev, listed_dev, top_digit_max,
+                                    no_order_overflow, seq ? ctx->mbox_dev : nullptr, seq);
+    }
     if (listed_dev && !vals) {
         Tmp<u32> sorted(ctx);
         GK_TRY(sorted.alloc(n));
@@ -1129,6 +1140,7 @@ struct RelabelState {
     u32 n_act_prev = 0;
     bool list_scan = true;                 // GK_WL_NO_LISTSCAN: always rebuild the active list from all nodes
     bool tiny = true;                      // GK_WL_NO_TINY: never run a level in the single-workgroup kernel
+    bool no_order = false;                 // full levels need no label-grouped order (graph-major features will read them)
     std::vector<char> tiny_level;          // levels run by wl_tiny_level_kernel (n_act_prev is then only a bound)
     i64 n_frozen_levels = 0;
     explicit RelabelState(gk_ctx* c) : frozen(c), act(c), fidx(c), scratch(c), act2(c) {}
@@ -1313,7 +1325,9 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                                                                                  (int)b->n_labels0, code_R, unresolved_dev);
             GK_TRY(dictionary_from_keys(ctx, hash.p, V, 32, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
                                         sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2, listed_dev,
-                                        listed_dev ? &st.posted_seq : nullptr, 0, nullptr, b->shared_flag + (size_t)level * V));
+                                        listed_dev ? &st.posted_seq : nullptr, 0, nullptr, b->shared_flag + (size_t)level * V,
+                                        (st.no_order && !exact) ? unresolved_dev : nullptr));
+            b->perm_valid[level] = !(st.no_order && !exact && listed_dev) ? 1 : 0;
             GK_HIP_CHECK(hipGetLastError());
             break;
         }
@@ -1328,7 +1342,9 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
                                     round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev,
                                     (listed_dev && !exact) ? &st.posted_seq : nullptr, 0, nullptr,
-                                    b->shared_flag + (size_t)level * V));
+                                    b->shared_flag + (size_t)level * V,
+                                    (st.no_order && !exact && round == 0) ? unresolved_dev : nullptr));
+        b->perm_valid[level] = !(st.no_order && !exact && round == 0 && listed_dev && bits >= 24) ? 1 : 0;
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
@@ -1372,12 +1388,16 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     if (out_rounds) *out_rounds = 0;
     b->n_sorted.assign((size_t)n_levels, V);
     b->active_layout.assign((size_t)n_levels, 0);
+    b->perm_valid.assign((size_t)n_levels, 1);
     RelabelState st(ctx);
     st.default_bits = default_bits;
     st.split = getenv("GK_WL_NO_SPLIT") == nullptr;
     st.full_level.assign((size_t)n_levels, 0);
     st.list_scan = getenv("GK_WL_NO_LISTSCAN") == nullptr;
     st.tiny = getenv("GK_WL_NO_TINY") == nullptr;
+    // the graph-major feature builder (features_gm.hip) takes graph batches with small graphs: their full levels
+    // then need no label-grouped order
+    st.no_order = !b->is_pair_batch && b->max_graph_nodes <= 1024 && !getenv("GK_FEAT_NO_GM") && !getenv("GK_WL_NO_BUCKET_DICT");
     st.tiny_level.assign((size_t)n_levels, 0);
     GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
     GK_TRY(st.act2.alloc(V / 4 + 1));      // active-set levels hold at most V/4 active nodes

@@ -9,7 +9,7 @@ import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "gram_ws_kernel" in r["Kernel_Name"] or "gram_tile_kernel" in r["Kernel_Name"] or "gram_i8" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "gram_ws_kernel<" in r["Kernel_Name"] or "gram_tile_kernel" in r["Kernel_Name"] or "gram_i8" in r["Kernel_Name"]]
 lo, hi = idx[-2] + 1, idx[-1] + 1
 t0 = int(rows[lo]["Start_Timestamp"])
 busy = 0.0
