@@ -46,6 +46,7 @@ struct GmLabelArrays {
 };
 
 #define GM_WAVES 16
+#define GM_FEW 24           // at most this many distinct labels: counted by ballots instead of the sort
 
 // One wave per graph (persistent workgroups: a wave walks graphs w, w + stride, ...), all levels.  Per level the
 // wave counts its graph's labels in a small open-addressing table in LDS (T slots, T >= 2 x the largest
@@ -69,12 +70,13 @@ struct GmPriv {
     int bins;                         // private bins in total (even)
 };
 
-__global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+template <int WAVES>
+__device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArrays A, const GmPriv R,
                                                                 const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
-                                                                u32* __restrict__ cnt, u64* __restrict__ selfk,
+                                                                i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
                                                                 u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
                                                                 int rectangular, u32 df_cap, int T, int prim_max,
-                                                                int wide_above, u32* __restrict__ part) {
+                                                                int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private histogram | per wave: keys[T] | count + owner << 16 [T]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32* priv = (u32*)gm_lds;                                          // two 16-bit bins per word
@@ -85,44 +87,36 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels 
     u32* co = (u32*)(keys + T);
     const u32 tmask = (u32)T - 1u;
     u32 maxc = 0, entries = 0;
-    for (i64 g = (i64)blockIdx.x * GM_WAVES + w; g < n_graphs; g += (i64)gridDim.x * GM_WAVES) {
+    for (i64 g = (i64)blockIdx.x * WAVES + w; g < n_graphs; g += (i64)gridDim.x * WAVES) {
         const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
         const int n = v1 - v0;
         u64 extra = 0;
         const u32 side_bit = g < n_fit ? 1u : 2u;
+        const i32 BIG = 0x7fffffff;
+        const bool small = n <= 128;
+        if (n == 0) {
+            for (int j = lane; j < P.L; j += 64) ent_n[(i64)j * n_graphs + g] = 0;
+            if (lane == 0) selfk[g] = 0;
+            continue;
+        }
+        // the next level's labels (and flags) are fetched while the current level is counted
+        i32 ra = 0, rb = 0;
+        u32 fa = 0, fb = 0;                                   // 0: no node at this position / not shared
+        auto fetch = [&](int j) __attribute__((always_inline)) {
+            const i32* __restrict__ lab = P.lab[j];
+            const unsigned char* __restrict__ fl = P.flag[j];
+            ra = rb = 0, fa = fb = 0;
+            if (lane < n) { ra = lab[v0 + lane]; fa = fl ? fl[v0 + lane] : 1u; }
+            if (lane + 64 < n) { rb = lab[v0 + lane + 64]; fb = fl ? fl[v0 + lane + 64] : 1u; }
+        };
+        if (small) fetch(0);
         for (int j = 0; j < P.L; ++j) {
             const i32* __restrict__ lab = P.lab[j];
             const unsigned char* __restrict__ fl = P.flag[j];
             const i32 base = P.id_base[j];
-            for (int t = lane; t < T; t += 64) keys[t] = -1, co[t] = 0;
-            __builtin_amdgcn_wave_barrier();
-            // insert: only nodes whose class has at least two members take part
-            for (int i = lane; i < n; i += 64) {
-                const i32 x = lab[v0 + i];
-                if (x < base || (fl && !fl[v0 + i])) continue;
-                u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
-                for (;;) {
-                    const i32 old = atomicCAS(&keys[h], -1, x);
-                    if (old == -1) { atomicAdd(&co[h], ((u32)i << 16) | 1u); break; }     // claimed the slot: owner of the entry
-                    if (old == x) { atomicAdd(&co[h], 1u); break; }
-                    h = (h + 1u) & tmask;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // the owner of a slot emits the entry
             const i32 poff = R.off[j];
-            for (int i = lane; i < n; i += 64) {
-                const i32 x = lab[v0 + i];
-                u32 c = 0;
-                if (x >= base && (!fl || fl[v0 + i])) {
-                    u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
-                    while (keys[h] != x) h = (h + 1u) & tmask;
-                    const u32 e = co[h];
-                    if ((e >> 16) == (u32)i) c = e & 0xffffu;
-                }
-                cnt[(i64)j * V + v0 + i] = c;
-                if (!c) continue;
+            // one (label, graph, count) entry: df / class flags of the label, the graph's self similarity
+            auto emit = [&](i32 x, u32 c) __attribute__((always_inline)) {
                 if (poff >= 0) {
                     const u32 bin = (u32)poff + (u32)(x - base);
                     const int sh = 16 * (bin & 1u);
@@ -136,7 +130,8 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels 
                     atomicAdd(&priv[bin >> 1], 1u << sh);
                 } else {
                     const i64 q = P.off[j] + (x - base);
-                    // guarded global atomics: look first (L2-coherent load), add only while it still counts
+                    // guarded global atomics (device-scope atomics execute memory-side: slow, and a label present
+                    // in thousands of graphs would queue thousands of them on one address): add only while df counts
                     if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
                     if (c >= 2u && __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) atomicMax(&A.cmax[q], c);
                     if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
@@ -144,9 +139,112 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels 
                 if (!kind) extra += (u64)c * c - c;
                 maxc = c > maxc ? c : maxc;
                 ++entries;
+            };
+            i32* __restrict__ el = ent_lab + (i64)j * V + v0;
+            u32* __restrict__ ec = ent_cnt + (i64)j * V + v0;
+            u32* __restrict__ ne = ent_n + (i64)j * n_graphs + g;
+            if (small) {
+                i32 a = (fa && ra >= base) ? ra : BIG, b2 = (fb && rb >= base) ? rb : BIG;
+                if (j + 1 < P.L) fetch(j + 1);
+                u64 Ma = __ballot(a != BIG), Mb = __ballot(b2 != BIG);
+                if (!(Ma | Mb)) {                                    // nothing shared in this graph at this level
+                    if (lane == 0) *ne = 0;
+                    continue;
+                }
+                if (__builtin_popcountll(Ma) + __builtin_popcountll(Mb) <= GM_FEW || P.off[j + 1] - P.off[j] <= GM_FEW) {
+                    // few distinct labels (deep levels: a handful of shared nodes per graph; level 0: a handful of
+                    // labels): one wave-uniform round per distinct label -- take the first remaining node's label,
+                    // ballot its equals; entry k lands in lane k
+                    i32 mx = 0;
+                    u32 mc = 0;
+                    int k = 0;
+                    while (Ma | Mb) {
+                        const int src = Ma ? __builtin_ctzll(Ma) : __builtin_ctzll(Mb);
+                        const i32 x = Ma ? __builtin_amdgcn_readlane(a, src) : __builtin_amdgcn_readlane(b2, src);
+                        const u64 ea = __ballot(a == x), eb = __ballot(b2 == x);
+                        if (lane == k) mx = x, mc = (u32)(__builtin_popcountll(ea) + __builtin_popcountll(eb));
+                        Ma &= ~ea, Mb &= ~eb, ++k;
+                    }
+                    if (lane < k) el[lane] = mx, ec[lane] = mc;
+                    if (lane == 0) *ne = (u32)k;
+                    if (lane < k) emit(mx, mc);
+                    continue;
+                }
+                // ---- the graph's shared labels sorted in registers (two per lane: positions lane and lane + 64), a
+                // bitonic network of 28 compare-exchange steps on wave shuffles; equal labels are then neighbours
+#pragma unroll
+                for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+                    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                        if (jj == 64) {                      // partner = the lane's other register (only k == 128: ascending)
+                            const i32 lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+                            a = lo, b2 = hi;
+                        } else {
+                            const i32 pa = __shfl_xor(a, jj, 64), pb = __shfl_xor(b2, jj, 64);
+                            const bool lower = (lane & jj) == 0;
+                            // direction: ascending iff (position & k) == 0; position = lane (+ 64 for the second register)
+                            const bool asc_a = k == 128 ? true : (k == 64 ? true : (lane & k) == 0);
+                            const bool asc_b = k == 128 ? true : (k == 64 ? false : (lane & k) == 0);
+                            const i32 mna = a < pa ? a : pa, mxa = a < pa ? pa : a;
+                            const i32 mnb = b2 < pb ? b2 : pb, mxb = b2 < pb ? pb : b2;
+                            a = (lower == asc_a) ? mna : mxa;
+                            b2 = (lower == asc_b) ? mnb : mxb;
+                        }
+                    }
+                }
+                // ---- run heads and run lengths over the 128 sorted positions
+                const i32 up_a = __shfl_up(a, 1, 64), up_b = __shfl_up(b2, 1, 64), a63 = __shfl(a, 63, 64);
+                const bool ha = lane == 0 || a != up_a;
+                const bool hb = b2 != (lane == 0 ? a63 : up_b);
+                const u64 Ha = __ballot(ha), Hb = __ballot(hb);
+                const u64 above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+                const u64 ma = Ha & above, mb = Hb & above;
+                const int next_a = ma ? __builtin_ctzll(ma) : (Hb ? 64 + __builtin_ctzll(Hb) : 128);
+                const int next_b = mb ? 64 + __builtin_ctzll(mb) : 128;
+                const u32 ca = (ha && a != BIG) ? (u32)(next_a - lane) : 0u;
+                const u32 cb = (hb && b2 != BIG) ? (u32)(next_b - 64 - lane) : 0u;
+                // entries stored compactly: slots 0 .. ne - 1 of the graph's node range
+                const u64 Va = __ballot(ca != 0), Vb = __ballot(cb != 0);
+                const u64 below = (1ull << lane) - 1ull;
+                const int na = __builtin_popcountll(Va);
+                if (ca) { const int k = __builtin_popcountll(Va & below); el[k] = a, ec[k] = ca; }
+                if (cb) { const int k = na + __builtin_popcountll(Vb & below); el[k] = b2, ec[k] = cb; }
+                if (lane == 0) *ne = (u32)(na + __builtin_popcountll(Vb));
+                if (ca) emit(a, ca);
+                if (cb) emit(b2, cb);
+            } else {
+                // ---- larger graphs: open-addressing table in LDS (compare-and-swap insertion, the claimer owns the entry)
+                for (int t = lane; t < T; t += 64) keys[t] = -1, co[t] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < n; i += 64) {
+                    const i32 x = lab[v0 + i];
+                    if (x < base || (fl && !fl[v0 + i])) continue;
+                    u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+                    for (;;) {
+                        const i32 old = atomicCAS(&keys[h], -1, x);
+                        if (old == -1) { atomicAdd(&co[h], ((u32)i << 16) | 1u); break; }
+                        if (old == x) { atomicAdd(&co[h], 1u); break; }
+                        h = (h + 1u) & tmask;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int i = lane; i < n; i += 64) {
+                    const i32 x = lab[v0 + i];
+                    u32 c = 0;
+                    if (x >= base && (!fl || fl[v0 + i])) {
+                        u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+                        while (keys[h] != x) h = (h + 1u) & tmask;
+                        const u32 e = co[h];
+                        if ((e >> 16) == (u32)i) c = e & 0xffffu;
+                    }
+                    el[i] = x, ec[i] = c;
+                    if (c) emit(x, c);
+                }
+                if (lane == 0) *ne = (u32)n;                      // one slot per node, count 0 = no entry
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         for (int off = 32; off > 0; off >>= 1) extra += __shfl_down(extra, off, 64);
         if (lane == 0) selfk[g] = (u64)n * (u64)n_levels + extra;
@@ -156,13 +254,41 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels 
         const u32 o = __shfl_down(maxc, off, 64);
         maxc = o > maxc ? o : maxc;
     }
-    if (lane == 0) {
-        if (maxc) atomicMax(&meta[GM_META_MAXC + (blockIdx.x & 63)], maxc);
-        if (entries) atomicAdd(&meta[GM_META_NNZ + (blockIdx.x & 63)], entries);
-    }
+    // largest count / entries of this workgroup: one plain store per workgroup (thousands of atomics on two cache
+    // lines of meta[] serialise in one L2 channel); block 0 of gm_scan_apply_kernel folds them into meta[]
+    __syncthreads();                                   // the counting tables are done with: reuse their first words
+    u32* red = (u32*)(gm_lds + priv_words);
+    if (lane == 0) red[2 * w] = maxc, red[2 * w + 1] = entries;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 m = 0, e = 0;
+        for (int k = 0; k < WAVES; ++k) m = red[2 * k] > m ? red[2 * k] : m, e += red[2 * k + 1];
+        wgmeta[2 * blockIdx.x] = m, wgmeta[2 * blockIdx.x + 1] = e;
+    }
     u32* mine = part + (size_t)blockIdx.x * priv_words;
     for (int t = threadIdx.x; t < priv_words; t += blockDim.x) mine[t] = priv[t];
+}
+
+// Occupancy: the body needs ~106 SGPRs, and the 800-SGPR file of a SIMD then holds 6 waves -- ONE 16-wave workgroup
+// per CU, the other half of a 2-per-CU grid queues behind it (measured: waves live 30 us, the kernel 73 us).
+//   variant 0: 8-wave workgroups, three per CU (24 waves / CU), no register caps;
+//   variant 1: 16-wave workgroups, two per CU (32 waves / CU), SGPRs capped at 80 (spills to VGPR lanes / scratch).
+#define GM_WAVES_SMALL 8
+__global__ __launch_bounds__(64 * GM_WAVES_SMALL) void gm_pairs_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+                                                                const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
+                                                                i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
+                                                                u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
+                                                                int rectangular, u32 df_cap, int T, int prim_max,
+                                                                int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta) {
+    gm_pairs_body<GM_WAVES_SMALL>(P, A, R, graph_ptr, n_graphs, V, ent_lab, ent_cnt, ent_n, selfk, meta, n_levels, kind, n_fit, rectangular, df_cap, T, prim_max, wide_above, part, wgmeta);
+}
+__global__ __launch_bounds__(64 * GM_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(80))) void gm_pairs_capped_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+                                                                const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
+                                                                i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
+                                                                u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
+                                                                int rectangular, u32 df_cap, int T, int prim_max,
+                                                                int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta) {
+    gm_pairs_body<GM_WAVES>(P, A, R, graph_ptr, n_graphs, V, ent_lab, ent_cnt, ent_n, selfk, meta, n_levels, kind, n_fit, rectangular, df_cap, T, prim_max, wide_above, part, wgmeta);
 }
 
 // sum the workgroups' private histograms: df (saturating at what the column scan distinguishes), the count class as
@@ -228,6 +354,7 @@ __device__ __forceinline__ Gm3 gm3_shfl_down(const Gm3& x, int off) {
 
 struct GmColumns {
     GmLabelArrays A; i64 Q; int symmetric; int low_df; int kind; int prim_max; int wide_above; u32* meta;
+    const u32* wgmeta; int n_wg;                  // gm_pairs_kernel's per-workgroup (largest count, entries)
     __device__ __forceinline__ Gm3 value(i64 q) const {
         Gm3 v{0, 0, 0};
         const u32 df = A.df[q];
@@ -287,6 +414,15 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
     __shared__ Gm3 wsum[G3_THREADS / 64];
     __shared__ Gm3 bsum[G3_THREADS / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && w == 0) {                  // fold the pair kernel's per-workgroup statistics
+        u32 m = 0, e = 0;
+        for (int k = lane; k < f.n_wg; k += 64) m = f.wgmeta[2 * k] > m ? f.wgmeta[2 * k] : m, e += f.wgmeta[2 * k + 1];
+        for (int off = 32; off > 0; off >>= 1) {
+            const u32 o = __shfl_down(m, off, 64);
+            m = o > m ? o : m, e += __shfl_down(e, off, 64);
+        }
+        if (lane == 0) f.meta[GM_META_MAXC] = m, f.meta[GM_META_NNZ] = e;
+    }
     Gm3 s{0, 0, 0};
     for (int i = threadIdx.x; i < (int)blockIdx.x; i += G3_THREADS) s += partial[i];
     for (int off = 32; off > 0; off >>= 1) s += gm3_shfl_down(s, off);
@@ -328,21 +464,25 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
 
 // one workgroup per graph: the operand row in LDS (row_bytes <= GM_ROW_LDS_MAX), written once
 __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const GmLabelArrays A,
-                                                      const i32* __restrict__ graph_ptr, i64 V, const u32* __restrict__ cnt,
+                                                      const i32* __restrict__ graph_ptr, i64 V, const i32* __restrict__ ent_lab,
+                                                      const u32* __restrict__ cnt, const u32* __restrict__ ent_n, i64 n_graphs,
                                                       int8_t* __restrict__ phi, i64 ld, i64 prim0 /* first byte of the primary region */,
                                                       int fp4, int kind, double* __restrict__ phi_w, i64 ldw,
                                                       i32* __restrict__ low_graph, i32* __restrict__ low_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row[];
     const i64 g = blockIdx.x;
     const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
+    __shared__ u32 slots[FEAT_MAX_LEVELS];                       // entries of this graph per level
+    if ((int)threadIdx.x < P.L) slots[threadIdx.x] = ent_n[(i64)threadIdx.x * n_graphs + g];
     for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) ((uint4*)row)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int n = v1 - v0;
     for (int t = threadIdx.x; t < n * P.L; t += blockDim.x) {
         const int j = t / n, i = t - j * n;
+        if ((u32)i >= slots[j]) continue;
         const u32 c = cnt[(i64)j * V + v0 + i];
         if (!c) continue;
-        const i64 q = P.off[j] + (P.lab[j][v0 + i] - P.id_base[j]);
+        const i64 q = P.off[j] + (ent_lab[(i64)j * V + v0 + i] - P.id_base[j]);
         const i32 col = A.colid[q];
         if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;          // secondary int8 region: bytes [0, prim0)
         else if (col >= 0) {
@@ -427,43 +567,51 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         *a = (i32*)q;
         f->arena.push_back(q);
     }
-    Tmp<u32> cnt(ctx);
+    Tmp<u32> cnt(ctx);           // the graphs' entries: slot v of level j = (label ent.p[..], count cnt.p[..]), count 0 = no entry
+    Tmp<i32> ent(ctx);
     GK_TRY(cnt.alloc((size_t)(P.L > 0 ? P.L : 1) * (size_t)(V > 0 ? V : 1)));
+    GK_TRY(ent.alloc((size_t)(P.L > 0 ? P.L : 1) * (size_t)(V > 0 ? V : 1)));
+    Tmp<u32> ent_n(ctx);         // entries (slots in use) per level and graph
+    GK_TRY(ent_n.alloc((size_t)(P.L > 0 ? P.L : 1) * (size_t)(N > 0 ? N : 1)));
     const int rectangular = f->symmetric ? 0 : 1;
     int T = 64;
     while (T < 2 * b->max_graph_nodes) T <<= 1;
     // ---- which levels count in workgroup-private histograms (small label spaces first come, 32 K bins in all)
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    i64 grid = cdiv(N, GM_WAVES);
-    if (grid > 2 * (i64)n_cu) grid = 2 * (i64)n_cu;
-    // two 1024-thread workgroups per CU: 160 KiB / 2 = private histogram + 16 counting tables
-    const i64 priv_budget = std::max<i64>(0, (80 * 1024 - 1024 - (i64)GM_WAVES * 2 * T * 4) / 2);
+    static const int variant = getenv("GK_GM_VARIANT") ? atoi(getenv("GK_GM_VARIANT")) : 0;
+    const int waves = variant ? GM_WAVES : GM_WAVES_SMALL, per_cu = variant ? 2 : 3;
+    i64 grid = cdiv(N, waves);
+    if (grid > per_cu * (i64)n_cu) grid = per_cu * (i64)n_cu;
+    // per_cu workgroups share a CU's 160 KiB: private histogram + one counting table per wave
+    const i64 priv_budget = std::max<i64>(0, (160 * 1024 / per_cu - 1024 - (i64)waves * 2 * T * 4) / 2);
     GmPriv R;
     R.bins = 0;
-    const bool priv_ok = kind == GK_FEAT_DOT && !getenv("GK_GM_NO_PRIV") && cdiv(N, grid * GM_WAVES) + 1 < (i64)GM_PRIV_COUNT_MASK;
+    const bool priv_ok = kind == GK_FEAT_DOT && !getenv("GK_GM_NO_PRIV") && cdiv(N, grid * waves) + 1 < (i64)GM_PRIV_COUNT_MASK;
     for (int j = 0; j < FEAT_MAX_LEVELS; ++j) R.off[j] = -1;
     for (int j = 0; j < P.L; ++j) {
         const i64 ids = P.off[j + 1] - P.off[j];
         if (priv_ok && ids > 0 && R.bins + ids <= priv_budget) R.off[j] = R.bins, R.bins += (int)ids;
     }
     R.bins = (R.bins + 1) & ~1;
-    const size_t pairs_lds = (size_t)R.bins * 2 + (size_t)GM_WAVES * 2 * T * 4;
+    const size_t pairs_lds = (size_t)R.bins * 2 + (size_t)waves * 2 * T * 4;
     GK_ARG(pairs_lds <= 160 * 1024, "gk_features_build: graph too large for the graph-major builder");
     static size_t pairs_lds_set = 0;
     if (pairs_lds > 48 * 1024 && pairs_lds > pairs_lds_set) {
         GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
+        GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_pairs_capped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
         pairs_lds_set = pairs_lds;
     }
-    Tmp<u32> part(ctx);
+    Tmp<u32> part(ctx), wgmeta(ctx);
+    GK_TRY(wgmeta.alloc((size_t)grid * 2));
     GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
-    gm_pairs_kernel<<<dim3((unsigned)grid), 64 * GM_WAVES, pairs_lds, ctx->stream>>>(
-        P, A, R, b->graph_ptr, N, V, cnt.p, f->selfk, f->meta, n_levels, kind, f->n_fit, rectangular,
-        (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p);
+    (variant ? gm_pairs_capped_kernel : gm_pairs_kernel)<<<dim3((unsigned)grid), 64 * waves, pairs_lds, ctx->stream>>>(
+        P, A, R, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, f->selfk, f->meta, n_levels, kind, f->n_fit, rectangular,
+        (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p, wgmeta.p);
     if (R.bins > 0)
         gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(P, A, R, part.p, (int)grid, prim_max, wide_above, rectangular);
     std::vector<u32> h(GM_META_WORDS, 0);
     if (Q > 0) {
-        GmColumns gc{A, Q, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta};
+        GmColumns gc{A, Q, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta.p, (int)grid};
         const i64 nblk = cdiv(Q, G3_TILE);
         Tmp<Gm3> partial(ctx);
         GK_TRY(partial.alloc((size_t)nblk));
@@ -510,7 +658,7 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         attr_set = true;
     }
     gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
-        P, A, b->graph_ptr, V, cnt.p, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
+        P, A, b->graph_ptr, V, ent.p, cnt.p, ent_n.p, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
         f->n_cols_wide_pad, lg, lc);
     const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
     gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
