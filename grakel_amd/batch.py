@@ -32,16 +32,19 @@ class GraphBatch(object):
 
     graph_ptr[n_graphs+1], row_ptr[n_nodes+1], col_idx[n_edges] (global node ids),
     node_label[n_nodes] (dense level-0 ids), n_labels (ids are < n_labels),
-    edge_weight[n_edges] or None (ShortestPath only).
+    edge_weight[n_edges] or None (ShortestPath only): positive integers; the weight of an edge
+    is edge_weight * weight_step (weight_step is 1.0 unless the input had float weights that are
+    integer multiples of a common power of two, see quantise_weights()).
     """
 
-    def __init__(self, graph_ptr, row_ptr, col_idx, node_label, n_labels, edge_weight=None):
+    def __init__(self, graph_ptr, row_ptr, col_idx, node_label, n_labels, edge_weight=None, weight_step=1.0):
         self.graph_ptr = np.ascontiguousarray(graph_ptr, dtype=np.int32)
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
         self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
         self.node_label = np.ascontiguousarray(node_label, dtype=np.int32)
         self.n_labels = int(n_labels)
         self.edge_weight = None if edge_weight is None else np.ascontiguousarray(edge_weight, np.int32)
+        self.weight_step = float(weight_step)
         if self.row_ptr.shape[0] != self.node_label.shape[0] + 1:
             raise ValueError("GraphBatch: row_ptr must have n_nodes+1 entries")
         if int(self.graph_ptr[-1]) != self.n_nodes or int(self.row_ptr[-1]) != self.n_edges:
@@ -64,20 +67,69 @@ class GraphBatch(object):
         e0, e1 = int(self.row_ptr[v0]), int(self.row_ptr[v1])
         ew = None if self.edge_weight is None else self.edge_weight[e0:e1]
         return GraphBatch(self.graph_ptr[lo:hi + 1] - v0, self.row_ptr[v0:v1 + 1] - e0,
-                          self.col_idx[e0:e1] - v0, self.node_label[v0:v1], self.n_labels, ew)
+                          self.col_idx[e0:e1] - v0, self.node_label[v0:v1], self.n_labels, ew,
+                          getattr(self, "weight_step", 1.0))
 
     @staticmethod
     def concat(a, b):
         """Union batch: graphs of ``a`` first, then graphs of ``b`` (transform = fit + targets)."""
-        ew = None
+        ew, step = None, 1.0
         if a.edge_weight is not None and b.edge_weight is not None:
-            ew = np.concatenate([a.edge_weight, b.edge_weight])
+            # one weight unit for the union: the finer of the two steps (both are powers of two)
+            sa, sb = getattr(a, "weight_step", 1.0), getattr(b, "weight_step", 1.0)
+            step = min(sa, sb)
+            wa = a.edge_weight.astype(np.int64) * int(round(sa / step))
+            wb = b.edge_weight.astype(np.int64) * int(round(sb / step))
+            for w in (wa, wb):
+                if w.size and int(w.max()) >= MAX_EDGE_WEIGHT:
+                    raise NotImplementedError('edge weights of the fitted and the target graphs need more than '
+                                              '20 bits at their common power-of-two step')
+            ew = np.concatenate([wa, wb])
         return GraphBatch(
             np.concatenate([a.graph_ptr, b.graph_ptr[1:] + a.n_nodes]),
             np.concatenate([a.row_ptr, b.row_ptr[1:] + a.n_edges]),
             np.concatenate([a.col_idx, b.col_idx + a.n_nodes]),
             np.concatenate([a.node_label, b.node_label]),
-            max(a.n_labels, b.n_labels), ew)
+            max(a.n_labels, b.n_labels), ew, step)
+
+
+MAX_EDGE_WEIGHT = 2 ** 20        # int32 distances: sp.hip guards (n - 1) * max weight < SP_INF per batch
+
+
+def quantise_weights(weights):
+    """Positive edge weights of a whole batch (list of arrays) -> (list of int64 arrays, step).
+
+    The reference keys ShortestPath features by the float distance itself (shortest_path.py:389,
+    graph.py:1767-1794: float sums of the weights along a path), so two pairs share a feature iff their
+    float sums are equal.  When every weight is an integer multiple of one power of two ``step`` and the
+    multiples stay below 2**20, every path sum is exact in float64 and equals ``step`` times the integer
+    sum: integer distances on the device then give exactly the reference's equalities (and
+    ``d * step`` is the reference's key).  Integral inputs keep step 1.  Anything else (0.1, 1/3, ...:
+    the reference's own sums then depend on rounding and on the order of addition) is declined.
+    """
+    flat = np.concatenate([np.asarray(w, np.float64).ravel() for w in weights]) if weights else np.zeros(0)
+    if flat.size == 0:
+        return [np.zeros(0, np.int64) for _ in weights], 1.0
+    if not np.all(np.isfinite(flat)) or flat.min() <= 0:
+        raise NotImplementedError('ShortestPath on MI355X supports positive finite edge weights only')
+    if np.array_equal(np.rint(flat), flat):
+        step_exp = 0
+    else:
+        m, e = np.frexp(flat)                                 # flat = m * 2**e, 0.5 <= m < 1
+        M = np.ldexp(m, 53).astype(np.int64)                  # the 53-bit mantissa as an integer
+        tz = np.log2((M & -M).astype(np.float64)).astype(np.int64)
+        step_exp = int((e.astype(np.int64) - 53 + tz).min())  # exponent of the lowest set bit of any weight
+    out = []
+    for w in weights:
+        k = np.ldexp(np.asarray(w, np.float64), -step_exp)
+        ki = np.rint(k).astype(np.int64)
+        if k.size and (not np.array_equal(ki, k) or ki.max() >= MAX_EDGE_WEIGHT):
+            raise NotImplementedError(
+                'ShortestPath on MI355X supports edge weights that are integers below 2**20, or float weights '
+                'that are integer multiples (below 2**20) of one common power of two (0.5, 1.25, ...); other '
+                'float weights make the reference use rounded float sums as dictionary keys (SURVEY.md 7.5c)')
+        out.append(ki)
+    return out, float(np.ldexp(1.0, step_exp))
 
 
 # ------------------------------------------------------------------------------------------
@@ -471,22 +523,16 @@ def _sp_graph_arrays(gobj, labels, with_labels):
             for b, w in d.items():
                 src.append(ia), dst.append(pos[b]), wl.append(w)
         ii, jj, ww = np.asarray(src, np.int64), np.asarray(dst, np.int64), np.asarray(wl)
-    if ww.size:
-        wi = np.rint(ww).astype(np.int64)
-        if not np.array_equal(wi, ww) or wi.min() <= 0:
-            raise NotImplementedError('ShortestPath on MI355X supports positive integer edge '
-                                      'weights only (float weights make the reference use float '
-                                      'sums as dictionary keys, SURVEY.md 7.5c)')
-        if wi.max() >= 2 ** 20:
-            raise NotImplementedError('edge weight too large for the int32 distance path')
-    else:
-        wi = np.zeros(0, np.int64)
+    try:                                             # integers come later, per batch (quantise_weights)
+        ww = np.asarray(ww, np.float64) if ww.size else np.zeros(0, np.float64)
+    except (TypeError, ValueError):
+        raise NotImplementedError('ShortestPath on MI355X needs numeric edge weights')
     vals = None
     if with_labels:
         if not labels:
             raise ValueError('Graph does not have any labels for vertices.')   # graph.py:737-738
         vals = [labels[v] for v in verts]            # KeyError when a vertex has no label
-    return n, vals, ii, jj, wi
+    return n, vals, ii, jj, ww
 
 
 def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_iterable=TypeError):
@@ -527,7 +573,8 @@ def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_ite
         n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
     else:
         ids, mapping, n_labels = np.zeros(int(np.sum(sizes)), np.int32), {}, 1
+    wts, step = quantise_weights(wts)
     graph_ptr, row_ptr, col, w = _pack_csr(sizes, srcs, dsts, wts)
     if w is None:
         w = np.zeros(0, np.int64)
-    return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1), edge_weight=w), mapping
+    return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1), edge_weight=w, weight_step=step), mapping

@@ -169,11 +169,13 @@ class ShortestPath(Kernel):
             lab = gb.node_label[v0:v1].tolist()
             row = dict()
             us, vs = np.nonzero((S >= 0) & ~np.eye(n, dtype=bool))
+            step = getattr(gb, "weight_step", 1.0)        # float weights: device distances count this unit
             for u, v, d in zip(us.tolist(), vs.tolist(), S[us, vs].tolist()):
+                d = float(d) * step
                 if self.with_labels:
-                    key = (inv[lab[u]], inv[lab[v]], float(d)) if inv is not None else (lab[u], lab[v], float(d))
+                    key = (inv[lab[u]], inv[lab[v]], d) if inv is not None else (lab[u], lab[v], d)
                 else:
-                    key = float(d)
+                    key = d
                 idx = enum.get(key)
                 if idx is None:
                     idx = new_enum.get(key)

@@ -33,7 +33,7 @@ from grakel.datasets.base import read_data  # noqa: E402
 
 from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs  # noqa: E402
 sys.path.insert(0, HERE)
-from small_sets import SMALL_SETS, split, sp_inputs  # noqa: E402
+from small_sets import SMALL_SETS, split, sp_inputs, sp_dyadic_graphs  # noqa: E402
 
 warnings.filterwarnings("ignore")
 
@@ -150,6 +150,29 @@ def mutag():
         wl5_label_counts=np.array([len(wl5._inv_labels[i]) for i in range(6)], np.int64))
     print("MUTAG sums", K_vh.sum(), K_wl.sum(), K_sp.sum(), "traces",
           np.trace(K_vh), np.trace(K_wl), np.trace(K_sp))
+
+
+def sp_dyadic():
+    """ShortestPath on float edge weights that are multiples of a power of two: the
+    reference's Gram matrices, and its ``_enum`` keys (float distances) for the fitted-state comparison."""
+    G = sp_dyadic_graphs()
+    tr, te = G[:16], G[16:]
+    out = {}
+    for name, kw in (("auto", {}), ("fw", dict(algorithm_type="floyd_warshall"))):
+        sp = ShortestPath(normalize=False, **kw)
+        out["K_fit_" + name] = as_int(sp.fit_transform(tr))
+        out["K_tr_" + name] = as_int(sp.transform(te))
+        keys = sorted(sp._enum.items(), key=lambda kv: kv[1])
+        out["enum_labels_" + name] = np.array([[k[0], k[1]] for k, _ in keys])
+        out["enum_dist_" + name] = np.array([float(k[2]) for k, _ in keys])
+    spn = ShortestPath(normalize=True)
+    out["K_fit_norm"] = spn.fit_transform(tr)
+    out["K_tr_norm"] = spn.transform(te)
+    spu = ShortestPath(normalize=False, with_labels=False)
+    out["K_fit_unlabelled"] = as_int(spu.fit_transform([[g[0]] for g in tr]))
+    np.savez_compressed(os.path.join(HERE, "sp_dyadic.npz"), **out)
+    print("sp_dyadic: fit", out["K_fit_auto"].shape, "sum", int(out["K_fit_auto"].sum()), "features", len(out["enum_dist_auto"]),
+          "auto == fw:", bool(np.array_equal(out["K_fit_auto"], out["K_fit_fw"])))
 
 
 def mutag_state(n_graphs=60):
@@ -291,8 +314,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip config 3 (~100 s) and NCI1-4110")
     ap.add_argument("--only-state", action="store_true", help="only the fitted-state fixture (mutag_state.npz)")
+    ap.add_argument("--only-dyadic", action="store_true", help="only the float-weight ShortestPath fixture (sp_dyadic.npz)")
     a = ap.parse_args()
     print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
+    sp_dyadic()
+    if a.only_dyadic:
+        sys.exit(0)
     mutag_state()
     if a.only_state:
         sys.exit(0)

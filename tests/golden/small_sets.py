@@ -30,3 +30,25 @@ def sp_inputs(kw, graphs):
                 A[a, b] = 1
         out.append([A, g[1]])
     return out
+
+
+def sp_dyadic_graphs(n_graphs=24, seed=11):
+    """Weighted graphs whose float edge weights are multiples of 1/8 (0.125 .. 4.0): every path sum is exact
+    in float64, so the reference's float distance keys are well defined (graph.py:1767-1794).  Adjacency
+    matrices (symmetric) and, for every third graph, a weighted edge dictionary."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for g in range(n_graphs):
+        n = int(rs.randint(4, 12))
+        A = np.zeros((n, n))
+        for i in range(n):
+            for j in range(i + 1, n):
+                if rs.rand() < 0.35:
+                    A[i, j] = A[j, i] = rs.randint(1, 33) / 8.0
+        lab = {i: "xyz"[int(rs.randint(0, 3))] for i in range(n)}
+        if g % 3 == 2:
+            d = {i: {j: float(A[i, j]) for j in range(n) if A[i, j] > 0} for i in range(n)}
+            out.append([d, lab])
+        else:
+            out.append([A, lab])
+    return out

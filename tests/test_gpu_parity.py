@@ -11,7 +11,7 @@ import pickle
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import GOLDEN, load_golden
 from golden.small_sets import SMALL_SETS, split, sp_inputs
 from oracle import grakel_oracle as O
 from grakel_amd.synthetic import (er_dataset, er_dataset_csr, nci1_like, random_labelled_graphs)
@@ -413,6 +413,40 @@ def test_nci1_like_sp_against_reference_goldens(gk):
     assert np.array_equal(np.diagonal(K), z["diag"])
     assert np.array_equal(K[z["samp_i"], z["samp_j"]], z["samp_v"])
     assert np.array_equal(K.sum(axis=1), z["row_sums"])
+
+
+def test_sp_float_weights_against_reference_goldens(gk):
+    """Float edge weights that are integer multiples of a power of two (here 1/8): integer distances in that
+    unit on the device, the reference's matrices and float-keyed ``_enum`` (graph.py:1767-1794,
+    shortest_path.py:389).  Other float weights are declined (tests/test_host.py)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from small_sets import sp_dyadic_graphs
+    z = load_golden("sp_dyadic.npz")
+    G = sp_dyadic_graphs()
+    tr, te = G[:16], G[16:]
+    for name, algo in (("auto", "auto"), ("fw", "floyd_warshall")):
+        sp = gk.ShortestPath(algorithm_type=algo)
+        assert np.array_equal(sp.fit_transform(tr), z["K_fit_" + name])
+        assert np.array_equal(sp.transform(te), z["K_tr_" + name])
+        keys = sorted(sp._enum.items(), key=lambda kv: kv[1])
+        assert [[k[0], k[1]] for k, _ in keys] == z["enum_labels_" + name].tolist()
+        assert [float(k[2]) for k, _ in keys] == z["enum_dist_" + name].tolist()
+    spn = gk.ShortestPath(normalize=True)
+    assert np.allclose(spn.fit_transform(tr), z["K_fit_norm"], rtol=1e-5, atol=0)
+    assert np.allclose(spn.transform(te), z["K_tr_norm"], rtol=1e-5, atol=0)
+    assert np.array_equal(gk.ShortestPath(with_labels=False).fit_transform([[g[0]] for g in tr]), z["K_fit_unlabelled"])
+    # targets with integer weights against a fit in units of 1/8: the union counts in the finer unit
+    sp = gk.ShortestPath()
+    sp.fit(tr)
+    ints = [[np.rint(np.asarray(g[0]) * 8), g[1]] for g in te if not isinstance(g[0], dict)]
+    eighths = [[np.asarray(g[0]) * 8 / 8.0, g[1]] for g in te if not isinstance(g[0], dict)]
+    spo = O.SPOracle()
+    spo.fit_transform(tr)
+    assert np.array_equal(sp.transform(ints), spo.transform(ints))
+    assert np.array_equal(sp.transform(eighths), spo.transform(eighths))
+    with pytest.raises(NotImplementedError):
+        gk.ShortestPath().fit_transform([[np.array([[0, 0.1], [0.1, 0]]), {0: 'a', 1: 'b'}]])
 
 
 def test_errors_match_reference(gk):

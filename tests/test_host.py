@@ -329,10 +329,40 @@ def test_sp_ingestion_vertex_order_weights_and_errors():
     assert gb.node_label.tolist() == [0, 1, 0]
     with pytest.raises(ValueError):                      # no labels with with_labels=True
         sp_batch_from_input([[{0: [1], 1: [0]}, {}]], True)
-    with pytest.raises(NotImplementedError):             # float weights are out of scope
-        sp_batch_from_input([[{(0, 1): 0.5}, {0: 1, 1: 1}]], True)
+    with pytest.raises(NotImplementedError):             # not a multiple of a power of two: declined
+        sp_batch_from_input([[{(0, 1): 0.1}, {0: 1, 1: 1}]], True)
     gb, _ = sp_batch_from_input([[np.array([[0, 3], [0, 0]])]], False)
     assert gb.edge_weight.tolist() == [3] and gb.n_labels == 1
+
+
+def test_float_edge_weights_are_quantised_exactly_or_declined():
+    """quantise_weights: one power-of-two unit per batch, multiples below 2**20, exact or NotImplementedError."""
+    from grakel_amd.batch import quantise_weights, GraphBatch
+    ints, step = quantise_weights([np.array([0.5, 1.25, 3.0]), np.array([2.0])])
+    assert step == 0.25 and [a.tolist() for a in ints] == [[2, 5, 12], [8]]
+    assert quantise_weights([np.array([2.0, 4.0])])[1] == 1.0             # integral input keeps the unit 1
+    assert quantise_weights([np.array([2.0 ** -20, 1.0 - 2.0 ** -20])])[1] == 2.0 ** -20
+    for bad in ([0.1], [1.0 / 3], [2.0 ** 20], [2.0 ** -30, 1.0], [0.0], [-0.5], [np.inf], [np.nan]):
+        with pytest.raises(NotImplementedError):
+            quantise_weights([np.array(bad)])
+    # every path sum of such weights is exact: the integer distances times the step are the float distances
+    rs = np.random.RandomState(5)
+    w = rs.randint(1, 2 ** 12, size=200) / 64.0
+    ints, step = quantise_weights([w])
+    for _ in range(50):
+        idx = rs.randint(0, 200, size=30)
+        assert float(np.sum(w[idx])) == float(ints[0][idx].sum()) * step
+    # the union of a fitted and a target batch counts in the finer unit
+    A = np.array([[0, 0.5, 0], [0.5, 0, 1.25], [0, 1.25, 0]])
+    a, _ = sp_batch_from_input([[A, {0: 'a', 1: 'b', 2: 'a'}]], True)
+    b, _ = sp_batch_from_input([[np.array([[0, 3], [3, 0]]), {0: 'a', 1: 'b'}]], True)
+    assert a.weight_step == 0.25 and a.edge_weight.tolist() == [2, 2, 5, 5] and b.weight_step == 1.0
+    u = GraphBatch.concat(a, b)
+    assert u.weight_step == 0.25 and u.edge_weight.tolist() == [2, 2, 5, 5, 12, 12]
+    assert a.slice_graphs(0, 1).weight_step == 0.25
+    big, _ = sp_batch_from_input([[np.array([[0, 2 ** 19], [2 ** 19, 0]]), {0: 'a', 1: 'b'}]], True)
+    with pytest.raises(NotImplementedError):
+        GraphBatch.concat(a, big)
 
 
 def test_vh_reads_only_the_label_dict():

@@ -173,6 +173,28 @@ def test_nci1_like_sp_against_reference():
     assert np.array_equal(K, K2)
 
 
+def test_sp_float_weights_against_reference():
+    """Float edge weights that are multiples of 1/8: the reference keys features by the float distance
+    (shortest_path.py:389, graph.py:1767-1794); the oracle keeps float distances and must give its matrices."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from small_sets import sp_dyadic_graphs
+    z = load_golden("sp_dyadic.npz")
+    G = sp_dyadic_graphs()
+    tr, te = G[:16], G[16:]
+    for name, algo in (("auto", "auto"), ("fw", "floyd_warshall")):
+        sp = O.SPOracle(algorithm_type=algo)
+        assert np.array_equal(sp.fit_transform(tr), z["K_fit_" + name])
+        assert np.array_equal(sp.transform(te), z["K_tr_" + name])
+        keys = sorted(sp.enum.items(), key=lambda kv: kv[1])
+        assert [[k[0], k[1]] for k, _ in keys] == z["enum_labels_" + name].tolist()
+        assert [float(k[2]) for k, _ in keys] == z["enum_dist_" + name].tolist()
+    spn = O.SPOracle(normalize=True)
+    assert np.allclose(spn.fit_transform(tr), z["K_fit_norm"], rtol=1e-12, atol=0)
+    assert np.allclose(spn.transform(te), z["K_tr_norm"], rtol=1e-12, atol=0)
+    assert np.array_equal(O.SPOracle(with_labels=False).fit_transform([[g[0]] for g in tr]), z["K_fit_unlabelled"])
+
+
 def test_error_behaviour_matches_reference():
     # weisfeiler_lehman.py:143-144,193-194 ; shortest_path.py:251-252
     with pytest.raises(TypeError):
