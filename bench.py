@@ -81,9 +81,10 @@ def cpu_info():
 
 def cpu_baseline(sample_graphs, cfg):
     """The CPU oracle (a literal restatement of the reference's algorithm, oracle/grakel_oracle.py) on a
-    bounded sample of the same workload: the first `sample_graphs` graphs of the generator, ONE host core
-    (the reference's only parallel mode, n_jobs, hands pairwise kernel calls to joblib threads; the WL /
-    VertexHistogram path computes its matrices with one scipy product per level and never uses it)."""
+    bounded sample of the same workload: the first `sample_graphs` graphs of the generator.  Two legs, as
+    SURVEY.md 8d asks: n_jobs=None (ONE host core; `value`) and n_jobs = number of WL levels (the only
+    parallelism the reference has on this path: joblib runs the per-level base-kernel products side by side,
+    weisfeiler_lehman.py:271-283; more workers than levels cannot be used)."""
     from oracle import grakel_oracle as O
     from grakel_amd.synthetic import er_dataset
     X = er_dataset(sample_graphs, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])
@@ -91,11 +92,22 @@ def cpu_baseline(sample_graphs, cfg):
     K = O.WLOracle(n_iter=cfg["n_iter"]).fit_transform(X)
     dt = time.perf_counter() - t0
     model, nproc = cpu_info()
+    jobs = min(cfg["n_iter"] + 1, max(nproc, 1))
+    ksum = int(K.sum())
+    del K
+    t0 = time.perf_counter()
+    Kj = O.WLOracle(n_iter=cfg["n_iter"]).fit_transform(X, n_jobs=jobs)
+    dtj = time.perf_counter() - t0
+    same = int(Kj.sum()) == ksum
+    del Kj
     return dict(value=sample_graphs * sample_graphs / dt, unit="graph-pairs/s", cores=1, kind="port",
                 cpu_model=model, host_cores_available=nproc,
+                n_jobs=dict(value=sample_graphs * sample_graphs / dtj, cores=jobs, seconds=round(dtj, 2), same_K_sum=same,
+                            note="per-level products in %d worker processes (the reference's joblib granularity); "
+                                 "the relabel loop and the sum of the level matrices stay on one core" % jobs),
                 sample="first %d graphs of the %d-graph generator (n=%d p=%.2f h=%d), oracle.WLOracle.fit_transform, "
                        "%.1f s, K sum %d; the cost is ~N^2 (one dense N x N float64 per level), so the full-size rate "
-                       "is at or below this one" % (sample_graphs, cfg["N"], cfg["n"], cfg["p"], cfg["n_iter"], dt, int(K.sum())),
+                       "is at or below this one" % (sample_graphs, cfg["N"], cfg["n"], cfg["p"], cfg["n_iter"], dt, ksum),
                 reference_real="grakel 0.1.11 itself, full config 3, one core of the build container (Intel Xeon "
                                "2.1 GHz): 93.1 s = 1.07e6 graph-pairs/s (tests/golden/er_config3.npz: ref_seconds); "
                                "it cannot travel to the GPU box")

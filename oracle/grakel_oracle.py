@@ -222,13 +222,20 @@ def _credential(L, ed, v):
     return str(L[v]) + "," + str(sorted([L[n] for n in ed.get(v, dict()).keys()]))
 
 
+def _level_gram(phi):
+    return (phi @ phi.T).toarray()                                     # vertex_histogram.py:156-184
+
+
 class WLOracle(object):
     """WeisfeilerLehman(base_graph_kernel=VertexHistogram)."""
 
     def __init__(self, n_iter=5, normalize=False):
         self.n_iter, self.normalize = n_iter, normalize
 
-    def fit_transform(self, X, keep_levels=False):
+    def fit_transform(self, X, keep_levels=False, n_jobs=None):
+        """n_jobs > 1: the per-level base-kernel products run in worker processes, as the reference hands
+        ``efit_transform(base_graph_kernel[i], level i)`` to joblib (weisfeiler_lehman.py:271-283); the relabel
+        loop itself stays sequential there too (it is the generator joblib consumes)."""
         eds, L = _wl_ingest(X)
         n_lev = self.n_iter + 1                                        # weisfeiler_lehman.py:114
         inv0 = {dv: i for i, dv in enumerate(sorted({l for d in L for l in d.values()}))}
@@ -250,7 +257,12 @@ class WLOracle(object):
             cols = dict()
             phi = vh_features(L, cols)                                 # weisfeiler_lehman.py:269
             self.vh.append((phi, cols))
-            mats.append((phi @ phi.T).toarray())
+            if not n_jobs or n_jobs <= 1:
+                mats.append((phi @ phi.T).toarray())
+        if n_jobs and n_jobs > 1:
+            import multiprocessing
+            with multiprocessing.get_context("fork").Pool(min(int(n_jobs), n_lev)) as pool:
+                mats = pool.map(_level_gram, [phi for phi, _ in self.vh])
         K = np.sum(mats, axis=0)                                       # weisfeiler_lehman.py:270
         self.label_counts = [len(self.inv_labels[i]) for i in range(n_lev)]
         self.x_diag = np.diagonal(K).copy()
