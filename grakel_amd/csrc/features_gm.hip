@@ -657,7 +657,10 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GM_ROW_LDS_MAX));
         attr_set = true;
     }
-    gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
+    // one workgroup per graph; a graph has ~n entries, so small workgroups (more of them per CU) hide the
+    // dependent loads (entry -> column id) better than wide ones
+    static const int rows_threads = getenv("GK_GM_ROWS_THREADS") ? atoi(getenv("GK_GM_ROWS_THREADS")) : 256;
+    gm_rows_kernel<<<dim3((unsigned)N), rows_threads, (size_t)f->n_cols_pad, ctx->stream>>>(
         P, A, b->graph_ptr, V, ent.p, cnt.p, ent_n.p, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
         f->n_cols_wide_pad, lg, lc);
     const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;

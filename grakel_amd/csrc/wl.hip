@@ -268,8 +268,10 @@ struct ActiveScan {
     const u32* extra;          // one more word to report (largest top-digit bucket of the last sort)
     u32* mbox; u32 seq;        // host mailbox (null: the host reads total_out / extra back itself)
     const i32* iso_info;       // gk_batch::iso_info (null: no isolated vertices): those are carried, never active
+    const unsigned char* shared;   // not null: the previous level left "class of two or more" bytes instead of frozen[]
     __device__ __forceinline__ u32 value(i64 v) const {
-        return (frozen[v] || (iso_info && iso_info[v] < 0)) ? 0u : 1u;
+        const bool fr = shared ? !shared[v] : frozen[v] != 0u;
+        return (fr || (iso_info && iso_info[v] < 0)) ? 0u : 1u;
     }
     __device__ __forceinline__ void emit(i64 v, u32 a, u32 incl) const {
         if (a) { act[incl - 1] = (u32)v; fidx[v] = 0xffffffffu; return; }
@@ -1070,7 +1072,8 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
                                 i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr,
                                 u32* listed_dev = nullptr, u32* posted_seq = nullptr, u32 lab_base = 0,
                                 const u32* lab_base_dev = nullptr, unsigned char* shared_out = nullptr,
-                                u32* no_order_overflow = nullptr) {
+                                u32* no_order_overflow = nullptr, bool* frozen_in_shared = nullptr) {
+    if (frozen_in_shared) *frozen_in_shared = false;
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         if (listed_dev) GK_TRY(gk_zero_async(ctx, listed_dev, 4));
@@ -1087,8 +1090,12 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
         // the level is redone by the sorting path (gk_wl_relabel)
         const u32 seq = posted_seq ? gk_mbox_begin(ctx) : 0u;
         if (posted_seq) *posted_seq = seq;
-        return gk_bucket_dictionary(ctx, keys, n, key_bits, lab, rep, frozen, shared_out, count_dev, listed_dev, top_digit_max,
-                                    no_order_overflow, seq ? ctx->mbox_dev : nullptr, seq);
+        // singleton flags: one scattered byte per node (shared_out) instead of a byte and a word -- the only reader of
+        // frozen[] after a full level, ActiveScan, takes the bytes
+        const bool bytes_only = shared_out && frozen_in_shared && !getenv("GK_WL_FROZEN_WORDS");
+        if (bytes_only) *frozen_in_shared = true;
+        return gk_bucket_dictionary(ctx, keys, n, key_bits, lab, rep, bytes_only ? nullptr : frozen, shared_out, count_dev, listed_dev,
+                                    top_digit_max, no_order_overflow, seq ? ctx->mbox_dev : nullptr, seq);
     }
     if (listed_dev && !vals) {
         Tmp<u32> sorted(ctx);
@@ -1134,6 +1141,9 @@ struct RelabelState {
     bool split = true;                     // GK_WL_NO_SPLIT: keep the plain label-grouped order
     u32 posted_seq = 0;                    // mailbox message {listed nodes, top-digit max} of the previous (full) level
     Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active, [2] = top-digit max
+    bool frozen_in_shared = false;         // the last full level wrote its singleton flags to shared_flag only (never with
+                                           // GK_WL_NO_LISTSCAN: every level then scans frozen[] of all nodes)
+    const unsigned char* shared_prev = nullptr;
     Tmp<u32> act2;                         // second active list (the list of a level is built from the previous level's)
     u32* act_cur = nullptr;                // the current level's active list (act or act2)
     bool prev_active = false;              // the previous level took the active-set path (its list is act_cur)
@@ -1225,7 +1235,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         } else {
             const u32 seq = gk_mbox_begin(ctx);
             ActiveScan as{st.frozen.p, st.act.p, st.fidx.p, st.scratch.p + 1, st.scratch.p + 2, seq ? ctx->mbox_dev : nullptr, seq,
-                          n_car > 0 ? b->iso_info : nullptr};
+                          n_car > 0 ? b->iso_info : nullptr, st.frozen_in_shared ? st.shared_prev : nullptr};
             GK_TRY((gk_scan_fn<u32, ActiveScan>(ctx, as, V, nullptr)));
             if (seq) GK_TRY(gk_mbox_wait(ctx, seq, back, 2));
             else GK_TRY(gk_readback(ctx, st.scratch.p + 1, back, 2));
@@ -1326,7 +1336,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             GK_TRY(dictionary_from_keys(ctx, hash.p, V, 32, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
                                         sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2, listed_dev,
                                         listed_dev ? &st.posted_seq : nullptr, 0, nullptr, b->shared_flag + (size_t)level * V,
-                                        (st.no_order && !exact) ? unresolved_dev : nullptr));
+                                        (st.no_order && !exact) ? unresolved_dev : nullptr, st.list_scan ? &st.frozen_in_shared : nullptr));
+            st.shared_prev = b->shared_flag + (size_t)level * V;
             b->perm_valid[level] = !(st.no_order && !exact && listed_dev) ? 1 : 0;
             GK_HIP_CHECK(hipGetLastError());
             break;
@@ -1343,7 +1354,8 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                                     round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev,
                                     (listed_dev && !exact) ? &st.posted_seq : nullptr, 0, nullptr,
                                     b->shared_flag + (size_t)level * V,
-                                    (st.no_order && !exact && round == 0) ? unresolved_dev : nullptr));
+                                    (st.no_order && !exact && round == 0) ? unresolved_dev : nullptr, st.list_scan ? &st.frozen_in_shared : nullptr));
+        st.shared_prev = b->shared_flag + (size_t)level * V;
         b->perm_valid[level] = !(st.no_order && !exact && round == 0 && listed_dev && bits >= 24) ? 1 : 0;
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
