@@ -262,7 +262,7 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
 // Dictionary without a sort (full WL levels whose label-grouped order nobody reads): see scan_sort.hip
 int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* rep, u32* frozen,
                          unsigned char* shared_out, u32* count_dev, u32* listed_dev, u32* top_digit_max, u32* overflow,
-                         u32* mbox, u32 seq);
+                         u32* mbox, u32 seq, int flag_in_rep = 0);
 
 // ---- wl.hip ---------------------------------------------------------------------------
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);

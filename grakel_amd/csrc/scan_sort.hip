@@ -830,7 +830,8 @@ __global__ __launch_bounds__(1024) void bucket_assign_kernel(const u32* __restri
                                                              i32* __restrict__ lab, i32* __restrict__ rep, u32* __restrict__ frozen,
                                                              unsigned char* __restrict__ shared_out, u32* __restrict__ listed_out,
                                                              u32* __restrict__ count_out, unsigned long long* __restrict__ ticket,
-                                                             u32* __restrict__ mbox, u32 seq, const u32* __restrict__ extra, i64 n) {
+                                                             u32* __restrict__ mbox, u32 seq, const u32* __restrict__ extra, i64 n,
+                                                             int flag_in_rep) {
     // one item per thread (the scattered stores need many workgroups in flight); the bucket of an item is found
     // in the two 256-entry prefixes every workgroup rebuilds in LDS
     __shared__ u32 starts[257], bases[257];
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(1024) void bucket_assign_kernel(const u32* __restri
         lab[node] = (i32)id;
         if (frozen) frozen[node] = single;
         if (shared_out) shared_out[node] = single ? 0 : 1;
-        if ((t >> 30) & 1u) rep[id] = (i32)node;
+        if ((t >> 30) & 1u) rep[id] = (i32)(node | (flag_in_rep ? single << 31 : 0u));      // bit 31: singleton class (verify_kernel)
         listed = single ? 0u : 1u;
     }
     for (int off = 32; off > 0; off >>= 1) listed += __shfl_down(listed, off, 64);
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(1024) void bucket_assign_kernel(const u32* __restri
 // *overflow gets 0x80000000 or-ed in when a bucket did not fit.
 int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* rep, u32* frozen,
                          unsigned char* shared_out, u32* count_dev, u32* listed_dev, u32* top_digit_max, u32* overflow,
-                         u32* mbox, u32 seq) {
+                         u32* mbox, u32 seq, int flag_in_rep) {
     if (key_bits > 64) key_bits = 64;
     const int passes = (key_bits + 7) / 8;
     const int shift = 8 * (passes - 1);
@@ -934,7 +935,8 @@ int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32*
         kern<<<dim3(256), dim3(1024), lds, ctx->stream>>>(kx.p, bucket_totals, shift, item.p, nd.p, overflow, ticket);
     }
     bucket_assign_kernel<<<dim3((unsigned)cdiv(n, 1024)), dim3(1024), 0, ctx->stream>>>(
-        vx.p, item.p, bucket_totals, nd.p, lab, rep, frozen, shared_out, listed_dev, count_dev, ticket, mbox, seq, top_digit_max, n);
+        vx.p, item.p, bucket_totals, nd.p, lab, rep, frozen, shared_out, listed_dev, count_dev, ticket, mbox, seq, top_digit_max, n,
+        flag_in_rep);
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }

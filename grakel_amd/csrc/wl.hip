@@ -593,12 +593,20 @@ __global__ void frozen_assign_verify_kernel(const u32* __restrict__ fidx, const 
     if (!ok) atomicAdd(unresolved, 1u);
 }
 
+// shared_out (may be null): the dictionary left "singleton class" in bit 31 of rep[] (gk_bucket_dictionary with
+// flag_in_rep) -- this pass gathers rep[lab[v]] for every node anyway and writes the level's "class of two or more"
+// bytes in node order, instead of one more scattered store per node in bucket_assign_kernel
 __global__ void verify_kernel(const i32* __restrict__ row_ptr, const i32* __restrict__ lab_prev,
                               const i32* __restrict__ nbr_sorted, const i32* __restrict__ lab,
-                              const i32* __restrict__ rep, u32* __restrict__ unresolved, i64 n) {
+                              const i32* __restrict__ rep, u32* __restrict__ unresolved, i64 n,
+                              unsigned char* __restrict__ shared_out) {
     i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     i32 r = rep[lab[v]];
+    if (shared_out) {
+        shared_out[v] = r < 0 ? 0 : 1;
+        r &= 0x7fffffff;
+    }
     if (r == (i32)v) return;
     bool ok = lab_prev[v] == lab_prev[r];
     i32 s = row_ptr[v], sr = row_ptr[r];
@@ -1072,8 +1080,10 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
                                 i64 rep_capacity = 0, int use_buckets = 0, u32* top_digit_max = nullptr,
                                 u32* listed_dev = nullptr, u32* posted_seq = nullptr, u32 lab_base = 0,
                                 const u32* lab_base_dev = nullptr, unsigned char* shared_out = nullptr,
-                                u32* no_order_overflow = nullptr, bool* frozen_in_shared = nullptr) {
+                                u32* no_order_overflow = nullptr, bool* frozen_in_shared = nullptr,
+                                bool* flag_in_rep = nullptr) {
     if (frozen_in_shared) *frozen_in_shared = false;
+    if (flag_in_rep) *flag_in_rep = false;
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         if (listed_dev) GK_TRY(gk_zero_async(ctx, listed_dev, 4));
@@ -1094,8 +1104,13 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
         // frozen[] after a full level, ActiveScan, takes the bytes
         const bool bytes_only = shared_out && frozen_in_shared && !getenv("GK_WL_FROZEN_WORDS");
         if (bytes_only) *frozen_in_shared = true;
-        return gk_bucket_dictionary(ctx, keys, n, key_bits, lab, rep, bytes_only ? nullptr : frozen, shared_out, count_dev, listed_dev,
-                                    top_digit_max, no_order_overflow, seq ? ctx->mbox_dev : nullptr, seq);
+        // ... and when the caller's verification pass follows (it gathers rep[lab[v]] per node), not even the byte:
+        // the flag rides in bit 31 of rep[] and verify_kernel writes the bytes in node order
+        const bool in_rep = bytes_only && flag_in_rep && rep != rep_tmp.p && !getenv("GK_WL_FLAG_BYTES");
+        if (in_rep) *flag_in_rep = true;
+        return gk_bucket_dictionary(ctx, keys, n, key_bits, lab, rep, bytes_only ? nullptr : frozen, in_rep ? nullptr : shared_out,
+                                    count_dev, listed_dev, top_digit_max, no_order_overflow, seq ? ctx->mbox_dev : nullptr, seq,
+                                    in_rep ? 1 : 0);
     }
     if (listed_dev && !vals) {
         Tmp<u32> sorted(ctx);
@@ -1343,6 +1358,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             break;
         }
         GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), full_mask));
+        bool flag_in_rep = false;
         int bits = hash_bits;
         const u64* sort_keys = hash.p;           // round 0: the sort reads the hashes in place
         if (round > 0) {
@@ -1354,12 +1370,14 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                                     round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev,
                                     (listed_dev && !exact) ? &st.posted_seq : nullptr, 0, nullptr,
                                     b->shared_flag + (size_t)level * V,
-                                    (st.no_order && !exact && round == 0) ? unresolved_dev : nullptr, st.list_scan ? &st.frozen_in_shared : nullptr));
+                                    (st.no_order && !exact && round == 0) ? unresolved_dev : nullptr, st.list_scan ? &st.frozen_in_shared : nullptr,
+                                    &flag_in_rep));
         st.shared_prev = b->shared_flag + (size_t)level * V;
         b->perm_valid[level] = !(st.no_order && !exact && round == 0 && listed_dev && bits >= 24) ? 1 : 0;
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
-        verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V);
+        verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V,
+                                                                  flag_in_rep ? b->shared_flag + (size_t)level * V : nullptr);
         GK_HIP_CHECK(hipGetLastError());
         if (!exact) break;
         u32 un = 0;
