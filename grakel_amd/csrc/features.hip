@@ -534,14 +534,13 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     // levels), a level that lists nothing adds one per node to the diagonal and nothing else
     FeatLevels P;
     P.L = 0, P.off[0] = 0, P.synth = -1;
-    int n_unlisted = 0;
     std::vector<int> slot_of_level(n_levels, -1);
     const bool hist0 = b->level0_hist && !b->is_pair_batch && V > 0;
     const i64 L0 = b->n_labels0;
     for (int l = 0; l < n_levels && V > 0; ++l) {
         i64 nl = (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V;
         if (l == 0 && hist0) nl = L0 * N;           // items of the synthesized slot: (label, graph) cells
-        if (nl == 0) { ++n_unlisted; continue; }
+        if (nl == 0) continue;
         if (!(l == 0 && hist0) && (size_t)l < b->perm_valid.size() && !b->perm_valid[l]) {
             gk_set_error("gk_features_build: this batch was relabelled without label-grouped orders (graph-major features); "
                          "set GK_WL_NO_BUCKET_DICT=1 to use the label-major builder");

@@ -3,11 +3,14 @@
 // features.hip (flags, triple scan, counts: ~16 bytes x items x 4 passes) disappear.
 //
 // A graph is small (n <= 111 in every config), so one WAVE owns a graph:
-//   gm_pairs_kernel  per level, the wave stages the graph's labels in LDS; node v counts the nodes of
-//                    its graph carrying its label (c) and learns whether it is the first of them.  The first
-//                    one is the graph's (label, graph, c) entry: cnt[level][v] = c (0 for everybody else),
-//                    df[label] += 1, cmax[label] = max(c), exact self similarity
-//                    selfk[g] = n_g x levels + sum over entries of (c^2 - c)  -- no atomics, no triples.
+//   gm_pairs_kernel  per level, the wave holds the graph's shared labels in registers (two per lane, n <= 128) and
+//                    turns them into (label, count) entries without LDS atomics: a handful of distinct labels
+//                    (deep levels, level 0) by one ballot round per label, otherwise an in-register bitonic
+//                    sort (28 shuffle steps) + run lengths from ballots; graphs above 128 nodes use an
+//                    open-addressing table in LDS.  Entries are stored compactly (ent_lab / ent_cnt / ent_n per
+//                    level and graph); df[label] += 1 / count class go to workgroup-private LDS histograms
+//                    (small label spaces) or guarded global atomics; exact self similarity
+//                    selfk[g] = n_g x levels + sum over entries of (c^2 - c).
 //                    Only nodes whose class has at least two members take part (ids of an active-set level
 //                    say so themselves, wl.hip; full levels pass a flag array).
 //   GmColumns scan   over the labels that can be shared (all levels concatenated): df / cmax -> column
@@ -45,7 +48,7 @@ struct GmLabelArrays {
     i32* colid; u32* roff; u32* cursor; i32* low_q;
 };
 
-#define GM_WAVES 16
+#define GM_WAVES 8
 #define GM_FEW 24           // at most this many distinct labels: counted by ballots instead of the sort
 
 // One wave per graph (persistent workgroups: a wave walks graphs w, w + stride, ...), all levels.  Per level the
@@ -269,20 +272,11 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
     for (int t = threadIdx.x; t < priv_words; t += blockDim.x) mine[t] = priv[t];
 }
 
-// Occupancy: the body needs ~106 SGPRs, and the 800-SGPR file of a SIMD then holds 6 waves -- ONE 16-wave workgroup
-// per CU, the other half of a 2-per-CU grid queues behind it (measured: waves live 30 us, the kernel 73 us).
-//   variant 0: 8-wave workgroups, three per CU (24 waves / CU), no register caps;
-//   variant 1: 16-wave workgroups, two per CU (32 waves / CU), SGPRs capped at 80 (spills to VGPR lanes / scratch).
-#define GM_WAVES_SMALL 8
-__global__ __launch_bounds__(64 * GM_WAVES_SMALL) void gm_pairs_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
-                                                                const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
-                                                                i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
-                                                                u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
-                                                                int rectangular, u32 df_cap, int T, int prim_max,
-                                                                int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta) {
-    gm_pairs_body<GM_WAVES_SMALL>(P, A, R, graph_ptr, n_graphs, V, ent_lab, ent_cnt, ent_n, selfk, meta, n_levels, kind, n_fit, rectangular, df_cap, T, prim_max, wide_above, part, wgmeta);
-}
-__global__ __launch_bounds__(64 * GM_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(80))) void gm_pairs_capped_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+// Occupancy: the body needs ~106 SGPRs, and the 800-SGPR file of a SIMD then holds 6 waves.  16-wave workgroups would
+// run ONE per CU (the other half of a 2-per-CU grid queues behind it: measured waves live 30 us, the kernel 73 us);
+// capping the SGPRs at 80 to fit two spills to scratch and is no faster (75 us).  So: 8-wave workgroups, three per CU
+// (24 waves / CU), 61 us.
+__global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
                                                                 const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
                                                                 i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
                                                                 u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
@@ -290,7 +284,6 @@ __global__ __launch_bounds__(64 * GM_WAVES) __attribute__((amdgpu_waves_per_eu(8
                                                                 int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta) {
     gm_pairs_body<GM_WAVES>(P, A, R, graph_ptr, n_graphs, V, ent_lab, ent_cnt, ent_n, selfk, meta, n_levels, kind, n_fit, rectangular, df_cap, T, prim_max, wide_above, part, wgmeta);
 }
-
 // sum the workgroups' private histograms: df (saturating at what the column scan distinguishes), the count class as
 // a representative cmax (1, prim_max + 1 or wide_above + 1), the side bits
 __global__ __launch_bounds__(1024) void gm_reduce_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
@@ -324,13 +317,6 @@ __global__ __launch_bounds__(1024) void gm_reduce_kernel(const GmLevels P, const
         A.cmax[q] = (f & GM_PRIV_BIG2) ? (u32)wide_above + 1u : ((f & GM_PRIV_BIG1) ? (u32)prim_max + 1u : (c ? 1u : 0u));
         if (rectangular) A.side[q] = (unsigned char)((f >> GM_PRIV_SIDE_SHIFT) & 3u);
     }
-}
-
-// listed prefix of a full level's label-grouped order -> flag array (the relabel sort leaves the nodes of
-// shared classes in perm[0 .. n_sorted))
-__global__ void gm_flags_kernel(const i32* __restrict__ perm, i64 n_listed, unsigned char* __restrict__ flag) {
-    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_listed) flag[perm[k]] = 1;
 }
 
 // Column classes per shareable label, one prefix sum for everything:
@@ -521,8 +507,6 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     // ---- level slots
     GmLevels P;
     P.L = 0, P.off[0] = 0;
-    std::vector<const i32*> perm_of;
-    std::vector<i64> listed_of;
     for (int l = 0; l < n_levels; ++l) {
         const i64 nl = (l == 0 && b->level0_hist) ? V : ((size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V);
         if (nl == 0) continue;                                // nothing shared: baseline only
@@ -535,32 +519,18 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         P.off[j + 1] = P.off[j] + (count - P.id_base[j]);
         // full level with a listed prefix: the relabel left per-node flags (wl.hip: HeadAssignSplit)
         if (!act && nl < V && b->shared_flag) P.flag[j] = b->shared_flag + (size_t)l * V;
-        perm_of.push_back(nullptr);
-        listed_of.push_back(nl);
     }
     const i64 Q = P.off[P.L];
     GK_ARG(Q < (1ll << 31), "gk_features_build: label space too large");
     // ---- per-label arrays (zeroed in one go), flags of the full levels, counts
     const size_t qa = (size_t)round_up(Q > 0 ? Q : 1, 64);
-    Tmp<u32> zeroed(ctx);                     // [df | cmax | cursor | side (bytes) | flags (bytes, V per flagged level)]
-    size_t n_flag_levels = 0;
-    for (const i32* pp : perm_of) n_flag_levels += pp ? 1 : 0;
-    const size_t zero_words = 3 * qa + qa / 4 + n_flag_levels * (size_t)round_up(V, 64) / 4;
+    Tmp<u32> zeroed(ctx);                     // [df | cmax | cursor | side (bytes)]
+    const size_t zero_words = 3 * qa + qa / 4;
     GK_TRY(zeroed.alloc(zero_words));
     GK_TRY(gk_zero_async(ctx, zeroed.p, zero_words * 4));
     GmLabelArrays A;
     A.df = zeroed.p, A.cmax = zeroed.p + qa, A.cursor = zeroed.p + 2 * qa;
     A.side = (unsigned char*)(zeroed.p + 3 * qa);
-    unsigned char* flag_mem = A.side + qa;
-    {
-        size_t k = 0;
-        for (int j = 0; j < P.L; ++j)
-            if (perm_of[j]) {
-                unsigned char* fl = flag_mem + (k++) * (size_t)round_up(V, 64);
-                P.flag[j] = fl;
-                gm_flags_kernel<<<grid_for(listed_of[j], 256), 256, 0, ctx->stream>>>(perm_of[j], listed_of[j], fl);
-            }
-    }
     i32** keep[] = {&A.colid, (i32**)&A.roff, &A.low_q};
     for (i32** a : keep) {
         GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));
@@ -578,8 +548,7 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     while (T < 2 * b->max_graph_nodes) T <<= 1;
     // ---- which levels count in workgroup-private histograms (small label spaces first come, 32 K bins in all)
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    static const int variant = getenv("GK_GM_VARIANT") ? atoi(getenv("GK_GM_VARIANT")) : 0;
-    const int waves = variant ? GM_WAVES : GM_WAVES_SMALL, per_cu = variant ? 2 : 3;
+    const int waves = GM_WAVES, per_cu = 3;
     i64 grid = cdiv(N, waves);
     if (grid > per_cu * (i64)n_cu) grid = per_cu * (i64)n_cu;
     // per_cu workgroups share a CU's 160 KiB: private histogram + one counting table per wave
@@ -598,13 +567,12 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     static size_t pairs_lds_set = 0;
     if (pairs_lds > 48 * 1024 && pairs_lds > pairs_lds_set) {
         GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_pairs_capped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
         pairs_lds_set = pairs_lds;
     }
     Tmp<u32> part(ctx), wgmeta(ctx);
     GK_TRY(wgmeta.alloc((size_t)grid * 2));
     GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
-    (variant ? gm_pairs_capped_kernel : gm_pairs_kernel)<<<dim3((unsigned)grid), 64 * waves, pairs_lds, ctx->stream>>>(
+    gm_pairs_kernel<<<dim3((unsigned)grid), 64 * waves, pairs_lds, ctx->stream>>>(
         P, A, R, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, f->selfk, f->meta, n_levels, kind, f->n_fit, rectangular,
         (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p, wgmeta.p);
     if (R.bins > 0)
@@ -657,10 +625,9 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GM_ROW_LDS_MAX));
         attr_set = true;
     }
-    // one workgroup per graph; a graph has ~n entries, so small workgroups (more of them per CU) hide the
-    // dependent loads (entry -> column id) better than wide ones
-    static const int rows_threads = getenv("GK_GM_ROWS_THREADS") ? atoi(getenv("GK_GM_ROWS_THREADS")) : 256;
-    gm_rows_kernel<<<dim3((unsigned)N), rows_threads, (size_t)f->n_cols_pad, ctx->stream>>>(
+    // one workgroup per graph (64- and 128-thread workgroups measured the same 30 us: the chain of dependent loads
+    // slot -> entry -> column id binds, not the number of workgroups in flight)
+    gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
         P, A, b->graph_ptr, V, ent.p, cnt.p, ent_n.p, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
         f->n_cols_wide_pad, lg, lc);
     const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;

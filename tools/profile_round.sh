@@ -26,3 +26,16 @@ python tools/pmc_summary.py "$out/pmc_sq" "$out/pmc_mem" > "$out/pmc_sq_waves.cs
 rm -rf "$out/trace" "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE "$out"/pmc_mfma "$out"/pmc_sq "$out"/pmc_mem
 python bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.log"
 tail -c 600 "$out/bench_n1.json"
+[ "${2:-}" = "main-only" ] && exit 0
+# ---- the other kernels of the path: ShortestPath (BASELINE config 4 stand-in), WL-OA, config 5 (50 k graphs), and
+# the multi-GPU code path at world size 1; kernel stats of the SP and WL-OA runs
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/sp_trace" -- python $root/tools/bench_sp.py 4110 5 > "$out/sp_config4_bench.json" 2> "$out/sp_trace.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wloa_trace" -- python $root/tools/bench_wloa.py config3 > "$out/wloa.json" 2> "$out/wloa_trace.log"
+cd "$root"
+cp "$(ls $out/sp_trace/*/*kernel_stats.csv | head -1)" "$out/sp_config4_kernel_stats.csv" 2>/dev/null
+cp "$(ls $out/wloa_trace/*/*kernel_stats.csv | head -1)" "$out/wloa_kernel_stats.csv" 2>/dev/null
+rm -rf "$out/sp_trace" "$out/wloa_trace"
+python bench.py --workload config5 --steps 3 --warmup 1 --no-cpu-baseline > "$out/config5_50k.json" 2> "$out/config5.log"
+python tools/bench_sharded_1rank.py > "$out/sharded_1rank.txt" 2>&1
+tail -c 300 "$out/config5_50k.json"; tail -3 "$out/sharded_1rank.txt"
