@@ -112,7 +112,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
             if (lane < n) { ra = lab[v0 + lane]; fa = fl ? fl[v0 + lane] : 1u; }
             if (lane + 64 < n) { rb = lab[v0 + lane + 64]; fb = fl ? fl[v0 + lane + 64] : 1u; }
         };
-        if (small) fetch(0);
+        if (small && P.L > 0) fetch(0);
         for (int j = 0; j < P.L; ++j) {
             const i32* __restrict__ lab = P.lab[j];
             const unsigned char* __restrict__ fl = P.flag[j];
@@ -505,7 +505,7 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     const int kind = f->kind;
     void* q = nullptr;
     // ---- level slots
-    GmLevels P;
+    GmLevels P = {};                                    // unused slots stay null (deterministic)
     P.L = 0, P.off[0] = 0;
     for (int l = 0; l < n_levels; ++l) {
         const i64 nl = (l == 0 && b->level0_hist) ? V : ((size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V);

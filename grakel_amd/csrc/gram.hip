@@ -885,7 +885,7 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
             f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0, col_lo, col_hi);
     } else if (has_low) {
         for (int l0 = 0; l0 < f->n_levels; l0 += GK_PACK_LEVELS) {     // one launch per 16 levels
-            LevelPack P;
+            LevelPack P = {};
             P.n = 0, P.first[0] = 0;
             for (int l = l0; l < f->n_levels && l < l0 + GK_PACK_LEVELS; ++l) {
                 LevelTriples& L = f->lev[l];
