@@ -1,4 +1,6 @@
-// Label-count features (the VertexHistogram of every WL level) on gfx950.
+// Label-count features (the VertexHistogram of every WL level) on gfx950 -- the LABEL-MAJOR builder: pair batches
+// (ShortestPath), operand rows wider than features_gm.hip holds in LDS, GK_FEAT_NO_GM.  Graph batches take the
+// graph-major builder (features_gm.hip), which this file dispatches to first.
 //
 // Input per level: labels[v] and perm[] = nodes grouped by label, ascending node (hence
 // ascending graph) inside a group -- exactly what the relabel sort leaves behind.  One pass

@@ -68,7 +68,10 @@ class ShortestPath(Kernel):
     Parameters as the reference (shortest_path.py:224-228): n_jobs, normalize, verbose,
     with_labels=True, algorithm_type in {"auto", "dijkstra", "floyd_warshall"} (validated; the
     device always runs the batched Floyd-Warshall / row-relaxation kernels, which give the
-    same distances as either host algorithm for positive integer weights).
+    same distances as either host algorithm).  Edge weights: positive integers below 2**20, or floats that
+    are integer multiples of one common power of two (0.5, 1.25, ...): distances are then counted exactly in
+    that unit (batch.quantise_weights) and ``_enum`` keys are the reference's float distances; other float
+    weights raise NotImplementedError.
     """
 
     def __init__(self, n_jobs=None, normalize=False, verbose=False, with_labels=True,
