@@ -70,10 +70,30 @@ __device__ __forceinline__ void insertion_sort(P x, int d) {
     }
 }
 
+// bitonic compare-exchange network on the first N (power of two) registers of x: every index is a compile-time
+// constant after unrolling, so the elements stay in VGPRs (80 comparators for N = 16, 24 for N = 8)
+template <int N>
+__device__ __forceinline__ void sort_regs(i32 (&x)[16]) {
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const i32 a = x[i], b = x[l];
+                    const i32 lo = a < b ? a : b, hi = a < b ? b : a;
+                    if ((i & k) == 0) x[i] = lo, x[l] = hi;
+                    else x[i] = hi, x[l] = lo;
+                }
+            }
+}
+
 __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
     const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted, u64* __restrict__ hash,
-    i64 V, u64 seed, u64 mask) {
+    i64 V, u64 seed, u64 mask, int sig_regs) {
     __shared__ i32 buf[SIG_LDS_CAP];
     const int tid = threadIdx.x;
     const i64 v0 = (i64)blockIdx.x * SIG_THREADS;
@@ -89,12 +109,31 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     }
     __syncthreads();
     const i64 v = v0 + tid;
+    // largest degree of the wave: up to 16 neighbours per node are sorted in registers (a fixed network: no
+    // dependent LDS round trip per insertion step, no divergence); the multiset hash is a sum, so the order in
+    // which the elements are added does not matter
+    int dwave = 0;
+    {
+        const int dv = v < v1 ? row_ptr[v + 1] - row_ptr[v] : 0;
+        dwave = dv;
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(dwave, off, 64); dwave = o > dwave ? o : dwave; }
+    }
     if (v < v1) {
         const i32 s = row_ptr[v];
         const int d = row_ptr[v + 1] - s;
         if (d <= WL_DEG_SMALL) {
             u64 acc = sig_head((u32)lab_prev[v], (u32)d, seed);
-            if (use_lds) {
+            if (use_lds && dwave <= 16 && sig_regs) {
+                i32* x = buf + (s - e0);
+                i32 r[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) r[k] = (k < d && (k < 8 || dwave > 8)) ? x[k] : 0x7fffffff;
+                if (dwave <= 8) sort_regs<8>(r);
+                else sort_regs<16>(r);
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < d) { x[k] = r[k]; acc += sig_elem((u32)r[k], seed); }
+            } else if (use_lds) {
                 i32* x = buf + (s - e0);
                 insertion_sort(x, d);
                 for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
@@ -1059,8 +1098,9 @@ static u64 level_seed(int level, int round) {
 static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash, u64 seed, u64 mask) {
     i64 V = b->n_nodes;
     if (V == 0) return GK_OK;
+    static const int sig_regs = getenv("GK_WL_SIG_NO_REGS") ? 0 : 1;      // A/B switch: insertion sort in LDS instead
     wl_signature_small_kernel<<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
-        b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask);
+        b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask, sig_regs);
     if (b->n_big > 0)
         wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
             b->big_nodes, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, seed, mask);
