@@ -90,6 +90,22 @@ __device__ __forceinline__ void sort_regs(i32 (&x)[16]) {
             }
 }
 
+// One node's signature key with its neighbour labels gathered straight into registers (degree <= 16): the 16
+// gathers are independent loads, the sort is the fixed network, the sorted list goes to nbr_sorted for the verifier.
+// (An insertion sort in global memory pays two memory latencies per step.)
+__device__ __forceinline__ u64 node_key_regs(const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+                                             i32* __restrict__ x, i32 s, int d, u32 own, u64 seed) {
+    i32 r[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = k < d ? lab_prev[col_idx[s + k]] : 0x7fffffff;
+    sort_regs<16>(r);
+    u64 acc = sig_head(own, (u32)d, seed);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < d) { x[k] = r[k]; acc += sig_elem((u32)r[k], seed); }
+    return acc;
+}
+
 __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
     const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted, u64* __restrict__ hash,
@@ -345,10 +361,14 @@ __global__ void wl_signature_list_kernel(const u32* __restrict__ act, i64 n_act,
     const int d = row_ptr[v + 1] - s;
     if (d > WL_DEG_SMALL) return;               // hubs: wl_signature_big_kernel (writes hash_node[v])
     i32* x = nbr_sorted + s;
-    for (int k = 0; k < d; ++k) x[k] = lab_prev[col_idx[s + k]];
-    insertion_sort(x, d);
-    u64 acc = sig_head((u32)lab_prev[v], (u32)d, seed);
-    for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+    u64 acc;
+    if (d <= 16) acc = node_key_regs(col_idx, lab_prev, x, s, d, (u32)lab_prev[v], seed);
+    else {
+        for (int k = 0; k < d; ++k) x[k] = lab_prev[col_idx[s + k]];
+        insertion_sort(x, d);
+        acc = sig_head((u32)lab_prev[v], (u32)d, seed);
+        for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+    }
     hash_out[j] = mix64(acc) & mask;
 }
 
@@ -500,6 +520,7 @@ __global__ __launch_bounds__(TINY_MAX) void wl_tiny_level_kernel(
     __shared__ u32 act_s[TINY_MAX];
     __shared__ __attribute__((aligned(16))) u64 elem_s[TINY_MAX];
     __shared__ u64 skey[TINY_MAX];
+    __shared__ u64 korig[TINY_MAX];
     __shared__ u32 sidx[TINY_MAX];
     __shared__ i32 rep_s[TINY_MAX];
     __shared__ u32 wsum[TINY_MAX / 64];
@@ -528,26 +549,38 @@ __global__ __launch_bounds__(TINY_MAX) void wl_tiny_level_kernel(
         const i32 s = row_ptr[v];
         const int d = row_ptr[v + 1] - s;
         i32* x = nbr_sorted + s;
-        for (int k = 0; k < d; ++k) x[k] = lab_prev[col_idx[s + k]];
-        insertion_sort(x, d);
-        u64 acc = sig_head((u32)lab_prev[v], (u32)d, seed);
-        for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+        u64 acc;
+        if (d <= 16) acc = node_key_regs(col_idx, lab_prev, x, s, d, (u32)lab_prev[v], seed);
+        else {
+            for (int k = 0; k < d; ++k) x[k] = lab_prev[col_idx[s + k]];
+            insertion_sort(x, d);
+            acc = sig_head((u32)lab_prev[v], (u32)d, seed);
+            for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+        }
         key = mix64(acc) & mask;
     }
     elem_s[j] = j < n_act ? ((key << 10) | (u64)j) : ~0ull;
+    korig[j] = key;
     __syncthreads();
-    // ---- rank against all others (elements are distinct): the rank is the sorted position
-    if (j < n_act) {
-        const u64 mine = elem_s[j];
-        const u32 n_even = (n_act + 1u) & ~1u;
-        u32 r = 0;
-#pragma unroll 4
-        for (u32 i = 0; i < n_even; i += 2) {
-            const ulonglong2 ab = *(const ulonglong2*)(elem_s + i);
-            r += (ab.x < mine ? 1u : 0u) + (ab.y < mine ? 1u : 0u);
+    // ---- sort the (key, list position) elements (distinct; the padding ~0 sorts last): bitonic network in LDS, one
+    // compare-exchange per thread and step (55 steps at 1024 elements).  Neither this nor the in-register neighbour
+    // sort changed the kernel's 24-30 us at 650 active nodes: a single workgroup walks ~12 DEPENDENT global accesses
+    // (list -> flags -> row_ptr -> col_idx -> labels -> ... -> representative's list) at ~2 us each
+    u32 p2 = 2;
+    while (p2 < n_act) p2 <<= 1;
+    for (u32 k = 2; k <= p2; k <<= 1)
+        for (u32 jj = k >> 1; jj > 0; jj >>= 1) {
+            if (j < p2 / 2) {
+                const u32 i = ((j & ~(jj - 1u)) << 1) | (j & (jj - 1u)), l = i | jj;
+                const u64 a = elem_s[i], b = elem_s[l];
+                if ((a > b) == ((i & k) == 0u)) elem_s[i] = b, elem_s[l] = a;
+            }
+            __syncthreads();
         }
-        skey[r] = key;
-        sidx[r] = j;
+    if (j < n_act) {
+        const u32 src = (u32)(elem_s[j] & 1023u);
+        skey[j] = korig[src];
+        sidx[j] = src;
     }
     __syncthreads();
     // ---- run heads -> class ids, singleton flags, representatives
@@ -573,7 +606,13 @@ __global__ __launch_bounds__(TINY_MAX) void wl_tiny_level_kernel(
         const i32 s = row_ptr[v], sr = row_ptr[r];
         const int d = row_ptr[v + 1] - s;
         ok = ok && (d == row_ptr[r + 1] - sr);
-        if (ok)
+        if (ok && d <= 16) {                // all loads in flight together (an early exit would chain them)
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < d) same = same && nbr_sorted[s + k] == nbr_sorted[sr + k];
+            ok = same;
+        } else if (ok)
             for (int k = 0; k < d; ++k)
                 if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
         if (!ok) atomicAdd(unresolved, 1u);
