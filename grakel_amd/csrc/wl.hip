@@ -525,6 +525,19 @@ __global__ __launch_bounds__(TINY_MAX) void wl_tiny_level_kernel(
     __shared__ i32 rep_s[TINY_MAX];
     __shared__ u32 wsum[TINY_MAX / 64];
     const u32 j = threadIdx.x;
+    if (blockIdx.x > 0) {
+        // the carried classes of the isolated vertices (thousands of scattered stores: 6.5 us when the level's one
+        // workgroup does them itself) on further workgroups.  Only launched when the active list is taken as it is
+        // (do_scan == 0): *n_act_io is then rewritten with the same value by workgroup 0
+        const u32 n_act0 = *n_act_io;
+        const u32 n_frozen0 = (u32)(V - (i64)n_act0 - (i64)n_car);
+        for (u32 c = (blockIdx.x - 1u) * TINY_MAX + j; c < n_car; c += (gridDim.x - 1u) * TINY_MAX) {
+            const i32 cv = car_nodes[c];
+            lab[cv] = (i32)(n_frozen0 + (u32)car_class[c]);
+            perm[n_act0 + c] = cv;
+        }
+        return;
+    }
     const u32 n_in = *n_act_io;                       // every thread reads it before thread 0 overwrites it below
     u32 n_act = n_in;
     if (do_scan) {
@@ -559,26 +572,33 @@ __global__ __launch_bounds__(TINY_MAX) void wl_tiny_level_kernel(
         }
         key = mix64(acc) & mask;
     }
-    elem_s[j] = j < n_act ? ((key << 10) | (u64)j) : ~0ull;
+    // ---- sort the (key, list position) elements (distinct; the padding ~0 sorts last): bitonic network, one
+    // element per thread in a register -- partners closer than 64 exchange by wave shuffle, the 10 farther steps
+    // (at 1024 elements) through two alternating LDS buffers, one barrier each.  (The same network entirely in LDS:
+    // 55 barriers, 10.7 us of the kernel's 26; s_memtime stamps.)
+    u64 e = j < n_act ? ((key << 10) | (u64)j) : ~0ull;
     korig[j] = key;
-    __syncthreads();
-    // ---- sort the (key, list position) elements (distinct; the padding ~0 sorts last): bitonic network in LDS, one
-    // compare-exchange per thread and step (55 steps at 1024 elements).  Neither this nor the in-register neighbour
-    // sort changed the kernel's 24-30 us at 650 active nodes: a single workgroup walks ~12 DEPENDENT global accesses
-    // (list -> flags -> row_ptr -> col_idx -> labels -> ... -> representative's list) at ~2 us each
     u32 p2 = 2;
     while (p2 < n_act) p2 <<= 1;
+    int flip = 0;
     for (u32 k = 2; k <= p2; k <<= 1)
         for (u32 jj = k >> 1; jj > 0; jj >>= 1) {
-            if (j < p2 / 2) {
-                const u32 i = ((j & ~(jj - 1u)) << 1) | (j & (jj - 1u)), l = i | jj;
-                const u64 a = elem_s[i], b = elem_s[l];
-                if ((a > b) == ((i & k) == 0u)) elem_s[i] = b, elem_s[l] = a;
+            u64 o;
+            if (jj >= 64) {
+                u64* buf = flip ? skey : elem_s;
+                flip ^= 1;
+                buf[j] = e;
+                __syncthreads();
+                o = buf[j ^ jj];
+            } else {
+                o = __shfl_xor(e, (int)jj, 64);
             }
-            __syncthreads();
+            const bool keep_min = ((j & jj) == 0u) == ((j & k) == 0u);
+            e = keep_min ? (e < o ? e : o) : (e < o ? o : e);
         }
+    __syncthreads();                    // skey may still be read as an exchange buffer; korig is complete
     if (j < n_act) {
-        const u32 src = (u32)(elem_s[j] & 1023u);
+        const u32 src = (u32)(e & 1023u);
         skey[j] = korig[src];
         sidx[j] = src;
     }
@@ -617,11 +637,12 @@ __global__ __launch_bounds__(TINY_MAX) void wl_tiny_level_kernel(
                 if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
         if (!ok) atomicAdd(unresolved, 1u);
     }
-    for (u32 c = j; c < n_car; c += TINY_MAX) {
-        const i32 cv = car_nodes[c];
-        lab[cv] = (i32)(n_frozen + (u32)car_class[c]);
-        perm[n_act + c] = cv;
-    }
+    if (gridDim.x == 1)
+        for (u32 c = j; c < n_car; c += TINY_MAX) {
+            const i32 cv = car_nodes[c];
+            lab[cv] = (i32)(n_frozen + (u32)car_class[c]);
+            perm[n_act + c] = cv;
+        }
     if (j == 0) {
         *count_out = base + ra;
         *n_act_io = n_act;
@@ -1260,7 +1281,8 @@ static int launch_tiny_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits,
     int bits = hash_bits;
     if (hash_bits >= 32) bits = 32;        // 2 * log2(1024) + 8 = 28 bits, rounded up to whole digits; (key << 10 | position) fits 64 bits
     const u64 mask = (1ull << bits) - 1ull;
-    wl_tiny_level_kernel<<<1, TINY_MAX, 0, ctx->stream>>>(
+    const unsigned carried_wgs = (do_scan == 0 && n_car > 0) ? (unsigned)std::min<i64>(cdiv(n_car, TINY_MAX), 8) : 0u;
+    wl_tiny_level_kernel<<<1 + carried_wgs, TINY_MAX, 0, ctx->stream>>>(
         act_prev, act_cur, st.scratch.p + 1, do_scan, st.frozen.p, b->row_ptr, b->col_idx, prev, b->nbr_sorted, cur, perm,
         level_seed(level, 0), mask, b->car_nodes, b->car_class, (u32)n_car,
         n_car > 0 ? (const u32*)b->car_class + n_car : nullptr, V, count_dev, tiny_dev, unresolved_dev);
