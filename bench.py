@@ -220,6 +220,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and the config-4 object")
     a = ap.parse_args()
 
+    # the CPU baseline runs FIRST: its n_jobs leg forks worker processes, which must not happen in a process
+    # that already holds an initialised HIP runtime (runtime threads, locks)
+    cpu_base = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1 and not a.no_cpu_baseline:
+        cfg0 = dict(WORKLOADS[a.workload])
+        if a.graphs not in (0, cfg0["N"]):
+            cfg0["N"] = a.graphs
+        cpu_base = cpu_baseline(min(a.cpu_sample, cfg0["N"]), cfg0)
+
     import torch
     from grakel_amd import GraphBatch, _lib
     from grakel_amd.engine import get_engine
@@ -431,10 +440,7 @@ def main():
             "phases_ms": phases,
             "phases_hbm": phases_hbm,
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, N), cfg)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_base            # measured before the GPU part (see the top of main)
         if world == 1 and not a.no_extras:
             out["end_to_end"] = end_to_end(eng, full, cfg, with_objects=(a.workload == "config3"))
             try:
