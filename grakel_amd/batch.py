@@ -380,15 +380,47 @@ def compress_labels(values, fitted=None):
         arr = None
     if fitted is None:
         if arr is not None:
-            uniq, inv = np.unique(arr, return_inverse=True)
+            uniq, inv = _unique_inverse(arr)
             return inv.astype(np.int32), {int(u): i for i, u in enumerate(uniq.tolist())}
         mapping = {dv: i for i, dv in enumerate(sorted(set(values)))}
         return np.fromiter((mapping[v] for v in values), np.int32, len(values)), mapping
     nl = len(fitted)
+    if arr is not None and arr.size and all(type(k) is int for k in fitted):
+        # integer labels: the look-up as a sorted search instead of a million dictionary probes
+        keys = np.fromiter(fitted.keys(), np.int64, nl) if nl else np.zeros(0, np.int64)
+        kid = np.fromiter(fitted.values(), np.int64, nl) if nl else np.zeros(0, np.int64)
+        order = np.argsort(keys, kind="stable")
+        keys, kid = keys[order], kid[order]
+        a64 = arr.astype(np.int64, copy=False)
+        pos = np.searchsorted(keys, a64)
+        pos_c = np.minimum(pos, max(nl - 1, 0))
+        seen = (keys[pos_c] == a64) if nl else np.zeros(a64.shape, bool)
+        ids = (kid[pos_c] if nl else np.zeros(a64.shape[0], np.int64)).astype(np.int32)
+        ext = {}
+        if not seen.all():
+            unseen = ~seen
+            fresh, inv = _unique_inverse(a64[unseen])         # sorted distinct unseen values
+            ids[unseen] = nl + inv
+            ext = {int(u): nl + i for i, u in enumerate(fresh.tolist())}
+        return ids, ext
     fresh = sorted({v for v in values if v not in fitted})
     ext = {dv: nl + i for i, dv in enumerate(fresh)}
     ids = np.fromiter((fitted[v] if v in fitted else ext[v] for v in values), np.int32, len(values))
     return ids, ext
+
+
+def _unique_inverse(arr):
+    """np.unique(arr, return_inverse=True) for an integer array; a counting pass instead of a sort when the
+    values span a small non-negative range (label alphabets usually do)."""
+    if arr.size:
+        lo, hi = int(arr.min()), int(arr.max())
+        if lo >= 0 and hi < (1 << 22):
+            present = np.zeros(hi + 1, bool)
+            present[arr] = True
+            uniq = np.flatnonzero(present)
+            rank = np.cumsum(present) - 1
+            return uniq.astype(arr.dtype, copy=False), rank[arr]
+    return np.unique(arr, return_inverse=True)
 
 
 def _pack_csr(n_nodes_per_graph, srcs, dsts, weights=None):
