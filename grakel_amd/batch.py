@@ -372,12 +372,18 @@ def compress_labels(values, fitted=None):
     Returns (int32 ids, mapping dict label -> id used for FIT (or the extension for transform)).
     """
     arr = None
-    try:
-        cand = np.asarray(values)
-        if cand.ndim == 1 and cand.dtype.kind in "iu" and len(values) == cand.shape[0]:
-            arr = cand
-    except Exception:
-        arr = None
+    if isinstance(values, (bytearray, bytes)):          # csrc/ingest.c: every label is an exact int64
+        arr = np.frombuffer(values, dtype=np.int64)
+        values = arr
+    else:
+        try:
+            cand = np.asarray(values)
+            if cand.ndim == 1 and cand.dtype.kind in "iu" and len(values) == cand.shape[0]:
+                arr = cand
+        except Exception:
+            arr = None
+    if arr is not None and fitted is not None and not all(type(k) is int for k in fitted):
+        values = arr.tolist()                            # the generic look-up below wants Python objects
     if fitted is None:
         if arr is not None:
             uniq, inv = _unique_inverse(arr)

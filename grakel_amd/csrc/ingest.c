@@ -41,6 +41,18 @@ static int vec_push(vec32* v, int32_t x) {
     return 0;
 }
 
+typedef struct { int64_t* p; size_t n, cap; } vec64;
+static int v64_push(vec64* v, int64_t x) {
+    if (v->n == v->cap) {
+        size_t nc = v->cap ? v->cap * 2 : 1024;
+        int64_t* q = (int64_t*)realloc(v->p, nc * sizeof(int64_t));
+        if (!q) return -1;
+        v->p = q, v->cap = nc;
+    }
+    v->p[v->n++] = x;
+    return 0;
+}
+
 static int cmp32(const void* a, const void* b) {
     int32_t x = *(const int32_t*)a, y = *(const int32_t*)b;
     return (x > y) - (x < y);
@@ -124,6 +136,8 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
     if (min_len < 2) min_len = 2;
 
     vec32 sizes = {0}, rowp = {0}, col = {0}, tmp = {0};
+    vec64 ivals = {0};                 /* the label values while every one of them is an exact int64 */
+    int all_int = 1;
     /* want_mask (WL-OA, weisfeiler_lehman_optimal_assignment.py:176): per labelled vertex, does it own an
      * entry in the reference's edge dictionary?  dict of lists: a key with a non-empty list, or a vertex
      * that only occurs as a neighbour; dict of dicts: any key or neighbour (batch.py: _edge_lists).
@@ -184,6 +198,12 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
                     if (PyErr_Occurred()) PyErr_Clear();
                 }
                 if (PyList_Append(values, lv)) { status = ST_ERROR; break; }
+                if (all_int) {                 /* exact ints that fit int64: the caller gets them as an array */
+                    int ovf = 0;
+                    long long iv = PyLong_CheckExact(lv) ? PyLong_AsLongLongAndOverflow(lv, &ovf) : 0;
+                    if (!PyLong_CheckExact(lv) || ovf) all_int = 0;
+                    else if (v64_push(&ivals, (int64_t)iv)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                }
                 ++i;
             }
             if (status != ST_OK) break;
@@ -264,12 +284,19 @@ done:;
         PyObject* a = PyByteArray_FromStringAndSize((const char*)sizes.p, (Py_ssize_t)(sizes.n * 4));
         PyObject* b = PyByteArray_FromStringAndSize((const char*)rowp.p, (Py_ssize_t)(rowp.n * 4));
         PyObject* c = PyByteArray_FromStringAndSize((const char*)col.p, (Py_ssize_t)(col.n * 4));
+        /* labels: a bytearray of int64 when all are exact ints (no million-element list -> array conversion), else the list */
+        PyObject* vals = values;
+        PyObject* packed = NULL;
+        if (all_int && ivals.n == (size_t)V) {
+            packed = PyByteArray_FromStringAndSize((const char*)ivals.p, (Py_ssize_t)(ivals.n * 8));
+            if (packed) vals = packed; else PyErr_Clear();
+        }
         if (a && b && c && want_mask) {
             PyObject* mk = PyByteArray_FromStringAndSize((const char*)flag, (Py_ssize_t)V);
-            if (mk) result = PyTuple_Pack(5, a, b, c, values, mk);
+            if (mk) result = PyTuple_Pack(5, a, b, c, vals, mk);
             Py_XDECREF(mk);
-        } else if (a && b && c) result = PyTuple_Pack(4, a, b, c, values);
-        Py_XDECREF(a); Py_XDECREF(b); Py_XDECREF(c);
+        } else if (a && b && c) result = PyTuple_Pack(4, a, b, c, vals);
+        Py_XDECREF(a); Py_XDECREF(b); Py_XDECREF(c); Py_XDECREF(packed);
     } else if (status == ST_DECLINE) {
         if (PyErr_Occurred()) PyErr_Clear();
         result = Py_None;
@@ -277,7 +304,7 @@ done:;
     }
     Py_XDECREF(values);
     Py_XDECREF(pos);
-    free(sizes.p); free(rowp.p); free(col.p); free(tmp.p); free(flag);
+    free(sizes.p); free(rowp.p); free(col.p); free(tmp.p); free(flag); free(ivals.p);
     return result;
 }
 
@@ -330,18 +357,7 @@ static int as_weight(PyObject* o, int32_t* out) {
     return ST_OK;
 }
 
-typedef struct { int64_t* p; size_t n, cap; } vec64;
 typedef struct { edge_t* p; size_t n, cap; } vecE;
-static int v64_push(vec64* v, int64_t x) {
-    if (v->n == v->cap) {
-        size_t nc = v->cap ? v->cap * 2 : 1024;
-        int64_t* q = (int64_t*)realloc(v->p, nc * sizeof(int64_t));
-        if (!q) return -1;
-        v->p = q, v->cap = nc;
-    }
-    v->p[v->n++] = x;
-    return 0;
-}
 static int vE_push(vecE* v, int64_t key, int32_t w) {
     if (v->n == v->cap) {
         size_t nc = v->cap ? v->cap * 2 : 1024;
