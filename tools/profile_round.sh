@@ -32,7 +32,15 @@ tail -c 600 "$out/bench_n1.json"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/sp_trace" -- python $root/tools/bench_sp.py 4110 5 > "$out/sp_config4_bench.json" 2> "$out/sp_trace.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wloa_trace" -- python $root/tools/bench_wloa.py config3 > "$out/wloa.json" 2> "$out/wloa_trace.log"
+# HBM counters of the same two runs (separate passes, as for the main bench)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d "$out/sp_pmc_$c" -- python $root/tools/bench_sp.py 4110 5 > /dev/null 2> "$out/sp_pmc_$c.log"
+  rocprofv3 --pmc $c --output-format csv -d "$out/wloa_pmc_$c" -- python $root/tools/bench_wloa.py config3 > /dev/null 2> "$out/wloa_pmc_$c.log"
+done
 cd "$root"
+python tools/pmc_summary.py "$out/sp_pmc_FETCH_SIZE" "$out/sp_pmc_WRITE_SIZE" > "$out/sp_config4_pmc_hbm_bytes.csv"
+python tools/pmc_summary.py "$out/wloa_pmc_FETCH_SIZE" "$out/wloa_pmc_WRITE_SIZE" > "$out/wloa_pmc_hbm_bytes.csv"
+rm -rf "$out"/sp_pmc_FETCH_SIZE "$out"/sp_pmc_WRITE_SIZE "$out"/wloa_pmc_FETCH_SIZE "$out"/wloa_pmc_WRITE_SIZE
 cp "$(ls $out/sp_trace/*/*kernel_stats.csv | head -1)" "$out/sp_config4_kernel_stats.csv" 2>/dev/null
 cp "$(ls $out/wloa_trace/*/*kernel_stats.csv | head -1)" "$out/wloa_kernel_stats.csv" 2>/dev/null
 rm -rf "$out/sp_trace" "$out/wloa_trace"
