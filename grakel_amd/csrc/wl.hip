@@ -1158,7 +1158,7 @@ static u64 level_seed(int level, int round) {
 static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash, u64 seed, u64 mask) {
     i64 V = b->n_nodes;
     if (V == 0) return GK_OK;
-    static const int sig_regs = getenv("GK_WL_SIG_NO_REGS") ? 0 : 1;      // A/B switch: insertion sort in LDS instead
+    const int sig_regs = getenv("GK_WL_SIG_NO_REGS") ? 0 : 1;      // A/B switch: insertion sort in LDS instead
     wl_signature_small_kernel<<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
         b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask, sig_regs);
     if (b->n_big > 0)
