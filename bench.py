@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=6500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and the config-4 object")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="context option (gk_set_option, include/gk_hip.h), e.g. --opt wl.debug=1; A/B runs only")
     a = ap.parse_args()
 
     # the CPU baseline runs FIRST: its n_jobs leg forks worker processes, which must not happen in a process
@@ -266,6 +268,8 @@ def main():
     N, h = cfg["N"], cfg["n_iter"]
     eng = get_engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    for o in a.opt:
+        eng.set_option(o.split("=")[0], int(o.split("=")[1]))
 
     gp, rp, ci, lab = er_dataset_csr(N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])
     full = GraphBatch(gp, rp, ci, lab, cfg["L"])
@@ -292,7 +296,7 @@ def main():
             eng.wl_relabel(db, h)
             feat = eng.features(db, h + 1)
             eng.gram(feat, 0, to_host=False)
-            info.update(n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, dtype=feat.dtype,
+            info.update(n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, dtype=feat.dtype, operand=feat.operand,
                         label_counts=db.label_counts, nnz=feat.nnz)
             collect()
             pending.append(feat)
@@ -378,7 +382,7 @@ def main():
         operand_bytes = (N + 511) // 256 * 256 * ((d_dense + 255) // 256 * 128)
         gram_bytes = 8.0 * rows * N * (1.0 if world == 1 else 0.5 * (1.0 + 1.0 / world)) + operand_bytes
         achieved_gbs = gram_bytes / (gram_avg_ms * 1e-3) / 1e9
-        mfma_peak = I8_DENSE_PEAK_TOPS if os.environ.get("GK_GRAM_NO_FP4") else FP4_DENSE_PEAK_TOPS
+        mfma_peak = FP4_DENSE_PEAK_TOPS if str(info.get("operand", "fp4")).startswith("fp4") else I8_DENSE_PEAK_TOPS
         alg_flops = 2.0 * (N * (N + 1) / 2) * d_eff / world
         # HBM view of the two integer phases (SURVEY.md 8d algorithmic bytes, int32 everywhere):
         # relabel per level 8E + 12V (signature) + 24V (dictionary pass); features 16V per level
@@ -404,7 +408,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64" if f64_only else "fp4+i8",
+            "dtype": info.get("operand") or ("f64" if f64_only else "fp4+i8"),
             "data": "synthetic",
             "config": {"workload": "BASELINE %s: %d Erdos-Renyi graphs n=%d p=%.2f, %d labels, seed %d, "
                                    "WL-subtree h=%d, full NxN float64 Gram left in HBM"

@@ -37,6 +37,8 @@ SIGNATURES = {
     "gk_profile_enable": (c_int, [c_void_p, c_int]),
     "gk_profile_reset": (c_int, [c_void_p]),
     "gk_profile_get": (c_int, [c_void_p, c_char_p, _f64p, _i64p]),
+    "gk_set_option": (c_int, [c_void_p, c_char_p, c_int64]),
+    "gk_get_option": (c_int, [c_void_p, c_char_p, _i64p]),
     "gk_host_alloc": (c_int, [ctypes.c_uint64, _vpp]),
     "gk_host_free": (c_int, [c_void_p]),
     "gk_batch_create": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
@@ -51,6 +53,7 @@ SIGNATURES = {
     "gk_features_build_ex": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, _vpp]),
     "gk_features_destroy": (c_int, [c_void_p]),
     "gk_features_info": (c_int, [c_void_p, _i64p, _i64p, _i64p, _i64p, POINTER(c_int)]),
+    "gk_features_operand": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), _i64p]),
     "gk_features_selfk": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gk_features_debug_phi": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gk_gram": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
@@ -81,8 +84,7 @@ def load():
                       "There is no CPU fallback." % LIB_PATH)
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if /opt/rocm's
     # copy gets loaded first (through this library) a later `import torch` finds "No HIP GPUs".
-    # Importing torch first makes both share torch's runtime (measured on the MI355X box,
-    # tools/dbg_dist.py).  torch stays optional: without it the system runtime is used.
+    # Importing torch first makes both share torch's runtime (measured on the MI355X box).  torch stays optional: without it the system runtime is used.
     try:
         import torch  # noqa: F401
     except ImportError:

@@ -52,7 +52,7 @@ extern "C" int gk_create(int device_id, gk_ctx** out) {
     GK_HIP_CHECK(hipEventCreate(&ctx->ev1));
     GK_HIP_CHECK(hipEventCreate(&ctx->pv0));
     GK_HIP_CHECK(hipEventCreate(&ctx->pv1));
-    if (!getenv("GK_NO_MAILBOX")) {
+    {
         void* h = nullptr;
         void* d = nullptr;
         if (hipHostMalloc(&h, GK_MBOX_WORDS * 4, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
@@ -103,7 +103,7 @@ __global__ void mbox_post_kernel(const u32* __restrict__ src, int n_words, u32* 
 // number and ctx->mbox_dev, stores its words at mbox[1..] and then releases mbox[0] = seq at system
 // scope; the host collects them with gk_mbox_wait().  Returns 0 when the mailbox is unavailable.
 u32 gk_mbox_begin(gk_ctx* ctx) {
-    if (!ctx->mbox_host) return 0;
+    if (!ctx->mbox_host || ctx->opt.no_mailbox) return 0;
     if (++ctx->mbox_seq == 0) ++ctx->mbox_seq;     // never 0
     return ctx->mbox_seq;
 }
@@ -162,6 +162,44 @@ extern "C" int gk_host_free(void* p) {
     return GK_OK;
 }
 
+// ---- options ---------------------------------------------------------------------------------
+struct OptName { const char* name; int gk_opts::*field; };
+static const OptName g_opt_names[] = {
+    {"wl.no_tiny", &gk_opts::wl_no_tiny}, {"wl.no_listscan", &gk_opts::wl_no_listscan}, {"wl.no_iso", &gk_opts::wl_no_iso},
+    {"wl.no_split", &gk_opts::wl_no_split}, {"wl.no_exact1", &gk_opts::wl_no_exact1}, {"wl.no_active_set", &gk_opts::wl_no_active_set},
+    {"wl.no_bucket_dict", &gk_opts::wl_no_bucket_dict}, {"wl.no_hist0", &gk_opts::wl_no_hist0},
+    {"wl.frozen_words", &gk_opts::wl_frozen_words}, {"wl.flag_bytes", &gk_opts::wl_flag_bytes},
+    {"wl.sig_no_regs", &gk_opts::wl_sig_no_regs}, {"wl.debug", &gk_opts::wl_debug}, {"sort.buckets", &gk_opts::sort_buckets},
+    {"wl.bd_slots", &gk_opts::bd_slots}, {"feat.no_gm", &gk_opts::feat_no_gm}, {"feat.gm_no_priv", &gk_opts::gm_no_priv},
+    {"feat.low_df", &gk_opts::low_df}, {"feat.gm_row_lds_max", &gk_opts::gm_row_lds_max},
+    {"gram.no_fp4", &gk_opts::gram_no_fp4}, {"gram.no_ws", &gk_opts::gram_no_ws}, {"gram.no_sym", &gk_opts::gram_no_sym},
+    {"gram.no_patch", &gk_opts::gram_no_patch}, {"gram.xcc", &gk_opts::gram_xcc}, {"no_mailbox", &gk_opts::no_mailbox},
+    {"debug.poison", &gk_opts::poison},
+};
+
+extern "C" int gk_set_option(gk_ctx* ctx, const char* name, int64_t value) {
+    GK_ARG(ctx && name, "gk_set_option: null argument");
+    GK_ARG(value >= -2147483647 && value <= 2147483647, "gk_set_option: value out of range");
+    for (const OptName& o : g_opt_names)
+        if (!strcmp(o.name, name)) {
+            ctx->opt.*(o.field) = (int)value;
+            return GK_OK;
+        }
+    gk_set_error("gk_set_option: unknown option '%s'", name);
+    return GK_ERR_ARG;
+}
+
+extern "C" int gk_get_option(gk_ctx* ctx, const char* name, int64_t* out_value) {
+    GK_ARG(ctx && name && out_value, "gk_get_option: null argument");
+    for (const OptName& o : g_opt_names)
+        if (!strcmp(o.name, name)) {
+            *out_value = ctx->opt.*(o.field);
+            return GK_OK;
+        }
+    gk_set_error("gk_get_option: unknown option '%s'", name);
+    return GK_ERR_ARG;
+}
+
 extern "C" int gk_set_stream(gk_ctx* ctx, void* hip_stream) {
     GK_ARG(ctx, "gk_set_stream: null ctx");
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -211,6 +249,16 @@ extern "C" int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int
     return GK_OK;
 }
 
+int gk_func_lds(gk_ctx* ctx, const void* func, int bytes) {
+    if (bytes <= 32 * 1024) return GK_OK;        // below every default limit
+    int& have = ctx->func_lds[func];
+    if (bytes > have) {
+        GK_HIP_CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        have = bytes;
+    }
+    return GK_OK;
+}
+
 static size_t bucket_size(size_t bytes) {
     if (bytes < 512) return 512;
     if (bytes <= (1u << 20)) {   // next power of two up to 1 MiB
@@ -227,6 +275,22 @@ static void cache_release_all(gk_ctx* ctx) {
     ctx->cache.free_blocks.clear();
 }
 
+// debug.poison: every block the allocator hands out is filled with a byte pattern first, so that a kernel
+// reading memory nobody wrote sees the same garbage in every run (tests/tools/poison_suite.sh)
+__global__ void gk_poison_kernel(uint4* __restrict__ p, size_t n16, u32 word) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint4 z = make_uint4(word, word, word, word);
+    for (; i < n16; i += stride) p[i] = z;
+}
+static void poison_block(gk_ctx* ctx, void* p, size_t cap) {
+    if (!ctx->opt.poison) return;
+    const u32 b = (u32)ctx->opt.poison & 0xffu, word = b | (b << 8) | (b << 16) | (b << 24);
+    size_t blocks = (cap / 16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    gk_poison_kernel<<<dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, ctx->stream>>>((uint4*)p, cap / 16, word);
+}
+
 int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes) {
     const size_t cap = bucket_size(bytes);
     BlockCache& c = ctx->cache;
@@ -234,6 +298,7 @@ int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes) {
     if (it != c.free_blocks.end() && it->first <= cap + cap / 2) {   // bounded internal waste
         *p = it->second;
         c.live[*p] = it->first;
+        poison_block(ctx, *p, it->first);
         c.free_blocks.erase(it);
         return GK_OK;
     }
@@ -252,6 +317,7 @@ int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes) {
     }
     c.live[*p] = cap;
     c.bytes_total += cap;
+    poison_block(ctx, *p, cap);
     return GK_OK;
 }
 

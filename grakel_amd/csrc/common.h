@@ -58,8 +58,28 @@ struct BlockCache {
     size_t bytes_total = 0;
 };
 
+// Route / tuning options of a context (gk_set_option, include/gk_hip.h).  Every option leaves the results
+// unchanged: each one removes or forces one of several equivalent routes (the parity tests run the job through
+// every one of them) or resizes a capacity so that a fallback is taken.  All zero = production behaviour.  The
+// library reads NO environment variables.
+struct gk_opts {
+    // relabel routes (wl.hip)
+    int wl_no_tiny = 0, wl_no_listscan = 0, wl_no_iso = 0, wl_no_split = 0, wl_no_exact1 = 0, wl_no_active_set = 0;
+    int wl_no_bucket_dict = 0, wl_no_hist0 = 0, wl_frozen_words = 0, wl_flag_bytes = 0, wl_sig_no_regs = 0, wl_debug = 0;
+    int sort_buckets = 0;        // 0 decide per level, 1 never, 2 always the bucket finish of the sort
+    int bd_slots = 0;            // > 0: capacity (distinct keys per bucket) of the sort-free dictionary, to force its overflow
+    // features
+    int feat_no_gm = 0, gm_no_priv = 0, low_df = 0 /* 0 = 24 */, gm_row_lds_max = 0 /* 0 = GM_ROW_LDS_MAX */;
+    // Gram
+    int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
+    // plumbing
+    int no_mailbox = 0;
+    int poison = 0;              // debug: fill every block handed out by the allocator with this byte pattern (| 0x100)
+};
+
 struct gk_ctx {
     int device = 0;
+    gk_opts opt;
     BlockCache cache;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
@@ -73,6 +93,7 @@ struct gk_ctx {
     u32* mbox_dev = nullptr;
     u32 mbox_seq = 0;
     int n_cu = 0;                              // compute units of the device (persistent-kernel grids)
+    std::map<const void*, int> func_lds;       // kernel -> dynamic LDS limit already set for THIS context's device (gk_func_lds)
 };
 #define GK_MBOX_WORDS 512
 #define GK_HIST0_MAX_LABELS 256
@@ -82,6 +103,10 @@ struct gk_ctx {
 int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words);
 u32 gk_mbox_begin(gk_ctx* ctx);                                     // 0: no mailbox, use gk_readback
 int gk_mbox_wait(gk_ctx* ctx, u32 seq, u32* dst_host, int n_words);
+
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) to at least `bytes`; remembered per
+// context, i.e. per device (contexts of several devices may live in one process)
+int gk_func_lds(gk_ctx* ctx, const void* func, int bytes);
 
 // Device allocation through the context's block cache (stream-ordered reuse on ctx->stream).
 int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes);
@@ -260,12 +285,14 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
                         i64 n, int key_bits, int use_buckets = 0, u32* top_digit_max = nullptr);
 
 // Dictionary without a sort (full WL levels whose label-grouped order nobody reads): see scan_sort.hip
+bool gk_bucket_dictionary_fits(gk_ctx* ctx, i64 n);      // a-priori test: can no bucket overflow when every key is distinct?
 int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* rep, u32* frozen,
                          unsigned char* shared_out, u32* count_dev, u32* listed_dev, u32* top_digit_max, u32* overflow,
                          u32* mbox, u32 seq, int flag_in_rep = 0);
 
 // ---- wl.hip ---------------------------------------------------------------------------
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);
+int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level);      // perm[level] on demand (sort-free dictionary levels)
 
 // ---- gram.hip -------------------------------------------------------------------------
 int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normalize, double* K);

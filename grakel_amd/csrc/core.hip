@@ -67,8 +67,7 @@ extern "C" int gk_core_numbers(gk_ctx* ctx, gk_batch* b, int32_t* out_core) {
     GK_TRY(gk_zero_async(ctx, too_big.p, 4));
     i64 nmax = b->max_graph_nodes < CORE_MAX_N ? b->max_graph_nodes : CORE_MAX_N;
     const size_t lds = (size_t)(nmax > 0 ? nmax : 1) * 8;
-    if (lds > 48 * 1024)
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)core_number_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GK_TRY(gk_func_lds(ctx, (const void*)core_number_kernel, (int)lds));
     core_number_kernel<<<dim3((unsigned)N), CORE_THREADS, lds, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, core.p, too_big.p);
     GK_HIP_CHECK(hipGetLastError());
     u32 h_big = 0;

@@ -498,8 +498,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         return fail(GK_ERR_HIP);
     }
     {
-        const char* e = getenv("GK_LOW_DF");     // df threshold below which a column leaves the dense operand
-        f->low_df = e ? atoi(e) : 24;
+        f->low_df = ctx->opt.low_df > 0 ? ctx->opt.low_df : 24;     // df threshold below which a column leaves the dense operand
         if (f->low_df < 2) f->low_df = 2;        // 2 == everything useful is dense
     }
     if (!b->graph_ptr) {
@@ -517,12 +516,12 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
                              ? (double)n_levels * (double)b->max_graph_nodes
                              : (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
     f->dtype = (kind == GK_FEAT_MINSUM || bound < 2147483647.0) ? 0 : 1;
-    f->phi_fp4 = f->dtype == 0 && bound < 16777216.0 && !getenv("GK_GRAM_NO_FP4");
+    f->phi_fp4 = f->dtype == 0 && bound < 16777216.0 && !ctx->opt.gram_no_fp4;
     const int wide_above = kind == GK_FEAT_MINSUM ? 0x7fffffff : (f->dtype == 0 ? 127 : -1);
     const int prim_max = f->dtype != 0 ? -1 : (f->phi_fp4 ? 4 : 127);
     // ---- graph batches with small graphs: the graph-major builder (features_gm.hip); it declines (row wider
     // than its LDS image) with GK_ERR_UNSUPPORTED and this builder takes over
-    if (!b->is_pair_batch && V > 0 && b->max_graph_nodes <= GM_MAX_NODES && !getenv("GK_FEAT_NO_GM")) {
+    if (!b->is_pair_batch && V > 0 && b->max_graph_nodes <= GM_MAX_NODES && !ctx->opt.feat_no_gm) {
         r = gk_features_build_gm(ctx, b, f, n_levels, prim_max, wide_above);
         if (r == GK_OK) { *out = f; return GK_OK; }
         if (r != GK_ERR_UNSUPPORTED) return fail(r);
@@ -543,11 +542,9 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
         i64 nl = (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V;
         if (l == 0 && hist0) nl = L0 * N;           // items of the synthesized slot: (label, graph) cells
         if (nl == 0) continue;
-        if (!(l == 0 && hist0) && (size_t)l < b->perm_valid.size() && !b->perm_valid[l]) {
-            gk_set_error("gk_features_build: this batch was relabelled without label-grouped orders (graph-major features); "
-                         "set GK_WL_NO_BUCKET_DICT=1 to use the label-major builder");
-            return fail(GK_ERR_STATE);
-        }
+        // the relabel skipped this level's label-grouped order (sort-free dictionary, wl.hip): build it now
+        if (!(l == 0 && hist0) && (size_t)l < b->perm_valid.size() && !b->perm_valid[l] && (r = gk_batch_rebuild_order(ctx, b, l)))
+            return fail(r);
         const int j = P.L++;
         slot_of_level[l] = j;
         P.perm[j] = b->perm + (size_t)l * V, P.lab[j] = b->labels + (size_t)l * V;
@@ -679,6 +676,15 @@ extern "C" int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* n_col
     if (nnz) *nnz = f->nnz;
     if (max_count) *max_count = f->max_count;
     if (dtype) *dtype = (f->n_cols_wide > 0 && f->n_cols == 0) ? 1 : 0;   // 1: only the float64 operand is in use
+    return GK_OK;
+}
+
+extern "C" int gk_features_operand(gk_feat* f, int* fp4, int* k_steps_primary, int* k_steps_i8_secondary, int64_t* n_cols_f64) {
+    GK_ARG(f, "gk_features_operand: null");
+    if (fp4) *fp4 = f->phi_fp4 ? 1 : 0;
+    if (k_steps_primary) *k_steps_primary = f->k1_steps;
+    if (k_steps_i8_secondary) *k_steps_i8_secondary = f->k8_steps;
+    if (n_cols_f64) *n_cols_f64 = f->n_cols_wide;
     return GK_OK;
 }
 

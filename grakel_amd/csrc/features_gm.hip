@@ -555,7 +555,7 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     const i64 priv_budget = std::max<i64>(0, (160 * 1024 / per_cu - 1024 - (i64)waves * 2 * T * 4) / 2);
     GmPriv R;
     R.bins = 0;
-    const bool priv_ok = kind == GK_FEAT_DOT && !getenv("GK_GM_NO_PRIV") && cdiv(N, grid * waves) + 1 < (i64)GM_PRIV_COUNT_MASK;
+    const bool priv_ok = kind == GK_FEAT_DOT && !ctx->opt.gm_no_priv && cdiv(N, grid * waves) + 1 < (i64)GM_PRIV_COUNT_MASK;
     for (int j = 0; j < FEAT_MAX_LEVELS; ++j) R.off[j] = -1;
     for (int j = 0; j < P.L; ++j) {
         const i64 ids = P.off[j + 1] - P.off[j];
@@ -564,11 +564,7 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     R.bins = (R.bins + 1) & ~1;
     const size_t pairs_lds = (size_t)R.bins * 2 + (size_t)waves * 2 * T * 4;
     GK_ARG(pairs_lds <= 160 * 1024, "gk_features_build: graph too large for the graph-major builder");
-    static size_t pairs_lds_set = 0;
-    if (pairs_lds > 48 * 1024 && pairs_lds > pairs_lds_set) {
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
-        pairs_lds_set = pairs_lds;
-    }
+    GK_TRY(gk_func_lds(ctx, (const void*)gm_pairs_kernel, (int)pairs_lds));
     Tmp<u32> part(ctx), wgmeta(ctx);
     GK_TRY(wgmeta.alloc((size_t)grid * 2));
     GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
@@ -602,7 +598,8 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     f->k1_steps = (int)(n1p / (f->phi_fp4 ? 256 : 128)), f->k8_steps = (int)(n8p / 128);
     f->n_cols_pad = (f->phi_fp4 ? n1p / 2 : n1p) + n8p;
     f->n_rows_pad = round_up(N, 256) + 256;
-    if (f->n_cols_pad > GM_ROW_LDS_MAX) return GK_ERR_UNSUPPORTED;            // caller falls back to features.hip
+    const i64 row_lds_max = ctx->opt.gm_row_lds_max > 0 ? (i64)ctx->opt.gm_row_lds_max : (i64)GM_ROW_LDS_MAX;     // option: test hook
+    if (f->n_cols_pad > row_lds_max) return GK_ERR_UNSUPPORTED;              // caller falls back to features.hip
     GK_TRY(gk_dev_alloc(ctx, &q, (size_t)f->n_rows_pad * f->n_cols_pad));
     f->phi = q;
     if (f->n_cols_wide > 0) {
@@ -620,11 +617,7 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
         lc = (i32*)q, f->arena.push_back(q);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)gm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GM_ROW_LDS_MAX));
-        attr_set = true;
-    }
+    GK_TRY(gk_func_lds(ctx, (const void*)gm_rows_kernel, (int)f->n_cols_pad));
     // one workgroup per graph (64- and 128-thread workgroups measured the same 30 us: the chain of dependent loads
     // slot -> entry -> column id binds, not the number of workgroups in flight)
     gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(

@@ -648,7 +648,10 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
     int k_all = f->k1_steps + f->k8_steps, k8 = f->k8_steps;
     i64 M_store = M;
     int abl_bits = 0;
-    if (const char* abl = getenv("GK_GRAM_ABL")) {     // timing ablations (tools/gram_only.py): WRONG results
+#ifdef GK_ABLATION
+    // timing ablations (WRONG results by construction): only in the tools' build of the library
+    // (make -C grakel_amd/csrc abl -> libgk_hip_abl.so, tools/gram_only.py); the shipped library has none of this
+    if (const char* abl = getenv("GK_GRAM_ABL")) {
         if (!strcmp(abl, "nostore")) M_store = 0, abl_bits = 6;       // K loop only: every store is predicated off
         if (!strcmp(abl, "nok")) k_all = 0, k8 = 0;     // epilogue only
         if (!strcmp(abl, "noload")) abl_bits = 1;      // persistent kernel: MFMA + LDS reads only
@@ -657,42 +660,42 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
         if (!strcmp(abl, "nobarrier")) abl_bits = 4;   // no loads, no per-step barrier
         if (!strcmp(abl, "puremfma")) abl_bits = 5;    // compute waves: MFMA only, store waves idle, no barriers
     }
-    const bool use_ws = getenv("GK_GRAM_NO_WS") == nullptr;
+#endif
+    const bool use_ws = !ctx->opt.gram_no_ws;
     if (use_ws) {
         const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
         const i64 grid = blocks < n_cu ? blocks : n_cu;
         unsigned* ticket = nullptr;
         Tmp<unsigned> ticket_buf(ctx);
-        if (getenv("GK_GRAM_XCC")) {
+        if (ctx->opt.gram_xcc) {
             GK_TRY(ticket_buf.alloc(8));
             GK_TRY(gk_zero_async(ctx, ticket_buf.p, 32));
             ticket = ticket_buf.p;
         }
         void (*kern)(const int8_t*, const int8_t*, i64, int, int, const u64*, double*, i64, i64, i64, int, i64, int, int, int,
                      int, int, int, i64, unsigned*, i64, i64, int) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
+#ifdef GK_ABLATION
         if (abl_bits == 1) kern = gram_ws_kernel<true, 1>;
         if (abl_bits == 2) kern = gram_ws_kernel<true, 2>;
         if (abl_bits == 3) kern = gram_ws_kernel<true, 3>;
         if (abl_bits == 4) kern = gram_ws_kernel<true, 4>;
         if (abl_bits == 5) kern = gram_ws_kernel<true, 5>;
         if (abl_bits == 6) kern = gram_ws_kernel<true, 6>, M_store = M;
-        static std::map<const void*, bool> attr_done;      // once per kernel instance
-        if (!attr_done[(const void*)kern]) {
-            GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
-            attr_done[(const void*)kern] = true;
-        }
+#endif
+        (void)abl_bits;
+        GK_TRY(gk_func_lds(ctx, (const void*)kern, WS_LDS_BYTES));
         kern<<<dim3((unsigned)grid), dim3(512), WS_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
             normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket, ldk, col_lo, even);
     } else if (f->phi_fp4) {
         auto kern = gram_tile_kernel<true>;
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES));
+        GK_TRY(gk_func_lds(ctx, (const void*)kern, GT_LDS_BYTES));
         kern<<<dim3((unsigned)blocks), dim3(256), GT_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M_store, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
             normalize, tiles_m, tiles_n, tri, patch_sz, ldk, col_lo, even);
     } else {
         auto kern = gram_tile_kernel<false>;
-        GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES));
+        GK_TRY(gk_func_lds(ctx, (const void*)kern, GT_LDS_BYTES));
         kern<<<dim3((unsigned)blocks), dim3(256), GT_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M_store, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
             normalize, tiles_m, tiles_n, tri, patch_sz, ldk, col_lo, even);
@@ -865,8 +868,8 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
         const int8_t* phi = (const int8_t*)f->phi;
         const int8_t* pa = phi + first_row_graph * f->n_cols_pad;
         const int8_t* pb = phi + col_lo * f->n_cols_pad;
-        const int tri = (f->symmetric && row_lo == col_lo && row_hi == col_hi && !getenv("GK_GRAM_NO_SYM")) ? 1 : 0;
-        const int patch = getenv("GK_GRAM_NO_PATCH") ? 0 : 1;
+        const int tri = (f->symmetric && row_lo == col_lo && row_hi == col_hi && !ctx->opt.gram_no_sym) ? 1 : 0;
+        const int patch = ctx->opt.gram_no_patch ? 0 : 1;
         GK_TRY(launch_tiles(ctx, f, pa, pb, M, NC, row_lo, normalize, K, tri, patch, &entries_done, ldk, col_lo));
     }
     GK_HIP_CHECK(hipGetLastError());

@@ -683,12 +683,7 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
             radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
                 keys_in, vals_in, kx, vx, n, shift, hist.p, totals, nblk, bucket_totals, top_digit_max);
         }
-        static bool attr_set = false;
-        if (!attr_set) {
-            GK_HIP_CHECK(hipFuncSetAttribute((const void*)radix_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             BK_LDS_BYTES));
-            attr_set = true;
-        }
+        GK_TRY(gk_func_lds(ctx, (const void*)radix_bucket_kernel, BK_LDS_BYTES));
         radix_bucket_kernel<<<dim3(256), dim3(BK_THREADS), BK_LDS_BYTES, ctx->stream>>>(kx, vx, ky, vy, bucket_totals, inner);
         GK_HIP_CHECK(hipGetLastError());
         return GK_OK;
@@ -720,32 +715,38 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
 // Dictionary WITHOUT a sort (full WL levels of graph batches, wl.hip): equal keys only have to MEET, no
 // consumer needs them in order once the label-count features are built graph-major (features_gm.hip).
 // One stable pass on the top digit (as above) leaves 256 buckets; a workgroup then owns a bucket and
-// runs an open-addressing table in LDS over the remaining key bits: an item claims a slot with a
-// compare-and-swap or finds its key there and bumps the slot's counter.  Slots in use, ranked by a
-// workgroup prefix sum, are the bucket's classes; bucket offsets (a 256-entry prefix) make the ids dense.
-// Replaces the remaining 3-5 digit passes of the bucket finish AND the run-head scan over the sorted array.
-//   slot word: bits 0-13 owner item + 1 (0 = empty) | bits 14-27 members, later the slot's rank | bit 28 singleton
+// runs an open-addressing table in LDS over the remaining key bits.  The table holds DISTINCT keys -- a slot is
+// (key + 1 as a 64-bit word, 0 = empty | member count) -- and the bucket's items stream through it from HBM in
+// 1024-item chunks (twice: insert, then look up), so a bucket may hold any number of items as long as its
+// distinct keys fit: a class of 14 000 isolated vertices is one slot.  (The first version kept every ITEM's key in
+// LDS and overflowed at 8 192 items per bucket: config 5, 50 000 graphs with 70 000 isolated vertices, redid every
+// level on the sorting path -- profiles/r03a_config5_*.)  An item claims an empty slot with one 64-bit
+// compare-and-swap that publishes its key at the same time, or finds its key and bumps the counter.  Slots in
+// use, ranked by a workgroup prefix sum, are the bucket's classes; bucket offsets (a 256-entry prefix) make the
+// ids dense.  Replaces the remaining 3-5 digit passes of the bucket finish AND the run-head scan.
 //   per item (bucket_dict_kernel -> bucket_assign_kernel): bits 0-13 rank of its class in the bucket,
-//   bit 30 the item owns the class (its node becomes the representative), bit 31 singleton
-// A bucket above the capacity is not handled: the kernel raises BD_OVERFLOW in *overflow (and keeps the
-// outputs memory-safe); the caller redoes the level with the sorting path.
+//   bit 30 the item claimed the class (its node becomes the representative), bit 31 singleton
+// More distinct keys than max_distinct (or more than 64 chunks of items): the kernel raises BD_OVERFLOW in
+// *overflow (and keeps the outputs memory-safe); the caller redoes the level with the sorting path.
+// gk_bucket_dictionary_fits() is the caller's a-priori test (all-distinct worst case).
 // ---------------------------------------------------------------------------------------
-#define BD_SLOTS 16384
-#define BD_CAP32 12288          // keys of <= 32 remaining bits: 48 KiB of keys + 64 KiB of slots
-#define BD_CAP64 8192           // wider keys: 64 KiB + 64 KiB
+#define BD_SLOTS 12288          // 12 B per slot: 144 KiB of LDS
+#define BD_MAX_DISTINCT 9216    // load factor 0.75
+#define BD_MAX_CHUNKS 64        // claim flags of a thread: one bit per chunk
 
-template <typename K, int CAP>
 __global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict__ kx, const u32* __restrict__ totals,
                                                            int shift, u32* __restrict__ item_out, u32* __restrict__ nd,
-                                                           u32* __restrict__ overflow, unsigned long long* __restrict__ ticket) {
+                                                           u32* __restrict__ overflow, unsigned long long* __restrict__ ticket,
+                                                           u32 max_distinct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bd_lds[];
-    K* key_s = (K*)bd_lds;                                   // [CAP]
-    u32* slot_s = (u32*)(bd_lds + (size_t)CAP * sizeof(K));  // [BD_SLOTS]
+    unsigned long long* key_s = (unsigned long long*)bd_lds;                   // [BD_SLOTS] key + 1, 0 = empty
+    u32* word_s = (u32*)(bd_lds + (size_t)BD_SLOTS * 8);                       // [BD_SLOTS] members, later rank | singleton << 31
     __shared__ u32 dsum[4];
     __shared__ u32 wsum[16];
-    __shared__ u32 bstart;
+    __shared__ u32 bstart, n_claimed, ovf;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (blockIdx.x == 0 && tid == 0) *ticket = 0;           // bucket_assign_kernel's arrival counter
+    if (tid == 0) n_claimed = 0, ovf = 0;
     {   // bucket range: exclusive prefix of the digit totals
         const u32 t = tid < 256 ? totals[tid] : 0u;
         const u32 inc = wave_incl_scan(t);
@@ -761,34 +762,45 @@ __global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict
     const u32 size = totals[blockIdx.x];
     const i64 start = bstart;
     if (size == 0) { if (tid == 0) nd[blockIdx.x] = 0; return; }
-    if (size > (u32)CAP) {              // not handled here: one class for the whole bucket (memory-safe), level redone by the caller
+    const u64 kmask = shift >= 64 ? ~0ull : ((1ull << shift) - 1ull);       // shift <= 56: key + 1 never wraps to 0
+    for (int t = tid; t < BD_SLOTS; t += 1024) key_s[t] = 0ull, word_s[t] = 0u;
+    __syncthreads();
+    const bool too_long = size > (u32)BD_MAX_CHUNKS * 1024u;
+    // ---- insert: the thread keeps one "I claimed the slot" bit per chunk
+    u64 claimed = 0;
+    if (!too_long) {
+        int c = 0;
+        for (u32 i = tid; i < size; i += 1024, ++c) {
+            const u64 k1 = (kx[start + i] & kmask) + 1ull;
+            u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)BD_SLOTS) >> 32);
+            for (;;) {
+                unsigned long long v = key_s[h];
+                if (v == 0ull) {
+                    if (*(volatile u32*)&ovf) break;                                       // table declared full: stop claiming
+                    v = atomicCAS(&key_s[h], 0ull, (unsigned long long)k1);
+                    if (v == 0ull) {                                      // claimed: this item owns the class
+                        claimed |= 1ull << c;
+                        atomicAdd(&word_s[h], 1u);
+                        if (atomicAdd(&n_claimed, 1u) + 1u > max_distinct) ovf = 1u;
+                        break;
+                    }
+                }
+                if (v == k1) { atomicAdd(&word_s[h], 1u); break; }
+                h = h + 1u == (u32)BD_SLOTS ? 0u : h + 1u;
+            }
+        }
+    }
+    __syncthreads();
+    if (too_long || ovf) {              // not handled here: one class for the whole bucket (memory-safe), level redone by the caller
         for (u32 i = tid; i < size; i += 1024) item_out[start + i] = i == 0 ? (1u << 30) : 0u;
         if (tid == 0) { nd[blockIdx.x] = 1; atomicOr(overflow, 0x80000000u); }
         return;
     }
-    const u64 kmask = shift >= 64 ? ~0ull : ((1ull << shift) - 1ull);
-    for (u32 i = tid; i < size; i += 1024) key_s[i] = (K)(kx[start + i] & kmask);
-    for (int t = tid; t < BD_SLOTS; t += 1024) slot_s[t] = 0;
-    __syncthreads();
-    // ---- insert
-    for (u32 i = tid; i < size; i += 1024) {
-        const K k = key_s[i];
-        u32 h = (u32)(((u64)k * 0x9E3779B97F4A7C15ull) >> 50);       // 14 bits
-        for (;;) {
-            u32 v = slot_s[h];
-            if (v == 0) {
-                v = atomicCAS(&slot_s[h], 0u, (i + 1u) | (1u << 14));
-                if (v == 0) break;                                   // claimed: owner, one member
-            }
-            if (key_s[(v & 0x3fffu) - 1u] == k) { atomicAdd(&slot_s[h], 1u << 14); break; }
-            h = (h + 1u) & (BD_SLOTS - 1);
-        }
-    }
-    __syncthreads();
-    // ---- rank the slots in use: thread t owns slots [16t, 16t + 16)
+    // ---- rank the slots in use: thread t owns slots [12t, 12t + 12)
+    constexpr int PER = BD_SLOTS / 1024;
     u32 mine = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) mine += slot_s[16 * tid + q] ? 1u : 0u;
+    for (int q = 0; q < PER; ++q) mine += word_s[PER * tid + q] ? 1u : 0u;
     const u32 inc = wave_incl_scan(mine);
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
@@ -798,28 +810,33 @@ __global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict
         all += wsum[q];
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const u32 v = slot_s[16 * tid + q];
-        if (v) {
-            const u32 members = (v >> 14) & 0x3fffu;
-            slot_s[16 * tid + q] = (v & 0x3fffu) | (before << 14) | (members == 1u ? 1u << 28 : 0u);
+    for (int q = 0; q < PER; ++q) {
+        const u32 members = word_s[PER * tid + q];
+        if (members) {
+            word_s[PER * tid + q] = before | (members == 1u ? 0x80000000u : 0u);
             ++before;
         }
     }
     if (tid == 0) nd[blockIdx.x] = all;
     __syncthreads();
     // ---- every item looks its class up again
-    for (u32 i = tid; i < size; i += 1024) {
-        const K k = key_s[i];
-        u32 h = (u32)(((u64)k * 0x9E3779B97F4A7C15ull) >> 50);
-        u32 v;
-        for (;;) {
-            v = slot_s[h];
-            if (key_s[(v & 0x3fffu) - 1u] == k) break;
-            h = (h + 1u) & (BD_SLOTS - 1);
-        }
-        item_out[start + i] = ((v >> 14) & 0x3fffu) | ((v & 0x3fffu) == i + 1u ? 1u << 30 : 0u) | ((v >> 28) & 1u) << 31;
+    int c = 0;
+    for (u32 i = tid; i < size; i += 1024, ++c) {
+        const u64 k1 = (kx[start + i] & kmask) + 1ull;
+        u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)BD_SLOTS) >> 32);
+        while (key_s[h] != k1) h = h + 1u == (u32)BD_SLOTS ? 0u : h + 1u;
+        const u32 v = word_s[h];
+        item_out[start + i] = (v & 0x3fffu) | (((claimed >> c) & 1ull) ? 1u << 30 : 0u) | (v & 0x80000000u);
     }
+}
+
+// all-distinct worst case of a bucket: mean + 6 standard deviations of the binomial split over 256 buckets
+bool gk_bucket_dictionary_fits(gk_ctx* ctx, i64 n) {
+    const double m = (double)n / 256.0;
+    const double cap = ctx->opt.bd_slots > 0 ? 1e30 : (double)BD_MAX_DISTINCT;      // test hook: overflow is the point
+    double sd = 1.0;
+    while (sd * sd < m) sd += 1.0;
+    return m + 6.0 * sd <= cap;
 }
 
 // second half: dense ids = bucket offset + rank; labels, representatives, singleton / shared flags, the level's
@@ -915,24 +932,13 @@ int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32*
         radix_scatter_kernel<1024, false><<<dim3(nblk), dim3(1024), 0, ctx->stream>>>(
             keys, nullptr, kx.p, vx.p, n, shift, hist.p, totals, nblk, bucket_totals, top_digit_max);
     }
-    if (shift <= 32) {
-        auto kern = bucket_dict_kernel<u32, BD_CAP32>;
-        const int lds = BD_CAP32 * 4 + BD_SLOTS * 4;
-        static bool attr32 = false;
-        if (!attr32) {
-            GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr32 = true;
-        }
-        kern<<<dim3(256), dim3(1024), lds, ctx->stream>>>(kx.p, bucket_totals, shift, item.p, nd.p, overflow, ticket);
-    } else {
-        auto kern = bucket_dict_kernel<u64, BD_CAP64>;
-        const int lds = BD_CAP64 * 8 + BD_SLOTS * 4;
-        static bool attr64 = false;
-        if (!attr64) {
-            GK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr64 = true;
-        }
-        kern<<<dim3(256), dim3(1024), lds, ctx->stream>>>(kx.p, bucket_totals, shift, item.p, nd.p, overflow, ticket);
+    {
+        const int lds = BD_SLOTS * 12;
+        GK_TRY(gk_func_lds(ctx, (const void*)bucket_dict_kernel, lds));
+        u32 max_distinct = BD_MAX_DISTINCT;
+        if (ctx->opt.bd_slots > 0 && (u32)ctx->opt.bd_slots < max_distinct) max_distinct = (u32)ctx->opt.bd_slots;     // test hook
+        bucket_dict_kernel<<<dim3(256), dim3(1024), lds, ctx->stream>>>(kx.p, bucket_totals, shift, item.p, nd.p, overflow, ticket,
+                                                                      max_distinct);
     }
     bucket_assign_kernel<<<dim3((unsigned)cdiv(n, 1024)), dim3(1024), 0, ctx->stream>>>(
         vx.p, item.p, bucket_totals, nd.p, lab, rep, frozen, shared_out, listed_dev, count_dev, ticket, mbox, seq, top_digit_max, n,

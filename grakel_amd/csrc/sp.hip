@@ -230,8 +230,7 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
         if (nmax > split) {
             const int nfw = nmax < cap ? nmax : cap;
             lds = (size_t)nfw * (nfw | 1) * 4;
-            if (lds > 64 * 1024)
-                GK_HIP_CHECK(hipFuncSetAttribute((const void*)sp_fw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            GK_TRY(gk_func_lds(ctx, (const void*)sp_fw_kernel, (int)lds));
             sp_fw_kernel<<<dim3((unsigned)N), 1024, lds, ctx->stream>>>(
                 b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, split, cap);
         }
@@ -239,8 +238,7 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     if (nmax > cap) {
         GK_ARG(nmax <= SP_ROW_MAX_N, "ShortestPath: graphs above 32768 vertices are not supported");
         size_t lds = (size_t)nmax * 4;
-        if (lds > 64 * 1024)
-            GK_HIP_CHECK(hipFuncSetAttribute((const void*)sp_relax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GK_TRY(gk_func_lds(ctx, (const void*)sp_relax_kernel, (int)lds));
         GK_ARG(nmax <= 65535, "ShortestPath: grid.y overflow");
         sp_relax_kernel<<<dim3((unsigned)N, (unsigned)nmax), SP_THREADS, lds, ctx->stream>>>(
             b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, cap);

@@ -34,6 +34,7 @@
 #include "scan_fn.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <memory>
 
 #define WL_DEG_SMALL 32       // nodes up to this degree: one thread sorts its list in LDS
 #define SIG_THREADS 256
@@ -892,7 +893,7 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
     b->max_graph_nodes = (i32)h[0], b->max_degree = (i32)h[1], b->n_big = h[2];
     b->n_labels0_present = few_labels ? (i32)h[4] : 0;
     b->n_iso = 0;
-    if (h[3] > 0 && !getenv("GK_WL_NO_ISO")) {
+    if (h[3] > 0 && !ctx->opt.wl_no_iso) {
         // the carried list of the isolated vertices (see gk_batch::iso_info)
         const i64 n_iso = h[3];
         void* q = nullptr;
@@ -1158,7 +1159,7 @@ static u64 level_seed(int level, int round) {
 static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash, u64 seed, u64 mask) {
     i64 V = b->n_nodes;
     if (V == 0) return GK_OK;
-    const int sig_regs = getenv("GK_WL_SIG_NO_REGS") ? 0 : 1;      // A/B switch: insertion sort in LDS instead
+    const int sig_regs = ctx->opt.wl_sig_no_regs ? 0 : 1;      // route option: insertion sort in LDS instead
     wl_signature_small_kernel<<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
         b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask, sig_regs);
     if (b->n_big > 0)
@@ -1181,9 +1182,10 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
                                 u32* listed_dev = nullptr, u32* posted_seq = nullptr, u32 lab_base = 0,
                                 const u32* lab_base_dev = nullptr, unsigned char* shared_out = nullptr,
                                 u32* no_order_overflow = nullptr, bool* frozen_in_shared = nullptr,
-                                bool* flag_in_rep = nullptr) {
+                                bool* flag_in_rep = nullptr, bool* no_order_taken = nullptr) {
     if (frozen_in_shared) *frozen_in_shared = false;
     if (flag_in_rep) *flag_in_rep = false;
+    if (no_order_taken) *no_order_taken = false;
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
         if (listed_dev) GK_TRY(gk_zero_async(ctx, listed_dev, 4));
@@ -1193,7 +1195,8 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
     GK_TRY(ks.alloc(n));
     Tmp<i32> rep_tmp(ctx);
     if (!rep) { GK_TRY(rep_tmp.alloc(rep_capacity > n ? rep_capacity : n)); rep = rep_tmp.p; }
-    if (listed_dev && !vals && no_order_overflow && key_bits >= 24) {
+    if (listed_dev && !vals && no_order_overflow && key_bits >= 24 && gk_bucket_dictionary_fits(ctx, n)) {
+        if (no_order_taken) *no_order_taken = true;
         // nobody reads this level's label-grouped order (graph-major features): equal keys only have to meet --
         // top-digit partition + one LDS table per bucket instead of the remaining digit passes and the
         // run-head scan (scan_sort.hip); a bucket that does not fit raises a flag in *no_order_overflow and
@@ -1202,11 +1205,11 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
         if (posted_seq) *posted_seq = seq;
         // singleton flags: one scattered byte per node (shared_out) instead of a byte and a word -- the only reader of
         // frozen[] after a full level, ActiveScan, takes the bytes
-        const bool bytes_only = shared_out && frozen_in_shared && !getenv("GK_WL_FROZEN_WORDS");
+        const bool bytes_only = shared_out && frozen_in_shared && !ctx->opt.wl_frozen_words;
         if (bytes_only) *frozen_in_shared = true;
         // ... and when the caller's verification pass follows (it gathers rep[lab[v]] per node), not even the byte:
         // the flag rides in bit 31 of rep[] and verify_kernel writes the bytes in node order
-        const bool in_rep = bytes_only && flag_in_rep && rep != rep_tmp.p && !getenv("GK_WL_FLAG_BYTES");
+        const bool in_rep = bytes_only && flag_in_rep && rep != rep_tmp.p && !ctx->opt.wl_flag_bytes;
         if (in_rep) *flag_in_rep = true;
         return gk_bucket_dictionary(ctx, keys, n, key_bits, lab, rep, bytes_only ? nullptr : frozen, in_rep ? nullptr : shared_out,
                                     count_dev, listed_dev, top_digit_max, no_order_overflow, seq ? ctx->mbox_dev : nullptr, seq,
@@ -1240,10 +1243,9 @@ int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i
 // the average.  Classes only split from level to level, so the largest bucket of the PREVIOUS
 // level's sort bounds this level's largest class; it is read back together with n_active.
 #define SORT_BUCKET_MAX_KEYS 12288     // what one workgroup sorts entirely in LDS (scan_sort.hip: BK_CAP)
-static int sort_buckets_ok(u32 prev_top_max, i64 n, bool exact) {
-    static const char* e = getenv("GK_SORT_BUCKETS");       // "0" never, "1" always (tests), unset: decide
-    if (e && e[0] == '0') return 0;
-    if (e && e[0] == '1') return 1;
+static int sort_buckets_ok(gk_ctx* ctx, u32 prev_top_max, i64 n, bool exact) {
+    if (ctx->opt.sort_buckets == 1) return 0;       // option "sort.buckets": 1 never, 2 always (tests), 0 decide
+    if (ctx->opt.sort_buckets == 2) return 1;
     if (exact || n / 256 > SORT_BUCKET_MAX_KEYS) return 0;
     if (prev_top_max > 0 && prev_top_max <= SORT_BUCKET_MAX_KEYS) return 1;
     return 2;       // no bound from the previous level (e.g. level 1 after a few input labels): let the sort probe
@@ -1314,14 +1316,14 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         // the full path again, and the active-set scan (two launches over all nodes) is not needed
         u32 back[2] = {0, 0};
         GK_TRY(gk_mbox_wait(ctx, st.posted_seq, back, 2));
-        if (((i64)back[0] - n_car) * 4 > V && !getenv("GK_WL_NO_ACTIVE_SET")) {
+        if (((i64)back[0] - n_car) * 4 > V && !ctx->opt.wl_no_active_set) {
             n_act = back[0], st.prev_top_max = back[1], decided = true;
         }
     }
     st.posted_seq = 0;
     bool list_based = false;               // this level's active list came from the previous level's list
     if (decided) {
-    } else if (!exact && !getenv("GK_WL_NO_ACTIVE_SET") && level >= 2) {
+    } else if (!exact && !ctx->opt.wl_no_active_set && level >= 2) {
         u32 back[2] = {0, 0};
         if (st.prev_active && st.list_scan) {
             // the previous level took the active-set path: frozen ids are permanent, so this level's labels
@@ -1358,8 +1360,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             st.act_cur = st.act.p;
         }
         n_act = back[0], st.prev_top_max = back[1];
-        static const bool dbg = getenv("GK_WL_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[gk] level %d: active %u of %lld%s, previous top-digit bucket max %u\n", level, n_act,
+        if (ctx->opt.wl_debug) fprintf(stderr, "[gk] level %d: active %u of %lld%s, previous top-digit bucket max %u\n", level, n_act,
                          (long long)V, list_based ? " (from the previous list)" : "", back[1]);
     } else {
         st.prev_top_max = 0;
@@ -1410,7 +1411,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act_cur, n_act, b->row_ptr, hash_node.p, hash_act.p);
         }
         GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act_cur, st.frozen.p, 0,
-                                    sort_buckets_ok(st.prev_top_max, n_act, exact), st.scratch.p + 2, nullptr, nullptr,
+                                    sort_buckets_ok(ctx, st.prev_top_max, n_act, exact), st.scratch.p + 2, nullptr, nullptr,
                                     n_frozen, n_cc_dev));
         // *unresolved_dev is still zero here: gk_wl_relabel cleared it and this path runs once per level
         if (list_based) {
@@ -1440,21 +1441,23 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     // level 1 of a job with few input labels: exact 32-bit signature codes (wl_signature_exact_kernel)
     bool exact_code = false;
     u64 code_R = (u64)b->max_degree + 1;
-    if (level == 1 && !exact && st.default_bits && b->n_labels0 >= 1 && b->n_labels0 <= 16 && !getenv("GK_WL_NO_EXACT1")) {
+    if (level == 1 && !exact && st.default_bits && b->n_labels0 >= 1 && b->n_labels0 <= 16 && !ctx->opt.wl_no_exact1) {
         double span = (double)b->n_labels0;
         for (int i = 0; i < b->n_labels0; ++i) span *= (double)code_R;
         exact_code = span < 4294967296.0;
     }
+    bool no_order_taken = false;
     for (int round = 0;; ++round) {
         if (exact_code) {
             wl_signature_exact_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, b->col_idx, prev, hash.p, V,
                                                                                  (int)b->n_labels0, code_R, unresolved_dev);
             GK_TRY(dictionary_from_keys(ctx, hash.p, V, 32, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
-                                        sort_buckets_ok(st.prev_top_max, V, exact), st.scratch.p + 2, listed_dev,
+                                        sort_buckets_ok(ctx, st.prev_top_max, V, exact), st.scratch.p + 2, listed_dev,
                                         listed_dev ? &st.posted_seq : nullptr, 0, nullptr, b->shared_flag + (size_t)level * V,
-                                        (st.no_order && !exact) ? unresolved_dev : nullptr, st.list_scan ? &st.frozen_in_shared : nullptr));
+                                        (st.no_order && !exact) ? unresolved_dev : nullptr, st.list_scan ? &st.frozen_in_shared : nullptr,
+                                        nullptr, &no_order_taken));
             st.shared_prev = b->shared_flag + (size_t)level * V;
-            b->perm_valid[level] = !(st.no_order && !exact && listed_dev) ? 1 : 0;
+            b->perm_valid[level] = no_order_taken ? 0 : 1;
             GK_HIP_CHECK(hipGetLastError());
             break;
         }
@@ -1468,13 +1471,13 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             bits = 64, sort_keys = keys.p;
         }
         GK_TRY(dictionary_from_keys(ctx, sort_keys, V, bits, cur, perm, rep.p, count_dev, nullptr, st.frozen.p, 0,
-                                    round == 0 ? sort_buckets_ok(st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev,
+                                    round == 0 ? sort_buckets_ok(ctx, st.prev_top_max, V, exact) : 0, st.scratch.p + 2, listed_dev,
                                     (listed_dev && !exact) ? &st.posted_seq : nullptr, 0, nullptr,
                                     b->shared_flag + (size_t)level * V,
                                     (st.no_order && !exact && round == 0) ? unresolved_dev : nullptr, st.list_scan ? &st.frozen_in_shared : nullptr,
-                                    &flag_in_rep));
+                                    &flag_in_rep, &no_order_taken));
         st.shared_prev = b->shared_flag + (size_t)level * V;
-        b->perm_valid[level] = !(st.no_order && !exact && round == 0 && listed_dev && bits >= 24) ? 1 : 0;
+        b->perm_valid[level] = no_order_taken ? 0 : 1;
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V,
@@ -1491,6 +1494,50 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             return GK_ERR_STATE;
         }
     }
+    return GK_OK;
+}
+
+// One hashed pass over all levels (level 0 included); h receives the per-level words of meta[] ([n_levels] counts,
+// unresolved, nodes of shared classes, active nodes of the single-workgroup levels).  force_sort: every dictionary
+// takes the sorting path (the second attempt after a bucket of the sort-free dictionary overflowed).
+static int relabel_pass(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits, bool force_sort,
+                        RelabelState& st, Tmp<u32>& meta, std::vector<u32>& h) {
+    const i64 V = b->n_nodes;
+    GK_TRY(gk_zero_async(ctx, meta.p, 16 * (size_t)n_levels));
+    b->n_sorted.assign((size_t)n_levels, V);
+    b->active_layout.assign((size_t)n_levels, 0);
+    b->perm_valid.assign((size_t)n_levels, 1);
+    st.default_bits = default_bits;
+    st.split = !ctx->opt.wl_no_split;
+    st.full_level.assign((size_t)n_levels, 0);
+    st.list_scan = !ctx->opt.wl_no_listscan;
+    st.tiny = !ctx->opt.wl_no_tiny;
+    // the graph-major feature builder (features_gm.hip) takes graph batches with small graphs: their full levels
+    // then need no label-grouped order
+    st.no_order = !b->is_pair_batch && b->max_graph_nodes <= 1024 && !ctx->opt.feat_no_gm && !ctx->opt.wl_no_bucket_dict && !force_sort;
+    st.tiny_level.assign((size_t)n_levels, 0);
+    GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
+    GK_TRY(st.act2.alloc(V / 4 + 1));      // active-set levels hold at most V/4 active nodes
+    // level 0: group nodes by the given label ids -- unless there are only a few of them: then nothing of
+    // level 0 needs an order (level 1 always takes the full path and never reads the singleton flags, the
+    // label-count features of level 0 come from one LDS histogram per graph, features.hip)
+    const bool hist0 = V > 0 && b->n_labels0 >= 1 && b->n_labels0 <= GK_HIST0_MAX_LABELS && !ctx->opt.wl_no_hist0;
+    b->level0_hist = hist0;
+    if (!hist0) {
+        Tmp<u64> keys(ctx);
+        Tmp<i32> lab_tmp(ctx);
+        GK_TRY(keys.alloc(V)); GK_TRY(lab_tmp.alloc(V));
+        if (V > 0) labels_to_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels, keys.p, V);
+        int bits = bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0);
+        st.full_level[0] = st.split ? 1 : 0;
+        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p, 0,
+                                    0, st.scratch.p + 2, st.split ? meta.p + 2 * n_levels : nullptr, nullptr, 0, nullptr,
+                                    b->shared_flag));
+    }
+    for (int lvl = 1; lvl < n_levels; ++lvl)
+        GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, st, meta.p + lvl, meta.p + n_levels + lvl,
+                             meta.p + 2 * n_levels + lvl, meta.p + 3 * n_levels + lvl, nullptr));
+    GK_TRY(gk_readback(ctx, meta.p, h.data(), 4 * n_levels));
     return GK_OK;
 }
 
@@ -1515,47 +1562,22 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     GK_TRY(gk_batch_ensure_levels(b, n_levels));
     Tmp<u32> meta(ctx);   // [n_levels] counts, [n_levels] unresolved, [n_levels] nodes of shared classes (full levels)
     GK_TRY(meta.alloc(4 * (size_t)n_levels));     // ... and [n_levels] active nodes of the levels run by the tiny kernel
-    GK_TRY(gk_zero_async(ctx, meta.p, 16 * (size_t)n_levels));
     if (out_rounds) *out_rounds = 0;
-    b->n_sorted.assign((size_t)n_levels, V);
-    b->active_layout.assign((size_t)n_levels, 0);
-    b->perm_valid.assign((size_t)n_levels, 1);
-    RelabelState st(ctx);
-    st.default_bits = default_bits;
-    st.split = getenv("GK_WL_NO_SPLIT") == nullptr;
-    st.full_level.assign((size_t)n_levels, 0);
-    st.list_scan = getenv("GK_WL_NO_LISTSCAN") == nullptr;
-    st.tiny = getenv("GK_WL_NO_TINY") == nullptr;
-    // the graph-major feature builder (features_gm.hip) takes graph batches with small graphs: their full levels
-    // then need no label-grouped order
-    st.no_order = !b->is_pair_batch && b->max_graph_nodes <= 1024 && !getenv("GK_FEAT_NO_GM") && !getenv("GK_WL_NO_BUCKET_DICT");
-    st.tiny_level.assign((size_t)n_levels, 0);
-    GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
-    GK_TRY(st.act2.alloc(V / 4 + 1));      // active-set levels hold at most V/4 active nodes
-    // level 0: group nodes by the given label ids -- unless there are only a few of them: then nothing of
-    // level 0 needs an order (level 1 always takes the full path and never reads the singleton flags, the
-    // label-count features of level 0 come from one LDS histogram per graph, features.hip)
-    const bool hist0 = V > 0 && b->n_labels0 >= 1 && b->n_labels0 <= GK_HIST0_MAX_LABELS && !getenv("GK_WL_NO_HIST0");
-    b->level0_hist = hist0;
-    if (!hist0) {
-        Tmp<u64> keys(ctx);
-        Tmp<i32> lab_tmp(ctx);
-        GK_TRY(keys.alloc(V)); GK_TRY(lab_tmp.alloc(V));
-        if (V > 0) labels_to_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels, keys.p, V);
-        int bits = bits_for(b->n_labels0 > 0 ? (u64)b->n_labels0 - 1 : 0);
-        st.full_level[0] = st.split ? 1 : 0;
-        GK_TRY(dictionary_from_keys(ctx, keys.p, V, bits, lab_tmp.p, b->perm, nullptr, meta.p, nullptr, st.frozen.p, 0,
-                                    0, st.scratch.p + 2, st.split ? meta.p + 2 * n_levels : nullptr, nullptr, 0, nullptr,
-                                    b->shared_flag));
-    }
     std::vector<u32> h(4 * (size_t)n_levels);
     int first_bad = -1;
-    for (int lvl = 1; lvl < n_levels; ++lvl)
-        GK_TRY(relabel_level(ctx, b, lvl, hash_bits, false, st, meta.p + lvl, meta.p + n_levels + lvl,
-                             meta.p + 2 * n_levels + lvl, meta.p + 3 * n_levels + lvl, nullptr));
-    GK_TRY(gk_readback(ctx, meta.p, h.data(), 4 * n_levels));
-    for (int lvl = 1; lvl < n_levels; ++lvl)
-        if (h[n_levels + lvl] != 0) { first_bad = lvl; break; }
+    std::unique_ptr<RelabelState> stp;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        stp.reset(new RelabelState(ctx));
+        GK_TRY(relabel_pass(ctx, b, n_levels, hash_bits, default_bits, attempt == 1, *stp, meta, h));
+        first_bad = -1;
+        for (int lvl = 1; lvl < n_levels; ++lvl)
+            if (h[n_levels + lvl] != 0) { first_bad = lvl; break; }
+        // a bucket of the sort-free dictionary overflowed (bit 31; gk_bucket_dictionary_fits makes that a matter of
+        // adversarial key distributions or of the wl.bd_slots test hook): once more, on the sorting path throughout
+        if (first_bad > 0 && (h[n_levels + first_bad] & 0x80000000u) && attempt == 0) continue;
+        break;
+    }
+    RelabelState& st = *stp;
     if (first_bad > 0) {   // a hash collision was detected: redo from that level, exactly
         for (int lvl = first_bad; lvl < n_levels; ++lvl)
             GK_TRY(relabel_level(ctx, b, lvl, hash_bits, true, st, meta.p + lvl, meta.p + n_levels + lvl,
@@ -1569,11 +1591,37 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         if (st.full_level[lvl]) b->n_sorted[lvl] = h[2 * n_levels + lvl];
         else if (st.tiny_level[lvl]) b->n_sorted[lvl] += h[3 * n_levels + lvl];      // carried + active
     }
-    if (hist0) h[0] = (u32)b->n_labels0_present;
+    if (b->level0_hist) h[0] = (u32)b->n_labels0_present;
     for (int lvl = 0; lvl < n_levels; ++lvl) {
         b->label_counts[lvl] = h[lvl];
         if (out_label_counts) out_label_counts[lvl] = h[lvl];
     }
+    return GK_OK;
+}
+
+// Label-grouped node order of a level whose dictionary ran without a sort (perm_valid == 0), built on demand:
+// the graph-major feature builder needs no order, but when it declines a job (operand row wider than its LDS
+// image) the label-major builder (features.hip) takes over and reads perm[level][0 .. n_sorted) = the nodes of
+// shared classes grouped by label, ascending node inside a group.  One stable sort of (label | singleton bit).
+__global__ void order_keys_kernel(const i32* __restrict__ lab, const unsigned char* __restrict__ shared, u64* __restrict__ keys,
+                                  i64 n, u64 single_key) {
+    const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) keys[v] = (!shared || shared[v]) ? (u64)(u32)lab[v] : single_key;
+}
+
+int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level) {
+    const i64 V = b->n_nodes;
+    if (V == 0 || (size_t)level >= b->perm_valid.size() || b->perm_valid[level]) return GK_OK;
+    GK_ARG(level >= 0 && level < b->n_levels && b->shared_flag, "gk_batch_rebuild_order: level without class flags");
+    const i64 count = level < (int)b->label_counts.size() ? b->label_counts[level] : V;
+    const int bits = bits_for((u64)(count > 0 ? count : 1));          // the singleton key `count` sorts behind every label
+    Tmp<u64> keys(ctx), ks(ctx);
+    GK_TRY(keys.alloc(V)); GK_TRY(ks.alloc(V));
+    order_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels + (size_t)level * V, b->shared_flag + (size_t)level * V,
+                                                                  keys.p, V, (u64)count);
+    GK_TRY(gk_radix_sort_pairs(ctx, keys.p, nullptr, ks.p, (u32*)(b->perm + (size_t)level * V), V, bits));
+    GK_HIP_CHECK(hipGetLastError());
+    b->perm_valid[level] = 1;
     return GK_OK;
 }
 

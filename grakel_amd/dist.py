@@ -301,7 +301,7 @@ class ShardedWL(object):
                 K = eng.gram(feat, 2 if self.normalize else 0, rows=rows, to_host=to_host)
                 info = dict()
             info.update(label_counts=counts, n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, rows=rows,
-                        n_graphs=N, gram=eng.gram_stats(feat), dtype=feat.dtype)
+                        n_graphs=N, gram=eng.gram_stats(feat), dtype=feat.dtype, operand=feat.operand)
             if keep:
                 info["feat"], info["batch"] = feat, db
             else:

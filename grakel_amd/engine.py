@@ -32,42 +32,84 @@ class _PinnedBlock(object):
 class PinnedPool(object):
     """Gram outputs live in pinned host memory: the 8 N^2-byte device -> host copy then runs at the PCIe
     rate (57 GB/s measured) instead of the pageable rate (12-18 GB/s).  Pinning is slow (~0.14 ms per MB),
-    so released blocks are kept (two per size) and handed out again: the first ``fit_transform`` of a
-    given size pays for the allocation, the following ones do not.  ``GK_PINNED_OUTPUT=0`` turns it off."""
+    so released blocks are kept and handed out again: the first ``fit_transform`` of a given size pays for
+    the allocation, the following ones do not.  Pinned memory cannot be swapped, so the pool is bounded:
+    one block is never larger than ``MAX_BLOCK`` (bigger outputs are ordinary pageable arrays), the blocks
+    retained for reuse never add up to more than ``MAX_RETAINED`` (least recently released go first), and
+    ``Engine.close()`` frees them all.  ``GK_PINNED_OUTPUT=0`` turns the pool off."""
 
     GRANULE = 2 << 20
     MIN_BYTES = 1 << 20
-    KEEP = 2
+    KEEP = 2                       # blocks retained per size
+    MAX_BLOCK = 24 << 30           # 50 000 x 50 000 float64 = 20 GB still gets a pinned block
+    MAX_RETAINED = 32 << 30
 
     def __init__(self, lib):
-        self.lib, self.free = lib, {}
+        import collections
+        import threading
+        self.lib = lib
+        self.free = collections.OrderedDict()        # (cap, ptr) in release order: oldest first
+        self.retained = 0
+        self.lock = threading.Lock()                 # _release runs from __del__, i.e. on any thread
+        self.closed = False
 
     def empty(self, shape):
         import os
         nbytes = 8
         for d in shape:
             nbytes *= int(d)
-        if nbytes < self.MIN_BYTES or os.environ.get("GK_PINNED_OUTPUT", "1") == "0":
+        if nbytes < self.MIN_BYTES or nbytes > self.MAX_BLOCK or os.environ.get("GK_PINNED_OUTPUT", "1") == "0":
             return np.empty(shape, dtype=np.float64)
         cap = -(-nbytes // self.GRANULE) * self.GRANULE
-        blocks = self.free.get(cap)
-        if blocks:
-            ptr = blocks.pop()
-        else:
+        ptr = None
+        with self.lock:
+            for key in self.free:
+                if key[0] == cap:
+                    ptr = key[1]
+                    del self.free[key]
+                    self.retained -= cap
+                    break
+        if ptr is None:
             p = c_void_p()
             if self.lib.gk_host_alloc(ctypes.c_uint64(cap), byref(p)) != 0 or not p.value:
-                return np.empty(shape, dtype=np.float64)          # no pinned memory left: pageable output
+                self.trim(0)                                          # give the retained blocks back and try once more
+                if self.lib.gk_host_alloc(ctypes.c_uint64(cap), byref(p)) != 0 or not p.value:
+                    return np.empty(shape, dtype=np.float64)          # no pinned memory left: pageable output
             ptr = p.value
         buf = (ctypes.c_char * nbytes).from_address(ptr)
         buf._gk_block = _PinnedBlock(self, ptr, cap)               # lives as long as any view of the array
         return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
     def _release(self, ptr, cap):
-        blocks = self.free.setdefault(cap, [])
-        if len(blocks) < self.KEEP:
-            blocks.append(ptr)
-        else:
-            self.lib.gk_host_free(c_void_p(ptr))
+        drop = []
+        with self.lock:
+            same = [k for k in self.free if k[0] == cap]
+            if self.closed or len(same) >= self.KEEP or cap > self.MAX_RETAINED:
+                drop.append(ptr)
+            else:
+                self.free[(cap, ptr)] = True
+                self.retained += cap
+                while self.retained > self.MAX_RETAINED and self.free:
+                    (c, q), _ = self.free.popitem(last=False)
+                    self.retained -= c
+                    drop.append(q)
+        for q in drop:
+            self.lib.gk_host_free(c_void_p(q))
+
+    def trim(self, keep_bytes=0):
+        """Free retained blocks, oldest first, until at most ``keep_bytes`` stay pinned."""
+        drop = []
+        with self.lock:
+            while self.retained > keep_bytes and self.free:
+                (c, q), _ = self.free.popitem(last=False)
+                self.retained -= c
+                drop.append(q)
+        for q in drop:
+            self.lib.gk_host_free(c_void_p(q))
+
+    def close(self):
+        self.closed = True           # blocks still referenced by live arrays are freed when those die
+        self.trim(0)
 
 
 class DeviceBatch(object):
@@ -95,6 +137,12 @@ class DeviceFeatures(object):
         check(engine.lib.gk_features_info(handle, byref(nc), byref(nl), byref(nnz), byref(mc), byref(dt)))
         self.n_cols, self.n_cols_low, self.nnz = nc.value, nl.value, nnz.value
         self.max_count, self.dtype = mc.value, dt.value
+        fp4, k1, k8, nw = c_int(), c_int(), c_int(), c_int64()
+        check(engine.lib.gk_features_operand(handle, byref(fp4), byref(k1), byref(k8), byref(nw)))
+        # arithmetic type of the dense product: "fp4+i8" (MX fp4 codes for counts <= 4, int8 for 5..127), "i8", "f64"
+        self.operand = "f64" if dt.value else ("fp4+i8" if fp4.value else "i8")
+        if nw.value and not dt.value:
+            self.operand += "+f64"
         self.symmetric = n_fit == batch.n_graphs
         self.n_rows = batch.n_graphs if self.symmetric else batch.n_graphs - n_fit
         self.n_out_cols = n_fit
@@ -125,6 +173,7 @@ class Engine(object):
 
     def close(self):
         if self.handle is not None:
+            self.pinned.close()
             self.lib.gk_destroy(self.handle)
             self.handle = None
 
@@ -135,6 +184,33 @@ class Engine(object):
             pass
 
     # -- plumbing -------------------------------------------------------------------------
+    def set_option(self, name, value):
+        """Route / capacity options of the context (``gk_set_option``, include/gk_hip.h): results never change."""
+        check(self.lib.gk_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = c_int64()
+        check(self.lib.gk_get_option(self.handle, name.encode(), byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """Context manager: ``with eng.options(**{"wl.no_tiny": 1}): ...`` -- restores the old values."""
+        eng = self
+
+        class _Scope(object):
+            def __enter__(self_):
+                self_.old = {k: eng.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    eng.set_option(k, v)
+                return eng
+
+            def __exit__(self_, *exc):
+                for k, v in self_.old.items():
+                    eng.set_option(k, v)
+                return False
+
+        return _Scope()
+
     def set_stream(self, stream_ptr):
         check(self.lib.gk_set_stream(self.handle, c_void_p(stream_ptr) if stream_ptr else None))
 

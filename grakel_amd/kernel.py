@@ -124,7 +124,7 @@ class Kernel(BaseEstimator, TransformerMixin):
         feat = eng.features(fb, n_levels, kind=self._feature_kind)
         self._X_diag = eng.selfk(feat)
         self._last_info = dict(n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, nnz=feat.nnz, max_count=feat.max_count,
-                               dtype=("i8", "f64")[feat.dtype], label_counts=fb.label_counts)
+                               dtype=feat.operand, label_counts=fb.label_counts)
         return eng, feat
 
     def _gram_transform(self, Y):
@@ -144,6 +144,7 @@ class Kernel(BaseEstimator, TransformerMixin):
         check_is_fitted(self, ['X'])
         if not hasattr(self, "_X_diag"):
             eng, feat = self._gram_fit()
+            feat.close()
         if getattr(self, "_is_transformed", False):
             return self._X_diag, self._Y_diag
         return self._X_diag

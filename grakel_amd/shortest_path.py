@@ -18,9 +18,32 @@ class _LazyDict(dict):
         self._fill, self._known_len = fill, known_len
 
     def _ensure(self):
-        f, self._fill = self._fill, None
+        f = self._fill
         if f is not None:
-            dict.update(self, f())
+            filled = f()                     # may raise (no GPU, out of memory): the next read tries again
+            self._fill = None
+            dict.update(self, filled)
+
+    def get(self, key, default=None):
+        self._ensure()
+        return dict.get(self, key, default)
+
+    def copy(self):
+        self._ensure()
+        return dict(dict.items(self))
+
+    def __eq__(self, other):
+        self._ensure()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._ensure()
+        return dict.__repr__(self)
 
     def __len__(self):
         if self._fill is not None and self._known_len is not None:

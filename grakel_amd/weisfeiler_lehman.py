@@ -31,14 +31,38 @@ class _LazyInvLabels(dict):
         self._fill = fill
 
     def _ensure(self):
-        f, self._fill = self._fill, None
+        f = self._fill
         if f is not None:
-            for k, v in f().items():
+            filled = f()                     # may raise (no GPU, out of memory): the next read tries again
+            self._fill = None
+            for k, v in filled.items():
                 dict.__setitem__(self, k, v)
 
     def __missing__(self, key):
         self._ensure()
         return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if key != 0:
+            self._ensure()
+        return dict.get(self, key, default)
+
+    def copy(self):
+        self._ensure()
+        return dict(dict.items(self))
+
+    def __eq__(self, other):
+        self._ensure()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._ensure()
+        return dict.__repr__(self)
 
     def __len__(self):
         self._ensure()

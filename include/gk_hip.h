@@ -64,6 +64,26 @@ int gk_profile_reset(gk_ctx* ctx);
  * Returns total ms and launch count. */
 int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_launches);
 
+/* Route and capacity options of a context.  The library reads NO environment variables; everything that
+ * selects between its equivalent routes goes through this table (tests/test_gpu_parity.py runs the jobs through
+ * every one of them), and EVERY option leaves the results unchanged -- an option removes or forces one of several
+ * equivalent routes, or shrinks a capacity so that a fallback is taken.  value 0 restores the default.  Names:
+ *   relabel:  "wl.no_tiny" "wl.no_listscan" "wl.no_iso" "wl.no_split" "wl.no_exact1" "wl.no_active_set"
+ *             "wl.no_bucket_dict" "wl.no_hist0" "wl.frozen_words" "wl.flag_bytes" "wl.sig_no_regs" "wl.debug"
+ *             "sort.buckets" (1 never / 2 always the per-bucket finish of the sort)
+ *             "wl.bd_slots" (distinct keys a bucket of the sort-free dictionary accepts: small values force its
+ *             overflow and with it the second, sorting attempt)
+ *   features: "feat.no_gm" "feat.gm_no_priv" "feat.low_df" (df below which a column becomes pair updates, default 24)
+ *             "feat.gm_row_lds_max" (bytes of operand row the graph-major builder accepts: small values force the
+ *             fall-back to the label-major builder)
+ *   Gram:     "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc"
+ *   plumbing: "no_mailbox" (small read-backs by hipMemcpy instead of the mapped mailbox),
+ *             "debug.poison" (the allocator fills every block it hands out with this byte: uninitialised reads
+ *             then see the same garbage in every run)
+ * Unknown names return GK_ERR_ARG.  The reference has no counterpart (its route is fixed). */
+int gk_set_option(gk_ctx* ctx, const char* name, int64_t value);
+int gk_get_option(gk_ctx* ctx, const char* name, int64_t* out_value);
+
 /* Pinned (page-locked) host memory for the outputs of gk_gram / gk_gram_rows: the device -> host copy of the
  * float64 matrix (8 N^2 bytes; the reference returns it as a host ndarray, kernel.py:167-204) then runs at the
  * PCIe rate instead of the pageable-copy rate (measured 57 vs 12-18 GB/s).  Any host pointer is accepted
@@ -110,7 +130,9 @@ int gk_batch_info(gk_batch* b, int64_t* n_graphs, int64_t* n_nodes, int64_t* n_e
  * Label ids are an arbitrary bijection per level; the listed order (nodes of shared classes
  * grouped by label) that gk_features_build consumes stays inside the batch.
  *   out_label_counts[n_iter+1] : number of distinct labels per level (host)
- *   hash_bits : 0 = default (64); tests pass small values to force collisions
+ *   hash_bits : 0 = default, 2*log2(n_nodes) + 8 rounded up to whole bytes (at least 32, at most 64): a colliding
+ *               pair then shows up in about one level of 256 and is resolved by the exact refinement; tests pass
+ *               small values to force collisions
  *   out_rounds : total extra refinement rounds that were needed (0 in practice), may be NULL */
 int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits,
                   int64_t* out_label_counts, int* out_rounds);
@@ -148,9 +170,13 @@ int gk_features_destroy(gk_feat* f);
 /* n_cols_kept: width of the dense MFMA operand Phi_s; n_cols_low: useful but rare columns
  * (fewer than GK_LOW_DF=24 graphs) that are applied as exact pair updates after the GEMM instead;
  * nnz: number of (label,graph) triples over all levels; max_count: largest single count;
- * dtype: 0 = int8 Phi / i32 MFMA, 1 = f64 Phi / f64 MFMA. */
+ * dtype: 0 = integer operand on the fp4 / int8 MFMA path (counts 0..4 as MX fp4 codes when every Gram entry stays
+ * below 2^24, counts up to 127 as int8; gk_features_operand says which), 1 = only the float64 side operand is in use. */
 int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* n_cols_low, int64_t* nnz,
                      int64_t* max_count, int* dtype);
+/* Layout of the dense operand: fp4 != 0 when the primary region holds MX fp4 (e2m1) codes, k_steps_fp4_or_i8 /
+ * k_steps_i8_secondary = its 128-byte K-steps, n_cols_f64 = columns of the float64 side operand. */
+int gk_features_operand(gk_feat* f, int* fp4, int* k_steps_primary, int* k_steps_i8_secondary, int64_t* n_cols_f64);
 int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk /* [n_graphs] */);
 /* Test hook: the dense column-compacted Phi_s as float64 [n_graphs x n_cols_kept]. */
 int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi);

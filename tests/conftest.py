@@ -42,3 +42,20 @@ def reference_available():
     """True only in the build container where the real grakel was built (oracle/build_ref.sh)."""
     ref = os.environ.get("GK_REF_BUILD", "/tmp/grakel_oracle")
     return os.path.isdir(os.path.join(ref, "grakel"))
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _poisoned_allocator():
+    """GK_TEST_POISON=<byte> (tests/tools/poison_suite.sh): every device block the library hands out is filled with
+    that byte first, in every engine of this process -- uninitialised reads become deterministic."""
+    pat = os.environ.get("GK_TEST_POISON")
+    if pat:
+        from grakel_amd import engine as E
+        orig = E.Engine.__init__
+
+        def init(self, device=0):
+            orig(self, device)
+            self.set_option("debug.poison", 0x100 | int(pat))
+
+        E.Engine.__init__ = init
+    yield

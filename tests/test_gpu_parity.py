@@ -30,6 +30,22 @@ def gk():
     return grakel_amd
 
 
+@pytest.fixture
+def gkopt(gk):
+    """Route / capacity options of the process-wide engine for ONE test (``gk_set_option``): restored afterwards."""
+    from grakel_amd.engine import get_engine
+    eng = get_engine()
+    old = {}
+
+    def set_option(name, value=1):
+        old.setdefault(name, eng.get_option(name))
+        eng.set_option(name, value)
+
+    yield set_option
+    for name, value in old.items():
+        eng.set_option(name, value)
+
+
 def _mix64(z):
     z = z.astype(np.uint64)
     z ^= z >> np.uint64(30)
@@ -197,18 +213,48 @@ def test_level1_exact_signature_codes_and_their_limits(gk, n_labels, with_isolat
                           O.WLOracle(n_iter=3).fit_transform(only_isolated))
 
 
-@pytest.mark.parametrize("switch", ["", "GK_WL_NO_TINY", "GK_WL_NO_LISTSCAN", "GK_WL_NO_ISO", "GK_WL_NO_SPLIT",
-                                    "GK_WL_NO_EXACT1", "GK_WL_NO_ACTIVE_SET"])
-def test_every_relabel_path_gives_the_reference_partition(gk, switch, monkeypatch):
+ROUTE_OPTIONS = [
+    (), ("wl.no_tiny",), ("wl.no_listscan",), ("wl.no_iso",), ("wl.no_split",), ("wl.no_exact1",), ("wl.no_active_set",),
+    # round 2: sort-free dictionary, graph-major features, level-0 histogram, where the singleton flags travel,
+    # register sort of the neighbour lists, workgroup-private df histograms
+    ("wl.no_bucket_dict",), ("feat.no_gm",), ("wl.no_hist0",), ("wl.frozen_words",), ("wl.flag_bytes",), ("wl.sig_no_regs",),
+    ("feat.gm_no_priv",), ("no_mailbox",), ("sort.buckets", 1), ("sort.buckets", 2),
+    # combinations that meet in real jobs: label-major features on top of a sort-free relabel is impossible by
+    # construction (feat.no_gm turns both off), the words + no list scan pair is the round-1 data flow
+    ("wl.frozen_words", "wl.no_listscan"), ("wl.no_hist0", "wl.no_exact1", "wl.no_bucket_dict"),
+]
+
+
+def _apply_route(gkopt, route):
+    it = iter(route)
+    for name in it:
+        if name == "sort.buckets":
+            gkopt(name, next(it))
+        else:
+            gkopt(name, 1)
+
+
+_route_cache = {}
+
+
+def _route_case():
+    """One oracle run for all the route tests."""
+    if "case" not in _route_cache:
+        X = er_dataset(500, 40, 0.07, 3, 17)          # sparse: isolated vertices, and the refinement needs ~6 levels
+        _route_cache["case"] = (X,) + _oracle_levels(X, 7)
+    return _route_cache["case"]
+
+
+@pytest.mark.parametrize("route", ROUTE_OPTIONS, ids=lambda r: "+".join(str(x) for x in r) or "default")
+def test_every_relabel_path_gives_the_reference_partition(gk, route, gkopt):
     """The relabel loop picks among several equivalent routes per level (single-workgroup tail levels,
     active list from the previous list or from all nodes, carried isolated classes, split listing, exact
-    level-1 codes, active sets at all); each switch removes one of them, the result must not move."""
+    level-1 codes, active sets at all, sort-free or sorting dictionary, flag transport) and the feature
+    builder between two forms; each option removes or forces one of them, the result must not move."""
     from grakel_amd.batch import wl_batch_from_input
     from grakel_amd.engine import get_engine
-    if switch:
-        monkeypatch.setenv(switch, "1")
-    X = er_dataset(500, 40, 0.07, 3, 17)          # sparse: isolated vertices, and the refinement needs ~6 levels
-    wl, K, levels = _oracle_levels(X, 7)
+    _apply_route(gkopt, route)
+    X, wl, K, levels = _route_case()
     gb, _ = wl_batch_from_input(X)
     eng = get_engine()
     db = eng.upload(gb)
@@ -216,6 +262,100 @@ def test_every_relabel_path_gives_the_reference_partition(gk, switch, monkeypatc
     for lvl in range(8):
         assert same_partition(eng.wl_labels(db, lvl), levels[lvl]), "level %d" % lvl
     assert np.array_equal(eng.gram(eng.features(db, 8)), K)
+    oa = gk.WeisfeilerLehmanOptimalAssignment(n_iter=3)      # the min-sum features take the same routes
+    if "oa" not in _route_cache:
+        _route_cache["oa"] = O.WLOAOracle(n_iter=3).fit_transform(X[:120])
+    assert np.array_equal(oa.fit_transform(X[:120]), _route_cache["oa"])
+
+
+@pytest.mark.parametrize("slots", [1, 8, 40])
+def test_bucket_dictionary_overflow_takes_the_sorting_path(gk, gkopt, slots):
+    """A bucket of the sort-free dictionary that holds more distinct keys than its table (forced here by shrinking
+    the table, ``wl.bd_slots``) raises the overflow flag; the whole job is then relabelled again on the sorting
+    path.  Partitions, label counts and K must be the oracle's, and a later feature build on the label-major path
+    must find its label-grouped orders."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    X, wl, K, levels = _route_case()
+    gb, _ = wl_batch_from_input(X)
+    eng = get_engine()
+    gkopt("wl.bd_slots", slots)
+    db = eng.upload(gb)
+    assert eng.wl_relabel(db, 7) == wl.label_counts
+    for lvl in range(8):
+        assert same_partition(eng.wl_labels(db, lvl), levels[lvl]), "level %d" % lvl
+    assert np.array_equal(eng.gram(eng.features(db, 8)), K)
+    gkopt("feat.gm_row_lds_max", 64)                     # ... and the label-major builder on the same batch
+    assert np.array_equal(eng.gram(eng.features(db, 8)), K)
+
+
+@pytest.mark.parametrize("kind", ["dot", "minsum"])
+def test_graph_major_builder_declines_and_the_label_major_builder_takes_over(gk, gkopt, kind):
+    """The graph-major builder assembles an operand row in LDS and declines rows wider than that
+    (GK_ERR_UNSUPPORTED inside the library); the relabel had skipped the label-grouped orders for it, so the
+    label-major builder first rebuilds them (gk_batch_rebuild_order).  Forced by ``feat.gm_row_lds_max``."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    X, wl, K, levels = _route_case()
+    eng = get_engine()
+    if kind == "dot":
+        gb, _ = wl_batch_from_input(X)
+        db = eng.upload(gb)
+        eng.wl_relabel(db, 7)
+        wide = eng.features(db, 8)
+        assert wide.n_cols > 256                              # the row is wider than the limit set below
+        gkopt("feat.gm_row_lds_max", 128)
+        assert np.array_equal(eng.gram(eng.features(db, 8)), K)
+        est = gk.WeisfeilerLehman(n_iter=7)
+        assert np.array_equal(est.fit_transform(X), K)
+        assert np.array_equal(est.transform(X[:9]), K[:9])
+    else:
+        gkopt("feat.gm_row_lds_max", 128)
+        want = O.WLOAOracle(n_iter=3)
+        Kw = want.fit_transform(X[:150])
+        oa = gk.WeisfeilerLehmanOptimalAssignment(n_iter=3)
+        assert np.array_equal(oa.fit_transform(X[:150]), Kw)
+        assert np.array_equal(oa.transform(X[150:170]), want.transform(X[150:170]))
+
+
+def test_natural_fallbacks_many_input_labels_and_a_large_graph(gk):
+    """No option set: more than 256 input labels (level 0 goes through the sorting dictionary instead of the
+    per-graph histogram) and a graph above 1024 nodes (the graph-major builder and the sort-free dictionary do
+    not apply to the batch) -- the routes real inputs of that shape take."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    rs = np.random.RandomState(5)
+    X = random_labelled_graphs(60, 5, 30, 0.2, 400, 31, fmt="dict")       # 400 possible input labels
+    assert len({l for g in X for l in g[1].values()}) > 256
+    eng = get_engine()
+    wl, K, levels = _oracle_levels(X, 3)
+    gb, _ = wl_batch_from_input(X)
+    db = eng.upload(gb)
+    assert eng.wl_relabel(db, 3) == wl.label_counts
+    for lvl in range(4):
+        assert same_partition(eng.wl_labels(db, lvl), levels[lvl]), "level %d" % lvl
+    assert np.array_equal(eng.gram(eng.features(db, 4)), K)
+    # one graph of 1300 nodes (a long path with chords) among small ones
+    n = 1300
+    ed = {i: [] for i in range(n)}
+    for i in range(n - 1):
+        ed[i].append(i + 1), ed[i + 1].append(i)
+    for a, b in zip(rs.randint(0, n, 200).tolist(), rs.randint(0, n, 200).tolist()):
+        if a != b and b not in ed[a]:
+            ed[a].append(b), ed[b].append(a)
+    big = [ed, {i: int(rs.randint(0, 3)) for i in range(n)}]
+    Y = [big] + er_dataset(80, 25, 0.1, 3, 9)
+    wl, K, levels = _oracle_levels(Y, 4)
+    gb, _ = wl_batch_from_input(Y)
+    db = eng.upload(gb)
+    assert eng.wl_relabel(db, 4) == wl.label_counts
+    for lvl in range(5):
+        assert same_partition(eng.wl_labels(db, lvl), levels[lvl]), "level %d" % lvl
+    assert np.array_equal(eng.gram(eng.features(db, 5)), K)
+    est = gk.WeisfeilerLehman(n_iter=4, normalize=True)
+    ref = O.WLOracle(n_iter=4, normalize=True)
+    assert np.allclose(est.fit_transform(Y), ref.fit_transform(Y), rtol=REL_TOL, atol=0)
+    assert np.allclose(est.transform(Y[:5]), ref.transform(Y[:5]), rtol=REL_TOL, atol=0)
 
 
 @pytest.mark.parametrize("bits", [3, 6, 10])
@@ -775,11 +915,11 @@ def test_wloa_small_sets_against_reference(gk, name):
     assert np.array_equal(oa.transform(te), z[name + "/oa3_tr"])
 
 
-@pytest.mark.parametrize("low_df", ["2", "32", "1000000"])
-def test_wloa_er_set_against_oracle_all_column_classes(gk, low_df, monkeypatch):
+@pytest.mark.parametrize("low_df", [2, 32, 1000000])
+def test_wloa_er_set_against_oracle_all_column_classes(gk, low_df, gkopt):
     """600 ER graphs: dense (unary-expanded), rare (pair updates with min) and dead columns all
-    occur; GK_LOW_DF moves the dense/rare boundary to both extremes."""
-    monkeypatch.setenv("GK_LOW_DF", low_df)
+    occur; the option feat.low_df moves the dense/rare boundary to both extremes."""
+    gkopt("feat.low_df", low_df)
     G = er_dataset(600, 30, 0.12, 3, 5)
     want = O.WLOAOracle(n_iter=3)
     Kw = want.fit_transform(G[:400])
@@ -1057,15 +1197,15 @@ def test_config5_row_sharded_over_two_processes(gk, tmp_path):
 # ------------------------------------------------------------------------------------------
 # the dense kernel against the host product of its own operand, every operand form and both kernel forms
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env", [dict(), dict(GK_GRAM_NO_FP4="1"), dict(GK_GRAM_NO_WS="1"),
-                                 dict(GK_GRAM_NO_WS="1", GK_GRAM_NO_FP4="1")])
+@pytest.mark.parametrize("env", [(), ("gram.no_fp4",), ("gram.no_ws",), ("gram.no_ws", "gram.no_fp4"), ("gram.no_sym",),
+                                 ("gram.no_patch",)], ids=lambda e: "+".join(e) or "default")
 @pytest.mark.parametrize("N,n", [(40, 20), (300, 20), (1001, 12)])
-def test_dense_gram_equals_the_product_of_its_own_operand(gk, monkeypatch, env, N, n):
+def test_dense_gram_equals_the_product_of_its_own_operand(gk, gkopt, env, N, n):
     from grakel_amd import GraphBatch
     from grakel_amd.engine import get_engine
-    monkeypatch.setenv("GK_LOW_DF", "2")                   # every useful column is dense
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    gkopt("feat.low_df", 2)                                # every useful column is dense
+    for k in env:
+        gkopt(k, 1)
     eng = get_engine()
     db = eng.upload(GraphBatch(*er_dataset_csr(N, n, 0.15, 3, 0), 3))
     eng.wl_relabel(db, 2)
@@ -1078,6 +1218,34 @@ def test_dense_gram_equals_the_product_of_its_own_operand(gk, monkeypatch, env, 
     assert np.array_equal(K, R)
     s, t, a = eng.gram_checksum(feat)
     assert (s, t, a) == (K.sum(), np.trace(K), 0.0)
+
+
+@pytest.mark.parametrize("big_n,want", [(4095, "fp4+i8"), (4096, "i8"), (46340, "i8"), (46341, "f64")])
+def test_operand_type_switches_at_the_exactness_bounds(gk, big_n, want):
+    """The dense operand type is chosen from the bound levels * max_n^2 on a Gram entry: below 2^24 counts <= 4 travel
+    as MX fp4 codes (float32 accumulation exact), below 2^31 everything is int8 (int32 accumulation), above it the
+    float64 MFMA path.  One VertexHistogram job on each side of both bounds (4095^2 < 2^24 <= 4096^2,
+    46340^2 < 2^31 < 46341^2), with columns of every count class (<= 4, 5..127, > 127), against the oracle."""
+    rs = np.random.RandomState(big_n)
+
+    def labels(n, heavy):
+        lab = np.where(rs.rand(n) < heavy, 0, 1 + rs.randint(0, 20, n))        # label 0 heavy, 1..20 medium
+        rare = rs.rand(n) < 0.02
+        lab[rare] = 21 + rs.randint(0, 279, int(rare.sum()))                     # 21..299: a few nodes each
+        return dict(enumerate(lab.tolist()))
+
+    big = [{i: [] for i in range(big_n)}, labels(big_n, 0.4)]
+    small = []
+    for _ in range(40):
+        n = int(rs.randint(100, 400))
+        small.append([{i: [] for i in range(n)}, labels(n, 0.5)])
+    X = [big] + small
+    vh = gk.VertexHistogram()
+    K = vh.fit_transform(X)
+    assert vh._last_info["dtype"].startswith(want), vh._last_info
+    assert vh._last_info["max_count"] > 127
+    assert np.array_equal(K, O.VHOracle().fit_transform(X))
+    assert np.array_equal(vh.transform(X[:3]), K[:3])
 
 
 def test_malformed_batches_are_rejected_at_the_c_abi(gk):

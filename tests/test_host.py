@@ -410,7 +410,16 @@ def test_fit_is_host_only_and_picklable():
     X = random_labelled_graphs(10, 3, 8, 0.4, 3, 1)
     wl = WeisfeilerLehman(n_iter=2).fit(X)               # no GPU needed to fit (ingestion only)
     wl2 = pickle.loads(pickle.dumps(wl))
-    assert wl2._nx == 10 and wl2._inv_labels == wl._inv_labels
+    assert wl2._nx == 10 and wl2._inv_labels[0] == wl._inv_labels[0]      # level 0 = the input label map
+    # the dictionaries of the levels >= 1 come from the device: without a GPU reading them fails loudly (and a
+    # later read tries again -- the lazy fill is only disarmed by a successful fill)
+    from grakel_amd._lib import GkError
+    for _ in range(2):
+        with pytest.raises(GkError):
+            wl2._inv_labels == wl._inv_labels
+        with pytest.raises(GkError):
+            wl2._inv_labels.get(1)
+    assert wl2._inv_labels.get(0) == wl._inv_labels[0]
     assert np.array_equal(wl2._fit_batch.col_idx, wl._fit_batch.col_idx)
     vh = pickle.loads(pickle.dumps(VertexHistogram().fit(X)))
     assert vh._labels == VertexHistogram().fit(X)._labels

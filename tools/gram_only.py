@@ -1,37 +1,47 @@
-"""Gram-kernel A/B on the config-3 features: python tools/gram_only.py [N]"""
+"""Gram-kernel A/B on the config-3 features: python tools/gram_only.py [N] [opt=val[,opt=val] ...] [--abl]
+
+Each further argument is one variant: comma separated context options (gk_set_option names, e.g.
+`gram.no_fp4=1`, `feat.low_df=16,gram.no_patch=1`).  `--abl` loads the tools' build of the library
+(`make -C grakel_amd/csrc abl` -> libgk_hip_abl.so), whose Gram kernel honours GK_GRAM_ABL=<nostore|nok|noload|
+nomfma|mfmaonly|nobarrier|puremfma>: timing ablations with WRONG results; the shipped library has none of that."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from grakel_amd import GraphBatch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from grakel_amd import GraphBatch, _lib
+args = [a for a in sys.argv[1:] if a != "--abl"]
+if "--abl" in sys.argv:
+    _lib.LIB_PATH = os.path.join(ROOT, "grakel_amd", "libgk_hip_abl.so")
 from grakel_amd.engine import get_engine
 from grakel_amd.synthetic import er_dataset_csr
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+N = int(args[0]) if args and args[0].isdigit() else 10000
 gp, rp, ci, lab = er_dataset_csr(N, 100, 0.05, 5, 0)
 eng = get_engine()
 db = eng.upload(GraphBatch(gp, rp, ci, lab, 5))
 eng.wl_relabel(db, 5)
 feat = eng.features(db, 6)
-print("cols", feat.n_cols, "dtype", feat.dtype)
+print("cols", feat.n_cols, "operand", feat.operand)
 ref = None
 variants = [dict()]
-variants += [dict(x.split("=") for x in v.split(",")) for v in sys.argv[2:]]
-for env in variants:
-    for k in list(os.environ):
-        if k.startswith("GK_GRAM") or k == "GK_LOW_DF": del os.environ[k]
-    os.environ.update(env)
-    if any(k in env for k in ("GK_LOW_DF", "GK_GRAM_NO_FP4")) or getattr(feat, "_special", False):
-        feat.close(); feat = eng.features(db, 6)
-        feat._special = any(k in env for k in ("GK_LOW_DF", "GK_GRAM_NO_FP4"))
-        print("   features: dense cols", feat.n_cols, "low_df", env.get("GK_LOW_DF"))
-    ms, tot = [], []
-    for it in range(6):
-        eng.timer_start()
-        eng.gram(feat, 0, to_host=False)
-        tot.append(eng.timer_stop_ms())
-        ms.append(eng.gram_stats(feat)[1])
-    fl = eng.gram_stats(feat)[0]
-    K = eng.gram(feat, 0)
-    chk = (int(K.sum()), int(np.trace(K)), bool(np.array_equal(K, K.T)))
-    if ref is None: ref = chk
-    print(env, "gemm ms min %.3f med %.3f | gram total min %.3f" % (min(ms), sorted(ms)[len(ms)//2], min(tot)), "TOP/s %.0f" % (fl / min(ms) / 1e9), "chk", chk, "OK" if chk == ref else "MISMATCH")
+variants += [dict((x.split("=")[0], int(x.split("=")[1])) for x in v.split(",")) for v in args if "=" in v]
+for opts in variants:
+    with eng.options(**opts):
+        rebuilt = any(k.startswith("feat.") or k == "gram.no_fp4" for k in opts)
+        f = eng.features(db, 6) if rebuilt else feat
+        if rebuilt:
+            print("   features: dense cols", f.n_cols, "rare", f.n_cols_low, "operand", f.operand)
+        ms, tot = [], []
+        for it in range(6):
+            eng.timer_start()
+            eng.gram(f, 0, to_host=False)
+            tot.append(eng.timer_stop_ms())
+            ms.append(eng.gram_stats(f)[1])
+        fl = eng.gram_stats(f)[0]
+        K = eng.gram(f, 0)
+        chk = (int(K.sum()), int(np.trace(K)), bool(np.array_equal(K, K.T)))
+        if ref is None: ref = chk
+        print(opts, os.environ.get("GK_GRAM_ABL", ""), "gemm ms min %.3f med %.3f | gram total min %.3f" % (min(ms), sorted(ms)[len(ms)//2], min(tot)),
+              "TOP/s %.0f" % (fl / min(ms) / 1e9), "chk", chk, "OK" if chk == ref else "MISMATCH")
+        if rebuilt:
+            f.close()
 if N == 10000: print("golden sum 200604613570 trace 25874190")
