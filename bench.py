@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=6500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and the config-4 object")
+    ap.add_argument("--plan", choices=["plain", "symmetric"], default="plain",
+                    help="N > 1: Gram sharding plan (grakel_amd.dist.gram_plan; plain row blocks is the default)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="context option (gk_set_option, include/gk_hip.h), e.g. --opt wl.debug=1; A/B runs only")
     a = ap.parse_args()
@@ -304,7 +306,7 @@ def main():
         from grakel_amd.dist import ShardedWL, shard_bounds
         b = shard_bounds(N, world)
         local = full.slice_graphs(b[rank], b[rank + 1])
-        sw = ShardedWL(eng, n_iter=h)
+        sw = ShardedWL(eng, n_iter=h, symmetric=(a.plan == "symmetric"))       # default: plain row blocks (dist.gram_plan)
 
         def step():
             _, i = sw.step(local)
@@ -380,7 +382,8 @@ def main():
         # once (1 GPU: all of K; N GPUs: the blocks of its symmetric plan, ~half of its row block), read the
         # dense operand once (fp4: two columns per byte, 128-byte K-steps)
         operand_bytes = (N + 511) // 256 * 256 * ((d_dense + 255) // 256 * 128)
-        gram_bytes = 8.0 * rows * N * (1.0 if world == 1 else 0.5 * (1.0 + 1.0 / world)) + operand_bytes
+        sym = world > 1 and a.plan == "symmetric"
+        gram_bytes = 8.0 * rows * N * (0.5 * (1.0 + 1.0 / world) if sym else 1.0) + operand_bytes
         achieved_gbs = gram_bytes / (gram_avg_ms * 1e-3) / 1e9
         mfma_peak = FP4_DENSE_PEAK_TOPS if str(info.get("operand", "fp4")).startswith("fp4") else I8_DENSE_PEAK_TOPS
         alg_flops = 2.0 * (N * (N + 1) / 2) * d_eff / world
@@ -415,8 +418,14 @@ def main():
                                    % (a.workload, N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"], h),
                        "graphs": N, "nodes": V_, "edges": E_,
                        "parallelism": "graphs+Gram rows sharded over %d GPU(s)%s" % (
-                           world, "" if world == 1 else "; every rank multiplies 1/%d of the upper triangle and ships the "
-                                                        "mirrored blocks point to point (grakel_amd.dist.symmetric_plan)" % world),
+                           world, "" if world == 1 else (
+                               "; every rank multiplies 1/%d of the upper triangle and ships the mirrored blocks point to "
+                               "point (grakel_amd.dist.symmetric_plan)" % world if sym else
+                               "; one all-gather of the CSR shards, relabel + features replicated, every rank multiplies and "
+                               "stores its own row block (plain row blocks: no collective on the Gram path)")),
+                       "gram_plan_model": (lambda m: {k: (v if k == "choice" else {kk: round(vv, 6) if kk == "seconds" else vv
+                                                                                 for kk, vv in v.items()}) for k, v in m.items()})(
+                           __import__("grakel_amd.dist", fromlist=["gram_plan"]).gram_plan(N, world)) if world > 1 else None,
                        "sharded_gram_ms": sharded_ms,
                        "label_counts": info.get("label_counts"), "gram_columns_dense": d_dense,
                        "gram_columns_rare": info.get("n_cols_low")},

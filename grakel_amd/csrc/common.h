@@ -288,7 +288,7 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
 bool gk_bucket_dictionary_fits(gk_ctx* ctx, i64 n);      // a-priori test: can no bucket overflow when every key is distinct?
 int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* rep, u32* frozen,
                          unsigned char* shared_out, u32* count_dev, u32* listed_dev, u32* top_digit_max, u32* overflow,
-                         u32* mbox, u32 seq, int flag_in_rep = 0);
+                         u32* mbox, u32 seq, int flag_in_lab = 0);
 
 // ---- wl.hip ---------------------------------------------------------------------------
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);

@@ -716,7 +716,7 @@ int gk_radix_sort_pairs(gk_ctx* ctx, const u64* keys_in, const u32* vals_in, u64
 // consumer needs them in order once the label-count features are built graph-major (features_gm.hip).
 // One stable pass on the top digit (as above) leaves 256 buckets; a workgroup then owns a bucket and
 // runs an open-addressing table in LDS over the remaining key bits.  The table holds DISTINCT keys -- a slot is
-// (key + 1 as a 64-bit word, 0 = empty | member count) -- and the bucket's items stream through it from HBM in
+// (key + 1 as a 64-bit word, 0 = empty | one member / several) -- and the bucket's items stream through it from HBM in
 // 1024-item chunks (twice: insert, then look up), so a bucket may hold any number of items as long as its
 // distinct keys fit: a class of 14 000 isolated vertices is one slot.  (The first version kept every ITEM's key in
 // LDS and overflowed at 8 192 items per bucket: config 5, 50 000 graphs with 70 000 isolated vertices, redid every
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict
                                                            u32 max_distinct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bd_lds[];
     unsigned long long* key_s = (unsigned long long*)bd_lds;                   // [BD_SLOTS] key + 1, 0 = empty
-    u32* word_s = (u32*)(bd_lds + (size_t)BD_SLOTS * 8);                       // [BD_SLOTS] members, later rank | singleton << 31
+    u32* word_s = (u32*)(bd_lds + (size_t)BD_SLOTS * 8);                       // [BD_SLOTS] 1 / 2 = one / several members, later rank | singleton << 31
     __shared__ u32 dsum[4];
     __shared__ u32 wsum[16];
     __shared__ u32 bstart, n_claimed, ovf;
@@ -780,12 +780,15 @@ __global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict
                     v = atomicCAS(&key_s[h], 0ull, (unsigned long long)k1);
                     if (v == 0ull) {                                      // claimed: this item owns the class
                         claimed |= 1ull << c;
-                        atomicAdd(&word_s[h], 1u);
+                        atomicMax(&word_s[h], 1u);
                         if (atomicAdd(&n_claimed, 1u) + 1u > max_distinct) ovf = 1u;
                         break;
                     }
                 }
-                if (v == k1) { atomicAdd(&word_s[h], 1u); break; }
+                // a second member makes the class shared; members are not counted: the thousands of items of a hot
+                // class (isolated vertices, degree-one nodes) then only READ the slot (a broadcast) instead of
+                // queueing on one LDS atomic
+                if (v == k1) { if (*(volatile u32*)&word_s[h] != 2u) atomicMax(&word_s[h], 2u); break; }
                 h = h + 1u == (u32)BD_SLOTS ? 0u : h + 1u;
             }
         }
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict
     }
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const u32 members = word_s[PER * tid + q];
+        const u32 members = word_s[PER * tid + q];                 // 1: one member, 2: two or more
         if (members) {
             word_s[PER * tid + q] = before | (members == 1u ? 0x80000000u : 0u);
             ++before;
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(1024) void bucket_assign_kernel(const u32* __restri
                                                              unsigned char* __restrict__ shared_out, u32* __restrict__ listed_out,
                                                              u32* __restrict__ count_out, unsigned long long* __restrict__ ticket,
                                                              u32* __restrict__ mbox, u32 seq, const u32* __restrict__ extra, i64 n,
-                                                             int flag_in_rep) {
+                                                             int flag_in_lab) {
     // one item per thread (the scattered stores need many workgroups in flight); the bucket of an item is found
     // in the two 256-entry prefixes every workgroup rebuilds in LDS
     __shared__ u32 starts[257], bases[257];
@@ -880,10 +883,14 @@ __global__ __launch_bounds__(1024) void bucket_assign_kernel(const u32* __restri
         const u32 node = vx[i], t = item_in[i];
         const u32 id = bases[lo] + (t & 0x3fffu);
         const u32 single = t >> 31;
-        lab[node] = (i32)id;
+        // flag_in_lab: the singleton flag rides in bit 31 of the label word until the caller's verification pass
+        // (one thread per node, in node order) strips it and writes the flag byte coalesced; a singleton is its own
+        // representative, so rep[] is only written for the shared classes -- at a deep level that is a tenth of the
+        // classes, i.e. a million scattered 4-byte stores fewer
+        lab[node] = (i32)(id | (flag_in_lab ? single << 31 : 0u));
         if (frozen) frozen[node] = single;
         if (shared_out) shared_out[node] = single ? 0 : 1;
-        if ((t >> 30) & 1u) rep[id] = (i32)(node | (flag_in_rep ? single << 31 : 0u));      // bit 31: singleton class (verify_kernel)
+        if (((t >> 30) & 1u) && !(flag_in_lab && single)) rep[id] = (i32)node;
         listed = single ? 0u : 1u;
     }
     for (int off = 32; off > 0; off >>= 1) listed += __shfl_down(listed, off, 64);
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(1024) void bucket_assign_kernel(const u32* __restri
 // *overflow gets 0x80000000 or-ed in when a bucket did not fit.
 int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* rep, u32* frozen,
                          unsigned char* shared_out, u32* count_dev, u32* listed_dev, u32* top_digit_max, u32* overflow,
-                         u32* mbox, u32 seq, int flag_in_rep) {
+                         u32* mbox, u32 seq, int flag_in_lab) {
     if (key_bits > 64) key_bits = 64;
     const int passes = (key_bits + 7) / 8;
     const int shift = 8 * (passes - 1);
@@ -942,7 +949,7 @@ int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32*
     }
     bucket_assign_kernel<<<dim3((unsigned)cdiv(n, 1024)), dim3(1024), 0, ctx->stream>>>(
         vx.p, item.p, bucket_totals, nd.p, lab, rep, frozen, shared_out, listed_dev, count_dev, ticket, mbox, seq, top_digit_max, n,
-        flag_in_rep);
+        flag_in_lab);
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }

@@ -693,20 +693,25 @@ __global__ void frozen_assign_verify_kernel(const u32* __restrict__ fidx, const 
     if (!ok) atomicAdd(unresolved, 1u);
 }
 
-// shared_out (may be null): the dictionary left "singleton class" in bit 31 of rep[] (gk_bucket_dictionary with
-// flag_in_rep) -- this pass gathers rep[lab[v]] for every node anyway and writes the level's "class of two or more"
-// bytes in node order, instead of one more scattered store per node in bucket_assign_kernel
+// shared_out (may be null): the dictionary left "singleton class" in bit 31 of the label word (gk_bucket_dictionary with
+// flag_in_lab) -- this pass walks the nodes in order anyway: it strips the bit, writes the level's "class of two or
+// more" bytes coalesced, and skips the representative look-up for singletons (they are their own representative;
+// rep[] holds no entry for them)
 __global__ void verify_kernel(const i32* __restrict__ row_ptr, const i32* __restrict__ lab_prev,
-                              const i32* __restrict__ nbr_sorted, const i32* __restrict__ lab,
+                              const i32* __restrict__ nbr_sorted, i32* __restrict__ lab,
                               const i32* __restrict__ rep, u32* __restrict__ unresolved, i64 n,
                               unsigned char* __restrict__ shared_out) {
     i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    i32 r = rep[lab[v]];
+    i32 l = lab[v];
     if (shared_out) {
-        shared_out[v] = r < 0 ? 0 : 1;
-        r &= 0x7fffffff;
+        shared_out[v] = l < 0 ? 0 : 1;
+        if (l < 0) {
+            lab[v] = l & 0x7fffffff;
+            return;
+        }
     }
+    const i32 r = rep[l];
     if (r == (i32)v) return;
     bool ok = lab_prev[v] == lab_prev[r];
     i32 s = row_ptr[v], sr = row_ptr[r];
@@ -1182,9 +1187,9 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
                                 u32* listed_dev = nullptr, u32* posted_seq = nullptr, u32 lab_base = 0,
                                 const u32* lab_base_dev = nullptr, unsigned char* shared_out = nullptr,
                                 u32* no_order_overflow = nullptr, bool* frozen_in_shared = nullptr,
-                                bool* flag_in_rep = nullptr, bool* no_order_taken = nullptr) {
+                                bool* flag_in_lab = nullptr, bool* no_order_taken = nullptr) {
     if (frozen_in_shared) *frozen_in_shared = false;
-    if (flag_in_rep) *flag_in_rep = false;
+    if (flag_in_lab) *flag_in_lab = false;
     if (no_order_taken) *no_order_taken = false;
     if (n == 0) {
         GK_TRY(gk_zero_async(ctx, count_dev, 4));
@@ -1207,10 +1212,10 @@ static int dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bit
         // frozen[] after a full level, ActiveScan, takes the bytes
         const bool bytes_only = shared_out && frozen_in_shared && !ctx->opt.wl_frozen_words;
         if (bytes_only) *frozen_in_shared = true;
-        // ... and when the caller's verification pass follows (it gathers rep[lab[v]] per node), not even the byte:
-        // the flag rides in bit 31 of rep[] and verify_kernel writes the bytes in node order
-        const bool in_rep = bytes_only && flag_in_rep && rep != rep_tmp.p && !ctx->opt.wl_flag_bytes;
-        if (in_rep) *flag_in_rep = true;
+        // ... and when the caller's verification pass follows (one thread per node), not even the byte:
+        // the flag rides in bit 31 of lab[] and verify_kernel writes the bytes in node order
+        const bool in_rep = bytes_only && flag_in_lab && rep != rep_tmp.p && !ctx->opt.wl_flag_bytes;
+        if (in_rep) *flag_in_lab = true;
         return gk_bucket_dictionary(ctx, keys, n, key_bits, lab, rep, bytes_only ? nullptr : frozen, in_rep ? nullptr : shared_out,
                                     count_dev, listed_dev, top_digit_max, no_order_overflow, seq ? ctx->mbox_dev : nullptr, seq,
                                     in_rep ? 1 : 0);
@@ -1462,7 +1467,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             break;
         }
         GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), full_mask));
-        bool flag_in_rep = false;
+        bool flag_in_lab = false;
         int bits = hash_bits;
         const u64* sort_keys = hash.p;           // round 0: the sort reads the hashes in place
         if (round > 0) {
@@ -1475,13 +1480,13 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
                                     (listed_dev && !exact) ? &st.posted_seq : nullptr, 0, nullptr,
                                     b->shared_flag + (size_t)level * V,
                                     (st.no_order && !exact && round == 0) ? unresolved_dev : nullptr, st.list_scan ? &st.frozen_in_shared : nullptr,
-                                    &flag_in_rep, &no_order_taken));
+                                    &flag_in_lab, &no_order_taken));
         st.shared_prev = b->shared_flag + (size_t)level * V;
         b->perm_valid[level] = no_order_taken ? 0 : 1;
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V,
-                                                                  flag_in_rep ? b->shared_flag + (size_t)level * V : nullptr);
+                                                                  flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr);
         GK_HIP_CHECK(hipGetLastError());
         if (!exact) break;
         u32 un = 0;

@@ -10,19 +10,24 @@ passed together with its ``label_map`` -- the ranks then exchange their distinct
 remap to the ids of the sorted union, exactly the reference's ``sorted(distinct_values)`` numbering
 (weisfeiler_lehman.py:199-210).  The exchange is therefore a single RCCL
 ``all_gather`` of the packed shards over xGMI (config 3: ~25 MB in total, i.e. ~3 MB per
-rank; a direct all-gather at ~153 GB/s per link takes tens of microseconds), after which
+rank; a direct all-gather at ~77 GB/s per link and direction takes tens of microseconds), after which
 
-    relabel + label-count features : replicated on every rank (latency-bound, well under 1 ms)
-    Gram                           : rank r OWNS rows [lo_r, hi_r) x all columns, but only multiplies half of
-                                     them: K is symmetric, so of every pair of blocks (K[B_p, B_q], K[B_q, B_p])
-                                     one rank computes one block and ships it to the owner of the mirrored block,
-                                     which stores it transposed (``symmetric_plan``).  R ranks together do the MACs
-                                     one GPU does alone (tiles on/above the diagonal), each 1/R of them.
+    relabel + label-count features : replicated on every rank (config 5: 1.06 ms of a 7.7 ms step)
+    Gram                           : rank r computes and stores its row block K[lo_r:hi_r, :] -- PLAIN ROW BLOCKS,
+                                     no data-path collective after the all-gather.
 
-so the N x N matrix never needs to exist on one device; each rank returns its row block.  The block
-exchange is point-to-point (``batch_isend_irecv``: xGMI links are point-to-point, every rank talks to
-about half of its peers with one message each); no other collective touches the data path.  ``torch.distributed`` is plumbing only: backend
-"nccl" (= RCCL) on GPUs, "gloo" in the CPU tests of the shard/gather/rebuild logic.
+Why not the symmetric plan (multiply half, ship the mirrored blocks): the Gram kernel is bound by the float64
+STORE of K (3 TB/s measured, 17 % MFMA-busy), so the multiply-adds a rank would save are free, while the blocks
+it would receive instead arrive over xGMI at a small fraction of the rate at which it can produce them locally --
+``gram_plan`` puts numbers on both plans (config 5, 8 ranks: 0.8 ms plain against ~4.5 ms symmetric).  The
+symmetric plan stays available (``ShardedWL(symmetric=True)``) for a future MFMA-bound operand.
+
+``ShardedSP`` is the same scheme for the ShortestPath kernel ("identical scheme; the ``_enum``
+dictionary is global", shortest_path.py:370-499): all-gather of the CSR shards (+ edge weights), all-pairs
+distances, pair dictionary and features replicated, Gram rows sharded.
+
+``torch.distributed`` is plumbing only: backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests of the
+shard/gather/rebuild logic.
 """
 import numpy as np
 
@@ -36,6 +41,32 @@ def shard_bounds(n_graphs, world_size):
     for r in range(world_size):
         b.append(b[-1] + base + (1 if r < rem else 0))
     return b
+
+
+# measured on one MI355X (profiles/r03_*): float64 store rate of the Gram kernel, device-to-device transposed
+# placement (read + write), and the xGMI link rate per direction (MI355X_MICROARCH.md: 7 links x 153.6 GB/s
+# bidirectional, point to point -- a rank talking to p peers uses p links)
+GRAM_STORE_BPS = 3.0e12
+PLACE_BPS = 1.5e12
+XGMI_LINK_BPS = 76.8e9
+
+
+def gram_plan(n_graphs, world, store_bps=GRAM_STORE_BPS, link_bps=XGMI_LINK_BPS, place_bps=PLACE_BPS):
+    """Bytes and predicted Gram-phase time per rank of the two sharding plans (a model from measured rates, not a
+    measurement): ``plain`` = every rank multiplies and stores its whole row block; ``symmetric`` = every rank
+    multiplies 1/R of the upper triangle (``symmetric_plan``), ships the mirrored blocks point to point and stores
+    what it receives transposed.  Returns {"plain": {...}, "symmetric": {...}, "choice": "plain" | "symmetric"}."""
+    N, R = float(n_graphs), int(world)
+    block = 8.0 * (N / R) * N                                   # float64 row block of one rank
+    plain = dict(hbm_store_bytes=block, xgmi_recv_bytes=0.0, seconds=block / store_bps)
+    if R == 1:
+        return dict(plain=plain, symmetric=dict(plain), choice="plain")
+    own = block * 0.5 * (1.0 + 1.0 / R)                          # diagonal block + the blocks towards half of the peers
+    recv = block - own
+    peers = max(1, (R - 1 + 1) // 2)                             # senders a rank receives from, one xGMI link each
+    sym = dict(hbm_store_bytes=own + recv, xgmi_recv_bytes=recv, peers=peers,
+               seconds=own / store_bps + recv / (peers * link_bps) + 2.0 * recv / place_bps)
+    return dict(plain=plain, symmetric=sym, choice="symmetric" if sym["seconds"] < plain["seconds"] else "plain")
 
 
 def symmetric_plan(bounds, rank):
@@ -138,6 +169,24 @@ class ShardExchange(object):
         self.zero = torch.zeros(1, dtype=torch.int32, device=dev)
         self.flat = None
         self._into_tensor = True
+        # edge weights (ShortestPath): present on any rank -> every rank sends a (unit-filled) weight segment
+        has_w = torch.tensor([1 if local.edge_weight is not None else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(has_w, op=dist.ReduceOp.MAX, group=group)
+        self.weights = None
+        if int(has_w.item()):
+            w = local.edge_weight if local.edge_weight is not None else np.ones(local.n_edges, dtype=np.int32)
+            self.weights = _pad_to(T(np.asarray(w, dtype=np.int32)), me, torch)
+            self.weight_step = float(getattr(local, "weight_step", 1.0))
+
+    def gather_weights(self):
+        """Global int32 edge-weight array (host) in the order of the gathered col_idx, or None (unit weights)."""
+        import torch
+        import torch.distributed as dist
+        if self.weights is None:
+            return None
+        parts = [torch.empty_like(self.weights) for _ in range(self.ws)]
+        dist.all_gather(parts, self.weights, group=self.group)
+        return np.concatenate([parts[r][:int(self.all_sizes[r, 2])].cpu().numpy() for r in range(self.ws)]).astype(np.int32)
 
     def gather_flat(self):
         """ONE collective into a preallocated buffer: the ws messages back to back (what
@@ -199,10 +248,13 @@ def tensors_to_batch(graph_ptr, row_ptr, col_idx, labels, n_labels):
 class ShardedWL(object):
     """WL-subtree Gram with graphs and Gram rows sharded over the ranks of ``group``."""
 
-    def __init__(self, engine, n_iter=5, normalize=False, group=None, symmetric=True):
+    def __init__(self, engine, n_iter=5, normalize=False, group=None, symmetric=False):
         import torch.distributed as dist
         self.engine, self.n_iter, self.normalize, self.group = engine, n_iter, normalize, group
-        self.symmetric = symmetric          # False: every rank multiplies its full row block (no exchange)
+        # False (default): plain row blocks, every rank multiplies and stores its whole block, no exchange.
+        # True: the symmetric plan (half the multiply-adds, mirrored blocks over xGMI) -- slower as long as the
+        # Gram kernel is store-bound (``gram_plan``)
+        self.symmetric = symmetric
         self.ws = dist.get_world_size(group)
         self._exchange, self._local = None, None
         self._stream = None
@@ -306,6 +358,53 @@ class ShardedWL(object):
                 info["feat"], info["batch"] = feat, db
             else:
                 feat.close()
+                db.close()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        return K, info
+
+
+class ShardedSP(object):
+    """ShortestPath Gram with graphs and Gram rows sharded over the ranks of ``group`` ("SP: identical
+    scheme"): the (l_u, l_v, d) feature dictionary is global (shortest_path.py:412-499: ``_enum`` grows over ALL
+    graphs), so after the all-gather of the CSR shards (+ edge weights when any rank has them) every rank runs the
+    all-pairs distances, the pair dictionary and the feature builder on the global batch and then multiplies and
+    stores only its own row block.  Shards must carry global level-0 ids (or their ``label_map``, see ShardExchange)."""
+
+    def __init__(self, engine, normalize=False, with_labels=True, group=None):
+        import torch.distributed as dist
+        self.engine, self.normalize, self.with_labels, self.group = engine, normalize, with_labels, group
+        self.ws = dist.get_world_size(group)
+        self._exchange, self._local, self._weights, self._stream = None, None, None, None
+
+    _shared_stream = ShardedWL._shared_stream
+    close = ShardedWL.close
+
+    def step(self, local_batch, to_host=False, label_map=None, keep=False):
+        """One fit_transform: returns (row block [n_local x N] or None, info dict)."""
+        import torch
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group)
+        dev = torch.device("cuda", self.engine.device)
+        if self._local is not local_batch:
+            self._exchange, self._local = ShardExchange(local_batch, self.group, dev, label_map), local_batch
+            self._weights = self._exchange.gather_weights()        # host array: gk_sp_build validates and uploads it
+        s = self._shared_stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        ex, eng = self._exchange, self.engine
+        with torch.cuda.stream(s):
+            flat = ex.gather_flat()
+            db = eng.batch_from_shards(ex.all_sizes[:, :3], ex.mg, ex.mv, ex.me, flat.data_ptr(), ex.n_labels)
+            pb = eng.sp_build(db, self._weights, self.with_labels)
+            feat = eng.features(pb, 1)
+            rows = (ex.bounds[rank], ex.bounds[rank + 1])
+            K = eng.gram(feat, 1 if self.normalize else 0, rows=rows, to_host=to_host)
+            info = dict(rows=rows, n_graphs=db.n_graphs, n_pairs=pb.n_nodes, n_keys=pb.label_counts[0],
+                        n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, gram=eng.gram_stats(feat), operand=feat.operand)
+            if keep:
+                info["feat"], info["batch"], info["pairs"] = feat, db, pb
+            else:
+                feat.close()
+                pb.close()
                 db.close()
         torch.cuda.current_stream(dev).wait_stream(s)
         return K, info

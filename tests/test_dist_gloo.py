@@ -84,6 +84,64 @@ def _worker_own_ingestion(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_weights(rank, world, port, out_dir):
+    """ShardedSP's exchange: edge weights travel with the shards (one rank without weights sends ones)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from grakel_amd.batch import GraphBatch, sp_batch_from_input
+    from grakel_amd.dist import ShardExchange, gram_plan, shard_bounds
+    from grakel_amd.synthetic import random_labelled_graphs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        G = random_labelled_graphs(17, 3, 10, 0.4, 3, 9, fmt="adj")
+        rs = np.random.RandomState(1)
+        for g in G[:9]:                                   # only the first shard's graphs carry weights 1..4
+            W = np.triu(rs.randint(1, 5, g[0].shape), 1)
+            g[0] = g[0] * (W + W.T)
+        full, _ = sp_batch_from_input(G, True)
+        b = shard_bounds(len(G), world)
+        assert b[1] == 9
+        local = full.slice_graphs(b[rank], b[rank + 1])
+        if rank == 1:                                      # a shard of unit-weight graphs has no weight array at all
+            local = GraphBatch(local.graph_ptr, local.row_ptr, local.col_idx, local.node_label, local.n_labels, None)
+        ex = ShardExchange(local)
+        w = ex.gather_weights()
+        ok = w is not None and np.array_equal(w, full.edge_weight)
+        # no rank has weights -> no weight exchange at all
+        plain = GraphBatch(local.graph_ptr, local.row_ptr, local.col_idx, local.node_label, local.n_labels, None)
+        full1, _ = sp_batch_from_input([[np.minimum(g[0], 1), g[1]] for g in G], True)
+        l1 = full1.slice_graphs(b[rank], b[rank + 1])
+        ok = ok and ShardExchange(GraphBatch(l1.graph_ptr, l1.row_ptr, l1.col_idx, l1.node_label, l1.n_labels, None)).gather_weights() is None
+        del plain
+        np.save(os.path.join(out_dir, "w_%d.npy" % rank), np.array([int(ok)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_edge_weights_travel_with_the_shards_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = 33000 + (os.getpid() % 2000)
+    mp.spawn(_worker_weights, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(os.path.join(str(tmp_path), "w_%d.npy" % r)).tolist() == [1]
+
+
+def test_gram_plan_model_prefers_plain_row_blocks_while_the_kernel_is_store_bound():
+    """The bytes model behind the default plan: with the measured store rate of the Gram kernel the
+    symmetric plan loses at every world size; it would only win if a rank produced entries slower than xGMI
+    delivers them."""
+    from grakel_amd.dist import gram_plan
+    for N in (10000, 50000):
+        for R in (2, 4, 8):
+            m = gram_plan(N, R)
+            assert m["choice"] == "plain" and m["plain"]["xgmi_recv_bytes"] == 0
+            assert abs(m["plain"]["hbm_store_bytes"] - 8.0 * N * N / R) < 1
+            assert m["symmetric"]["xgmi_recv_bytes"] >= 0.25 * m["plain"]["hbm_store_bytes"]
+    assert gram_plan(50000, 8, store_bps=20e9)["choice"] == "symmetric"       # a (hypothetical) 20 GB/s producer
+    assert gram_plan(10000, 1)["choice"] == "plain"
+
+
 def test_independently_ingested_shards_get_global_label_ids_world2(tmp_path):
     import torch.multiprocessing as mp
     port = 31000 + (os.getpid() % 2000)
