@@ -143,7 +143,7 @@ int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words) {
 }
 
 // Pinned host memory for Gram outputs: the float64 matrix is 8 N^2 bytes (800 MB at 10 k graphs) and a
-// device -> pageable copy runs at 12-18 GB/s, into pinned memory at 57 GB/s (tools/micro/pinbw).
+// device -> pageable copy runs at 12-18 GB/s, into pinned memory at 57 GB/s (tools/micro/pinbw.hip).
 extern "C" int gk_host_alloc(uint64_t bytes, void** out) {
     GK_ARG(out && bytes > 0, "gk_host_alloc: bad argument");
     void* p = nullptr;
