@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(
 // path needs that much to stream), and the load pipeline does not drain between tiles.
 //   LDS: ring 3 x 32 KiB | parked tile 64 KiB = 160 KiB (all of it).
 // ---------------------------------------------------------------------------------------
+#define WS_THREADS 768          // 12 waves: 4 multiply, 4 store, 4 load
 #define WS_RING 3
 #define WS_OUT_OFF (WS_RING * GT_STAGE)
 #define WS_LDS_BYTES (WS_OUT_OFF + GT_BM * GT_BM * 4)
@@ -328,8 +329,30 @@ __device__ __forceinline__ int ws_out_addr(int row, int col) {
     return col * (GT_BM * 4) + ((((row >> 2) ^ (col & 31)) << 4) | ((row & 3) << 2));
 }
 
+#ifdef GK_ABLATION
+// workgroup 0's cycle stamps (s_memtime), per role: [role][0] total, [1] waiting at barriers, [2] K-step body, [3] tile change
+// (load role: waiting for its own pieces).  Reading the counter drains lgkmcnt, i.e. it serialises outstanding LDS reads
+// into the "body" figure: compare totals across ablations, not bodies in isolation.
+__device__ unsigned long long g_ws_dbg[3][4];
+#define WS_DBG_DECL unsigned long long t_bar = 0, t_body = 0, t_walk = 0, t_x = 0; const unsigned long long t_start = __builtin_readcyclecounter();
+#define WS_DBG_T0() t_x = __builtin_readcyclecounter();
+#define WS_DBG_ADD(acc) { const unsigned long long t_y = __builtin_readcyclecounter(); acc += t_y - t_x; t_x = t_y; }
+#define WS_DBG_OUT(role_)                                                                       \
+    if (blockIdx.x == 0 && (tid & 255) == 0) {                                                 \
+        g_ws_dbg[role_][0] = __builtin_readcyclecounter() - t_start, g_ws_dbg[role_][1] = t_bar; \
+        g_ws_dbg[role_][2] = t_body, g_ws_dbg[role_][3] = t_walk;                               \
+    }
+#else
+#define WS_DBG_DECL
+#define WS_DBG_T0()
+#define WS_DBG_ADD(acc)
+#define WS_DBG_OUT(role_)
+#endif
+// ABL (tools' build only, timing ablations with WRONG results), a bit mask: 1 no operand loads, 2 the multiplying waves
+// skip their K-steps, 4 MFMAs on fabricated fragments (no LDS reads), 8 no stores, 16 no per-K-step barrier, 32 the store
+// waves skip their chunks altogether, 64 no parking of finished tiles
 template <bool FP4, int ABL>
-__global__ __launch_bounds__(512) void gram_ws_kernel(
+__global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
     int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int n_ids, i64 M_store, unsigned* __restrict__ xcc_ticket,
@@ -338,8 +361,11 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: scalar branches, scalar tile walk
-    const bool is_compute = wave < 4;                       // wave-uniform role
+    const int role = wave >> 2;                             // wave-uniform: 0 multiply, 1 store, 2 load
+    const bool is_compute = role == 0, is_loader = role == 2;
     const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
+    constexpr bool NO_LOAD = (ABL & 1) != 0, NO_COMPUTE = (ABL & 2) != 0, FAKE_READ = (ABL & 4) != 0, NO_STORE = (ABL & 8) != 0,
+                   NO_BAR = (ABL & 16) != 0, NO_CHUNK = (ABL & 32) != 0, NO_PARK = (ABL & 64) != 0;
 
     // ---- compute role state -------------------------------------------------------------
     // staging (as gram_tile_kernel): compute wave w fills stage rows [64w, 64w + 64)
@@ -400,7 +426,7 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
     if (ldt.ok) {                                                                              \
         const int8_t* gp = src_base + (i64)kt_ld * GT_BK;                                      \
         int8_t* st = smem + buf_ld * GT_STAGE + cw * (64 * GT_BK);                             \
-        if (ABL == 0 || ABL == 2 || ABL == 6) {                                                          \
+        if (!NO_LOAD) {                                                                        \
             _Pragma("unroll") for (int q = 0; q < PPW; ++q)                                    \
                 __builtin_amdgcn_global_load_lds((glb_void_t*)(gp + roff[q]), (lds_void_t*)(st + q * 1024), 16, 0, 0); \
         }                                                                                      \
@@ -412,7 +438,7 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
             WS_SRC_BASE()                                                                      \
         }                                                                                      \
     }
-    if (is_compute) {
+    if (is_loader) {
         WS_SRC_BASE()
         WS_ISSUE_NEXT()
         WS_ISSUE_NEXT()
@@ -434,7 +460,7 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
 // fragment reads run two slices ahead of the MFMAs: R0 R1 | R2 M0 | R3 M1 | M2 | M3 (sched_barrier keeps
 // the groups apart; the waits the compiler inserts are counted lgkmcnt, LDS returns in order).
 #define WS_READ(SL, BUF)                                                                       \
-    if (ABL != 3 && ABL != 5) {                                                                \
+    if (!FAKE_READ) {                                                                          \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[BUF][i] = *(const v4i*)(st + offa[i][SL]); \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[BUF][j] = *(const v4i*)(st + offb[j][SL]); \
     } else {                                                                                   \
@@ -446,10 +472,6 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
         const int8_t* st = smem + buf_cp * GT_STAGE;                                           \
         v4i fa[3][TM], fb[3][TN];                                                              \
         WS_READ(0, 0) WS_READ(1, 1)                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        /* the buffer computed in the previous step is free now: queue the stage after next (its */ \
-        /* issue time hides the latency of the reads above) */                                 \
-        WS_ISSUE_NEXT()                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                     \
         WS_READ(2, 2) WS_MFMA(fa[0], fb[0], AS_FP4)                                            \
         __builtin_amdgcn_sched_barrier(0);                                                     \
@@ -543,7 +565,7 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
                 if (u < u1) {
                     const v2d v = {WS_VAL(x[q].x), WS_VAL(x[q].y)};
                     double* dst = (u >= 32 ? dst_cols : dst_rows) + (i64)(u & 31) * ldk;
-                    if (ABL == 0) __builtin_nontemporal_store(v, (v2d*)dst);
+                    if (!NO_STORE) __builtin_nontemporal_store(v, (v2d*)dst);
                     else if (v.x == 1.2345e300) dst[0] = v.y;
                 }
             }
@@ -559,18 +581,18 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
     };
     const int upc = k_steps > 0 ? (64 + k_steps - 1) / k_steps : 64;           // units per chunk (a mirrored tile has 64 per wave)
 
+    WS_DBG_DECL
     // ---- main loops: one per role, with the same barrier sequence (k_steps + 1 per tile, one at the end).
     // Separate loop nests keep the accumulators of the compute role in one straight-line K loop.
     if (is_compute) {
 #define WS_STEP(AS_FP4)                                                                        \
     {                                                                                          \
-        /* this stage has landed; the one behind it may stay in flight */                      \
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");             \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
-        if (ABL < 4) __builtin_amdgcn_s_barrier();                                             \
-        --ahead;                                                                               \
-        if (ABL != 2) WS_COMPUTE(AS_FP4) else WS_ISSUE_NEXT()                                  \
+        WS_DBG_T0()                                                                            \
+        if (!NO_BAR) __builtin_amdgcn_s_barrier();       /* the load waves saw this stage land */ \
+        WS_DBG_ADD(t_bar)                                                                      \
+        if (!NO_COMPUTE) WS_COMPUTE(AS_FP4)                                                    \
         buf_cp = buf_cp == WS_RING - 1 ? 0 : buf_cp + 1;                                       \
+        WS_DBG_ADD(t_body)                                                                     \
     }
         while (cur.ok) {
             int kt = 0;
@@ -590,7 +612,10 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
             }
             // hand-over: the store waves have read the parked tile completely, park this one
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WS_DBG_T0()
             __builtin_amdgcn_s_barrier();
+            WS_DBG_ADD(t_bar)
+            if (!NO_PARK)
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -606,28 +631,59 @@ __global__ __launch_bounds__(512) void gram_ws_kernel(
                     }
                 }
             WS_ZERO_ACC()
-            // every stage of this tile has been queued, so the load cursor already stands on the next tile
-            // (with a single K-step per tile it may stand two tiles ahead: walk then)
-            if (k_steps >= 2) cur = ldt;
-            else cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+            cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+            WS_DBG_ADD(t_walk)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        WS_DBG_OUT(0)
 #undef WS_STEP
+    } else if (is_loader) {
+        // ---- load role: the operand ring.  Issuing a 1-KiB LDS-DMA piece costs the issuing wave ~100 cycles
+        // (MI355X_MICROARCH.md "LDS-DMA piece"; measured here: 820 cycles per K-step for eight pieces), so the pieces
+        // stay out of the multiplying waves' instruction streams: a wave per SIMD does nothing else.  Wait until the own
+        // pieces of the stage have landed, meet the others at the K-step's barrier, queue the stage after next into the
+        // buffer the multiplying waves have just left.
+        while (cur.ok) {
+            for (int kt = 0; kt < k_steps; ++kt) {
+                WS_DBG_T0()
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WS_DBG_ADD(t_walk)
+                if (!NO_BAR) __builtin_amdgcn_s_barrier();
+                WS_DBG_ADD(t_bar)
+                --ahead;
+                WS_ISSUE_NEXT()
+                WS_DBG_ADD(t_body)
+            }
+            WS_DBG_T0()
+            __builtin_amdgcn_s_barrier();
+            WS_DBG_ADD(t_bar)
+            cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+        }
+        __builtin_amdgcn_s_barrier();
+        WS_DBG_OUT(2)
     } else {
         while (cur.ok) {
             for (int kt = 0; kt < k_steps; ++kt) {
-                if (ABL < 4) __builtin_amdgcn_s_barrier();
-                if (prv.ok && ABL != 5) store_chunk(kt * upc, (kt + 1) * upc);
+                WS_DBG_T0()
+                if (!NO_BAR) __builtin_amdgcn_s_barrier();
+                WS_DBG_ADD(t_bar)
+                if (prv.ok && !NO_CHUNK) store_chunk(kt * upc, (kt + 1) * upc);
+                WS_DBG_ADD(t_body)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WS_DBG_T0()
             __builtin_amdgcn_s_barrier();
+            WS_DBG_ADD(t_bar)
             prv = cur;
             cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+            WS_DBG_ADD(t_walk)
         }
         // drain: the last parked tile
         __builtin_amdgcn_s_barrier();
         if (prv.ok) store_chunk(0, 64);
+        WS_DBG_OUT(1)
     }
 #undef WS_VAL
 #undef WS_COMPUTE
@@ -650,16 +706,9 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
     int abl_bits = 0;
 #ifdef GK_ABLATION
     // timing ablations (WRONG results by construction): only in the tools' build of the library
-    // (make -C grakel_amd/csrc abl -> libgk_hip_abl.so, tools/gram_only.py); the shipped library has none of this
-    if (const char* abl = getenv("GK_GRAM_ABL")) {
-        if (!strcmp(abl, "nostore")) M_store = 0, abl_bits = 6;       // K loop only: every store is predicated off
-        if (!strcmp(abl, "nok")) k_all = 0, k8 = 0;     // epilogue only
-        if (!strcmp(abl, "noload")) abl_bits = 1;      // persistent kernel: MFMA + LDS reads only
-        if (!strcmp(abl, "nomfma")) abl_bits = 2;      // persistent kernel: operand streaming only
-        if (!strcmp(abl, "mfmaonly")) abl_bits = 3;    // no loads, no LDS reads
-        if (!strcmp(abl, "nobarrier")) abl_bits = 4;   // no loads, no per-step barrier
-        if (!strcmp(abl, "puremfma")) abl_bits = 5;    // compute waves: MFMA only, store waves idle, no barriers
-    }
+    // (make -C grakel_amd/csrc abl -> libgk_hip_abl.so, tools/gram_only.py --abl, tools/gram_ablate.sh); the shipped
+    // library has none of this.  GK_GRAM_ABL = bit mask, see gram_ws_kernel
+    if (const char* abl = getenv("GK_GRAM_ABL")) abl_bits = atoi(abl);
 #endif
     const bool use_ws = !ctx->opt.gram_no_ws;
     if (use_ws) {
@@ -675,16 +724,14 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
         void (*kern)(const int8_t*, const int8_t*, i64, int, int, const u64*, double*, i64, i64, i64, int, i64, int, int, int,
                      int, int, int, i64, unsigned*, i64, i64, int) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
 #ifdef GK_ABLATION
-        if (abl_bits == 1) kern = gram_ws_kernel<true, 1>;
-        if (abl_bits == 2) kern = gram_ws_kernel<true, 2>;
-        if (abl_bits == 3) kern = gram_ws_kernel<true, 3>;
-        if (abl_bits == 4) kern = gram_ws_kernel<true, 4>;
-        if (abl_bits == 5) kern = gram_ws_kernel<true, 5>;
-        if (abl_bits == 6) kern = gram_ws_kernel<true, 6>, M_store = M;
+#define WS_ABL_CASE(X) if (abl_bits == X) kern = gram_ws_kernel<true, X>;
+        WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(8) WS_ABL_CASE(9) WS_ABL_CASE(10) WS_ABL_CASE(11) WS_ABL_CASE(13)
+        WS_ABL_CASE(24) WS_ABL_CASE(25) WS_ABL_CASE(43) WS_ABL_CASE(107)
+#undef WS_ABL_CASE
 #endif
         (void)abl_bits;
         GK_TRY(gk_func_lds(ctx, (const void*)kern, WS_LDS_BYTES));
-        kern<<<dim3((unsigned)grid), dim3(512), WS_LDS_BYTES, ctx->stream>>>(
+        kern<<<dim3((unsigned)grid), dim3(WS_THREADS), WS_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
             normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket, ldk, col_lo, even);
     } else if (f->phi_fp4) {
@@ -1116,3 +1163,12 @@ extern "C" int gk_gram_last_stats(gk_feat* f, double* out_flops, double* out_ms_
     if (out_ms_event) *out_ms_event = f->last_ms;
     return GK_OK;
 }
+
+#ifdef GK_ABLATION
+// tools' build only: cycle stamps of workgroup 0 of the last gram_ws_kernel launch ([role][total, barriers, body, tile change])
+extern "C" int gk_debug_ws_times(gk_ctx* ctx, unsigned long long* out12) {
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    GK_HIP_CHECK(hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_ws_dbg), sizeof(unsigned long long) * 12));
+    return GK_OK;
+}
+#endif

@@ -42,6 +42,14 @@ for opts in variants:
         if ref is None: ref = chk
         print(opts, os.environ.get("GK_GRAM_ABL", ""), "gemm ms min %.3f med %.3f | gram total min %.3f" % (min(ms), sorted(ms)[len(ms)//2], min(tot)),
               "TOP/s %.0f" % (fl / min(ms) / 1e9), "chk", chk, "OK" if chk == ref else "MISMATCH")
+        if "--abl" in sys.argv:
+            import ctypes
+            t = (ctypes.c_ulonglong * 12)()
+            eng.lib.gk_debug_ws_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            if eng.lib.gk_debug_ws_times(eng.handle, t) == 0:
+                for r, name in enumerate(("multiply", "store", "load")):
+                    tot, bar, body, walk = (t[4 * r + k] for k in range(4))
+                    print("      wg0 %-8s cycles: total %9d  barrier waits %9d  body %9d  other %9d" % (name, tot, bar, body, walk))
         if rebuilt:
             f.close()
 if N == 10000: print("golden sum 200604613570 trace 25874190")
