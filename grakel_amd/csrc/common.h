@@ -72,6 +72,9 @@ struct gk_opts {
     int feat_no_gm = 0, gm_no_priv = 0, low_df = 0 /* 0 = 24 */, gm_row_lds_max = 0 /* 0 = GM_ROW_LDS_MAX */;
     // Gram
     int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
+    // ShortestPath
+    int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)
+    int sp_no_reg = 0;           // all-pairs distances of small graphs by the LDS workgroup kernel instead of wave-per-graph registers
     // plumbing
     int no_mailbox = 0;
     int poison = 0;              // debug: fill every block handed out by the allocator with this byte pattern (| 0x100)

@@ -118,6 +118,424 @@ __global__ __launch_bounds__(1024) void sp_fw_kernel(
     block_count_max(cnt, mx, &pair_count[g], maxd);
 }
 
+// ---------------------------------------------------------------------------------------
+// Graphs of up to 64 vertices (97 % of the NCI1-like set): ONE WAVE per graph, the distance matrix in REGISTERS.
+// Lane i owns row i as NP registers (NP = n rounded up to a multiple of 8, a compile-time constant: register arrays
+// need static indices).  Pivot k relaxes d[i][j] = min(d[i][j], d[i][k] + d[k][j]): d[k][j] is lane k's register
+// (v_readlane with the lane number in an SGPR), d[i][k] would be the lane's OWN register number k -- a dynamic
+// register index.  So the rows ROTATE: the pass over j writes its results one register down, after pivot k register
+// r holds column (r + k + 1) mod NP, the needed d[i][k] is always register 0, and after NP pivots everything is
+// back in place.  Three VALU instructions per (k, j), no LDS traffic, no barrier of any kind in the main loop (the
+// workgroup form needs one s_barrier per pivot and kept half of its 64-lane rows idle at n = 30).
+// LDS only stages the adjacency on the way in (scattered edge writes) and the rows on the way out (coalesced store).
+// ---------------------------------------------------------------------------------------
+#define SP_REG_MAX_N 64
+#define SP_REG_WAVES 4
+
+template <int NP>
+__device__ __forceinline__ void sp_fw_reg_body(i32* __restrict__ lds, int n, const i32* __restrict__ row_ptr,
+                                               const i32* __restrict__ col_idx, const i32* __restrict__ w, i32 v0,
+                                               i32* __restrict__ out, u32* __restrict__ pair_count_g, u32* __restrict__ maxd) {
+    constexpr int LD = NP + 4;                       // 16-byte aligned rows, lanes spread over the banks
+    const int lane = threadIdx.x & 63;
+    for (int idx = lane; idx < NP * LD; idx += 64) lds[idx] = SP_INF;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+        const i32 e0 = row_ptr[v0 + lane], e1 = row_ptr[v0 + lane + 1];
+        for (i32 e = e0; e < e1; ++e) {               // multi-edges keep the lightest (the CSR holds each neighbour once)
+            const int j = col_idx[e] - v0;
+            const i32 wt = w ? w[e] : 1;
+            if (wt < lds[lane * LD + j]) lds[lane * LD + j] = wt;
+        }
+        lds[lane * LD + lane] = 0;                    // np.fill_diagonal(dist, 0): graph.py:1786
+    }
+    __builtin_amdgcn_wave_barrier();
+    i32 d[NP];
+    const int rl = lane < NP ? lane : NP - 1;          // lanes beyond the padded size read a valid row (their results are never used)
+#pragma unroll
+    for (int r = 0; r < NP; r += 4) {
+        const int4 t = *(const int4*)(lds + rl * LD + r);
+        d[r] = t.x, d[r + 1] = t.y, d[r + 2] = t.z, d[r + 3] = t.w;
+    }
+    for (int k = 0; k < NP; ++k) {
+        const i32 dik = d[0];
+        if (k < n) {                                  // wave-uniform
+            const i32 x0 = min(d[0], dik + __builtin_amdgcn_readlane(d[0], k));
+#pragma unroll
+            for (int r = 1; r < NP; ++r) d[r - 1] = min(d[r], dik + __builtin_amdgcn_readlane(d[r], k));
+            d[NP - 1] = x0;
+        } else {                                      // padding pivot: rotate only
+            const i32 x0 = d[0];
+#pragma unroll
+            for (int r = 1; r < NP; ++r) d[r - 1] = d[r];
+            d[NP - 1] = x0;
+        }
+    }
+    // rows back through LDS: coalesced n x n store, finite pairs and the largest distance on the way
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < NP; r += 4) *(int4*)(lds + rl * LD + r) = make_int4(d[r], d[r + 1], d[r + 2], d[r + 3]);
+    __builtin_amdgcn_wave_barrier();
+    u32 cnt = 0, mx = 0;
+    for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, j = idx - i * n;
+        const i32 x = lds[i * LD + j];
+        out[idx] = x;
+        if (i != j && x < SP_INF) { ++cnt; mx = (u32)x > mx ? (u32)x : mx; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        const u32 o = __shfl_down(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 0) {
+        *pair_count_g = cnt;
+        if (mx) atomicMax(maxd, mx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same with 16-bit distances, two columns per register (v_pk_add_u16 / v_pk_min_u16): whenever every finite distance
+// stays below 0x3fff -- (n - 1) x the largest weight < 16383, i.e. every unit-weight job -- a relaxation of two columns costs
+// one v_readlane + one packed add + one packed min, and a lane can own TWO rows (i and i + 64), which takes graphs of up
+// to 128 vertices into registers: the 3 % of the NCI1-like set above 64 vertices cost more in the LDS workgroup kernel
+// (one s_barrier per pivot, 166 us) than the other 97 % in the register kernel (97 us).  The rows rotate by one register
+// every second pivot (h = k & 1 selects the half of register 0 that holds d[i][k]).
+// ---------------------------------------------------------------------------------------
+#define SP_PK_INF 0x3fffu
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+
+template <int NP2, int ROWS>
+__device__ __forceinline__ void sp_fw_pk_body(unsigned short* __restrict__ lds, int n, const i32* __restrict__ row_ptr,
+                                              const i32* __restrict__ col_idx, const i32* __restrict__ w, i32 v0,
+                                              i32* __restrict__ out, u32* __restrict__ pair_count_g, u32* __restrict__ maxd) {
+    constexpr int NC = 2 * NP2, LD = NC + 8;           // columns; row pitch in halfwords (16-byte aligned rows)
+    constexpr int NR = 64 * ROWS;
+    const int lane = threadIdx.x & 63;
+    {
+        u32* z = (u32*)lds;
+        for (int idx = lane; idx < NR * LD / 2; idx += 64) z[idx] = SP_PK_INF | (SP_PK_INF << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s) {
+        const int i = lane + 64 * s;
+        if (i < n) {
+            const i32 e0 = row_ptr[v0 + i], e1 = row_ptr[v0 + i + 1];
+            for (i32 e = e0; e < e1; ++e) {
+                const int j = col_idx[e] - v0;
+                const unsigned short wt = (unsigned short)(w ? w[e] : 1);
+                if (wt < lds[i * LD + j]) lds[i * LD + j] = wt;
+            }
+            lds[i * LD + i] = 0;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    u32 d[ROWS][NP2];
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+#pragma unroll
+        for (int r = 0; r < NP2; r += 4) {
+            const uint4 t = *(const uint4*)(lds + (lane + 64 * s) * LD + 2 * r);
+            d[s][r] = t.x, d[s][r + 1] = t.y, d[s][r + 2] = t.z, d[s][r + 3] = t.w;
+        }
+    auto relax = [](u32 x, u32 dik2, u32 pk) __attribute__((always_inline)) {
+        const v2us a = __builtin_bit_cast(v2us, dik2) + __builtin_bit_cast(v2us, pk);
+        return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(v2us, x), a));
+    };
+    // one pivot, in place: PSET = row set that holds the pivot row (its lane kl); d[.][k] is half (k & 1) of register 0
+#define SP_PK_RELAX(PSET)                                                                          \
+    {                                                                                              \
+        u32 dik2[ROWS];                                                                            \
+        _Pragma("unroll") for (int s = 0; s < ROWS; ++s) {                                         \
+            const u32 h = (d[s][0] >> sh) & 0xffffu;                                               \
+            dik2[s] = h | (h << 16);                                                               \
+        }                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < NP2; ++r) {                                          \
+            const u32 pk = (u32)__builtin_amdgcn_readlane((int)d[PSET][r], kl);                    \
+            _Pragma("unroll") for (int s = 0; s < ROWS; ++s) d[s][r] = relax(d[s][r], dik2[s], pk); \
+        }                                                                                          \
+    }
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < NC; ++k) {
+        const int sh = (k & 1) << 4, kl = k & 63;
+        if (k < n) {                                   // wave-uniform; padding pivots relax nothing
+            if (ROWS == 1 || k < 64) SP_PK_RELAX(0)
+            else SP_PK_RELAX(ROWS - 1)
+        }
+        if (k & 1) {                                   // after every second pivot the rows move one register down
+#pragma unroll
+            for (int s = 0; s < ROWS; ++s) {
+                const u32 x0 = d[s][0];
+#pragma unroll
+                for (int r = 1; r < NP2; ++r) d[s][r - 1] = d[s][r];
+                d[s][NP2 - 1] = x0;
+            }
+        }
+    }
+#undef SP_PK_RELAX
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+#pragma unroll
+        for (int r = 0; r < NP2; r += 4)
+            *(uint4*)(lds + (lane + 64 * s) * LD + 2 * r) = make_uint4(d[s][r], d[s][r + 1], d[s][r + 2], d[s][r + 3]);
+    __builtin_amdgcn_wave_barrier();
+    u32 cnt = 0, mx = 0;
+    for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, j = idx - i * n;
+        const u32 x = lds[i * LD + j];
+        out[idx] = x >= SP_PK_INF ? SP_INF : (i32)x;
+        if (i != j && x < SP_PK_INF) { ++cnt; mx = x > mx ? x : mx; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        const u32 o = __shfl_down(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 0) {
+        *pair_count_g = cnt;
+        if (mx) atomicMax(maxd, mx);
+    }
+}
+
+// Graphs of 65..128 vertices: the single-wave form above is one long dependent chain (43 k instructions for n = 110,
+// 170 us -- the whole batch waits for its largest graphs).  Here a WORKGROUP of four waves owns the graph and every
+// wave a quarter of the COLUMNS for all rows (two rows per lane): the pivot row restricted to the wave's columns sits
+// in the wave's own lanes (readlane as before), only the pivot COLUMN d[.][k] has to travel -- its owner writes 128
+// halfwords to LDS, one s_barrier, everybody reads its two.  Floyd-Warshall is correct for any order of the pivots, so
+// they are taken round-robin over the waves' column slices (wave 0's first pair, wave 1's, ... then every wave rotates
+// its registers by one): the pivot column is always register 0 of its owner.
+template <int NP2>
+__device__ __forceinline__ void sp_fw_pkw_body(unsigned short* __restrict__ lds, int n, const i32* __restrict__ row_ptr,
+                                               const i32* __restrict__ col_idx, const i32* __restrict__ w, i32 v0,
+                                               i32* __restrict__ out, u32* __restrict__ pair_count_g, u32* __restrict__ maxd) {
+    constexpr int NC = 2 * NP2, LD = NC + 8, S = NP2 / 4;      // S registers (column pairs) per wave and row set
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned short* xch = lds + 128 * LD;                       // [2][128] pivot-column exchange
+    {
+        u32* z = (u32*)lds;
+        for (int idx = tid; idx < 128 * LD / 2; idx += 256) z[idx] = SP_PK_INF | (SP_PK_INF << 16);
+    }
+    __syncthreads();
+    if (tid < n) {
+        const i32 e0 = row_ptr[v0 + tid], e1 = row_ptr[v0 + tid + 1];
+        for (i32 e = e0; e < e1; ++e) {
+            const int j = col_idx[e] - v0;
+            const unsigned short wt = (unsigned short)(w ? w[e] : 1);
+            if (wt < lds[tid * LD + j]) lds[tid * LD + j] = wt;
+        }
+        lds[tid * LD + tid] = 0;
+    }
+    __syncthreads();
+    u32 d[2][S];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < S; ++r) d[s][r] = *(const u32*)(lds + (lane + 64 * s) * LD + 2 * (wv * S + r));
+    auto relax = [](u32 x, u32 dik2, u32 pk) __attribute__((always_inline)) {
+        const v2us a = __builtin_bit_cast(v2us, dik2) + __builtin_bit_cast(v2us, pk);
+        return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(v2us, x), a));
+    };
+    int slot = 0;
+#pragma clang loop unroll(disable)
+    for (int m = 0; m < S; ++m) {
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < 8; ++q) {                           // owner wave q >> 1, half q & 1 of its register 0
+            const int ow = q >> 1, sh = (q & 1) << 4;
+            const int k = 2 * (ow * S + m) + (q & 1);           // the column that register holds (workgroup-uniform)
+            if (k < n) {
+                if (wv == ow) {
+                    xch[slot * 128 + lane] = (unsigned short)(d[0][0] >> sh);
+                    xch[slot * 128 + 64 + lane] = (unsigned short)(d[1][0] >> sh);
+                }
+                __syncthreads();
+                u32 dik2[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const u32 h = xch[slot * 128 + 64 * s + lane];
+                    dik2[s] = h | (h << 16);
+                }
+                slot ^= 1;
+                const int kl = k & 63;
+                if (k < 64) {
+#pragma unroll
+                    for (int r = 0; r < S; ++r) {
+                        const u32 pk = (u32)__builtin_amdgcn_readlane((int)d[0][r], kl);
+                        d[0][r] = relax(d[0][r], dik2[0], pk), d[1][r] = relax(d[1][r], dik2[1], pk);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < S; ++r) {
+                        const u32 pk = (u32)__builtin_amdgcn_readlane((int)d[1][r], kl);
+                        d[0][r] = relax(d[0][r], dik2[0], pk), d[1][r] = relax(d[1][r], dik2[1], pk);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                           // every wave: one register down
+            const u32 x0 = d[s][0];
+#pragma unroll
+            for (int r = 1; r < S; ++r) d[s][r - 1] = d[s][r];
+            d[s][S - 1] = x0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < S; ++r) *(u32*)(lds + (lane + 64 * s) * LD + 2 * (wv * S + r)) = d[s][r];
+    __syncthreads();
+    u32 cnt = 0, mx = 0;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx - i * n;
+        const u32 x = lds[i * LD + j];
+        out[idx] = x >= SP_PK_INF ? SP_INF : (i32)x;
+        if (i != j && x < SP_PK_INF) { ++cnt; mx = x > mx ? x : mx; }
+    }
+    block_count_max(cnt, mx, pair_count_g, maxd);
+}
+
+__global__ __launch_bounds__(256) void sp_fw_pkw_kernel(
+    const i32* __restrict__ cls_list, i64 n_graphs, int c4, int c5, int c6, int c7, const i32* __restrict__ graph_ptr,
+    const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ w,
+    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd) {
+    extern __shared__ __attribute__((aligned(16))) i32 sp_lds[];
+    int gi = blockIdx.x, c = 4;                          // classes 4..7 (80 / 96 / 112 / 128 columns), one workgroup per graph
+    if (gi >= c4) { gi -= c4, c = 5; if (gi >= c5) { gi -= c5, c = 6; if (gi >= c6) { gi -= c6, c = 7; if (gi >= c7) return; } } }
+    const i32 g = cls_list[(i64)c * n_graphs + gi];
+    const i32 v0 = graph_ptr[g];
+    const int n = graph_ptr[g + 1] - v0;
+    i32* out = dist + dist_ptr[g];
+    unsigned short* lds = (unsigned short*)sp_lds;
+    u32* pc = &pair_count[g];
+    switch (c) {
+        case 4: sp_fw_pkw_body<40>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+        case 5: sp_fw_pkw_body<48>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+        case 6: sp_fw_pkw_body<56>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+        default: sp_fw_pkw_body<64>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+    }
+}
+
+// packed classes: c = 0..3 one row per lane, 16(c+1) columns; c = 4..7 two rows per lane, 80 / 96 / 112 / 128 columns
+struct SpPkClasses {
+    int first[9];
+    int count[8];
+};
+
+template <int BIG>
+__global__ __launch_bounds__(64 * SP_REG_WAVES) void sp_fw_pk_kernel(
+    const SpPkClasses C, const i32* __restrict__ cls_list, i64 n_graphs, const i32* __restrict__ graph_ptr,
+    const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ w,
+    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd) {
+    extern __shared__ __attribute__((aligned(16))) i32 sp_lds[];
+    // BIG = 0: the launch covers classes 0..3, BIG = 1: classes 4..7 (their LDS staging areas differ by 4x)
+    int c = BIG ? 4 : 0;
+    const int c_end = BIG ? 7 : 3;
+    while (c < c_end && (int)blockIdx.x >= C.first[c + 1] - C.first[BIG ? 4 : 0]) ++c;
+    const int wave = threadIdx.x >> 6;
+    const int gi = ((int)blockIdx.x - (C.first[c] - C.first[BIG ? 4 : 0])) * SP_REG_WAVES + wave;
+    if (gi >= C.count[c]) return;
+    const i32 g = cls_list[(i64)c * n_graphs + gi];
+    const i32 v0 = graph_ptr[g];
+    const int n = graph_ptr[g + 1] - v0;
+    i32* out = dist + dist_ptr[g];
+    unsigned short* lds = (unsigned short*)sp_lds + (size_t)wave * (BIG ? 128 * 136 : 64 * 72);
+    u32* pc = &pair_count[g];
+    if (!BIG) {
+        switch (c) {
+            case 0: sp_fw_pk_body<8, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+            case 1: sp_fw_pk_body<16, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+            case 2: sp_fw_pk_body<24, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+            default: sp_fw_pk_body<32, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+        }
+    } else {
+        switch (c) {
+            case 4: sp_fw_pk_body<40, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+            case 5: sp_fw_pk_body<48, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+            case 6: sp_fw_pk_body<56, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+            default: sp_fw_pk_body<64, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+        }
+    }
+}
+
+// packed-kernel classes: 0..3 = (0,16] (16,32] (32,48] (48,64]; 4..7 = (64,80] (80,96] (96,112] (112,128]; 8 = up to the LDS
+// cap; 9 = beyond
+__global__ void sp_bin_pk_kernel(const i32* __restrict__ graph_ptr, i64 n_graphs, int cap, u32* __restrict__ cls_count,
+                                 i32* __restrict__ cls_list) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = -1;
+    if (g < n_graphs) {
+        const int n = graph_ptr[g + 1] - graph_ptr[g];
+        c = n <= 0 ? 0 : (n <= 128 ? (n - 1) >> 4 : (n <= cap ? 8 : 9));
+    }
+    for (int k = 0; k < 10; ++k) {
+        const u64 m = __ballot(c == k);
+        if (!m) continue;
+        const int lane = threadIdx.x & 63;
+        u32 base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cls_count[k], (u32)__popcll(m));
+        base = __shfl(base, (int)__builtin_ctzll(m), 64);
+        if (c == k) cls_list[(i64)k * n_graphs + base + __popcll(m & ((1ull << lane) - 1ull))] = (i32)g;
+    }
+}
+
+// class c = 1..8: graphs of (8(c-1), 8c] vertices, listed in cls_list[(c-1) * n_graphs ..); blocks are dealt to the
+// classes by the prefix cls_first[] (workgroups per class)
+struct SpClasses {
+    int first[9];          // first workgroup of class c (index c - 1), [8] = total
+    int count[8];
+};
+
+__global__ __launch_bounds__(64 * SP_REG_WAVES) void sp_fw_reg_kernel(
+    const SpClasses C, const i32* __restrict__ cls_list, i64 n_graphs, const i32* __restrict__ graph_ptr,
+    const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ w,
+    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd) {
+    extern __shared__ __attribute__((aligned(16))) i32 sp_lds[];
+    int c = 0;
+    while (c < 7 && (int)blockIdx.x >= C.first[c + 1]) ++c;
+    const int wave = threadIdx.x >> 6;
+    const int gi = ((int)blockIdx.x - C.first[c]) * SP_REG_WAVES + wave;
+    if (gi >= C.count[c]) return;
+    const i32 g = cls_list[(i64)c * n_graphs + gi];
+    const i32 v0 = graph_ptr[g];
+    const int n = graph_ptr[g + 1] - v0;
+    i32* out = dist + dist_ptr[g];
+    i32* lds = sp_lds + (size_t)wave * (SP_REG_MAX_N * (SP_REG_MAX_N + 4));
+    switch (c) {
+        case 0: sp_fw_reg_body<8>(lds, n, row_ptr, col_idx, w, v0, out, &pair_count[g], maxd); break;
+        case 1: sp_fw_reg_body<16>(lds, n, row_ptr, col_idx, w, v0, out, &pair_count[g], maxd); break;
+        case 2: sp_fw_reg_body<24>(lds, n, row_ptr, col_idx, w, v0, out, &pair_count[g], maxd); break;
+        case 3: sp_fw_reg_body<32>(lds, n, row_ptr, col_idx, w, v0, out, &pair_count[g], maxd); break;
+        case 4: sp_fw_reg_body<40>(lds, n, row_ptr, col_idx, w, v0, out, &pair_count[g], maxd); break;
+        case 5: sp_fw_reg_body<48>(lds, n, row_ptr, col_idx, w, v0, out, &pair_count[g], maxd); break;
+        case 6: sp_fw_reg_body<56>(lds, n, row_ptr, col_idx, w, v0, out, &pair_count[g], maxd); break;
+        default: sp_fw_reg_body<64>(lds, n, row_ptr, col_idx, w, v0, out, &pair_count[g], maxd); break;
+    }
+}
+
+// size classes of the graphs: lists for the register kernel (classes 0..7), the LDS kernel (8: 64 < n <= cap) and the
+// row-relaxation kernel (9: n > cap).  cls_count[10]; lists are n_graphs apart.  Wave-aggregated appends.
+__global__ void sp_bin_kernel(const i32* __restrict__ graph_ptr, i64 n_graphs, int cap, u32* __restrict__ cls_count,
+                              i32* __restrict__ cls_list) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = -1;
+    if (g < n_graphs) {
+        const int n = graph_ptr[g + 1] - graph_ptr[g];
+        c = n <= 0 ? 0 : (n <= SP_REG_MAX_N ? (n - 1) >> 3 : (n <= cap ? 8 : 9));
+    }
+    for (int k = 0; k < 10; ++k) {
+        const u64 m = __ballot(c == k);
+        if (!m) continue;
+        const int lane = threadIdx.x & 63;
+        u32 base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cls_count[k], (u32)__popcll(m));
+        base = __shfl(base, (int)__builtin_ctzll(m), 64);
+        if (c == k) cls_list[(i64)k * n_graphs + base + __popcll(m & ((1ull << lane) - 1ull))] = (i32)g;
+    }
+}
+
 // grid (n_graphs, max_n): block (g, src) for graphs larger than the Floyd-Warshall LDS cap
 __global__ __launch_bounds__(SP_THREADS) void sp_relax_kernel(
     const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
@@ -206,7 +624,23 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     GK_TRY(gk_zero_async(ctx, s.maxd.p, 4));
     sp_sq_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, s.sq.p, N);
     GK_TRY(gk_scan_u64(ctx, s.sq.p, s.dist_ptr.p, N, true, s.total.p));
+    // size classes (one wave per graph in registers up to 64 vertices, the LDS workgroup form up to the LDS cap, row
+    // relaxation beyond): binned on the device, counts read back with the matrix total
+    const int cap = sp_fw_cap();
+    Tmp<u32> cls_count(ctx);
+    Tmp<i32> cls_list(ctx);
+    GK_TRY(cls_count.alloc(16)); GK_TRY(cls_list.alloc((size_t)10 * (size_t)N));
+    GK_TRY(gk_zero_async(ctx, cls_count.p, 64));
+    // 16-bit packed registers whenever every finite distance of a graph of up to 128 vertices stays below 0x3fff
+    i64 wmax = 1;
+    if (edge_weight)
+        for (i64 e = 0; e < b->n_edges; ++e) wmax = edge_weight[e] > wmax ? edge_weight[e] : wmax;
+    const bool use_pk = wmax <= 128 && !ctx->opt.sp_no_reg && !ctx->opt.sp_no_pk;
+    if (use_pk) sp_bin_pk_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, N, cap, cls_count.p, cls_list.p);
+    else sp_bin_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, N, cap, cls_count.p, cls_list.p);
+    u32 h_cls[10];
     GK_HIP_CHECK(hipMemcpyAsync(total_sq, s.total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipMemcpyAsync(h_cls, cls_count.p, 40, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     GK_ARG(*total_sq < (1ull << 31), "ShortestPath: sum of n^2 exceeds int32 item indexing");
     GK_TRY(s.dist.alloc(*total_sq));
@@ -216,26 +650,65 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
         GK_HIP_CHECK(hipMemcpyAsync(s.wdev.p, edge_weight, (size_t)b->n_edges * 4, hipMemcpyHostToDevice, ctx->stream));
         w = s.wdev.p;
     }
-    const int cap = sp_fw_cap();
     const int nmax = b->max_graph_nodes;
+    i64 n_launch = 0;
     ProfScope prof_fw(ctx, "sp_fw", 2);       // the all-pairs kernels alone (bench.py: min-plus rate)
-    {
-        // two launches over all graphs: small graphs (n <= 48) with 256 threads, the rest up to
-        // the LDS cap with 1024 threads; a launch's workgroups exit at once for the other class
-        const int split = 48;
-        const int nsmall = nmax < split ? nmax : split;
-        size_t lds = (size_t)nsmall * (nsmall | 1) * 4;
-        sp_fw_kernel<<<dim3((unsigned)N), 256, lds, ctx->stream>>>(
-            b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, 0, split);
-        if (nmax > split) {
+    if (use_pk) {
+        SpPkClasses C;
+        int wg = 0;
+        for (int c = 0; c < 8; ++c) {
+            C.first[c] = wg, C.count[c] = (int)h_cls[c];
+            wg += (int)cdiv(h_cls[c], SP_REG_WAVES);
+        }
+        C.first[8] = wg;
+        if (C.first[4] > 0) {
+            sp_fw_pk_kernel<0><<<dim3((unsigned)C.first[4]), 64 * SP_REG_WAVES, SP_REG_WAVES * 64 * 72 * 2, ctx->stream>>>(
+                C, cls_list.p, N, b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p);
+            ++n_launch;
+        }
+        const u32 n_big = h_cls[4] + h_cls[5] + h_cls[6] + h_cls[7];
+        if (n_big > 0) {                     // 65..128 vertices: a workgroup per graph, columns split over its four waves
+            const int lds = (128 * 136 + 256) * 2;
+            sp_fw_pkw_kernel<<<dim3(n_big), 256, lds, ctx->stream>>>(
+                cls_list.p, N, (int)h_cls[4], (int)h_cls[5], (int)h_cls[6], (int)h_cls[7], b->graph_ptr, b->row_ptr, b->col_idx, w,
+                s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p);
+            ++n_launch;
+        }
+        if (h_cls[8] > 0 && nmax > 128) {
             const int nfw = nmax < cap ? nmax : cap;
-            lds = (size_t)nfw * (nfw | 1) * 4;
+            const size_t lds = (size_t)nfw * (nfw | 1) * 4;
             GK_TRY(gk_func_lds(ctx, (const void*)sp_fw_kernel, (int)lds));
             sp_fw_kernel<<<dim3((unsigned)N), 1024, lds, ctx->stream>>>(
-                b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, split, cap);
+                b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, 128, cap);
+            ++n_launch;
+        }
+    } else {
+        SpClasses C;
+        int wg = 0;
+        for (int c = 0; c < 8; ++c) {
+            C.first[c] = wg, C.count[c] = (int)h_cls[c];
+            wg += (int)cdiv(h_cls[c], SP_REG_WAVES);
+        }
+        C.first[8] = wg;
+        if (wg > 0 && !ctx->opt.sp_no_reg) {
+            const int lds = SP_REG_WAVES * SP_REG_MAX_N * (SP_REG_MAX_N + 4) * 4;
+            GK_TRY(gk_func_lds(ctx, (const void*)sp_fw_reg_kernel, lds));
+            sp_fw_reg_kernel<<<dim3((unsigned)wg), 64 * SP_REG_WAVES, lds, ctx->stream>>>(
+                C, cls_list.p, N, b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p);
+            ++n_launch;
+        }
+        // 64 < n <= cap: one 1024-thread workgroup per graph with the matrix in LDS (workgroups of other sizes exit at once)
+        const int lo = ctx->opt.sp_no_reg ? 0 : SP_REG_MAX_N;
+        if ((h_cls[8] > 0 || ctx->opt.sp_no_reg) && nmax > lo) {
+            const int nfw = nmax < cap ? nmax : cap;
+            const size_t lds = (size_t)nfw * (nfw | 1) * 4;
+            GK_TRY(gk_func_lds(ctx, (const void*)sp_fw_kernel, (int)lds));
+            sp_fw_kernel<<<dim3((unsigned)N), 1024, lds, ctx->stream>>>(
+                b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, lo, cap);
+            ++n_launch;
         }
     }
-    if (nmax > cap) {
+    if (nmax > cap && h_cls[9] > 0) {
         GK_ARG(nmax <= SP_ROW_MAX_N, "ShortestPath: graphs above 32768 vertices are not supported");
         size_t lds = (size_t)nmax * 4;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_relax_kernel, (int)lds));
@@ -243,6 +716,7 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
         sp_relax_kernel<<<dim3((unsigned)N, (unsigned)nmax), SP_THREADS, lds, ctx->stream>>>(
             b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, cap);
     }
+    (void)n_launch;
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }
