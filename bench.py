@@ -195,12 +195,23 @@ def config4_sp(eng, steps=5):
     db.close()
     ops = float((sizes ** 3).sum())
     # a min-plus update reads d[i][k], d[k][j], d[i][j] and writes d[i][j]: 16 LDS bytes; 4-byte LDS reads
-    # stream at ~75 TB/s chip-wide (MI355X_MICROARCH.md "LDS")
+    # stream at ~75 TB/s chip-wide (MI355X_MICROARCH.md "LDS") -- the ceiling of the LDS-resident form (round 2)
     ceiling = 75e12 / 16.0
+    # the register form (sp.hip: 16-bit packed distances, two columns per register): 3.5 vector instructions per two
+    # relaxations of a lane (v_readlane, v_pk_add_u16, v_pk_min_u16, half a rotation move), 64 lanes; one VALU instruction per
+    # SIMD every 2 cycles at 2.4 GHz on 1024 SIMDs
+    valu_peak = 1024 * 2.4e9 / 2.0 * (2.0 * 64.0 / 3.5)
     return {"workload": "NCI1-like stand-in (SURVEY.md appendix A), %d graphs, ShortestPath(with_labels), packed CSR in HBM" % N,
             "ms_per_fit_transform": dt * 1e3, "graph_pairs_per_s": N * N / dt, "phases_ms": ph,
             "fw_minplus_ops": ops, "fw_Gops_per_s": ops / (ph["sp_fw"] * 1e-3) / 1e9,
             "fw_lds_ceiling_Gops_per_s": ceiling / 1e9, "fw_frac_of_lds_ceiling": ops / (ph["sp_fw"] * 1e-3) / ceiling,
+            "roofline": {"kernel": "sp_fw_pk_kernel (one wave per graph, <= 64 vertices) + sp_fw_pkw_kernel (four-wave column "
+                                   "split, 65..128 vertices): distance matrices in registers, 16-bit packed",
+                         "bound": "valu-issue", "achieved": ops / (ph["sp_fw"] * 1e-3) / 1e9, "peak": valu_peak / 1e9,
+                         "unit": "G min-plus/s", "frac": ops / (ph["sp_fw"] * 1e-3) / valu_peak,
+                         "note": "one dependent chain per graph (n pivots x n/2 registers): 4110 waves cannot fill 1024 SIMDs "
+                                 "four deep, so the rate is set by the chain length of the largest graphs, not by issue "
+                                 "bandwidth; algorithmic work = sum of n^3 min-plus updates (padding pivots / columns not counted)"},
             "pairs": info["n_pairs"], "features": info["n_keys"], "dense_columns": info["dense"],
             "rare_columns": info["rare"], "max_count": info["max_count"], "gram_kernel_ms": info["gram"][1],
             "K_sum": info["checksum"][0], "K_sum_expected": 87649686148.0,

@@ -73,6 +73,7 @@ struct gk_opts {
     // Gram
     int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
     // ShortestPath
+    int sp_no_hist = 0;          // pair features through explicit pair items + the sorting dictionary instead of per-graph histograms
     int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)
     int sp_no_reg = 0;           // all-pairs distances of small graphs by the LDS workgroup kernel instead of wave-per-graph registers
     // plumbing
@@ -203,6 +204,17 @@ struct gk_batch {
     // scratch kept between levels
     i32* nbr_sorted = nullptr;         // [n_edges] sorted neighbour labels of the level being built
     bool is_pair_batch = false;        // ShortestPath items: no CSR, level 0 only
+    // ShortestPath pair batch in HISTOGRAM form (sp.hip, features_gm.hip: gk_features_build_sp): no item arrays -- the
+    // (l_u, l_v, d) counts of a graph are taken straight from its distance matrix; graph_ptr = pair ranges (entry slots).
+    // The item arrays (labels / perm / node_graph) are materialised on demand (gk_sp_materialise) for the label-major builder.
+    bool sp_hist = false;
+    i32* sp_node_ptr = nullptr;        // [n_graphs + 1] node ranges of the source graphs
+    i32* sp_node_label = nullptr;      // [source nodes] level-0 labels
+    u64* sp_dist_ptr = nullptr;        // [n_graphs] start of each distance matrix
+    i32* sp_dist = nullptr;            // the n x n matrices (SP_INF = unreachable)
+    u32* sp_idtab = nullptr;           // [sp_keyspace] key -> dense feature id
+    i64 sp_L = 0, sp_dcap = 0, sp_keyspace = 0, sp_src_nodes = 0;
+    int sp_with_labels = 0;
     // level 0 of a batch with at most GK_HIST0_MAX_LABELS input labels is never sorted: the label-count
     // features of that level come from one LDS histogram per graph (features.hip), perm[0] stays unused
     bool level0_hist = false;
@@ -295,7 +307,8 @@ int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32*
 
 // ---- wl.hip ---------------------------------------------------------------------------
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);
-int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level);      // perm[level] on demand (sort-free dictionary levels)
+int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level);
+int gk_sp_materialise(gk_ctx* ctx, gk_batch* pair_batch);            // sp.hip: item arrays of a histogram-form pair batch      // perm[level] on demand (sort-free dictionary levels)
 
 // ---- gram.hip -------------------------------------------------------------------------
 int gk_gram_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, int normalize, double* K);

@@ -22,7 +22,13 @@
 #define GM_META_MAXC 8            // 64 partial maxima
 #define GM_META_NNZ 72            // 64 partial sums
 #define GM_META_WORDS 136
+#define GM_META_OVF 135           // gk_features_build_sp: a per-graph histogram table overflowed (last of the NNZ slots, unused otherwise)
 #define GM_MAX_NODES 1024         // largest graph a wave stages in LDS
 #define GM_ROW_LDS_MAX 65536      // widest operand row (bytes) assembled in LDS
 
 int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int prim_max, int wide_above);
+
+// ShortestPath pair batch in histogram form (common.h: gk_batch::sp_hist): features straight from the distance matrices.
+// GK_ERR_UNSUPPORTED: a graph has more distinct features than the LDS table holds or the operand row is too wide -- the
+// caller materialises the pair items (gk_sp_materialise) and takes the label-major builder.
+int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, int wide_above);

@@ -519,6 +519,19 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     f->phi_fp4 = f->dtype == 0 && bound < 16777216.0 && !ctx->opt.gram_no_fp4;
     const int wide_above = kind == GK_FEAT_MINSUM ? 0x7fffffff : (f->dtype == 0 ? 127 : -1);
     const int prim_max = f->dtype != 0 ? -1 : (f->phi_fp4 ? 4 : 127);
+    // ---- ShortestPath pair batch in histogram form: per-graph histograms of the distance matrices (features_gm.hip);
+    // on a decline the pair items are materialised and the label-major builder below takes over
+    if (b->is_pair_batch && b->sp_hist) {
+        r = (n_levels == 1 && kind == GK_FEAT_DOT && !ctx->opt.sp_no_hist) ? gk_features_build_sp(ctx, b, f, prim_max, wide_above) : GK_ERR_UNSUPPORTED;
+        if (r == GK_OK) { *out = f; return GK_OK; }
+        if (r != GK_ERR_UNSUPPORTED) return fail(r);
+        for (void* p : f->arena)
+            if (p) gk_dev_free(ctx, p);
+        f->arena.clear();
+        f->gm = false;
+        if (gk_zero_async(ctx, f->meta, n_meta * 4) != GK_OK) return fail(GK_ERR_HIP);
+        if ((r = gk_sp_materialise(ctx, b))) return fail(r);
+    }
     // ---- graph batches with small graphs: the graph-major builder (features_gm.hip); it declines (row wider
     // than its LDS image) with GK_ERR_UNSUPPORTED and this builder takes over
     if (!b->is_pair_batch && V > 0 && b->max_graph_nodes <= GM_MAX_NODES && !ctx->opt.feat_no_gm) {

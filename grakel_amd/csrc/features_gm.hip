@@ -499,6 +499,79 @@ __global__ void gm_pad_rows_kernel(int8_t* __restrict__ phi, i64 bytes) {
     if (i < bytes / 16) ((uint4*)phi)[i] = make_uint4(0, 0, 0, 0);
 }
 
+// Second half of the graph-major builder, shared with the ShortestPath histogram form (gk_features_build_sp): column classes
+// from df / cmax, operand sizes (one host read-back), operand rows, rare lists.  graph_ptr = item ranges of the graphs
+// (node ranges, or pair ranges of a pair batch), V = items in all; ent / cnt / ent_n = the graphs' (label, count) entries.
+static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& A, i64 Q, size_t qa, const i32* graph_ptr, i64 N, i64 V,
+                     const i32* ent, const u32* cnt, const u32* ent_n, const u32* wgmeta, int grid, int prim_max, int wide_above) {
+    const int kind = f->kind;
+    void* q = nullptr;
+    std::vector<u32> h(GM_META_WORDS, 0);
+    if (Q > 0) {
+        GmColumns gc{A, Q, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta, grid};
+        const i64 nblk = cdiv(Q, G3_TILE);
+        Tmp<Gm3> partial(ctx);
+        GK_TRY(partial.alloc((size_t)nblk));
+        if (nblk > 1) gm_scan_sums_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
+        gm_scan_apply_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
+    }
+    GK_TRY(gk_readback(ctx, f->meta, h.data(), GM_META_WORDS));     // one host sync: sizes of the operand
+    if (h[GM_META_OVF]) return GK_ERR_UNSUPPORTED;                  // a histogram table of gk_features_build_sp overflowed
+    f->n_cols1 = h[GM_META_PRIM], f->n_cols8 = h[GM_META_INT8], f->n_cols = f->n_cols1 + f->n_cols8;
+    f->n_cols_wide = h[GM_META_F64], f->n_low_cols = h[GM_META_RARE];
+    f->max_count = 0, f->nnz = 0;
+    for (int k = 0; k < 64; ++k) {
+        f->max_count = std::max<i64>(f->max_count, h[GM_META_MAXC + k]);
+        if (GM_META_NNZ + k != GM_META_OVF) f->nnz += h[GM_META_NNZ + k];
+    }
+    const i64 rare_entries = h[GM_META_RARE_ENTRIES];
+    // ---- operand: [secondary int8 | primary], 128-byte K-steps (features.hip has the rationale)
+    const i64 n1p = round_up(f->n_cols1, f->phi_fp4 ? 256 : 128);
+    i64 n8p = round_up(f->n_cols8, 128);
+    if (n1p + n8p == 0) n8p = 128;
+    f->k1_steps = (int)(n1p / (f->phi_fp4 ? 256 : 128)), f->k8_steps = (int)(n8p / 128);
+    f->n_cols_pad = (f->phi_fp4 ? n1p / 2 : n1p) + n8p;
+    f->n_rows_pad = round_up(N, 256) + 256;
+    const i64 row_lds_max = ctx->opt.gm_row_lds_max > 0 ? (i64)ctx->opt.gm_row_lds_max : (i64)GM_ROW_LDS_MAX;     // option: test hook
+    if (f->n_cols_pad > row_lds_max) return GK_ERR_UNSUPPORTED;              // caller falls back to features.hip
+    GK_TRY(gk_dev_alloc(ctx, &q, (size_t)f->n_rows_pad * f->n_cols_pad));
+    f->phi = q;
+    if (f->n_cols_wide > 0) {
+        f->n_cols_wide_pad = round_up(f->n_cols_wide, 16);
+        const size_t wb = (size_t)f->n_rows_pad * f->n_cols_wide_pad * 8;
+        GK_TRY(gk_dev_alloc(ctx, &q, wb));
+        f->phi_w = (double*)q;
+        GK_TRY(gk_zero_async(ctx, f->phi_w, wb));
+    }
+    i32* lg = nullptr;
+    i32* lc = nullptr;
+    if (rare_entries > 0) {
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
+        lg = (i32*)q, f->arena.push_back(q);
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
+        lc = (i32*)q, f->arena.push_back(q);
+    }
+    GK_TRY(gk_func_lds(ctx, (const void*)gm_rows_kernel, (int)f->n_cols_pad));
+    // one workgroup per graph (64- and 128-thread workgroups measured the same 30 us: the chain of dependent loads
+    // slot -> entry -> column id binds, not the number of workgroups in flight)
+    gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
+        P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
+        f->n_cols_wide_pad, lg, lc);
+    const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
+    gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
+    GK_HIP_CHECK(hipGetLastError());
+    // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries
+    f->gm = true;
+    f->gm_low_q = A.low_q, f->gm_roff = A.roff, f->gm_low_graph = lg, f->gm_low_cnt = lc;
+    // df is read by the pair-update kernel: keep it (moves out of the zeroed temporary)
+    {
+        GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));
+        GK_HIP_CHECK(hipMemcpyAsync(q, A.df, qa * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        f->gm_df = (u32*)q, f->arena.push_back(q);
+    }
+    return GK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int prim_max, int wide_above) {
     const i64 V = b->n_nodes, N = b->n_graphs;
@@ -573,67 +646,222 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p, wgmeta.p);
     if (R.bins > 0)
         gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(P, A, R, part.p, (int)grid, prim_max, wide_above, rectangular);
-    std::vector<u32> h(GM_META_WORDS, 0);
-    if (Q > 0) {
-        GmColumns gc{A, Q, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta.p, (int)grid};
-        const i64 nblk = cdiv(Q, G3_TILE);
-        Tmp<Gm3> partial(ctx);
-        GK_TRY(partial.alloc((size_t)nblk));
-        if (nblk > 1) gm_scan_sums_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
-        gm_scan_apply_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
+    return gm_finish(ctx, f, P, A, Q, qa, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ShortestPath pair batch in histogram form (sp.hip): the features of graph g are the counts of its keys (l_u, l_v, d)
+// over the ordered pairs u != v with a finite distance (shortest_path.py:412-499).  No pair items exist: a workgroup
+// walks the graph's n x n distance matrix, maps every key to its dense id (sp_idtab) and counts the ids in an LDS table;
+// the slots in use are the graph's (label, count) entries -- the same arrays gm_pairs_kernel leaves, so the column
+// classes, the operand rows and the rare lists come from the shared second half (gm_finish).  Replaces the pair-item
+// arrays (12 bytes x 4.4 M pairs at BASELINE config 4), a three-pass sort of them and the label-major builder's four
+// passes over them.
+// ---------------------------------------------------------------------------------------------------
+#define SPH_THREADS 1024
+#define SPH_T 8192                  // table slots (label id + count): 64 KiB
+#define SPH_INF 0x3f000000
+#define SPH_LAB 2048                // node labels of a graph staged in LDS up to this many vertices
+
+struct SpSource {
+    const i32* node_ptr; const i32* node_label; const u64* dist_ptr; const i32* dist; const u32* idtab; const i32* pair_base;
+    u64 L, d1; int with_labels;
+};
+
+__global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, const GmLevels P, const GmLabelArrays A, const GmPriv R,
+                                                              i64 n_graphs, i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt,
+                                                              u32* __restrict__ ent_n, u64* __restrict__ selfk, i64 n_fit, int rectangular,
+                                                              u32 df_cap, int prim_max, int wide_above, u32* __restrict__ part,
+                                                              u32* __restrict__ wgmeta, u32* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private df histogram | keys[SPH_T] | counts[SPH_T] | labels[SPH_LAB]
+    __shared__ u32 n_ent_s, ovf_s, red_m[SPH_THREADS / 64], red_e[SPH_THREADS / 64];
+    __shared__ u64 red_x[SPH_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    u32* priv = (u32*)gm_lds;
+    const int priv_words = R.bins / 2;
+    for (int t = tid; t < priv_words; t += SPH_THREADS) priv[t] = 0;
+    i32* keys = gm_lds + priv_words;
+    u32* co = (u32*)(keys + SPH_T);
+    i32* lab_s = (i32*)(co + SPH_T);                     // the graph's node labels (n <= SPH_LAB), else read from HBM
+    const i32 poff = R.off[0];
+    u32 maxc = 0, entries = 0;
+    for (i64 g = blockIdx.x; g < n_graphs; g += gridDim.x) {
+        const i32 v0 = S.node_ptr[g];
+        const int n = S.node_ptr[g + 1] - v0;
+        const i32 base = S.pair_base[g];
+        const u32 np = (u32)(S.pair_base[g + 1] - base);
+        if (np == 0) {                                    // workgroup-uniform
+            if (tid == 0) ent_n[g] = 0, selfk[g] = 0;
+            continue;
+        }
+        u32 T = 64;                                       // a table of at least twice the pairs (distinct keys <= pairs), capped
+        while (T < 2u * np && T < (u32)SPH_T) T <<= 1;
+        const u32 tmask = T - 1u, t_cap = T - (T >> 2);   // three quarters full at most (only binds at T == SPH_T)
+        __syncthreads();                                  // the previous graph's compaction is done with the table
+        for (u32 t = tid; t < T; t += SPH_THREADS) keys[t] = -1, co[t] = 0;
+        const bool lab_in_lds = S.with_labels && n <= SPH_LAB;
+        if (lab_in_lds)
+            for (int i = tid; i < n; i += SPH_THREADS) lab_s[i] = S.node_label[v0 + i];
+        if (tid == 0) n_ent_s = 0, ovf_s = 0;
+        __syncthreads();
+        const i32* dg = S.dist + S.dist_ptr[g];
+        const u32 side_bit = g < n_fit ? 1u : 2u;
+        // four matrix entries per thread and trip: the four distance loads are in flight together, then the four id
+        // look-ups (the kernel is a chain of dependent round trips otherwise: one workgroup per CU, 16 graphs each)
+        for (int idx0 = 0; idx0 < n * n; idx0 += 4 * SPH_THREADS) {
+            i32 x[4], id[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * SPH_THREADS + tid;
+                x[u] = idx < n * n ? dg[idx] : SPH_INF;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * SPH_THREADS + tid;
+                const int i = idx / n, j = idx - i * n;
+                id[u] = -1;
+                if (idx < n * n && i != j && x[u] < SPH_INF) {
+                    u64 key = (u64)x[u];
+                    if (S.with_labels) {
+                        const u32 li = (u32)(lab_in_lds ? lab_s[i] : S.node_label[v0 + i]), lj = (u32)(lab_in_lds ? lab_s[j] : S.node_label[v0 + j]);
+                        key += S.d1 * ((u64)li * S.L + (u64)lj);
+                    }
+                    id[u] = (i32)S.idtab[key];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (id[u] < 0) continue;
+                u32 h = ((u32)id[u] * 2654435761u) >> 8 & tmask;
+                for (;;) {
+                    i32 old = keys[h];
+                    if (old == -1) {
+                        if (*(volatile u32*)&ovf_s) break;
+                        old = atomicCAS(&keys[h], -1, id[u]);
+                        if (old == -1) {
+                            // claims only need counting when the table is at its largest (smaller ones hold every pair)
+                            if (T == (u32)SPH_T && atomicAdd(&n_ent_s, 1u) + 1u > t_cap) ovf_s = 1u;
+                            atomicAdd(&co[h], 1u);
+                            break;
+                        }
+                    }
+                    if (old == id[u]) { atomicAdd(&co[h], 1u); break; }
+                    h = (h + 1u) & tmask;
+                }
+            }
+        }
+        __syncthreads();
+        if (ovf_s) {                                      // more distinct keys than the table holds: the caller falls back
+            if (tid == 0) { atomicOr(overflow, 1u); ent_n[g] = 0; selfk[g] = 0; }
+            continue;
+        }
+        if (tid == 0) n_ent_s = 0;
+        __syncthreads();
+        u64 extra = 0;
+        for (u32 t0 = 0; t0 < T; t0 += SPH_THREADS) {      // T is a multiple of 64: whole waves
+            const u32 t = t0 + tid;
+            const i32 x = t < T ? keys[t] : -1;
+            // entry slots: one LDS atomic per wave (hundreds of lanes adding to ONE counter serialise)
+            const u64 m = __ballot(x >= 0);
+            u32 wbase = 0;
+            if (lane == 0 && m) wbase = atomicAdd(&n_ent_s, (u32)__popcll(m));
+            wbase = __shfl(wbase, 0, 64);
+            if (x < 0) continue;
+            const u32 c = co[t];
+            const u32 e = wbase + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            ent_lab[base + e] = x, ent_cnt[base + e] = c;
+            if (poff >= 0) {                              // df / count class in the workgroup's private histogram (gm_pairs_kernel)
+                const u32 bin = (u32)poff + (u32)x;
+                const int sh = 16 * (bin & 1u);
+                u32 add = 0;
+                if (rectangular) add |= side_bit << GM_PRIV_SIDE_SHIFT;
+                if ((int)c > prim_max) add |= GM_PRIV_BIG1;
+                if ((int)c > wide_above) add |= GM_PRIV_BIG2;
+                const u32 cur = (priv[bin >> 1] >> sh) & 0xffffu;
+                const u32 flags = add & ~cur & 0xf000u;
+                if (flags) atomicOr(&priv[bin >> 1], flags << sh);
+                atomicAdd(&priv[bin >> 1], 1u << sh);
+            } else {
+                const i64 q = P.off[0] + x;
+                if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
+                if (c >= 2u && __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) atomicMax(&A.cmax[q], c);
+                if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
+            }
+            extra += (u64)c * c - c;
+            maxc = c > maxc ? c : maxc;
+            ++entries;
+        }
+        for (int off = 32; off > 0; off >>= 1) extra += __shfl_down(extra, off, 64);
+        if (lane == 0) red_x[w] = extra;
+        __syncthreads();
+        if (tid == 0) {
+            u64 x = 0;
+            for (int k = 0; k < SPH_THREADS / 64; ++k) x += red_x[k];
+            ent_n[g] = n_ent_s;
+            selfk[g] = (u64)np + x;                       // sum of c^2 = sum of c + sum of (c^2 - c)
+        }
     }
-    GK_TRY(gk_readback(ctx, f->meta, h.data(), GM_META_WORDS));     // one host sync: sizes of the operand
-    f->n_cols1 = h[GM_META_PRIM], f->n_cols8 = h[GM_META_INT8], f->n_cols = f->n_cols1 + f->n_cols8;
-    f->n_cols_wide = h[GM_META_F64], f->n_low_cols = h[GM_META_RARE];
-    f->max_count = 0, f->nnz = 0;
-    for (int k = 0; k < 64; ++k) {
-        f->max_count = std::max<i64>(f->max_count, h[GM_META_MAXC + k]);
-        f->nnz += h[GM_META_NNZ + k];
+    for (int off = 32; off > 0; off >>= 1) {
+        entries += __shfl_down(entries, off, 64);
+        const u32 o = __shfl_down(maxc, off, 64);
+        maxc = o > maxc ? o : maxc;
     }
-    const i64 rare_entries = h[GM_META_RARE_ENTRIES];
-    // ---- operand: [secondary int8 | primary], 128-byte K-steps (features.hip has the rationale)
-    const i64 n1p = round_up(f->n_cols1, f->phi_fp4 ? 256 : 128);
-    i64 n8p = round_up(f->n_cols8, 128);
-    if (n1p + n8p == 0) n8p = 128;
-    f->k1_steps = (int)(n1p / (f->phi_fp4 ? 256 : 128)), f->k8_steps = (int)(n8p / 128);
-    f->n_cols_pad = (f->phi_fp4 ? n1p / 2 : n1p) + n8p;
-    f->n_rows_pad = round_up(N, 256) + 256;
-    const i64 row_lds_max = ctx->opt.gm_row_lds_max > 0 ? (i64)ctx->opt.gm_row_lds_max : (i64)GM_ROW_LDS_MAX;     // option: test hook
-    if (f->n_cols_pad > row_lds_max) return GK_ERR_UNSUPPORTED;              // caller falls back to features.hip
-    GK_TRY(gk_dev_alloc(ctx, &q, (size_t)f->n_rows_pad * f->n_cols_pad));
-    f->phi = q;
-    if (f->n_cols_wide > 0) {
-        f->n_cols_wide_pad = round_up(f->n_cols_wide, 16);
-        const size_t wb = (size_t)f->n_rows_pad * f->n_cols_wide_pad * 8;
-        GK_TRY(gk_dev_alloc(ctx, &q, wb));
-        f->phi_w = (double*)q;
-        GK_TRY(gk_zero_async(ctx, f->phi_w, wb));
+    if (lane == 0) red_m[w] = maxc, red_e[w] = entries;
+    __syncthreads();
+    if (tid == 0) {
+        u32 m = 0, e = 0;
+        for (int k = 0; k < SPH_THREADS / 64; ++k) m = red_m[k] > m ? red_m[k] : m, e += red_e[k];
+        wgmeta[2 * blockIdx.x] = m, wgmeta[2 * blockIdx.x + 1] = e;
     }
-    i32* lg = nullptr;
-    i32* lc = nullptr;
-    if (rare_entries > 0) {
-        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
-        lg = (i32*)q, f->arena.push_back(q);
-        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
-        lc = (i32*)q, f->arena.push_back(q);
-    }
-    GK_TRY(gk_func_lds(ctx, (const void*)gm_rows_kernel, (int)f->n_cols_pad));
-    // one workgroup per graph (64- and 128-thread workgroups measured the same 30 us: the chain of dependent loads
-    // slot -> entry -> column id binds, not the number of workgroups in flight)
-    gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
-        P, A, b->graph_ptr, V, ent.p, cnt.p, ent_n.p, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-        f->n_cols_wide_pad, lg, lc);
-    const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
-    gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
-    GK_HIP_CHECK(hipGetLastError());
-    // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries
-    f->gm = true;
-    f->gm_low_q = A.low_q, f->gm_roff = A.roff, f->gm_low_graph = lg, f->gm_low_cnt = lc;
-    // df is read by the pair-update kernel: keep it (moves out of the zeroed temporary)
-    {
+    u32* mine = part + (size_t)blockIdx.x * priv_words;
+    for (int t = tid; t < priv_words; t += SPH_THREADS) mine[t] = priv[t];
+}
+
+int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, int wide_above) {
+    const i64 N = pb->n_graphs, V = pb->n_nodes;              // V = pairs = entry slots
+    const i64 Q = pb->label_counts.empty() ? 0 : pb->label_counts[0];
+    if (V <= 0 || Q <= 0) return GK_ERR_UNSUPPORTED;
+    void* q = nullptr;
+    GmLevels P = {};
+    P.L = 1, P.off[0] = 0, P.off[1] = Q, P.lab[0] = nullptr, P.flag[0] = nullptr, P.id_base[0] = 0, P.level[0] = 0;
+    const size_t qa = (size_t)round_up(Q, 64);
+    Tmp<u32> zeroed(ctx);                     // [df | cmax | cursor | side (bytes)]
+    const size_t zero_words = 3 * qa + qa / 4;
+    GK_TRY(zeroed.alloc(zero_words));
+    GK_TRY(gk_zero_async(ctx, zeroed.p, zero_words * 4));
+    GmLabelArrays A;
+    A.df = zeroed.p, A.cmax = zeroed.p + qa, A.cursor = zeroed.p + 2 * qa;
+    A.side = (unsigned char*)(zeroed.p + 3 * qa);
+    i32** keep[] = {&A.colid, (i32**)&A.roff, &A.low_q};
+    for (i32** a : keep) {
         GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));
-        GK_HIP_CHECK(hipMemcpyAsync(q, A.df, qa * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        f->gm_df = (u32*)q, f->arena.push_back(q);
+        *a = (i32*)q;
+        f->arena.push_back(q);
     }
-    return GK_OK;
+    Tmp<u32> cnt(ctx), ent_n(ctx);
+    Tmp<i32> ent(ctx);
+    GK_TRY(cnt.alloc((size_t)V)); GK_TRY(ent.alloc((size_t)V)); GK_TRY(ent_n.alloc((size_t)N));
+    const int rectangular = f->symmetric ? 0 : 1;
+    const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    i64 grid = N < n_cu ? N : n_cu;                       // one workgroup per CU: the table and the private histogram fill its LDS
+    const i64 priv_budget = (160 * 1024 - 1024 - (i64)SPH_T * 8 - (i64)SPH_LAB * 4) / 2;
+    GmPriv R;
+    R.bins = 0;
+    for (int j = 0; j < FEAT_MAX_LEVELS; ++j) R.off[j] = -1;
+    if (!ctx->opt.gm_no_priv && Q <= priv_budget && cdiv(N, grid) + 1 < (i64)GM_PRIV_COUNT_MASK) R.off[0] = 0, R.bins = (int)Q;
+    R.bins = (R.bins + 1) & ~1;
+    const size_t lds = (size_t)R.bins * 2 + (size_t)SPH_T * 8 + (size_t)SPH_LAB * 4;
+    GK_TRY(gk_func_lds(ctx, (const void*)sp_hist_kernel, (int)lds));
+    Tmp<u32> part(ctx), wgmeta(ctx);
+    GK_TRY(wgmeta.alloc((size_t)grid * 2));
+    GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
+    SpSource S{pb->sp_node_ptr, pb->sp_node_label, pb->sp_dist_ptr, pb->sp_dist, pb->sp_idtab, pb->graph_ptr,
+               (u64)pb->sp_L, (u64)pb->sp_dcap, pb->sp_with_labels};
+    sp_hist_kernel<<<dim3((unsigned)grid), SPH_THREADS, lds, ctx->stream>>>(
+        S, P, A, R, N, ent.p, cnt.p, ent_n.p, f->selfk, f->n_fit, rectangular, (u32)(f->low_df > 2 ? f->low_df : 2), prim_max,
+        wide_above, part.p, wgmeta.p, f->meta + GM_META_OVF);
+    if (R.bins > 0)
+        gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(P, A, R, part.p, (int)grid, prim_max, wide_above, rectangular);
+    // the overflow word travels with the operand sizes: meta[] is read back once, in gm_finish
+    return gm_finish(ctx, f, P, A, Q, qa, pb->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
 }

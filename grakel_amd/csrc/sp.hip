@@ -12,6 +12,7 @@
 //                    of the shared dictionary code leaves (key, graph) runs = Phi triples.
 // Distances are exact int32 sums of positive integer edge weights (unit by default).
 #include "common.h"
+#include "scan_fn.h"
 #include <stdlib.h>
 
 #define SP_INF 0x3f000000
@@ -603,6 +604,34 @@ __global__ __launch_bounds__(SP_THREADS) void sp_emit_kernel(
     }
 }
 
+// histogram form of the pair batch (features_gm.hip: gk_features_build_sp): which keys occur at all ...
+__global__ __launch_bounds__(SP_THREADS) void sp_mark_kernel(
+    const i32* __restrict__ graph_ptr, const i32* __restrict__ node_label, const u64* __restrict__ dist_ptr,
+    const i32* __restrict__ dist, unsigned char* __restrict__ present, u64 n_labels, u64 d1, int with_labels) {
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const i32 v0 = graph_ptr[g];
+    const int n = graph_ptr[g + 1] - v0;
+    const i32* dg = dist + dist_ptr[g];
+    for (int idx = tid; idx < n * n; idx += SP_THREADS) {
+        const int i = idx / n, j = idx - i * n;
+        const i32 x = dg[idx];
+        if (i != j && x < SP_INF) {
+            u64 key = (u64)x;
+            if (with_labels) key += d1 * ((u64)(u32)node_label[v0 + i] * n_labels + (u64)(u32)node_label[v0 + j]);
+            if (!present[key]) present[key] = 1;           // same value from every writer
+        }
+    }
+}
+
+// ... and their dense ids: exclusive prefix of the presence bytes
+struct SpIdScan {
+    const unsigned char* present; u32* idtab; u32* n_keys;
+    __device__ __forceinline__ u32 value(i64 k) const { return present[k] ? 1u : 0u; }
+    __device__ __forceinline__ void emit(i64 k, u32 v, u32 incl) const { idtab[k] = v ? incl - 1u : 0xffffffffu; }
+    __device__ __forceinline__ void finish(u32 total) const { *n_keys = total; }
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
+};
+
 static int bits_for64(u64 v) {
     int b = 0;
     while (b < 64 && (v >> b)) ++b;
@@ -785,6 +814,51 @@ extern "C" int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_
     void* q = nullptr;
     int r;
     const size_t np = h_pairs > 0 ? h_pairs : 1;
+    {
+        // Histogram form (one level, a key space small enough for a direct table): no pair items at all.  The pair batch
+        // keeps the distance matrices; the feature builder counts every graph's (l_u, l_v, d) keys in an LDS table
+        // (features_gm.hip).  Which keys occur, and their dense ids: a presence table over the whole key space.
+        u64 L0 = 1;
+        if (with_labels) {
+            L0 = (u64)(b->n_labels0 > 0 ? b->n_labels0 : 1);
+            if (b->n_levels > 0 && (u64)b->label_counts[0] > L0) L0 = (u64)b->label_counts[0];
+        }
+        const u64 keyspace = d1 * L0 * L0;
+        if (n_levels == 1 && !ctx->opt.sp_no_hist && L0 < (1u << 15) && keyspace <= (1ull << 22) && h_pairs > 0) {
+            Tmp<unsigned char> present(ctx);
+            Tmp<u32> nk(ctx);
+            if ((r = present.alloc((size_t)keyspace)) || (r = nk.alloc(1))) return fail(r);
+            if ((r = gk_zero_async(ctx, present.p, (size_t)keyspace))) return fail(r);
+            sp_mark_kernel<<<dim3((unsigned)N), SP_THREADS, 0, ctx->stream>>>(b->graph_ptr, b->labels, s.dist_ptr.p, s.dist.p, present.p,
+                                                                            L0, d1, with_labels ? 1 : 0);
+            if ((r = gk_dev_alloc(ctx, &q, (size_t)keyspace * 4))) return fail(r);
+            pb->sp_idtab = (u32*)q;
+            SpIdScan sc{present.p, pb->sp_idtab, nk.p};
+            if ((r = gk_scan_fn<u32, SpIdScan>(ctx, sc, (i64)keyspace, nullptr))) return fail(r);
+            if ((r = gk_dev_alloc(ctx, &q, (size_t)(N + 1) * 4))) return fail(r);
+            pb->sp_node_ptr = (i32*)q;
+            if ((r = gk_dev_alloc(ctx, &q, (size_t)(V > 0 ? V : 1) * 4))) return fail(r);
+            pb->sp_node_label = (i32*)q;
+            u32 h_nk = 0;
+            if (hipMemcpyAsync(pb->sp_node_ptr, b->graph_ptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                (V > 0 && hipMemcpyAsync(pb->sp_node_label, b->labels, (size_t)V * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) ||
+                hipMemcpyAsync(&h_nk, nk.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                gk_set_error("gk_sp_build: %s", hipGetErrorString(hipGetLastError()));
+                return fail(GK_ERR_HIP);
+            }
+            pb->sp_dist = s.dist.p, s.dist.p = nullptr;             // the matrices move into the pair batch
+            pb->sp_dist_ptr = s.dist_ptr.p, s.dist_ptr.p = nullptr;
+            pb->sp_hist = true, pb->sp_L = (i64)L0, pb->sp_dcap = (i64)d1, pb->sp_keyspace = (i64)keyspace, pb->sp_src_nodes = V;
+            pb->sp_with_labels = with_labels ? 1 : 0;
+            pb->n_levels = 1, pb->cap_levels = 0;
+            pb->label_counts.assign(1, (i64)h_nk);
+            *out_pair_batch = pb;
+            if (out_n_pairs) *out_n_pairs = h_pairs;
+            if (out_n_keys) out_n_keys[0] = h_nk;
+            return GK_OK;
+        }
+    }
     if ((r = gk_dev_alloc(ctx, &q, np * 4))) return fail(r);
     pb->node_graph = (i32*)q;
     if ((r = gk_dev_alloc(ctx, &q, np * 4 * (size_t)n_levels))) return fail(r);
@@ -826,6 +900,32 @@ extern "C" int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_
     if (out_n_pairs) *out_n_pairs = h_pairs;
     if (out_n_keys)
         for (int l = 0; l < n_levels; ++l) out_n_keys[l] = h_keys[l];
+    return GK_OK;
+}
+
+// Item arrays of a histogram-form pair batch, on demand (the label-major feature builder reads them): the classic
+// emit + sorting dictionary on the stored distance matrices.
+int gk_sp_materialise(gk_ctx* ctx, gk_batch* pb) {
+    if (!pb->sp_hist || pb->labels) return GK_OK;
+    const i64 N = pb->n_graphs;
+    const size_t np = pb->n_nodes > 0 ? (size_t)pb->n_nodes : 1;
+    void* q = nullptr;
+    GK_TRY(gk_dev_alloc(ctx, &q, np * 4));
+    pb->node_graph = (i32*)q;
+    GK_TRY(gk_dev_alloc(ctx, &q, np * 4));
+    pb->labels = (i32*)q;
+    GK_TRY(gk_dev_alloc(ctx, &q, np * 4));
+    pb->perm = (i32*)q;
+    pb->cap_levels = 1;
+    Tmp<u64> keys(ctx);
+    Tmp<u32> nkeys(ctx);
+    GK_TRY(keys.alloc(np)); GK_TRY(nkeys.alloc(1));
+    const u64 L = (u64)pb->sp_L, d1 = (u64)pb->sp_dcap;
+    sp_emit_kernel<<<dim3((unsigned)N), SP_THREADS, 0, ctx->stream>>>(
+        pb->sp_node_ptr, pb->sp_node_label, pb->sp_dist_ptr, pb->sp_dist, (const u32*)pb->graph_ptr, keys.p, pb->node_graph, L, d1,
+        pb->sp_with_labels);
+    GK_TRY(gk_dictionary_from_keys(ctx, keys.p, pb->n_nodes, bits_for64(d1 * L * L - 1), pb->labels, pb->perm, nkeys.p));
+    GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }
 

@@ -1113,7 +1113,8 @@ extern "C" int gk_batch_destroy(gk_batch* b) {
     if (!b) return GK_OK;
     gk_ctx* ctx = b->ctx;
     void* ptrs[] = {b->graph_ptr, b->row_ptr, b->col_idx, b->node_graph, b->big_nodes,
-                    b->labels, b->perm, b->nbr_sorted, b->iso_info, b->car_class, b->car_nodes, b->shared_flag};
+                    b->labels, b->perm, b->nbr_sorted, b->iso_info, b->car_class, b->car_nodes, b->shared_flag,
+                    b->sp_node_ptr, b->sp_node_label, b->sp_dist_ptr, b->sp_dist, b->sp_idtab};
     for (void* p : ptrs)
         if (p) gk_dev_free(ctx, p);
     delete b;

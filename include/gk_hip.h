@@ -77,7 +77,9 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "feat.gm_row_lds_max" (bytes of operand row the graph-major builder accepts: small values force the
  *             fall-back to the label-major builder)
  *   Gram:     "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc"
- *   paths:    "sp.no_pk" (all-pairs distances never in the 16-bit packed register kernel: 32-bit registers up to 64
+ *   paths:    "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
+ *             histograms of the distance matrices),
+ *             "sp.no_pk" (all-pairs distances never in the 16-bit packed register kernel: 32-bit registers up to 64
  *             vertices, the LDS workgroup kernel beyond), "sp.no_reg" (the LDS workgroup kernel for every graph)
  *   plumbing: "no_mailbox" (small read-backs by hipMemcpy instead of the mapped mailbox),
  *             "debug.poison" (the allocator fills every block it hands out with this byte: uninitialised reads

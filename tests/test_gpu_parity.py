@@ -612,6 +612,40 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
         assert np.array_equal(K, gk.ShortestPath().fit_transform(G))
 
 
+@pytest.mark.parametrize("route", [(), ("sp.no_hist",), ("sp.no_pk",), ("sp.no_reg",), ("sp.no_hist", "sp.no_reg"),
+                                   ("feat.gm_row_lds_max",), ("feat.gm_no_priv",)], ids=lambda r: "+".join(r) or "default")
+def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
+    """ShortestPath picks among equivalent routes: all-pairs distances in 16-bit packed registers (one wave per graph up to
+    64 vertices, a four-wave workgroup up to 128), in 32-bit registers, or in the LDS workgroup kernel; pair features as
+    per-graph histograms of the distance matrices or through explicit pair items, the sorting dictionary and the
+    label-major builder (also reached when the histogram builder declines: feat.gm_row_lds_max).  Every route must
+    give the reference's matrix (fit_transform and transform), with unit, integer and dyadic float weights."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from small_sets import sp_dyadic_graphs
+    for name in route:
+        gkopt(name, 64 if name == "feat.gm_row_lds_max" else 1)
+    z = load_golden("nci1_like_sp_300.npz")
+    G = nci1_like(300, 0, as_adj=True)
+    sp = gk.ShortestPath()
+    K = sp.fit_transform(G)
+    assert int(K.sum()) == int(z["K_sum"][0]) and int(K.max()) == int(z["K_max"][0])
+    assert np.array_equal(K[:64, :64], z["K_block"])
+    assert np.array_equal(sp.transform(G[100:140]), K[100:140])
+    spn = gk.ShortestPath(normalize=True)
+    ref = O.SPOracle(normalize=True)
+    assert np.allclose(spn.fit_transform(G[:60]), ref.fit_transform(G[:60]), rtol=REL_TOL, atol=0)
+    assert np.allclose(spn.transform(G[60:75]), ref.transform(G[60:75]), rtol=REL_TOL, atol=0)
+    W = _sp_shard_input(80, True)                              # integer weights 1..3
+    assert np.array_equal(gk.ShortestPath().fit_transform(W), O.SPOracle().fit_transform(W))
+    D = sp_dyadic_graphs()
+    zd = load_golden("sp_dyadic.npz")
+    spd = gk.ShortestPath()
+    assert np.array_equal(spd.fit_transform(D[:16]), zd["K_fit_auto"]) and np.array_equal(spd.transform(D[16:]), zd["K_tr_auto"])
+    big = random_labelled_graphs(5, 140, 210, 0.02, 3, 3, fmt="adj") + G[:20]     # graphs above 128 vertices and above the LDS cap
+    assert np.array_equal(gk.ShortestPath().fit_transform(big), O.SPOracle().fit_transform(big))
+
+
 def test_sp_float_weights_against_reference_goldens(gk):
     """Float edge weights that are integer multiples of a power of two (here 1/8): integer distances in that
     unit on the device, the reference's matrices and float-keyed ``_enum`` (graph.py:1767-1794,
