@@ -44,6 +44,8 @@ SIGNATURES = {
     "gk_batch_create": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int32, c_int, _vpp]),
     "gk_batch_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, _vpp]),
+    "gk_export_state": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, _u64p]),
+    "gk_import_state": (c_int, [c_void_p, c_void_p, c_uint64, _vpp]),
     "gk_batch_destroy": (c_int, [c_void_p]),
     "gk_batch_info": (c_int, [c_void_p, _i64p, _i64p, _i64p]),
     "gk_wl_relabel": (c_int, [c_void_p, c_void_p, c_int, c_int, _i64p, POINTER(c_int)]),
@@ -51,6 +53,7 @@ SIGNATURES = {
     "gk_wl_debug_signature": (c_int, [c_void_p, c_void_p, c_int, c_uint64, c_void_p, c_void_p]),
     "gk_features_build": (c_int, [c_void_p, c_void_p, c_int, c_int64, _vpp]),
     "gk_features_build_ex": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, _vpp]),
+    "gk_features_build_range": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, _vpp]),
     "gk_features_destroy": (c_int, [c_void_p]),
     "gk_features_info": (c_int, [c_void_p, _i64p, _i64p, _i64p, _i64p, POINTER(c_int)]),
     "gk_features_operand": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), _i64p]),

@@ -254,7 +254,7 @@ struct gk_feat {
     int kind = 0;               // GK_FEAT_DOT (0) | GK_FEAT_MINSUM (1), see gk_features_build_ex
     gk_ctx* ctx = nullptr;
     gk_batch* batch = nullptr;
-    int n_levels = 0;
+    int n_levels = 0, level0 = 0;     // levels [level0, level0 + n_levels) of the batch
     i64 n_graphs = 0, n_fit = 0, n_nodes = 0;
     bool symmetric = true;
     std::vector<LevelTriples> lev;   // per-level VIEWS into the arena arrays below

@@ -469,11 +469,18 @@ extern "C" int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t
 
 extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, int kind,
                                     gk_feat** out) {
+    return gk_features_build_range(ctx, b, 0, n_levels, n_fit, kind, out);
+}
+
+extern "C" int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, int level_hi, int64_t n_fit, int kind,
+                                       gk_feat** out) {
     GK_ARG(ctx && b && out, "gk_features_build: null argument");
     GK_ARG(kind == GK_FEAT_DOT || kind == GK_FEAT_MINSUM, "gk_features_build_ex: unknown kind");
-    GK_ARG(n_levels >= 1 && n_levels <= (b->n_levels > 0 ? b->n_levels : 1),
+    GK_ARG(level_lo >= 0 && level_hi > level_lo && level_hi <= (b->n_levels > 0 ? b->n_levels : 1),
            "gk_features_build: levels not computed (call gk_wl_relabel first)");
-    GK_ARG(n_levels <= FEAT_MAX_LEVELS, "gk_features_build: more than 48 levels are not supported");
+    const int n_levels = level_hi - level_lo;        // local level l of this job = level level_lo + l of the batch
+    GK_ARG(n_levels <= FEAT_MAX_LEVELS, "gk_features_build: at most 48 levels per feature job (gk_features_build_range "
+                                        "takes a deep hierarchy in chunks; the matrices of the chunks add up)");
     GK_ARG(n_fit >= 1 && n_fit <= b->n_graphs, "gk_features_build: bad n_fit");
     GK_ARG(b->n_levels > 0, "gk_features_build: batch has no label-grouped order (call gk_wl_relabel with n_iter>=0)");
     GK_HIP_CHECK(hipSetDevice(ctx->device));
@@ -483,6 +490,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     f->ctx = ctx, f->batch = b, f->n_levels = n_levels, f->n_graphs = N, f->n_fit = n_fit, f->n_nodes = V;
     f->symmetric = (n_fit == N);
     f->kind = kind;
+    f->level0 = level_lo;
     f->lev.resize(n_levels);
     auto fail = [&](int r) { gk_features_destroy(f); return r; };
     int r;
@@ -522,7 +530,7 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     // ---- ShortestPath pair batch in histogram form: per-graph histograms of the distance matrices (features_gm.hip);
     // on a decline the pair items are materialised and the label-major builder below takes over
     if (b->is_pair_batch && b->sp_hist) {
-        r = (n_levels == 1 && kind == GK_FEAT_DOT && !ctx->opt.sp_no_hist) ? gk_features_build_sp(ctx, b, f, prim_max, wide_above) : GK_ERR_UNSUPPORTED;
+        r = (n_levels == 1 && level_lo == 0 && kind == GK_FEAT_DOT && !ctx->opt.sp_no_hist) ? gk_features_build_sp(ctx, b, f, prim_max, wide_above) : GK_ERR_UNSUPPORTED;
         if (r == GK_OK) { *out = f; return GK_OK; }
         if (r != GK_ERR_UNSUPPORTED) return fail(r);
         for (void* p : f->arena)
@@ -549,18 +557,19 @@ extern "C" int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int6
     FeatLevels P;
     P.L = 0, P.off[0] = 0, P.synth = -1;
     std::vector<int> slot_of_level(n_levels, -1);
-    const bool hist0 = b->level0_hist && !b->is_pair_batch && V > 0;
+    const bool hist0 = b->level0_hist && !b->is_pair_batch && V > 0 && level_lo == 0;
     const i64 L0 = b->n_labels0;
     for (int l = 0; l < n_levels && V > 0; ++l) {
-        i64 nl = (size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V;
+        const int bl = level_lo + l;                 // the batch's level
+        i64 nl = (size_t)bl < b->n_sorted.size() ? b->n_sorted[bl] : V;
         if (l == 0 && hist0) nl = L0 * N;           // items of the synthesized slot: (label, graph) cells
         if (nl == 0) continue;
         // the relabel skipped this level's label-grouped order (sort-free dictionary, wl.hip): build it now
-        if (!(l == 0 && hist0) && (size_t)l < b->perm_valid.size() && !b->perm_valid[l] && (r = gk_batch_rebuild_order(ctx, b, l)))
+        if (!(l == 0 && hist0) && (size_t)bl < b->perm_valid.size() && !b->perm_valid[bl] && (r = gk_batch_rebuild_order(ctx, b, bl)))
             return fail(r);
         const int j = P.L++;
         slot_of_level[l] = j;
-        P.perm[j] = b->perm + (size_t)l * V, P.lab[j] = b->labels + (size_t)l * V;
+        P.perm[j] = b->perm + (size_t)bl * V, P.lab[j] = b->labels + (size_t)bl * V;
         P.n[j] = nl, P.level[j] = l;
         if (l == 0 && hist0) P.synth = j;
         P.off[j + 1] = P.off[j] + round_up(nl, SF_TILE);

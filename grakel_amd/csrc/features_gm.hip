@@ -580,13 +580,14 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     // ---- level slots
     GmLevels P = {};                                    // unused slots stay null (deterministic)
     P.L = 0, P.off[0] = 0;
-    for (int l = 0; l < n_levels; ++l) {
+    for (int ll = 0; ll < n_levels; ++ll) {
+        const int l = f->level0 + ll;                         // the batch's level (a feature job may cover a range of levels)
         const i64 nl = (l == 0 && b->level0_hist) ? V : ((size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V);
         if (nl == 0) continue;                                // nothing shared: baseline only
         const int j = P.L++;
         const bool act = (size_t)l < b->active_layout.size() && b->active_layout[l];
         const i64 count = l == 0 ? (i64)b->n_labels0 : b->label_counts[l];     // level 0 keeps the input ids
-        P.lab[j] = b->labels + (size_t)l * V, P.level[j] = l;
+        P.lab[j] = b->labels + (size_t)l * V, P.level[j] = ll;
         P.id_base[j] = act ? (i32)(V - nl) : 0;
         P.flag[j] = nullptr;
         P.off[j + 1] = P.off[j] + (count - P.id_base[j]);

@@ -91,6 +91,15 @@ enum { ST_OK = 0, ST_DECLINE = 1, ST_ERROR = 2 };
  * objects hash and compare like the int, so dictionary semantics are unchanged.  ST_DECLINE otherwise. */
 static int int_value(PyObject* o, long long* out) {
     int overflow = 0;
+#if PY_VERSION_HEX < 0x030C0000
+    /* one-digit exact ints (every vertex number below 2^30) without a call: CPython 3.8 .. 3.11 keep the sign in
+     * ob_size and 30-bit digits in ob_digit; later versions take the API path below */
+    if (PyLong_CheckExact(o)) {
+        const Py_ssize_t sz = Py_SIZE(o);
+        if (sz == 1) { *out = (long long)((PyLongObject*)o)->ob_digit[0]; return ST_OK; }
+        if (sz == 0) { *out = 0; return ST_OK; }
+    }
+#endif
     if (PyLong_CheckExact(o)) {
         *out = PyLong_AsLongLongAndOverflow(o, &overflow);
         return overflow ? ST_DECLINE : ST_OK;
@@ -197,13 +206,30 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
                     identity = 0;
                     if (PyErr_Occurred()) PyErr_Clear();
                 }
-                if (PyList_Append(values, lv)) { status = ST_ERROR; break; }
                 if (all_int) {                 /* exact ints that fit int64: the caller gets them as an array */
                     int ovf = 0;
                     long long iv = PyLong_CheckExact(lv) ? PyLong_AsLongLongAndOverflow(lv, &ovf) : 0;
-                    if (!PyLong_CheckExact(lv) || ovf) all_int = 0;
-                    else if (v64_push(&ivals, (int64_t)iv)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                    if (!PyLong_CheckExact(lv) || ovf) {
+                        /* first label that is not an int64: from here on the values travel as a list -- catch up on
+                         * the graphs walked so far (their dictionaries have not changed: we hold the GIL) */
+                        all_int = 0;
+                        for (Py_ssize_t e2 = 0; e2 < e && status == ST_OK; ++e2) {
+                            PyObject* l2 = PySequence_Fast_GET_ITEM(PySequence_Fast_GET_ITEM(X, e2), 1);
+                            Py_ssize_t it2 = 0;
+                            PyObject *k2, *v2;
+                            while (PyDict_Next(l2, &it2, &k2, &v2))
+                                if (PyList_Append(values, v2)) { status = ST_ERROR; break; }
+                        }
+                        Py_ssize_t it2 = 0, seen = 0;
+                        PyObject *k2, *v2;
+                        while (status == ST_OK && seen < i && PyDict_Next(labels, &it2, &k2, &v2)) {
+                            if (PyList_Append(values, v2)) status = ST_ERROR;
+                            ++seen;
+                        }
+                        if (status != ST_OK) break;
+                    } else if (v64_push(&ivals, (int64_t)iv)) { status = ST_ERROR; PyErr_NoMemory(); break; }
                 }
+                if (!all_int && PyList_Append(values, lv)) { status = ST_ERROR; break; }
                 ++i;
             }
             if (status != ST_OK) break;
@@ -224,11 +250,23 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
         }
 
         /* rows in label order */
-        Py_ssize_t it = 0;
+        Py_ssize_t it = 0, itg = 0;
+        int lockstep = 1;              /* the edge dictionary lists its keys in the order of the label dictionary (the usual
+                                        * case: both were filled vertex by vertex): walk both, no hash look-up per vertex */
         PyObject *k, *lv;
         while (PyDict_Next(labels, &it, &k, &lv) && status == ST_OK) {
-            PyObject* d = PyDict_GetItemWithError(g, k);          /* borrowed; absent: no out-edges */
-            if (!d && PyErr_Occurred()) { PyErr_Clear(); status = ST_DECLINE; break; }
+            PyObject* d = NULL;
+            if (lockstep) {
+                PyObject *gk, *gd;
+                Py_ssize_t save = itg;
+                if (PyDict_Next(g, &itg, &gk, &gd) && (gk == k || (PyLong_CheckExact(gk) && PyLong_CheckExact(k) &&
+                                                                    PyObject_RichCompareBool(gk, k, Py_EQ) == 1))) d = gd;
+                else { lockstep = 0; itg = save; }
+            }
+            if (!d) {
+                d = PyDict_GetItemWithError(g, k);          /* borrowed; absent: no out-edges */
+                if (!d && PyErr_Occurred()) { PyErr_Clear(); status = ST_DECLINE; break; }
+            }
             tmp.n = 0;
             if (d) {
                 const int has = all_list ? PyList_GET_SIZE(d) > 0 : PyDict_GET_SIZE(d) > 0;
@@ -236,15 +274,28 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
                 lab_nonempty += has;
                 if (want_mask) flag[rowp.n - 1] |= (unsigned char)(1 | (has ? 2 : 0));     /* rowp.n - 1 == this vertex */
             }
+            int ascending = 1;           /* strictly ascending neighbour lists (the usual case) need no sort */
             if (d && all_list) {
                 const Py_ssize_t m = PyList_GET_SIZE(d);
+                while (tmp.cap < (size_t)m) {            /* room for the whole row once: plain stores below */
+                    size_t nc = tmp.cap ? tmp.cap * 2 : 64;
+                    int32_t* q2 = (int32_t*)realloc(tmp.p, nc * sizeof(int32_t));
+                    if (!q2) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                    tmp.p = q2, tmp.cap = nc;
+                }
+                if (status != ST_OK) break;
+                int32_t prev = -1;
                 for (Py_ssize_t q = 0; q < m; ++q) {
                     Py_ssize_t j;
                     status = neighbour_index(PyList_GET_ITEM(d, q), identity, n, pos, &j);
                     if (status != ST_OK) break;
-                    if (vec_push(&tmp, (int32_t)(V + j))) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                    const int32_t c = (int32_t)(V + j);
+                    ascending &= c > prev;
+                    prev = c;
+                    tmp.p[tmp.n++] = c;
                 }
             } else if (d) {
+                ascending = 0;
                 Py_ssize_t it2 = 0;
                 PyObject *nb, *w;
                 while (PyDict_Next(d, &it2, &nb, &w)) {
@@ -256,11 +307,18 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
                 }
             }
             if (status != ST_OK) break;
-            const size_t m = sort_unique(tmp.p, tmp.n);
-            for (size_t q = 0; q < m; ++q) {
-                if (want_mask) flag[tmp.p[q]] |= 4;
-                if (vec_push(&col, tmp.p[q])) { status = ST_ERROR; PyErr_NoMemory(); break; }
+            const size_t m = ascending ? tmp.n : sort_unique(tmp.p, tmp.n);
+            if (want_mask)
+                for (size_t q = 0; q < m; ++q) flag[tmp.p[q]] |= 4;
+            while (col.n + m > col.cap) {                 /* the row in one copy */
+                size_t nc = col.cap ? col.cap * 2 : 4096;
+                int32_t* q2 = (int32_t*)realloc(col.p, nc * sizeof(int32_t));
+                if (!q2) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                col.p = q2, col.cap = nc;
             }
+            if (status != ST_OK) break;
+            if (m) memcpy(col.p + col.n, tmp.p, m * sizeof(int32_t));
+            col.n += m;
             if (col.n >= 2147483647ULL) { status = ST_DECLINE; break; }
             if (status == ST_OK && vec_push(&rowp, (int32_t)col.n)) { status = ST_ERROR; PyErr_NoMemory(); }
         }

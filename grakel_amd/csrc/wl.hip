@@ -34,6 +34,7 @@
 #include "scan_fn.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <memory>
 
 #define WL_DEG_SMALL 32       // nodes up to this degree: one thread sorts its list in LDS
@@ -1107,6 +1108,55 @@ extern "C" int gk_batch_concat(gk_ctx* ctx, gk_batch* a, gk_batch* b, int32_t n_
     if ((r = batch_finish(ctx, u))) return fail(r);
     *out = u;
     return GK_OK;
+}
+
+// ---- fitted state for consumers without Python (gk_export_state / gk_import_state) ------------------
+// What a fit leaves behind on this path is the packed batch itself (transform relabels the targets jointly with the
+// fitted graphs; every level array is recomputed from it), so the persistent state is the CSR + level-0 label ids:
+//   header: "GKB1", then int64 n_graphs, n_nodes, n_edges, n_labels0;  arrays: graph_ptr, row_ptr, col_idx, node_label (int32)
+// The meaning of the label ids (label value -> id) stays with the caller, as in gk_batch_create.
+#define GK_STATE_MAGIC 0x31424b47u       /* "GKB1" */
+extern "C" int gk_export_state(gk_ctx* ctx, gk_batch* b, void* out_buf, uint64_t buf_bytes, uint64_t* out_needed) {
+    GK_ARG(ctx && b && out_needed, "gk_export_state: null argument");
+    GK_ARG(!b->is_pair_batch, "gk_export_state: needs a graph batch");
+    const uint64_t need = 8 + 4 * 8 + 4ull * (uint64_t)((b->n_graphs + 1) + (b->n_nodes + 1) + b->n_edges + b->n_nodes);
+    *out_needed = need;
+    if (!out_buf) return GK_OK;                     // size query
+    GK_ARG(buf_bytes >= need, "gk_export_state: buffer too small (call with a null buffer for the size)");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    unsigned char* p = (unsigned char*)out_buf;
+    const u32 magic[2] = {GK_STATE_MAGIC, 1u};
+    memcpy(p, magic, 8);
+    const int64_t hdr[4] = {b->n_graphs, b->n_nodes, b->n_edges, b->n_labels0};
+    memcpy(p + 8, hdr, 32);
+    p += 40;
+    const void* src[4] = {b->graph_ptr, b->row_ptr, b->col_idx, b->labels};
+    const i64 cnt[4] = {b->n_graphs + 1, b->n_nodes + 1, b->n_edges, b->n_nodes};
+    for (int k = 0; k < 4; ++k) {
+        if (cnt[k] > 0) GK_HIP_CHECK(hipMemcpyAsync(p, src[k], (size_t)cnt[k] * 4, hipMemcpyDeviceToHost, ctx->stream));
+        p += (size_t)cnt[k] * 4;
+    }
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return GK_OK;
+}
+
+extern "C" int gk_import_state(gk_ctx* ctx, const void* buf, uint64_t bytes, gk_batch** out) {
+    GK_ARG(ctx && buf && out, "gk_import_state: null argument");
+    GK_ARG(bytes >= 40, "gk_import_state: truncated state");
+    const unsigned char* p = (const unsigned char*)buf;
+    u32 magic[2];
+    int64_t hdr[4];
+    memcpy(magic, p, 8);
+    memcpy(hdr, p + 8, 32);
+    GK_ARG(magic[0] == GK_STATE_MAGIC && magic[1] == 1u, "gk_import_state: not a gk_hip state blob (or a newer format)");
+    GK_ARG(hdr[0] > 0 && hdr[1] >= 0 && hdr[2] >= 0 && hdr[1] < (1ll << 31) && hdr[2] < (1ll << 31), "gk_import_state: bad sizes");
+    const uint64_t need = 40 + 4ull * (uint64_t)((hdr[0] + 1) + (hdr[1] + 1) + hdr[2] + hdr[1]);
+    GK_ARG(bytes >= need, "gk_import_state: truncated state");
+    const int32_t* gp = (const int32_t*)(p + 40);
+    const int32_t* rp = gp + (hdr[0] + 1);
+    const int32_t* ci = rp + (hdr[1] + 1);
+    const int32_t* lab = ci + hdr[2];
+    return gk_batch_create(ctx, hdr[0], hdr[1], hdr[2], gp, rp, ci, lab, (int32_t)hdr[3], 0, out);     // validates the CSR
 }
 
 extern "C" int gk_batch_destroy(gk_batch* b) {

@@ -159,6 +159,32 @@ class DeviceFeatures(object):
             pass
 
 
+MAX_LEVELS_PER_JOB = 48          # FEAT_MAX_LEVELS of csrc/features.h
+
+
+class ChunkedFeatures(object):
+    """Features of a hierarchy deeper than one job holds (48 levels): one ``DeviceFeatures`` per chunk of levels.  K is a
+    sum over levels (weisfeiler_lehman.py:269-270), so the chunks' matrices and self-similarity vectors add up;
+    ``Engine.gram`` / ``Engine.selfk`` do that, normalisation happens on the sum."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        p0 = parts[0]
+        self.engine, self.batch, self.n_fit = p0.engine, p0.batch, p0.n_fit
+        self.symmetric, self.n_rows, self.n_out_cols = p0.symmetric, p0.n_rows, p0.n_out_cols
+        self.n_cols = sum(p.n_cols for p in parts)
+        self.n_cols_low = sum(p.n_cols_low for p in parts)
+        self.nnz = sum(p.nnz for p in parts)
+        self.max_count = max(p.max_count for p in parts)
+        self.dtype = max(p.dtype for p in parts)
+        self.operand = "|".join(sorted(set(p.operand for p in parts)))
+        self.handle = None
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+
+
 class Engine(object):
     """A libgk_hip context bound to one GPU."""
 
@@ -266,6 +292,22 @@ class Engine(object):
                                             int(mg), int(mv), int(me), c_void_p(int(gathered_ptr)), int(n_labels), byref(h)))
         return DeviceBatch(self, h, int(sizes[:, 0].sum()), int(sizes[:, 1].sum()), int(sizes[:, 2].sum()))
 
+    def export_state(self, db):
+        """The fitted batch as one self-describing blob (``gk_export_state``): what a consumer of the C ABI persists."""
+        need = ctypes.c_uint64()
+        check(self.lib.gk_export_state(self.handle, db.handle, None, 0, byref(need)))
+        buf = np.empty(need.value, dtype=np.uint8)
+        check(self.lib.gk_export_state(self.handle, db.handle, _ptr(buf), need.value, byref(need)))
+        return buf
+
+    def import_state(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        h = c_void_p()
+        check(self.lib.gk_import_state(self.handle, _ptr(blob), int(blob.size), byref(h)))
+        ng, nv, ne = c_int64(), c_int64(), c_int64()
+        check(self.lib.gk_batch_info(h, byref(ng), byref(nv), byref(ne)))
+        return DeviceBatch(self, h, ng.value, nv.value, ne.value)
+
     # -- WL ---------------------------------------------------------------------------------
     def wl_relabel(self, db, n_iter, hash_bits=0):
         counts = (c_int64 * (n_iter + 1))()
@@ -290,13 +332,25 @@ class Engine(object):
 
     # -- features / Gram -----------------------------------------------------------------------
     def features(self, db, n_levels, n_fit=None, kind=0):
-        """kind 0: dot product of label counts; 1: histogram intersection (min-sum)."""
+        """kind 0: dot product of label counts; 1: histogram intersection (min-sum).  More than 48 levels: a
+        ``ChunkedFeatures`` (one job per 48 levels; ``gram`` / ``selfk`` add the chunks up)."""
         n_fit = db.n_graphs if n_fit is None else int(n_fit)
-        h = c_void_p()
-        check(self.lib.gk_features_build_ex(self.handle, db.handle, int(n_levels), n_fit, int(kind), byref(h)))
-        return DeviceFeatures(self, h, db, n_fit)
+        n_levels = int(n_levels)
+        if n_levels <= MAX_LEVELS_PER_JOB:
+            h = c_void_p()
+            check(self.lib.gk_features_build_ex(self.handle, db.handle, n_levels, n_fit, int(kind), byref(h)))
+            return DeviceFeatures(self, h, db, n_fit)
+        parts = []
+        for lo in range(0, n_levels, MAX_LEVELS_PER_JOB):
+            h = c_void_p()
+            check(self.lib.gk_features_build_range(self.handle, db.handle, lo, min(lo + MAX_LEVELS_PER_JOB, n_levels), n_fit,
+                                                   int(kind), byref(h)))
+            parts.append(DeviceFeatures(self, h, db, n_fit))
+        return ChunkedFeatures(parts)
 
     def selfk(self, feat):
+        if isinstance(feat, ChunkedFeatures):
+            return sum(self.selfk(p) for p in feat.parts)
         out = np.empty(feat.batch.n_graphs, dtype=np.float64)
         check(self.lib.gk_features_selfk(self.handle, feat.handle, _ptr(out)))
         return out
@@ -307,6 +361,22 @@ class Engine(object):
         return out
 
     def gram(self, feat, normalize=0, rows=None, to_host=True):
+        if isinstance(feat, ChunkedFeatures):
+            if not to_host:
+                raise _lib.GkError("a hierarchy of more than 48 levels is summed on the host: to_host=False is not available")
+            lo, hi = (0, feat.n_rows) if rows is None else rows
+            K = None
+            for p in feat.parts:                      # integer-valued float64 matrices: the sum is exact
+                Kp = self.gram(p, 0, rows=rows)
+                K = Kp if K is None else np.add(K, Kp, out=K)
+            if normalize:
+                d = self.selfk(feat)
+                dr = d[lo:hi] if feat.symmetric else d[feat.n_fit + lo:feat.n_fit + hi]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    K = np.divide(K, np.sqrt(np.outer(dr, d[:feat.n_out_cols])), out=K)
+                if normalize == 2:
+                    K = np.nan_to_num(K, copy=False)
+            return K
         lo, hi = (0, feat.n_rows) if rows is None else rows
         out = self.pinned.empty((hi - lo, feat.n_out_cols)) if to_host else None
         check(self.lib.gk_gram_rows(self.handle, feat.handle, lo, hi, int(normalize), _ptr(out)))

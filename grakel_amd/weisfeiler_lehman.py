@@ -6,7 +6,7 @@ from sklearn.utils.validation import check_is_fitted
 from .batch import GraphBatch, sp_batch_from_input, wl_batch_from_input
 from .kernel import Kernel, NORM_NONE, NORM_NAN_TO_NUM
 from .shortest_path import ShortestPath
-from .vertex_histogram import VertexHistogram, FittedFeatures, count_matrix, first_seen_columns
+from .vertex_histogram import EdgeHistogram, VertexHistogram, FittedFeatures, count_matrix, first_seen_columns
 
 
 MAX_LEVELS = 48        # FEAT_MAX_LEVELS of csrc/features.hip
@@ -16,7 +16,8 @@ def _accelerated(base):
     """The reference's own ``grakel.VertexHistogram`` / ``grakel.ShortestPath`` classes (callers that only
     swapped the WeisfeilerLehman import) map to the accelerated classes of the same name."""
     if type(base) is type and getattr(base, "__module__", "").split(".")[0] == "grakel":
-        return {"VertexHistogram": VertexHistogram, "ShortestPath": ShortestPath}.get(base.__name__, base)
+        return {"VertexHistogram": VertexHistogram, "ShortestPath": ShortestPath,
+                "EdgeHistogram": EdgeHistogram}.get(base.__name__, base)
     return base
 
 
@@ -178,10 +179,12 @@ class WeisfeilerLehman(Kernel):
                 probe = ShortestPath(**{k: v for k, v in params.items() if k != "normalize"})
                 probe.initialize()                       # validates algorithm_type like the reference
                 self._sp_with_labels = bool(probe.with_labels)
+            elif base is EdgeHistogram:
+                EdgeHistogram(**{k: v for k, v in params.items() if k != "normalize"}).initialize()
             elif base is not VertexHistogram:
                 raise NotImplementedError(
-                    'grakel_amd accelerates WeisfeilerLehman with the VertexHistogram and '
-                    'ShortestPath base kernels; other base kernels are outside the MI355X hot path')
+                    'grakel_amd accelerates WeisfeilerLehman with the VertexHistogram, ShortestPath and '
+                    'EdgeHistogram base kernels; other base kernels are outside the MI355X hot path')
             params["normalize"] = False
             params["verbose"] = self.verbose
             params["n_jobs"] = None
@@ -191,11 +194,22 @@ class WeisfeilerLehman(Kernel):
         if not self._initialized["n_iter"]:
             if type(self.n_iter) is not int or self.n_iter <= 0:
                 raise TypeError("'n_iter' must be a positive integer")
-            if self.n_iter + 1 > MAX_LEVELS:
-                raise NotImplementedError("grakel_amd builds the features of at most %d WL levels in one job "
-                                          "(n_iter <= %d)" % (MAX_LEVELS, MAX_LEVELS - 1))
             self._n_iter = self.n_iter + 1
             self._initialized["n_iter"] = True
+
+    # ---- base kernel EdgeHistogram: the edge labels x[2] reach the base kernel untouched at every level
+    # (weisfeiler_lehman.py:186-190: extras = x[2:], :235-258 relabels the NODES only), so every level's matrix is the
+    # EdgeHistogram matrix and their sum is (n_iter + 1) times it.  The WL ingestion still runs (it validates the node
+    # labels exactly like the reference does before the base kernels see anything).
+    def _eh_inner(self):
+        return EdgeHistogram(**dict(self._params))
+
+    def _eh_scale(self, K, dr, dc):
+        K = K * float(self._n_iter)
+        if self.normalize:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                K = np.nan_to_num(np.divide(K, np.sqrt(np.outer(dr, dc))))
+        return K
 
     def _ingest(self, X, fitted):
         not_iter = TypeError if fitted is None else ValueError      # :143-144 vs :358-359
@@ -273,8 +287,11 @@ class WeisfeilerLehman(Kernel):
         self.initialize()
         if X is None:
             raise ValueError('`fit` input cannot be None')
+        X = list(X) if self._base_graph_kernel is EdgeHistogram and not isinstance(X, (list, tuple)) else X
         self._fit_host(X)
         self._after_fit()
+        if self._base_graph_kernel is EdgeHistogram:
+            self._eh = self._eh_inner().fit(X)
         return self
 
     def fit_transform(self, X, y=None):
@@ -284,8 +301,14 @@ class WeisfeilerLehman(Kernel):
         self.initialize()
         if X is None:
             raise ValueError('transform input cannot be None')
+        X = list(X) if self._base_graph_kernel is EdgeHistogram and not isinstance(X, (list, tuple)) else X
         self._fit_host(X)
         self._after_fit()
+        if self._base_graph_kernel is EdgeHistogram:
+            self._eh = self._eh_inner()
+            K = self._eh.fit_transform(X)
+            self._X_diag = self._eh.diagonal() * float(self._n_iter)
+            return self._eh_scale(K, self._X_diag, self._X_diag)
         eng, feat = self._gram_fit()
         for i, c in enumerate(self._last_info["label_counts"]):
             self.X[i].X.shape = (self._nx, c)
@@ -299,9 +322,27 @@ class WeisfeilerLehman(Kernel):
         check_is_fitted(self, ['X', '_nx'])
         if X is None:
             raise ValueError('transform input cannot be None')
+        if self._base_graph_kernel is EdgeHistogram:
+            X = list(X) if not isinstance(X, (list, tuple)) else X
+            ybatch, _ = self._ingest(X, self._label_map if self._label_map is not None else {})     # WL's own input checks
+            self._ny = ybatch.n_graphs
+            K = self._eh.transform(X)
+            xd, yd = self._eh.diagonal()
+            self._X_diag, self._Y_diag = xd * float(self._n_iter), yd * float(self._n_iter)
+            self._is_transformed = True
+            return self._eh_scale(K, self._Y_diag, self._X_diag)
         eng, feat = self._gram_transform(X)
         self._is_transformed = True
         return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
+
+    def diagonal(self):
+        """weisfeiler_lehman.py:502-555."""
+        if getattr(self, "_base_graph_kernel", None) is EdgeHistogram:
+            check_is_fitted(self, ['X'])
+            if not hasattr(self, "_X_diag"):
+                self._X_diag = self._eh.diagonal() * float(self._n_iter)
+            return (self._X_diag, self._Y_diag) if getattr(self, "_is_transformed", False) else self._X_diag
+        return super(WeisfeilerLehman, self).diagonal()
 
     def _all_inv_labels(self):
         """Reference-identical ``_inv_labels`` for every level.

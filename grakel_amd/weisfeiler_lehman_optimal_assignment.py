@@ -36,8 +36,6 @@ class WeisfeilerLehmanOptimalAssignment(Kernel):
         if not self._initialized["n_iter"]:
             if type(self.n_iter) is not int or self.n_iter <= 0:
                 raise TypeError("'n_iter' must be a positive integer")
-            if self.n_iter + 1 > 48:       # FEAT_MAX_LEVELS of csrc/features.hip
-                raise NotImplementedError("grakel_amd builds the features of at most 48 WL levels in one job (n_iter <= 47)")
             self._n_iter = self.n_iter + 1
             self._initialized["n_iter"] = True
         if not self._initialized["sparse"]:

@@ -116,6 +116,13 @@ int gk_batch_from_shards(gk_ctx* ctx, int n_ranks, const int64_t* shard_sizes, i
  * weisfeiler_lehman.py:330-500, vertex_histogram.py:57-154 with the fitted label columns).  `a` usually is the
  * fitted batch kept in HBM between calls, so only the targets cross PCIe.  Both inputs stay valid. */
 int gk_batch_concat(gk_ctx* ctx, gk_batch* a, gk_batch* b, int32_t n_labels0, gk_batch** out);
+/* Fitted state for consumers without Python (the reference pickles its estimator, grakel/tests/test_common.py:53-58): on
+ * this path a fit is the packed batch itself -- transform relabels the targets jointly with the fitted graphs, every level
+ * array is recomputed -- so the state is the CSR + the level-0 label ids as one self-describing blob.
+ * gk_export_state: out_buf == NULL only reports the size in *out_needed.  gk_import_state validates like gk_batch_create.
+ * The label value -> id map stays with the caller (as for gk_batch_create). */
+int gk_export_state(gk_ctx* ctx, gk_batch* b, void* out_buf, uint64_t buf_bytes, uint64_t* out_needed);
+int gk_import_state(gk_ctx* ctx, const void* buf, uint64_t bytes, gk_batch** out);
 int gk_batch_destroy(gk_batch* b);
 int gk_batch_info(gk_batch* b, int64_t* n_graphs, int64_t* n_nodes, int64_t* n_edges);
 
@@ -170,6 +177,10 @@ int gk_features_build(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, gk_
 #define GK_FEAT_DOT 0
 #define GK_FEAT_MINSUM 1
 int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, int kind, gk_feat** out);
+/* The same over the levels [level_lo, level_hi) of the batch, at most 48 per job: a hierarchy deeper than that
+ * (the reference takes any n_iter, weisfeiler_lehman.py:112-114) is built in chunks whose matrices -- and selfk vectors --
+ * add up (K is a sum over levels, weisfeiler_lehman.py:269-270); normalisation then happens on the sum. */
+int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, int level_hi, int64_t n_fit, int kind, gk_feat** out);
 int gk_features_destroy(gk_feat* f);
 /* n_cols_kept: width of the dense MFMA operand Phi_s; n_cols_low: useful but rare columns
  * (fewer than GK_LOW_DF=24 graphs) that are applied as exact pair updates after the GEMM instead;

@@ -310,13 +310,43 @@ def nci1_sp(N):
                                                                   len(sp._enum)))
 
 
+def round3():
+    """Round-3 fixtures: WeisfeilerLehman over the EdgeHistogram base kernel, and more than 48 WL levels (the level
+    chunking of grakel_amd), both on MUTAG."""
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "grakel", "tests", "data"))
+    try:
+        G = read_data('MUTAG', with_classes=True).data
+    finally:
+        os.chdir(cwd)
+    out = {}
+    wl = WeisfeilerLehman(n_iter=3, base_graph_kernel=EdgeHistogram)
+    out["wleh_fit"] = as_int(wl.fit_transform(G[:100]))
+    out["wleh_tr"] = as_int(wl.transform(G[100:130]))
+    wln = WeisfeilerLehman(n_iter=2, base_graph_kernel=(EdgeHistogram, {}), normalize=True)
+    out["wleh_fit_norm"] = wln.fit_transform(G[:100])
+    out["wleh_tr_norm"] = wln.transform(G[100:130])
+    deep = WeisfeilerLehman(n_iter=55)
+    out["deep_fit"] = as_int(deep.fit_transform(G[:40]))
+    out["deep_tr"] = as_int(deep.transform(G[40:52]))
+    deepn = WeisfeilerLehman(n_iter=50, normalize=True)
+    out["deep_fit_norm"] = deepn.fit_transform(G[:40])
+    out["deep_tr_norm"] = deepn.transform(G[40:52])
+    np.savez_compressed(os.path.join(HERE, "round3.npz"), **out)
+    print("round3.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip config 3 (~100 s) and NCI1-4110")
     ap.add_argument("--only-state", action="store_true", help="only the fitted-state fixture (mutag_state.npz)")
     ap.add_argument("--only-dyadic", action="store_true", help="only the float-weight ShortestPath fixture (sp_dyadic.npz)")
+    ap.add_argument("--only-round3", action="store_true", help="only round3.npz (WL over EdgeHistogram, more than 48 levels)")
     a = ap.parse_args()
     print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
+    if a.only_round3:
+        round3()
+        sys.exit(0)
     sp_dyadic()
     if a.only_dyadic:
         sys.exit(0)
@@ -332,3 +362,5 @@ if __name__ == "__main__":
     if not a.skip_big:
         nci1_sp(4110)
         er_config("config3", 10000, 100, 0.05, 5, 0, 5, 20000, with_oa=False)
+    round3()
+

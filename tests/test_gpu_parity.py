@@ -1358,6 +1358,61 @@ def test_operand_type_switches_at_the_exactness_bounds(gk, big_n, want):
     assert np.array_equal(vh.transform(X[:3]), K[:3])
 
 
+def test_wl_over_edge_histogram_and_deep_hierarchies_against_reference_goldens(gk, mutag_graphs):
+    """tests/golden/round3.npz (the real reference on MUTAG): WeisfeilerLehman over the EdgeHistogram base kernel -- the
+    edge labels reach every level's base kernel untouched, so the matrix is (n_iter + 1) x EdgeHistogram's -- and
+    hierarchies of more than 48 levels, which grakel_amd builds in chunks of 48 (gk_features_build_range) and sums."""
+    G, _ = mutag_graphs
+    z = load_golden("round3.npz")
+    wl = gk.WeisfeilerLehman(n_iter=3, base_graph_kernel=gk.EdgeHistogram)
+    assert np.array_equal(wl.fit_transform(G[:100]), z["wleh_fit"])
+    assert np.array_equal(wl.transform(G[100:130]), z["wleh_tr"])
+    assert np.array_equal(wl.diagonal()[0], np.diagonal(z["wleh_fit"]))
+    wln = gk.WeisfeilerLehman(n_iter=2, base_graph_kernel=(gk.EdgeHistogram, {}), normalize=True)
+    assert np.allclose(wln.fit_transform(G[:100]), z["wleh_fit_norm"], rtol=REL_TOL, atol=0)
+    assert np.allclose(wln.transform(G[100:130]), z["wleh_tr_norm"], rtol=REL_TOL, atol=0)
+    deep = gk.WeisfeilerLehman(n_iter=55)
+    assert np.array_equal(deep.fit_transform(G[:40]), z["deep_fit"])
+    assert np.array_equal(deep.transform(G[40:52]), z["deep_tr"])
+    assert np.array_equal(deep.diagonal()[0], np.diagonal(z["deep_fit"]))
+    deepn = gk.WeisfeilerLehman(n_iter=50, normalize=True)
+    assert np.allclose(deepn.fit_transform(G[:40]), z["deep_fit_norm"], rtol=REL_TOL, atol=0)
+    assert np.allclose(deepn.transform(G[40:52]), z["deep_tr_norm"], rtol=REL_TOL, atol=0)
+    X = er_dataset(60, 20, 0.15, 3, 8)                       # the oracle on another set; WL-OA takes the same chunks
+    assert np.array_equal(gk.WeisfeilerLehman(n_iter=60).fit_transform(X), O.WLOracle(n_iter=60).fit_transform(X))
+    assert np.array_equal(gk.WeisfeilerLehmanOptimalAssignment(n_iter=49).fit_transform(X), O.WLOAOracle(n_iter=49).fit_transform(X))
+
+
+def test_export_and_import_of_the_fitted_state_through_the_c_abi(gk):
+    """gk_export_state / gk_import_state: the fitted batch as a blob; a context that imports it computes the same matrix,
+    a damaged blob is an argument error (not a fault)."""
+    from grakel_amd._lib import GkError
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    X = er_dataset(120, 25, 0.1, 3, 4)
+    K = O.WLOracle(n_iter=3).fit_transform(X)
+    eng = get_engine()
+    gb, _ = wl_batch_from_input(X)
+    db = eng.upload(gb)
+    blob = eng.export_state(db)
+    db.close()
+    db2 = eng.import_state(blob)
+    assert (db2.n_graphs, db2.n_nodes, db2.n_edges) == (gb.n_graphs, gb.n_nodes, gb.n_edges)
+    eng.wl_relabel(db2, 3)
+    assert np.array_equal(eng.gram(eng.features(db2, 4)), K)
+    bad = blob.copy()
+    bad[0] ^= 0xff
+    with pytest.raises(GkError, match="not a gk_hip state blob"):
+        eng.import_state(bad)
+    with pytest.raises(GkError, match="truncated"):
+        eng.import_state(blob[:blob.size // 2])
+    worse = blob.copy()
+    worse[40 + 4 * 5] = 0xff                                  # graph_ptr[5] far out of range
+    worse[40 + 4 * 5 + 3] = 0x7f
+    with pytest.raises(GkError, match="malformed batch"):
+        eng.import_state(worse)
+
+
 def test_malformed_batches_are_rejected_at_the_c_abi(gk):
     """gk_batch_create validates the CSR on the device: a malformed batch is GK_ERR_ARG, not an out-of-bounds gather."""
     from grakel_amd import GraphBatch

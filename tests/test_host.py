@@ -395,9 +395,12 @@ def test_estimator_parameters_and_lazy_initialisation():
     wsp = WeisfeilerLehman(base_graph_kernel=(ShortestPath, {"with_labels": False}))
     wsp.initialize()                                   # SP is an accelerated base kernel
     assert wsp._base_graph_kernel is ShortestPath and wsp._sp_with_labels is False
-    with pytest.raises(NotImplementedError):
-        from grakel_amd import EdgeHistogram
-        WeisfeilerLehman(base_graph_kernel=EdgeHistogram).initialize()
+    from grakel_amd import EdgeHistogram, WeisfeilerLehmanOptimalAssignment
+    weh = WeisfeilerLehman(base_graph_kernel=EdgeHistogram)
+    weh.initialize()                                   # round 3: EdgeHistogram is an accelerated base kernel too
+    assert weh._base_graph_kernel is EdgeHistogram
+    with pytest.raises(NotImplementedError):           # any other Kernel subclass is outside the hot path
+        WeisfeilerLehman(base_graph_kernel=WeisfeilerLehmanOptimalAssignment).initialize()
     with pytest.raises(ValueError):
         WeisfeilerLehman(base_graph_kernel=(ShortestPath, {"algorithm_type": "bfs"})).initialize()
     with pytest.raises(ValueError):
@@ -542,14 +545,13 @@ def test_induced_subbatch_and_core_framework_parameters():
 
 
 def test_limits_fail_early_and_reference_base_classes_are_accepted():
-    """n_iter beyond what one feature job holds fails in initialize(), not deep inside fit_transform; a malformed
-    packed batch fails in GraphBatch; the reference's own base-kernel classes map to the accelerated ones."""
+    """n_iter is not capped; a malformed packed batch fails in GraphBatch; the reference's own base-kernel classes map to the accelerated ones."""
     from grakel_amd import GraphBatch
     from grakel_amd.weisfeiler_lehman_optimal_assignment import WeisfeilerLehmanOptimalAssignment
-    with pytest.raises(NotImplementedError):
-        WeisfeilerLehman(n_iter=48).initialize()
-    with pytest.raises(NotImplementedError):
-        WeisfeilerLehmanOptimalAssignment(n_iter=60).initialize()
+    # any positive n_iter, like the reference (weisfeiler_lehman.py:112-114): beyond 48 levels the features are built
+    # in chunks (gk_features_build_range) and the chunks' matrices add up
+    WeisfeilerLehman(n_iter=48).initialize()
+    WeisfeilerLehmanOptimalAssignment(n_iter=60).initialize()
     WeisfeilerLehman(n_iter=47).initialize()
     gp, rp, ci, lab = np.array([0, 2, 3]), np.array([0, 1, 2, 2]), np.array([1, 0]), np.array([0, 1, 0])
     assert GraphBatch(gp, rp, ci, lab, 2).n_graphs == 2

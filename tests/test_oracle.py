@@ -204,3 +204,18 @@ def test_error_behaviour_matches_reference():
             O.WLOracle().fit_transform([[]])
     with pytest.raises(ValueError):
         O.SPOracle(algorithm_type="bfs").fit_transform([H2O])
+
+
+def test_oracle_matches_round3_goldens(mutag_graphs):
+    """round3.npz (real reference): hierarchies deeper than 48 levels, and WeisfeilerLehman over the EdgeHistogram base
+    kernel = (n_iter + 1) x the EdgeHistogram matrix (the edge labels reach every level unchanged)."""
+    G, _ = mutag_graphs
+    z = load_golden("round3.npz")
+    deep = O.WLOracle(n_iter=55)
+    assert np.array_equal(deep.fit_transform(G[:40]), z["deep_fit"])
+    assert np.array_equal(deep.transform(G[40:52]), z["deep_tr"])
+    deepn = O.WLOracle(n_iter=50, normalize=True)
+    assert np.allclose(deepn.fit_transform(G[:40]), z["deep_fit_norm"], rtol=1e-12, atol=0)
+    eh = O.EHOracle()
+    assert np.array_equal(4 * eh.fit_transform(G[:100]), z["wleh_fit"])
+    assert np.array_equal(4 * eh.transform(G[100:130]), z["wleh_tr"])
