@@ -44,7 +44,7 @@ I8_DENSE_PEAK_TOPS = 5000.0
 # (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, summarised by
 # tools/pmc_summary.py): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read,
 # MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.  NOT measured in this run.
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_bytes.csv")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_bytes.csv")
 GRAM_KERNELS = ("gram_ws_kernel", "gram_tile_kernel")
 
 
@@ -450,7 +450,7 @@ def main():
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r02_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE, KiB) -- a committed PMC "
+                "traffic_source": "profiles/r03_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE, KiB) -- a committed PMC "
                                   "pass of this script, NOT measured in this run" if traffic else None,
                 "algorithmic_bytes_per_launch": gram_bytes, "avg_launch_ms": gram_avg_ms,
                 "mfma_view": {

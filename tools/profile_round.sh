@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r02        -> gpurun_out/r02/{kernel_stats.csv, step_timeline.txt, pmc_*.csv, bench_n1.json}
 # Kernel trace and every counter group are separate rocprofv3 runs (--pmc is never combined with other traces).
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
@@ -44,6 +44,7 @@ rm -rf "$out"/sp_pmc_FETCH_SIZE "$out"/sp_pmc_WRITE_SIZE "$out"/wloa_pmc_FETCH_S
 cp "$(ls $out/sp_trace/*/*kernel_stats.csv | head -1)" "$out/sp_config4_kernel_stats.csv" 2>/dev/null
 cp "$(ls $out/wloa_trace/*/*kernel_stats.csv | head -1)" "$out/wloa_kernel_stats.csv" 2>/dev/null
 rm -rf "$out/sp_trace" "$out/wloa_trace"
-python bench.py --workload config5 --steps 3 --warmup 1 --no-cpu-baseline > "$out/config5_50k.json" 2> "$out/config5.log"
+bash tools/profile_config5.sh "$tag" > "$out/config5_profile.log" 2>&1
 python tools/bench_sharded_1rank.py > "$out/sharded_1rank.txt" 2>&1
 tail -c 300 "$out/config5_50k.json"; tail -3 "$out/sharded_1rank.txt"
+python tools/kstats.py "$out/kernel_stats.csv" 30 > "$out/kernel_stats_top.txt" 2>&1
