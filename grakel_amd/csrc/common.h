@@ -69,8 +69,11 @@ struct gk_opts {
     int sort_buckets = 0;        // 0 decide per level, 1 never, 2 always the bucket finish of the sort
     int bd_slots = 0;            // > 0: capacity (distinct keys per bucket) of the sort-free dictionary, to force its overflow
     // features
+    int gm_rows_wg = 0;          // operand rows always by the workgroup-per-graph kernel (small rows: a wave per graph otherwise)
     int feat_no_gm = 0, gm_no_priv = 0, low_df = 0 /* 0 = 24 */, gm_row_lds_max = 0 /* 0 = GM_ROW_LDS_MAX */;
     // Gram
+    int gram_dd = 0;             // Gram kernel form with two accumulator sets and direct stores (no parked tile, five-stage ring):
+                                 // 0 chosen per job (small fp4 jobs), 1 always, 2 never
     int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
     // ShortestPath
     int sp_no_hist = 0;          // pair features through explicit pair items + the sorting dictionary instead of per-graph histograms

@@ -493,6 +493,60 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
     for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) dst[i] = ((const uint4*)row)[i];
 }
 
+// The same with one WAVE per graph (four graphs per workgroup) for operand rows of up to GM_ROW_WAVE_MAX bytes: 50 000
+// graphs of 30 nodes are 50 000 workgroups of 256 threads for 180 entry slots each in the form above (112 us, bound by
+// workgroup dispatch); wave-level barriers only.
+#define GM_ROW_WAVE_MAX 8192
+__global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, const GmLabelArrays A,
+                                                           const i32* __restrict__ graph_ptr, i64 V, const i32* __restrict__ ent_lab,
+                                                           const u32* __restrict__ cnt, const u32* __restrict__ ent_n, i64 n_graphs,
+                                                           int8_t* __restrict__ phi, i64 ld, i64 prim0, int fp4, int kind,
+                                                           double* __restrict__ phi_w, i64 ldw, i32* __restrict__ low_graph,
+                                                           i32* __restrict__ low_cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char row_all[];
+    __shared__ u32 slots_all[4][FEAT_MAX_LEVELS];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const i64 g = (i64)blockIdx.x * 4 + w;
+    if (g >= n_graphs) return;                                    // wave-uniform: no workgroup barrier below
+    unsigned char* row = row_all + (size_t)w * ld;
+    u32* slots = slots_all[w];
+    const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
+    if (lane < P.L) slots[lane] = ent_n[(i64)lane * n_graphs + g];
+    for (i64 i = lane; i < ld / 16; i += 64) ((uint4*)row)[i] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int n = v1 - v0;
+    for (int t = lane; t < n * P.L; t += 64) {
+        const int j = t / n, i = t - j * n;
+        if ((u32)i >= slots[j]) continue;
+        const u32 c = cnt[(i64)j * V + v0 + i];
+        if (!c) continue;
+        const i64 q = P.off[j] + (ent_lab[(i64)j * V + v0 + i] - P.id_base[j]);
+        const i32 col = A.colid[q];
+        if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;
+        else if (col >= 0) {
+            if (kind) {
+                for (u32 x = 0; x < c; ++x) {
+                    const i64 cc = col + x;
+                    if (fp4) atomicOr((u32*)(row + prim0 + ((cc >> 1) & ~3ll)), 2u << (8 * ((cc >> 1) & 3) + 4 * (cc & 1)));
+                    else row[prim0 + cc] = 1;
+                }
+            } else if (fp4) {
+                const u32 code = (0x65420u >> (4 * c)) & 15u;
+                atomicOr((u32*)(row + prim0 + ((col >> 1) & ~3)), code << (8 * ((col >> 1) & 3) + 4 * (col & 1)));
+            } else row[prim0 + col] = (unsigned char)c;
+        } else if (col <= -4) phi_w[g * ldw + (-4 - col)] = (double)c;
+        else if (col == -2) {
+            const u32 pos = A.roff[q] + atomicAdd(&A.cursor[q], 1u);
+            low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint4* dst = (uint4*)(phi + g * ld);
+    for (i64 i = lane; i < ld / 16; i += 64) dst[i] = ((const uint4*)row)[i];
+}
+
 // rows [n_graphs, n_rows_pad) of the operand: zero
 __global__ void gm_pad_rows_kernel(int8_t* __restrict__ phi, i64 bytes) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -554,9 +608,14 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     GK_TRY(gk_func_lds(ctx, (const void*)gm_rows_kernel, (int)f->n_cols_pad));
     // one workgroup per graph (64- and 128-thread workgroups measured the same 30 us: the chain of dependent loads
     // slot -> entry -> column id binds, not the number of workgroups in flight)
-    gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
-        P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-        f->n_cols_wide_pad, lg, lc);
+    if (f->n_cols_pad <= GM_ROW_WAVE_MAX && !ctx->opt.gm_rows_wg)       // small rows: a wave per graph, four graphs per workgroup
+        gm_rows_wave_kernel<<<dim3((unsigned)cdiv(N, 4)), 256, (size_t)f->n_cols_pad * 4, ctx->stream>>>(
+            P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
+            f->n_cols_wide_pad, lg, lc);
+    else
+        gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
+            P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
+            f->n_cols_wide_pad, lg, lc);
     const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
     gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
     GK_HIP_CHECK(hipGetLastError());

@@ -694,6 +694,265 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
 #undef WS_ZERO_ACC
 }
 
+// ---------------------------------------------------------------------------------------
+// Third form (option gram.dd): NO parked tile and no store waves.  Four multiplying waves keep TWO accumulator sets: the
+// tile being multiplied and the finished previous tile, whose entries they convert and store a few registers at a time
+// between the K-steps of the current one (one (row group, 32x32 block) per K-step: four 256-byte row stores + two
+// 16-byte pieces of the mirrored tile per lane).  The 64 KiB of LDS the parked tile took go to the operand ring: five
+// stages, four of them in flight (128 KiB instead of 64), filled by four load waves.  Eight waves per workgroup.
+// What it trades: the stores leave from the multiplying waves' own instruction streams (an HBM back-pressure stall there
+// stalls their MFMA issue too), and the mirrored half goes out as 64-byte runs instead of 1-KiB rows.
+// ---------------------------------------------------------------------------------------
+#define DD_THREADS 512
+#define DD_RING 5
+#define DD_LDS_BYTES (DD_RING * GT_STAGE)
+
+template <bool FP4>
+__global__ __launch_bounds__(DD_THREADS) void gram_dd_kernel(
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
+    const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
+    int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int n_ids, i64 ldk, i64 col_base,
+    int even_in) {
+    constexpr int BM = GT_BM, BN = GT_BM, TM = 2, TN = 2, PPW = 8;
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_compute = wave < 4;
+    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
+    const int stride = gridDim.x;
+    WsTile cur = ws_next_tile((int)blockIdx.x - stride, stride, n_ids, tiles_m, tiles_n, tri, patch);
+    if (!is_compute) {
+        // ---- load role: stage g (global K-step counter) goes to ring slot g % 5; at most four stages in flight
+        i64 roff[PPW];
+        {
+            const int srow = lane >> 3, pch = lane & 7;
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) {
+                const int r = q * 8 + srow;
+                roff[q] = (i64)r * ld + ((pch ^ ((r >> 1) & 7)) << 4);
+            }
+        }
+        WsTile ldt = cur;
+        int kt_ld = 0, buf_ld = 0, ahead = 0;
+        const int8_t* src_base = nullptr;
+        auto set_base = [&]() __attribute__((always_inline)) {
+            src_base = cw < 2 ? A + ((i64)ldt.bm * BM + cw * 64) * ld : B + ((i64)ldt.bn * BN + (cw - 2) * 64) * ld;
+        };
+        auto issue = [&]() __attribute__((always_inline)) {
+            if (!ldt.ok) return;
+            const int8_t* gp = src_base + (i64)kt_ld * GT_BK;
+            int8_t* st = smem + buf_ld * GT_STAGE + cw * (64 * GT_BK);
+#pragma unroll
+            for (int q = 0; q < PPW; ++q)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gp + roff[q]), (lds_void_t*)(st + q * 1024), 16, 0, 0);
+            buf_ld = buf_ld == DD_RING - 1 ? 0 : buf_ld + 1;
+            ++ahead;
+            if (++kt_ld == k_steps) {
+                kt_ld = 0;
+                ldt = ws_next_tile(ldt.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+                set_base();
+            }
+        };
+        set_base();
+        issue(); issue(); issue(); issue();
+        while (cur.ok) {
+            for (int kt = 0; kt < k_steps; ++kt) {
+                // the oldest stage in flight has landed when at most (ahead - 1) stages' pieces are outstanding
+                if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+                else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+                else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                --ahead;
+                issue();          // into the slot the multiplying waves left at the previous step
+            }
+            cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+        }
+        return;
+    }
+    // ---- multiply role
+    const int fr = lane & 31, fh = lane >> 5;
+    int offa[TM][4], offb[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rr = wm * 64 + i * 32 + fr;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) offa[i][sl] = rr * GT_BK + (((2 * sl + fh) ^ ((rr >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int rr = BM + wn * 64 + j * 32 + fr;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) offb[j][sl] = rr * GT_BK + (((2 * sl + fh) ^ ((rr >> 1) & 7)) << 4);
+    }
+    v16f acc[TM][TN], old[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f, old[i][j][r] = 0.0f;
+    WsTile prv;
+    prv.ok = 0, prv.bm = prv.bn = 0, prv.id = 0;
+    const bool even = even_in != 0;
+#define DD_VAL(X) (FP4 ? (double)(X) : (double)gt_bits(X))
+    // rows 8 Q + 4 (lane >> 5) + 0..3 of block (MT, NT) of the PREVIOUS tile: four row stores (32 lanes = 256 contiguous
+    // bytes each) and, for an off-diagonal tile of a symmetric job, the same four values as 32 contiguous bytes of the
+    // mirrored tile's row
+#define DD_GROUP(MT, NT, Q)                                                                       \
+    {                                                                                             \
+        const int ctile = (wn * TN + (NT)) * 32 + (lane & 31);                                    \
+        const i64 col = (i64)prv.bn * BN + ctile;                                                 \
+        const int rtile = (wm * TM + (MT)) * 32 + 8 * (Q) + 4 * (lane >> 5);                      \
+        const i64 row0 = (i64)prv.bm * BM + rtile;                                                \
+        double v[4];                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            const i64 row = row0 + j;                                                             \
+            v[j] = DD_VAL(old[MT][NT][4 * (Q) + j]);                                              \
+            if (row < M && col < N) {                                                             \
+                if (slow) v[j] = finish_entry(v[j], row_base + row, col_base + col, symmetric != 0, selfk, n_fit, normalize); \
+                __builtin_nontemporal_store(v[j], &K[row * ldk + col]);                           \
+            }                                                                                     \
+        }                                                                                         \
+        if (mirror && col < N) {                                                                  \
+            double* dst = K + col * ldk + row0;                                                   \
+            if (even && row0 + 3 < M) {                                                           \
+                typedef double v2d_ __attribute__((ext_vector_type(2)));                          \
+                __builtin_nontemporal_store((v2d_){v[0], v[1]}, (v2d_*)dst);                      \
+                __builtin_nontemporal_store((v2d_){v[2], v[3]}, (v2d_*)(dst + 2));                \
+            } else {                                                                              \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+                    if (row0 + j < M) dst[j] = v[j];                                              \
+            }                                                                                     \
+        }                                                                                         \
+    }
+    // group g = 0..15 of the previous tile: (MT, NT, Q) = (g >> 3, (g >> 2) & 1, g & 3); g is a compile-time constant at
+    // every use (the K loop is unrolled sixteen-fold), so the accumulator registers are addressed statically.  Interior
+    // tiles of plain jobs (no diagonal, no normalisation, no ragged edge: prv_plain) take the short form DD_FAST from
+    // per-tile lane pointers; every other tile is written in one go by DD_STORE before its successor starts.
+#define DD_STORE(G)                                                                               \
+    {                                                                                             \
+        const bool mirror = tri && prv.bm != prv.bn;                                              \
+        const i64 d0 = row_base + (i64)prv.bm * BM - col_base - (i64)prv.bn * BN;                 \
+        const bool slow = normalize != 0 || (symmetric && d0 > -BM && d0 < BN);                   \
+        DD_GROUP(((G) >> 3), (((G) >> 2) & 1), ((G) & 3))                                         \
+    }
+    typedef double v2d_ __attribute__((ext_vector_type(2)));
+    double* p_dir = nullptr;         // previous tile: &K[row of this lane in block (0,0), group 0][its column]
+    double* p_mir = nullptr;         // ... and the mirrored position &K[its column][that row]
+    bool prv_plain = false, prv_mirror = false;
+#define DD_FAST(G)                                                                                \
+    {                                                                                             \
+        const int MT_ = (G) >> 3, NT_ = ((G) >> 2) & 1, Q_ = (G) & 3;                             \
+        double* pd = p_dir + (i64)(MT_ * 32 + 8 * Q_) * ldk + NT_ * 32;                           \
+        const double v0 = DD_VAL(old[MT_][NT_][4 * Q_]), v1 = DD_VAL(old[MT_][NT_][4 * Q_ + 1]);  \
+        const double v2 = DD_VAL(old[MT_][NT_][4 * Q_ + 2]), v3 = DD_VAL(old[MT_][NT_][4 * Q_ + 3]); \
+        __builtin_nontemporal_store(v0, pd);                                                      \
+        __builtin_nontemporal_store(v1, pd + ldk);                                                \
+        __builtin_nontemporal_store(v2, pd + 2 * ldk);                                            \
+        __builtin_nontemporal_store(v3, pd + 3 * ldk);                                            \
+        if (prv_mirror) {                                                                         \
+            double* pm = p_mir + (i64)(NT_ * 32) * ldk + MT_ * 32 + 8 * Q_;                       \
+            __builtin_nontemporal_store((v2d_){v0, v1}, (v2d_*)pm);                               \
+            __builtin_nontemporal_store((v2d_){v2, v3}, (v2d_*)(pm + 2));                         \
+        }                                                                                         \
+    }
+    int buf_cp = 0;
+#define DD_MFMA(FA, FB, AS_FP4)                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+            if (AS_FP4) {                                                                      \
+                const v8i xa = {FA[i][0], FA[i][1], FA[i][2], FA[i][3], 0, 0, 0, 0};           \
+                const v8i xb = {FB[j][0], FB[j][1], FB[j][2], FB[j][3], 0, 0, 0, 0};           \
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, xb, acc[i][j], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+            } else {                                                                           \
+                acc[i][j] = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(    \
+                    FA[i], FB[j], __builtin_bit_cast(v16i, acc[i][j]), 0, 0, 0));              \
+            }                                                                                  \
+        }
+#define DD_READ(SL, BUF)                                                                       \
+    {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[BUF][i] = *(const v4i*)(st + offa[i][SL]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[BUF][j] = *(const v4i*)(st + offb[j][SL]); \
+    }
+#define DD_STEP(AS_FP4)                                                                        \
+    {                                                                                          \
+        __builtin_amdgcn_s_barrier();                                                          \
+        const int8_t* st = smem + buf_cp * GT_STAGE;                                           \
+        v4i fa[3][TM], fb[3][TN];                                                              \
+        DD_READ(0, 0) DD_READ(1, 1)                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        DD_READ(2, 2) DD_MFMA(fa[0], fb[0], AS_FP4)                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        DD_READ(3, 0) DD_MFMA(fa[1], fb[1], AS_FP4)                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        DD_MFMA(fa[2], fb[2], AS_FP4)                                                          \
+        DD_MFMA(fa[0], fb[0], AS_FP4)                                                          \
+        buf_cp = buf_cp == DD_RING - 1 ? 0 : buf_cp + 1;                                       \
+    }
+#define DD_CONVERT()                                                                           \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = (float)gt_bits(acc[i][j][r]);
+    while (cur.ok) {
+        int kt = 0;
+        if (FP4) {                                                 // the (few) int8 K-steps first; the stores ride the others
+            for (; kt < k8_steps; ++kt) DD_STEP(false)
+            if (k8_steps > 0) { DD_CONVERT() }
+        }
+        const int k_rest = k_steps - kt;
+        for (int kt0 = 0; kt0 < k_rest; kt0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (kt0 + u < k_rest) {                           // wave-uniform
+                    DD_STEP(FP4)
+                    if (prv_plain && kt0 == 0) DD_FAST(u)         // one group of the previous tile per K-step
+                }
+            }
+        }
+        if (prv_plain) {                                          // fewer than 16 such K-steps: the rest of the previous tile
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (g >= k_rest) DD_FAST(g)
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                old[i][j] = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            }
+        prv = cur;
+        cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
+        {
+            const i64 d0 = row_base + (i64)prv.bm * BM - col_base - (i64)prv.bn * BN;
+            prv_mirror = tri && prv.bm != prv.bn;
+            prv_plain = normalize == 0 && !(symmetric && d0 > -BM && d0 < BN) && even && ((i64)prv.bm + 1) * BM <= M &&
+                        ((i64)prv.bn + 1) * BN <= N && (!prv_mirror || (((i64)prv.bn + 1) * BN <= M && ((i64)prv.bm + 1) * BM <= N));
+            const i64 r_l = (i64)prv.bm * BM + wm * 64 + 4 * (lane >> 5), c_l = (i64)prv.bn * BN + wn * 64 + (lane & 31);
+            p_dir = K + r_l * ldk + c_l;
+            p_mir = K + c_l * ldk + r_l;
+        }
+        if (!prv_plain) {                                         // diagonal / edge / normalised tile: all of it now
+#pragma unroll
+            for (int g = 0; g < 16; ++g) DD_STORE(g)
+        }
+    }
+    if (prv.ok && prv_plain) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) DD_FAST(g)
+    }
+#undef DD_FAST
+#undef DD_CONVERT
+#undef DD_STORE
+#undef DD_STEP
+#undef DD_READ
+#undef DD_MFMA
+#undef DD_GROUP
+#undef DD_VAL
+}
+
 static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
                         i64 row_lo, int normalize, double* K, int tri, int patch, double* entries_done, i64 ldk, i64 col_lo) {
     // a / b: operand rows of the job's first row / first column; K: the job's entry (0, 0)
@@ -711,7 +970,20 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
     if (const char* abl = getenv("GK_GRAM_ABL")) abl_bits = atoi(abl);
 #endif
     const bool use_ws = !ctx->opt.gram_no_ws;
-    if (use_ws) {
+    // which persistent form: the direct-store form wins while the job is a few tiles per CU (measured, fp4 operands:
+    // N = 2000 0.035 vs 0.051 ms, N = 4000 0.071 vs 0.084, N = 6000 0.132 vs 0.117; int8-only operands lose at 561 tiles:
+    // 0.170 vs 0.140); option gram.dd: 0 = this rule, 1 = always, 2 = never
+    const i64 real_tiles = tri ? (i64)tiles_m * (tiles_m + 1) / 2 : (i64)tiles_m * tiles_n;
+    const bool use_dd = use_ws && (ctx->opt.gram_dd == 1 || (ctx->opt.gram_dd == 0 && f->phi_fp4 && real_tiles <= 600));
+    if (use_dd) {
+        const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+        const i64 grid = blocks < n_cu ? blocks : n_cu;
+        auto kern = f->phi_fp4 ? gram_dd_kernel<true> : gram_dd_kernel<false>;
+        GK_TRY(gk_func_lds(ctx, (const void*)kern, DD_LDS_BYTES));
+        kern<<<dim3((unsigned)grid), dim3(DD_THREADS), DD_LDS_BYTES, ctx->stream>>>(
+            a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
+            normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, ldk, col_lo, even);
+    } else if (use_ws) {
         const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
         const i64 grid = blocks < n_cu ? blocks : n_cu;
         unsigned* ticket = nullptr;

@@ -770,8 +770,14 @@ __global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict
     u64 claimed = 0;
     if (!too_long) {
         int c = 0;
+        // the next chunk's key is in flight while this one probes the table: the largest bucket (a heavy class sends
+        // 14 000 equal keys into ONE bucket: 3-4x the average size) is the kernel's critical path, one HBM round trip
+        // per chunk otherwise
+        u64 k_cur = tid < size ? kx[start + tid] : 0ull;
         for (u32 i = tid; i < size; i += 1024, ++c) {
-            const u64 k1 = (kx[start + i] & kmask) + 1ull;
+            const u64 k_nxt = i + 1024 < size ? kx[start + i + 1024] : 0ull;
+            const u64 k1 = (k_cur & kmask) + 1ull;
+            k_cur = k_nxt;
             u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)BD_SLOTS) >> 32);
             for (;;) {
                 unsigned long long v = key_s[h];
@@ -824,8 +830,11 @@ __global__ __launch_bounds__(1024) void bucket_dict_kernel(const u64* __restrict
     __syncthreads();
     // ---- every item looks its class up again
     int c = 0;
+    u64 k_cur = tid < size ? kx[start + tid] : 0ull;
     for (u32 i = tid; i < size; i += 1024, ++c) {
-        const u64 k1 = (kx[start + i] & kmask) + 1ull;
+        const u64 k_nxt = i + 1024 < size ? kx[start + i + 1024] : 0ull;
+        const u64 k1 = (k_cur & kmask) + 1ull;
+        k_cur = k_nxt;
         u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)BD_SLOTS) >> 32);
         while (key_s[h] != k1) h = h + 1u == (u32)BD_SLOTS ? 0u : h + 1u;
         const u32 v = word_s[h];

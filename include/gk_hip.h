@@ -73,10 +73,10 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "sort.buckets" (1 never / 2 always the per-bucket finish of the sort)
  *             "wl.bd_slots" (distinct keys a bucket of the sort-free dictionary accepts: small values force its
  *             overflow and with it the second, sorting attempt)
- *   features: "feat.no_gm" "feat.gm_no_priv" "feat.low_df" (df below which a column becomes pair updates, default 24)
+ *   features: "feat.no_gm" "feat.gm_no_priv" "feat.gm_rows_wg" "feat.low_df" (df below which a column becomes pair updates, default 24)
  *             "feat.gm_row_lds_max" (bytes of operand row the graph-major builder accepts: small values force the
  *             fall-back to the label-major builder)
- *   Gram:     "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc"
+ *   Gram:     "gram.dd" (the direct-store form of the persistent kernel: 1 always, 2 never, 0 per job) "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc"
  *   paths:    "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
  *             histograms of the distance matrices),
  *             "sp.no_pk" (all-pairs distances never in the 16-bit packed register kernel: 32-bit registers up to 64

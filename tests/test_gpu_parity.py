@@ -218,7 +218,7 @@ ROUTE_OPTIONS = [
     # round 2: sort-free dictionary, graph-major features, level-0 histogram, where the singleton flags travel,
     # register sort of the neighbour lists, workgroup-private df histograms
     ("wl.no_bucket_dict",), ("feat.no_gm",), ("wl.no_hist0",), ("wl.frozen_words",), ("wl.flag_bytes",), ("wl.sig_no_regs",),
-    ("feat.gm_no_priv",), ("no_mailbox",), ("sort.buckets", 1), ("sort.buckets", 2),
+    ("feat.gm_no_priv",), ("feat.gm_rows_wg",), ("no_mailbox",), ("sort.buckets", 1), ("sort.buckets", 2),
     # combinations that meet in real jobs: label-major features on top of a sort-free relabel is impossible by
     # construction (feat.no_gm turns both off), the words + no list scan pair is the round-1 data flow
     ("wl.frozen_words", "wl.no_listscan"), ("wl.no_hist0", "wl.no_exact1", "wl.no_bucket_dict"),
@@ -1293,14 +1293,15 @@ def test_config5_row_sharded_over_two_processes(gk, tmp_path):
 # the dense kernel against the host product of its own operand, every operand form and both kernel forms
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("env", [(), ("gram.no_fp4",), ("gram.no_ws",), ("gram.no_ws", "gram.no_fp4"), ("gram.no_sym",),
-                                 ("gram.no_patch",)], ids=lambda e: "+".join(e) or "default")
+                                 ("gram.no_patch",), ("gram.dd",), ("gram.dd", "gram.no_fp4"), ("gram.dd=2",)],
+                         ids=lambda e: "+".join(e) or "default")
 @pytest.mark.parametrize("N,n", [(40, 20), (300, 20), (1001, 12)])
 def test_dense_gram_equals_the_product_of_its_own_operand(gk, gkopt, env, N, n):
     from grakel_amd import GraphBatch
     from grakel_amd.engine import get_engine
     gkopt("feat.low_df", 2)                                # every useful column is dense
     for k in env:
-        gkopt(k, 1)
+        gkopt(k.split("=")[0], int(k.split("=")[1]) if "=" in k else 1)
     eng = get_engine()
     db = eng.upload(GraphBatch(*er_dataset_csr(N, n, 0.15, 3, 0), 3))
     eng.wl_relabel(db, 2)
@@ -1313,6 +1314,11 @@ def test_dense_gram_equals_the_product_of_its_own_operand(gk, gkopt, env, N, n):
     assert np.array_equal(K, R)
     s, t, a = eng.gram_checksum(feat)
     assert (s, t, a) == (K.sum(), np.trace(K), 0.0)
+    d = eng.selfk(feat)                                      # normalised epilogue and a row block with an odd offset
+    Kn = eng.gram(feat, 2, rows=(3, N - 2))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = np.nan_to_num(R[3:N - 2] / np.sqrt(np.outer(d[3:N - 2], d)))
+    assert np.allclose(Kn, want, rtol=1e-13, atol=0)
 
 
 @pytest.mark.parametrize("big_n,want", [(4095, "fp4+i8+f64"), (4096, "i8+f64"), (46340, "i8+f64"), (46341, "f64")])
