@@ -1,5 +1,5 @@
 // Label-count features (the VertexHistogram of every WL level) on gfx950 -- the LABEL-MAJOR builder: pair batches
-// (ShortestPath), operand rows wider than features_gm.hip holds in LDS, GK_FEAT_NO_GM.  Graph batches take the
+// (ShortestPath), operand rows wider than features_gm.hip holds in LDS, option feat.no_gm.  Graph batches take the
 // graph-major builder (features_gm.hip), which this file dispatches to first.
 //
 // Input per level: labels[v] and perm[] = nodes grouped by label, ascending node (hence

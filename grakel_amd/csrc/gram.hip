@@ -6,13 +6,17 @@
 //                            (v_mfma_scale_f32_32x32x64_f8f6f4, exact), counts 5..127 as int8
 //                            (v_mfma_i32_32x32x32_i8); features.hip only allows fp4 when every entry stays
 //                            below 2^24 (exact float32 accumulation) and int8 below 2^31: bit-exact versus
-//                            the reference's float64 result.  Persistent, warp-specialised: four waves
-//                            multiply, four waves write K (float64) under the next tile's K loop.
-//                            gram_tile_kernel is the plain one-tile-per-workgroup form (GK_GRAM_NO_WS=1).
+//                            the reference's float64 result.  Persistent, warp-specialised, three roles of
+//                            four waves: multiply / fill the LDS-DMA operand ring / write the parked previous
+//                            tile to K (float64) under the current tile's K loop.
+//      gram_dd_kernel      : the same job without parked tile and store waves: the multiplying waves write the
+//                            previous tile from a second accumulator set between their K-steps; picked for fp4
+//                            jobs of <= 600 tiles (option gram.dd forces / forbids it).
+//      gram_tile_kernel    : the plain one-tile-per-workgroup form (option gram.no_ws).
 //   2. gram_f64_kernel     : dense columns holding a count > 127 (typical for ShortestPath
 //                            histograms) form a narrow float64 side operand,
 //                            v_mfma_f64_16x16x4_f64, accumulated onto K (exact while K < 2^53).
-//   3. gram_low_kernel     : useful columns present in < 24 graphs (GK_LOW_DF) never enter a dense operand;
+//   3. gram_low_kernel     : useful columns present in < 24 graphs (option feat.low_df) never enter a dense operand;
 //                            their df*(df-1) pair products are added as float64 atomics.
 //   4. gram_normalize_kernel, only when 2. or 3. ran and normalisation was requested.
 // Histogram-intersection features (kind 1) arrive unary-expanded (features.hip), so step 1 computes

@@ -4,17 +4,20 @@
 //   1. wl_signature_*  : per node, gather the previous labels of its out-neighbours (coalesced
 //                        col_idx stream, LDS-staged), sort them, write the sorted list to
 //                        nbr_sorted[] and form a 64-bit multiset hash of (own, degree, list).
-//   2. radix sort       : (hash, node) pairs, stable -> equal signatures become adjacent and
-//                        keep ascending node order inside a group (scan_sort.hip: pass by pass,
-//                        or top digit + one workgroup per bucket when the classes are small).
-//   3. heads + scan     : group index = new dense label id; first node = representative.
+//   2. dictionary       : equal hashes -> one dense label id, the lowest node of the class = its representative.
+//                        Sort-free form (scan_sort.hip: top-digit partition + one LDS table of DISTINCT keys per
+//                        bucket, bucket_dict_kernel / bucket_assign_kernel) whenever gk_bucket_dictionary_fits;
+//                        sorting form (stable radix sort of (hash, node), run heads + scan) for active-set levels,
+//                        pair items, and as the redo path when a bucket's table overflows after all
+//                        (gk_wl_relabel then relabels the whole job again with the sorting dictionary).
+//   3. singleton flags  : ride in bit 31 of the label word until verify strips them (shared_flag[]).
 //   4. verify           : every node compares its FULL signature (own label, degree, sorted
 //                        list) with its group's representative -> the dictionary is exact, the
 //                        hash only proposes groups.  Any mismatch (a 64-bit collision) is
 //                        counted; the host then re-runs that level in "exact" mode, refining
 //                        groups with re-seeded hashes until no mismatch is left.
-// Work that cannot change the partition is not done (every switch below has a GK_WL_NO_* override,
-// tests/test_gpu_parity.py runs the job through each combination's removal):
+// Work that cannot change the partition is not done (every switch below is a context option, gk_set_option "wl.*";
+// tests/test_gpu_parity.py runs the job through the removal of each):
 //   * level 1 with few input labels and small degrees: exact 32-bit signature codes instead of
 //     hashes -- no sorted lists, fewer digit passes, nothing to verify (wl_signature_exact_kernel);
 //   * a level that sorts every node splits its label-grouped order: nodes of classes >= 2 first
@@ -1311,18 +1314,18 @@ struct RelabelState {
     u32 prev_top_max = 0;                  // largest top-digit bucket of the previous level's sort
     bool default_bits = true;              // the caller did not force a hash width (tests do, to provoke collisions)
     std::vector<char> full_level;          // levels that sorted every node (their perm is split: shared classes first)
-    bool split = true;                     // GK_WL_NO_SPLIT: keep the plain label-grouped order
+    bool split = true;                     // option wl.no_split: keep the plain label-grouped order
     u32 posted_seq = 0;                    // mailbox message {listed nodes, top-digit max} of the previous (full) level
     Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active, [2] = top-digit max
     bool frozen_in_shared = false;         // the last full level wrote its singleton flags to shared_flag only (never with
-                                           // GK_WL_NO_LISTSCAN: every level then scans frozen[] of all nodes)
+                                           // option wl.no_listscan: every level then scans frozen[] of all nodes)
     const unsigned char* shared_prev = nullptr;
     Tmp<u32> act2;                         // second active list (the list of a level is built from the previous level's)
     u32* act_cur = nullptr;                // the current level's active list (act or act2)
     bool prev_active = false;              // the previous level took the active-set path (its list is act_cur)
     u32 n_act_prev = 0;
-    bool list_scan = true;                 // GK_WL_NO_LISTSCAN: always rebuild the active list from all nodes
-    bool tiny = true;                      // GK_WL_NO_TINY: never run a level in the single-workgroup kernel
+    bool list_scan = true;                 // option wl.no_listscan: always rebuild the active list from all nodes
+    bool tiny = true;                      // option wl.no_tiny: never run a level in the single-workgroup kernel
     bool no_order = false;                 // full levels need no label-grouped order (graph-major features will read them)
     std::vector<char> tiny_level;          // levels run by wl_tiny_level_kernel (n_act_prev is then only a bound)
     i64 n_frozen_levels = 0;
