@@ -142,10 +142,18 @@ def end_to_end(eng, full, cfg, with_objects):
     del K
     packed()
     dt_packed, K = packed()
+    with eng.options(**{"gram.no_compact": 1}):          # the plain 8 N^2-byte copy, for comparison
+        packed()
+        dt_plain, Kp = packed()
+    same_plain = bool(np.array_equal(K, Kp))
+    del Kp
     out = {"packed_csr_host_to_host_ms": dt_packed * 1e3, "value_host_to_host": N * N / dt_packed,
+           "plain_float64_copy_ms": dt_plain * 1e3, "compact_equals_plain": same_plain,
            "first_call_ms_incl_pinning_the_output": first * 1e3,
-           "note": "packed: H2D of the CSR + step + D2H of the %d MB float64 K into a pinned, reused output "
-                   "block (grakel_amd.engine.PinnedPool)" % (N * N * 8 // 1000000)}
+           "note": "packed: H2D of the CSR + step + the %d MB float64 K into a pinned, reused output block "
+                   "(grakel_amd.engine.PinnedPool); integer-valued matrices cross PCIe as uint16 / int32 and are "
+                   "widened by host threads (gram.hip: gram_copy_out), plain_float64_copy_ms = the 8 N^2-byte copy"
+                   % (N * N * 8 // 1000000)}
     if with_objects:
         X = er_dataset(N, cfg["n"], cfg["p"], cfg["L"], cfg["seed"])      # {u: [v, ...]} + {u: label} per graph
         from grakel_amd.batch import wl_batch_from_input

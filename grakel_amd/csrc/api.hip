@@ -77,6 +77,9 @@ extern "C" int gk_destroy(gk_ctx* ctx) {
     (void)hipEventDestroy(ctx->pv0);
     (void)hipEventDestroy(ctx->pv1);
     if (ctx->mbox_host) (void)hipHostFree(ctx->mbox_host);
+    if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     cache_release_all(ctx);
     for (auto& kv : ctx->cache.live) (void)hipFree(kv.first);   // leaked by the caller: reclaim
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -173,7 +176,7 @@ static const OptName g_opt_names[] = {
     {"wl.bd_slots", &gk_opts::bd_slots}, {"feat.no_gm", &gk_opts::feat_no_gm}, {"feat.gm_no_priv", &gk_opts::gm_no_priv}, {"feat.gm_rows_wg", &gk_opts::gm_rows_wg},
     {"feat.low_df", &gk_opts::low_df}, {"feat.gm_row_lds_max", &gk_opts::gm_row_lds_max},
     {"gram.dd", &gk_opts::gram_dd}, {"gram.no_fp4", &gk_opts::gram_no_fp4}, {"gram.no_ws", &gk_opts::gram_no_ws}, {"gram.no_sym", &gk_opts::gram_no_sym},
-    {"gram.no_patch", &gk_opts::gram_no_patch}, {"gram.xcc", &gk_opts::gram_xcc}, {"sp.no_reg", &gk_opts::sp_no_reg}, {"sp.no_pk", &gk_opts::sp_no_pk}, {"sp.no_hist", &gk_opts::sp_no_hist}, {"no_mailbox", &gk_opts::no_mailbox},
+    {"gram.no_patch", &gk_opts::gram_no_patch}, {"gram.xcc", &gk_opts::gram_xcc}, {"gram.no_compact", &gk_opts::gram_no_compact}, {"gram.copy_threads", &gk_opts::gram_copy_threads}, {"sp.no_reg", &gk_opts::sp_no_reg}, {"sp.no_pk", &gk_opts::sp_no_pk}, {"sp.no_hist", &gk_opts::sp_no_hist}, {"no_mailbox", &gk_opts::no_mailbox},
     {"debug.poison", &gk_opts::poison},
 };
 

@@ -75,6 +75,8 @@ struct gk_opts {
     int gram_dd = 0;             // Gram kernel form with two accumulator sets and direct stores (no parked tile, five-stage ring):
                                  // 0 chosen per job (small fp4 jobs), 1 always, 2 never
     int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
+    int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
+    int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
     // ShortestPath
     int sp_no_hist = 0;          // pair features through explicit pair items + the sorting dictionary instead of per-graph histograms
     int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)
@@ -98,6 +100,9 @@ struct gk_ctx {
     // writes into, then a sequence word the host spins on -- no staging copy, no stream drain
     u32* mbox_host = nullptr;
     u32* mbox_dev = nullptr;
+    // pinned staging ring + events of the compact device -> host copy of a Gram matrix (gram.hip: gram_copy_out)
+    void* stage_host = nullptr;
+    hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     u32 mbox_seq = 0;
     int n_cu = 0;                              // compute units of the device (persistent-kernel grids)
     std::map<const void*, int> func_lds;       // kernel -> dynamic LDS limit already set for THIS context's device (gk_func_lds)
@@ -275,6 +280,7 @@ struct gk_feat {
     void* phi = nullptr;
     i64 n_cols1 = 0, n_cols8 = 0;
     int k1_steps = 0, k8_steps = 0;
+    double k_bound = 0.0;       // upper bound of every entry of the job's matrix (n_levels * max_graph_nodes^2; * nodes for min-sum)
     bool phi_fp4 = false;       // counts <= 4 travel as fp4 (needs every Gram entry < 2^24: f32 accumulation stays exact)
     // dense columns holding a count > 127 cannot be int8 operands: they form a (usually
     // narrow) float64 side operand whose product is accumulated onto K after the int8 GEMM

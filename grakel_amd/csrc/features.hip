@@ -524,6 +524,7 @@ extern "C" int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, i
                              ? (double)n_levels * (double)b->max_graph_nodes
                              : (double)n_levels * (double)b->max_graph_nodes * (double)b->max_graph_nodes;
     f->dtype = (kind == GK_FEAT_MINSUM || bound < 2147483647.0) ? 0 : 1;
+    f->k_bound = bound;
     f->phi_fp4 = f->dtype == 0 && bound < 16777216.0 && !ctx->opt.gram_no_fp4;
     const int wide_above = kind == GK_FEAT_MINSUM ? 0x7fffffff : (f->dtype == 0 ? 127 : -1);
     const int prim_max = f->dtype != 0 ? -1 : (f->phi_fp4 ? 4 : 127);

@@ -499,6 +499,34 @@ def test_config3_full_size_against_reference_checksums(gk):
     assert np.array_equal(K, K.T)
 
 
+@pytest.mark.parametrize("n,form", [(40, "uint16"), (110, "int32")])
+def test_compact_host_copy_is_the_plain_copy(gk, gkopt, n, form):
+    """An integer-valued matrix crosses PCIe as uint16 (bound below 2^16) or int32 (below 2^31) and is widened by host
+    threads (gram.hip: gram_copy_out); the float64 array the caller gets must be the plain copy's, for every thread count,
+    for a row range that does not start at a chunk boundary, and for a normalised (float) matrix, which goes plain."""
+    from grakel_amd import GraphBatch
+    from grakel_amd.engine import get_engine
+    eng = get_engine()
+    N = 2300                                                  # 5.3 M entries: above the compact path's 4 Mi threshold
+    db = eng.upload(GraphBatch(*er_dataset_csr(N, n, 0.08, 3, 5), 3))
+    eng.wl_relabel(db, 5)
+    feat = eng.features(db, 6)
+    assert (6 * n * n < 65536) == (form == "uint16")
+    gkopt("gram.no_compact", 1)
+    plain = eng.gram(feat, 0).copy()
+    plain_rows = eng.gram(feat, 0, rows=(7, N - 3)).copy()
+    norm = eng.gram(feat, 2).copy()
+    gkopt("gram.no_compact", 0)
+    for threads in (0, 1, 3, 7):
+        gkopt("gram.copy_threads", threads)
+        K = eng.gram(feat, 0)
+        assert np.array_equal(K, plain), threads
+        del K
+    assert np.array_equal(eng.gram(feat, 0, rows=(7, N - 3)), plain_rows)
+    assert np.array_equal(eng.gram(feat, 2), norm)
+    assert plain.max() < (65536 if form == "uint16" else 2 ** 31) and np.array_equal(plain, plain.T)
+
+
 def test_counts_above_127_take_the_f64_path(gk):
     """A label occurring > 127 times in one graph cannot be an int8 operand."""
     rs = np.random.RandomState(3)
