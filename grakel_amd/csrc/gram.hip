@@ -358,7 +358,7 @@ __device__ unsigned long long g_ws_dbg[3][4];
 #endif
 // ABL (tools' build only, timing ablations with WRONG results), a bit mask: 1 no operand loads, 2 the multiplying waves
 // skip their K-steps, 4 MFMAs on fabricated fragments (no LDS reads), 8 no stores, 16 no per-K-step barrier, 32 the store
-// waves skip their chunks altogether, 64 no parking of finished tiles
+// waves skip their chunks altogether, 64 no parking of finished tiles, 128 K-step barrier only every second step (races: timing only)
 template <bool FP4, int ABL>
 __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
     const bool is_compute = role == 0, is_loader = role == 2;
     const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
     constexpr bool NO_LOAD = (ABL & 1) != 0, NO_COMPUTE = (ABL & 2) != 0, FAKE_READ = (ABL & 4) != 0, NO_STORE = (ABL & 8) != 0,
-                   NO_BAR = (ABL & 16) != 0, NO_CHUNK = (ABL & 32) != 0, NO_PARK = (ABL & 64) != 0;
+                   NO_BAR = (ABL & 16) != 0, NO_CHUNK = (ABL & 32) != 0, NO_PARK = (ABL & 64) != 0, HALF_BAR = (ABL & 128) != 0;
 
     // ---- compute role state -------------------------------------------------------------
     // staging (as gram_tile_kernel): compute wave w fills stage rows [64w, 64w + 64)
@@ -538,56 +538,69 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
             }
         }
     };
-    // Fast form for interior tiles of plain jobs (no selfk look-up, even N).  The LDS reads are inline
-    // asm: in a kernel that also uses LDS-DMA the compiler puts s_waitcnt vmcnt(0) in front of every LDS
-    // read, i.e. the store waves would wait for their own stores every row.  Four rows per batch,
-    // 16-byte non-temporal stores.
+    // Interior tiles of plain jobs (no selfk look-up, even N, tile completely inside the matrix): LEAN batches of four
+    // rows.  The store role is instruction-bound -- one wave per SIMD issues a vector instruction every 4-8 cycles and a
+    // taken branch costs more -- and it is the role the other two wait for at the K-step barriers (ablation: with the
+    // store waves idle the kernel takes 0.18 ms, with the round-2 store code but no store instructions 0.25).  So a
+    // batch is straight-line code: the parked layout keeps four consecutive rows of a column in one 16-byte group, i.e.
+    // a batch of tile rows is TWO ds_read_b128 (columns e, e + 1) and a batch of rows of the transposed tile FOUR
+    // ds_read_b64; lane-constant address parts are computed once per kernel, the tile's destination rows once per tile.
+    // The LDS reads are inline asm: in a kernel that also uses LDS-DMA the compiler puts s_waitcnt vmcnt(0) in front of
+    // every LDS read, i.e. the store waves would wait for their own stores every row.
     typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
     const unsigned out_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int8_t*)outb;
-    auto store_units_fast = [&](int u0, int u1) __attribute__((always_inline)) {
+    const int e = 2 * lane;
+    const unsigned lane_c0 = out_lds + (unsigned)e * (GT_BM * 4), lane_c1 = lane_c0 + GT_BM * 4;      // column bases of e, e + 1
+    const unsigned lane_x0 = (unsigned)(e & 31), lane_x1 = (unsigned)((e + 1) & 31);
+    const unsigned lane_t = out_lds + (unsigned)((e & 3) << 2), lane_g = (unsigned)(e >> 2);          // rows e, e + 1 of a column
+    bool prv_plain = false;
+    int prv_batches = 0;                 // 8 batches of tile rows, 8 more of transposed rows for a mirrored tile
+    double* dst_rows = nullptr;          // K row of tile row 32 sw, column of tile column e
+    double* dst_cols = nullptr;          // the same for the transposed tile
+    auto tile_setup = [&]() __attribute__((always_inline)) {
         const bool mirror = tri && prv.bm != prv.bn;
-        const int n_units = mirror ? 64 : 32;
-        if (u1 > n_units) u1 = n_units;
-        const int e = 2 * lane;
-        double* const dst_rows = K + ((i64)prv.bm * BM + sw * 32) * ldk + (i64)prv.bn * BN + e;     // row-major rows
-        double* const dst_cols = K + ((i64)prv.bn * BN + sw * 32) * ldk + (i64)prv.bm * BM + e;     // rows of the transpose
-        for (int ub = u0; ub < u1; ub += 4) {
+        const i64 d0 = row_base + (i64)prv.bm * BM - col_base - (i64)prv.bn * BN;
+        prv_plain = normalize == 0 && !(symmetric && d0 > -BM && d0 < BN) && even &&
+                    ((i64)prv.bm + 1) * BM <= M_store && ((i64)prv.bn + 1) * BN <= N &&
+                    (!mirror || (((i64)prv.bn + 1) * BN <= M_store && ((i64)prv.bm + 1) * BM <= N));
+        prv_batches = mirror ? 16 : 8;
+        dst_rows = K + ((i64)prv.bm * BM + sw * 32) * ldk + (i64)prv.bn * BN + e;
+        dst_cols = K + ((i64)prv.bn * BN + sw * 32) * ldk + (i64)prv.bm * BM + e;
+    };
+    auto store_batch = [&](int b) __attribute__((always_inline)) {          // b wave-uniform
+        if (b < 8) {
+            const unsigned g = (unsigned)(sw * 8 + b);
+            v4f x0, x1;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(x0) : "v"(lane_c0 + ((g ^ lane_x0) << 4)));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(x1) : "v"(lane_c1 + ((g ^ lane_x1) << 4)));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1));
+            double* const d = dst_rows + (i64)(4 * b) * ldk;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v2d v = {WS_VAL(x0[q]), WS_VAL(x1[q])};
+                if (!NO_STORE) __builtin_nontemporal_store(v, (v2d*)(d + (i64)q * ldk));
+                else if (v.x == 1.2345e300) d[0] = v.y;
+            }
+        } else {
+            const unsigned c0 = (unsigned)(sw * 32 + 4 * (b - 8));
             float2 x[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int u = ub + q;
-                if (u < u1) {                      // wave-uniform
-                    const int r = sw * 32 + (u & 31);
-                    if (u >= 32) {                 // tile entries (e, r), (e + 1, r): 8 contiguous bytes
-                        asm volatile("ds_read_b64 %0, %1" : "=v"(x[q]) : "v"(out_lds + (unsigned)ws_out_addr(e, r)));
-                    } else {                       // tile entries (r, e), (r, e + 1)
-                        asm volatile("ds_read_b32 %0, %1" : "=v"(x[q].x) : "v"(out_lds + (unsigned)ws_out_addr(r, e)));
-                        asm volatile("ds_read_b32 %0, %1" : "=v"(x[q].y) : "v"(out_lds + (unsigned)ws_out_addr(r, e + 1)));
-                    }
-                }
+                const unsigned c = c0 + (unsigned)q;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(x[q]) : "v"(lane_t + c * (GT_BM * 4) + ((lane_g ^ (c & 31u)) << 4)));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+            double* const d = dst_cols + (i64)(4 * (b - 8)) * ldk;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int u = ub + q;
-                if (u < u1) {
-                    const v2d v = {WS_VAL(x[q].x), WS_VAL(x[q].y)};
-                    double* dst = (u >= 32 ? dst_cols : dst_rows) + (i64)(u & 31) * ldk;
-                    if (!NO_STORE) __builtin_nontemporal_store(v, (v2d*)dst);
-                    else if (v.x == 1.2345e300) dst[0] = v.y;
-                }
+                const v2d v = {WS_VAL(x[q].x), WS_VAL(x[q].y)};
+                if (!NO_STORE) __builtin_nontemporal_store(v, (v2d*)(d + (i64)q * ldk));
+                else if (v.x == 1.2345e300) d[0] = v.y;
             }
         }
     };
-    auto store_chunk = [&](int u0, int u1) __attribute__((always_inline)) {
-        const i64 d0 = row_base + (i64)prv.bm * BM - col_base - (i64)prv.bn * BN;
-        const bool plain = normalize == 0 && !(symmetric && d0 > -BM && d0 < BN) && even &&
-                           ((i64)prv.bm + 1) * BM <= M_store && ((i64)prv.bn + 1) * BN <= N &&
-                           (!(tri && prv.bm != prv.bn) || (((i64)prv.bn + 1) * BN <= M_store && ((i64)prv.bm + 1) * BM <= N));
-        if (plain) store_units_fast(u0, u1);
-        else store_units(u0, u1);
-    };
-    const int upc = k_steps > 0 ? (64 + k_steps - 1) / k_steps : 64;           // units per chunk (a mirrored tile has 64 per wave)
+    const int upc = k_steps > 0 ? (64 + k_steps - 1) / k_steps : 64;           // general path: units per K-step (a mirrored tile has 64 per wave)
 
     WS_DBG_DECL
     // ---- main loops: one per role, with the same barrier sequence (k_steps + 1 per tile, one at the end).
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
 #define WS_STEP(AS_FP4)                                                                        \
     {                                                                                          \
         WS_DBG_T0()                                                                            \
-        if (!NO_BAR) __builtin_amdgcn_s_barrier();       /* the load waves saw this stage land */ \
+        if (!NO_BAR && !(HALF_BAR && (kt & 1))) __builtin_amdgcn_s_barrier();       /* the load waves saw this stage land */ \
         WS_DBG_ADD(t_bar)                                                                      \
         if (!NO_COMPUTE) WS_COMPUTE(AS_FP4)                                                    \
         buf_cp = buf_cp == WS_RING - 1 ? 0 : buf_cp + 1;                                       \
@@ -658,7 +671,7 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
                 if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 WS_DBG_ADD(t_walk)
-                if (!NO_BAR) __builtin_amdgcn_s_barrier();
+                if (!NO_BAR && !(HALF_BAR && (kt & 1))) __builtin_amdgcn_s_barrier();
                 WS_DBG_ADD(t_bar)
                 --ahead;
                 WS_ISSUE_NEXT()
@@ -673,11 +686,16 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
         WS_DBG_OUT(2)
     } else {
         while (cur.ok) {
+            int due = 0, next_b = 0;               // batches spread evenly over the K-steps: due += batches, one leaves per k_steps
             for (int kt = 0; kt < k_steps; ++kt) {
                 WS_DBG_T0()
-                if (!NO_BAR) __builtin_amdgcn_s_barrier();
+                if (!NO_BAR && !(HALF_BAR && (kt & 1))) __builtin_amdgcn_s_barrier();
                 WS_DBG_ADD(t_bar)
-                if (prv.ok && !NO_CHUNK) store_chunk(kt * upc, (kt + 1) * upc);
+                if (prv.ok && !NO_CHUNK) {
+                    if (prv_plain) {
+                        for (due += prv_batches; due >= k_steps; due -= k_steps) store_batch(next_b++);
+                    } else store_units(kt * upc, (kt + 1) * upc);
+                }
                 WS_DBG_ADD(t_body)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -685,12 +703,17 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
             __builtin_amdgcn_s_barrier();
             WS_DBG_ADD(t_bar)
             prv = cur;
+            tile_setup();
             cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
             WS_DBG_ADD(t_walk)
         }
         // drain: the last parked tile
         __builtin_amdgcn_s_barrier();
-        if (prv.ok) store_chunk(0, 64);
+        if (prv.ok) {
+            if (prv_plain) {
+                for (int b = 0; b < prv_batches; ++b) store_batch(b);
+            } else store_units(0, 64);
+        }
         WS_DBG_OUT(1)
     }
 #undef WS_VAL
@@ -1006,7 +1029,7 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
 #ifdef GK_ABLATION
 #define WS_ABL_CASE(X) if (abl_bits == X) kern = gram_ws_kernel<true, X>;
         WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(8) WS_ABL_CASE(9) WS_ABL_CASE(10) WS_ABL_CASE(11) WS_ABL_CASE(13)
-        WS_ABL_CASE(24) WS_ABL_CASE(25) WS_ABL_CASE(43) WS_ABL_CASE(107)
+        WS_ABL_CASE(24) WS_ABL_CASE(25) WS_ABL_CASE(32) WS_ABL_CASE(43) WS_ABL_CASE(107) WS_ABL_CASE(128) WS_ABL_CASE(136)
 #undef WS_ABL_CASE
 #endif
         (void)abl_bits;
