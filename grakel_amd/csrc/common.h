@@ -75,6 +75,7 @@ struct gk_opts {
     int gram_dd = 0;             // Gram kernel form with two accumulator sets and direct stores (no parked tile, five-stage ring):
                                  // 0 chosen per job (small fp4 jobs), 1 always, 2 never
     int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
+    int gram_no_fold = 0;        // rare labels' pair updates as float64 atomics after the tile kernel instead of inside it
     int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
     int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
     // ShortestPath
@@ -292,6 +293,13 @@ struct gk_feat {
     u32* gm_roff = nullptr;     // per label index: first entry of its list
     u32* gm_df = nullptr;       // per label index: entries (graphs) of its list
     i32* gm_low_graph = nullptr, *gm_low_cnt = nullptr;    // the lists: graph, count
+    // the rare labels' pair updates binned by 128x128 output tile (gram.hip: built on the first full symmetric Gram job,
+    // applied to the parked tile inside gram_ws_kernel instead of as float64 atomics afterwards)
+    u32* pair_off = nullptr;    // [pair_T * pair_T + 1] first pair of tile (bm, bn), bm <= bn
+    uint2* pairs = nullptr;     // .x = row in tile | col in tile << 7, .y = value
+    int pair_T = 0;             // tiles per side; 0: not built
+    i64 n_pairs = 0;            // capacity of pairs[] (an upper bound: rare entries * (low_df - 1) / 2)
+    i64 rare_entries = 0;       // entries of all rare labels' lists
     double* K = nullptr;        // last Gram output (device)
     i64 K_rows = 0, K_cols = 0;
     double last_flops = 0, last_ms = 0;

@@ -579,6 +579,7 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
         if (GM_META_NNZ + k != GM_META_OVF) f->nnz += h[GM_META_NNZ + k];
     }
     const i64 rare_entries = h[GM_META_RARE_ENTRIES];
+    f->rare_entries = rare_entries;
     // ---- operand: [secondary int8 | primary], 128-byte K-steps (features.hip has the rationale)
     const i64 n1p = round_up(f->n_cols1, f->phi_fp4 ? 256 : 128);
     i64 n8p = round_up(f->n_cols8, 128);

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
     int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int n_ids, i64 M_store, unsigned* __restrict__ xcc_ticket,
-    i64 ldk, i64 col_base, int even_in) {
+    i64 ldk, i64 col_base, int even_in, const u32* __restrict__ pair_off, const uint2* __restrict__ pairs, int pair_T) {
     constexpr int BM = GT_BM, BN = GT_BM, TM = 2, TN = 2, PPW = 8;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -600,7 +600,44 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
             }
         }
     };
-    const int upc = k_steps > 0 ? (64 + k_steps - 1) / k_steps : 64;           // general path: units per K-step (a mirrored tile has 64 per wave)
+    const int k_first = 0, k_out = k_steps;
+    const int upc = k_out > 0 ? (64 + k_out - 1) / k_out : 64;                 // general path: units per K-step (a mirrored tile has 64 per wave)
+
+    // ---- rare labels' pair updates, folded into the tile (pairs != nullptr): right after parking its quadrant of a tile a
+    // multiplying wave reads the tile's pair list and adds the values that fall into ITS OWN quadrant to the parked entries
+    // with LDS atomics -- LDS executes a wave's instructions in order, so no barrier is needed between its own park and its
+    // own adds, and the adds are complete (lgkmcnt) before the wave reaches the next K-step barrier, after which the store
+    // waves start on the tile.  The multiplying waves have no other vector-memory traffic and wait at that barrier anyway.
+    // Integer values: exact in the float32 / int32 the tile is parked in.  A tile on the diagonal holds (r, c) and (c, r).
+    const bool fold = pairs != nullptr;
+    auto pairs_apply = [&](const WsTile& t) __attribute__((always_inline)) {
+        const int idx = t.bm * pair_T + t.bn;
+        const int lo = (int)pair_off[idx], hi = (int)pair_off[idx + 1];
+        const bool diag = t.bm == t.bn;
+        for (int j0 = lo; j0 < hi; j0 += 256) {
+            uint2 p[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = j0 + lane + 64 * i;
+                p[i] = j < hi ? pairs[j] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (j0 + lane + 64 * i >= hi) continue;
+                const int r = (int)(p[i].x & 127u), c = (int)((p[i].x >> 7) & 127u);
+                const bool own = (r >> 6) == wm && (c >> 6) == wn, own_t = diag && (c >> 6) == wm && (r >> 6) == wn;
+                const unsigned a0 = out_lds + (unsigned)ws_out_addr(r, c), a1 = out_lds + (unsigned)ws_out_addr(c, r);
+                if (FP4) {
+                    const float v = (float)p[i].y;
+                    if (own) asm volatile("ds_add_f32 %0, %1" ::"v"(a0), "v"(v) : "memory");
+                    if (own_t) asm volatile("ds_add_f32 %0, %1" ::"v"(a1), "v"(v) : "memory");
+                } else {
+                    if (own) asm volatile("ds_add_u32 %0, %1" ::"v"(a0), "v"(p[i].y) : "memory");
+                    if (own_t) asm volatile("ds_add_u32 %0, %1" ::"v"(a1), "v"(p[i].y) : "memory");
+                }
+            }
+        }
+    };
 
     WS_DBG_DECL
     // ---- main loops: one per role, with the same barrier sequence (k_steps + 1 per tile, one at the end).
@@ -651,6 +688,10 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
                         asm volatile("ds_write_b128 %0, %1" ::"v"(out_lds + (unsigned)ws_out_addr(rtile, ctile)), "v"(t) : "memory");
                     }
                 }
+            if (fold) {
+                pairs_apply(cur);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the adds are in before the next barrier
+            }
             WS_ZERO_ACC()
             cur = ws_next_tile(cur.id, stride, n_ids, tiles_m, tiles_n, tri, patch);
             WS_DBG_ADD(t_walk)
@@ -686,15 +727,15 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
         WS_DBG_OUT(2)
     } else {
         while (cur.ok) {
-            int due = 0, next_b = 0;               // batches spread evenly over the K-steps: due += batches, one leaves per k_steps
+            int due = 0, next_b = 0;               // batches spread evenly over the K-steps: due += batches, one leaves per k_out
             for (int kt = 0; kt < k_steps; ++kt) {
                 WS_DBG_T0()
                 if (!NO_BAR && !(HALF_BAR && (kt & 1))) __builtin_amdgcn_s_barrier();
                 WS_DBG_ADD(t_bar)
-                if (prv.ok && !NO_CHUNK) {
+                if (prv.ok && !NO_CHUNK && kt >= k_first) {          // folding: the pair updates land during the first K-step
                     if (prv_plain) {
-                        for (due += prv_batches; due >= k_steps; due -= k_steps) store_batch(next_b++);
-                    } else store_units(kt * upc, (kt + 1) * upc);
+                        for (due += prv_batches; due >= k_out; due -= k_out) store_batch(next_b++);
+                    } else store_units((kt - k_first) * upc, (kt - k_first + 1) * upc);
                 }
                 WS_DBG_ADD(t_body)
             }
@@ -984,8 +1025,101 @@ __global__ __launch_bounds__(DD_THREADS) void gram_dd_kernel(
 #undef DD_VAL
 }
 
+// ---------------------------------------------------------------------------------------
+// Rare labels' pair updates binned by output tile (for gram_ws_kernel's fold-in).  One wave per rare label walks its
+// df * (df - 1) / 2 unordered pairs of entries: pass 0 counts them per tile (bm <= bn), a single-workgroup scan turns the
+// counts into offsets, pass 1 writes {row in tile | col in tile << 7, value}.  No host synchronisation: the pair array is
+// sized by the bound rare entries * (low_df - 1) / 2.
+// ---------------------------------------------------------------------------------------
+__global__ void gram_pairs_kernel(const i32* __restrict__ low_q, i64 n_low, const u32* __restrict__ roff,
+                                  const u32* __restrict__ df, const i32* __restrict__ lgraph, const i32* __restrict__ lcnt,
+                                  int minsum, int T, u32* __restrict__ counter, const u32* __restrict__ off,
+                                  uint2* __restrict__ out, int fill) {
+    const i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_low) return;
+    const i32 q = low_q[w];
+    const u32 t0 = roff[q];
+    const int m = (int)df[q];
+    for (int p = lane; p < m * m; p += 64) {
+        const int ia = p / m, ib = p - ia * m;
+        if (ia >= ib) continue;
+        const i32 ga = lgraph[t0 + ia], gb = lgraph[t0 + ib];
+        if (ga == gb) continue;
+        const i32 r = ga < gb ? ga : gb, c = ga < gb ? gb : ga;
+        const int tile = (r >> 7) * T + (c >> 7);
+        if (!fill) atomicAdd(&counter[tile], 1u);
+        else {
+            const u32 pos = off[tile] + atomicAdd(&counter[tile], 1u);
+            const u32 ca = (u32)lcnt[t0 + ia], cb = (u32)lcnt[t0 + ib];
+            out[pos] = make_uint2((u32)(r & 127) | ((u32)(c & 127) << 7), minsum ? (ca < cb ? ca : cb) : ca * cb);
+        }
+    }
+}
+
+// exclusive scan of cnt[0..n) into off[0..n], off[n] = total; cnt is zeroed (it becomes the fill pass's cursor)
+__global__ __launch_bounds__(1024) void gram_pairs_scan_kernel(u32* __restrict__ cnt, int n, u32* __restrict__ off) {
+    __shared__ u32 part[1024];
+    const int tid = threadIdx.x, per = (n + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < n ? lo + per : n;
+    u32 sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const u32 v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = part[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+        const u32 c = cnt[i];
+        off[i] = run, run += c;
+        cnt[i] = 0;
+    }
+    if (tid == 1023) off[n] = part[1023];
+}
+
+static int gram_build_pairs(gk_ctx* ctx, gk_feat* f) {
+    const i64 N = f->n_graphs;
+    const int T = (int)cdiv(N, GT_BM);
+    const i64 cap = std::max<i64>(1, f->rare_entries * (i64)(f->low_df > 1 ? f->low_df - 1 : 1) / 2);
+    void* q = nullptr;
+    GK_TRY(gk_dev_alloc(ctx, &q, ((size_t)T * T + 1) * 4));
+    f->pair_off = (u32*)q, f->arena.push_back(q);
+    GK_TRY(gk_dev_alloc(ctx, &q, (size_t)cap * 8));
+    f->pairs = (uint2*)q, f->arena.push_back(q);
+    f->n_pairs = cap;
+    Tmp<u32> cnt(ctx);
+    GK_TRY(cnt.alloc((size_t)T * T));
+    GK_TRY(gk_zero_async(ctx, cnt.p, (size_t)T * T * 4));
+    const dim3 grid((unsigned)cdiv(f->n_low_cols * 64, 256)), block(256);
+    const int minsum = f->kind == GK_FEAT_MINSUM ? 1 : 0;
+    gram_pairs_kernel<<<grid, block, 0, ctx->stream>>>(f->gm_low_q, f->n_low_cols, f->gm_roff, f->gm_df, f->gm_low_graph,
+                                                      f->gm_low_cnt, minsum, T, cnt.p, nullptr, nullptr, 0);
+    gram_pairs_scan_kernel<<<1, 1024, 0, ctx->stream>>>(cnt.p, T * T, f->pair_off);
+    gram_pairs_kernel<<<grid, block, 0, ctx->stream>>>(f->gm_low_q, f->n_low_cols, f->gm_roff, f->gm_df, f->gm_low_graph,
+                                                      f->gm_low_cnt, minsum, T, cnt.p, f->pair_off, f->pairs, 1);
+    GK_HIP_CHECK(hipGetLastError());
+    f->pair_T = T;
+    return GK_OK;
+}
+
+// which kernel form launch_tiles takes for a job: 0 plain tile kernel, 1 gram_ws_kernel, 2 gram_dd_kernel
+static int tiles_kernel_form(gk_ctx* ctx, gk_feat* f, i64 M, i64 n_cols, int tri) {
+    if (ctx->opt.gram_no_ws) return 0;
+    // the direct-store form wins while the job is a few tiles per CU (measured, fp4 operands: N = 2000 0.035 vs 0.050 ms,
+    // N = 4000 0.070 vs 0.079, N = 6000 0.132 vs 0.110; int8-only operands lose at 561 tiles: 0.170 vs 0.140);
+    // option gram.dd: 0 = this rule, 1 = always, 2 = never
+    const i64 tiles_m = cdiv(M, GT_BM), tiles_n = cdiv(n_cols, GT_BM);
+    const i64 real_tiles = tri ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+    return (ctx->opt.gram_dd == 1 || (ctx->opt.gram_dd == 0 && f->phi_fp4 && real_tiles <= 600)) ? 2 : 1;
+}
+
 static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
-                        i64 row_lo, int normalize, double* K, int tri, int patch, double* entries_done, i64 ldk, i64 col_lo) {
+                        i64 row_lo, int normalize, double* K, int tri, int patch, double* entries_done, i64 ldk, i64 col_lo,
+                        bool want_fold, bool* folded) {
     // a / b: operand rows of the job's first row / first column; K: the job's entry (0, 0)
     const int even = ((uintptr_t)K % 16 == 0 && ldk % 2 == 0) ? 1 : 0;      // 16-byte stores of two float64
     const int tiles_m = (int)cdiv(M, GT_BM), tiles_n = (int)cdiv(n_cols, GT_BM);
@@ -1000,12 +1134,9 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
     // library has none of this.  GK_GRAM_ABL = bit mask, see gram_ws_kernel
     if (const char* abl = getenv("GK_GRAM_ABL")) abl_bits = atoi(abl);
 #endif
-    const bool use_ws = !ctx->opt.gram_no_ws;
-    // which persistent form: the direct-store form wins while the job is a few tiles per CU (measured, fp4 operands:
-    // N = 2000 0.035 vs 0.051 ms, N = 4000 0.071 vs 0.084, N = 6000 0.132 vs 0.117; int8-only operands lose at 561 tiles:
-    // 0.170 vs 0.140); option gram.dd: 0 = this rule, 1 = always, 2 = never
-    const i64 real_tiles = tri ? (i64)tiles_m * (tiles_m + 1) / 2 : (i64)tiles_m * tiles_n;
-    const bool use_dd = use_ws && (ctx->opt.gram_dd == 1 || (ctx->opt.gram_dd == 0 && f->phi_fp4 && real_tiles <= 600));
+    const int form = tiles_kernel_form(ctx, f, M, n_cols, tri);
+    const bool use_ws = form != 0, use_dd = form == 2;
+    *folded = false;
     if (use_dd) {
         const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
         const i64 grid = blocks < n_cu ? blocks : n_cu;
@@ -1025,7 +1156,7 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
             ticket = ticket_buf.p;
         }
         void (*kern)(const int8_t*, const int8_t*, i64, int, int, const u64*, double*, i64, i64, i64, int, i64, int, int, int,
-                     int, int, int, i64, unsigned*, i64, i64, int) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
+                     int, int, int, i64, unsigned*, i64, i64, int, const u32*, const uint2*, int) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
 #ifdef GK_ABLATION
 #define WS_ABL_CASE(X) if (abl_bits == X) kern = gram_ws_kernel<true, X>;
         WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(8) WS_ABL_CASE(9) WS_ABL_CASE(10) WS_ABL_CASE(11) WS_ABL_CASE(13)
@@ -1034,9 +1165,14 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
 #endif
         (void)abl_bits;
         GK_TRY(gk_func_lds(ctx, (const void*)kern, WS_LDS_BYTES));
+        // the rare labels' pair updates go into the tiles of a full symmetric job (binned on the job's first launch)
+        const bool fold = want_fold;
+        if (fold && f->pair_T == 0) GK_TRY(gram_build_pairs(ctx, f));
+        *folded = fold;
         kern<<<dim3((unsigned)grid), dim3(WS_THREADS), WS_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
-            normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket, ldk, col_lo, even);
+            normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket, ldk, col_lo, even,
+            fold ? f->pair_off : nullptr, fold ? f->pairs : nullptr, fold ? f->pair_T : 0);
     } else if (f->phi_fp4) {
         auto kern = gram_tile_kernel<true>;
         GK_TRY(gk_func_lds(ctx, (const void*)kern, GT_LDS_BYTES));
@@ -1213,14 +1349,20 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
     double entries_done = (double)M * NC;
     const int normalize_req = normalize;
     const bool has_low = f->n_low_cols > 0, has_wide = f->n_cols_wide > 0;
-    if (has_low || has_wide) normalize = 0;   // normalise after the extra terms instead of in the epilogue
+    // the rare labels' pair updates can go INTO the tiles (gram_ws_kernel) when this is the whole symmetric matrix of a
+    // graph-major feature job; the epilogue then normalises as well, unless a float64 side operand follows
+    const bool want_fold = has_low && f->gm && f->symmetric && row_lo == 0 && col_lo == 0 && M == f->n_graphs && NC == f->n_graphs &&
+                           !ctx->opt.gram_no_fold && !ctx->opt.gram_no_sym && f->rare_entries > 0 && f->k1_steps + f->k8_steps >= 2 &&
+                           tiles_kernel_form(ctx, f, M, NC, 1) == 1;
+    bool folded = false;
+    if ((has_low && !want_fold) || has_wide) normalize = 0;   // normalise after the extra terms instead of in the epilogue
     {
         const int8_t* phi = (const int8_t*)f->phi;
         const int8_t* pa = phi + first_row_graph * f->n_cols_pad;
         const int8_t* pb = phi + col_lo * f->n_cols_pad;
         const int tri = (f->symmetric && row_lo == col_lo && row_hi == col_hi && !ctx->opt.gram_no_sym) ? 1 : 0;
         const int patch = ctx->opt.gram_no_patch ? 0 : 1;
-        GK_TRY(launch_tiles(ctx, f, pa, pb, M, NC, row_lo, normalize, K, tri, patch, &entries_done, ldk, col_lo));
+        GK_TRY(launch_tiles(ctx, f, pa, pb, M, NC, row_lo, normalize, K, tri, patch, &entries_done, ldk, col_lo, want_fold, &folded));
     }
     GK_HIP_CHECK(hipGetLastError());
     GK_HIP_CHECK(hipEventRecord(e1, ctx->stream));
@@ -1232,7 +1374,9 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
             (int)(f->n_cols_wide_pad / GD_BK), f->selfk, K, M, NC, row_lo, f->symmetric ? 1 : 0, f->n_fit, 0, tiles_n, 1,
             ldk, col_lo);
     }
-    if (has_low && f->gm) {
+    if (has_low && folded) {
+        // applied inside the tile kernel
+    } else if (has_low && f->gm) {
         gram_low_gm_kernel<<<dim3((unsigned)cdiv(f->n_low_cols * 64, 256)), dim3(256), 0, ctx->stream>>>(
             f->gm_low_q, f->n_low_cols, f->gm_roff, f->gm_df, f->gm_low_graph, f->gm_low_cnt, K, ldk, row_lo, row_hi,
             f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0, col_lo, col_hi);

@@ -527,6 +527,41 @@ def test_compact_host_copy_is_the_plain_copy(gk, gkopt, n, form):
     assert plain.max() < (65536 if form == "uint16" else 2 ** 31) and np.array_equal(plain, plain.T)
 
 
+@pytest.mark.parametrize("opts", [(), ("gram.no_fp4",), ("feat.low_df=200",), ("feat.low_df=200", "gram.no_fp4"), ("kind=1",)],
+                         ids=lambda o: "+".join(o) or "default")
+def test_rare_pair_updates_inside_the_tile_kernel_equal_the_atomic_updates(gk, gkopt, opts):
+    """A full symmetric job of the warp-specialised tile kernel takes the rare labels' pair updates INTO its parked tiles
+    (binned per tile, LDS atomics by the wave that parked the quadrant) instead of float64 atomics afterwards, and then
+    normalises in its own epilogue.  Same matrix as the atomic route (which the oracle tests pin), plain and normalised,
+    fp4 and int8 operands, dot and min-sum features, also when nearly every column is rare (thousands of pairs per tile,
+    several rounds per wave) and on diagonal tiles."""
+    from grakel_amd import GraphBatch
+    from grakel_amd.engine import get_engine
+    eng = get_engine()
+    kind = 0
+    gkopt("gram.dd", 2)                                        # small jobs would take the direct-store form, which does not fold
+    for o in opts:
+        name, _, val = o.partition("=")
+        if name == "kind":
+            kind = int(val)
+        else:
+            gkopt(name, int(val) if val else 1)
+    N = 700
+    db = eng.upload(GraphBatch(*er_dataset_csr(N, 30, 0.1, 4, 3), 4))
+    eng.wl_relabel(db, 3)
+    feat = eng.features(db, 4, kind=kind)
+    assert feat.n_cols_low > 0
+    folded, folded_n = eng.gram(feat, 0).copy(), eng.gram(feat, 2).copy()
+    gkopt("gram.no_fold", 1)
+    atomics, atomics_n = eng.gram(feat, 0).copy(), eng.gram(feat, 2).copy()
+    assert np.array_equal(folded, atomics) and np.array_equal(folded, folded.T)
+    assert np.allclose(folded_n, atomics_n, rtol=1e-14, atol=0)
+    if kind == 0:
+        wl = O.WLOracle(n_iter=3)
+        from grakel_amd.synthetic import er_dataset
+        assert np.array_equal(folded[:60, :60], wl.fit_transform(er_dataset(N, 30, 0.1, 4, 3)[:60]))
+
+
 def test_counts_above_127_take_the_f64_path(gk):
     """A label occurring > 127 times in one graph cannot be an int8 operand."""
     rs = np.random.RandomState(3)
