@@ -75,7 +75,9 @@ struct gk_opts {
     int gram_dd = 0;             // Gram kernel form with two accumulator sets and direct stores (no parked tile, five-stage ring):
                                  // 0 chosen per job (small fp4 jobs), 1 always, 2 never
     int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
-    int gram_no_fold = 0;        // rare labels' pair updates as float64 atomics after the tile kernel instead of inside it
+    int gram_pair_cap = 0;       // test hook: capacity of the per-tile pair buckets (0: four times the mean load + 128)
+    int gram_fold = 0;           // rare labels' pair updates INSIDE the tile kernel (which then normalises in its epilogue as well):
+                                 // 0 = when it pays (normalised jobs whose separate normalisation pass costs more than the binning), 1 = whenever legal, 2 = never
     int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
     int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
     // ShortestPath
@@ -293,12 +295,17 @@ struct gk_feat {
     u32* gm_roff = nullptr;     // per label index: first entry of its list
     u32* gm_df = nullptr;       // per label index: entries (graphs) of its list
     i32* gm_low_graph = nullptr, *gm_low_cnt = nullptr;    // the lists: graph, count
+    i32* gm_low_lab = nullptr;  // ... and the label index of every entry (the pair binning of gram.hip runs one thread per entry)
     // the rare labels' pair updates binned by 128x128 output tile (gram.hip: built on the first full symmetric Gram job,
     // applied to the parked tile inside gram_ws_kernel instead of as float64 atomics afterwards)
-    u32* pair_off = nullptr;    // [pair_T * pair_T + 1] first pair of tile (bm, bn), bm <= bn
-    uint2* pairs = nullptr;     // .x = row in tile | col in tile << 7, .y = value
+    u32* pair_cnt = nullptr;    // [pair_T * pair_T] pairs of tile (bm, bn), bm <= bn (may exceed pair_cap: the rest is in pair_ovf)
+    uint2* pairs = nullptr;     // bucket of tile t = pairs[t * pair_cap ...]: .x = row in tile | col in tile << 7, .y = value
     int pair_T = 0;             // tiles per side; 0: not built
-    i64 n_pairs = 0;            // capacity of pairs[] (an upper bound: rare entries * (low_df - 1) / 2)
+    int pair_cap = 0;           // bucket capacity
+    uint4* pair_ovf = nullptr;  // pairs that found their bucket full: (row, col, value, -), applied as float64 atomics afterwards
+    u32* pair_ovf_n = nullptr;
+    double* rs = nullptr;       // [n_graphs] 1 / sqrt(selfk): normalised jobs' lean store path (gram.hip)
+    i64 pair_ovf_cap = 0;
     i64 rare_entries = 0;       // entries of all rare labels' lists
     double* K = nullptr;        // last Gram output (device)
     i64 K_rows = 0, K_cols = 0;

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
                                                       const u32* __restrict__ cnt, const u32* __restrict__ ent_n, i64 n_graphs,
                                                       int8_t* __restrict__ phi, i64 ld, i64 prim0 /* first byte of the primary region */,
                                                       int fp4, int kind, double* __restrict__ phi_w, i64 ldw,
-                                                      i32* __restrict__ low_graph, i32* __restrict__ low_cnt) {
+                                                      i32* __restrict__ low_graph, i32* __restrict__ low_cnt, i32* __restrict__ low_lab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row[];
     const i64 g = blockIdx.x;
     const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
         } else if (col <= -4) phi_w[g * ldw + (-4 - col)] = (double)c;
         else if (col == -2) {
             const u32 pos = A.roff[q] + atomicAdd(&A.cursor[q], 1u);
-            low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c;
+            low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c, low_lab[pos] = (i32)q;
         }
     }
     __syncthreads();
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
                                                            const u32* __restrict__ cnt, const u32* __restrict__ ent_n, i64 n_graphs,
                                                            int8_t* __restrict__ phi, i64 ld, i64 prim0, int fp4, int kind,
                                                            double* __restrict__ phi_w, i64 ldw, i32* __restrict__ low_graph,
-                                                           i32* __restrict__ low_cnt) {
+                                                           i32* __restrict__ low_cnt, i32* __restrict__ low_lab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row_all[];
     __shared__ u32 slots_all[4][FEAT_MAX_LEVELS];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
         } else if (col <= -4) phi_w[g * ldw + (-4 - col)] = (double)c;
         else if (col == -2) {
             const u32 pos = A.roff[q] + atomicAdd(&A.cursor[q], 1u);
-            low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c;
+            low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c, low_lab[pos] = (i32)q;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -600,11 +600,14 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     }
     i32* lg = nullptr;
     i32* lc = nullptr;
+    i32* ll = nullptr;
     if (rare_entries > 0) {
         GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
         lg = (i32*)q, f->arena.push_back(q);
         GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
         lc = (i32*)q, f->arena.push_back(q);
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)rare_entries * 4));
+        ll = (i32*)q, f->arena.push_back(q);
     }
     GK_TRY(gk_func_lds(ctx, (const void*)gm_rows_kernel, (int)f->n_cols_pad));
     // one workgroup per graph (64- and 128-thread workgroups measured the same 30 us: the chain of dependent loads
@@ -612,17 +615,17 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     if (f->n_cols_pad <= GM_ROW_WAVE_MAX && !ctx->opt.gm_rows_wg)       // small rows: a wave per graph, four graphs per workgroup
         gm_rows_wave_kernel<<<dim3((unsigned)cdiv(N, 4)), 256, (size_t)f->n_cols_pad * 4, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-            f->n_cols_wide_pad, lg, lc);
+            f->n_cols_wide_pad, lg, lc, ll);
     else
         gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-            f->n_cols_wide_pad, lg, lc);
+            f->n_cols_wide_pad, lg, lc, ll);
     const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
     gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
     GK_HIP_CHECK(hipGetLastError());
     // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries
     f->gm = true;
-    f->gm_low_q = A.low_q, f->gm_roff = A.roff, f->gm_low_graph = lg, f->gm_low_cnt = lc;
+    f->gm_low_q = A.low_q, f->gm_roff = A.roff, f->gm_low_graph = lg, f->gm_low_cnt = lc, f->gm_low_lab = ll;
     // df is read by the pair-update kernel: keep it (moves out of the zeroed temporary)
     {
         GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));

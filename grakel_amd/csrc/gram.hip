@@ -332,6 +332,18 @@ __device__ __forceinline__ WsTile ws_next_tile(int id, int stride, int n_ids, in
     return t;
 }
 
+// numpy.nan_to_num of a normalised entry (mode 2), as finish_entry does
+__device__ __forceinline__ double ws_fix(double v, int normalize) {
+    if (normalize == 2) {          // wave-uniform; selects, no divergent branches in the store role
+        const double m = __builtin_fmin(v, 1.7976931348623157e308);
+        v = (v != v) ? 0.0 : m;
+    }
+    return v;
+}
+__device__ __forceinline__ double ws_readlane_f64(double v, int l) {      // l wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 // parked tile: entry (row, col) of the 128x128 tile as a 32-bit word at
 __device__ __forceinline__ int ws_out_addr(int row, int col) {
     return col * (GT_BM * 4) + ((((row >> 2) ^ (col & 31)) << 4) | ((row & 3) << 2));
@@ -359,12 +371,16 @@ __device__ unsigned long long g_ws_dbg[3][4];
 // ABL (tools' build only, timing ablations with WRONG results), a bit mask: 1 no operand loads, 2 the multiplying waves
 // skip their K-steps, 4 MFMAs on fabricated fragments (no LDS reads), 8 no stores, 16 no per-K-step barrier, 32 the store
 // waves skip their chunks altogether, 64 no parking of finished tiles, 128 K-step barrier only every second step (races: timing only)
-template <bool FP4, int ABL>
+// FULL: the variant that can also take the rare labels' pair updates into its tiles, normalise in the lean store path and
+// keep diagonal tiles lean; the plain variant carries none of that code -- its store role is instruction-bound, and every
+// wave-uniform test more costs the unnormalised default ~4 %
+template <bool FP4, int ABL, bool FULL = false>
 __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, i64 ld, int k_steps, int k8_steps,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
     int symmetric, i64 n_fit, int normalize, int tiles_m, int tiles_n, int tri, int patch, int n_ids, i64 M_store, unsigned* __restrict__ xcc_ticket,
-    i64 ldk, i64 col_base, int even_in, const u32* __restrict__ pair_off, const uint2* __restrict__ pairs, int pair_T) {
+    i64 ldk, i64 col_base, int even_in, const u32* __restrict__ pair_cnt, const uint2* __restrict__ pairs, int pair_T, int pair_cap,
+    const double* __restrict__ rs) {
     constexpr int BM = GT_BM, BN = GT_BM, TM = 2, TN = 2, PPW = 8;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -558,10 +574,39 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
     int prv_batches = 0;                 // 8 batches of tile rows, 8 more of transposed rows for a mirrored tile
     double* dst_rows = nullptr;          // K row of tile row 32 sw, column of tile column e
     double* dst_cols = nullptr;          // the same for the transposed tile
+    // normalised jobs (rs = 1 / sqrt(self similarity) per graph, float64): entry * rs[row] * rs[col] in the lean path --
+    // within 2 ulp of the reference's entry / sqrt(K_ii K_jj); tiles that touch the diagonal take the general path, whose
+    // finish_entry is the reference's formula (the diagonal is exactly 1)
+    const bool scaled = FULL && normalize != 0 && rs != nullptr;
+    const i64 rs_row0 = (symmetric ? 0 : n_fit) + row_base;       // rs index of the job's row 0
+    double cf0 = 1.0, cf1 = 1.0, tf0 = 1.0, tf1 = 1.0;   // column factors of the lane: tile columns e, e + 1 | transposed tile
+    bool prv_diag = false;
+    int fix_mode = 0;
+    double dgv = 0.0;                    // diagonal tile: the value of entry (r, r) for tile row r = 32 sw + (lane & 31)
+    double rfv = 1.0;                    // row factors, one per lane: lanes 0-31 rs of tile rows 32 sw + lane, lanes 32-63 of the
+                                         // transposed tile's rows 32 sw + lane - 32 (read back with v_readlane: no memory
+                                         // access, hence no wait for the wave's own stores, per row)
     auto tile_setup = [&]() __attribute__((always_inline)) {
         const bool mirror = tri && prv.bm != prv.bn;
         const i64 d0 = row_base + (i64)prv.bm * BM - col_base - (i64)prv.bn * BN;
-        prv_plain = normalize == 0 && !(symmetric && d0 > -BM && d0 < BN) && even &&
+        // a tile exactly on the diagonal of a symmetric job stays lean: entry (r, r) is the exact self similarity
+        // (normalised: 1, or what 0/0 gives for a graph without features), one value per lane for the wave's 32 rows
+        prv_diag = FULL && symmetric && d0 == 0;
+        fix_mode = 0;
+        if (scaled) {
+            const double* cr = rs + col_base + (i64)prv.bn * BN;           // factors of the tile's columns
+            const double* rr = rs + rs_row0 + (i64)prv.bm * BM;            // ... of its rows
+            cf0 = cr[e], cf1 = cr[e + 1], tf0 = rr[e], tf1 = rr[e + 1];
+            rfv = lane < 32 ? rr[sw * 32 + lane] : cr[sw * 32 + lane - 32];
+            // numpy.nan_to_num only matters when a factor is infinite (a graph without features): wave-uniform, rare
+            const bool odd = !(cf0 <= 1.0) || !(cf1 <= 1.0) || !(tf0 <= 1.0) || !(tf1 <= 1.0) || !(rfv <= 1.0);
+            fix_mode = (normalize == 2 && __builtin_amdgcn_ballot_w64(odd) != 0ull) ? 2 : 0;
+        }
+        if (prv_diag) {
+            const u64 sk = selfk[rs_row0 + (i64)prv.bm * BM + sw * 32 + (lane & 31)];
+            dgv = normalize == 0 ? (double)sk : (sk != 0 ? 1.0 : (normalize == 2 ? 0.0 : __builtin_nan("")));
+        }
+        prv_plain = (normalize == 0 || scaled) && !(symmetric && d0 > -BM && d0 < BN && !prv_diag) && even &&
                     ((i64)prv.bm + 1) * BM <= M_store && ((i64)prv.bn + 1) * BN <= N &&
                     (!mirror || (((i64)prv.bn + 1) * BN <= M_store && ((i64)prv.bm + 1) * BM <= N));
         prv_batches = mirror ? 16 : 8;
@@ -578,7 +623,16 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
             double* const d = dst_rows + (i64)(4 * b) * ldk;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const v2d v = {WS_VAL(x0[q]), WS_VAL(x1[q])};
+                v2d v = {WS_VAL(x0[q]), WS_VAL(x1[q])};
+                if (scaled) {
+                    const double rf = ws_readlane_f64(rfv, 4 * b + q);
+                    v.x = ws_fix(v.x * rf * cf0, fix_mode), v.y = ws_fix(v.y * rf * cf1, fix_mode);
+                }
+                if (prv_diag) {                                        // wave-uniform
+                    const int rt = sw * 32 + 4 * b + q;
+                    const double dv = ws_readlane_f64(dgv, 4 * b + q);
+                    v.x = e == rt ? dv : v.x, v.y = e + 1 == rt ? dv : v.y;
+                }
                 if (!NO_STORE) __builtin_nontemporal_store(v, (v2d*)(d + (i64)q * ldk));
                 else if (v.x == 1.2345e300) d[0] = v.y;
             }
@@ -594,7 +648,11 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
             double* const d = dst_cols + (i64)(4 * (b - 8)) * ldk;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const v2d v = {WS_VAL(x[q].x), WS_VAL(x[q].y)};
+                v2d v = {WS_VAL(x[q].x), WS_VAL(x[q].y)};
+                if (scaled) {
+                    const double rf = ws_readlane_f64(rfv, 32 + 4 * (b - 8) + q);
+                    v.x = ws_fix(v.x * rf * tf0, fix_mode), v.y = ws_fix(v.y * rf * tf1, fix_mode);
+                }
                 if (!NO_STORE) __builtin_nontemporal_store(v, (v2d*)(d + (i64)q * ldk));
                 else if (v.x == 1.2345e300) d[0] = v.y;
             }
@@ -609,17 +667,19 @@ __global__ __launch_bounds__(WS_THREADS) void gram_ws_kernel(
     // own adds, and the adds are complete (lgkmcnt) before the wave reaches the next K-step barrier, after which the store
     // waves start on the tile.  The multiplying waves have no other vector-memory traffic and wait at that barrier anyway.
     // Integer values: exact in the float32 / int32 the tile is parked in.  A tile on the diagonal holds (r, c) and (c, r).
-    const bool fold = pairs != nullptr;
+    const bool fold = FULL && pairs != nullptr;
     auto pairs_apply = [&](const WsTile& t) __attribute__((always_inline)) {
         const int idx = t.bm * pair_T + t.bn;
-        const int lo = (int)pair_off[idx], hi = (int)pair_off[idx + 1];
+        const int n = (int)pair_cnt[idx];
+        const int hi = n < pair_cap ? n : pair_cap;          // the rest sits in the overflow list
+        const uint2* __restrict__ bucket = pairs + (i64)idx * pair_cap;
         const bool diag = t.bm == t.bn;
-        for (int j0 = lo; j0 < hi; j0 += 256) {
+        for (int j0 = 0; j0 < hi; j0 += 256) {
             uint2 p[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int j = j0 + lane + 64 * i;
-                p[i] = j < hi ? pairs[j] : make_uint2(0u, 0u);
+                p[i] = j < hi ? bucket[j] : make_uint2(0u, 0u);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1026,81 +1086,91 @@ __global__ __launch_bounds__(DD_THREADS) void gram_dd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Rare labels' pair updates binned by output tile (for gram_ws_kernel's fold-in).  One wave per rare label walks its
-// df * (df - 1) / 2 unordered pairs of entries: pass 0 counts them per tile (bm <= bn), a single-workgroup scan turns the
-// counts into offsets, pass 1 writes {row in tile | col in tile << 7, value}.  No host synchronisation: the pair array is
-// sized by the bound rare entries * (low_df - 1) / 2.
+// Rare labels' pair updates binned by output tile (for gram_ws_kernel's fold-in), in ONE pass: a thread per entry
+// (label, graph a) walks the later entries (graph b) of its label's list and drops {row in tile | col in tile << 7, value}
+// into the bucket of tile (min(a,b) / 128, max(a,b) / 128) -- a slot from the tile's counter.  Buckets have a fixed
+// capacity (four times the mean load + 128); a pair that finds its bucket full goes to an overflow list that a small
+// kernel applies as float64 atomics after the tile kernel (normalised there if the job is).  No host synchronisation.
 // ---------------------------------------------------------------------------------------
-__global__ void gram_pairs_kernel(const i32* __restrict__ low_q, i64 n_low, const u32* __restrict__ roff,
-                                  const u32* __restrict__ df, const i32* __restrict__ lgraph, const i32* __restrict__ lcnt,
-                                  int minsum, int T, u32* __restrict__ counter, const u32* __restrict__ off,
-                                  uint2* __restrict__ out, int fill) {
-    const i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (w >= n_low) return;
-    const i32 q = low_q[w];
+__global__ void gram_bin_pairs_kernel(const i32* __restrict__ low_lab, const u32* __restrict__ roff, const u32* __restrict__ df,
+                                      const i32* __restrict__ lgraph, const i32* __restrict__ lcnt, i64 n_entries, int minsum,
+                                      int T, int cap, u32* __restrict__ tile_cnt, uint2* __restrict__ bucket,
+                                      u32* __restrict__ ovf_n, uint4* __restrict__ ovf, u32 ovf_cap) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const i32 q = low_lab[e];
     const u32 t0 = roff[q];
-    const int m = (int)df[q];
-    for (int p = lane; p < m * m; p += 64) {
-        const int ia = p / m, ib = p - ia * m;
-        if (ia >= ib) continue;
-        const i32 ga = lgraph[t0 + ia], gb = lgraph[t0 + ib];
+    const int m = (int)df[q], ia = (int)(e - (i64)t0);
+    const i32 ga = lgraph[e];
+    const u32 ca = (u32)lcnt[e];
+#pragma unroll 4
+    for (int ib = ia + 1; ib < m; ++ib) {
+        const i32 gb = lgraph[t0 + ib];
+        const u32 cb = (u32)lcnt[t0 + ib];
         if (ga == gb) continue;
         const i32 r = ga < gb ? ga : gb, c = ga < gb ? gb : ga;
         const int tile = (r >> 7) * T + (c >> 7);
-        if (!fill) atomicAdd(&counter[tile], 1u);
+        const u32 value = minsum ? (ca < cb ? ca : cb) : ca * cb;
+        const u32 pos = atomicAdd(&tile_cnt[tile], 1u);
+        if (pos < (u32)cap) bucket[(i64)tile * cap + pos] = make_uint2((u32)(r & 127) | ((u32)(c & 127) << 7), value);
         else {
-            const u32 pos = off[tile] + atomicAdd(&counter[tile], 1u);
-            const u32 ca = (u32)lcnt[t0 + ia], cb = (u32)lcnt[t0 + ib];
-            out[pos] = make_uint2((u32)(r & 127) | ((u32)(c & 127) << 7), minsum ? (ca < cb ? ca : cb) : ca * cb);
+            const u32 o = atomicAdd(ovf_n, 1u);
+            if (o < ovf_cap) ovf[o] = make_uint4((u32)r, (u32)c, value, 0u);
         }
     }
 }
 
-// exclusive scan of cnt[0..n) into off[0..n], off[n] = total; cnt is zeroed (it becomes the fill pass's cursor)
-__global__ __launch_bounds__(1024) void gram_pairs_scan_kernel(u32* __restrict__ cnt, int n, u32* __restrict__ off) {
-    __shared__ u32 part[1024];
-    const int tid = threadIdx.x, per = (n + 1023) / 1024;
-    const int lo = tid * per, hi = lo + per < n ? lo + per : n;
-    u32 sum = 0;
-    for (int i = lo; i < hi; ++i) sum += cnt[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const u32 v = tid >= d ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+// the overflow list (usually empty): K[r][c] += v, K[c][r] += v; a normalised job gets the normalised contribution
+__global__ void gram_pairs_overflow_kernel(const u32* __restrict__ ovf_n, const uint4* __restrict__ ovf, u32 ovf_cap,
+                                           double* __restrict__ K, i64 ldk, const u64* __restrict__ selfk, int normalize) {
+    const u32 n = *ovf_n < ovf_cap ? *ovf_n : ovf_cap;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint4 p = ovf[i];
+        double v = (double)p.z;
+        if (normalize) v /= sqrt((double)selfk[p.x] * (double)selfk[p.y]);
+        atomicAdd(&K[(i64)p.x * ldk + p.y], v);
+        atomicAdd(&K[(i64)p.y * ldk + p.x], v);
     }
-    u32 run = part[tid] - sum;
-    for (int i = lo; i < hi; ++i) {
-        const u32 c = cnt[i];
-        off[i] = run, run += c;
-        cnt[i] = 0;
-    }
-    if (tid == 1023) off[n] = part[1023];
+}
+
+// rs[g] = 1 / sqrt(self similarity of graph g): the lean store path of a normalised job multiplies by two of these
+__global__ void gram_rs_kernel(const u64* __restrict__ selfk, i64 n, double* __restrict__ rs) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rs[i] = 1.0 / sqrt((double)selfk[i]);
+}
+
+// Does the fold-in pay?  Measured (config 3, 10 000 graphs): binning 48 us + 8 us inside the tile kernel against 46 us of
+// float64 atomics -- a loss -- unless the job is normalised: the atomics route then needs a separate pass over the whole
+// matrix (0.3 ms there).  The binning kernel is bound by same-address atomics on the tile counters (~0.1 us each in
+// series: ShortestPath's 4 110 graphs with 2 000 pairs per tile took 232 us), the normalisation pass by 16 N^2 bytes.
+static bool gram_fold_pays(const gk_feat* f, int normalize) {
+    if (!normalize) return false;
+    const double N = (double)f->n_graphs, T = ceil(N / GT_BM), tiles = T * (T + 1) / 2;
+    const double bound = (double)f->rare_entries * (double)(f->low_df > 1 ? f->low_df - 1 : 1) / 2;
+    return 20.0 + 0.1 * bound / tiles < 16.0 * N * N / 5.0e6;          // microseconds
 }
 
 static int gram_build_pairs(gk_ctx* ctx, gk_feat* f) {
     const i64 N = f->n_graphs;
     const int T = (int)cdiv(N, GT_BM);
-    const i64 cap = std::max<i64>(1, f->rare_entries * (i64)(f->low_df > 1 ? f->low_df - 1 : 1) / 2);
+    const i64 bound = std::max<i64>(1, f->rare_entries * (i64)(f->low_df > 1 ? f->low_df - 1 : 1) / 2);     // pairs at most
+    const i64 tiles = (i64)T * (T + 1) / 2;
+    i64 cap = 4 * cdiv(bound, tiles) + 128;
+    if (cap > 4096) cap = 4096;
+    if (ctx->opt.gram_pair_cap > 0) cap = ctx->opt.gram_pair_cap;
     void* q = nullptr;
     GK_TRY(gk_dev_alloc(ctx, &q, ((size_t)T * T + 1) * 4));
-    f->pair_off = (u32*)q, f->arena.push_back(q);
-    GK_TRY(gk_dev_alloc(ctx, &q, (size_t)cap * 8));
+    f->pair_cnt = (u32*)q, f->arena.push_back(q);
+    f->pair_ovf_n = f->pair_cnt + (size_t)T * T;
+    GK_TRY(gk_dev_alloc(ctx, &q, (size_t)T * T * (size_t)cap * 8));
     f->pairs = (uint2*)q, f->arena.push_back(q);
-    f->n_pairs = cap;
-    Tmp<u32> cnt(ctx);
-    GK_TRY(cnt.alloc((size_t)T * T));
-    GK_TRY(gk_zero_async(ctx, cnt.p, (size_t)T * T * 4));
-    const dim3 grid((unsigned)cdiv(f->n_low_cols * 64, 256)), block(256);
-    const int minsum = f->kind == GK_FEAT_MINSUM ? 1 : 0;
-    gram_pairs_kernel<<<grid, block, 0, ctx->stream>>>(f->gm_low_q, f->n_low_cols, f->gm_roff, f->gm_df, f->gm_low_graph,
-                                                      f->gm_low_cnt, minsum, T, cnt.p, nullptr, nullptr, 0);
-    gram_pairs_scan_kernel<<<1, 1024, 0, ctx->stream>>>(cnt.p, T * T, f->pair_off);
-    gram_pairs_kernel<<<grid, block, 0, ctx->stream>>>(f->gm_low_q, f->n_low_cols, f->gm_roff, f->gm_df, f->gm_low_graph,
-                                                      f->gm_low_cnt, minsum, T, cnt.p, f->pair_off, f->pairs, 1);
+    GK_TRY(gk_dev_alloc(ctx, &q, (size_t)bound * 16));
+    f->pair_ovf = (uint4*)q, f->arena.push_back(q);
+    f->pair_ovf_cap = bound, f->pair_cap = (int)cap;
+    GK_TRY(gk_zero_async(ctx, f->pair_cnt, ((size_t)T * T + 1) * 4));
+    gram_bin_pairs_kernel<<<dim3((unsigned)cdiv(f->rare_entries, 256)), dim3(256), 0, ctx->stream>>>(
+        f->gm_low_lab, f->gm_roff, f->gm_df, f->gm_low_graph, f->gm_low_cnt, f->rare_entries, f->kind == GK_FEAT_MINSUM ? 1 : 0, T,
+        (int)cap, f->pair_cnt, f->pairs, f->pair_ovf_n, f->pair_ovf, (u32)std::min<i64>(bound, 0xffffffffll));
     GK_HIP_CHECK(hipGetLastError());
     f->pair_T = T;
     return GK_OK;
@@ -1156,7 +1226,8 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
             ticket = ticket_buf.p;
         }
         void (*kern)(const int8_t*, const int8_t*, i64, int, int, const u64*, double*, i64, i64, i64, int, i64, int, int, int,
-                     int, int, int, i64, unsigned*, i64, i64, int, const u32*, const uint2*, int) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
+                     int, int, int, i64, unsigned*, i64, i64, int, const u32*, const uint2*, int, int, const double*) = f->phi_fp4 ? gram_ws_kernel<true, 0> : gram_ws_kernel<false, 0>;
+        if (want_fold || normalize) kern = f->phi_fp4 ? gram_ws_kernel<true, 0, true> : gram_ws_kernel<false, 0, true>;
 #ifdef GK_ABLATION
 #define WS_ABL_CASE(X) if (abl_bits == X) kern = gram_ws_kernel<true, X>;
         WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(8) WS_ABL_CASE(9) WS_ABL_CASE(10) WS_ABL_CASE(11) WS_ABL_CASE(13)
@@ -1167,12 +1238,12 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
         GK_TRY(gk_func_lds(ctx, (const void*)kern, WS_LDS_BYTES));
         // the rare labels' pair updates go into the tiles of a full symmetric job (binned on the job's first launch)
         const bool fold = want_fold;
-        if (fold && f->pair_T == 0) GK_TRY(gram_build_pairs(ctx, f));
         *folded = fold;
         kern<<<dim3((unsigned)grid), dim3(WS_THREADS), WS_LDS_BYTES, ctx->stream>>>(
             a, b, f->n_cols_pad, k_all, k8, f->selfk, K, M, n_cols, row_lo, f->symmetric ? 1 : 0, f->n_fit,
             normalize, tiles_m, tiles_n, tri, patch_sz, (int)blocks, M_store, ticket, ldk, col_lo, even,
-            fold ? f->pair_off : nullptr, fold ? f->pairs : nullptr, fold ? f->pair_T : 0);
+            fold ? f->pair_cnt : nullptr, fold ? f->pairs : nullptr, fold ? f->pair_T : 0, fold ? f->pair_cap : 0,
+            normalize ? f->rs : nullptr);
     } else if (f->phi_fp4) {
         auto kern = gram_tile_kernel<true>;
         GK_TRY(gk_func_lds(ctx, (const void*)kern, GT_LDS_BYTES));
@@ -1345,17 +1416,24 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
         GK_HIP_CHECK(hipEventCreate(&f->ev1));
     }
     hipEvent_t e0 = f->ev0, e1 = f->ev1;
-    GK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
     double entries_done = (double)M * NC;
     const int normalize_req = normalize;
     const bool has_low = f->n_low_cols > 0, has_wide = f->n_cols_wide > 0;
     // the rare labels' pair updates can go INTO the tiles (gram_ws_kernel) when this is the whole symmetric matrix of a
     // graph-major feature job; the epilogue then normalises as well, unless a float64 side operand follows
     const bool want_fold = has_low && f->gm && f->symmetric && row_lo == 0 && col_lo == 0 && M == f->n_graphs && NC == f->n_graphs &&
-                           !ctx->opt.gram_no_fold && !ctx->opt.gram_no_sym && f->rare_entries > 0 && f->k1_steps + f->k8_steps >= 2 &&
-                           tiles_kernel_form(ctx, f, M, NC, 1) == 1;
+                           ctx->opt.gram_fold != 2 && !ctx->opt.gram_no_sym && f->rare_entries > 0 && f->k1_steps + f->k8_steps >= 2 &&
+                           tiles_kernel_form(ctx, f, M, NC, 1) == 1 && (ctx->opt.gram_fold == 1 || gram_fold_pays(f, normalize_req));
     bool folded = false;
     if ((has_low && !want_fold) || has_wide) normalize = 0;   // normalise after the extra terms instead of in the epilogue
+    if (want_fold && f->pair_T == 0) GK_TRY(gram_build_pairs(ctx, f));          // once per feature job
+    if (normalize && !f->rs) {
+        void* q = nullptr;
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)f->n_graphs * 8));
+        f->rs = (double*)q, f->arena.push_back(q);
+        gram_rs_kernel<<<dim3((unsigned)cdiv(f->n_graphs, 256)), dim3(256), 0, ctx->stream>>>(f->selfk, f->n_graphs, f->rs);
+    }
+    GK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
     {
         const int8_t* phi = (const int8_t*)f->phi;
         const int8_t* pa = phi + first_row_graph * f->n_cols_pad;
@@ -1375,7 +1453,9 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
             ldk, col_lo);
     }
     if (has_low && folded) {
-        // applied inside the tile kernel
+        // applied inside the tile kernel; what did not fit its tile's bucket (usually nothing) follows here
+        gram_pairs_overflow_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(f->pair_ovf_n, f->pair_ovf, (u32)std::min<i64>(f->pair_ovf_cap, 0xffffffffll),
+                                                                          K, ldk, f->selfk, has_wide ? 0 : normalize_req);
     } else if (has_low && f->gm) {
         gram_low_gm_kernel<<<dim3((unsigned)cdiv(f->n_low_cols * 64, 256)), dim3(256), 0, ctx->stream>>>(
             f->gm_low_q, f->n_low_cols, f->gm_roff, f->gm_df, f->gm_low_graph, f->gm_low_cnt, K, ldk, row_lo, row_hi,
@@ -1397,7 +1477,7 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
                 P, K, ldk, row_lo, row_hi, f->symmetric ? 1 : 0, f->n_fit, f->kind == GK_FEAT_MINSUM ? 1 : 0, col_lo, col_hi);
         }
     }
-    if (has_low || has_wide) {
+    if ((has_low && !folded) || has_wide) {
         if (normalize_req) {
             GK_ARG(col_lo == 0 && ldk == NC, "gram: normalisation of a column block is applied by gk_gram_normalize_rows");
             gram_normalize_kernel<<<dim3((unsigned)cdiv(M * NC, 256)), dim3(256), 0, ctx->stream>>>(

@@ -77,6 +77,9 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "feat.gm_row_lds_max" (bytes of operand row the graph-major builder accepts: small values force the
  *             fall-back to the label-major builder)
  *   Gram:     "gram.dd" (the direct-store form of the persistent kernel: 1 always, 2 never, 0 per job) "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc"
+ *             "gram.fold" (the rare labels' pair updates inside the tile kernel, which then normalises in its epilogue too, instead of float64
+ *             atomics + a normalisation pass afterwards: 0 when it pays, 1 whenever legal, 2 never)
+ *             "gram.pair_cap" (test hook: capacity of the per-tile pair buckets of that fold-in)
  *             "gram.no_compact" (host copies of integer-valued matrices as plain float64 instead of uint16 / int32 + widening)
  *             "gram.copy_threads" (host threads of that widening; 0: min(hardware threads, 16))
  *   paths:    "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
