@@ -195,6 +195,36 @@ def test_sp_float_weights_against_reference():
     assert np.array_equal(O.SPOracle(with_labels=False).fit_transform([[g[0]] for g in tr]), z["K_fit_unlabelled"])
 
 
+def test_why_non_dyadic_float_weights_are_declined():
+    """The reference keys ShortestPath features by the float distance as computed (shortest_path.py:389,412-499): with
+    weights like 0.1 the key depends on rounding -- a path 0.1 + 0.2 (0.30000000000000004) and an edge 0.3 are DIFFERENT
+    features, and 0.1 + 0.2 + 0.3 differs from 0.3 + 0.2 + 0.1 -- so "the" matrix depends on the order in which the
+    all-pairs routine adds.  The device path counts distances as exact integer multiples of one power of two and
+    therefore declines such weights (grakel_amd.batch.quantise_weights, tests/test_host.py) instead of returning a
+    matrix that agrees with the reference only up to such coincidences.  This pins the behaviour it declines to the
+    oracle (and, in the build container, to the reference itself)."""
+    lab = {0: 'a', 1: 'b', 2: 'a'}
+    path = [np.array([[0, 0.1, 0], [0.1, 0, 0.2], [0, 0.2, 0]]), lab]           # a -0.1- b -0.2- a
+    edge = [np.array([[0, 0, 0.3], [0, 0, 0], [0.3, 0, 0]]), lab]               # a -0.3- a, b apart
+    assert 0.1 + 0.2 != 0.3
+    K = O.SPOracle().fit_transform([path, edge])
+    # (a, a, 0.30000000000000004) twice in `path`, (a, a, 0.3) twice in `edge`: no common feature at all
+    assert K.tolist() == [[8.0, 0.0], [0.0, 4.0]]
+    exact = [np.array([[0, 0.125, 0], [0.125, 0, 0.25], [0, 0.25, 0]]), lab]    # dyadic weights: 0.125 + 0.25 == 0.375
+    edge2 = [np.array([[0, 0, 0.375], [0, 0, 0], [0.375, 0, 0]]), lab]
+    assert O.SPOracle().fit_transform([exact, edge2]).tolist() == [[8.0, 4.0], [4.0, 4.0]]
+    ref = os.environ.get("GK_REF_BUILD", "/tmp/grakel_oracle")
+    if os.path.isdir(os.path.join(ref, "grakel")):
+        import sys
+        sys.path.insert(0, ref)
+        try:
+            from grakel import ShortestPath
+        finally:
+            sys.path.remove(ref)
+        assert ShortestPath().fit_transform([path, edge]).tolist() == K.tolist()
+        assert ShortestPath().fit_transform([exact, edge2]).tolist() == [[8.0, 4.0], [4.0, 4.0]]
+
+
 def test_error_behaviour_matches_reference():
     # weisfeiler_lehman.py:143-144,193-194 ; shortest_path.py:251-252
     with pytest.raises(TypeError):
