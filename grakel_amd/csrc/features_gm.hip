@@ -612,7 +612,9 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     GK_TRY(gk_func_lds(ctx, (const void*)gm_rows_kernel, (int)f->n_cols_pad));
     // one workgroup per graph (64- and 128-thread workgroups measured the same 30 us: the chain of dependent loads
     // slot -> entry -> column id binds, not the number of workgroups in flight)
-    if (f->n_cols_pad <= GM_ROW_WAVE_MAX && !ctx->opt.gm_rows_wg)       // small rows: a wave per graph, four graphs per workgroup
+    // small rows AND few entries per graph: a wave per graph, four graphs per workgroup (config 5, ~100 entries per graph:
+    // 112 -> 85 us; ShortestPath histograms with ~10x the entries per graph: 30 us by workgroups, 76 us by waves)
+    if (f->n_cols_pad <= GM_ROW_WAVE_MAX && f->nnz <= 192 * N && !ctx->opt.gm_rows_wg)
         gm_rows_wave_kernel<<<dim3((unsigned)cdiv(N, 4)), 256, (size_t)f->n_cols_pad * 4, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
             f->n_cols_wide_pad, lg, lc, ll);
