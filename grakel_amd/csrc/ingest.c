@@ -195,19 +195,11 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
         if (n == 0 || PyDict_GET_SIZE(g) == 0) { status = ST_DECLINE; break; }
         if (V + n >= 2147483647LL) { status = ST_DECLINE; break; }
 
-        /* form of the edge dictionary: all values lists, or all values dicts (graph.py:1640-1690) */
-        int all_list = 1, all_dict = 1;
+        /* form of the edge dictionary: all values lists, or all values dicts (graph.py:1640-1690).  The row pass below
+         * sees the type of every value it uses; when it has walked the WHOLE edge dictionary in step with the labels (the
+         * usual case) that is the form check, otherwise a separate walk over g follows it */
+        int all_list = 1, all_dict = 1, seen_list = 0, seen_dict = 0;
         Py_ssize_t g_nonempty = 0;                 /* keys of g with out-edges */
-        {
-            Py_ssize_t it = 0;
-            PyObject *k, *d;
-            while (PyDict_Next(g, &it, &k, &d)) {
-                if (!PyList_CheckExact(d)) all_list = 0; else if (PyList_GET_SIZE(d) > 0) ++g_nonempty;
-                if (!PyDict_CheckExact(d)) all_dict = 0; else if (PyDict_GET_SIZE(d) > 0) ++g_nonempty;
-                if (!all_list && !all_dict) break;
-            }
-        }
-        if (!all_list && !all_dict) { status = ST_DECLINE; break; }
         if (want_mask) {
             if ((size_t)(V + n) > flag_cap) {
                 size_t nc = flag_cap ? flag_cap * 2 : 65536;
@@ -309,7 +301,12 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
             const size_t vrow = rowp.n / 4 - 1;              /* this vertex */
             size_t m = 0;
             if (d) {
-                const Py_ssize_t len = all_list ? PyList_GET_SIZE(d) : PyDict_GET_SIZE(d);
+                const int is_list = PyList_CheckExact(d);
+                if (is_list) seen_list = 1;
+                else if (PyDict_CheckExact(d)) seen_dict = 1;
+                else { status = ST_DECLINE; break; }
+                const Py_ssize_t len = is_list ? PyList_GET_SIZE(d) : PyDict_GET_SIZE(d);
+                g_nonempty += len > 0;         /* complete only if every entry of g is visited: checked below */
                 ++lab_in_g;
                 lab_nonempty += len > 0;
                 if (want_mask) flag[vrow] |= (unsigned char)(1 | (len > 0 ? 2 : 0));
@@ -317,7 +314,7 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
                 int32_t* const row = (int32_t*)(PyByteArray_AS_STRING(col.ba) + col.n);
                 int ascending = 1;           /* strictly ascending neighbour lists (the usual case) need no sort */
                 int32_t prev = -1;
-                if (all_list) {
+                if (is_list) {
                     for (Py_ssize_t q = 0; q < len; ++q) {
                         Py_ssize_t j;
                         status = neighbour_index(PyList_GET_ITEM(d, q), identity, n, pos, &j);
@@ -350,7 +347,26 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
             if (col.n / 4 >= 2147483647ULL) { status = ST_DECLINE; break; }
             *(int32_t*)(PyByteArray_AS_STRING(rowp.ba) + rowp.n) = (int32_t)(col.n / 4), rowp.n += 4;
         }
-        if (status != ST_OK) break;
+        if (status != ST_OK) {
+            /* nothing about this element's form has been established yet: whatever is wrong with it, the Python path
+             * (the behavioural reference) reports it */
+            if (PyErr_Occurred()) PyErr_Clear();
+            status = ST_DECLINE;
+            break;
+        }
+        if (lockstep && PyDict_GET_SIZE(g) == n) {           /* every entry of g was visited, once */
+            all_list = !seen_dict, all_dict = !seen_list;
+        } else {
+            g_nonempty = 0;
+            Py_ssize_t it2 = 0;
+            PyObject *k2, *d2;
+            while (PyDict_Next(g, &it2, &k2, &d2)) {
+                if (!PyList_CheckExact(d2)) all_list = 0; else if (PyList_GET_SIZE(d2) > 0) ++g_nonempty;
+                if (!PyDict_CheckExact(d2)) all_dict = 0; else if (PyDict_GET_SIZE(d2) > 0) ++g_nonempty;
+                if (!all_list && !all_dict) break;
+            }
+        }
+        if (!all_list && !all_dict) { status = ST_DECLINE; break; }
         if (want_mask) {
             /* an entry vertex without a label is the reference's KeyError: which one it names depends on
              * set order, so let the Python path raise it */
