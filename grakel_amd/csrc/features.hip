@@ -28,6 +28,7 @@
 // count is m becomes m 0/1 columns ([c>=1], [c>=2], ...), so Phi_s . Phi_s^T IS the min-sum,
 // exactly, on the int8 MFMA path; selfk[g] = sum of counts (= nodes x levels).
 #include "common.h"
+#include <math.h>
 #include "scan_fn.h"
 #include "features.h"
 #include <stdlib.h>
@@ -506,7 +507,12 @@ extern "C" int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, i
         return fail(GK_ERR_HIP);
     }
     {
-        f->low_df = ctx->opt.low_df > 0 ? ctx->opt.low_df : 24;     // df threshold below which a column leaves the dense operand
+        // df threshold below which a column leaves the dense operand and becomes pair updates.  A dense column costs ~N^2
+        // (operand traffic and MFMA time of every tile), a rare one ~df^2 float64 atomics, so the break-even grows with the
+        // job: measured optima 12 at 4 000 graphs, 24 at 10 000, 36 at 20 000 (config-3-like), 72-128 at 50 000 (config 5:
+        // step 7.7 -> 5.9 ms) -- 24 (N / 10 000)^0.75, kept within [8, 128].  Option feat.low_df fixes it.
+        const double scaled_df = 24.0 * pow((double)std::max<i64>(N, 1) / 10000.0, 0.75);
+        f->low_df = ctx->opt.low_df > 0 ? ctx->opt.low_df : (int)std::min(128.0, std::max(8.0, floor(scaled_df + 0.5)));
         if (f->low_df < 2) f->low_df = 2;        // 2 == everything useful is dense
     }
     if (!b->graph_ptr) {
