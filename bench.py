@@ -472,7 +472,7 @@ def main():
                     "algorithmic_flops": alg_flops, "gram_phase_ms": (phases or {}).get("gram")},
                 "note": "achieved = (8 bytes x rows x N of float64 K written once + the packed dense operand read once) / "
                         "avg HIP-event duration of the Gram kernel.  1 GPU: only tiles on/above the diagonal are "
-                        "multiplied, both halves are stored; label columns present in < 24 graphs never enter the dense "
+                        "multiplied, both halves are stored; label columns present in fewer graphs than the job's threshold (24 at 10 000 graphs, DESIGN.md 2) never enter the dense "
                         "operand, their exact pair updates (gram_low_kernel) are inside gram_phase_ms."},
             "phases_ms": phases,
             "phases_hbm": phases_hbm,

@@ -73,7 +73,7 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "sort.buckets" (1 never / 2 always the per-bucket finish of the sort)
  *             "wl.bd_slots" (distinct keys a bucket of the sort-free dictionary accepts: small values force its
  *             overflow and with it the second, sorting attempt)
- *   features: "feat.no_gm" "feat.gm_no_priv" "feat.gm_rows_wg" "feat.low_df" (df below which a column becomes pair updates, default 24)
+ *   features: "feat.no_gm" "feat.gm_no_priv" "feat.gm_rows_wg" "feat.low_df" (df below which a column becomes pair updates; default 24 (N / 10 000)^0.75 within [8, 128])
  *             "feat.gm_row_lds_max" (bytes of operand row the graph-major builder accepts: small values force the
  *             fall-back to the label-major builder)
  *   Gram:     "gram.dd" (the direct-store form of the persistent kernel: 1 always, 2 never, 0 per job) "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc"
@@ -188,7 +188,7 @@ int gk_features_build_ex(gk_ctx* ctx, gk_batch* b, int n_levels, int64_t n_fit, 
 int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, int level_hi, int64_t n_fit, int kind, gk_feat** out);
 int gk_features_destroy(gk_feat* f);
 /* n_cols_kept: width of the dense MFMA operand Phi_s; n_cols_low: useful but rare columns
- * (fewer than GK_LOW_DF=24 graphs) that are applied as exact pair updates after the GEMM instead;
+ * (fewer graphs than the job's threshold, option feat.low_df) that are applied as exact pair updates after the GEMM instead;
  * nnz: number of (label,graph) triples over all levels; max_count: largest single count;
  * dtype: 0 = integer operand on the fp4 / int8 MFMA path (counts 0..4 as MX fp4 codes when every Gram entry stays
  * below 2^24, counts up to 127 as int8; gk_features_operand says which), 1 = only the float64 side operand is in use. */
