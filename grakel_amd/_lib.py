@@ -73,6 +73,8 @@ SIGNATURES = {
     "gk_core_numbers": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gk_sp_build_levels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, _vpp, _i64p, _i64p]),
     "gk_sp_debug_apsp": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gk_sp_build_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, _vpp, _i64p, _i64p]),
+    "gk_sp_debug_apsp_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 

@@ -35,9 +35,14 @@ class GraphBatch(object):
     edge_weight[n_edges] or None (ShortestPath only): positive integers; the weight of an edge
     is edge_weight * weight_step (weight_step is 1.0 unless the input had float weights that are
     integer multiples of a common power of two, see quantise_weights()).
+    float_weight[n_edges] (float64) or None: ShortestPath input with OTHER positive float weights; the device then
+    reproduces the reference's float distances bit for bit (sp.hip: gk_sp_build_f64) and needs to know per graph which of
+    its two algorithms the reference's "auto" runs: from_dict[n_graphs] (uint8), 1 = the element was an edge dictionary
+    (dijkstra), 0 = an adjacency matrix (floyd_warshall).  edge_weight is None in that mode.
     """
 
-    def __init__(self, graph_ptr, row_ptr, col_idx, node_label, n_labels, edge_weight=None, weight_step=1.0):
+    def __init__(self, graph_ptr, row_ptr, col_idx, node_label, n_labels, edge_weight=None, weight_step=1.0,
+                 float_weight=None, from_dict=None):
         self.graph_ptr = np.ascontiguousarray(graph_ptr, dtype=np.int32)
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
         self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
@@ -45,6 +50,10 @@ class GraphBatch(object):
         self.n_labels = int(n_labels)
         self.edge_weight = None if edge_weight is None else np.ascontiguousarray(edge_weight, np.int32)
         self.weight_step = float(weight_step)
+        self.float_weight = None if float_weight is None else np.ascontiguousarray(float_weight, np.float64)
+        self.from_dict = None if from_dict is None else np.ascontiguousarray(from_dict, np.uint8)
+        if self.float_weight is not None and (self.float_weight.shape[0] != self.col_idx.shape[0] or self.edge_weight is not None):
+            raise ValueError("GraphBatch: float_weight needs one value per edge and excludes edge_weight")
         if self.row_ptr.shape[0] != self.node_label.shape[0] + 1:
             raise ValueError("GraphBatch: row_ptr must have n_nodes+1 entries")
         if int(self.graph_ptr[-1]) != self.n_nodes or int(self.row_ptr[-1]) != self.n_edges:
@@ -66,14 +75,37 @@ class GraphBatch(object):
         v0, v1 = int(self.graph_ptr[lo]), int(self.graph_ptr[hi])
         e0, e1 = int(self.row_ptr[v0]), int(self.row_ptr[v1])
         ew = None if self.edge_weight is None else self.edge_weight[e0:e1]
+        fw = getattr(self, "float_weight", None)
+        fd = getattr(self, "from_dict", None)
         return GraphBatch(self.graph_ptr[lo:hi + 1] - v0, self.row_ptr[v0:v1 + 1] - e0,
                           self.col_idx[e0:e1] - v0, self.node_label[v0:v1], self.n_labels, ew,
-                          getattr(self, "weight_step", 1.0))
+                          getattr(self, "weight_step", 1.0), None if fw is None else fw[e0:e1],
+                          None if fd is None else fd[lo:hi])
 
     @staticmethod
     def concat(a, b):
         """Union batch: graphs of ``a`` first, then graphs of ``b`` (transform = fit + targets)."""
         ew, step = None, 1.0
+        fa, fb = getattr(a, "float_weight", None), getattr(b, "float_weight", None)
+        da, db_ = getattr(a, "from_dict", None), getattr(b, "from_dict", None)
+        fd = None
+        if da is not None or db_ is not None:
+            fd = np.concatenate([da if da is not None else np.zeros(a.n_graphs, np.uint8),
+                                 db_ if db_ is not None else np.zeros(b.n_graphs, np.uint8)])
+        if fa is not None or fb is not None:
+            # one side has general float weights: the union counts in float64 (the other side's exact weights as floats)
+            def as_float(x, f):
+                if f is not None:
+                    return f
+                if x.edge_weight is None:
+                    return np.ones(x.n_edges, np.float64)
+                return x.edge_weight.astype(np.float64) * getattr(x, "weight_step", 1.0)
+            return GraphBatch(
+                np.concatenate([a.graph_ptr, b.graph_ptr[1:] + a.n_nodes]),
+                np.concatenate([a.row_ptr, b.row_ptr[1:] + a.n_edges]),
+                np.concatenate([a.col_idx, b.col_idx + a.n_nodes]),
+                np.concatenate([a.node_label, b.node_label]),
+                max(a.n_labels, b.n_labels), None, 1.0, np.concatenate([as_float(a, fa), as_float(b, fb)]), fd)
         if a.edge_weight is not None and b.edge_weight is not None:
             # one weight unit for the union: the finer of the two steps (both are powers of two)
             sa, sb = getattr(a, "weight_step", 1.0), getattr(b, "weight_step", 1.0)
@@ -90,10 +122,11 @@ class GraphBatch(object):
             np.concatenate([a.row_ptr, b.row_ptr[1:] + a.n_edges]),
             np.concatenate([a.col_idx, b.col_idx + a.n_nodes]),
             np.concatenate([a.node_label, b.node_label]),
-            max(a.n_labels, b.n_labels), ew, step)
+            max(a.n_labels, b.n_labels), ew, step, None, fd)
 
 
 MAX_EDGE_WEIGHT = 2 ** 20        # int32 distances: sp.hip guards (n - 1) * max weight < SP_INF per batch
+MAX_FLOAT_WEIGHT_NODES = 143     # general float weights: the float64 distance matrix of a graph lives in LDS (sp.hip)
 
 
 def quantise_weights(weights):
@@ -530,8 +563,10 @@ def vh_batch_from_input(X, fitted_labels=None, edge_labels=False):
 # indexes them (sorted symbols for edge dictionaries, graph.py:894-907; 0..n-1 for matrices)
 # ------------------------------------------------------------------------------------------
 def _sp_graph_arrays(gobj, labels, with_labels):
-    """-> (n, label_values list or None, src, dst, weight) with local vertex indices."""
+    """-> (n, label_values list or None, src, dst, weight, is_dict) with local vertex indices; is_dict: the reference
+    holds this element in its dictionary format (and runs dijkstra on it under algorithm_type="auto", graph.py:652-656)."""
     A = _adjacency_array(gobj)
+    is_dict = 0 if A is not None else (0 if getattr(gobj, "_format", None) == "adjacency" else 1)
     if A is not None:
         if A.shape[0] != A.shape[1]:
             raise ValueError('input matrix must be squared')
@@ -570,7 +605,7 @@ def _sp_graph_arrays(gobj, labels, with_labels):
         if not labels:
             raise ValueError('Graph does not have any labels for vertices.')   # graph.py:737-738
         vals = [labels[v] for v in verts]            # KeyError when a vertex has no label
-    return n, vals, ii, jj, ww
+    return n, vals, ii, jj, ww, is_dict
 
 
 def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_iterable=TypeError):
@@ -590,20 +625,21 @@ def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_ite
                 n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
             else:
                 ids, mapping, n_labels = np.zeros(int(graph_ptr[-1]), np.int32), {}, 1
+            fd = np.fromiter((1 if isinstance(x[0], dict) else 0 for x in X), np.uint8, len(X))
             return GraphBatch(graph_ptr, np.frombuffer(row_ptr, dtype=np.int32), np.frombuffer(col, dtype=np.int32), ids,
-                              max(n_labels, 1), edge_weight=np.frombuffer(w, dtype=np.int32)), mapping
+                              max(n_labels, 1), edge_weight=np.frombuffer(w, dtype=np.int32), from_dict=fd), mapping
     msg = 'each element of X must have at least one and at most 3 elements\n'
     ok = (lambda n: n in (2, 3)) if with_labels else (lambda n: n in (1, 2, 3))
     if len_ok is not None:
         ok = len_ok
-    sizes, srcs, dsts, wts, values = [], [], [], [], []
+    sizes, srcs, dsts, wts, values, dicts = [], [], [], [], [], []
     for x in iter_elements(X, ok, msg, not_iterable):
         if _is_graph_object(x):
             gobj, labels = x, (x.get_labels(purpose="dictionary") if with_labels else {})
         else:
             gobj, labels = x[0], (x[1] if len(x) > 1 else {})
-        n, vals, s, d, w = _sp_graph_arrays(gobj, labels, with_labels)
-        sizes.append(n), srcs.append(s), dsts.append(d), wts.append(w)
+        n, vals, s, d, w, is_dict = _sp_graph_arrays(gobj, labels, with_labels)
+        sizes.append(n), srcs.append(s), dsts.append(d), wts.append(w), dicts.append(is_dict)
         if with_labels:
             values.extend(vals)
     if with_labels:
@@ -611,8 +647,21 @@ def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_ite
         n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
     else:
         ids, mapping, n_labels = np.zeros(int(np.sum(sizes)), np.int32), {}, 1
-    wts, step = quantise_weights(wts)
-    graph_ptr, row_ptr, col, w = _pack_csr(sizes, srcs, dsts, wts)
+    fd = np.asarray(dicts, np.uint8)
+    try:
+        qw, step = quantise_weights(wts)
+    except NotImplementedError:
+        # general positive float weights: the device reproduces the reference's float distances (GraphBatch.float_weight)
+        flat = np.concatenate(wts) if wts else np.zeros(0)
+        if flat.size and (not np.all(np.isfinite(flat)) or flat.min() <= 0 or flat.max() >= 1e300):
+            raise
+        if max(sizes) > MAX_FLOAT_WEIGHT_NODES:
+            raise NotImplementedError('ShortestPath on MI355X supports general float edge weights on graphs of up to '
+                                      '%d vertices (integer or power-of-two-multiple weights have no such limit)'
+                                      % MAX_FLOAT_WEIGHT_NODES)
+        graph_ptr, row_ptr, col, w = _pack_csr(sizes, srcs, dsts, wts)
+        return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1), float_weight=w, from_dict=fd), mapping
+    graph_ptr, row_ptr, col, w = _pack_csr(sizes, srcs, dsts, qw)
     if w is None:
         w = np.zeros(0, np.int64)
-    return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1), edge_weight=w, weight_step=step), mapping
+    return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1), edge_weight=w, weight_step=step, from_dict=fd), mapping

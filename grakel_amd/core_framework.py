@@ -32,6 +32,8 @@ def induced_subbatch(gb, keep):
     graph_ptr = np.zeros(len(gidx) + 1, np.int64)
     np.cumsum(sizes[gidx], out=graph_ptr[1:])
     ew = gb.edge_weight[ekeep] if gb.edge_weight is not None and gb.edge_weight.size else gb.edge_weight
+    if getattr(gb, "float_weight", None) is not None:
+        raise NotImplementedError('CoreFramework on MI355X: general float edge weights are only supported by ShortestPath itself')
     return GraphBatch(graph_ptr, row_ptr, new_id[gb.col_idx[ekeep]], gb.node_label[keep], gb.n_labels, ew), gidx
 
 

@@ -750,6 +750,162 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     return GK_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Arbitrary positive float64 edge weights.  The reference keys its features by the float distance AS IT COMPUTES IT
+// (shortest_path.py:389,469-490), so the distances have to be its distances bit for bit:
+//   * floyd_warshall (graph.py:1767-1794; adjacency input): pivots 0..n-1 in order, one rounded add per update; within a
+//     pivot the updates are independent (row and column k do not change: D[k][k] = 0), so a float64 sweep per pivot with
+//     the same pivot order gives the same bits;
+//   * dijkstra (graph.py:1712-1764; dictionary input): for positive weights and monotone rounding the final distances
+//     are the LEAST FIXED POINT of d(w) = min over edges (v, w) of fl(d(v) + weight(v, w)), d(source) = 0 -- per source
+//     the minimum over paths of the left-to-right float sum (D[u][v] and D[v][u] may differ) -- which relaxation sweeps
+//     from +inf reach in any order (checked against the reference's dijkstra on 3 000 random float graphs, and by the
+//     goldens of tests/golden/sp_float.npz).
+// One workgroup per graph, the n x n float64 matrix in LDS (n <= 143).  The distinct distance values of the whole batch
+// are then RANKED (the shared sorting dictionary on the 63-bit patterns of the positive doubles) and the ranks 1..R take
+// the place of the integer distances in everything downstream.
+// ---------------------------------------------------------------------------------------
+#define SPF_MAX_N 143
+#define SPF_INF_BITS 0x7ff0000000000000ull
+
+__global__ __launch_bounds__(1024) void sp_f64_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr,
+                                                      const i32* __restrict__ col_idx, const double* __restrict__ w,
+                                                      const unsigned char* __restrict__ algo, const u64* __restrict__ dist_ptr,
+                                                      double* __restrict__ out, int only_graph) {
+    extern __shared__ __attribute__((aligned(16))) double spf_d[];
+    __shared__ int changed;
+    const int g = only_graph >= 0 ? only_graph : (int)blockIdx.x;
+    const i32 v0 = graph_ptr[g];
+    const int n = graph_ptr[g + 1] - v0, tid = threadIdx.x, nt = blockDim.x;
+    const double inf = __longlong_as_double((long long)SPF_INF_BITS);
+    for (int idx = tid; idx < n * n; idx += nt) spf_d[idx] = (idx / n == idx % n) ? 0.0 : inf;
+    __syncthreads();
+    if (algo[g] == 0) {
+        for (int u = tid; u < n; u += nt)
+            for (i32 e = row_ptr[v0 + u]; e < row_ptr[v0 + u + 1]; ++e) {
+                const int v = col_idx[e] - v0;
+                if (v != u) spf_d[u * n + v] = w[e];
+            }
+        __syncthreads();
+        for (int k = 0; k < n; ++k) {
+            for (int idx = tid; idx < n * n; idx += nt) {
+                const int i = idx / n, j = idx - i * n;
+                const double c = spf_d[i * n + k] + spf_d[k * n + j];        // entries of row / column k never change in pivot k
+                if (c < spf_d[idx]) spf_d[idx] = c;
+            }
+            __syncthreads();
+        }
+    } else {
+        unsigned long long* bits = (unsigned long long*)spf_d;             // positive doubles order like their bit patterns
+        for (;;) {
+            if (tid == 0) changed = 0;
+            __syncthreads();
+            for (int idx = tid; idx < n * n; idx += nt) {                 // idx = (source, v): relax the out-edges of v
+                const int src = idx / n, v = idx - src * n;
+                const double dv = spf_d[idx];
+                if (!(dv < inf)) continue;
+                for (i32 e = row_ptr[v0 + v]; e < row_ptr[v0 + v + 1]; ++e) {
+                    const int t = col_idx[e] - v0;
+                    const double c = dv + w[e];
+                    if (c < spf_d[src * n + t]) {
+                        atomicMin(&bits[src * n + t], (unsigned long long)__double_as_longlong(c));
+                        changed = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!changed) break;
+            __syncthreads();
+        }
+    }
+    double* o = out + (only_graph >= 0 ? 0 : dist_ptr[g]);
+    for (int idx = tid; idx < n * n; idx += nt) o[idx] = spf_d[idx];
+}
+
+// sort keys of the ranking: the bit pattern of a finite off-diagonal distance, +inf's pattern otherwise
+__global__ void spf_keys_kernel(const i32* __restrict__ graph_ptr, const u64* __restrict__ dist_ptr, const double* __restrict__ D,
+                                u64* __restrict__ keys, i64 n_graphs) {
+    const int g = blockIdx.x;
+    const int n = graph_ptr[g + 1] - graph_ptr[g];
+    const u64 base = dist_ptr[g];
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+        const u64 b = (u64)__double_as_longlong(D[base + idx]);
+        keys[base + idx] = (idx / n == idx % n || b >= SPF_INF_BITS) ? SPF_INF_BITS : b;
+    }
+}
+
+// ranks -> the int32 distance matrices the rest of sp.hip works on, pair counts per graph, the largest rank
+__global__ __launch_bounds__(256) void spf_finish_kernel(const i32* __restrict__ graph_ptr, const u64* __restrict__ dist_ptr,
+                                                         const u64* __restrict__ keys, const i32* __restrict__ lab,
+                                                         i32* __restrict__ dist, u32* __restrict__ pair_count,
+                                                         u32* __restrict__ maxd) {
+    const int g = blockIdx.x;
+    const int n = graph_ptr[g + 1] - graph_ptr[g];
+    const u64 base = dist_ptr[g];
+    u32 cnt = 0, mx = 0;
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+        i32 d;
+        if (keys[base + idx] == SPF_INF_BITS) d = (idx / n == idx % n) ? 0 : SP_INF;
+        else {
+            d = lab[base + idx] + 1;
+            ++cnt, mx = (u32)d > mx ? (u32)d : mx;
+        }
+        dist[base + idx] = d;
+    }
+    block_count_max(cnt, mx, pair_count + g, maxd);
+}
+
+static int sp_compute_dist_f64(gk_ctx* ctx, gk_batch* b, const double* edge_weight, const unsigned char* graph_algo, SpDist& s,
+                               u64* total_sq) {
+    const i64 N = b->n_graphs;
+    if (b->max_graph_nodes > SPF_MAX_N) {
+        gk_set_error("ShortestPath with non-dyadic float edge weights: graphs above %d vertices are not supported (largest: %d)",
+                     SPF_MAX_N, b->max_graph_nodes);
+        return GK_ERR_UNSUPPORTED;
+    }
+    for (i64 e = 0; e < b->n_edges; ++e)
+        GK_ARG(edge_weight[e] > 0.0 && edge_weight[e] < 1.0e300, "ShortestPath: float edge weights must be positive and finite");
+    GK_TRY(s.sq.alloc(N)); GK_TRY(s.dist_ptr.alloc(N)); GK_TRY(s.total.alloc(1));
+    GK_TRY(s.pair_count.alloc(N)); GK_TRY(s.maxd.alloc(1));
+    GK_TRY(gk_zero_async(ctx, s.pair_count.p, (size_t)N * 4));
+    GK_TRY(gk_zero_async(ctx, s.maxd.p, 4));
+    sp_sq_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, s.sq.p, N);
+    GK_TRY(gk_scan_u64(ctx, s.sq.p, s.dist_ptr.p, N, true, s.total.p));
+    GK_HIP_CHECK(hipMemcpyAsync(total_sq, s.total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    GK_ARG(*total_sq < (1ull << 31), "ShortestPath: sum of n^2 exceeds int32 item indexing");
+    const size_t tot = *total_sq > 0 ? (size_t)*total_sq : 1;
+    GK_TRY(s.dist.alloc(tot));
+    Tmp<double> wdev(ctx), D(ctx);
+    Tmp<unsigned char> adev(ctx);
+    Tmp<u64> keys(ctx);
+    Tmp<i32> lab(ctx), perm(ctx);
+    Tmp<u32> cnt(ctx);
+    GK_TRY(wdev.alloc(b->n_edges > 0 ? (size_t)b->n_edges : 1)); GK_TRY(adev.alloc(N > 0 ? (size_t)N : 1)); GK_TRY(D.alloc(tot));
+    GK_TRY(keys.alloc(tot)); GK_TRY(lab.alloc(tot)); GK_TRY(perm.alloc(tot)); GK_TRY(cnt.alloc(1));
+    if (b->n_edges > 0) GK_HIP_CHECK(hipMemcpyAsync(wdev.p, edge_weight, (size_t)b->n_edges * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (N > 0) GK_HIP_CHECK(hipMemcpyAsync(adev.p, graph_algo, (size_t)N, hipMemcpyHostToDevice, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // the host arrays may go away
+    if (N == 0 || *total_sq == 0) return GK_OK;
+    const int nmax = b->max_graph_nodes;
+    const size_t lds = (size_t)nmax * nmax * 8;
+    GK_TRY(gk_func_lds(ctx, (const void*)sp_f64_kernel, (int)lds));
+    sp_f64_kernel<<<dim3((unsigned)N), 1024, lds, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, wdev.p, adev.p, s.dist_ptr.p,
+                                                               D.p, -1);
+    spf_keys_kernel<<<dim3((unsigned)N), 256, 0, ctx->stream>>>(b->graph_ptr, s.dist_ptr.p, D.p, keys.p, N);
+    GK_HIP_CHECK(hipGetLastError());
+    GK_TRY(gk_dictionary_from_keys(ctx, keys.p, (i64)*total_sq, 63, lab.p, perm.p, cnt.p));
+    spf_finish_kernel<<<dim3((unsigned)N), 256, 0, ctx->stream>>>(b->graph_ptr, s.dist_ptr.p, keys.p, lab.p, s.dist.p, s.pair_count.p,
+                                                                 s.maxd.p);
+    GK_HIP_CHECK(hipGetLastError());
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // the temporaries above are released in stream order anyway
+    return GK_OK;
+}
+
+static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, const double* weight_f64,
+                         const unsigned char* graph_algo, int with_labels, int n_levels, gk_batch** out_pair_batch,
+                         int64_t* out_n_pairs, int64_t* out_n_keys);
+
 extern "C" int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_labels,
                            gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys) {
     return gk_sp_build_levels(ctx, b, edge_weight, with_labels, 1, out_pair_batch, out_n_pairs, out_n_keys);
@@ -763,6 +919,20 @@ extern "C" int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
 extern "C" int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_labels,
                                   int n_levels, gk_batch** out_pair_batch, int64_t* out_n_pairs,
                                   int64_t* out_n_keys) {
+    return sp_build_impl(ctx, b, edge_weight, nullptr, nullptr, with_labels, n_levels, out_pair_batch, out_n_pairs, out_n_keys);
+}
+
+// the same with float64 edge weights [n_edges] that are matched to the reference bit for bit (above); graph_algo[n_graphs]:
+// 0 = the reference would run floyd_warshall on this graph, 1 = dijkstra
+extern "C" int gk_sp_build_f64(gk_ctx* ctx, gk_batch* b, const double* edge_weight, const uint8_t* graph_algo, int with_labels,
+                               int n_levels, gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys) {
+    GK_ARG(edge_weight && graph_algo, "gk_sp_build_f64: null weights / algorithm flags");
+    return sp_build_impl(ctx, b, nullptr, edge_weight, graph_algo, with_labels, n_levels, out_pair_batch, out_n_pairs, out_n_keys);
+}
+
+static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, const double* weight_f64,
+                         const unsigned char* graph_algo, int with_labels, int n_levels, gk_batch** out_pair_batch,
+                         int64_t* out_n_pairs, int64_t* out_n_keys) {
     GK_ARG(ctx && b && out_pair_batch, "gk_sp_build: null argument");
     GK_ARG(!b->is_pair_batch, "gk_sp_build: needs a graph batch");
     GK_ARG(n_levels >= 1, "gk_sp_build_levels: n_levels must be >= 1");
@@ -771,7 +941,7 @@ extern "C" int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_
     GK_HIP_CHECK(hipSetDevice(ctx->device));
     ProfScope prof(ctx, "sp");
     const i64 N = b->n_graphs, V = b->n_nodes;
-    {   // distances are int32 sums below SP_INF: the longest simple path must stay under it, otherwise a
+    if (!weight_f64) {   // distances are int32 sums below SP_INF: the longest simple path must stay under it, otherwise a
         // finite distance would silently count as "unreachable"
         i64 wmax = 1;
         if (edge_weight)
@@ -788,7 +958,8 @@ extern "C" int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_
     }
     SpDist s(ctx);
     u64 total_sq = 0;
-    GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq));
+    if (weight_f64) GK_TRY(sp_compute_dist_f64(ctx, b, weight_f64, graph_algo, s, &total_sq));
+    else GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq));
     // pair offsets double as the pair batch's graph_ptr[N+1]
     Tmp<u32> ptotal(ctx);
     void* gpq = nullptr;
@@ -948,5 +1119,36 @@ extern "C" int gk_sp_debug_apsp(gk_ctx* ctx, gk_batch* b, const int32_t* edge_we
         GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     for (i64 i = 0; i < n * n; ++i) out_dist[i] = h[i] >= SP_INF ? -1 : h[i];
+    return GK_OK;
+}
+
+// float64 distance matrix of ONE graph exactly as the reference computes it (gk_sp_build_f64); unreachable = -1
+extern "C" int gk_sp_debug_apsp_f64(gk_ctx* ctx, gk_batch* b, const double* edge_weight, const uint8_t* graph_algo, int64_t graph,
+                                    double* out_dist) {
+    GK_ARG(ctx && b && out_dist && edge_weight && graph_algo, "gk_sp_debug_apsp_f64: null argument");
+    GK_ARG(graph >= 0 && graph < b->n_graphs && !b->is_pair_batch, "gk_sp_debug_apsp_f64: bad graph index");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    if (b->max_graph_nodes > SPF_MAX_N) {
+        gk_set_error("ShortestPath with non-dyadic float edge weights: graphs above %d vertices are not supported", SPF_MAX_N);
+        return GK_ERR_UNSUPPORTED;
+    }
+    std::vector<i32> gp(2);
+    GK_HIP_CHECK(hipMemcpyAsync(gp.data(), b->graph_ptr + graph, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const i64 n = gp[1] - gp[0];
+    if (n == 0) return GK_OK;
+    Tmp<double> wdev(ctx), D(ctx);
+    Tmp<unsigned char> adev(ctx);
+    GK_TRY(wdev.alloc(b->n_edges > 0 ? (size_t)b->n_edges : 1)); GK_TRY(adev.alloc((size_t)b->n_graphs)); GK_TRY(D.alloc((size_t)(n * n)));
+    if (b->n_edges > 0) GK_HIP_CHECK(hipMemcpyAsync(wdev.p, edge_weight, (size_t)b->n_edges * 8, hipMemcpyHostToDevice, ctx->stream));
+    GK_HIP_CHECK(hipMemcpyAsync(adev.p, graph_algo, (size_t)b->n_graphs, hipMemcpyHostToDevice, ctx->stream));
+    const size_t lds = (size_t)n * n * 8;
+    GK_TRY(gk_func_lds(ctx, (const void*)sp_f64_kernel, (int)lds));
+    sp_f64_kernel<<<dim3(1), 1024, lds, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, wdev.p, adev.p, nullptr, D.p, (int)graph);
+    GK_HIP_CHECK(hipGetLastError());
+    GK_HIP_CHECK(hipMemcpyAsync(out_dist, D.p, (size_t)(n * n) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (i64 i = 0; i < n * n; ++i)
+        if (!(out_dist[i] < 1.0e308)) out_dist[i] = -1.0;
     return GK_OK;
 }

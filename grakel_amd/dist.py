@@ -170,6 +170,9 @@ class ShardExchange(object):
         self.flat = None
         self._into_tensor = True
         # edge weights (ShortestPath): present on any rank -> every rank sends a (unit-filled) weight segment
+        if getattr(local, "float_weight", None) is not None:
+            raise NotImplementedError('sharded ShortestPath: general float edge weights are not exchanged; use the '
+                                      'single-GPU ShortestPath, or integer / power-of-two-multiple weights')
         has_w = torch.tensor([1 if local.edge_weight is not None else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(has_w, op=dist.ReduceOp.MAX, group=group)
         self.weights = None

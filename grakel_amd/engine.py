@@ -409,13 +409,21 @@ class Engine(object):
         return fl.value, ms.value
 
     # -- shortest paths -------------------------------------------------------------------------
-    def sp_build(self, db, edge_weight, with_labels, n_levels=1):
+    def sp_build(self, db, edge_weight, with_labels, n_levels=1, float_weights=None, graph_algo=None):
         """Pair batch of the ShortestPath features; n_levels > 1 keys level l by the WL labels of
-        level l (``wl_relabel(db, n_levels - 1)`` first): the WL framework over the SP base kernel."""
+        level l (``wl_relabel(db, n_levels - 1)`` first): the WL framework over the SP base kernel.
+        ``float_weights`` (float64[n_edges]) + ``graph_algo`` (uint8[n_graphs]: 0 floyd_warshall, 1 dijkstra): arbitrary
+        positive float weights, distances bit-identical to the reference's (gk_sp_build_f64)."""
         h = c_void_p()
         npairs, nkeys = c_int64(), (c_int64 * int(n_levels))()
-        check(self.lib.gk_sp_build_levels(self.handle, db.handle, _ptr(edge_weight), 1 if with_labels else 0,
-                                          int(n_levels), byref(h), byref(npairs), nkeys))
+        if float_weights is not None:
+            fw = np.ascontiguousarray(float_weights, np.float64)
+            ga = np.ascontiguousarray(graph_algo, np.uint8)
+            check(self.lib.gk_sp_build_f64(self.handle, db.handle, _ptr(fw), _ptr(ga), 1 if with_labels else 0,
+                                           int(n_levels), byref(h), byref(npairs), nkeys))
+        else:
+            check(self.lib.gk_sp_build_levels(self.handle, db.handle, _ptr(edge_weight), 1 if with_labels else 0,
+                                              int(n_levels), byref(h), byref(npairs), nkeys))
         pb = DeviceBatch(self, h, db.n_graphs, npairs.value, 0)
         pb.label_counts = [int(k) for k in nkeys]
         return pb
@@ -423,6 +431,13 @@ class Engine(object):
     def core_numbers(self, db):
         out = np.empty(db.n_nodes, dtype=np.int32)
         check(self.lib.gk_core_numbers(self.handle, db.handle, _ptr(out)))
+        return out
+
+    def sp_debug_apsp_f64(self, db, float_weights, graph_algo, graph, n):
+        out = np.empty((n, n), dtype=np.float64)
+        fw = np.ascontiguousarray(float_weights, np.float64)
+        ga = np.ascontiguousarray(graph_algo, np.uint8)
+        check(self.lib.gk_sp_debug_apsp_f64(self.handle, db.handle, _ptr(fw), _ptr(ga), int(graph), _ptr(out)))
         return out
 
     def sp_debug_apsp(self, db, edge_weight, graph, n):

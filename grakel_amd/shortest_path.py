@@ -85,6 +85,27 @@ class _LazyDict(dict):
         return (dict, (dict(dict.items(self)),))
 
 
+def sp_weight_args(gb, algorithm_type):
+    """What ``Engine.sp_build`` needs for the edge weights of ``gb``: (int32 weights or None, float64 weights or None,
+    per-graph algorithm flags or None).  General float weights (``GraphBatch.float_weight``): the device reproduces the
+    reference's float distances, and which of its two algorithms it runs matters then -- "auto" follows the element's
+    format (graph.py:652-656: dictionary -> dijkstra, adjacency -> floyd_warshall), a named algorithm converts every
+    element (shortest_path.py:244-250).  Integer / power-of-two-multiple weights: both algorithms give the same exact
+    distances."""
+    fw = getattr(gb, "float_weight", None)
+    if fw is not None:
+        if algorithm_type == "auto":
+            fd = getattr(gb, "from_dict", None)
+            algo = fd if fd is not None else np.zeros(gb.n_graphs, np.uint8)
+        else:
+            algo = np.full(gb.n_graphs, 1 if algorithm_type == "dijkstra" else 0, np.uint8)
+        return None, fw, algo
+    w = gb.edge_weight
+    if w is not None and (w.size == 0 or np.all(w == 1)):
+        w = None
+    return w, None, None
+
+
 class ShortestPath(Kernel):
     """K[i,j] = <histogram of (label_u, label_v, d(u,v)) over ordered pairs of G_i, same of G_j>.
 
@@ -93,8 +114,10 @@ class ShortestPath(Kernel):
     device always runs the batched Floyd-Warshall / row-relaxation kernels, which give the
     same distances as either host algorithm).  Edge weights: positive integers below 2**20, or floats that
     are integer multiples of one common power of two (0.5, 1.25, ...): distances are then counted exactly in
-    that unit (batch.quantise_weights) and ``_enum`` keys are the reference's float distances; other float
-    weights raise NotImplementedError.
+    that unit (batch.quantise_weights) and ``_enum`` keys are the reference's float distances.  Other positive
+    float weights (0.1, ...): the reference's features then depend on how it rounds, so the device reproduces its
+    float distances bit for bit -- its floyd_warshall for adjacency input, its dijkstra for dictionary input, as
+    ``algorithm_type`` says (sp.hip: gk_sp_build_f64) -- on graphs of up to 143 vertices.
     """
 
     def __init__(self, n_jobs=None, normalize=False, verbose=False, with_labels=True,
@@ -122,11 +145,8 @@ class ShortestPath(Kernel):
         return sp_batch_from_input(X, bool(self.with_labels), fitted)
 
     def _prepare(self, engine, dbatch):
-        gb = self._cur_batch
-        w = gb.edge_weight
-        if w is not None and (w.size == 0 or np.all(w == 1)):
-            w = None
-        pb = engine.sp_build(dbatch, w, bool(self.with_labels))
+        w, fw, algo = sp_weight_args(self._cur_batch, self.algorithm_type)
+        pb = engine.sp_build(dbatch, w, bool(self.with_labels), float_weights=fw, graph_algo=algo)
         pb._parent = dbatch
         return pb, 1
 
@@ -181,9 +201,7 @@ class ShortestPath(Kernel):
         first).  Distances come from the device (gk_sp_debug_apsp), labels are the original values."""
         eng = self._engine()
         db = eng.upload(gb)
-        w = gb.edge_weight
-        if w is not None and (w.size == 0 or np.all(w == 1)):
-            w = None
+        w, fw, algo = sp_weight_args(gb, self.algorithm_type)
         inv = None
         if self.with_labels and self._label_map is not None:
             inv = {i: k for k, i in self._all_label_ids.items()}
@@ -191,11 +209,14 @@ class ShortestPath(Kernel):
         for g in range(gb.n_graphs):
             v0, v1 = int(gb.graph_ptr[g]), int(gb.graph_ptr[g + 1])
             n = v1 - v0
-            S = eng.sp_debug_apsp(db, w, g, n) if n > 0 else np.zeros((0, 0), np.int32)
+            if fw is not None:
+                S = eng.sp_debug_apsp_f64(db, fw, algo, g, n) if n > 0 else np.zeros((0, 0))
+            else:
+                S = eng.sp_debug_apsp(db, w, g, n) if n > 0 else np.zeros((0, 0), np.int32)
             lab = gb.node_label[v0:v1].tolist()
             row = dict()
             us, vs = np.nonzero((S >= 0) & ~np.eye(n, dtype=bool))
-            step = getattr(gb, "weight_step", 1.0)        # float weights: device distances count this unit
+            step = 1.0 if fw is not None else getattr(gb, "weight_step", 1.0)   # dyadic weights: device distances count this unit
             for u, v, d in zip(us.tolist(), vs.tolist(), S[us, vs].tolist()):
                 d = float(d) * step
                 if self.with_labels:

@@ -179,6 +179,7 @@ class WeisfeilerLehman(Kernel):
                 probe = ShortestPath(**{k: v for k, v in params.items() if k != "normalize"})
                 probe.initialize()                       # validates algorithm_type like the reference
                 self._sp_with_labels = bool(probe.with_labels)
+                self._sp_algorithm_type = probe.algorithm_type
             elif base is EdgeHistogram:
                 EdgeHistogram(**{k: v for k, v in params.items() if k != "normalize"}).initialize()
             elif base is not VertexHistogram:
@@ -222,10 +223,12 @@ class WeisfeilerLehman(Kernel):
     def _prepare(self, engine, dbatch):
         engine.wl_relabel(dbatch, self._n_iter - 1)
         if self._base_graph_kernel is ShortestPath:
-            w = self._cur_batch.edge_weight
-            if w is not None and (w.size == 0 or np.all(w == 1)):
-                w = None
-            pb = engine.sp_build(dbatch, w, self._sp_with_labels, n_levels=self._n_iter)
+            from .shortest_path import sp_weight_args
+            # the reference's WL keeps every graph in its dictionary format (weisfeiler_lehman.py:56) and hands the base
+            # kernel edge dictionaries, so "auto" means dijkstra for every element there (matters for general float weights)
+            algo_type = "dijkstra" if self._sp_algorithm_type == "auto" else self._sp_algorithm_type
+            w, fw, algo = sp_weight_args(self._cur_batch, algo_type)
+            pb = engine.sp_build(dbatch, w, self._sp_with_labels, n_levels=self._n_iter, float_weights=fw, graph_algo=algo)
             pb._parent = dbatch
             pb.label_counts, pb.pair_key_counts = dbatch.label_counts, pb.label_counts
             return pb, self._n_iter

@@ -256,6 +256,17 @@ int gk_sp_build(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_l
  * n_levels, ...) + gk_gram return sum_l K_SP(level l).  out_n_keys: int64[n_levels]. */
 int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int with_labels, int n_levels,
                        gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys);
+/* The same for ARBITRARY positive float64 edge weights (edge_weight[n_edges]).  The reference keys its features by the
+ * float distance as it computes it (shortest_path.py:389,469-490), so the distances are reproduced bit for bit: per graph
+ * graph_algo[g] = 0 runs the reference's floyd_warshall (graph.py:1767-1794: adjacency input, or algorithm_type
+ * "floyd_warshall"), 1 its dijkstra (graph.py:1712-1764: dictionary input, or "dijkstra") -- see sp.hip for why a float64
+ * pivot sweep / relaxation to the fixed point give the same bits.  The distinct distances of the batch are ranked and the
+ * ranks stand in for integer distances from there on.  Graphs of up to 143 vertices (GK_ERR_UNSUPPORTED beyond). */
+int gk_sp_build_f64(gk_ctx* ctx, gk_batch* b, const double* edge_weight, const uint8_t* graph_algo, int with_labels, int n_levels,
+                    gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys);
+/* float64 distance matrix of one graph as gk_sp_build_f64 computes it (n x n, -1 = unreachable): the lazy `_enum` state */
+int gk_sp_debug_apsp_f64(gk_ctx* ctx, gk_batch* b, const double* edge_weight, const uint8_t* graph_algo, int64_t graph,
+                         double* out_dist);
 /* Test hook: all-pairs distance matrix of one graph (n x n int32, -1 = unreachable). */
 int gk_sp_debug_apsp(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int64_t graph,
                      int32_t* out_dist);

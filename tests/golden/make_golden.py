@@ -33,7 +33,7 @@ from grakel.datasets.base import read_data  # noqa: E402
 
 from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs  # noqa: E402
 sys.path.insert(0, HERE)
-from small_sets import SMALL_SETS, split, sp_inputs, sp_dyadic_graphs  # noqa: E402
+from small_sets import SMALL_SETS, split, sp_inputs, sp_dyadic_graphs, sp_float_graphs  # noqa: E402
 
 warnings.filterwarnings("ignore")
 
@@ -173,6 +173,34 @@ def sp_dyadic():
     np.savez_compressed(os.path.join(HERE, "sp_dyadic.npz"), **out)
     print("sp_dyadic: fit", out["K_fit_auto"].shape, "sum", int(out["K_fit_auto"].sum()), "features", len(out["enum_dist_auto"]),
           "auto == fw:", bool(np.array_equal(out["K_fit_auto"], out["K_fit_fw"])))
+
+
+def sp_float():
+    """ShortestPath on GENERAL float edge weights (round 3): the reference's matrices for its three algorithm settings,
+    its ``_enum`` keys as float64 bit patterns, transform, normalisation, unlabelled, and WL over ShortestPath."""
+    G = sp_float_graphs()
+    tr, te = G[:28], G[28:]
+    out = {}
+    for name, kw in (("auto", {}), ("fw", dict(algorithm_type="floyd_warshall")), ("dij", dict(algorithm_type="dijkstra"))):
+        sp = ShortestPath(normalize=False, **kw)
+        out["K_fit_" + name] = as_int(sp.fit_transform(tr))
+        out["K_tr_" + name] = as_int(sp.transform(te))
+        keys = sorted(sp._enum.items(), key=lambda kv: kv[1])
+        out["enum_labels_" + name] = np.array([[k[0], k[1]] for k, _ in keys])
+        out["enum_dist_bits_" + name] = np.array([float(k[2]) for k, _ in keys], np.float64).view(np.int64)
+    spn = ShortestPath(normalize=True)
+    out["K_fit_norm"] = spn.fit_transform(tr)
+    out["K_tr_norm"] = spn.transform(te)
+    spu = ShortestPath(normalize=False, with_labels=False)
+    out["K_fit_unlabelled"] = as_int(spu.fit_transform([[g[0]] for g in tr]))
+    wl = WeisfeilerLehman(n_iter=2, base_graph_kernel=ShortestPath)
+    out["K_fit_wl_sp"] = as_int(wl.fit_transform(tr))
+    out["K_tr_wl_sp"] = as_int(wl.transform(te))
+    np.savez_compressed(os.path.join(HERE, "sp_float.npz"), **out)
+    print("sp_float: fit", out["K_fit_auto"].shape, "sums auto / fw / dij", int(out["K_fit_auto"].sum()), int(out["K_fit_fw"].sum()),
+          int(out["K_fit_dij"].sum()), "features", len(out["enum_labels_auto"]),
+          "auto == fw:", bool(np.array_equal(out["K_fit_auto"], out["K_fit_fw"])),
+          "fw == dij:", bool(np.array_equal(out["K_fit_fw"], out["K_fit_dij"])))
 
 
 def mutag_state(n_graphs=60):
@@ -342,10 +370,14 @@ if __name__ == "__main__":
     ap.add_argument("--only-state", action="store_true", help="only the fitted-state fixture (mutag_state.npz)")
     ap.add_argument("--only-dyadic", action="store_true", help="only the float-weight ShortestPath fixture (sp_dyadic.npz)")
     ap.add_argument("--only-round3", action="store_true", help="only round3.npz (WL over EdgeHistogram, more than 48 levels)")
+    ap.add_argument("--only-float", action="store_true", help="only sp_float.npz (ShortestPath on general float edge weights)")
     a = ap.parse_args()
     print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
     if a.only_round3:
         round3()
+        sys.exit(0)
+    if a.only_float:
+        sp_float()
         sys.exit(0)
     sp_dyadic()
     if a.only_dyadic:
@@ -363,4 +395,5 @@ if __name__ == "__main__":
         nci1_sp(4110)
         er_config("config3", 10000, 100, 0.05, 5, 0, 5, 20000, with_oa=False)
     round3()
+    sp_float()
 

@@ -32,6 +32,40 @@ def sp_inputs(kw, graphs):
     return out
 
 
+def sp_float_graphs(n_graphs=40, seed=23):
+    """Weighted graphs with GENERAL float edge weights (0.1-multiples, two-decimal and random floats): the reference's
+    feature keys are then its rounded float path sums, which differ between its floyd_warshall (adjacency input) and its
+    dijkstra (dictionary input) and, for dijkstra, between the two directions of a pair.  Symmetric adjacency matrices,
+    every third graph a weighted edge dictionary, every seventh a DIRECTED adjacency matrix; graphs 0..3 are hand-made
+    cases (0.1 + 0.2 against 0.3; a path whose sums differ by direction)."""
+    rs = np.random.RandomState(seed)
+    lab3 = {0: 'x', 1: 'y', 2: 'x'}
+    out = [[np.array([[0, 0.1, 0], [0.1, 0, 0.2], [0, 0.2, 0]]), dict(lab3)],
+           [np.array([[0, 0, 0.3], [0, 0, 0], [0.3, 0, 0]]), dict(lab3)],
+           [{0: {1: 0.1}, 1: {0: 0.1, 2: 0.2}, 2: {1: 0.2, 3: 0.3}, 3: {2: 0.3}}, {0: 'x', 1: 'y', 2: 'x', 3: 'y'}],
+           [np.array([[0, 0.1, 0, 0], [0.1, 0, 0.2, 0], [0, 0.2, 0, 0.3], [0, 0, 0.3, 0]]), {0: 'x', 1: 'y', 2: 'x', 3: 'y'}]]
+    for g in range(4, n_graphs):
+        n = int(rs.randint(4, 13))
+        A = np.zeros((n, n))
+        kind = g % 3
+        for i in range(n):
+            for j in range(n):
+                if i == j or (g % 7 != 0 and j < i):
+                    continue
+                if rs.rand() < 0.3:
+                    w = [rs.randint(1, 30) / 10.0, round(rs.rand() * 3 + 0.01, 2), rs.rand() + 0.05][kind]
+                    A[i, j] = w
+                    if g % 7 != 0:
+                        A[j, i] = w
+        lab = {i: "xyz"[int(rs.randint(0, 3))] for i in range(n)}
+        if g % 3 == 2:
+            d = {i: {j: float(A[i, j]) for j in range(n) if A[i, j] > 0} for i in range(n)}
+            out.append([d, lab])
+        else:
+            out.append([A, lab])
+    return out
+
+
 def sp_dyadic_graphs(n_graphs=24, seed=11):
     """Weighted graphs whose float edge weights are multiples of 1/8 (0.125 .. 4.0): every path sum is exact
     in float64, so the reference's float distance keys are well defined (graph.py:1767-1794).  Adjacency

@@ -715,7 +715,7 @@ def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
 def test_sp_float_weights_against_reference_goldens(gk):
     """Float edge weights that are integer multiples of a power of two (here 1/8): integer distances in that
     unit on the device, the reference's matrices and float-keyed ``_enum`` (graph.py:1767-1794,
-    shortest_path.py:389).  Other float weights are declined (tests/test_host.py)."""
+    shortest_path.py:389).  General float weights: test_sp_general_float_weights_against_reference_goldens."""
     import sys
     sys.path.insert(0, GOLDEN)
     from small_sets import sp_dyadic_graphs
@@ -742,8 +742,48 @@ def test_sp_float_weights_against_reference_goldens(gk):
     spo.fit_transform(tr)
     assert np.array_equal(sp.transform(ints), spo.transform(ints))
     assert np.array_equal(sp.transform(eighths), spo.transform(eighths))
-    with pytest.raises(NotImplementedError):
-        gk.ShortestPath().fit_transform([[np.array([[0, 0.1], [0.1, 0]]), {0: 'a', 1: 'b'}]])
+
+
+@pytest.mark.parametrize("route", [(), ("sp.no_hist",)], ids=lambda r: "+".join(r) or "default")
+def test_sp_general_float_weights_against_reference_goldens(gk, gkopt, route):
+    """General positive float edge weights (0.1-multiples, random floats, directed matrices, edge dictionaries).  The
+    reference keys its features by its own rounded float path sums, which differ between its floyd_warshall and its dijkstra
+    (and between the two directions of a pair): the device reproduces both bit for bit (sp.hip: sp_f64_kernel), ranks the
+    distinct distances and goes on as with integer distances.  Golden: the real reference's three different matrices for
+    algorithm_type auto / floyd_warshall / dijkstra, its transform, its ``_enum`` keys down to the bits of the distances,
+    normalised and unlabelled variants, WL over ShortestPath (tests/golden/sp_float.npz)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from small_sets import sp_float_graphs
+    for name in route:
+        gkopt(name, 1)
+    z = load_golden("sp_float.npz")
+    G = sp_float_graphs()
+    tr, te = G[:28], G[28:]
+    for name, algo in (("auto", "auto"), ("fw", "floyd_warshall"), ("dij", "dijkstra")):
+        sp = gk.ShortestPath(algorithm_type=algo)
+        assert np.array_equal(sp.fit_transform(tr), z["K_fit_" + name]), name
+        assert np.array_equal(sp.transform(te), z["K_tr_" + name]), name
+        keys = sorted(sp._enum.items(), key=lambda kv: kv[1])
+        assert [[k[0], k[1]] for k, _ in keys] == z["enum_labels_" + name].tolist()
+        assert np.array([float(k[2]) for k, _ in keys]).view(np.int64).tolist() == z["enum_dist_bits_" + name].tolist()
+    spn = gk.ShortestPath(normalize=True)
+    assert np.allclose(spn.fit_transform(tr), z["K_fit_norm"], rtol=1e-12, atol=0, equal_nan=True)
+    assert np.allclose(spn.transform(te), z["K_tr_norm"], rtol=1e-12, atol=0, equal_nan=True)
+    assert np.array_equal(gk.ShortestPath(with_labels=False).fit_transform([[g[0]] for g in tr]), z["K_fit_unlabelled"])
+    wl = gk.WeisfeilerLehman(n_iter=2, base_graph_kernel=gk.ShortestPath)
+    assert np.array_equal(wl.fit_transform(tr), z["K_fit_wl_sp"])
+    assert np.array_equal(wl.transform(te), z["K_tr_wl_sp"])
+    # a fit on integer weights, targets with general floats: the union counts in float64 (the oracle is pinned to the
+    # reference on this golden by tests/test_oracle.py)
+    ints = [[np.rint(np.asarray(g[0]) * 10), g[1]] for g in tr if not isinstance(g[0], dict)]
+    sp, spo = gk.ShortestPath(), O.SPOracle()
+    sp.fit(ints), spo.fit_transform(ints)
+    assert np.array_equal(sp.transform(te), spo.transform(te))
+    big = np.zeros((150, 150))
+    big[0, 1] = big[1, 0] = 0.1
+    with pytest.raises(NotImplementedError):                  # the float64 matrix of a graph has to fit LDS
+        gk.ShortestPath().fit_transform([[big, {i: 'a' for i in range(150)}]])
 
 
 def test_errors_match_reference(gk):

@@ -329,8 +329,18 @@ def test_sp_ingestion_vertex_order_weights_and_errors():
     assert gb.node_label.tolist() == [0, 1, 0]
     with pytest.raises(ValueError):                      # no labels with with_labels=True
         sp_batch_from_input([[{0: [1], 1: [0]}, {}]], True)
-    with pytest.raises(NotImplementedError):             # not a multiple of a power of two: declined
-        sp_batch_from_input([[{(0, 1): 0.1}, {0: 1, 1: 1}]], True)
+    # not a multiple of a power of two: the batch keeps the float64 weights and which algorithm the reference's "auto" runs
+    gb, _ = sp_batch_from_input([[{(0, 1): 0.1}, {0: 1, 1: 1}], [np.array([[0, 0.3], [0.3, 0]]), {0: 1, 1: 1}]], True)
+    assert gb.edge_weight is None and gb.float_weight.tolist() == [0.1, 0.3, 0.3] and gb.from_dict.tolist() == [1, 0]
+    ints, _ = sp_batch_from_input([[np.array([[0, 2], [2, 0]]), {0: 1, 1: 1}]], True)
+    u = GraphBatch.concat(ints, gb)                      # an integer-weight fit + float-weight targets: the union counts in floats
+    assert u.edge_weight is None and u.float_weight.tolist() == [2.0, 2.0, 0.1, 0.3, 0.3] and u.from_dict.tolist() == [0, 1, 0]
+    assert u.slice_graphs(1, 3).float_weight.tolist() == [0.1, 0.3, 0.3]
+    big = np.zeros((150, 150)); big[0, 1] = big[1, 0] = 0.1
+    with pytest.raises(NotImplementedError):             # general floats: the float64 matrix of a graph has to fit LDS
+        sp_batch_from_input([[big, {i: 0 for i in range(150)}]], True)
+    with pytest.raises(NotImplementedError):
+        sp_batch_from_input([[np.array([[0, -0.1], [-0.1, 0]]), {0: 1, 1: 1}]], True)
     gb, _ = sp_batch_from_input([[np.array([[0, 3], [0, 0]])]], False)
     assert gb.edge_weight.tolist() == [3] and gb.n_labels == 1
 

@@ -195,14 +195,39 @@ def test_sp_float_weights_against_reference():
     assert np.array_equal(O.SPOracle(with_labels=False).fit_transform([[g[0]] for g in tr]), z["K_fit_unlabelled"])
 
 
-def test_why_non_dyadic_float_weights_are_declined():
+def test_sp_general_float_weights_against_reference():
+    """General float edge weights (0.1-multiples, random floats, directed matrices, edge dictionaries): the reference's
+    three algorithm settings give three DIFFERENT matrices (tests/golden/sp_float.npz, from the real reference); the
+    oracle must give each of them, with the reference's ``_enum`` keys down to the bits of the float distances."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from small_sets import sp_float_graphs
+    z = load_golden("sp_float.npz")
+    G = sp_float_graphs()
+    tr, te = G[:28], G[28:]
+    assert not np.array_equal(z["K_fit_auto"], z["K_fit_fw"]) and not np.array_equal(z["K_fit_fw"], z["K_fit_dij"])
+    for name, algo in (("auto", "auto"), ("fw", "floyd_warshall"), ("dij", "dijkstra")):
+        sp = O.SPOracle(algorithm_type=algo)
+        assert np.array_equal(sp.fit_transform(tr), z["K_fit_" + name]), name
+        assert np.array_equal(sp.transform(te), z["K_tr_" + name]), name
+        keys = sorted(sp.enum.items(), key=lambda kv: kv[1])
+        assert [[k[0], k[1]] for k, _ in keys] == z["enum_labels_" + name].tolist()
+        assert np.array([float(k[2]) for k, _ in keys]).view(np.int64).tolist() == z["enum_dist_bits_" + name].tolist()
+    spn = O.SPOracle(normalize=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        assert np.allclose(spn.fit_transform(tr), z["K_fit_norm"], rtol=1e-12, atol=0, equal_nan=True)
+        assert np.allclose(spn.transform(te), z["K_tr_norm"], rtol=1e-12, atol=0, equal_nan=True)
+    assert np.array_equal(O.SPOracle(with_labels=False).fit_transform([[g[0]] for g in tr]), z["K_fit_unlabelled"])
+
+
+def test_what_general_float_weights_mean_in_the_reference():
     """The reference keys ShortestPath features by the float distance as computed (shortest_path.py:389,412-499): with
     weights like 0.1 the key depends on rounding -- a path 0.1 + 0.2 (0.30000000000000004) and an edge 0.3 are DIFFERENT
     features, and 0.1 + 0.2 + 0.3 differs from 0.3 + 0.2 + 0.1 -- so "the" matrix depends on the order in which the
-    all-pairs routine adds.  The device path counts distances as exact integer multiples of one power of two and
-    therefore declines such weights (grakel_amd.batch.quantise_weights, tests/test_host.py) instead of returning a
-    matrix that agrees with the reference only up to such coincidences.  This pins the behaviour it declines to the
-    oracle (and, in the build container, to the reference itself)."""
+    all-pairs routine adds.  Integer and power-of-two-multiple weights are counted exactly as integers on the device
+    (grakel_amd.batch.quantise_weights); for anything else it has to reproduce the reference's own float distances bit
+    for bit (sp.hip: gk_sp_build_f64; goldens: test_sp_general_float_weights_against_reference).  This pins the behaviour
+    to the oracle (and, in the build container, to the reference itself)."""
     lab = {0: 'a', 1: 'b', 2: 'a'}
     path = [np.array([[0, 0.1, 0], [0.1, 0, 0.2], [0, 0.2, 0]]), lab]           # a -0.1- b -0.2- a
     edge = [np.array([[0, 0, 0.3], [0, 0, 0], [0.3, 0, 0]]), lab]               # a -0.3- a, b apart
