@@ -142,7 +142,9 @@ class ShardExchange(object):
         self.group, self.ws = group, dist.get_world_size(group)
         if label_map is not None:          # the shard was ingested on its own: make the level-0 ids global
             ids, n_labels = reconcile_label_ids(local, label_map, group)
-            local = GraphBatch(local.graph_ptr, local.row_ptr, local.col_idx, ids, n_labels, local.edge_weight)
+            local = GraphBatch(local.graph_ptr, local.row_ptr, local.col_idx, ids, n_labels, local.edge_weight,
+                               getattr(local, "weight_step", 1.0), getattr(local, "float_weight", None),
+                               getattr(local, "from_dict", None))
         self.dev = torch.device("cpu") if device is None else device
         dev = self.dev
 
@@ -170,13 +172,22 @@ class ShardExchange(object):
         self.flat = None
         self._into_tensor = True
         # edge weights (ShortestPath): present on any rank -> every rank sends a (unit-filled) weight segment
-        if getattr(local, "float_weight", None) is not None:
-            raise NotImplementedError('sharded ShortestPath: general float edge weights are not exchanged; use the '
-                                      'single-GPU ShortestPath, or integer / power-of-two-multiple weights')
-        has_w = torch.tensor([1 if local.edge_weight is not None else 0], dtype=torch.int64, device=dev)
+        # general float weights on ANY rank (GraphBatch.float_weight): every rank then sends float64 weights -- its exact
+        # integer / power-of-two-multiple weights as floats -- and, per graph, whether the element came as a dictionary
+        fw_local = getattr(local, "float_weight", None)
+        has_w = torch.tensor([2 if fw_local is not None else (1 if local.edge_weight is not None else 0)],
+                             dtype=torch.int64, device=dev)
         dist.all_reduce(has_w, op=dist.ReduceOp.MAX, group=group)
-        self.weights = None
-        if int(has_w.item()):
+        self.weights, self.float_weights, self.from_dict = None, None, None
+        mode = int(has_w.item())
+        if mode == 2:
+            if fw_local is None:
+                fw_local = (np.ones(local.n_edges, np.float64) if local.edge_weight is None
+                            else local.edge_weight.astype(np.float64) * float(getattr(local, "weight_step", 1.0)))
+            fd = getattr(local, "from_dict", None)
+            self.float_weights = _pad_to(T(np.asarray(fw_local, np.float64)), me, torch)
+            self.from_dict = _pad_to(T(np.asarray(fd if fd is not None else np.zeros(local.n_graphs), np.int32)), mg, torch)
+        elif mode == 1:
             w = local.edge_weight if local.edge_weight is not None else np.ones(local.n_edges, dtype=np.int32)
             self.weights = _pad_to(T(np.asarray(w, dtype=np.int32)), me, torch)
             self.weight_step = float(getattr(local, "weight_step", 1.0))
@@ -190,6 +201,21 @@ class ShardExchange(object):
         parts = [torch.empty_like(self.weights) for _ in range(self.ws)]
         dist.all_gather(parts, self.weights, group=self.group)
         return np.concatenate([parts[r][:int(self.all_sizes[r, 2])].cpu().numpy() for r in range(self.ws)]).astype(np.int32)
+
+    def gather_float_weights(self):
+        """(float64 edge weights, uint8 dictionary flags) of the global batch in the order of the gathered col_idx /
+        graphs, or (None, None): general float weights on some rank (GraphBatch.float_weight)."""
+        import torch
+        import torch.distributed as dist
+        if self.float_weights is None:
+            return None, None
+        pw = [torch.empty_like(self.float_weights) for _ in range(self.ws)]
+        pf = [torch.empty_like(self.from_dict) for _ in range(self.ws)]
+        dist.all_gather(pw, self.float_weights, group=self.group)
+        dist.all_gather(pf, self.from_dict, group=self.group)
+        w = np.concatenate([pw[r][:int(self.all_sizes[r, 2])].cpu().numpy() for r in range(self.ws)]).astype(np.float64)
+        f = np.concatenate([pf[r][:int(self.all_sizes[r, 0])].cpu().numpy() for r in range(self.ws)]).astype(np.uint8)
+        return w, f
 
     def gather_flat(self):
         """ONE collective into a preallocated buffer: the ws messages back to back (what
@@ -373,9 +399,12 @@ class ShardedSP(object):
     all-pairs distances, the pair dictionary and the feature builder on the global batch and then multiplies and
     stores only its own row block.  Shards must carry global level-0 ids (or their ``label_map``, see ShardExchange)."""
 
-    def __init__(self, engine, normalize=False, with_labels=True, group=None):
+    def __init__(self, engine, normalize=False, with_labels=True, group=None, algorithm_type="auto"):
         import torch.distributed as dist
+        if algorithm_type not in ("auto", "floyd_warshall", "dijkstra"):
+            raise ValueError('Unsupported "algorithm_type"')
         self.engine, self.normalize, self.with_labels, self.group = engine, normalize, with_labels, group
+        self.algorithm_type = algorithm_type          # only matters for general float edge weights (shortest_path.py)
         self.ws = dist.get_world_size(group)
         self._exchange, self._local, self._weights, self._stream = None, None, None, None
 
@@ -391,13 +420,18 @@ class ShardedSP(object):
         if self._local is not local_batch:
             self._exchange, self._local = ShardExchange(local_batch, self.group, dev, label_map), local_batch
             self._weights = self._exchange.gather_weights()        # host array: gk_sp_build validates and uploads it
+            self._fweights, fd = self._exchange.gather_float_weights()
+            self._algo = None
+            if self._fweights is not None:
+                self._algo = fd if self.algorithm_type == "auto" else np.full(
+                    fd.shape[0], 1 if self.algorithm_type == "dijkstra" else 0, np.uint8)
         s = self._shared_stream(dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         ex, eng = self._exchange, self.engine
         with torch.cuda.stream(s):
             flat = ex.gather_flat()
             db = eng.batch_from_shards(ex.all_sizes[:, :3], ex.mg, ex.mv, ex.me, flat.data_ptr(), ex.n_labels)
-            pb = eng.sp_build(db, self._weights, self.with_labels)
+            pb = eng.sp_build(db, self._weights, self.with_labels, float_weights=self._fweights, graph_algo=self._algo)
             feat = eng.features(pb, 1)
             rows = (ex.bounds[rank], ex.bounds[rank + 1])
             K = eng.gram(feat, 1 if self.normalize else 0, rows=rows, to_host=to_host)

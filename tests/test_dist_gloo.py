@@ -114,6 +114,22 @@ def _worker_weights(rank, world, port, out_dir):
         l1 = full1.slice_graphs(b[rank], b[rank + 1])
         ok = ok and ShardExchange(GraphBatch(l1.graph_ptr, l1.row_ptr, l1.col_idx, l1.node_label, l1.n_labels, None)).gather_weights() is None
         del plain
+        # general float weights on ONE rank: every rank sends float64 weights (its exact integer weights as floats) and
+        # the per-graph dictionary flags; the gathered arrays are those of the whole batch ingested at once
+        Gf = [[g[0] * 1.0, g[1]] for g in G]
+        for g in Gf[9:]:
+            g[0] = g[0] * 0.1
+        Gf[12] = [{i: {j: float(Gf[12][0][i, j]) for j in range(Gf[12][0].shape[0]) if Gf[12][0][i, j] > 0}
+                   for i in range(Gf[12][0].shape[0])}, Gf[12][1]]
+        fullf, _ = sp_batch_from_input(Gf, True)
+        assert fullf.float_weight is not None and fullf.from_dict[12] == 1
+        lf, _ = sp_batch_from_input(Gf[b[rank]:b[rank + 1]], True, fitted_labels=None)
+        lf = GraphBatch(lf.graph_ptr, lf.row_ptr, lf.col_idx, fullf.slice_graphs(b[rank], b[rank + 1]).node_label, fullf.n_labels,
+                        lf.edge_weight, lf.weight_step, lf.float_weight, lf.from_dict)
+        assert (lf.float_weight is None) == (rank == 0)              # rank 0's shard has integer weights only
+        exf = ShardExchange(lf)
+        fw, fd = exf.gather_float_weights()
+        ok = ok and exf.gather_weights() is None and np.array_equal(fw, fullf.float_weight) and np.array_equal(fd, fullf.from_dict)
         np.save(os.path.join(out_dir, "w_%d.npy" % rank), np.array([int(ok)]))
     finally:
         dist.destroy_process_group()

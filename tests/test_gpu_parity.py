@@ -645,6 +645,11 @@ def _sp_rank_worker(rank, world, port, out_dir, n_graphs, weighted):
 
 
 def _sp_shard_input(n_graphs, weighted):
+    if weighted == "float":                                   # general float weights, edge dictionaries, directed matrices
+        import sys
+        sys.path.insert(0, GOLDEN)
+        from small_sets import sp_float_graphs
+        return sp_float_graphs(n_graphs)
     G = nci1_like(n_graphs, 0, as_adj=True)
     if weighted:                                              # integer edge weights 1..3 on the adjacency matrices
         rs = np.random.RandomState(3)
@@ -655,12 +660,13 @@ def _sp_shard_input(n_graphs, weighted):
     return G
 
 
-@pytest.mark.parametrize("n_graphs,weighted", [(4110, False), (300, True)])
+@pytest.mark.parametrize("n_graphs,weighted", [(4110, False), (300, True), (40, "float")])
 def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, weighted):
     """ShardedSP with two ranks (both on cuda:0, gloo): shard -> all-gather (CSR + edge weights) -> distances, pair
     dictionary and features on the global batch -> the rank's Gram rows.  The stacked row blocks are the
     single-process matrix; at 4110 graphs that is BASELINE config 4's stand-in, checked against the real reference's
-    golden (tests/golden/nci1_like_sp_4110.npz)."""
+    golden (tests/golden/nci1_like_sp_4110.npz); the third case has general float edge weights (float64 weights and the
+    per-graph dictionary flags travel with the shards, the reference's float distances are reproduced on every rank)."""
     import torch.multiprocessing as mp
     port = 29000 + (os.getpid() % 2000)
     mp.spawn(_sp_rank_worker, args=(2, port, str(tmp_path), n_graphs, weighted), nprocs=2, join=True)
@@ -673,7 +679,7 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
         assert np.array_equal(np.diagonal(K), z["diag"]) and np.array_equal(K.sum(axis=1), z["row_sums"])
         assert np.array_equal(K[z["samp_i"], z["samp_j"]], z["samp_v"])
     else:
-        G = _sp_shard_input(n_graphs, True)
+        G = _sp_shard_input(n_graphs, weighted)
         assert np.array_equal(K, O.SPOracle().fit_transform(G))
         assert np.array_equal(K, gk.ShortestPath().fit_transform(G))
 
