@@ -408,7 +408,8 @@ def compress_labels(values, fitted=None):
     if isinstance(values, (bytearray, bytes)):          # csrc/ingest.c: every label is an exact int64
         arr = np.frombuffer(values, dtype=np.int64)
         values = arr
-    else:
+    elif len(values) and isinstance(values[0], (int, np.integer)) and not isinstance(values[0], bool):
+        # (a list that starts with anything else cannot become an integer array: skip the million-element conversion)
         try:
             cand = np.asarray(values)
             if cand.ndim == 1 and cand.dtype.kind in "iu" and len(values) == cand.shape[0]:
@@ -422,7 +423,7 @@ def compress_labels(values, fitted=None):
             uniq, inv = _unique_inverse(arr)
             return inv.astype(np.int32), {int(u): i for i, u in enumerate(uniq.tolist())}
         mapping = {dv: i for i, dv in enumerate(sorted(set(values)))}
-        return np.fromiter((mapping[v] for v in values), np.int32, len(values)), mapping
+        return np.fromiter(map(mapping.__getitem__, values), np.int32, len(values)), mapping
     nl = len(fitted)
     if arr is not None and arr.size and all(type(k) is int for k in fitted):
         # integer labels: the look-up as a sorted search instead of a million dictionary probes
@@ -442,9 +443,11 @@ def compress_labels(values, fitted=None):
             ids[unseen] = nl + inv
             ext = {int(u): nl + i for i, u in enumerate(fresh.tolist())}
         return ids, ext
-    fresh = sorted({v for v in values if v not in fitted})
+    fresh = sorted(set(values).difference(fitted))
     ext = {dv: nl + i for i, dv in enumerate(fresh)}
-    ids = np.fromiter((fitted[v] if v in fitted else ext[v] for v in values), np.int32, len(values))
+    both = dict(fitted)
+    both.update(ext)                                          # one C-level look-up per value
+    ids = np.fromiter(map(both.__getitem__, values), np.int32, len(values))
     return ids, ext
 
 
