@@ -390,10 +390,14 @@ done:;
         PyObject* vals = values;
         PyObject* packed = NULL;
         if (all_int && ivals.n == 8 * (size_t)V) {
+            /* the value LIST was not filled while all_int held: without the packed form there are no labels to hand
+             * back, so a failed allocation is the MemoryError it is (never an empty label list for V vertices) */
             packed = bvec_finish(&ivals);
-            if (packed) vals = packed; else PyErr_Clear();
+            vals = packed;
         }
-        if (a && b && c && want_mask) {
+        if (!vals) {
+            if (!PyErr_Occurred()) PyErr_NoMemory();
+        } else if (a && b && c && want_mask) {
             PyObject* mk = PyByteArray_FromStringAndSize((const char*)flag, (Py_ssize_t)V);
             if (mk) result = PyTuple_Pack(5, a, b, c, vals, mk);
             Py_XDECREF(mk);

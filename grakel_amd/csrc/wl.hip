@@ -959,7 +959,8 @@ extern "C" int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, i
                                int32_t n_labels0, int src_on_device, gk_batch** out) {
     GK_ARG(ctx && out, "gk_batch_create: null ctx/out");
     GK_ARG(n_graphs > 0 && n_nodes >= 0 && n_edges >= 0, "gk_batch_create: bad sizes");
-    GK_ARG(n_nodes < (1ll << 31) - 1 && n_edges < (1ll << 31) - 1, "gk_batch_create: int32 index overflow");
+    GK_ARG(n_nodes < (1ll << 31) - 1 && n_edges < (1ll << 31) - 1 && n_graphs < (1ll << 31) - 1, "gk_batch_create: int32 index overflow");
+    GK_ARG(n_labels0 >= 0, "gk_batch_create: negative n_labels0");
     GK_ARG(graph_ptr && row_ptr && node_label && (col_idx || n_edges == 0), "gk_batch_create: null array");
     GK_HIP_CHECK(hipSetDevice(ctx->device));
     gk_batch* b = new gk_batch();
@@ -1152,8 +1153,11 @@ extern "C" int gk_import_state(gk_ctx* ctx, const void* buf, uint64_t bytes, gk_
     memcpy(magic, p, 8);
     memcpy(hdr, p + 8, 32);
     GK_ARG(magic[0] == GK_STATE_MAGIC && magic[1] == 1u, "gk_import_state: not a gk_hip state blob (or a newer format)");
-    GK_ARG(hdr[0] > 0 && hdr[1] >= 0 && hdr[2] >= 0 && hdr[1] < (1ll << 31) && hdr[2] < (1ll << 31), "gk_import_state: bad sizes");
-    const uint64_t need = 40 + 4ull * (uint64_t)((hdr[0] + 1) + (hdr[1] + 1) + hdr[2] + hdr[1]);
+    // every count below 2^31 (so the sum below cannot wrap), a label count that fits the int32 it is handed on as
+    GK_ARG(hdr[0] > 0 && hdr[0] < (1ll << 31) - 1 && hdr[1] >= 0 && hdr[2] >= 0 && hdr[1] < (1ll << 31) - 1 && hdr[2] < (1ll << 31) - 1,
+           "gk_import_state: bad sizes");
+    GK_ARG(hdr[3] >= 0 && hdr[3] <= 0x7fffffffll, "gk_import_state: bad label count");
+    const uint64_t need = 40 + 4ull * ((uint64_t)(hdr[0] + 1) + (uint64_t)(hdr[1] + 1) + (uint64_t)hdr[2] + (uint64_t)hdr[1]);
     GK_ARG(bytes >= need, "gk_import_state: truncated state");
     const int32_t* gp = (const int32_t*)(p + 40);
     const int32_t* rp = gp + (hdr[0] + 1);

@@ -31,7 +31,7 @@ shard/gather/rebuild logic.
 """
 import numpy as np
 
-from .batch import GraphBatch
+from .batch import GraphBatch, MAX_EDGE_WEIGHT, MAX_FLOAT_WEIGHT_NODES, FLOAT_WEIGHT_LIMIT_MESSAGE
 
 
 def shard_bounds(n_graphs, world_size):
@@ -181,6 +181,15 @@ class ShardExchange(object):
         self.weights, self.float_weights, self.from_dict = None, None, None
         mode = int(has_w.item())
         if mode == 2:
+            # the union counts in float64: EVERY graph of the job then goes through the LDS-resident float64 kernel
+            # (sp.hip: sp_f64_kernel), whatever its own weights were -- same limit, same error as the ingestion's
+            if int(a[:, 0].sum()) and int(np.diff(local.graph_ptr).max(initial=0)) > MAX_FLOAT_WEIGHT_NODES:
+                big = torch.tensor([1], dtype=torch.int64, device=dev)
+            else:
+                big = torch.tensor([0], dtype=torch.int64, device=dev)
+            dist.all_reduce(big, op=dist.ReduceOp.MAX, group=group)
+            if int(big.item()):
+                raise NotImplementedError(FLOAT_WEIGHT_LIMIT_MESSAGE)
             if fw_local is None:
                 fw_local = (np.ones(local.n_edges, np.float64) if local.edge_weight is None
                             else local.edge_weight.astype(np.float64) * float(getattr(local, "weight_step", 1.0)))
@@ -188,9 +197,22 @@ class ShardExchange(object):
             self.float_weights = _pad_to(T(np.asarray(fw_local, np.float64)), me, torch)
             self.from_dict = _pad_to(T(np.asarray(fd if fd is not None else np.zeros(local.n_graphs), np.int32)), mg, torch)
         elif mode == 1:
-            w = local.edge_weight if local.edge_weight is not None else np.ones(local.n_edges, dtype=np.int32)
-            self.weights = _pad_to(T(np.asarray(w, dtype=np.int32)), me, torch)
-            self.weight_step = float(getattr(local, "weight_step", 1.0))
+            # every shard was quantised on its own (batch.quantise_weights): one weight unit for the whole job is the
+            # finest of the ranks' steps (all are powers of two), and every rank re-expresses its integers in it --
+            # otherwise a distance of 0.5 on one rank and of 1.0 on another would both travel as the integer 1
+            step_local = float(getattr(local, "weight_step", 1.0)) if local.edge_weight is not None else 1.0
+            st = torch.tensor([step_local], dtype=torch.float64, device=dev)
+            dist.all_reduce(st, op=dist.ReduceOp.MIN, group=group)
+            self.weight_step = float(st.item())
+            w = (np.asarray(local.edge_weight, dtype=np.int64) if local.edge_weight is not None
+                 else np.ones(local.n_edges, dtype=np.int64))
+            w = w * int(round(step_local / self.weight_step))
+            too_big = torch.tensor([1 if (w.size and int(w.max()) >= MAX_EDGE_WEIGHT) else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(too_big, op=dist.ReduceOp.MAX, group=group)          # every rank raises, or none does
+            if int(too_big.item()):
+                raise NotImplementedError('edge weights of the shards need more than 20 bits at their common '
+                                          'power-of-two step')
+            self.weights = _pad_to(T(w.astype(np.int32)), me, torch)
 
     def gather_weights(self):
         """Global int32 edge-weight array (host) in the order of the gathered col_idx, or None (unit weights)."""

@@ -50,8 +50,36 @@ class PinnedPool(object):
         self.lib = lib
         self.free = collections.OrderedDict()        # (cap, ptr) in release order: oldest first
         self.retained = 0
-        self.lock = threading.Lock()                 # _release runs from __del__, i.e. on any thread
+        # _release runs from __del__, i.e. on any thread and -- when a cyclic-GC pass starts inside one of the critical
+        # sections below -- possibly on the thread that already holds the lock.  So __del__ never waits: it parks the
+        # block in `pending` (deque.append is atomic) and files it only if the lock is free right now; whoever holds
+        # the lock files the parked blocks before it leaves.
+        self.pending = collections.deque()
+        self.lock = threading.Lock()
         self.closed = False
+
+    def _file_pending_locked(self):
+        """(lock held) parked blocks -> the free list, or a list of pointers to hand back to the driver."""
+        drop = []
+        while True:
+            try:
+                ptr, cap = self.pending.popleft()
+            except IndexError:
+                break
+            same = 0
+            for k in self.free:
+                if k[0] == cap:
+                    same += 1
+            if self.closed or same >= self.KEEP or cap > self.MAX_RETAINED:
+                drop.append(ptr)
+                continue
+            self.free[(cap, ptr)] = True
+            self.retained += cap
+            while self.retained > self.MAX_RETAINED and self.free:
+                (c, q), _ = self.free.popitem(last=False)
+                self.retained -= c
+                drop.append(q)
+        return drop
 
     def empty(self, shape):
         import os
@@ -63,12 +91,15 @@ class PinnedPool(object):
         cap = -(-nbytes // self.GRANULE) * self.GRANULE
         ptr = None
         with self.lock:
+            drop = self._file_pending_locked()
             for key in self.free:
                 if key[0] == cap:
                     ptr = key[1]
                     del self.free[key]
                     self.retained -= cap
                     break
+        for q in drop:
+            self.lib.gk_host_free(c_void_p(q))
         if ptr is None:
             p = c_void_p()
             if self.lib.gk_host_alloc(ctypes.c_uint64(cap), byref(p)) != 0 or not p.value:
@@ -81,25 +112,20 @@ class PinnedPool(object):
         return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
     def _release(self, ptr, cap):
-        drop = []
-        with self.lock:
-            same = [k for k in self.free if k[0] == cap]
-            if self.closed or len(same) >= self.KEEP or cap > self.MAX_RETAINED:
-                drop.append(ptr)
-            else:
-                self.free[(cap, ptr)] = True
-                self.retained += cap
-                while self.retained > self.MAX_RETAINED and self.free:
-                    (c, q), _ = self.free.popitem(last=False)
-                    self.retained -= c
-                    drop.append(q)
+        self.pending.append((ptr, cap))
+        if not self.lock.acquire(False):             # held (maybe by this very thread): the holder files the block
+            return
+        try:
+            drop = self._file_pending_locked()
+        finally:
+            self.lock.release()
         for q in drop:
             self.lib.gk_host_free(c_void_p(q))
 
     def trim(self, keep_bytes=0):
         """Free retained blocks, oldest first, until at most ``keep_bytes`` stay pinned."""
-        drop = []
         with self.lock:
+            drop = self._file_pending_locked()
             while self.retained > keep_bytes and self.free:
                 (c, q), _ = self.free.popitem(last=False)
                 self.retained -= c

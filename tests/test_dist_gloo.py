@@ -130,6 +130,18 @@ def _worker_weights(rank, world, port, out_dir):
         exf = ShardExchange(lf)
         fw, fd = exf.gather_float_weights()
         ok = ok and exf.gather_weights() is None and np.array_equal(fw, fullf.float_weight) and np.array_equal(fd, fullf.from_dict)
+        # shards ingested ON THEIR OWN, with different weight units: rank 0's weights are multiples of 0.5, rank 1's are
+        # integers -- each shard's quantisation picks its own step (0.5 and 1.0), the exchange must re-express both in
+        # the finer one, or a distance of 0.5 and a distance of 1.0 would be the same integer
+        Gs = [[np.minimum(g[0], 1) * (0.5 if i < 9 else 1.0), g[1]] for i, g in enumerate(G)]
+        fulls, _ = sp_batch_from_input(Gs, True)
+        ls, _ = sp_batch_from_input(Gs[b[rank]:b[rank + 1]], True)
+        assert ls.weight_step == (0.5 if rank == 0 else 1.0) and fulls.weight_step == 0.5
+        ls = GraphBatch(ls.graph_ptr, ls.row_ptr, ls.col_idx, fulls.slice_graphs(b[rank], b[rank + 1]).node_label, fulls.n_labels,
+                        ls.edge_weight, ls.weight_step)
+        exs = ShardExchange(ls)
+        ws = exs.gather_weights()
+        ok = ok and exs.weight_step == 0.5 and np.array_equal(ws, fulls.edge_weight)
         np.save(os.path.join(out_dir, "w_%d.npy" % rank), np.array([int(ok)]))
     finally:
         dist.destroy_process_group()
