@@ -172,7 +172,7 @@ static const OptName g_opt_names[] = {
     {"wl.no_split", &gk_opts::wl_no_split}, {"wl.no_exact1", &gk_opts::wl_no_exact1}, {"wl.no_active_set", &gk_opts::wl_no_active_set},
     {"wl.no_bucket_dict", &gk_opts::wl_no_bucket_dict}, {"wl.no_hist0", &gk_opts::wl_no_hist0},
     {"wl.frozen_words", &gk_opts::wl_frozen_words}, {"wl.flag_bytes", &gk_opts::wl_flag_bytes},
-    {"wl.sig_no_regs", &gk_opts::wl_sig_no_regs}, {"wl.debug", &gk_opts::wl_debug}, {"sort.buckets", &gk_opts::sort_buckets},
+    {"wl.sig_no_regs", &gk_opts::wl_sig_no_regs}, {"wl.no_stream", &gk_opts::wl_no_stream}, {"wl.debug", &gk_opts::wl_debug}, {"sort.buckets", &gk_opts::sort_buckets},
     {"wl.bd_slots", &gk_opts::bd_slots}, {"feat.no_gm", &gk_opts::feat_no_gm}, {"feat.gm_no_priv", &gk_opts::gm_no_priv}, {"feat.gm_rows_wg", &gk_opts::gm_rows_wg},
     {"feat.low_df", &gk_opts::low_df}, {"feat.gm_row_lds_max", &gk_opts::gm_row_lds_max},
     {"gram.dd", &gk_opts::gram_dd}, {"gram.no_fp4", &gk_opts::gram_no_fp4}, {"gram.no_ws", &gk_opts::gram_no_ws}, {"gram.no_sym", &gk_opts::gram_no_sym},

@@ -85,6 +85,7 @@ struct gk_opts {
     int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)
     int sp_no_reg = 0;           // all-pairs distances of small graphs by the LDS workgroup kernel instead of wave-per-graph registers
     // plumbing
+    int wl_no_stream = 0;        // never the relabel route without host round trips (wl_stream.hip)
     int no_mailbox = 0;
     int poison = 0;              // debug: fill every block handed out by the allocator with this byte pattern (| 0x100)
 };
@@ -198,6 +199,7 @@ struct gk_batch {
     i32* car_class = nullptr;   // [n_iso + 1]
     i32* car_nodes = nullptr;   // [n_iso] the carried list itself: vertex at each slot
     i64 n_iso = 0;
+    i64 n_isolated = 0;         // isolated vertices of the batch (n_iso stays 0 under option wl.no_iso: nothing is carried then)
     // levels
     int n_levels = 0;                  // levels currently valid (0 = only level-0 labels)
     int cap_levels = 0;
@@ -230,7 +232,27 @@ struct gk_batch {
     // features of that level come from one LDS histogram per graph (features.hip), perm[0] stays unused
     bool level0_hist = false;
     i32 n_labels0_present = 0;         // distinct level-0 label ids that occur (valid when n_labels0 <= GK_HIST0_MAX_LABELS)
+    // ---- stream layout (wl_stream.hip: the relabel route without host round trips).  ids of a level l >= 1 are
+    //   [carried classes 0 .. n_cc) | frozen nodes [n_cc, n_cc + F_l) | shared classes [.., + S_l) | new singletons [.., + T_l)
+    // a label can be shared iff id < n_cc or n_cc + F_l <= id < n_cc + F_l + S_l; F_l / S_l / T_l live on the device
+    // (sr_ctl, SR_CTL words per level) so that the feature builder can be queued without the host knowing them
+    bool stream_layout = false;
+    u32* sr_ctl = nullptr;             // [cap of sr_ctl_levels][SR_CTL]
+    int sr_ctl_levels = 0;
+    std::vector<u32> sr_F, sr_S;       // host copies (after the job's one read-back)
+    u32 sr_ncc = 0;
 };
+
+// per-level control words of the stream layout (device)
+#define SR_CTL 16
+#define SR_F 0          // frozen nodes before this level (ids [n_cc, n_cc + F))
+#define SR_S 1          // classes with two or more members among the level's active nodes
+#define SR_T 2          // singleton classes among them
+#define SR_COUNT 3      // labels of the level = n_cc + F + S + T
+#define SR_LISTED 4     // active nodes whose class is shared (= the next level's active nodes)
+#define SR_UNRES 5      // nodes whose full signature differs from their class representative's (hash collision)
+#define SR_NCC 6        // carried classes (isolated vertices by input label)
+#define SR_OVF 7        // a bucket of the dictionary overflowed
 
 // ---------------------------------------------------------------------------------------
 // Features
@@ -331,6 +353,8 @@ int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32*
 
 // ---- wl.hip ---------------------------------------------------------------------------
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);
+// wl_stream.hip: GK_ERR_UNSUPPORTED = not applicable to this job / a table overflowed / a hash collision: take the host-driven route
+int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits, std::vector<u32>& counts);
 int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level);
 int gk_sp_materialise(gk_ctx* ctx, gk_batch* pair_batch);            // sp.hip: item arrays of a histogram-form pair batch      // perm[level] on demand (sort-free dictionary levels)
 

@@ -73,8 +73,54 @@ struct GmPriv {
     int bins;                         // private bins in total (even)
 };
 
+// The level slots as the kernels of the graph batches read them -- from DEVICE memory, so that a job whose label counts
+// only exist on the device (stream layout, wl_stream.hip) is queued without a host round trip.  Labels of slot j that can be
+// shared: [0, ncc) and [lo, lo + S); their index in the concatenated label space is off + x resp. off + ncc + (x - lo).
+// (host-driven layouts: ncc = 0, lo = first shareable id, S = labels from there on.)
+struct GmTable {
+    u32 lo[FEAT_MAX_LEVELS], S[FEAT_MAX_LEVELS], ncc[FEAT_MAX_LEVELS];
+    u32 off[FEAT_MAX_LEVELS + 1];
+    i32 poff[FEAT_MAX_LEVELS];        // first private bin of the slot, -1: global atomics (GmPriv)
+    u32 bins;                         // private bins in total (even)
+    u32 Q;                            // shareable labels of all slots = off[L]
+    u32 L;
+};
+
+// First launch of a graph-major feature job: the level table (copied from the host's, or computed from the stream
+// layout's control words) and the zero fill of the per-label counters -- only the Q labels there are, not the bound the
+// arrays were allocated for.
+__global__ __launch_bounds__(256) void gm_prep_kernel(const GmTable Tv, const u32* __restrict__ ctl, int level0, int priv_ok,
+                                                       u32 priv_budget, GmTable* __restrict__ Td, u32* __restrict__ df,
+                                                       u32* __restrict__ cmax, u32* __restrict__ cursor, u32* __restrict__ side_words) {
+    __shared__ u32 Qs;
+    if (threadIdx.x == 0) {
+        if (!ctl) {
+            if (blockIdx.x == 0) *Td = Tv;
+            Qs = Tv.Q;
+        } else {
+            const bool w = blockIdx.x == 0;
+            u32 off = 0, bins = 0;
+            for (u32 j = 0; j < Tv.L; ++j) {
+                const u32* c = ctl + (size_t)(level0 + (int)j) * SR_CTL;
+                const u32 ncc = c[SR_NCC], lo = ncc + c[SR_F], S = c[SR_S], space = ncc + S;
+                i32 po = -1;
+                if (priv_ok && space > 0 && bins + space <= priv_budget) po = (i32)bins, bins += space;
+                if (w) Td->lo[j] = lo, Td->S[j] = S, Td->ncc[j] = ncc, Td->off[j] = off, Td->poff[j] = po;
+                off += space;
+            }
+            if (w) Td->off[Tv.L] = off, Td->bins = (bins + 1u) & ~1u, Td->Q = off, Td->L = Tv.L;
+            Qs = off;
+        }
+    }
+    __syncthreads();
+    const u32 Q = Qs;
+    const u32 stride = gridDim.x * 256u;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < Q; i += stride) df[i] = 0u, cmax[i] = 0u, cursor[i] = 0u;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < (Q + 3u) / 4u; i += stride) side_words[i] = 0u;
+}
+
 template <int WAVES>
-__device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+__device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArrays A, const GmTable* __restrict__ Tb, int priv_cap_words,
                                                                 const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
                                                                 i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
                                                                 u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
@@ -83,10 +129,10 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private histogram | per wave: keys[T] | count + owner << 16 [T]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32* priv = (u32*)gm_lds;                                          // two 16-bit bins per word
-    const int priv_words = R.bins / 2;
+    const int priv_words = (int)(Tb->bins / 2u);                       // <= priv_cap_words (the LDS image is laid out for the cap)
     for (int t = threadIdx.x; t < priv_words; t += blockDim.x) priv[t] = 0;
     __syncthreads();
-    i32* keys = gm_lds + priv_words + (size_t)w * 2 * T;
+    i32* keys = gm_lds + priv_cap_words + (size_t)w * 2 * T;
     u32* co = (u32*)(keys + T);
     const u32 tmask = (u32)T - 1u;
     u32 maxc = 0, entries = 0;
@@ -116,12 +162,16 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
         for (int j = 0; j < P.L; ++j) {
             const i32* __restrict__ lab = P.lab[j];
             const unsigned char* __restrict__ fl = P.flag[j];
-            const i32 base = P.id_base[j];
-            const i32 poff = R.off[j];
+            const u32 lo = Tb->lo[j], nsh = Tb->S[j], ncc = Tb->ncc[j], qoff = Tb->off[j];
+            const u32 space = Tb->off[j + 1] - qoff;
+            const i32 poff = Tb->poff[j];
+            // can the label be shared (see GmTable), and its index in the concatenated label space
+            auto shareable = [&](i32 x) __attribute__((always_inline)) { return (u32)x - lo < nsh || (u32)x < ncc; };
+            auto qof = [&](i32 x) __attribute__((always_inline)) { return (i32)(qoff + ((u32)x < ncc ? (u32)x : ncc + ((u32)x - lo))); };
             // one (label, graph, count) entry: df / class flags of the label, the graph's self similarity
             auto emit = [&](i32 x, u32 c) __attribute__((always_inline)) {
                 if (poff >= 0) {
-                    const u32 bin = (u32)poff + (u32)(x - base);
+                    const u32 bin = (u32)poff + ((u32)qof(x) - qoff);
                     const int sh = 16 * (bin & 1u);
                     u32 add = 1u;
                     if (rectangular) add |= side_bit << GM_PRIV_SIDE_SHIFT;
@@ -132,7 +182,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                     if (flags) atomicOr(&priv[bin >> 1], flags << sh);
                     atomicAdd(&priv[bin >> 1], 1u << sh);
                 } else {
-                    const i64 q = P.off[j] + (x - base);
+                    const i64 q = qof(x);
                     // guarded global atomics (device-scope atomics execute memory-side: slow, and a label present
                     // in thousands of graphs would queue thousands of them on one address): add only while df counts
                     if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
@@ -147,14 +197,14 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
             u32* __restrict__ ec = ent_cnt + (i64)j * V + v0;
             u32* __restrict__ ne = ent_n + (i64)j * n_graphs + g;
             if (small) {
-                i32 a = (fa && ra >= base) ? ra : BIG, b2 = (fb && rb >= base) ? rb : BIG;
+                i32 a = (fa && shareable(ra)) ? ra : BIG, b2 = (fb && shareable(rb)) ? rb : BIG;
                 if (j + 1 < P.L) fetch(j + 1);
                 u64 Ma = __ballot(a != BIG), Mb = __ballot(b2 != BIG);
                 if (!(Ma | Mb)) {                                    // nothing shared in this graph at this level
                     if (lane == 0) *ne = 0;
                     continue;
                 }
-                if (__builtin_popcountll(Ma) + __builtin_popcountll(Mb) <= GM_FEW || P.off[j + 1] - P.off[j] <= GM_FEW) {
+                if (__builtin_popcountll(Ma) + __builtin_popcountll(Mb) <= GM_FEW || space <= (u32)GM_FEW) {
                     // few distinct labels (deep levels: a handful of shared nodes per graph; level 0: a handful of
                     // labels): one wave-uniform round per distinct label -- take the first remaining node's label,
                     // ballot its equals; entry k lands in lane k
@@ -168,7 +218,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                         if (lane == k) mx = x, mc = (u32)(__builtin_popcountll(ea) + __builtin_popcountll(eb));
                         Ma &= ~ea, Mb &= ~eb, ++k;
                     }
-                    if (lane < k) el[lane] = mx, ec[lane] = mc;
+                    if (lane < k) el[lane] = qof(mx), ec[lane] = mc;
                     if (lane == 0) *ne = (u32)k;
                     if (lane < k) emit(mx, mc);
                     continue;
@@ -180,8 +230,8 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
 #pragma unroll
                     for (int jj = k >> 1; jj > 0; jj >>= 1) {
                         if (jj == 64) {                      // partner = the lane's other register (only k == 128: ascending)
-                            const i32 lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
-                            a = lo, b2 = hi;
+                            const i32 mn = a < b2 ? a : b2, mx2 = a < b2 ? b2 : a;
+                            a = mn, b2 = mx2;
                         } else {
                             const i32 pa = __shfl_xor(a, jj, 64), pb = __shfl_xor(b2, jj, 64);
                             const bool lower = (lane & jj) == 0;
@@ -210,8 +260,8 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                 const u64 Va = __ballot(ca != 0), Vb = __ballot(cb != 0);
                 const u64 below = (1ull << lane) - 1ull;
                 const int na = __builtin_popcountll(Va);
-                if (ca) { const int k = __builtin_popcountll(Va & below); el[k] = a, ec[k] = ca; }
-                if (cb) { const int k = na + __builtin_popcountll(Vb & below); el[k] = b2, ec[k] = cb; }
+                if (ca) { const int k = __builtin_popcountll(Va & below); el[k] = qof(a), ec[k] = ca; }
+                if (cb) { const int k = na + __builtin_popcountll(Vb & below); el[k] = qof(b2), ec[k] = cb; }
                 if (lane == 0) *ne = (u32)(na + __builtin_popcountll(Vb));
                 if (ca) emit(a, ca);
                 if (cb) emit(b2, cb);
@@ -221,7 +271,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                 __builtin_amdgcn_wave_barrier();
                 for (int i = lane; i < n; i += 64) {
                     const i32 x = lab[v0 + i];
-                    if (x < base || (fl && !fl[v0 + i])) continue;
+                    if (!shareable(x) || (fl && !fl[v0 + i])) continue;
                     u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
                     for (;;) {
                         const i32 old = atomicCAS(&keys[h], -1, x);
@@ -235,13 +285,14 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                 for (int i = lane; i < n; i += 64) {
                     const i32 x = lab[v0 + i];
                     u32 c = 0;
-                    if (x >= base && (!fl || fl[v0 + i])) {
+                    const bool sh = shareable(x) && (!fl || fl[v0 + i]);
+                    if (sh) {
                         u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
                         while (keys[h] != x) h = (h + 1u) & tmask;
                         const u32 e = co[h];
                         if ((e >> 16) == (u32)i) c = e & 0xffffu;
                     }
-                    el[i] = x, ec[i] = c;
+                    el[i] = sh ? qof(x) : 0, ec[i] = c;
                     if (c) emit(x, c);
                 }
                 if (lane == 0) *ne = (u32)n;                      // one slot per node, count 0 = no entry
@@ -260,7 +311,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
     // largest count / entries of this workgroup: one plain store per workgroup (thousands of atomics on two cache
     // lines of meta[] serialise in one L2 channel); block 0 of gm_scan_apply_kernel folds them into meta[]
     __syncthreads();                                   // the counting tables are done with: reuse their first words
-    u32* red = (u32*)(gm_lds + priv_words);
+    u32* red = (u32*)(gm_lds + priv_cap_words);
     if (lane == 0) red[2 * w] = maxc, red[2 * w + 1] = entries;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -276,23 +327,24 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
 // run ONE per CU (the other half of a 2-per-CU grid queues behind it: measured waves live 30 us, the kernel 73 us);
 // capping the SGPRs at 80 to fit two spills to scratch and is no faster (75 us).  So: 8-wave workgroups, three per CU
 // (24 waves / CU), 61 us.
-__global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+__global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels P, const GmLabelArrays A, const GmTable* __restrict__ Tb, int priv_cap_words,
                                                                 const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
                                                                 i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
                                                                 u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
                                                                 int rectangular, u32 df_cap, int T, int prim_max,
                                                                 int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta) {
-    gm_pairs_body<GM_WAVES>(P, A, R, graph_ptr, n_graphs, V, ent_lab, ent_cnt, ent_n, selfk, meta, n_levels, kind, n_fit, rectangular, df_cap, T, prim_max, wide_above, part, wgmeta);
+    gm_pairs_body<GM_WAVES>(P, A, Tb, priv_cap_words, graph_ptr, n_graphs, V, ent_lab, ent_cnt, ent_n, selfk, meta, n_levels, kind, n_fit, rectangular, df_cap, T, prim_max, wide_above, part, wgmeta);
 }
 // sum the workgroups' private histograms: df (saturating at what the column scan distinguishes), the count class as
 // a representative cmax (1, prim_max + 1 or wide_above + 1), the side bits
-__global__ __launch_bounds__(1024) void gm_reduce_kernel(const GmLevels P, const GmLabelArrays A, const GmPriv R,
+__global__ __launch_bounds__(1024) void gm_reduce_kernel(const GmLabelArrays A, const GmTable* __restrict__ Tb,
                                                          const u32* __restrict__ part, int n_wg, int prim_max, int wide_above,
                                                          int rectangular) {
     // block = 64 consecutive words x 16 row groups (wave w sums the workgroups w, w + 16, ...), combined in LDS
     __shared__ u32 sc0[16][64], sc1[16][64], sf[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int words = R.bins / 2;
+    const int words = (int)(Tb->bins / 2u);
+    if ((int)blockIdx.x * 64 >= words) return;                 // the grid covers the cap of the private bins
     const int t = blockIdx.x * 64 + lane;
     u32 c0 = 0, c1 = 0, fl = 0;
     if (t < words)
@@ -309,10 +361,10 @@ __global__ __launch_bounds__(1024) void gm_reduce_kernel(const GmLevels P, const
     for (int k = 0; k < 2; ++k) {
         const u32 bin = 2u * (u32)t + (u32)k, c = k ? c1 : c0, f = k ? (fl >> 16) : (fl & 0xffffu);
         int j = -1;
-        for (int s = 0; s < P.L; ++s)
-            if (R.off[s] >= 0 && (i64)bin >= R.off[s] && (i64)bin < R.off[s] + (P.off[s + 1] - P.off[s])) j = s;
+        for (int s = 0; s < (int)Tb->L; ++s)
+            if (Tb->poff[s] >= 0 && (i64)bin >= Tb->poff[s] && (i64)bin < (i64)Tb->poff[s] + (i64)(Tb->off[s + 1] - Tb->off[s])) j = s;
         if (j < 0) continue;                                   // padding bin
-        const i64 q = P.off[j] + (bin - (u32)R.off[j]);
+        const i64 q = (i64)Tb->off[j] + (bin - (u32)Tb->poff[j]);
         A.df[q] = c;
         A.cmax[q] = (f & GM_PRIV_BIG2) ? (u32)wide_above + 1u : ((f & GM_PRIV_BIG1) ? (u32)prim_max + 1u : (c ? 1u : 0u));
         if (rectangular) A.side[q] = (unsigned char)((f >> GM_PRIV_SIDE_SHIFT) & 3u);
@@ -339,7 +391,7 @@ __device__ __forceinline__ Gm3 gm3_shfl_down(const Gm3& x, int off) {
 }
 
 struct GmColumns {
-    GmLabelArrays A; i64 Q; int symmetric; int low_df; int kind; int prim_max; int wide_above; u32* meta;
+    GmLabelArrays A; const GmTable* Tb; int symmetric; int low_df; int kind; int prim_max; int wide_above; u32* meta;
     const u32* wgmeta; int n_wg;                  // gm_pairs_kernel's per-workgroup (largest count, entries)
     __device__ __forceinline__ Gm3 value(i64 q) const {
         Gm3 v{0, 0, 0};
@@ -380,11 +432,12 @@ struct GmColumns {
 __global__ __launch_bounds__(G3_THREADS) void gm_scan_sums_kernel(const GmColumns f, Gm3* __restrict__ partial) {
     __shared__ Gm3 wsum[G3_THREADS / 64];
     const i64 base = (i64)blockIdx.x * G3_TILE;
+    const i64 Q = f.Tb->Q;                      // the grid covers the bound the arrays were allocated for
     Gm3 s{0, 0, 0};
 #pragma unroll
     for (int i = 0; i < G3_ITEMS; ++i) {
         const i64 idx = base + (i64)i * G3_THREADS + threadIdx.x;
-        if (idx < f.Q) s += f.value(idx);
+        if (idx < Q) s += f.value(idx);
     }
     for (int off = 32; off > 0; off >>= 1) s += gm3_shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
@@ -400,6 +453,9 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
     __shared__ Gm3 wsum[G3_THREADS / 64];
     __shared__ Gm3 bsum[G3_THREADS / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const i64 Q = f.Tb->Q;
+    const i64 last_tile = Q > 0 ? (Q - 1) / G3_TILE : 0;
+    if ((i64)blockIdx.x > last_tile) return;         // the grid covers the bound the arrays were allocated for
     if (blockIdx.x == 0 && w == 0) {                  // fold the pair kernel's per-workgroup statistics
         u32 m = 0, e = 0;
         for (int k = lane; k < f.n_wg; k += 64) m = f.wgmeta[2 * k] > m ? f.wgmeta[2 * k] : m, e += f.wgmeta[2 * k + 1];
@@ -421,7 +477,7 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
     for (int i = 0; i < G3_ITEMS; ++i) {
         const i64 idx = tile0 + (i64)i * G3_THREADS + threadIdx.x;
         Gm3 v{0, 0, 0};
-        if (idx < f.Q) v = f.value(idx);
+        if (idx < Q) v = f.value(idx);
         Gm3 inc = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -436,7 +492,7 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
             if (q < w) woff += wsum[q];
             row += wsum[q];
         }
-        if (idx < f.Q) {
+        if (idx < Q) {
             Gm3 incl = carry;
             incl += woff;
             incl += inc;
@@ -445,7 +501,7 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
         carry += row;
         __syncthreads();
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) f.finish(carry);
+    if ((i64)blockIdx.x == last_tile && threadIdx.x == 0) f.finish(carry);
 }
 
 // one workgroup per graph: the operand row in LDS (row_bytes <= GM_ROW_LDS_MAX), written once
@@ -468,7 +524,7 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
         if ((u32)i >= slots[j]) continue;
         const u32 c = cnt[(i64)j * V + v0 + i];
         if (!c) continue;
-        const i64 q = P.off[j] + (ent_lab[(i64)j * V + v0 + i] - P.id_base[j]);
+        const i64 q = ent_lab[(i64)j * V + v0 + i];                                     // index in the concatenated label space
         const i32 col = A.colid[q];
         if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;          // secondary int8 region: bytes [0, prim0)
         else if (col >= 0) {
@@ -521,7 +577,7 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
         if ((u32)i >= slots[j]) continue;
         const u32 c = cnt[(i64)j * V + v0 + i];
         if (!c) continue;
-        const i64 q = P.off[j] + (ent_lab[(i64)j * V + v0 + i] - P.id_base[j]);
+        const i64 q = ent_lab[(i64)j * V + v0 + i];
         const i32 col = A.colid[q];
         if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;
         else if (col >= 0) {
@@ -556,13 +612,14 @@ __global__ void gm_pad_rows_kernel(int8_t* __restrict__ phi, i64 bytes) {
 // Second half of the graph-major builder, shared with the ShortestPath histogram form (gk_features_build_sp): column classes
 // from df / cmax, operand sizes (one host read-back), operand rows, rare lists.  graph_ptr = item ranges of the graphs
 // (node ranges, or pair ranges of a pair batch), V = items in all; ent / cnt / ent_n = the graphs' (label, count) entries.
-static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& A, i64 Q, size_t qa, const i32* graph_ptr, i64 N, i64 V,
+// Q = bound of the label space (the arrays' allocation; the label count itself is Tb->Q on the device)
+static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& A, const GmTable* Tb, i64 Q, const i32* graph_ptr, i64 N, i64 V,
                      const i32* ent, const u32* cnt, const u32* ent_n, const u32* wgmeta, int grid, int prim_max, int wide_above) {
     const int kind = f->kind;
     void* q = nullptr;
     std::vector<u32> h(GM_META_WORDS, 0);
     if (Q > 0) {
-        GmColumns gc{A, Q, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta, grid};
+        GmColumns gc{A, Tb, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta, grid};
         const i64 nblk = cdiv(Q, G3_TILE);
         Tmp<Gm3> partial(ctx);
         GK_TRY(partial.alloc((size_t)nblk));
@@ -628,12 +685,23 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries
     f->gm = true;
     f->gm_low_q = A.low_q, f->gm_roff = A.roff, f->gm_low_graph = lg, f->gm_low_cnt = lc, f->gm_low_lab = ll;
-    // df is read by the pair-update kernel: keep it (moves out of the zeroed temporary)
-    {
+    f->gm_df = A.df;            // read by the pair-update kernels of gram.hip (owned by the job's arena)
+    return GK_OK;
+}
+
+// per-label arrays of a graph-major job (qa entries each): df / colid / roff / low_q stay with the job (arena),
+// cmax / cursor / side live as long as the builder runs
+static int gm_label_arrays(gk_ctx* ctx, gk_feat* f, size_t qa, GmLabelArrays& A, Tmp<u32>& scratch) {
+    void* q = nullptr;
+    i32** keep[] = {(i32**)&A.df, &A.colid, (i32**)&A.roff, &A.low_q};
+    for (i32** a : keep) {
         GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));
-        GK_HIP_CHECK(hipMemcpyAsync(q, A.df, qa * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        f->gm_df = (u32*)q, f->arena.push_back(q);
+        *a = (i32*)q;
+        f->arena.push_back(q);
     }
+    GK_TRY(scratch.alloc(2 * qa + qa / 4));             // [cmax | cursor | side (bytes)]
+    A.cmax = scratch.p, A.cursor = scratch.p + qa;
+    A.side = (unsigned char*)(scratch.p + 2 * qa);
     return GK_OK;
 }
 
@@ -641,12 +709,23 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
 int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int prim_max, int wide_above) {
     const i64 V = b->n_nodes, N = b->n_graphs;
     const int kind = f->kind;
-    void* q = nullptr;
+    const bool stream = b->stream_layout;                     // the label counts of the levels only exist on the device
     // ---- level slots
     GmLevels P = {};                                    // unused slots stay null (deterministic)
+    GmTable Tv = {};
     P.L = 0, P.off[0] = 0;
+    i64 Qb = 0;                                         // bound of the label space (= the space itself when the host knows it)
     for (int ll = 0; ll < n_levels; ++ll) {
         const int l = f->level0 + ll;                         // the batch's level (a feature job may cover a range of levels)
+        if (stream) {
+            // every level is a slot (which ones list nothing is not known here); at most half of the nodes sit in
+            // shared classes' worth of labels, plus the carried classes
+            const int j = P.L++;
+            P.lab[j] = b->labels + (size_t)l * V, P.level[j] = ll, P.flag[j] = nullptr, P.id_base[j] = 0;
+            Qb += l == 0 ? (i64)b->n_labels0 : std::min<i64>(b->n_iso, (i64)b->n_labels0) + V / 2;
+            P.off[j + 1] = Qb;
+            continue;
+        }
         const i64 nl = (l == 0 && b->level0_hist) ? V : ((size_t)l < b->n_sorted.size() ? b->n_sorted[l] : V);
         if (nl == 0) continue;                                // nothing shared: baseline only
         const int j = P.L++;
@@ -658,25 +737,18 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         P.off[j + 1] = P.off[j] + (count - P.id_base[j]);
         // full level with a listed prefix: the relabel left per-node flags (wl.hip: HeadAssignSplit)
         if (!act && nl < V && b->shared_flag) P.flag[j] = b->shared_flag + (size_t)l * V;
+        Tv.lo[j] = (u32)P.id_base[j], Tv.S[j] = (u32)(count - P.id_base[j]), Tv.ncc[j] = 0, Tv.off[j] = (u32)P.off[j];
+        Qb = P.off[j + 1];
     }
-    const i64 Q = P.off[P.L];
+    const i64 Q = Qb;
     GK_ARG(Q < (1ll << 31), "gk_features_build: label space too large");
-    // ---- per-label arrays (zeroed in one go), flags of the full levels, counts
+    Tv.L = (u32)P.L, Tv.Q = (u32)Q, Tv.off[P.L] = (u32)Q;
+    // ---- per-label arrays, the graphs' entries
     const size_t qa = (size_t)round_up(Q > 0 ? Q : 1, 64);
-    Tmp<u32> zeroed(ctx);                     // [df | cmax | cursor | side (bytes)]
-    const size_t zero_words = 3 * qa + qa / 4;
-    GK_TRY(zeroed.alloc(zero_words));
-    GK_TRY(gk_zero_async(ctx, zeroed.p, zero_words * 4));
     GmLabelArrays A;
-    A.df = zeroed.p, A.cmax = zeroed.p + qa, A.cursor = zeroed.p + 2 * qa;
-    A.side = (unsigned char*)(zeroed.p + 3 * qa);
-    i32** keep[] = {&A.colid, (i32**)&A.roff, &A.low_q};
-    for (i32** a : keep) {
-        GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));
-        *a = (i32*)q;
-        f->arena.push_back(q);
-    }
-    Tmp<u32> cnt(ctx);           // the graphs' entries: slot v of level j = (label ent.p[..], count cnt.p[..]), count 0 = no entry
+    Tmp<u32> scratch(ctx);
+    GK_TRY(gm_label_arrays(ctx, f, qa, A, scratch));
+    Tmp<u32> cnt(ctx);           // the graphs' entries: slot v of level j = (label index ent.p[..], count cnt.p[..]), count 0 = no entry
     Tmp<i32> ent(ctx);
     GK_TRY(cnt.alloc((size_t)(P.L > 0 ? P.L : 1) * (size_t)(V > 0 ? V : 1)));
     GK_TRY(ent.alloc((size_t)(P.L > 0 ? P.L : 1) * (size_t)(V > 0 ? V : 1)));
@@ -691,28 +763,33 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     i64 grid = cdiv(N, waves);
     if (grid > per_cu * (i64)n_cu) grid = per_cu * (i64)n_cu;
     // per_cu workgroups share a CU's 160 KiB: private histogram + one counting table per wave
-    const i64 priv_budget = std::max<i64>(0, (160 * 1024 / per_cu - 1024 - (i64)waves * 2 * T * 4) / 2);
-    GmPriv R;
-    R.bins = 0;
+    const i64 priv_budget = std::max<i64>(0, (160 * 1024 / per_cu - 1024 - (i64)waves * 2 * T * 4) / 2) & ~1ll;
     const bool priv_ok = kind == GK_FEAT_DOT && !ctx->opt.gm_no_priv && cdiv(N, grid * waves) + 1 < (i64)GM_PRIV_COUNT_MASK;
-    for (int j = 0; j < FEAT_MAX_LEVELS; ++j) R.off[j] = -1;
-    for (int j = 0; j < P.L; ++j) {
+    i64 bins = 0;
+    for (int j = 0; j < FEAT_MAX_LEVELS; ++j) Tv.poff[j] = -1;
+    for (int j = 0; j < P.L && !stream; ++j) {
         const i64 ids = P.off[j + 1] - P.off[j];
-        if (priv_ok && ids > 0 && R.bins + ids <= priv_budget) R.off[j] = R.bins, R.bins += (int)ids;
+        if (priv_ok && ids > 0 && bins + ids <= priv_budget) Tv.poff[j] = (i32)bins, bins += ids;
     }
-    R.bins = (R.bins + 1) & ~1;
-    const size_t pairs_lds = (size_t)R.bins * 2 + (size_t)waves * 2 * T * 4;
+    Tv.bins = (u32)((bins + 1) & ~1ll);
+    // the LDS image is laid out for the cap of the private bins when only the device knows the label spaces
+    const int priv_cap_words = stream ? (int)(priv_ok ? priv_budget / 2 : 0) : (int)(Tv.bins / 2);
+    const size_t pairs_lds = (size_t)priv_cap_words * 4 + (size_t)waves * 2 * T * 4;
     GK_ARG(pairs_lds <= 160 * 1024, "gk_features_build: graph too large for the graph-major builder");
     GK_TRY(gk_func_lds(ctx, (const void*)gm_pairs_kernel, (int)pairs_lds));
     Tmp<u32> part(ctx), wgmeta(ctx);
+    Tmp<GmTable> table(ctx);
+    GK_TRY(table.alloc(1));
     GK_TRY(wgmeta.alloc((size_t)grid * 2));
-    GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
+    GK_TRY(part.alloc((size_t)grid * (size_t)(priv_cap_words > 0 ? priv_cap_words : 1)));
+    gm_prep_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q > 0 ? Q : 1, 1024), 1024)), 256, 0, ctx->stream>>>(
+        Tv, stream ? b->sr_ctl : nullptr, f->level0, priv_ok ? 1 : 0, (u32)priv_budget, table.p, A.df, A.cmax, A.cursor, (u32*)A.side);
     gm_pairs_kernel<<<dim3((unsigned)grid), 64 * waves, pairs_lds, ctx->stream>>>(
-        P, A, R, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, f->selfk, f->meta, n_levels, kind, f->n_fit, rectangular,
+        P, A, table.p, priv_cap_words, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, f->selfk, f->meta, n_levels, kind, f->n_fit, rectangular,
         (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p, wgmeta.p);
-    if (R.bins > 0)
-        gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(P, A, R, part.p, (int)grid, prim_max, wide_above, rectangular);
-    return gm_finish(ctx, f, P, A, Q, qa, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
+    if (priv_cap_words > 0)
+        gm_reduce_kernel<<<grid_for(priv_cap_words, 64), 1024, 0, ctx->stream>>>(A, table.p, part.p, (int)grid, prim_max, wide_above, rectangular);
+    return gm_finish(ctx, f, P, A, table.p, Q, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -887,23 +964,13 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     const i64 N = pb->n_graphs, V = pb->n_nodes;              // V = pairs = entry slots
     const i64 Q = pb->label_counts.empty() ? 0 : pb->label_counts[0];
     if (V <= 0 || Q <= 0) return GK_ERR_UNSUPPORTED;
-    void* q = nullptr;
+
     GmLevels P = {};
     P.L = 1, P.off[0] = 0, P.off[1] = Q, P.lab[0] = nullptr, P.flag[0] = nullptr, P.id_base[0] = 0, P.level[0] = 0;
     const size_t qa = (size_t)round_up(Q, 64);
-    Tmp<u32> zeroed(ctx);                     // [df | cmax | cursor | side (bytes)]
-    const size_t zero_words = 3 * qa + qa / 4;
-    GK_TRY(zeroed.alloc(zero_words));
-    GK_TRY(gk_zero_async(ctx, zeroed.p, zero_words * 4));
     GmLabelArrays A;
-    A.df = zeroed.p, A.cmax = zeroed.p + qa, A.cursor = zeroed.p + 2 * qa;
-    A.side = (unsigned char*)(zeroed.p + 3 * qa);
-    i32** keep[] = {&A.colid, (i32**)&A.roff, &A.low_q};
-    for (i32** a : keep) {
-        GK_TRY(gk_dev_alloc(ctx, &q, qa * 4));
-        *a = (i32*)q;
-        f->arena.push_back(q);
-    }
+    Tmp<u32> scratch(ctx);
+    GK_TRY(gm_label_arrays(ctx, f, qa, A, scratch));
     Tmp<u32> cnt(ctx), ent_n(ctx);
     Tmp<i32> ent(ctx);
     GK_TRY(cnt.alloc((size_t)V)); GK_TRY(ent.alloc((size_t)V)); GK_TRY(ent_n.alloc((size_t)N));
@@ -921,13 +988,20 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     Tmp<u32> part(ctx), wgmeta(ctx);
     GK_TRY(wgmeta.alloc((size_t)grid * 2));
     GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
+    GmTable Tv = {};
+    Tv.L = 1, Tv.Q = (u32)Q, Tv.lo[0] = 0, Tv.S[0] = (u32)Q, Tv.ncc[0] = 0, Tv.off[0] = 0, Tv.off[1] = (u32)Q, Tv.bins = (u32)R.bins;
+    for (int j = 0; j < FEAT_MAX_LEVELS; ++j) Tv.poff[j] = R.off[j];
+    Tmp<GmTable> table(ctx);
+    GK_TRY(table.alloc(1));
+    gm_prep_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q, 1024), 1024)), 256, 0, ctx->stream>>>(Tv, nullptr, 0, 0, 0u, table.p, A.df, A.cmax, A.cursor,
+                                                                                          (u32*)A.side);
     SpSource S{pb->sp_node_ptr, pb->sp_node_label, pb->sp_dist_ptr, pb->sp_dist, pb->sp_idtab, pb->graph_ptr,
                (u64)pb->sp_L, (u64)pb->sp_dcap, pb->sp_with_labels};
     sp_hist_kernel<<<dim3((unsigned)grid), SPH_THREADS, lds, ctx->stream>>>(
         S, P, A, R, N, ent.p, cnt.p, ent_n.p, f->selfk, f->n_fit, rectangular, (u32)(f->low_df > 2 ? f->low_df : 2), prim_max,
         wide_above, part.p, wgmeta.p, f->meta + GM_META_OVF);
     if (R.bins > 0)
-        gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(P, A, R, part.p, (int)grid, prim_max, wide_above, rectangular);
+        gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(A, table.p, part.p, (int)grid, prim_max, wide_above, rectangular);
     // the overflow word travels with the operand sizes: meta[] is read back once, in gm_finish
-    return gm_finish(ctx, f, P, A, Q, qa, pb->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
+    return gm_finish(ctx, f, P, A, table.p, Q, pb->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
 }

@@ -40,76 +40,7 @@
 #include <string.h>
 #include <memory>
 
-#define WL_DEG_SMALL 32       // nodes up to this degree: one thread sorts its list in LDS
-#define SIG_THREADS 256
-#define SIG_LDS_CAP 6144      // ints staged per 256-node chunk (24 KiB)
-#define BIG_THREADS 256
-#define BIG_LDS_CAP 16384     // ints: one workgroup bitonic-sorts a big node's list in LDS
-
-__device__ __forceinline__ u64 mix64(u64 z) {
-    z ^= z >> 30;
-    z *= 0xbf58476d1ce4e5b9ULL;
-    z ^= z >> 27;
-    z *= 0x94d049bb133111ebULL;
-    z ^= z >> 31;
-    return z;
-}
-__device__ __forceinline__ u64 sig_elem(u32 lab, u64 seed) {
-    return mix64(((u64)lab + 1ull) * 0x9E3779B97F4A7C15ULL + seed);
-}
-__device__ __forceinline__ u64 sig_head(u32 own, u32 deg, u64 seed) {
-    return mix64(mix64((u64)own + 0x632BE59BD9B4E019ULL * (seed | 1ull)) ^
-                 ((u64)deg * 0xD6E8FEB86659FD93ULL));
-}
-
-template <typename P>
-__device__ __forceinline__ void insertion_sort(P x, int d) {
-    for (int i = 1; i < d; ++i) {
-        i32 key = x[i];
-        int j = i - 1;
-        while (j >= 0 && x[j] > key) {
-            x[j + 1] = x[j];
-            --j;
-        }
-        x[j + 1] = key;
-    }
-}
-
-// bitonic compare-exchange network on the first N (power of two) registers of x: every index is a compile-time
-// constant after unrolling, so the elements stay in VGPRs (80 comparators for N = 16, 24 for N = 8)
-template <int N>
-__device__ __forceinline__ void sort_regs(i32 (&x)[16]) {
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const i32 a = x[i], b = x[l];
-                    const i32 lo = a < b ? a : b, hi = a < b ? b : a;
-                    if ((i & k) == 0) x[i] = lo, x[l] = hi;
-                    else x[i] = hi, x[l] = lo;
-                }
-            }
-}
-
-// One node's signature key with its neighbour labels gathered straight into registers (degree <= 16): the 16
-// gathers are independent loads, the sort is the fixed network, the sorted list goes to nbr_sorted for the verifier.
-// (An insertion sort in global memory pays two memory latencies per step.)
-__device__ __forceinline__ u64 node_key_regs(const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
-                                             i32* __restrict__ x, i32 s, int d, u32 own, u64 seed) {
-    i32 r[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) r[k] = k < d ? lab_prev[col_idx[s + k]] : 0x7fffffff;
-    sort_regs<16>(r);
-    u64 acc = sig_head(own, (u32)d, seed);
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-        if (k < d) { x[k] = r[k]; acc += sig_elem((u32)r[k], seed); }
-    return acc;
-}
+#include "wl_sig.h"
 
 __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
@@ -858,8 +789,8 @@ __global__ void iso_slots_kernel(const i32* __restrict__ order, const i32* __res
 }
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
-static int bits_for(u64 max_value);
 int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32* lab, i32* perm, u32* count_dev);
+int gk_sr_rebuild_order(gk_ctx* ctx, gk_batch* b, int level);      // wl_stream.hip
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -902,6 +833,7 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
     b->max_graph_nodes = (i32)h[0], b->max_degree = (i32)h[1], b->n_big = h[2];
     b->n_labels0_present = few_labels ? (i32)h[4] : 0;
     b->n_iso = 0;
+    b->n_isolated = h[3];
     if (h[3] > 0 && !ctx->opt.wl_no_iso) {
         // the carried list of the isolated vertices (see gk_batch::iso_info)
         const i64 n_iso = h[3];
@@ -1171,7 +1103,7 @@ extern "C" int gk_batch_destroy(gk_batch* b) {
     gk_ctx* ctx = b->ctx;
     void* ptrs[] = {b->graph_ptr, b->row_ptr, b->col_idx, b->node_graph, b->big_nodes,
                     b->labels, b->perm, b->nbr_sorted, b->iso_info, b->car_class, b->car_nodes, b->shared_flag,
-                    b->sp_node_ptr, b->sp_node_label, b->sp_dist_ptr, b->sp_dist, b->sp_idtab};
+                    b->sp_node_ptr, b->sp_node_label, b->sp_dist_ptr, b->sp_dist, b->sp_idtab, b->sr_ctl};
     for (void* p : ptrs)
         if (p) gk_dev_free(ctx, p);
     delete b;
@@ -1207,17 +1139,6 @@ int gk_batch_ensure_levels(gk_batch* b, int n_levels) {
     return GK_OK;
 }
 
-static int bits_for(u64 max_value) {
-    int b = 0;
-    while (b < 64 && (max_value >> b)) ++b;
-    return b;
-}
-
-static u64 level_seed(int level, int round) {
-    u64 z = 0x243F6A8885A308D3ULL + (u64)level * 0x9E3779B97F4A7C15ULL + (u64)round * 0xC2B2AE3D27D4EB4FULL;
-    z ^= z >> 31; z *= 0xff51afd7ed558ccdULL; z ^= z >> 29;
-    return z;
-}
 
 static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash, u64 seed, u64 mask) {
     i64 V = b->n_nodes;
@@ -1626,6 +1547,24 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
     Tmp<u32> meta(ctx);   // [n_levels] counts, [n_levels] unresolved, [n_levels] nodes of shared classes (full levels)
     GK_TRY(meta.alloc(4 * (size_t)n_levels));     // ... and [n_levels] active nodes of the levels run by the tiny kernel
     if (out_rounds) *out_rounds = 0;
+    // ---- the route without host round trips (wl_stream.hip); it declines jobs it is not built for and hands hash
+    // collisions / table overflows back
+    b->stream_layout = false;
+    {
+        std::vector<u32> counts;
+        const int r = gk_wl_relabel_stream(ctx, b, n_levels, hash_bits, default_bits, counts);
+        if (r == GK_OK) {
+            b->n_levels = n_levels;
+            b->label_counts.resize(n_levels);
+            for (int lvl = 0; lvl < n_levels; ++lvl) {
+                b->label_counts[lvl] = counts[lvl];
+                if (out_label_counts) out_label_counts[lvl] = counts[lvl];
+            }
+            return GK_OK;
+        }
+        if (r != GK_ERR_UNSUPPORTED) return r;
+        b->stream_layout = false;
+    }
     std::vector<u32> h(4 * (size_t)n_levels);
     int first_bad = -1;
     std::unique_ptr<RelabelState> stp;
@@ -1675,6 +1614,10 @@ __global__ void order_keys_kernel(const i32* __restrict__ lab, const unsigned ch
 int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level) {
     const i64 V = b->n_nodes;
     if (V == 0 || (size_t)level >= b->perm_valid.size() || b->perm_valid[level]) return GK_OK;
+    if (b->stream_layout) {
+        GK_ARG(level >= 1 && level < b->n_levels && (size_t)level < b->sr_F.size(), "gk_batch_rebuild_order: level not computed");
+        return gk_sr_rebuild_order(ctx, b, level);
+    }
     GK_ARG(level >= 0 && level < b->n_levels && b->shared_flag, "gk_batch_rebuild_order: level without class flags");
     const i64 count = level < (int)b->label_counts.size() ? b->label_counts[level] : V;
     const int bits = bits_for((u64)(count > 0 ? count : 1));          // the singleton key `count` sorts behind every label

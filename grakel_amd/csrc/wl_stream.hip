@@ -1,0 +1,622 @@
+// Weisfeiler-Lehman relabelling WITHOUT host round trips (the default route for graph batches; wl.hip keeps the
+// host-driven route for everything this one declines, and as the redo path).
+//
+// Reference: grakel/kernels/weisfeiler_lehman.py:223-258 (fit) -- one level = signature of every node, a dictionary
+// that numbers the distinct signatures, the new labels.
+//
+// wl.hip decides per level on the HOST which route a level takes (full / active set / single workgroup), which costs a
+// device -> host -> device round trip per level (mailbox waits: profiles/r03_step_timeline.txt, 160 us of idle device per
+// profiled step).  Here every level is the SAME six launches with static grids; everything data dependent is read from
+// device memory (gk_batch::sr_ctl, SR_CTL words per level), so a whole job -- relabel, and the feature builder behind it
+// (features_gm.hip reads the same words) -- is queued without the host knowing a single count:
+//   sr_sig      signature key of every ACTIVE node (class of two or more members at the level before, not isolated);
+//               everybody else gets the sentinel key and costs one label read.  A 256-node chunk with many active nodes
+//               stages its neighbour labels through LDS (coalesced col_idx stream), a sparse chunk gathers per thread.
+//   sr_hist / sr_rowscan / sr_scatter   stable partition of the active keys by their top digit (sentinels dropped);
+//               the scatter also leaves pos_of[node] = position of the node's key, so that the last pass runs in NODE order
+//   sr_dict     one workgroup per top-digit bucket: LDS table of the bucket's DISTINCT keys (as scan_sort.hip's
+//               bucket_dict_kernel), slots ranked separately for classes of two or more members and singletons;
+//               the claimer of a shared class records itself as its representative
+//   sr_finish   node order: new label, exact verification of the full signature against the class representative
+//               (counts mismatches = hash collisions), and for a node whose class just became a singleton its FINAL id
+//               at every later level.
+// Label ids of a level l >= 1 (dense):
+//   [carried classes 0 .. n_cc) [frozen nodes .. + F_l) [shared classes .. + S_l) [new singletons .. + T_l)
+// carried = isolated vertices grouped by input label (they never split and never merge: gk_batch::car_class), frozen =
+// nodes whose class was a singleton at an earlier level (classes only split, so they keep a class of their own for ever:
+// their id is final from the level after the one they froze at: id - S), F_{l+1} = F_l + T_l.  A label can be shared iff
+// id < n_cc or n_cc + F_l <= id < n_cc + F_l + S_l -- the only labels the feature builder looks at.
+// The host reads the control words back ONCE at the end; a hash collision (SR_UNRES) or a table overflow (SR_OVF) sends
+// the whole job to wl.hip's route (which re-seeds / sorts as before).
+#include "common.h"
+#include "features.h"
+#include "wl_sig.h"
+#include <vector>
+
+#define SR_SENT (~0ull)
+#define SR_TILE 2048            // keys per partition tile
+#define SR_DENSE_MIN 48         // active nodes of a 256-node chunk from which the chunk stages its neighbour lists through LDS
+
+static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
+
+template <typename T>
+__device__ __forceinline__ T sr_wave_incl_scan(T x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        T y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    return x;
+}
+
+// ---- prologue: control words, level 0's row, the carried classes' labels at every level ------------------------------------------
+__global__ __launch_bounds__(256) void sr_init_kernel(u32* __restrict__ ctl, int n_levels, u32 n_labels0, u32 n_present0,
+                                                       const i32* __restrict__ car_nodes, const i32* __restrict__ car_class,
+                                                       u32 n_car, i32* __restrict__ labels, i64 V) {
+    const u32 ncc = n_car ? (u32)car_class[n_car] : 0u;
+    if (blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < n_levels * SR_CTL; t += 256) {
+            const int l = t / SR_CTL, w = t - l * SR_CTL;
+            u32 x = 0;
+            if (l == 0) x = w == SR_S ? n_labels0 : (w == SR_COUNT ? n_present0 : 0u);     // level 0: every input label can be shared
+            else if (w == SR_NCC) x = ncc;
+            ctl[t] = x;
+        }
+        return;
+    }
+    const u32 k = (blockIdx.x - 1u) * 256u + threadIdx.x;
+    if (k >= n_car) return;
+    const i32 v = car_nodes[k], id = car_class[k];
+    for (int l = 1; l < n_levels; ++l) labels[(size_t)l * V + v] = id;
+}
+
+// ---- signatures -------------------------------------------------------------------------------------------------------
+template <bool LEVEL1>
+__global__ __launch_bounds__(SIG_THREADS) void sr_sig_kernel(
+    const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+    i32* __restrict__ nbr_sorted, u64* __restrict__ key_out, i64 V, u64 seed, u64 mask, int sig_regs,
+    const u32* __restrict__ ctl_prev) {
+    __shared__ i32 buf[SIG_LDS_CAP];
+    __shared__ int wcnt[SIG_THREADS / 64];
+    const int tid = threadIdx.x;
+    const i64 v0 = (i64)blockIdx.x * SIG_THREADS;
+    const i64 v1 = (v0 + SIG_THREADS < V) ? v0 + SIG_THREADS : V;
+    const i64 v = v0 + tid;
+    bool act = false;
+    i32 s = 0, own = 0;
+    int d = 0;
+    if (v < v1) {
+        s = row_ptr[v];
+        d = row_ptr[v + 1] - s;
+        own = lab_prev[v];
+        if (LEVEL1) act = d > 0;
+        else {
+            const u32 lo = ctl_prev[SR_NCC] + ctl_prev[SR_F];
+            act = (u32)own - lo < ctl_prev[SR_S];
+        }
+    }
+    {
+        const u64 m = __ballot(act);
+        if ((tid & 63) == 0) wcnt[tid >> 6] = __builtin_popcountll(m);
+    }
+    __syncthreads();
+    const int n_act = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];        // block-uniform
+    if (n_act == 0) {
+        if (v < v1) key_out[v] = SR_SENT;
+        return;
+    }
+    u64 acc = 0;
+    if (n_act >= SR_DENSE_MIN) {
+        // dense chunk: coalesced stream over the chunk's col_idx, neighbour labels staged in LDS (wl.hip: wl_signature_small_kernel)
+        const i32 e0 = row_ptr[v0], e1 = row_ptr[v1];
+        const int cnt = e1 - e0;
+        const bool use_lds = cnt <= SIG_LDS_CAP;
+        for (int i = tid; i < cnt; i += SIG_THREADS) {
+            const i32 l = lab_prev[col_idx[e0 + i]];
+            if (use_lds) buf[i] = l;
+            else nbr_sorted[e0 + i] = l;
+        }
+        __syncthreads();
+        int dwave = act ? d : 0;
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(dwave, off, 64); dwave = o > dwave ? o : dwave; }
+        if (act) {
+            acc = sig_head((u32)own, (u32)d, seed);
+            if (use_lds && dwave <= 16 && sig_regs) {
+                i32* x = buf + (s - e0);
+                i32 r[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) r[k] = (k < d && (k < 8 || dwave > 8)) ? x[k] : 0x7fffffff;
+                if (dwave <= 8) sort_regs<8>(r);
+                else sort_regs<16>(r);
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < d) { x[k] = r[k]; acc += sig_elem((u32)r[k], seed); }
+            } else if (use_lds) {
+                i32* x = buf + (s - e0);
+                insertion_sort(x, d);
+                for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+            } else {
+                i32* x = nbr_sorted + s;
+                insertion_sort(x, d);
+                for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+            }
+        }
+        __syncthreads();
+        if (use_lds)
+            for (int i = tid; i < cnt; i += SIG_THREADS) nbr_sorted[e0 + i] = buf[i];
+    } else if (act) {
+        // sparse chunk: the few active nodes gather their own lists
+        i32* x = nbr_sorted + s;
+        if (d <= 16) acc = node_key_regs(col_idx, lab_prev, x, s, d, (u32)own, seed);
+        else {
+            for (int k = 0; k < d; ++k) x[k] = lab_prev[col_idx[s + k]];
+            insertion_sort(x, d);
+            acc = sig_head((u32)own, (u32)d, seed);
+            for (int k = 0; k < d; ++k) acc += sig_elem((u32)x[k], seed);
+        }
+    }
+    if (v < v1) key_out[v] = act ? (mix64(acc) & mask) : SR_SENT;
+}
+
+// level 1 with few input labels and small degrees: exact 32-bit codes (wl.hip: wl_signature_exact_kernel); isolated
+// vertices are carried, not coded
+__global__ __launch_bounds__(256) void sr_sig_exact_kernel(
+    const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+    u64* __restrict__ key_out, i64 n, int L, u64 R, u32* __restrict__ unresolved) {
+    __shared__ u64 pw[20];
+    if ((int)threadIdx.x <= L) {
+        u64 p = 1;
+        for (int i = 0; i < (int)threadIdx.x; ++i) p *= R;
+        pw[threadIdx.x] = p;
+    }
+    __syncthreads();
+    const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const i32 s = row_ptr[v], e = row_ptr[v + 1];
+    if (e == s) { key_out[v] = SR_SENT; return; }
+    const u32 own = (u32)lab_prev[v];
+    bool in_range = own < (u32)L;
+    u64 key = (u64)own * pw[L];
+    for (i32 k = s; k < e; ++k) {
+        const u32 l = (u32)lab_prev[col_idx[k]];
+        in_range = in_range && l < (u32)L;
+        key += pw[l < (u32)L ? l : 0];
+    }
+    if (!in_range) atomicAdd(unresolved, 1u);
+    u32 x = (u32)key;                    // bijective scramble: the partition's top digit stays balanced
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    key_out[v] = (u64)x;
+}
+
+// ---- partition by the top digit (sentinel keys take no part) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_hist_kernel(const u64* __restrict__ kin, i64 n, int shift, u32* __restrict__ hist, int nblk) {
+    __shared__ u32 h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const i64 tile0 = (i64)blockIdx.x * SR_TILE;
+#pragma unroll
+    for (int r = 0; r < SR_TILE / 256; ++r) {
+        const i64 idx = tile0 + r * 256 + tid;
+        if (idx < n) {
+            const u64 k = kin[idx];
+            if (k != SR_SENT) atomicAdd(&h[(u32)(k >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(i64)tid * nblk + blockIdx.x] = h[tid];
+}
+
+// block d: exclusive prefix of digit d's tile counts (in place) and the digit total
+__global__ __launch_bounds__(256) void sr_rowscan_kernel(u32* __restrict__ hist, int nblk, u32* __restrict__ totals) {
+    __shared__ u32 wsum[4];
+    const int tid = threadIdx.x;
+    u32* row = hist + (i64)blockIdx.x * nblk;
+    u32 carry = 0;
+    for (int c0 = 0; c0 < nblk; c0 += 256) {
+        const int i = c0 + tid;
+        const u32 v = i < nblk ? row[i] : 0u;
+        const u32 inc = sr_wave_incl_scan(v);
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < (tid >> 6); ++w) woff += wsum[w];
+        const u32 all = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (i < nblk) row[i] = carry + woff + inc - v;
+        carry += all;
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = carry;
+}
+
+// stable scatter of one 2048-key tile (scan_sort.hip: radix_scatter_kernel<1024, false>), values = item indices;
+// pos_of[item] = its position (0xffffffff for a sentinel)
+__global__ __launch_bounds__(1024) void sr_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout, u32* __restrict__ vout,
+                                                          u32* __restrict__ pos_of, i64 n, int shift, const u32* __restrict__ offs,
+                                                          const u32* __restrict__ totals, int nblk) {
+    constexpr int THREADS = 1024, NWAVE = THREADS / 64, ROUNDS = SR_TILE / THREADS, NQ = ROUNDS * NWAVE;   // NQ == 32
+    __shared__ u32 cnt[NQ * 256];     // 32 KiB
+    __shared__ u32 dsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const i64 tile0 = (i64)blockIdx.x * SR_TILE;
+    u64 key[ROUNDS];
+    u32 rank[ROUNDS];
+    bool act[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const i64 idx = tile0 + r * THREADS + tid;
+        key[r] = idx < n ? kin[idx] : SR_SENT;
+        act[r] = key[r] != SR_SENT;
+    }
+    u32 before = 0, total = 0;
+    if (tid < 256) {
+        before = offs[(i64)tid * nblk + blockIdx.x];
+        total = totals[tid];
+    }
+    const u32 dincl = sr_wave_incl_scan(total);
+    if (lane == 63 && w < 4) dsum[w] = dincl;
+#pragma unroll
+    for (int q = 0; q < NQ * 256 / THREADS; ++q) cnt[q * THREADS + tid] = 0;
+    __syncthreads();
+    const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const u32 d = (u32)(key[r] >> shift) & 255u;
+        u64 m = __ballot(act[r]);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bb = __ballot(act[r] && bit);
+            m &= bit ? bb : ~bb;
+        }
+        rank[r] = (u32)__popcll(m & lt);
+        if (act[r] && rank[r] == 0) cnt[(r * NWAVE + w) * 256 + d] = (u32)__popcll(m);
+    }
+    __syncthreads();
+    if (tid < 256) {
+        u32 run = dincl - total + before;    // keys with smaller digits + equal digits in earlier tiles
+        for (int q = 0; q < w; ++q) run += dsum[q];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const u32 c = cnt[q * 256 + tid];
+            cnt[q * 256 + tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const i64 idx = tile0 + r * THREADS + tid;
+        if (idx < n) {
+            u32 pos = 0xffffffffu;
+            if (act[r]) {
+                const u32 d = (u32)(key[r] >> shift) & 255u;
+                pos = cnt[(r * NWAVE + w) * 256 + d] + rank[r];
+                kout[pos] = key[r];
+                vout[pos] = (u32)idx;
+            }
+            pos_of[idx] = pos;
+        }
+    }
+}
+
+// ---- dictionary of one top-digit bucket (scan_sort.hip: bucket_dict_kernel, ranked for the stream layout) ------------
+#define SRD_SLOTS 12288          // 12 B per slot: 144 KiB of LDS
+#define SRD_MAX_DISTINCT 9216    // load factor 0.75
+#define SRD_MAX_CHUNKS 64        // claim flags of a thread: one bit per 1024-item chunk
+
+// item_out[pos] = rank of the item's class among the bucket's shared / singleton classes (bits 0-13) | singleton << 31;
+// nd_sh / nd_si / listed [bucket] = shared classes, singleton classes, items of shared classes; rep2[bucket start + rank] =
+// representative (the claiming item's node) of each shared class
+__global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ kx, const u32* __restrict__ vx, const u32* __restrict__ totals,
+                                                       int shift, u32* __restrict__ item_out, i32* __restrict__ rep2,
+                                                       u32* __restrict__ nd_sh, u32* __restrict__ nd_si, u32* __restrict__ listed,
+                                                       u32* __restrict__ overflow, u32 max_distinct) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char srd_lds[];
+    unsigned long long* key_s = (unsigned long long*)srd_lds;                  // [SRD_SLOTS] key + 1, 0 = empty
+    u32* word_s = (u32*)(srd_lds + (size_t)SRD_SLOTS * 8);                     // [SRD_SLOTS] 1 / 2 = one / several members, later rank | singleton << 31
+    __shared__ u32 dsum[4];
+    __shared__ u32 wsum[16];
+    __shared__ u32 bstart, n_claimed, ovf;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) n_claimed = 0, ovf = 0;
+    {   // bucket range: exclusive prefix of the digit totals
+        const u32 t = tid < 256 ? totals[tid] : 0u;
+        const u32 inc = sr_wave_incl_scan(t);
+        if (lane == 63 && w < 4) dsum[w] = inc;
+        __syncthreads();
+        if (tid == (int)blockIdx.x) {
+            u32 off = inc - t;
+            for (int q = 0; q < w; ++q) off += dsum[q];
+            bstart = off;
+        }
+        __syncthreads();
+    }
+    const u32 size = totals[blockIdx.x];
+    const i64 start = bstart;
+    if (size == 0) {
+        if (tid == 0) nd_sh[blockIdx.x] = 0, nd_si[blockIdx.x] = 0, listed[blockIdx.x] = 0;
+        return;
+    }
+    const u64 kmask = (1ull << shift) - 1ull;       // shift <= 48: key + 1 never wraps to 0
+    for (int t = tid; t < SRD_SLOTS; t += 1024) key_s[t] = 0ull, word_s[t] = 0u;
+    __syncthreads();
+    const bool too_long = size > (u32)SRD_MAX_CHUNKS * 1024u;
+    u64 claimed = 0;
+    if (!too_long) {
+        int c = 0;
+        u64 k_cur = (u32)tid < size ? kx[start + tid] : 0ull;
+        for (u32 i = tid; i < size; i += 1024, ++c) {
+            const u64 k_nxt = i + 1024 < size ? kx[start + i + 1024] : 0ull;
+            const u64 k1 = (k_cur & kmask) + 1ull;
+            k_cur = k_nxt;
+            u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)SRD_SLOTS) >> 32);
+            for (;;) {
+                unsigned long long v = key_s[h];
+                if (v == 0ull) {
+                    if (*(volatile u32*)&ovf) break;                                       // table declared full: stop claiming
+                    v = atomicCAS(&key_s[h], 0ull, (unsigned long long)k1);
+                    if (v == 0ull) {                                      // claimed: this item owns the class
+                        claimed |= 1ull << c;
+                        atomicMax(&word_s[h], 1u);
+                        if (atomicAdd(&n_claimed, 1u) + 1u > max_distinct) ovf = 1u;
+                        break;
+                    }
+                }
+                if (v == k1) { if (*(volatile u32*)&word_s[h] != 2u) atomicMax(&word_s[h], 2u); break; }
+                h = h + 1u == (u32)SRD_SLOTS ? 0u : h + 1u;
+            }
+        }
+    }
+    __syncthreads();
+    if (too_long || ovf) {              // not handled here: every item a "singleton" of rank 0 (memory-safe), the job is redone by wl.hip
+        for (u32 i = tid; i < size; i += 1024) item_out[start + i] = 0x80000000u;
+        if (tid == 0) {
+            nd_sh[blockIdx.x] = 0, nd_si[blockIdx.x] = 1, listed[blockIdx.x] = 0;
+            atomicOr(overflow, 1u);
+        }
+        return;
+    }
+    // ---- rank the slots in use, shared classes (low half) and singletons (high half) apart: thread t owns slots [12t, 12t + 12)
+    constexpr int PER = SRD_SLOTS / 1024;
+    u32 mine = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 m = word_s[PER * tid + q];
+        mine += m == 2u ? 1u : (m == 1u ? 0x10000u : 0u);
+    }
+    const u32 inc = sr_wave_incl_scan(mine);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 before = inc - mine, all = 0;
+    for (int q = 0; q < 16; ++q) {
+        if (q < w) before += wsum[q];
+        all += wsum[q];
+    }
+    u32 b_sh = before & 0xffffu, b_si = before >> 16;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 members = word_s[PER * tid + q];
+        if (members == 2u) word_s[PER * tid + q] = b_sh++;
+        else if (members == 1u) word_s[PER * tid + q] = (b_si++) | 0x80000000u;
+    }
+    if (tid == 0) nd_sh[blockIdx.x] = all & 0xffffu, nd_si[blockIdx.x] = all >> 16;
+    __syncthreads();
+    // ---- every item looks its class up again
+    u32 my_listed = 0;
+    int c = 0;
+    u64 k_cur = (u32)tid < size ? kx[start + tid] : 0ull;
+    for (u32 i = tid; i < size; i += 1024, ++c) {
+        const u64 k_nxt = i + 1024 < size ? kx[start + i + 1024] : 0ull;
+        const u64 k1 = (k_cur & kmask) + 1ull;
+        k_cur = k_nxt;
+        u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)SRD_SLOTS) >> 32);
+        while (key_s[h] != k1) h = h + 1u == (u32)SRD_SLOTS ? 0u : h + 1u;
+        const u32 v = word_s[h];
+        item_out[start + i] = v & 0x80003fffu;
+        if (!(v >> 31)) {
+            ++my_listed;
+            if ((claimed >> c) & 1ull) rep2[start + (v & 0x3fffu)] = (i32)vx[start + i];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) my_listed += __shfl_down(my_listed, off, 64);
+    __syncthreads();                    // wsum is read above by every thread
+    if (lane == 0) wsum[w] = my_listed;
+    __syncthreads();
+    if (tid == 0) {
+        u32 t = 0;
+        for (int q = 0; q < 16; ++q) t += wsum[q];
+        listed[blockIdx.x] = t;
+    }
+}
+
+// ---- node order: labels, verification, final ids of the nodes that just froze ------------------------------------------
+__global__ __launch_bounds__(1024) void sr_finish_kernel(const u32* __restrict__ pos_of, const u32* __restrict__ item,
+                                                         const i32* __restrict__ rep2, const u32* __restrict__ totals,
+                                                         const u32* __restrict__ nd_sh, const u32* __restrict__ nd_si,
+                                                         const u32* __restrict__ listed, u32* __restrict__ ctl_cur, u32* __restrict__ ctl_next,
+                                                         i32* __restrict__ labels, i64 V, int level, int n_levels, int verify,
+                                                         const i32* __restrict__ row_ptr, const i32* __restrict__ nbr_sorted) {
+    __shared__ u32 starts[257], bsh[257], bsi[257];
+    __shared__ u32 d0[4], d1[4], d2[4], d3[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    {
+        const u32 t = tid < 256 ? totals[tid] : 0u, a = tid < 256 ? nd_sh[tid] : 0u, b = tid < 256 ? nd_si[tid] : 0u;
+        const u32 li = (tid < 256 && blockIdx.x == 0) ? listed[tid] : 0u;
+        const u32 it = sr_wave_incl_scan(t), ia = sr_wave_incl_scan(a), ib = sr_wave_incl_scan(b), il = sr_wave_incl_scan(li);
+        if (lane == 63 && w < 4) d0[w] = it, d1[w] = ia, d2[w] = ib, d3[w] = il;
+        __syncthreads();
+        if (tid < 256) {
+            u32 x = it, y = ia, z = ib;
+            for (int q = 0; q < w; ++q) x += d0[q], y += d1[q], z += d2[q];
+            starts[tid + 1] = x, bsh[tid + 1] = y, bsi[tid + 1] = z;            // inclusive -> entry tid + 1
+        }
+        if (tid == 0) starts[0] = 0, bsh[0] = 0, bsi[0] = 0;
+        __syncthreads();
+    }
+    const u32 S = bsh[256], T = bsi[256];
+    const u32 F = ctl_cur[SR_F], ncc = ctl_cur[SR_NCC];
+    if (blockIdx.x == 0 && tid == 0) {
+        ctl_cur[SR_S] = S, ctl_cur[SR_T] = T, ctl_cur[SR_COUNT] = ncc + F + S + T;
+        ctl_cur[SR_LISTED] = d3[0] + d3[1] + d3[2] + d3[3];
+        if (ctl_next) ctl_next[SR_F] = F + T;
+    }
+    const i64 v = (i64)blockIdx.x * 1024 + tid;
+    if (v >= V) return;
+    const u32 pos = pos_of[v];
+    if (pos == 0xffffffffu) return;               // not active: the label of this level was written when the node froze (or is carried)
+    const u32 t = item[pos];
+    int lo = 0, hi = 256;                         // largest b with starts[b] <= pos
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (starts[mid] <= pos) lo = mid; else hi = mid;
+    }
+    const u32 rank = t & 0x3fffu;
+    i32* lab = labels + (size_t)level * V;
+    if (t >> 31) {
+        const u32 id = ncc + F + S + bsi[lo] + rank;
+        lab[v] = (i32)id;
+        const i32 fin = (i32)(id - S);            // = n_cc + F_{l+1} slot: the node's id at every later level
+        for (int l2 = level + 1; l2 < n_levels; ++l2) labels[(size_t)l2 * V + v] = fin;
+        return;
+    }
+    lab[v] = (i32)(ncc + F + bsh[lo] + rank);
+    if (!verify) return;
+    const i32 r = rep2[starts[lo] + rank];
+    if (r == (i32)v) return;
+    const i32* lab_prev = labels + (size_t)(level - 1) * V;
+    bool ok = lab_prev[v] == lab_prev[r];
+    const i32 s = row_ptr[v], sr = row_ptr[r];
+    const int d = row_ptr[v + 1] - s;
+    ok = ok && (d == row_ptr[r + 1] - sr);
+    if (ok)
+        for (int k = 0; k < d; ++k)
+            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+    if (!ok) atomicAdd(&ctl_cur[SR_UNRES], 1u);
+}
+
+// label-grouped node order of a stream-layout level, on demand (the label-major feature builder, features.hip): key =
+// compact shareable label, everything else behind
+__global__ void sr_order_keys_kernel(const i32* __restrict__ lab, u64* __restrict__ keys, i64 n, u32 ncc, u32 lo, u32 S) {
+    const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const u32 x = (u32)lab[v];
+    keys[v] = x < ncc ? (u64)x : (x - lo < S ? (u64)(ncc + (x - lo)) : (u64)ncc + (u64)S);
+}
+
+int gk_sr_rebuild_order(gk_ctx* ctx, gk_batch* b, int level) {
+    const i64 V = b->n_nodes;
+    const u32 ncc = b->sr_ncc, F = b->sr_F[level], S = b->sr_S[level];
+    Tmp<u64> keys(ctx), ks(ctx);
+    GK_TRY(keys.alloc(V)); GK_TRY(ks.alloc(V));
+    sr_order_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->labels + (size_t)level * V, keys.p, V, ncc, ncc + F, S);
+    GK_TRY(gk_radix_sort_pairs(ctx, keys.p, nullptr, ks.p, (u32*)(b->perm + (size_t)level * V), V, bits_for((u64)ncc + (u64)S)));
+    GK_HIP_CHECK(hipGetLastError());
+    b->perm_valid[level] = 1;
+    return GK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits, std::vector<u32>& counts) {
+    const i64 V = b->n_nodes;
+    const i64 n_car = b->n_iso;
+    // ---- is this the job this route is built for?  (graph batches of small graphs whose features the graph-major builder
+    // takes, a handful of input labels; everything else keeps wl.hip's route)
+    if (ctx->opt.wl_no_stream || b->is_pair_batch || V <= 0 || n_levels < 2 || b->n_big > 0) return GK_ERR_UNSUPPORTED;
+    if (b->max_graph_nodes > GM_MAX_NODES || ctx->opt.feat_no_gm || ctx->opt.wl_no_bucket_dict || ctx->opt.wl_no_hist0) return GK_ERR_UNSUPPORTED;
+    if (!(b->n_labels0 >= 1 && b->n_labels0 <= GK_HIST0_MAX_LABELS)) return GK_ERR_UNSUPPORTED;
+    if (hash_bits < 32 || hash_bits > 56 || !gk_bucket_dictionary_fits(ctx, V)) return GK_ERR_UNSUPPORTED;
+    if (b->n_isolated != n_car || (n_car > 0 && !(b->car_class && b->car_nodes))) return GK_ERR_UNSUPPORTED;    // option wl.no_iso: nothing carried
+    if (ctx->opt.wl_no_active_set || ctx->opt.wl_no_split) return GK_ERR_UNSUPPORTED;                 // route options of wl.hip: run that route
+    if (b->sr_ctl_levels < n_levels) {
+        if (b->sr_ctl) gk_dev_free(ctx, b->sr_ctl);
+        b->sr_ctl = nullptr, b->sr_ctl_levels = 0;
+        void* q = nullptr;
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)n_levels * SR_CTL * 4));
+        b->sr_ctl = (u32*)q, b->sr_ctl_levels = n_levels;
+    }
+    u32* ctl = b->sr_ctl;
+    const int nblk = (int)cdiv(V, SR_TILE);
+    Tmp<u64> key(ctx), kx(ctx);
+    Tmp<u32> vx(ctx), pos_of(ctx), item(ctx), hist(ctx), small(ctx);
+    Tmp<i32> rep2(ctx);
+    GK_TRY(key.alloc(V)); GK_TRY(kx.alloc(V)); GK_TRY(vx.alloc(V)); GK_TRY(pos_of.alloc(V)); GK_TRY(item.alloc(V));
+    GK_TRY(rep2.alloc(V)); GK_TRY(hist.alloc((size_t)256 * nblk)); GK_TRY(small.alloc(5 * 256));
+    u32* totals = small.p;
+    u32* nd_sh = small.p + 256;
+    u32* nd_si = small.p + 512;
+    u32* listed = small.p + 768;
+    sr_init_kernel<<<dim3(1u + (unsigned)cdiv(n_car, 256)), 256, 0, ctx->stream>>>(
+        ctl, n_levels, (u32)b->n_labels0, (u32)b->n_labels0_present, b->car_nodes, b->car_class, (u32)n_car, b->labels, V);
+    const u64 full_mask = (1ull << hash_bits) - 1ull;
+    const int sig_regs = ctx->opt.wl_sig_no_regs ? 0 : 1;
+    const int lds = SRD_SLOTS * 12;
+    GK_TRY(gk_func_lds(ctx, (const void*)sr_dict_kernel, lds));
+    u32 max_distinct = SRD_MAX_DISTINCT;
+    if (ctx->opt.bd_slots > 0 && (u32)ctx->opt.bd_slots < max_distinct) max_distinct = (u32)ctx->opt.bd_slots;     // test hook
+    for (int lvl = 1; lvl < n_levels; ++lvl) {
+        const i32* prev = b->labels + (size_t)(lvl - 1) * V;
+        u32* cc = ctl + (size_t)lvl * SR_CTL;
+        u32* cn = lvl + 1 < n_levels ? cc + SR_CTL : nullptr;
+        int bits = hash_bits, verify = 1;
+        // level 1 of a job with few input labels: exact 32-bit signature codes (wl.hip: relabel_level)
+        bool exact_code = false;
+        const u64 code_R = (u64)b->max_degree + 1;
+        if (lvl == 1 && default_bits && b->n_labels0 <= 16 && !ctx->opt.wl_no_exact1) {
+            double span = (double)b->n_labels0;
+            for (int i = 0; i < b->n_labels0; ++i) span *= (double)code_R;
+            exact_code = span < 4294967296.0;
+        }
+        if (exact_code) {
+            bits = 32, verify = 0;
+            sr_sig_exact_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, b->col_idx, prev, key.p, V, (int)b->n_labels0,
+                                                                           code_R, cc + SR_UNRES);
+        } else if (lvl == 1) {
+            sr_sig_kernel<true><<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
+                b->row_ptr, b->col_idx, prev, b->nbr_sorted, key.p, V, level_seed(lvl, 0), full_mask, sig_regs, nullptr);
+        } else {
+            sr_sig_kernel<false><<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
+                b->row_ptr, b->col_idx, prev, b->nbr_sorted, key.p, V, level_seed(lvl, 0), full_mask, sig_regs, cc - SR_CTL);
+        }
+        const int shift = 8 * ((bits + 7) / 8 - 1);
+        sr_hist_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(key.p, V, shift, hist.p, nblk);
+        sr_rowscan_kernel<<<dim3(256), 256, 0, ctx->stream>>>(hist.p, nblk, totals);
+        sr_scatter_kernel<<<dim3(nblk), 1024, 0, ctx->stream>>>(key.p, kx.p, vx.p, pos_of.p, V, shift, hist.p, totals, nblk);
+        sr_dict_kernel<<<dim3(256), 1024, lds, ctx->stream>>>(kx.p, vx.p, totals, shift, item.p, rep2.p, nd_sh, nd_si, listed,
+                                                              cc + SR_OVF, max_distinct);
+        sr_finish_kernel<<<grid_for(V, 1024), 1024, 0, ctx->stream>>>(pos_of.p, item.p, rep2.p, totals, nd_sh, nd_si, listed, cc, cn,
+                                                                      b->labels, V, lvl, n_levels, verify, b->row_ptr, b->nbr_sorted);
+    }
+    GK_HIP_CHECK(hipGetLastError());
+    std::vector<u32> h((size_t)n_levels * SR_CTL);
+    GK_TRY(gk_readback(ctx, ctl, h.data(), n_levels * SR_CTL));
+    for (int lvl = 1; lvl < n_levels; ++lvl)
+        if (h[(size_t)lvl * SR_CTL + SR_UNRES] || h[(size_t)lvl * SR_CTL + SR_OVF]) {
+            if (ctx->opt.wl_debug)
+                fprintf(stderr, "[gk] stream relabel: level %d unresolved %u overflow %u -> host-driven route\n", lvl,
+                        h[(size_t)lvl * SR_CTL + SR_UNRES], h[(size_t)lvl * SR_CTL + SR_OVF]);
+            return GK_ERR_UNSUPPORTED;
+        }
+    // ---- what the consumers on the host need
+    b->stream_layout = true;
+    b->level0_hist = true;
+    b->sr_ncc = n_levels > 1 ? h[SR_CTL + SR_NCC] : 0u;
+    b->sr_F.assign((size_t)n_levels, 0), b->sr_S.assign((size_t)n_levels, 0);
+    b->n_sorted.assign((size_t)n_levels, V);
+    b->active_layout.assign((size_t)n_levels, 0);
+    b->perm_valid.assign((size_t)n_levels, 0);
+    counts.assign((size_t)n_levels, 0);
+    for (int lvl = 0; lvl < n_levels; ++lvl) {
+        const u32* c = h.data() + (size_t)lvl * SR_CTL;
+        counts[lvl] = c[SR_COUNT];
+        b->sr_F[lvl] = c[SR_F], b->sr_S[lvl] = c[SR_S];
+        if (lvl > 0) b->n_sorted[lvl] = (i64)c[SR_LISTED] + n_car;       // nodes that can share their label
+        if (ctx->opt.wl_debug)
+            fprintf(stderr, "[gk] stream level %d: frozen %u shared classes %u new singletons %u labels %u listed %u\n", lvl, c[SR_F],
+                    c[SR_S], c[SR_T], c[SR_COUNT], c[SR_LISTED]);
+    }
+    return GK_OK;
+}

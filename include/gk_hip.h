@@ -70,6 +70,8 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  * equivalent routes, or shrinks a capacity so that a fallback is taken.  value 0 restores the default.  Names:
  *   relabel:  "wl.no_tiny" "wl.no_listscan" "wl.no_iso" "wl.no_split" "wl.no_exact1" "wl.no_active_set"
  *             "wl.no_bucket_dict" "wl.no_hist0" "wl.frozen_words" "wl.flag_bytes" "wl.sig_no_regs" "wl.debug"
+ *             "wl.no_stream" (never the relabel route without host round trips, wl_stream.hip: the host-driven
+ *             route of wl.hip, which all the other "wl.*" switches select within)
  *             "sort.buckets" (1 never / 2 always the per-bucket finish of the sort)
  *             "wl.bd_slots" (distinct keys a bucket of the sort-free dictionary accepts: small values force its
  *             overflow and with it the second, sorting attempt)

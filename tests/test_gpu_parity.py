@@ -213,7 +213,8 @@ def test_level1_exact_signature_codes_and_their_limits(gk, n_labels, with_isolat
                           O.WLOracle(n_iter=3).fit_transform(only_isolated))
 
 
-ROUTE_OPTIONS = [
+# the host-driven relabel route (wl.hip) and its per-level choices: every entry also switches the stream route off
+_HOST_ROUTES = [
     (), ("wl.no_tiny",), ("wl.no_listscan",), ("wl.no_iso",), ("wl.no_split",), ("wl.no_exact1",), ("wl.no_active_set",),
     # round 2: sort-free dictionary, graph-major features, level-0 histogram, where the singleton flags travel,
     # register sort of the neighbour lists, workgroup-private df histograms
@@ -223,6 +224,9 @@ ROUTE_OPTIONS = [
     # construction (feat.no_gm turns both off), the words + no list scan pair is the round-1 data flow
     ("wl.frozen_words", "wl.no_listscan"), ("wl.no_hist0", "wl.no_exact1", "wl.no_bucket_dict"),
 ]
+# round 4: the relabel route without host round trips (wl_stream.hip) is the default; its own switches
+ROUTE_OPTIONS = [(), ("wl.no_exact1",), ("wl.sig_no_regs",), ("feat.gm_no_priv",), ("feat.gm_rows_wg",), ("no_mailbox",)] + \
+    [r + ("wl.no_stream",) for r in _HOST_ROUTES]
 
 
 def _apply_route(gkopt, route):
