@@ -86,29 +86,32 @@ struct GmTable {
     u32 L;
 };
 
-// First launch of a graph-major feature job: the level table (copied from the host's, or computed from the stream
-// layout's control words) and the zero fill of the per-label counters -- only the Q labels there are, not the bound the
-// arrays were allocated for.
-__global__ __launch_bounds__(256) void gm_prep_kernel(const GmTable Tv, const u32* __restrict__ ctl, int level0, int priv_ok,
+// First launch of a graph-major feature job: the zero fill of the per-label counters -- only the Q labels there are, not
+// the bound the arrays were allocated for -- and, for the stream layout, the level table computed from the control words
+// (ctl != null; host-known layouts upload their table before the launch and pass Q).
+__global__ __launch_bounds__(256) void gm_prep_kernel(const u32* __restrict__ ctl, int level0, int L, u32 Q_host, int priv_ok,
                                                        u32 priv_budget, GmTable* __restrict__ Td, u32* __restrict__ df,
                                                        u32* __restrict__ cmax, u32* __restrict__ cursor, u32* __restrict__ side_words) {
     __shared__ u32 Qs;
+    __shared__ u32 cw[FEAT_MAX_LEVELS][3];
+    if (ctl && (int)threadIdx.x < L) {            // one round trip for all levels' words, not one per level
+        const u32* c = ctl + (size_t)(level0 + (int)threadIdx.x) * SR_CTL;
+        cw[threadIdx.x][0] = c[SR_NCC], cw[threadIdx.x][1] = c[SR_F], cw[threadIdx.x][2] = c[SR_S];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        if (!ctl) {
-            if (blockIdx.x == 0) *Td = Tv;
-            Qs = Tv.Q;
-        } else {
+        if (!ctl) Qs = Q_host;
+        else {
             const bool w = blockIdx.x == 0;
             u32 off = 0, bins = 0;
-            for (u32 j = 0; j < Tv.L; ++j) {
-                const u32* c = ctl + (size_t)(level0 + (int)j) * SR_CTL;
-                const u32 ncc = c[SR_NCC], lo = ncc + c[SR_F], S = c[SR_S], space = ncc + S;
+            for (int j = 0; j < L; ++j) {
+                const u32 ncc = cw[j][0], lo = ncc + cw[j][1], S = cw[j][2], space = ncc + S;
                 i32 po = -1;
                 if (priv_ok && space > 0 && bins + space <= priv_budget) po = (i32)bins, bins += space;
                 if (w) Td->lo[j] = lo, Td->S[j] = S, Td->ncc[j] = ncc, Td->off[j] = off, Td->poff[j] = po;
                 off += space;
             }
-            if (w) Td->off[Tv.L] = off, Td->bins = (bins + 1u) & ~1u, Td->Q = off, Td->L = Tv.L;
+            if (w) Td->off[L] = off, Td->bins = (bins + 1u) & ~1u, Td->Q = off, Td->L = (u32)L;
             Qs = off;
         }
     }
@@ -782,8 +785,10 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     GK_TRY(table.alloc(1));
     GK_TRY(wgmeta.alloc((size_t)grid * 2));
     GK_TRY(part.alloc((size_t)grid * (size_t)(priv_cap_words > 0 ? priv_cap_words : 1)));
-    gm_prep_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q > 0 ? Q : 1, 1024), 1024)), 256, 0, ctx->stream>>>(
-        Tv, stream ? b->sr_ctl : nullptr, f->level0, priv_ok ? 1 : 0, (u32)priv_budget, table.p, A.df, A.cmax, A.cursor, (u32*)A.side);
+    // host-known layout: the table travels as it is (a by-value kernel argument of this size ends up in per-thread scratch)
+    if (!stream) GK_HIP_CHECK(hipMemcpyAsync(table.p, &Tv, sizeof(GmTable), hipMemcpyHostToDevice, ctx->stream));
+    gm_prep_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q > 0 ? Q : 1, 1024), stream ? 64 : 1024)), 256, 0, ctx->stream>>>(
+        stream ? b->sr_ctl : nullptr, f->level0, P.L, (u32)Q, priv_ok ? 1 : 0, (u32)priv_budget, table.p, A.df, A.cmax, A.cursor, (u32*)A.side);
     gm_pairs_kernel<<<dim3((unsigned)grid), 64 * waves, pairs_lds, ctx->stream>>>(
         P, A, table.p, priv_cap_words, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, f->selfk, f->meta, n_levels, kind, f->n_fit, rectangular,
         (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p, wgmeta.p);
@@ -993,7 +998,8 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     for (int j = 0; j < FEAT_MAX_LEVELS; ++j) Tv.poff[j] = R.off[j];
     Tmp<GmTable> table(ctx);
     GK_TRY(table.alloc(1));
-    gm_prep_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q, 1024), 1024)), 256, 0, ctx->stream>>>(Tv, nullptr, 0, 0, 0u, table.p, A.df, A.cmax, A.cursor,
+    GK_HIP_CHECK(hipMemcpyAsync(table.p, &Tv, sizeof(GmTable), hipMemcpyHostToDevice, ctx->stream));
+    gm_prep_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q, 1024), 1024)), 256, 0, ctx->stream>>>(nullptr, 0, 1, (u32)Q, 0, 0u, table.p, A.df, A.cmax, A.cursor,
                                                                                           (u32*)A.side);
     SpSource S{pb->sp_node_ptr, pb->sp_node_label, pb->sp_dist_ptr, pb->sp_dist, pb->sp_idtab, pb->graph_ptr,
                (u64)pb->sp_L, (u64)pb->sp_dcap, pb->sp_with_labels};

@@ -26,6 +26,12 @@
 // nodes whose class was a singleton at an earlier level (classes only split, so they keep a class of their own for ever:
 // their id is final from the level after the one they froze at: id - S), F_{l+1} = F_l + T_l.  A label can be shared iff
 // id < n_cc or n_cc + F_l <= id < n_cc + F_l + S_l -- the only labels the feature builder looks at.
+// DENSE and LIST levels.  A level whose active nodes are more than a quarter of the batch walks the nodes (item j = node j,
+// inactive nodes carry the sentinel key); otherwise it walks the LIST of active nodes the level before left behind: every
+// workgroup of sr_finish compacts the members of shared classes among its 1024 items into its own segment (seg[1024 b ..],
+// wg_cnt[b]; no atomics), and the next level's sr_sig turns the segments into compact item arrays (key[j], node_of[j],
+// j < SR_LISTED of the level before).  Which of the two a level is, is decided ON THE DEVICE by every kernel from the same
+// control word; grids are static (sized for the dense case), workgroups beyond the item count leave at once.
 // The host reads the control words back ONCE at the end; a hash collision (SR_UNRES) or a table overflow (SR_OVF) sends
 // the whole job to wl.hip's route (which re-seeds / sorts as before).
 #include "common.h"
@@ -48,6 +54,15 @@ __device__ __forceinline__ T sr_wave_incl_scan(T x) {
         if (lane >= off) x += y;
     }
     return x;
+}
+
+// items of a level: all nodes (dense) or the previous level's listed nodes; ctl_prev == null: level 1, dense
+__device__ __forceinline__ bool sr_dense(const u32* __restrict__ ctl_prev, i64 V, i64& n_items) {
+    if (!ctl_prev) { n_items = V; return true; }
+    const u32 listed = ctl_prev[SR_LISTED];
+    const bool dense = (u64)listed * 4ull > (u64)V;
+    n_items = dense ? V : (i64)listed;
+    return dense;
 }
 
 // ---- prologue: control words, level 0's row, the carried classes' labels at every level ------------------------------------------
@@ -76,10 +91,43 @@ template <bool LEVEL1>
 __global__ __launch_bounds__(SIG_THREADS) void sr_sig_kernel(
     const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
     i32* __restrict__ nbr_sorted, u64* __restrict__ key_out, i64 V, u64 seed, u64 mask, int sig_regs,
-    const u32* __restrict__ ctl_prev) {
+    const u32* __restrict__ ctl_prev, const u32* __restrict__ seg, const u32* __restrict__ wg_cnt, u32* __restrict__ node_of) {
     __shared__ i32 buf[SIG_LDS_CAP];
     __shared__ int wcnt[SIG_THREADS / 64];
     const int tid = threadIdx.x;
+    if (!LEVEL1) {
+        i64 n_items;
+        if (!sr_dense(ctl_prev, V, n_items)) {
+            // ---- list level: this workgroup takes a quarter of one segment of the previous level's sr_finish
+            const u32 b = blockIdx.x >> 2, q0 = (blockIdx.x & 3u) * SIG_THREADS;
+            const u32 cnt = wg_cnt[b];
+            if (q0 >= cnt) return;
+            u32 before = 0;
+            for (u32 i = tid; i < b; i += SIG_THREADS) before += wg_cnt[i];
+            for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
+            if ((tid & 63) == 0) wcnt[tid >> 6] = (int)before;
+            __syncthreads();
+            const u32 base = (u32)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+            const u32 k = q0 + (u32)tid;
+            if (k >= cnt) return;
+            const i32 v = (i32)seg[(size_t)b * 1024u + k];
+            const i32 s = row_ptr[v];
+            const int d = row_ptr[v + 1] - s;
+            const i32 own = lab_prev[v];
+            i32* x = nbr_sorted + s;
+            u64 acc;
+            if (d <= 16) acc = node_key_regs(col_idx, lab_prev, x, s, d, (u32)own, seed);
+            else {
+                for (int kk = 0; kk < d; ++kk) x[kk] = lab_prev[col_idx[s + kk]];
+                insertion_sort(x, d);
+                acc = sig_head((u32)own, (u32)d, seed);
+                for (int kk = 0; kk < d; ++kk) acc += sig_elem((u32)x[kk], seed);
+            }
+            key_out[base + k] = mix64(acc) & mask;
+            node_of[base + k] = (u32)v;
+            return;
+        }
+    }
     const i64 v0 = (i64)blockIdx.x * SIG_THREADS;
     const i64 v1 = (v0 + SIG_THREADS < V) ? v0 + SIG_THREADS : V;
     const i64 v = v0 + tid;
@@ -192,12 +240,16 @@ __global__ __launch_bounds__(256) void sr_sig_exact_kernel(
 }
 
 // ---- partition by the top digit (sentinel keys take no part) ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void sr_hist_kernel(const u64* __restrict__ kin, i64 n, int shift, u32* __restrict__ hist, int nblk) {
+__global__ __launch_bounds__(256) void sr_hist_kernel(const u64* __restrict__ kin, i64 V, int shift, u32* __restrict__ hist, int nblk,
+                                                      const u32* __restrict__ ctl_prev) {
     __shared__ u32 h[256];
     const int tid = threadIdx.x;
+    i64 n;
+    sr_dense(ctl_prev, V, n);
+    const i64 tile0 = (i64)blockIdx.x * SR_TILE;
+    if (tile0 >= n) return;                       // the grid covers the dense case
     h[tid] = 0;
     __syncthreads();
-    const i64 tile0 = (i64)blockIdx.x * SR_TILE;
 #pragma unroll
     for (int r = 0; r < SR_TILE / 256; ++r) {
         const i64 idx = tile0 + r * 256 + tid;
@@ -211,10 +263,14 @@ __global__ __launch_bounds__(256) void sr_hist_kernel(const u64* __restrict__ ki
 }
 
 // block d: exclusive prefix of digit d's tile counts (in place) and the digit total
-__global__ __launch_bounds__(256) void sr_rowscan_kernel(u32* __restrict__ hist, int nblk, u32* __restrict__ totals) {
+__global__ __launch_bounds__(256) void sr_rowscan_kernel(u32* __restrict__ hist, int nblk_max, u32* __restrict__ totals, i64 V,
+                                                         const u32* __restrict__ ctl_prev) {
     __shared__ u32 wsum[4];
     const int tid = threadIdx.x;
-    u32* row = hist + (i64)blockIdx.x * nblk;
+    i64 n;
+    sr_dense(ctl_prev, V, n);
+    const int nblk = (int)((n + SR_TILE - 1) / SR_TILE);          // tiles in use (rows keep the stride of the dense case)
+    u32* row = hist + (i64)blockIdx.x * nblk_max;
     u32 carry = 0;
     for (int c0 = 0; c0 < nblk; c0 += 256) {
         const int i = c0 + tid;
@@ -235,13 +291,17 @@ __global__ __launch_bounds__(256) void sr_rowscan_kernel(u32* __restrict__ hist,
 // stable scatter of one 2048-key tile (scan_sort.hip: radix_scatter_kernel<1024, false>), values = item indices;
 // pos_of[item] = its position (0xffffffff for a sentinel)
 __global__ __launch_bounds__(1024) void sr_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout, u32* __restrict__ vout,
-                                                          u32* __restrict__ pos_of, i64 n, int shift, const u32* __restrict__ offs,
-                                                          const u32* __restrict__ totals, int nblk) {
+                                                          u32* __restrict__ pos_of, i64 V, int shift, const u32* __restrict__ offs,
+                                                          const u32* __restrict__ totals, int nblk, const u32* __restrict__ ctl_prev,
+                                                          const u32* __restrict__ node_of) {
     constexpr int THREADS = 1024, NWAVE = THREADS / 64, ROUNDS = SR_TILE / THREADS, NQ = ROUNDS * NWAVE;   // NQ == 32
     __shared__ u32 cnt[NQ * 256];     // 32 KiB
     __shared__ u32 dsum[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const i64 tile0 = (i64)blockIdx.x * SR_TILE;
+    i64 n;
+    const bool dense = sr_dense(ctl_prev, V, n);
+    if (tile0 >= n) return;                       // the grid covers the dense case
     u64 key[ROUNDS];
     u32 rank[ROUNDS];
     bool act[ROUNDS];
@@ -296,7 +356,7 @@ __global__ __launch_bounds__(1024) void sr_scatter_kernel(const u64* __restrict_
                 const u32 d = (u32)(key[r] >> shift) & 255u;
                 pos = cnt[(r * NWAVE + w) * 256 + d] + rank[r];
                 kout[pos] = key[r];
-                vout[pos] = (u32)idx;
+                vout[pos] = dense ? (u32)idx : node_of[idx];
             }
             pos_of[idx] = pos;
         }
@@ -342,7 +402,9 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
         return;
     }
     const u64 kmask = (1ull << shift) - 1ull;       // shift <= 48: key + 1 never wraps to 0
-    for (int t = tid; t < SRD_SLOTS; t += 1024) key_s[t] = 0ull, word_s[t] = 0u;
+    // a table of four slots per item is as good as the full one (distinct keys <= items) and much quicker to clear and to rank
+    const u32 nslots = size >= (u32)SRD_SLOTS / 4u ? (u32)SRD_SLOTS : (size < 64u ? 256u : 4u * size);
+    for (u32 t = tid; t < nslots; t += 1024) key_s[t] = 0ull, word_s[t] = 0u;
     __syncthreads();
     const bool too_long = size > (u32)SRD_MAX_CHUNKS * 1024u;
     u64 claimed = 0;
@@ -353,7 +415,7 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
             const u64 k_nxt = i + 1024 < size ? kx[start + i + 1024] : 0ull;
             const u64 k1 = (k_cur & kmask) + 1ull;
             k_cur = k_nxt;
-            u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)SRD_SLOTS) >> 32);
+            u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)nslots) >> 32);
             for (;;) {
                 unsigned long long v = key_s[h];
                 if (v == 0ull) {
@@ -367,7 +429,7 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
                     }
                 }
                 if (v == k1) { if (*(volatile u32*)&word_s[h] != 2u) atomicMax(&word_s[h], 2u); break; }
-                h = h + 1u == (u32)SRD_SLOTS ? 0u : h + 1u;
+                h = h + 1u == nslots ? 0u : h + 1u;
             }
         }
     }
@@ -385,7 +447,7 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
     u32 mine = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const u32 m = word_s[PER * tid + q];
+        const u32 m = (u32)(PER * tid + q) < nslots ? word_s[PER * tid + q] : 0u;
         mine += m == 2u ? 1u : (m == 1u ? 0x10000u : 0u);
     }
     const u32 inc = sr_wave_incl_scan(mine);
@@ -399,7 +461,7 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
     u32 b_sh = before & 0xffffu, b_si = before >> 16;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const u32 members = word_s[PER * tid + q];
+        const u32 members = (u32)(PER * tid + q) < nslots ? word_s[PER * tid + q] : 0u;
         if (members == 2u) word_s[PER * tid + q] = b_sh++;
         else if (members == 1u) word_s[PER * tid + q] = (b_si++) | 0x80000000u;
     }
@@ -413,8 +475,8 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
         const u64 k_nxt = i + 1024 < size ? kx[start + i + 1024] : 0ull;
         const u64 k1 = (k_cur & kmask) + 1ull;
         k_cur = k_nxt;
-        u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)SRD_SLOTS) >> 32);
-        while (key_s[h] != k1) h = h + 1u == (u32)SRD_SLOTS ? 0u : h + 1u;
+        u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)nslots) >> 32);
+        while (key_s[h] != k1) h = h + 1u == nslots ? 0u : h + 1u;
         const u32 v = word_s[h];
         item_out[start + i] = v & 0x80003fffu;
         if (!(v >> 31)) {
@@ -433,19 +495,22 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
     }
 }
 
-// ---- node order: labels, verification, final ids of the nodes that just froze ------------------------------------------
+// ---- item order: labels, verification, final ids of the nodes that just froze, the next level's active list ----------
 __global__ __launch_bounds__(1024) void sr_finish_kernel(const u32* __restrict__ pos_of, const u32* __restrict__ item,
                                                          const i32* __restrict__ rep2, const u32* __restrict__ totals,
                                                          const u32* __restrict__ nd_sh, const u32* __restrict__ nd_si,
                                                          const u32* __restrict__ listed, u32* __restrict__ ctl_cur, u32* __restrict__ ctl_next,
-                                                         i32* __restrict__ labels, i64 V, int level, int n_levels, int verify,
-                                                         const i32* __restrict__ row_ptr, const i32* __restrict__ nbr_sorted) {
+                                                         const u32* __restrict__ ctl_prev, i32* __restrict__ labels, i64 V, int level,
+                                                         int n_levels, int verify, const i32* __restrict__ row_ptr,
+                                                         const i32* __restrict__ nbr_sorted, const u32* __restrict__ node_of,
+                                                         u32* __restrict__ seg, u32* __restrict__ wg_cnt) {
     __shared__ u32 starts[257], bsh[257], bsi[257];
     __shared__ u32 d0[4], d1[4], d2[4], d3[4];
+    __shared__ u32 wsh[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     {
         const u32 t = tid < 256 ? totals[tid] : 0u, a = tid < 256 ? nd_sh[tid] : 0u, b = tid < 256 ? nd_si[tid] : 0u;
-        const u32 li = (tid < 256 && blockIdx.x == 0) ? listed[tid] : 0u;
+        const u32 li = tid < 256 ? listed[tid] : 0u;
         const u32 it = sr_wave_incl_scan(t), ia = sr_wave_incl_scan(a), ib = sr_wave_incl_scan(b), il = sr_wave_incl_scan(li);
         if (lane == 63 && w < 4) d0[w] = it, d1[w] = ia, d2[w] = ib, d3[w] = il;
         __syncthreads();
@@ -458,44 +523,72 @@ __global__ __launch_bounds__(1024) void sr_finish_kernel(const u32* __restrict__
         __syncthreads();
     }
     const u32 S = bsh[256], T = bsi[256];
+    const u32 listed_all = d3[0] + d3[1] + d3[2] + d3[3];             // items of shared classes = the next level's active nodes
     const u32 F = ctl_cur[SR_F], ncc = ctl_cur[SR_NCC];
     if (blockIdx.x == 0 && tid == 0) {
         ctl_cur[SR_S] = S, ctl_cur[SR_T] = T, ctl_cur[SR_COUNT] = ncc + F + S + T;
-        ctl_cur[SR_LISTED] = d3[0] + d3[1] + d3[2] + d3[3];
+        ctl_cur[SR_LISTED] = listed_all;
         if (ctl_next) ctl_next[SR_F] = F + T;
     }
-    const i64 v = (i64)blockIdx.x * 1024 + tid;
-    if (v >= V) return;
-    const u32 pos = pos_of[v];
-    if (pos == 0xffffffffu) return;               // not active: the label of this level was written when the node froze (or is carried)
-    const u32 t = item[pos];
-    int lo = 0, hi = 256;                         // largest b with starts[b] <= pos
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (starts[mid] <= pos) lo = mid; else hi = mid;
+    i64 n_items;
+    const bool dense = sr_dense(ctl_prev, V, n_items);
+    // the next level walks a list only when these are at most a quarter of the batch (sr_dense): no list otherwise
+    const bool want_list = ctl_next != nullptr && (u64)listed_all * 4ull <= (u64)V;
+    const i64 j = (i64)blockIdx.x * 1024 + tid;
+    u32 pos = 0xffffffffu;
+    i32 v = 0;
+    if (j < n_items) {
+        pos = pos_of[j];
+        v = dense ? (i32)j : (i32)node_of[j];
     }
-    const u32 rank = t & 0x3fffu;
-    i32* lab = labels + (size_t)level * V;
-    if (t >> 31) {
-        const u32 id = ncc + F + S + bsi[lo] + rank;
-        lab[v] = (i32)id;
-        const i32 fin = (i32)(id - S);            // = n_cc + F_{l+1} slot: the node's id at every later level
-        for (int l2 = level + 1; l2 < n_levels; ++l2) labels[(size_t)l2 * V + v] = fin;
-        return;
+    bool shared = false;
+    if (pos != 0xffffffffu) {                    // else: not active -- the label of this level was written when the node froze (or is carried)
+        const u32 t = item[pos];
+        int lo = 0, hi = 256;                    // largest b with starts[b] <= pos
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (starts[mid] <= pos) lo = mid; else hi = mid;
+        }
+        const u32 rank = t & 0x3fffu;
+        i32* lab = labels + (size_t)level * V;
+        if (t >> 31) {
+            const u32 id = ncc + F + S + bsi[lo] + rank;
+            lab[v] = (i32)id;
+            const i32 fin = (i32)(id - S);       // = n_cc + F_{l+1} slot: the node's id at every later level
+            for (int l2 = level + 1; l2 < n_levels; ++l2) labels[(size_t)l2 * V + v] = fin;
+        } else {
+            shared = true;
+            lab[v] = (i32)(ncc + F + bsh[lo] + rank);
+            if (verify) {
+                const i32 r = rep2[starts[lo] + rank];
+                if (r != v) {
+                    const i32* lab_prev = labels + (size_t)(level - 1) * V;
+                    bool ok = lab_prev[v] == lab_prev[r];
+                    const i32 s = row_ptr[v], sr = row_ptr[r];
+                    const int d = row_ptr[v + 1] - s;
+                    ok = ok && (d == row_ptr[r + 1] - sr);
+                    if (ok)
+                        for (int k = 0; k < d; ++k)
+                            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+                    if (!ok) atomicAdd(&ctl_cur[SR_UNRES], 1u);
+                }
+            }
+        }
     }
-    lab[v] = (i32)(ncc + F + bsh[lo] + rank);
-    if (!verify) return;
-    const i32 r = rep2[starts[lo] + rank];
-    if (r == (i32)v) return;
-    const i32* lab_prev = labels + (size_t)(level - 1) * V;
-    bool ok = lab_prev[v] == lab_prev[r];
-    const i32 s = row_ptr[v], sr = row_ptr[r];
-    const int d = row_ptr[v + 1] - s;
-    ok = ok && (d == row_ptr[r + 1] - sr);
-    if (ok)
-        for (int k = 0; k < d; ++k)
-            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
-    if (!ok) atomicAdd(&ctl_cur[SR_UNRES], 1u);
+    if (!want_list) return;                      // block-uniform
+    // ---- this workgroup's segment of the next level's active list (ballot compaction: no atomics, ascending items)
+    const u64 m = __ballot(shared);
+    if (lane == 0) wsh[w] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const u32 c = wsh[q];
+        if (q < w) before += c;
+        all += c;
+    }
+    if (shared) seg[(size_t)blockIdx.x * 1024u + before + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)v;
+    if (tid == 0) wg_cnt[blockIdx.x] = all;
 }
 
 // label-grouped node order of a stream-layout level, on demand (the label-major feature builder, features.hip): key =
@@ -541,10 +634,12 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
     u32* ctl = b->sr_ctl;
     const int nblk = (int)cdiv(V, SR_TILE);
     Tmp<u64> key(ctx), kx(ctx);
-    Tmp<u32> vx(ctx), pos_of(ctx), item(ctx), hist(ctx), small(ctx);
+    Tmp<u32> vx(ctx), pos_of(ctx), item(ctx), hist(ctx), small(ctx), node_of(ctx), seg(ctx), wg_cnt(ctx);
     Tmp<i32> rep2(ctx);
     GK_TRY(key.alloc(V)); GK_TRY(kx.alloc(V)); GK_TRY(vx.alloc(V)); GK_TRY(pos_of.alloc(V)); GK_TRY(item.alloc(V));
     GK_TRY(rep2.alloc(V)); GK_TRY(hist.alloc((size_t)256 * nblk)); GK_TRY(small.alloc(5 * 256));
+    const i64 n_fin = cdiv(V, 1024);                      // workgroups of sr_finish = segments of the active list
+    GK_TRY(node_of.alloc(V / 4 + 1)); GK_TRY(seg.alloc((size_t)n_fin * 1024)); GK_TRY(wg_cnt.alloc((size_t)n_fin));
     u32* totals = small.p;
     u32* nd_sh = small.p + 256;
     u32* nd_si = small.p + 512;
@@ -576,19 +671,23 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
                                                                            code_R, cc + SR_UNRES);
         } else if (lvl == 1) {
             sr_sig_kernel<true><<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
-                b->row_ptr, b->col_idx, prev, b->nbr_sorted, key.p, V, level_seed(lvl, 0), full_mask, sig_regs, nullptr);
+                b->row_ptr, b->col_idx, prev, b->nbr_sorted, key.p, V, level_seed(lvl, 0), full_mask, sig_regs, nullptr, nullptr, nullptr,
+                nullptr);
         } else {
             sr_sig_kernel<false><<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
-                b->row_ptr, b->col_idx, prev, b->nbr_sorted, key.p, V, level_seed(lvl, 0), full_mask, sig_regs, cc - SR_CTL);
+                b->row_ptr, b->col_idx, prev, b->nbr_sorted, key.p, V, level_seed(lvl, 0), full_mask, sig_regs, cc - SR_CTL, seg.p,
+                wg_cnt.p, node_of.p);
         }
+        const u32* cp = lvl >= 2 ? cc - SR_CTL : nullptr;       // the level before: how many items this level has (null: level 1, all nodes)
         const int shift = 8 * ((bits + 7) / 8 - 1);
-        sr_hist_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(key.p, V, shift, hist.p, nblk);
-        sr_rowscan_kernel<<<dim3(256), 256, 0, ctx->stream>>>(hist.p, nblk, totals);
-        sr_scatter_kernel<<<dim3(nblk), 1024, 0, ctx->stream>>>(key.p, kx.p, vx.p, pos_of.p, V, shift, hist.p, totals, nblk);
+        sr_hist_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(key.p, V, shift, hist.p, nblk, cp);
+        sr_rowscan_kernel<<<dim3(256), 256, 0, ctx->stream>>>(hist.p, nblk, totals, V, cp);
+        sr_scatter_kernel<<<dim3(nblk), 1024, 0, ctx->stream>>>(key.p, kx.p, vx.p, pos_of.p, V, shift, hist.p, totals, nblk, cp, node_of.p);
         sr_dict_kernel<<<dim3(256), 1024, lds, ctx->stream>>>(kx.p, vx.p, totals, shift, item.p, rep2.p, nd_sh, nd_si, listed,
                                                               cc + SR_OVF, max_distinct);
-        sr_finish_kernel<<<grid_for(V, 1024), 1024, 0, ctx->stream>>>(pos_of.p, item.p, rep2.p, totals, nd_sh, nd_si, listed, cc, cn,
-                                                                      b->labels, V, lvl, n_levels, verify, b->row_ptr, b->nbr_sorted);
+        sr_finish_kernel<<<dim3((unsigned)n_fin), 1024, 0, ctx->stream>>>(pos_of.p, item.p, rep2.p, totals, nd_sh, nd_si, listed, cc, cn, cp,
+                                                                          b->labels, V, lvl, n_levels, verify, b->row_ptr, b->nbr_sorted,
+                                                                          node_of.p, seg.p, wg_cnt.p);
     }
     GK_HIP_CHECK(hipGetLastError());
     std::vector<u32> h((size_t)n_levels * SR_CTL);
