@@ -6,14 +6,15 @@
 //
 // wl.hip decides per level on the HOST which route a level takes (full / active set / single workgroup), which costs a
 // device -> host -> device round trip per level (mailbox waits: profiles/r03_step_timeline.txt, 160 us of idle device per
-// profiled step).  Here every level is the SAME six launches with static grids; everything data dependent is read from
+// profiled step).  Here every level is the SAME four launches with static grids; everything data dependent is read from
 // device memory (gk_batch::sr_ctl, SR_CTL words per level), so a whole job -- relabel, and the feature builder behind it
 // (features_gm.hip reads the same words) -- is queued without the host knowing a single count:
 //   sr_sig      signature key of every ACTIVE node (class of two or more members at the level before, not isolated);
 //               everybody else gets the sentinel key and costs one label read.  A 256-node chunk with many active nodes
 //               stages its neighbour labels through LDS (coalesced col_idx stream), a sparse chunk gathers per thread.
-//   sr_hist / sr_rowscan / sr_scatter   stable partition of the active keys by their top digit (sentinels dropped);
-//               the scatter also leaves pos_of[node] = position of the node's key, so that the last pass runs in NODE order
+//   sr_part     TILE-LOCAL partition of the active keys by their top digit (sentinels dropped): no global histogram, no
+//               prefix over the tiles -- a bucket is the union of its 2048-key tiles' runs; also leaves pos_of[item] =
+//               position of the item's key, so that the last pass runs in ITEM order
 //   sr_dict     one workgroup per top-digit bucket: LDS table of the bucket's DISTINCT keys (as scan_sort.hip's
 //               bucket_dict_kernel), slots ranked separately for classes of two or more members and singletons;
 //               the claimer of a shared class records itself as its representative
@@ -239,61 +240,15 @@ __global__ __launch_bounds__(256) void sr_sig_exact_kernel(
     key_out[v] = (u64)x;
 }
 
-// ---- partition by the top digit (sentinel keys take no part) ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void sr_hist_kernel(const u64* __restrict__ kin, i64 V, int shift, u32* __restrict__ hist, int nblk,
-                                                      const u32* __restrict__ ctl_prev) {
-    __shared__ u32 h[256];
-    const int tid = threadIdx.x;
-    i64 n;
-    sr_dense(ctl_prev, V, n);
-    const i64 tile0 = (i64)blockIdx.x * SR_TILE;
-    if (tile0 >= n) return;                       // the grid covers the dense case
-    h[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SR_TILE / 256; ++r) {
-        const i64 idx = tile0 + r * 256 + tid;
-        if (idx < n) {
-            const u64 k = kin[idx];
-            if (k != SR_SENT) atomicAdd(&h[(u32)(k >> shift) & 255u], 1u);
-        }
-    }
-    __syncthreads();
-    hist[(i64)tid * nblk + blockIdx.x] = h[tid];
-}
-
-// block d: exclusive prefix of digit d's tile counts (in place) and the digit total
-__global__ __launch_bounds__(256) void sr_rowscan_kernel(u32* __restrict__ hist, int nblk_max, u32* __restrict__ totals, i64 V,
-                                                         const u32* __restrict__ ctl_prev) {
-    __shared__ u32 wsum[4];
-    const int tid = threadIdx.x;
-    i64 n;
-    sr_dense(ctl_prev, V, n);
-    const int nblk = (int)((n + SR_TILE - 1) / SR_TILE);          // tiles in use (rows keep the stride of the dense case)
-    u32* row = hist + (i64)blockIdx.x * nblk_max;
-    u32 carry = 0;
-    for (int c0 = 0; c0 < nblk; c0 += 256) {
-        const int i = c0 + tid;
-        const u32 v = i < nblk ? row[i] : 0u;
-        const u32 inc = sr_wave_incl_scan(v);
-        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-        __syncthreads();
-        u32 woff = 0;
-        for (int w = 0; w < (tid >> 6); ++w) woff += wsum[w];
-        const u32 all = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (i < nblk) row[i] = carry + woff + inc - v;
-        carry += all;
-        __syncthreads();
-    }
-    if (tid == 0) totals[blockIdx.x] = carry;
-}
-
-// stable scatter of one 2048-key tile (scan_sort.hip: radix_scatter_kernel<1024, false>), values = item indices;
-// pos_of[item] = its position (0xffffffff for a sentinel)
-__global__ __launch_bounds__(1024) void sr_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout, u32* __restrict__ vout,
-                                                          u32* __restrict__ pos_of, i64 V, int shift, const u32* __restrict__ offs,
-                                                          const u32* __restrict__ totals, int nblk, const u32* __restrict__ ctl_prev,
-                                                          const u32* __restrict__ node_of) {
+// ---- partition by the top digit, TILE-LOCAL: a tile's 2048 keys are grouped by digit inside the tile's own range, and the
+// (start, count) of every digit run goes to runs[digit][tile].  Nothing global is needed to place a key -- no histogram pass,
+// no prefix pass over the tiles' counts (two launches of ~5 us each per level, whatever the level's size) -- and the owner of
+// bucket d (sr_dict) walks its 64-byte runs tile by tile instead of one contiguous range.  Sentinel keys take no part.
+// pos_of[item] = position of its key (0xffffffff for a sentinel); values = nodes.
+#define SR_MAX_TILES 1088       // tiles a bucket owner indexes in LDS (2.2 M items; gk_bucket_dictionary_fits binds earlier)
+__global__ __launch_bounds__(1024) void sr_part_kernel(const u64* __restrict__ kin, u64* __restrict__ kout, u32* __restrict__ vout,
+                                                       u32* __restrict__ pos_of, i64 V, int shift, u32* __restrict__ runs, int nblk,
+                                                       const u32* __restrict__ ctl_prev, const u32* __restrict__ node_of) {
     constexpr int THREADS = 1024, NWAVE = THREADS / 64, ROUNDS = SR_TILE / THREADS, NQ = ROUNDS * NWAVE;   // NQ == 32
     __shared__ u32 cnt[NQ * 256];     // 32 KiB
     __shared__ u32 dsum[4];
@@ -311,13 +266,6 @@ __global__ __launch_bounds__(1024) void sr_scatter_kernel(const u64* __restrict_
         key[r] = idx < n ? kin[idx] : SR_SENT;
         act[r] = key[r] != SR_SENT;
     }
-    u32 before = 0, total = 0;
-    if (tid < 256) {
-        before = offs[(i64)tid * nblk + blockIdx.x];
-        total = totals[tid];
-    }
-    const u32 dincl = sr_wave_incl_scan(total);
-    if (lane == 63 && w < 4) dsum[w] = dincl;
 #pragma unroll
     for (int q = 0; q < NQ * 256 / THREADS; ++q) cnt[q * THREADS + tid] = 0;
     __syncthreads();
@@ -336,9 +284,18 @@ __global__ __launch_bounds__(1024) void sr_scatter_kernel(const u64* __restrict_
         if (act[r] && rank[r] == 0) cnt[(r * NWAVE + w) * 256 + d] = (u32)__popcll(m);
     }
     __syncthreads();
+    u32 total = 0;
     if (tid < 256) {
-        u32 run = dincl - total + before;    // keys with smaller digits + equal digits in earlier tiles
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) total += cnt[q * 256 + tid];
+    }
+    const u32 dincl = sr_wave_incl_scan(total);
+    if (lane == 63 && w < 4) dsum[w] = dincl;
+    __syncthreads();
+    if (tid < 256) {
+        u32 run = dincl - total;                 // keys of the tile with smaller digits
         for (int q = 0; q < w; ++q) run += dsum[q];
+        runs[(i64)tid * nblk + blockIdx.x] = (run << 16) | total;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const u32 c = cnt[q * 256 + tid];
@@ -354,7 +311,7 @@ __global__ __launch_bounds__(1024) void sr_scatter_kernel(const u64* __restrict_
             u32 pos = 0xffffffffu;
             if (act[r]) {
                 const u32 d = (u32)(key[r] >> shift) & 255u;
-                pos = cnt[(r * NWAVE + w) * 256 + d] + rank[r];
+                pos = (u32)tile0 + cnt[(r * NWAVE + w) * 256 + d] + rank[r];
                 kout[pos] = key[r];
                 vout[pos] = dense ? (u32)idx : node_of[idx];
             }
@@ -368,39 +325,64 @@ __global__ __launch_bounds__(1024) void sr_scatter_kernel(const u64* __restrict_
 #define SRD_MAX_DISTINCT 9216    // load factor 0.75
 #define SRD_MAX_CHUNKS 64        // claim flags of a thread: one bit per 1024-item chunk
 
-// item_out[pos] = rank of the item's class among the bucket's shared / singleton classes (bits 0-13) | singleton << 31;
-// nd_sh / nd_si / listed [bucket] = shared classes, singleton classes, items of shared classes; rep2[bucket start + rank] =
+// item_out[pos] = rank of the item's class among the bucket's shared / singleton classes (bits 0-13) | bucket << 14 | singleton << 31;
+// nd_sh / nd_si / listed [bucket] = shared classes, singleton classes, items of shared classes; rep2[bucket * SRD_SLOTS + rank] =
 // representative (the claiming item's node) of each shared class
-__global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ kx, const u32* __restrict__ vx, const u32* __restrict__ totals,
-                                                       int shift, u32* __restrict__ item_out, i32* __restrict__ rep2,
+__global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ kx, const u32* __restrict__ vx, const u32* __restrict__ runs,
+                                                       int nblk, i64 V, const u32* __restrict__ ctl_prev, int shift,
+                                                       u32* __restrict__ item_out, i32* __restrict__ rep2,
                                                        u32* __restrict__ nd_sh, u32* __restrict__ nd_si, u32* __restrict__ listed,
                                                        u32* __restrict__ overflow, u32 max_distinct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char srd_lds[];
     unsigned long long* key_s = (unsigned long long*)srd_lds;                  // [SRD_SLOTS] key + 1, 0 = empty
     u32* word_s = (u32*)(srd_lds + (size_t)SRD_SLOTS * 8);                     // [SRD_SLOTS] 1 / 2 = one / several members, later rank | singleton << 31
-    __shared__ u32 dsum[4];
+    __shared__ u32 tpre[SR_MAX_TILES + 1];      // items of this bucket in the tiles before tile t
+    __shared__ u32 toff[SR_MAX_TILES];          // position of the bucket's run in tile t
     __shared__ u32 wsum[16];
-    __shared__ u32 bstart, n_claimed, ovf;
+    __shared__ u32 n_claimed, ovf;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u32 bucket = blockIdx.x;
     if (tid == 0) n_claimed = 0, ovf = 0;
-    {   // bucket range: exclusive prefix of the digit totals
-        const u32 t = tid < 256 ? totals[tid] : 0u;
-        const u32 inc = sr_wave_incl_scan(t);
-        if (lane == 63 && w < 4) dsum[w] = inc;
-        __syncthreads();
-        if (tid == (int)blockIdx.x) {
-            u32 off = inc - t;
-            for (int q = 0; q < w; ++q) off += dsum[q];
-            bstart = off;
+    i64 n_items;
+    sr_dense(ctl_prev, V, n_items);
+    const int nt = (int)((n_items + SR_TILE - 1) / SR_TILE);        // tiles in use
+    u32 size = 0;
+    {   // the bucket's runs: exclusive prefix of their lengths over the tiles
+        u32 carry = 0;
+        for (int t0 = 0; t0 < nt; t0 += 1024) {
+            const int t = t0 + tid;
+            const u32 rw = t < nt ? runs[(i64)bucket * nblk + t] : 0u;
+            const u32 c = rw & 0xffffu;
+            const u32 inc = sr_wave_incl_scan(c);
+            __syncthreads();                     // wsum of the round before is read below
+            if (lane == 63) wsum[w] = inc;
+            __syncthreads();
+            u32 before = 0, all = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q < w) before += wsum[q];
+                all += wsum[q];
+            }
+            if (t < nt) tpre[t] = carry + before + inc - c, toff[t] = (u32)t * SR_TILE + (rw >> 16);
+            carry += all;
         }
+        size = carry;
+        if (tid == 0) tpre[nt] = size;
         __syncthreads();
     }
-    const u32 size = totals[blockIdx.x];
-    const i64 start = bstart;
     if (size == 0) {
-        if (tid == 0) nd_sh[blockIdx.x] = 0, nd_si[blockIdx.x] = 0, listed[blockIdx.x] = 0;
+        if (tid == 0) nd_sh[bucket] = 0, nd_si[bucket] = 0, listed[bucket] = 0;
         return;
     }
+    // bucket-local item i -> its position: the run of the tile with tpre[t] <= i < tpre[t + 1]
+    auto locate = [&](u32 i) __attribute__((always_inline)) {
+        int lo = 0, hi = nt;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (tpre[mid] <= i) lo = mid; else hi = mid;
+        }
+        return toff[lo] + (i - tpre[lo]);
+    };
     const u64 kmask = (1ull << shift) - 1ull;       // shift <= 48: key + 1 never wraps to 0
     // a table of four slots per item is as good as the full one (distinct keys <= items) and much quicker to clear and to rank
     const u32 nslots = size >= (u32)SRD_SLOTS / 4u ? (u32)SRD_SLOTS : (size < 64u ? 256u : 4u * size);
@@ -410,9 +392,9 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
     u64 claimed = 0;
     if (!too_long) {
         int c = 0;
-        u64 k_cur = (u32)tid < size ? kx[start + tid] : 0ull;
+        u64 k_cur = (u32)tid < size ? kx[locate((u32)tid)] : 0ull;
         for (u32 i = tid; i < size; i += 1024, ++c) {
-            const u64 k_nxt = i + 1024 < size ? kx[start + i + 1024] : 0ull;
+            const u64 k_nxt = i + 1024 < size ? kx[locate(i + 1024)] : 0ull;
             const u64 k1 = (k_cur & kmask) + 1ull;
             k_cur = k_nxt;
             u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)nslots) >> 32);
@@ -435,9 +417,9 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
     }
     __syncthreads();
     if (too_long || ovf) {              // not handled here: every item a "singleton" of rank 0 (memory-safe), the job is redone by wl.hip
-        for (u32 i = tid; i < size; i += 1024) item_out[start + i] = 0x80000000u;
+        for (u32 i = tid; i < size; i += 1024) item_out[locate(i)] = 0x80000000u | (bucket << 14);
         if (tid == 0) {
-            nd_sh[blockIdx.x] = 0, nd_si[blockIdx.x] = 1, listed[blockIdx.x] = 0;
+            nd_sh[bucket] = 0, nd_si[bucket] = 1, listed[bucket] = 0;
             atomicOr(overflow, 1u);
         }
         return;
@@ -465,23 +447,26 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
         if (members == 2u) word_s[PER * tid + q] = b_sh++;
         else if (members == 1u) word_s[PER * tid + q] = (b_si++) | 0x80000000u;
     }
-    if (tid == 0) nd_sh[blockIdx.x] = all & 0xffffu, nd_si[blockIdx.x] = all >> 16;
+    if (tid == 0) nd_sh[bucket] = all & 0xffffu, nd_si[bucket] = all >> 16;
     __syncthreads();
     // ---- every item looks its class up again
     u32 my_listed = 0;
     int c = 0;
-    u64 k_cur = (u32)tid < size ? kx[start + tid] : 0ull;
+    u32 p_cur = (u32)tid < size ? locate((u32)tid) : 0u;
+    u64 k_cur = (u32)tid < size ? kx[p_cur] : 0ull;
     for (u32 i = tid; i < size; i += 1024, ++c) {
-        const u64 k_nxt = i + 1024 < size ? kx[start + i + 1024] : 0ull;
+        const u32 p_nxt = i + 1024 < size ? locate(i + 1024) : 0u;
+        const u64 k_nxt = i + 1024 < size ? kx[p_nxt] : 0ull;
         const u64 k1 = (k_cur & kmask) + 1ull;
-        k_cur = k_nxt;
+        const u32 p = p_cur;
+        k_cur = k_nxt, p_cur = p_nxt;
         u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)nslots) >> 32);
         while (key_s[h] != k1) h = h + 1u == nslots ? 0u : h + 1u;
         const u32 v = word_s[h];
-        item_out[start + i] = v & 0x80003fffu;
+        item_out[p] = (v & 0x80003fffu) | (bucket << 14);
         if (!(v >> 31)) {
             ++my_listed;
-            if ((claimed >> c) & 1ull) rep2[start + (v & 0x3fffu)] = (i32)vx[start + i];
+            if ((claimed >> c) & 1ull) rep2[(size_t)bucket * SRD_SLOTS + (v & 0x3fffu)] = (i32)vx[p];
         }
     }
     for (int off = 32; off > 0; off >>= 1) my_listed += __shfl_down(my_listed, off, 64);
@@ -491,35 +476,35 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
     if (tid == 0) {
         u32 t = 0;
         for (int q = 0; q < 16; ++q) t += wsum[q];
-        listed[blockIdx.x] = t;
+        listed[bucket] = t;
     }
 }
 
 // ---- item order: labels, verification, final ids of the nodes that just froze, the next level's active list ----------
 __global__ __launch_bounds__(1024) void sr_finish_kernel(const u32* __restrict__ pos_of, const u32* __restrict__ item,
-                                                         const i32* __restrict__ rep2, const u32* __restrict__ totals,
+                                                         const i32* __restrict__ rep2,
                                                          const u32* __restrict__ nd_sh, const u32* __restrict__ nd_si,
                                                          const u32* __restrict__ listed, u32* __restrict__ ctl_cur, u32* __restrict__ ctl_next,
                                                          const u32* __restrict__ ctl_prev, i32* __restrict__ labels, i64 V, int level,
                                                          int n_levels, int verify, const i32* __restrict__ row_ptr,
                                                          const i32* __restrict__ nbr_sorted, const u32* __restrict__ node_of,
                                                          u32* __restrict__ seg, u32* __restrict__ wg_cnt) {
-    __shared__ u32 starts[257], bsh[257], bsi[257];
-    __shared__ u32 d0[4], d1[4], d2[4], d3[4];
+    __shared__ u32 bsh[257], bsi[257];
+    __shared__ u32 d1[4], d2[4], d3[4];
     __shared__ u32 wsh[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    {
-        const u32 t = tid < 256 ? totals[tid] : 0u, a = tid < 256 ? nd_sh[tid] : 0u, b = tid < 256 ? nd_si[tid] : 0u;
+    {   // class ids are dense across the buckets: prefixes of their shared / singleton class counts
+        const u32 a = tid < 256 ? nd_sh[tid] : 0u, b = tid < 256 ? nd_si[tid] : 0u;
         const u32 li = tid < 256 ? listed[tid] : 0u;
-        const u32 it = sr_wave_incl_scan(t), ia = sr_wave_incl_scan(a), ib = sr_wave_incl_scan(b), il = sr_wave_incl_scan(li);
-        if (lane == 63 && w < 4) d0[w] = it, d1[w] = ia, d2[w] = ib, d3[w] = il;
+        const u32 ia = sr_wave_incl_scan(a), ib = sr_wave_incl_scan(b), il = sr_wave_incl_scan(li);
+        if (lane == 63 && w < 4) d1[w] = ia, d2[w] = ib, d3[w] = il;
         __syncthreads();
         if (tid < 256) {
-            u32 x = it, y = ia, z = ib;
-            for (int q = 0; q < w; ++q) x += d0[q], y += d1[q], z += d2[q];
-            starts[tid + 1] = x, bsh[tid + 1] = y, bsi[tid + 1] = z;            // inclusive -> entry tid + 1
+            u32 y = ia, z = ib;
+            for (int q = 0; q < w; ++q) y += d1[q], z += d2[q];
+            bsh[tid + 1] = y, bsi[tid + 1] = z;            // inclusive -> entry tid + 1
         }
-        if (tid == 0) starts[0] = 0, bsh[0] = 0, bsi[0] = 0;
+        if (tid == 0) bsh[0] = 0, bsi[0] = 0;
         __syncthreads();
     }
     const u32 S = bsh[256], T = bsi[256];
@@ -544,11 +529,7 @@ __global__ __launch_bounds__(1024) void sr_finish_kernel(const u32* __restrict__
     bool shared = false;
     if (pos != 0xffffffffu) {                    // else: not active -- the label of this level was written when the node froze (or is carried)
         const u32 t = item[pos];
-        int lo = 0, hi = 256;                    // largest b with starts[b] <= pos
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (starts[mid] <= pos) lo = mid; else hi = mid;
-        }
+        const int lo = (int)((t >> 14) & 255u);  // the item's bucket
         const u32 rank = t & 0x3fffu;
         i32* lab = labels + (size_t)level * V;
         if (t >> 31) {
@@ -560,7 +541,7 @@ __global__ __launch_bounds__(1024) void sr_finish_kernel(const u32* __restrict__
             shared = true;
             lab[v] = (i32)(ncc + F + bsh[lo] + rank);
             if (verify) {
-                const i32 r = rep2[starts[lo] + rank];
+                const i32 r = rep2[(size_t)lo * SRD_SLOTS + rank];
                 if (r != v) {
                     const i32* lab_prev = labels + (size_t)(level - 1) * V;
                     bool ok = lab_prev[v] == lab_prev[r];
@@ -621,7 +602,7 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
     if (ctx->opt.wl_no_stream || b->is_pair_batch || V <= 0 || n_levels < 2 || b->n_big > 0) return GK_ERR_UNSUPPORTED;
     if (b->max_graph_nodes > GM_MAX_NODES || ctx->opt.feat_no_gm || ctx->opt.wl_no_bucket_dict || ctx->opt.wl_no_hist0) return GK_ERR_UNSUPPORTED;
     if (!(b->n_labels0 >= 1 && b->n_labels0 <= GK_HIST0_MAX_LABELS)) return GK_ERR_UNSUPPORTED;
-    if (hash_bits < 32 || hash_bits > 56 || !gk_bucket_dictionary_fits(ctx, V)) return GK_ERR_UNSUPPORTED;
+    if (hash_bits < 32 || hash_bits > 56 || !gk_bucket_dictionary_fits(ctx, V) || cdiv(V, SR_TILE) > SR_MAX_TILES) return GK_ERR_UNSUPPORTED;
     if (b->n_isolated != n_car || (n_car > 0 && !(b->car_class && b->car_nodes))) return GK_ERR_UNSUPPORTED;    // option wl.no_iso: nothing carried
     if (ctx->opt.wl_no_active_set || ctx->opt.wl_no_split) return GK_ERR_UNSUPPORTED;                 // route options of wl.hip: run that route
     if (b->sr_ctl_levels < n_levels) {
@@ -637,13 +618,12 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
     Tmp<u32> vx(ctx), pos_of(ctx), item(ctx), hist(ctx), small(ctx), node_of(ctx), seg(ctx), wg_cnt(ctx);
     Tmp<i32> rep2(ctx);
     GK_TRY(key.alloc(V)); GK_TRY(kx.alloc(V)); GK_TRY(vx.alloc(V)); GK_TRY(pos_of.alloc(V)); GK_TRY(item.alloc(V));
-    GK_TRY(rep2.alloc(V)); GK_TRY(hist.alloc((size_t)256 * nblk)); GK_TRY(small.alloc(5 * 256));
+    GK_TRY(rep2.alloc((size_t)256 * SRD_SLOTS)); GK_TRY(hist.alloc((size_t)256 * nblk)); GK_TRY(small.alloc(4 * 256));
     const i64 n_fin = cdiv(V, 1024);                      // workgroups of sr_finish = segments of the active list
     GK_TRY(node_of.alloc(V / 4 + 1)); GK_TRY(seg.alloc((size_t)n_fin * 1024)); GK_TRY(wg_cnt.alloc((size_t)n_fin));
-    u32* totals = small.p;
-    u32* nd_sh = small.p + 256;
-    u32* nd_si = small.p + 512;
-    u32* listed = small.p + 768;
+    u32* nd_sh = small.p;
+    u32* nd_si = small.p + 256;
+    u32* listed = small.p + 512;
     sr_init_kernel<<<dim3(1u + (unsigned)cdiv(n_car, 256)), 256, 0, ctx->stream>>>(
         ctl, n_levels, (u32)b->n_labels0, (u32)b->n_labels0_present, b->car_nodes, b->car_class, (u32)n_car, b->labels, V);
     const u64 full_mask = (1ull << hash_bits) - 1ull;
@@ -680,12 +660,10 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
         }
         const u32* cp = lvl >= 2 ? cc - SR_CTL : nullptr;       // the level before: how many items this level has (null: level 1, all nodes)
         const int shift = 8 * ((bits + 7) / 8 - 1);
-        sr_hist_kernel<<<dim3(nblk), 256, 0, ctx->stream>>>(key.p, V, shift, hist.p, nblk, cp);
-        sr_rowscan_kernel<<<dim3(256), 256, 0, ctx->stream>>>(hist.p, nblk, totals, V, cp);
-        sr_scatter_kernel<<<dim3(nblk), 1024, 0, ctx->stream>>>(key.p, kx.p, vx.p, pos_of.p, V, shift, hist.p, totals, nblk, cp, node_of.p);
-        sr_dict_kernel<<<dim3(256), 1024, lds, ctx->stream>>>(kx.p, vx.p, totals, shift, item.p, rep2.p, nd_sh, nd_si, listed,
+        sr_part_kernel<<<dim3(nblk), 1024, 0, ctx->stream>>>(key.p, kx.p, vx.p, pos_of.p, V, shift, hist.p, nblk, cp, node_of.p);
+        sr_dict_kernel<<<dim3(256), 1024, lds, ctx->stream>>>(kx.p, vx.p, hist.p, nblk, V, cp, shift, item.p, rep2.p, nd_sh, nd_si, listed,
                                                               cc + SR_OVF, max_distinct);
-        sr_finish_kernel<<<dim3((unsigned)n_fin), 1024, 0, ctx->stream>>>(pos_of.p, item.p, rep2.p, totals, nd_sh, nd_si, listed, cc, cn, cp,
+        sr_finish_kernel<<<dim3((unsigned)n_fin), 1024, 0, ctx->stream>>>(pos_of.p, item.p, rep2.p, nd_sh, nd_si, listed, cc, cn, cp,
                                                                           b->labels, V, lvl, n_levels, verify, b->row_ptr, b->nbr_sorted,
                                                                           node_of.p, seg.p, wg_cnt.p);
     }
