@@ -332,8 +332,10 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
                                                        int nblk, i64 V, const u32* __restrict__ ctl_prev, int shift,
                                                        u32* __restrict__ item_out, i32* __restrict__ rep2,
                                                        u32* __restrict__ nd_sh, u32* __restrict__ nd_si, u32* __restrict__ listed,
-                                                       u32* __restrict__ overflow, u32 max_distinct) {
+                                                       u32* __restrict__ overflow, u32 max_distinct, u64* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char srd_lds[];
+#define SRD_STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+    SRD_STAMP(0);
     unsigned long long* key_s = (unsigned long long*)srd_lds;                  // [SRD_SLOTS] key + 1, 0 = empty
     u32* word_s = (u32*)(srd_lds + (size_t)SRD_SLOTS * 8);                     // [SRD_SLOTS] 1 / 2 = one / several members, later rank | singleton << 31
     __shared__ u32 tpre[SR_MAX_TILES + 1];      // items of this bucket in the tiles before tile t
@@ -374,10 +376,25 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
         if (tid == 0) nd_sh[bucket] = 0, nd_si[bucket] = 0, listed[bucket] = 0;
         return;
     }
+    SRD_STAMP(1);
     // bucket-local item i -> its position: the run of the tile with tpre[t] <= i < tpre[t + 1]
+    // (runs are ~size / nt items each: start at the proportional guess and gallop -- a few LDS reads instead of the 11
+    // dependent ones of a bisection over all tiles, which cost more than the table look-up they serve)
     auto locate = [&](u32 i) __attribute__((always_inline)) {
-        int lo = 0, hi = nt;
-        while (hi - lo > 1) {
+        int lo = (int)(((u64)i * (u64)nt) / (u64)size), hi;
+        if (tpre[lo] <= i) {
+            int step = 1;
+            hi = lo + 1;
+            while (hi < nt && tpre[hi] <= i) { lo = hi; hi += step; step <<= 1; }
+            if (hi > nt) hi = nt;
+        } else {
+            int step = 1;
+            hi = lo;
+            lo = hi - 1;
+            while (lo > 0 && tpre[lo] > i) { hi = lo; lo -= step; step <<= 1; }
+            if (lo < 0) lo = 0;
+        }
+        while (hi - lo > 1) {                    // tpre[lo] <= i < tpre[hi]
             const int mid = (lo + hi) >> 1;
             if (tpre[mid] <= i) lo = mid; else hi = mid;
         }
@@ -388,34 +405,55 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
     const u32 nslots = size >= (u32)SRD_SLOTS / 4u ? (u32)SRD_SLOTS : (size < 64u ? 256u : 4u * size);
     for (u32 t = tid; t < nslots; t += 1024) key_s[t] = 0ull, word_s[t] = 0u;
     __syncthreads();
+    SRD_STAMP(2);
     const bool too_long = size > (u32)SRD_MAX_CHUNKS * 1024u;
     u64 claimed = 0;
+    // four items per thread and trip: their positions first, then the four key loads in flight together, then the table
+    // (one load in flight per thread made the pass a chain of memory latencies: 16 waves per CU cannot hide one each)
+    u32 pp0[4] = {0u, 0u, 0u, 0u}, hh0[4] = {0u, 0u, 0u, 0u};     // first trip: positions and table slots, kept for the look-up pass
     if (!too_long) {
-        int c = 0;
-        u64 k_cur = (u32)tid < size ? kx[locate((u32)tid)] : 0ull;
-        for (u32 i = tid; i < size; i += 1024, ++c) {
-            const u64 k_nxt = i + 1024 < size ? kx[locate(i + 1024)] : 0ull;
-            const u64 k1 = (k_cur & kmask) + 1ull;
-            k_cur = k_nxt;
-            u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)nslots) >> 32);
-            for (;;) {
-                unsigned long long v = key_s[h];
-                if (v == 0ull) {
-                    if (*(volatile u32*)&ovf) break;                                       // table declared full: stop claiming
-                    v = atomicCAS(&key_s[h], 0ull, (unsigned long long)k1);
-                    if (v == 0ull) {                                      // claimed: this item owns the class
-                        claimed |= 1ull << c;
-                        atomicMax(&word_s[h], 1u);
-                        if (atomicAdd(&n_claimed, 1u) + 1u > max_distinct) ovf = 1u;
-                        break;
+        for (u32 i0 = tid; i0 < size; i0 += 4096u) {
+            u32 pp[4];
+            u64 kk[4];
+#pragma unroll
+            for (u32 u = 0; u < 4u; ++u) pp[u] = i0 + u * 1024u < size ? locate(i0 + u * 1024u) : 0u;
+#pragma unroll
+            for (u32 u = 0; u < 4u; ++u) kk[u] = i0 + u * 1024u < size ? kx[pp[u]] : 0ull;
+#pragma unroll
+            for (u32 u = 0; u < 4u; ++u) {
+                const bool have = i0 + u * 1024u < size;
+                const int c = (int)((i0 + u * 1024u) >> 10);
+                bool won = false;
+                // the table is declared full at max_distinct claims; checked once per item, not per probe (a dependent LDS read
+                // on the path to every claim): every thread claims at most once in between, 9216 + 1024 < 12288 slots
+                if (have && !*(volatile u32*)&ovf) {
+                    const u64 k1 = (kk[u] & kmask) + 1ull;
+                    u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)nslots) >> 32);
+                    for (;;) {
+                        unsigned long long v = key_s[h];
+                        if (v == 0ull) {
+                            v = atomicCAS(&key_s[h], 0ull, (unsigned long long)k1);
+                            if (v == 0ull) {                                      // claimed: this item owns the class
+                                won = true;
+                                atomicMax(&word_s[h], 1u);
+                                break;
+                            }
+                        }
+                        if (v == k1) { if (*(volatile u32*)&word_s[h] != 2u) atomicMax(&word_s[h], 2u); break; }
+                        h = h + 1u == nslots ? 0u : h + 1u;
                     }
+                    if (i0 < 1024u) pp0[u] = pp[u], hh0[u] = h;
                 }
-                if (v == k1) { if (*(volatile u32*)&word_s[h] != 2u) atomicMax(&word_s[h], 2u); break; }
-                h = h + 1u == nslots ? 0u : h + 1u;
+                // distinct keys are counted once per wave (a thousand lanes adding to ONE LDS word serialise: half of this
+                // pass at a level where every key is new); a wave can overshoot max_distinct by 63 slots, the table has room
+                if (won) claimed |= 1ull << c;
+                const u64 wm = __ballot(won);
+                if (wm && lane == 0 && atomicAdd(&n_claimed, (u32)__popcll(wm)) + (u32)__popcll(wm) > max_distinct) ovf = 1u;
             }
         }
     }
     __syncthreads();
+    SRD_STAMP(3);
     if (too_long || ovf) {              // not handled here: every item a "singleton" of rank 0 (memory-safe), the job is redone by wl.hip
         for (u32 i = tid; i < size; i += 1024) item_out[locate(i)] = 0x80000000u | (bucket << 14);
         if (tid == 0) {
@@ -424,13 +462,24 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
         }
         return;
     }
-    // ---- rank the slots in use, shared classes (low half) and singletons (high half) apart: thread t owns slots [12t, 12t + 12)
+    // ---- rank the slots in use, shared classes (low half) and singletons (high half) apart: thread t owns slots [12t, 12t + 12),
+    // read and written as three 16-byte words (twelve strided 4-byte LDS accesses per thread and direction were ~4 us per bucket)
     constexpr int PER = SRD_SLOTS / 1024;
+    u32 mw[PER];
+    const bool any_mine = (u32)(PER * tid) < nslots;
+    {
+        const uint4* src = (const uint4*)(word_s + PER * tid);
+#pragma unroll
+        for (int q4 = 0; q4 < PER / 4; ++q4) {
+            const uint4 x = any_mine ? src[q4] : make_uint4(0, 0, 0, 0);
+            mw[4 * q4] = x.x, mw[4 * q4 + 1] = x.y, mw[4 * q4 + 2] = x.z, mw[4 * q4 + 3] = x.w;
+        }
+    }
     u32 mine = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const u32 m = (u32)(PER * tid + q) < nslots ? word_s[PER * tid + q] : 0u;
-        mine += m == 2u ? 1u : (m == 1u ? 0x10000u : 0u);
+        if ((u32)(PER * tid + q) >= nslots) mw[q] = 0u;
+        mine += mw[q] == 2u ? 1u : (mw[q] == 1u ? 0x10000u : 0u);
     }
     const u32 inc = sr_wave_incl_scan(mine);
     if (lane == 63) wsum[w] = inc;
@@ -443,30 +492,51 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
     u32 b_sh = before & 0xffffu, b_si = before >> 16;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const u32 members = (u32)(PER * tid + q) < nslots ? word_s[PER * tid + q] : 0u;
-        if (members == 2u) word_s[PER * tid + q] = b_sh++;
-        else if (members == 1u) word_s[PER * tid + q] = (b_si++) | 0x80000000u;
+        if (mw[q] == 2u) mw[q] = b_sh++;
+        else if (mw[q] == 1u) mw[q] = (b_si++) | 0x80000000u;
+    }
+    if (any_mine) {
+        uint4* dst = (uint4*)(word_s + PER * tid);
+#pragma unroll
+        for (int q4 = 0; q4 < PER / 4; ++q4) dst[q4] = make_uint4(mw[4 * q4], mw[4 * q4 + 1], mw[4 * q4 + 2], mw[4 * q4 + 3]);
     }
     if (tid == 0) nd_sh[bucket] = all & 0xffffu, nd_si[bucket] = all >> 16;
     __syncthreads();
+    SRD_STAMP(4);
     // ---- every item looks its class up again
     u32 my_listed = 0;
-    int c = 0;
-    u32 p_cur = (u32)tid < size ? locate((u32)tid) : 0u;
-    u64 k_cur = (u32)tid < size ? kx[p_cur] : 0ull;
-    for (u32 i = tid; i < size; i += 1024, ++c) {
-        const u32 p_nxt = i + 1024 < size ? locate(i + 1024) : 0u;
-        const u64 k_nxt = i + 1024 < size ? kx[p_nxt] : 0ull;
-        const u64 k1 = (k_cur & kmask) + 1ull;
-        const u32 p = p_cur;
-        k_cur = k_nxt, p_cur = p_nxt;
-        u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)nslots) >> 32);
-        while (key_s[h] != k1) h = h + 1u == nslots ? 0u : h + 1u;
-        const u32 v = word_s[h];
-        item_out[p] = (v & 0x80003fffu) | (bucket << 14);
+    // the first 4096 items (all of them, in a bucket of a balanced partition): the slot is known from the insert pass, no key
+    // reload, no probing
+#pragma unroll
+    for (u32 u = 0; u < 4u; ++u) {
+        if ((u32)tid + u * 1024u >= size) continue;
+        const u32 v = word_s[hh0[u]];
+        item_out[pp0[u]] = (v & 0x80003fffu) | (bucket << 14);
         if (!(v >> 31)) {
             ++my_listed;
-            if ((claimed >> c) & 1ull) rep2[(size_t)bucket * SRD_SLOTS + (v & 0x3fffu)] = (i32)vx[p];
+            if ((claimed >> u) & 1ull) rep2[(size_t)bucket * SRD_SLOTS + (v & 0x3fffu)] = (i32)vx[pp0[u]];
+        }
+    }
+    for (u32 i0 = tid + 4096u; i0 < size; i0 += 4096u) {
+        u32 pp[4];
+        u64 kk[4];
+#pragma unroll
+        for (u32 u = 0; u < 4u; ++u) pp[u] = i0 + u * 1024u < size ? locate(i0 + u * 1024u) : 0u;
+#pragma unroll
+        for (u32 u = 0; u < 4u; ++u) kk[u] = i0 + u * 1024u < size ? kx[pp[u]] : 0ull;
+#pragma unroll
+        for (u32 u = 0; u < 4u; ++u) {
+            if (i0 + u * 1024u >= size) continue;
+            const int c = (int)((i0 + u * 1024u) >> 10);
+            const u64 k1 = (kk[u] & kmask) + 1ull;
+            u32 h = (u32)((((k1 * 0x9E3779B97F4A7C15ull) >> 32) * (u64)nslots) >> 32);
+            while (key_s[h] != k1) h = h + 1u == nslots ? 0u : h + 1u;
+            const u32 v = word_s[h];
+            item_out[pp[u]] = (v & 0x80003fffu) | (bucket << 14);
+            if (!(v >> 31)) {
+                ++my_listed;
+                if ((claimed >> c) & 1ull) rep2[(size_t)bucket * SRD_SLOTS + (v & 0x3fffu)] = (i32)vx[pp[u]];
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) my_listed += __shfl_down(my_listed, off, 64);
@@ -478,6 +548,8 @@ __global__ __launch_bounds__(1024) void sr_dict_kernel(const u64* __restrict__ k
         for (int q = 0; q < 16; ++q) t += wsum[q];
         listed[bucket] = t;
     }
+    SRD_STAMP(5);
+#undef SRD_STAMP
 }
 
 // ---- item order: labels, verification, final ids of the nodes that just froze, the next level's active list ----------
@@ -613,6 +685,8 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
         b->sr_ctl = (u32*)q, b->sr_ctl_levels = n_levels;
     }
     u32* ctl = b->sr_ctl;
+    Tmp<u64> dbg(ctx);                                  // option wl.debug = 2: cycle stamps of sr_dict's phases
+    if (ctx->opt.wl_debug == 2) { GK_TRY(dbg.alloc((size_t)n_levels * 2048)); GK_TRY(gk_zero_async(ctx, dbg.p, (size_t)n_levels * 2048 * 8)); }
     const int nblk = (int)cdiv(V, SR_TILE);
     Tmp<u64> key(ctx), kx(ctx);
     Tmp<u32> vx(ctx), pos_of(ctx), item(ctx), hist(ctx), small(ctx), node_of(ctx), seg(ctx), wg_cnt(ctx);
@@ -662,7 +736,7 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
         const int shift = 8 * ((bits + 7) / 8 - 1);
         sr_part_kernel<<<dim3(nblk), 1024, 0, ctx->stream>>>(key.p, kx.p, vx.p, pos_of.p, V, shift, hist.p, nblk, cp, node_of.p);
         sr_dict_kernel<<<dim3(256), 1024, lds, ctx->stream>>>(kx.p, vx.p, hist.p, nblk, V, cp, shift, item.p, rep2.p, nd_sh, nd_si, listed,
-                                                              cc + SR_OVF, max_distinct);
+                                                              cc + SR_OVF, max_distinct, dbg.p ? dbg.p + (size_t)lvl * 2048 : nullptr);
         sr_finish_kernel<<<dim3((unsigned)n_fin), 1024, 0, ctx->stream>>>(pos_of.p, item.p, rep2.p, nd_sh, nd_si, listed, cc, cn, cp,
                                                                           b->labels, V, lvl, n_levels, verify, b->row_ptr, b->nbr_sorted,
                                                                           node_of.p, seg.p, wg_cnt.p);
@@ -677,6 +751,24 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
                         h[(size_t)lvl * SR_CTL + SR_UNRES], h[(size_t)lvl * SR_CTL + SR_OVF]);
             return GK_ERR_UNSUPPORTED;
         }
+    if (dbg.p) {
+        std::vector<u64> hd((size_t)n_levels * 2048);
+        GK_HIP_CHECK(hipMemcpyAsync(hd.data(), dbg.p, hd.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int lvl = 1; lvl < n_levels; ++lvl) {
+            double ph[5] = {0, 0, 0, 0, 0}, mx = 0;
+            int nb = 0;
+            for (int wg = 0; wg < 256; ++wg) {
+                const u64* d = hd.data() + (size_t)lvl * 2048 + wg * 8;
+                if (!d[5]) continue;
+                ++nb;
+                for (int k = 0; k < 5; ++k) ph[k] += (double)(d[k + 1] - d[k]);
+                mx = std::max(mx, (double)(d[5] - d[0]));
+            }
+            if (nb) fprintf(stderr, "[gk] sr_dict level %d cycles (avg of %d buckets): runs %.0f clear %.0f insert %.0f rank %.0f lookup %.0f | slowest bucket %.0f\n",
+                            lvl, nb, ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[3] / nb, ph[4] / nb, mx);
+        }
+    }
     // ---- what the consumers on the host need
     b->stream_layout = true;
     b->level0_hist = true;
