@@ -1631,6 +1631,13 @@ int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level) {
     return GK_OK;
 }
 
+// 1: the last gk_wl_relabel of the batch ran without host round trips and left the stream id layout (wl_stream.hip), 0: host-driven route
+extern "C" int gk_wl_route(gk_batch* b, int* out_stream) {
+    GK_ARG(b && out_stream, "gk_wl_route: null argument");
+    *out_stream = b->stream_layout ? 1 : 0;
+    return GK_OK;
+}
+
 extern "C" int gk_wl_get_labels(gk_ctx* ctx, gk_batch* b, int level, int32_t* out_labels) {
     GK_ARG(ctx && b && out_labels, "gk_wl_get_labels: null argument");
     GK_ARG(level >= 0 && level < (b->n_levels > 0 ? b->n_levels : 1), "gk_wl_get_labels: level not computed");

@@ -342,6 +342,9 @@ class Engine(object):
                                      byref(rounds)))
         db.label_counts = [int(c) for c in counts]
         db.refine_rounds = rounds.value
+        route = c_int(0)
+        check(self.lib.gk_wl_route(db.handle, byref(route)))
+        db.stream_route = bool(route.value)           # relabelled without host round trips (csrc/wl_stream.hip)
         return db.label_counts
 
     def wl_labels(self, db, level):

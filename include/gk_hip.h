@@ -156,6 +156,11 @@ int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits,
                   int64_t* out_label_counts, int* out_rounds);
 /* Level labels back to the host (parity tests: partition equality with the oracle). */
 int gk_wl_get_labels(gk_ctx* ctx, gk_batch* b, int level, int32_t* out_labels);
+/* Which route the batch's last gk_wl_relabel took: *out_stream = 1 the route without host round trips (csrc/wl_stream.hip;
+ * graph batches of small graphs with at most 256 input labels), 0 the host-driven route (everything else, option
+ * "wl.no_stream", and the redo after a hash collision or a table overflow).  Same partitions, same matrices either way;
+ * the label ids differ (both dense).  The reference has no counterpart. */
+int gk_wl_route(gk_batch* b, int* out_stream);
 /* Kernel-level test hooks: the raw 64-bit signature hash and the sorted neighbour-label
  * lists of level `level` (computed from level-1 labels), before dictionary assignment. */
 int gk_wl_debug_signature(gk_ctx* ctx, gk_batch* b, int level, uint64_t seed,

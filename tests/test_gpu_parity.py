@@ -272,6 +272,51 @@ def test_every_relabel_path_gives_the_reference_partition(gk, route, gkopt):
     assert np.array_equal(oa.fit_transform(X[:120]), _route_cache["oa"])
 
 
+def _few_labels_many_isolated(seed):
+    rs = np.random.RandomState(seed)
+    X = []
+    for g in range(70):
+        m = int(rs.randint(4, 12))
+        ed = {i: [] for i in range(m)}
+        for i in range(1, m):
+            j = int(rs.randint(0, i))
+            ed[i].append(j), ed[j].append(i)
+        lab = {i: int(rs.randint(0, 3)) for i in range(m)}
+        for q in range(int(rs.randint(10, 30))):       # isolated vertices, three labels (one of them rare)
+            ed[m + q] = []
+            lab[m + q] = 2 if rs.rand() < 0.02 else int(rs.randint(0, 2))
+        X.append([ed, lab])
+    return X
+
+
+@pytest.mark.parametrize("case", ["er", "sparse", "hashed1", "isolated", "deep"])
+def test_stream_relabel_route_against_the_oracle(gk, gkopt, case):
+    """The relabel route without host round trips (csrc/wl_stream.hip): it is the one that runs for these jobs, its
+    label ids are dense per level, partitions / label counts / K are the oracle's (levels that walk all nodes and levels
+    that walk the active list, exact level-1 codes and hashed level 1, isolated vertices carried from level 1 on, a
+    hierarchy deeper than the refinement), and a table overflow hands the job to the host-driven route."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    X, h = {"er": (er_dataset(300, 100, 0.05, 5, 3), 5), "sparse": (er_dataset(500, 40, 0.07, 3, 17), 7),
+            "hashed1": (er_dataset(200, 30, 0.1, 17, 5), 4), "isolated": (_few_labels_many_isolated(7), 5),
+            "deep": (er_dataset(40, 12, 0.3, 2, 9), 20)}[case]
+    wl, K, levels = _oracle_levels(X, h)
+    gb, _ = wl_batch_from_input(X)
+    eng = get_engine()
+    db = eng.upload(gb)
+    assert eng.wl_relabel(db, h) == wl.label_counts and db.stream_route
+    for lvl in range(h + 1):
+        lab = eng.wl_labels(db, lvl)
+        assert same_partition(lab, levels[lvl]), "level %d" % lvl
+        if lvl:
+            assert np.array_equal(np.unique(lab), np.arange(wl.label_counts[lvl])), "ids of level %d are not dense" % lvl
+    assert np.array_equal(eng.gram(eng.features(db, h + 1)), K)
+    gkopt("wl.bd_slots", 1)                     # every bucket overflows: the job is relabelled by the host-driven route
+    db2 = eng.upload(gb)
+    assert eng.wl_relabel(db2, h) == wl.label_counts and not db2.stream_route
+    assert np.array_equal(eng.gram(eng.features(db2, h + 1)), K)
+
+
 @pytest.mark.parametrize("slots", [1, 8, 40])
 def test_bucket_dictionary_overflow_takes_the_sorting_path(gk, gkopt, slots):
     """A bucket of the sort-free dictionary that holds more distinct keys than its table (forced here by shrinking
