@@ -51,6 +51,10 @@ SIGNATURES = {
     "gk_wl_relabel": (c_int, [c_void_p, c_void_p, c_int, c_int, _i64p, POINTER(c_int)]),
     "gk_wl_get_labels": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gk_wl_route": (c_int, [c_void_p, c_void_p]),
+    "gk_wl_fitted_create": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "gk_wl_fitted_destroy": (c_int, [c_void_p]),
+    "gk_wl_fitted_selfk": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gk_wl_transform": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gk_wl_debug_signature": (c_int, [c_void_p, c_void_p, c_int, c_uint64, c_void_p, c_void_p]),
     "gk_features_build": (c_int, [c_void_p, c_void_p, c_int, c_int64, _vpp]),
     "gk_features_build_ex": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, _vpp]),

@@ -236,6 +236,7 @@ struct gk_batch {
     //   [carried classes 0 .. n_cc) | frozen nodes [n_cc, n_cc + F_l) | shared classes [.., + S_l) | new singletons [.., + T_l)
     // a label can be shared iff id < n_cc or n_cc + F_l <= id < n_cc + F_l + S_l; F_l / S_l / T_l live on the device
     // (sr_ctl, SR_CTL words per level) so that the feature builder can be queued without the host knowing them
+    u64 relabel_gen = 0;               // bumped by every gk_wl_relabel: label ids of an earlier call are gone (wl_transform.hip)
     bool stream_layout = false;
     u32* sr_ctl = nullptr;             // [cap of sr_ctl_levels][SR_CTL]
     int sr_ctl_levels = 0;

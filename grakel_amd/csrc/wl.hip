@@ -1540,6 +1540,7 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         if (hash_bits > 64) hash_bits = 64;
     }
     GK_HIP_CHECK(hipSetDevice(ctx->device));
+    ++b->relabel_gen;
     ProfScope prof(ctx, "relabel");
     const int n_levels = n_iter + 1;
     const i64 V = b->n_nodes;

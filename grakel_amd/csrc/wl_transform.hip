@@ -1,0 +1,427 @@
+// WeisfeilerLehman.transform as a LOOK-UP against the fitted dictionaries (reference: grakel/kernels/weisfeiler_lehman.py:
+// 435-476 relabels only the targets and looks their credentials up in the fitted `_inv_labels[i]`, :493-498 sums the base
+// kernels' rectangular matrices; vertex_histogram.py:138-184 counts the targets' labels in the fitted columns).
+//
+// The joint route (gk_batch_concat + relabel of fitted graphs and targets together) costs O(fitted nodes) per call.  Here a fit
+// leaves on the device, per level l >= 1:
+//   * a table  hash of the full signature (own fitted label at l-1, multiset of the neighbours' fitted labels)  ->  fitted class,
+//     one entry per fitted class, computed from one representative node of the class (open addressing, 64-bit keys);
+//   * the inverted index  fitted class -> (graph, count) entries  (nodes stably sorted by class: a class's nodes then come
+//     graph after graph), also for level 0; the fitted self similarities.
+// A transform relabels the TARGETS ALONE (any route: that fixes their own partition exactly, hash collisions included), then
+// level by level matches every target class to a fitted class or to none: a class is matched iff the class of its
+// representative at the level before and those of all its neighbours are matched and the signature written in FITTED ids is in
+// the table -- verified against the fitted representative's full signature, the hash only proposes.  K[t, f] = sum over levels
+// and matched classes of count_t * count_f is then accumulated per target graph in LDS by walking the index lists: work
+// proportional to the targets, not to the fit.  Everything is exact integer arithmetic.
+// Declines (GK_ERR_UNSUPPORTED; the caller takes the joint route): two fitted classes with one 64-bit hash, a node of more than
+// TF_MAXDEG neighbours among the representatives, a target graph above GM_MAX_NODES nodes.
+#include "common.h"
+#include "features.h"
+#include "scan_fn.h"
+#include "wl_sig.h"
+#include <memory>
+#include <vector>
+
+#define TF_MAXDEG 64
+#define TA_COLS 32768            // fitted graphs per accumulator block (u32 in LDS)
+#define TA_SLOTS 2048            // label-count table of one target graph (n <= GM_MAX_NODES)
+
+static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
+
+struct gk_wl_fitted {
+    gk_ctx* ctx = nullptr;
+    gk_batch* fit = nullptr;
+    u64 fit_gen = 0;
+    int n_levels = 0;
+    i64 N = 0, V = 0;
+    i32 L0 = 0;
+    std::vector<u64*> table;      // [level] hash (0 = empty)
+    std::vector<i32*> tval;       // [level] class of the slot
+    std::vector<u64> mask;        // [level] capacity - 1
+    std::vector<i32*> rep;        // [level] one node per class
+    std::vector<i32*> cls_ptr;    // [level] first entry of each class (+ end)
+    std::vector<i32*> ent_graph;  // [level] entries: graph (build only)
+    std::vector<i32*> ent_pos;    // [level] entries: start in the class-sorted node order (count = next start - start; build only)
+    std::vector<uint2*> ent;      // [level] entries as the accumulation reads them: (graph, count)
+    std::vector<i64> count;       // classes per level
+    u64* selfk = nullptr;         // [N] fitted self similarities
+    u32* flags = nullptr;         // bit 0: two fitted classes share a hash, bit 1: degree above TF_MAXDEG
+};
+
+static inline u64 tf_seed(int level) { return 0x6a09e667f3bcc908ULL + (u64)level * 0x9E3779B97F4A7C15ULL; }
+
+// one representative per class (any writer wins)
+__global__ void tf_rep_kernel(const i32* __restrict__ lab, i32* __restrict__ rep, i64 V) {
+    const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V) rep[lab[v]] = (i32)v;
+}
+
+// fitted class c -> table: hash of its representative's signature in the labels of the level before
+__global__ void tf_insert_kernel(const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+                                 const i32* __restrict__ rep, i64 count, u64* __restrict__ table, i32* __restrict__ tval, u64 mask,
+                                 u64 seed, u32* __restrict__ flags) {
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    const i32 r = rep[c];
+    const i32 s = row_ptr[r];
+    const int d = row_ptr[r + 1] - s;
+    if (d > TF_MAXDEG) { atomicOr(flags, 2u); return; }
+    u64 acc = sig_head((u32)lab_prev[r], (u32)d, seed);
+    for (int k = 0; k < d; ++k) acc += sig_elem((u32)lab_prev[col_idx[s + k]], seed);
+    u64 h = mix64(acc);
+    if (h == 0) h = 1;
+    u64 slot = h & mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&table[slot], 0ull, (unsigned long long)h);
+        if (old == 0ull) { tval[slot] = (i32)c; return; }
+        if (old == h) { atomicOr(flags, 1u); return; }       // two classes, one hash: the look-up cannot tell them apart
+        slot = (slot + 1) & mask;
+    }
+}
+
+// inverted index of one level: nodes sorted by class (stable: ascending node = ascending graph inside a class); an entry
+// starts where the class or the graph changes
+struct TfIndex {
+    const u64* ks; const u32* perm; const i32* node_graph;
+    i32* ent_graph; i32* ent_pos; u32* cls_cnt; u32* n_ent; i64 V;
+    __device__ __forceinline__ bool chead(i64 k) const { return k == 0 || ks[k] != ks[k - 1]; }
+    __device__ __forceinline__ u32 value(i64 k) const {
+        return (chead(k) || node_graph[perm[k]] != node_graph[perm[k - 1]]) ? 1u : 0u;
+    }
+    __device__ __forceinline__ void emit(i64 k, u32 head, u32 incl) const {
+        if (!head) return;
+        const u32 e = incl - 1u;
+        ent_graph[e] = node_graph[perm[k]];
+        ent_pos[e] = (i32)k;
+        atomicAdd(&cls_cnt[ks[k]], 1u);
+    }
+    __device__ __forceinline__ void finish(u32 total) const { *n_ent = total; ent_pos[total] = (i32)V; }
+    __device__ __forceinline__ i64 seg_first_tile(i64) const { return 0; }
+};
+
+__global__ void tf_labels_to_keys_kernel(const i32* __restrict__ lab, u64* __restrict__ keys, i64 n) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (u64)(u32)lab[i];
+}
+
+// fitted self similarity: sum over levels and entries of count^2
+__global__ void tf_selfk_kernel(const i32* __restrict__ ent_graph, const i32* __restrict__ ent_pos, const u32* __restrict__ n_ent,
+                                unsigned long long* __restrict__ selfk, uint2* __restrict__ ent) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (i64)*n_ent) return;
+    const u64 c = (u64)(ent_pos[e + 1] - ent_pos[e]);
+    ent[e] = make_uint2((u32)ent_graph[e], (u32)c);
+    atomicAdd(&selfk[ent_graph[e]], c * c);
+}
+
+extern "C" int gk_wl_fitted_destroy(gk_wl_fitted* w) {
+    if (!w) return GK_OK;
+    gk_ctx* ctx = w->ctx;
+    auto rel = [&](void* p) { if (p) gk_dev_free(ctx, p); };
+    for (auto p : w->table) rel(p);
+    for (auto p : w->tval) rel(p);
+    for (auto p : w->rep) rel(p);
+    for (auto p : w->cls_ptr) rel(p);
+    for (auto p : w->ent_graph) rel(p);
+    for (auto p : w->ent_pos) rel(p);
+    for (auto p : w->ent) rel(p);
+    rel(w->selfk);
+    rel(w->flags);
+    delete w;
+    return GK_OK;
+}
+
+extern "C" int gk_wl_fitted_create(gk_ctx* ctx, gk_batch* fit, int n_iter, gk_wl_fitted** out) {
+    GK_ARG(ctx && fit && out, "gk_wl_fitted_create: null argument");
+    GK_ARG(!fit->is_pair_batch && fit->ctx == ctx, "gk_wl_fitted_create: needs a graph batch of this context");
+    GK_ARG(n_iter >= 0 && fit->n_levels == n_iter + 1, "gk_wl_fitted_create: the batch is not relabelled for n_iter levels (gk_wl_relabel first)");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    const i64 V = fit->n_nodes, N = fit->n_graphs;
+    const int L = n_iter + 1;
+    if (V <= 0) return GK_ERR_UNSUPPORTED;
+    gk_wl_fitted* w = new gk_wl_fitted();
+    w->ctx = ctx, w->fit = fit, w->fit_gen = fit->relabel_gen, w->n_levels = L, w->N = N, w->V = V, w->L0 = fit->n_labels0;
+    w->table.assign(L, nullptr), w->tval.assign(L, nullptr), w->mask.assign(L, 0), w->rep.assign(L, nullptr);
+    w->cls_ptr.assign(L, nullptr), w->ent_graph.assign(L, nullptr), w->ent_pos.assign(L, nullptr), w->count.assign(L, 0);
+    w->ent.assign(L, nullptr);
+    auto fail = [&](int r) { gk_wl_fitted_destroy(w); return r; };
+    int r;
+    void* q = nullptr;
+#define W_ALLOC(dst, type, n) do { if ((r = gk_dev_alloc(ctx, &q, (size_t)(n) * sizeof(type)))) return fail(r); dst = (type*)q; } while (0)
+    W_ALLOC(w->selfk, u64, N);
+    W_ALLOC(w->flags, u32, 4);
+    if ((r = gk_zero_async(ctx, w->selfk, (size_t)N * 8)) || (r = gk_zero_async(ctx, w->flags, 16))) return fail(r);
+    Tmp<u64> keys(ctx), ks(ctx);
+    Tmp<u32> perm(ctx);
+    if ((r = keys.alloc(V)) || (r = ks.alloc(V)) || (r = perm.alloc(V))) return fail(r);
+    for (int l = 0; l < L; ++l) {
+        Tmp<u32> cls_cnt(ctx);
+        const i64 count = l == 0 ? (i64)fit->n_labels0 : fit->label_counts[l];
+        w->count[l] = count;
+        const i32* lab = fit->labels + (size_t)l * V;
+        // ---- inverted index
+        W_ALLOC(w->cls_ptr[l], i32, count + 1);
+        W_ALLOC(w->ent_graph[l], i32, V + 1);
+        W_ALLOC(w->ent_pos[l], i32, V + 2);
+        W_ALLOC(w->ent[l], uint2, V + 1);
+        if ((r = cls_cnt.alloc((size_t)count + 2)) || (r = gk_zero_async(ctx, cls_cnt.p, ((size_t)count + 2) * 4))) return fail(r);
+        tf_labels_to_keys_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(lab, keys.p, V);
+        int bits = 1;
+        while (bits < 64 && ((u64)(count > 0 ? count - 1 : 0) >> bits)) ++bits;
+        if ((r = gk_radix_sort_pairs(ctx, keys.p, nullptr, ks.p, perm.p, V, bits))) return fail(r);
+        TfIndex ti{ks.p, perm.p, fit->node_graph, w->ent_graph[l], w->ent_pos[l], cls_cnt.p, cls_cnt.p + count + 1, V};
+        if ((r = gk_scan_fn<u32, TfIndex>(ctx, ti, V, nullptr))) return fail(r);
+        if ((r = gk_scan_u32(ctx, cls_cnt.p, (u32*)w->cls_ptr[l], count + 1, true, nullptr))) return fail(r);     // entry count + 1 slots: [count] = all entries
+        tf_selfk_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(w->ent_graph[l], w->ent_pos[l], cls_cnt.p + count + 1,
+                                                                    (unsigned long long*)w->selfk, w->ent[l]);
+        // the two build arrays are done with (stream order): only the packed entries stay
+        gk_dev_free(ctx, w->ent_graph[l]), gk_dev_free(ctx, w->ent_pos[l]);
+        w->ent_graph[l] = nullptr, w->ent_pos[l] = nullptr;
+        if (l == 0) continue;
+        // ---- signature table
+        u64 cap = 64;
+        while (cap < 2 * (u64)count) cap <<= 1;
+        w->mask[l] = cap - 1;
+        W_ALLOC(w->table[l], u64, cap);
+        W_ALLOC(w->tval[l], i32, cap);
+        W_ALLOC(w->rep[l], i32, count);
+        if ((r = gk_zero_async(ctx, w->table[l], (size_t)cap * 8))) return fail(r);
+        tf_rep_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(lab, w->rep[l], V);
+        tf_insert_kernel<<<grid_for(count, 256), 256, 0, ctx->stream>>>(fit->row_ptr, fit->col_idx, fit->labels + (size_t)(l - 1) * V, w->rep[l], count,
+                                                                         w->table[l], w->tval[l], w->mask[l], tf_seed(l),
+                                                                         w->flags);
+    }
+#undef W_ALLOC
+    if (hipGetLastError() != hipSuccess) { gk_set_error("gk_wl_fitted_create: kernel launch failed"); return fail(GK_ERR_HIP); }
+    u32 hf[4] = {0, 0, 0, 0};
+    if ((r = gk_readback(ctx, w->flags, hf, 4))) return fail(r);
+    if (hf[0]) {
+        gk_set_error("gk_wl_fitted_create: %s -- transform takes the joint route", (hf[0] & 1u) ? "two fitted classes share a 64-bit signature hash"
+                                                                                              : "a class representative has more than 64 neighbours");
+        return fail(GK_ERR_UNSUPPORTED);
+    }
+    *out = w;
+    return GK_OK;
+}
+
+// ---- transform ----------------------------------------------------------------------------------------------------------
+// target class k of a level >= 1 -> fitted class or -1.  xlat of the level before: level 0 is the identity below L0 (the
+// targets' input labels are ids of the fit's label map, unseen ones above it), later levels go through map_prev
+__global__ void tt_match_kernel(const i32* __restrict__ t_row_ptr, const i32* __restrict__ t_col_idx, const i32* __restrict__ t_lab_prev,
+                                const i32* __restrict__ t_rep, i64 t_count, const i32* __restrict__ map_prev, i32 L0, int prev_is_level0,
+                                const u64* __restrict__ table, const i32* __restrict__ tval, u64 mask, u64 seed,
+                                const i32* __restrict__ f_row_ptr, const i32* __restrict__ f_col_idx, const i32* __restrict__ f_lab_prev,
+                                const i32* __restrict__ f_rep, i32* __restrict__ map_cur, u32* __restrict__ flags) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= t_count) return;
+    auto xlat = [&](i32 x) __attribute__((always_inline)) { return prev_is_level0 ? (x < L0 ? x : -1) : map_prev[x]; };
+    const i32 r = t_rep[k];
+    const i32 s = t_row_ptr[r];
+    const int d = t_row_ptr[r + 1] - s;
+    i32 res = -1;
+    const i32 own = xlat(t_lab_prev[r]);
+    if (d > TF_MAXDEG) { atomicOr(flags, 2u); map_cur[k] = -1; return; }
+    i32 x[TF_MAXDEG];
+    bool all = own >= 0;
+    u64 acc = sig_head((u32)own, (u32)d, seed);
+    for (int i = 0; i < d && all; ++i) {
+        const i32 y = xlat(t_lab_prev[t_col_idx[s + i]]);
+        x[i] = y;
+        all = y >= 0;
+        acc += sig_elem((u32)y, seed);
+    }
+    if (all) {
+        u64 h = mix64(acc);
+        if (h == 0) h = 1;
+        u64 slot = h & mask;
+        for (;;) {
+            const u64 t = table[slot];
+            if (t == 0) break;
+            if (t == h) {
+                // the hash proposes, the full signature of the fitted representative decides
+                const i32 c = tval[slot];
+                const i32 rf = f_rep[c];
+                const i32 sf = f_row_ptr[rf];
+                bool ok = f_lab_prev[rf] == own && f_row_ptr[rf + 1] - sf == d;
+                if (ok) {
+                    i32 y[TF_MAXDEG];
+                    for (int i = 0; i < d; ++i) y[i] = f_lab_prev[f_col_idx[sf + i]];
+                    insertion_sort(x, d);
+                    insertion_sort(y, d);
+                    for (int i = 0; i < d; ++i)
+                        if (x[i] != y[i]) { ok = false; break; }
+                }
+                if (ok) res = c;
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+    }
+    map_cur[k] = res;
+}
+
+struct TaLevels {
+    const i32* t_lab[FEAT_MAX_LEVELS];       // target labels of the level
+    const i32* map[FEAT_MAX_LEVELS];         // target class -> fitted class (null: level 0, identity below L0)
+    const i32* cls_ptr[FEAT_MAX_LEVELS];
+    const uint2* ent[FEAT_MAX_LEVELS];       // fitted (graph, count) entries, grouped by class
+    int L;
+};
+
+// one workgroup per target graph: per level the graph's label counts (LDS table), then for every label that has a fitted class the
+// fitted (graph, count) entries of that class: acc[f] += count_t * count_f (LDS atomics), a wave per label, lanes over its entries
+__global__ __launch_bounds__(1024) void tt_accumulate_kernel(const TaLevels P, const i32* __restrict__ t_graph_ptr, i32 L0, i64 n_fit,
+                                                             const u64* __restrict__ x_selfk, int normalize, double* __restrict__ K,
+                                                             u64* __restrict__ y_selfk) {
+    extern __shared__ __attribute__((aligned(16))) u32 ta_lds[];
+    u32* acc = ta_lds;                                   // [TA_COLS]
+    i32* keys = (i32*)(ta_lds + TA_COLS);                // [TA_SLOTS]
+    u32* cnt = (u32*)(keys + TA_SLOTS);                  // [TA_SLOTS]
+    i32* item_c = (i32*)(cnt + TA_SLOTS);                // [GM_MAX_NODES] work list: fitted class
+    u32* item_n = (u32*)(item_c + GM_MAX_NODES);         // [GM_MAX_NODES]            count in the target
+    __shared__ u32 n_items;
+    __shared__ unsigned long long self_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const i64 t = blockIdx.x;
+    const i32 v0 = t_graph_ptr[t];
+    const int n = t_graph_ptr[t + 1] - v0;
+    u32 T = 64;
+    while (T < 2u * (u32)n) T <<= 1;
+    const u32 tmask = T - 1u;
+    if (tid == 0) self_s = 0ull;
+    for (i64 cb = 0; cb < n_fit; cb += TA_COLS) {
+        const i64 ce = cb + TA_COLS < n_fit ? cb + TA_COLS : n_fit;
+        for (int i = tid; i < (int)(ce - cb); i += 1024) acc[i] = 0u;
+        for (int l = 0; l < P.L; ++l) {
+            __syncthreads();                              // the level before is done with the tables
+            for (u32 i = tid; i < T; i += 1024) keys[i] = -1, cnt[i] = 0u;
+            if (tid == 0) n_items = 0u;
+            __syncthreads();
+            const i32* __restrict__ lab = P.t_lab[l];
+            for (int i = tid; i < n; i += 1024) {
+                const i32 x = lab[v0 + i];
+                u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+                for (;;) {
+                    const i32 old = atomicCAS(&keys[h], -1, x);
+                    if (old == -1 || old == x) { atomicAdd(&cnt[h], 1u); break; }
+                    h = (h + 1u) & tmask;
+                }
+            }
+            __syncthreads();
+            unsigned long long sq = 0ull;
+            for (u32 i = tid; i < T; i += 1024) {
+                const i32 x = keys[i];
+                if (x < 0) continue;
+                const u32 c = cnt[i];
+                sq += (unsigned long long)c * c;
+                const i32 fc = P.map[l] ? P.map[l][x] : (x < L0 ? x : -1);
+                if (fc >= 0) {
+                    const u32 e = atomicAdd(&n_items, 1u);
+                    item_c[e] = fc, item_n[e] = c;
+                }
+            }
+            if (cb == 0 && sq) atomicAdd(&self_s, sq);
+            __syncthreads();
+            const u32 ni = n_items;
+            const i32* __restrict__ cp = P.cls_ptr[l];
+            const uint2* __restrict__ en = P.ent[l];
+            for (u32 it = w; it < ni; it += 16) {
+                const i32 fc = item_c[it];
+                const u32 ct = item_n[it];
+                const i32 lo = cp[fc], hi = cp[fc + 1];
+                // four entries per lane in flight (one dependent load per trip made the walk a chain of memory latencies)
+                for (i32 e0 = lo + lane; e0 < hi; e0 += 256) {
+                    uint2 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = e0 + 64 * u < hi ? en[e0 + 64 * u] : make_uint2(0xffffffffu, 0u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const i64 f = (i64)x[u].x;
+                        if (x[u].x != 0xffffffffu && f >= cb && f < ce) atomicAdd(&acc[f - cb], ct * x[u].y);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const double ys = (double)self_s;
+        for (i64 f = cb + tid; f < ce; f += 1024) {
+            double v = (double)acc[f - cb];
+            if (normalize) {
+                const double den = sqrt(ys * (double)x_selfk[f]);
+                v = v / den;
+                if (normalize == 2) {                     // numpy.nan_to_num: nan -> 0, +inf -> the largest double
+                    if (v != v) v = 0.0;
+                    else if (v > 1.7976931348623157e308) v = 1.7976931348623157e308;
+                }
+            }
+            K[t * n_fit + f] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) y_selfk[t] = self_s;
+}
+
+extern "C" int gk_wl_fitted_selfk(gk_ctx* ctx, gk_wl_fitted* w, double* out_selfk) {
+    GK_ARG(ctx && w && out_selfk, "gk_wl_fitted_selfk: null argument");
+    std::vector<u64> h((size_t)w->N);
+    GK_HIP_CHECK(hipMemcpyAsync(h.data(), w->selfk, (size_t)w->N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (i64 i = 0; i < w->N; ++i) out_selfk[i] = (double)h[i];
+    return GK_OK;
+}
+
+// targets: relabelled ALONE (gk_wl_relabel with the fit's n_iter), level-0 ids in the fit's id space (unseen input labels >= the
+// fit's n_labels0).  out_K: host, [n_targets x n_fitted] float64; out_y_selfk: host, [n_targets].
+extern "C" int gk_wl_transform(gk_ctx* ctx, gk_wl_fitted* w, gk_batch* tb, int normalize, double* out_K, double* out_y_selfk) {
+    GK_ARG(ctx && w && tb && out_K && out_y_selfk, "gk_wl_transform: null argument");
+    GK_ARG(!tb->is_pair_batch && tb->ctx == ctx && w->ctx == ctx, "gk_wl_transform: needs graph batches of this context");
+    GK_ARG(tb->n_levels == w->n_levels, "gk_wl_transform: the targets are not relabelled for the fit's n_iter (gk_wl_relabel first)");
+    if (w->fit_gen != w->fit->relabel_gen) {
+        gk_set_error("gk_wl_transform: the fitted batch was relabelled again: its label ids are not the ones of this fitted state");
+        return GK_ERR_STATE;
+    }
+    if (tb->max_graph_nodes > GM_MAX_NODES || w->n_levels > FEAT_MAX_LEVELS) return GK_ERR_UNSUPPORTED;
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    ProfScope prof(ctx, "transform");
+    const i64 Vt = tb->n_nodes, Nt = tb->n_graphs, Nf = w->N;
+    const int L = w->n_levels;
+    gk_batch* fb = w->fit;
+    Tmp<u32> flags(ctx);
+    GK_TRY(flags.alloc(4));
+    GK_TRY(gk_zero_async(ctx, flags.p, 16));
+    std::vector<std::unique_ptr<Tmp<i32>>> maps((size_t)L), reps((size_t)L);
+    TaLevels P = {};
+    P.L = L;
+    for (int l = 0; l < L; ++l) {
+        P.t_lab[l] = tb->labels + (size_t)l * Vt;
+        P.cls_ptr[l] = w->cls_ptr[l], P.ent[l] = w->ent[l];
+        P.map[l] = nullptr;
+        if (l == 0 || Vt == 0) continue;
+        const i64 tc = tb->label_counts[l];
+        maps[l].reset(new Tmp<i32>(ctx)), reps[l].reset(new Tmp<i32>(ctx));
+        GK_TRY(maps[l]->alloc(tc)); GK_TRY(reps[l]->alloc(tc));
+        tf_rep_kernel<<<grid_for(Vt, 256), 256, 0, ctx->stream>>>(P.t_lab[l], reps[l]->p, Vt);
+        tt_match_kernel<<<grid_for(tc, 128), 128, 0, ctx->stream>>>(
+            tb->row_ptr, tb->col_idx, P.t_lab[l - 1], reps[l]->p, tc, l >= 2 ? maps[l - 1]->p : nullptr, w->L0, l == 1 ? 1 : 0,
+            w->table[l], w->tval[l], w->mask[l], tf_seed(l), fb->row_ptr, fb->col_idx,
+            fb->labels + (size_t)(l - 1) * fb->n_nodes, w->rep[l], maps[l]->p, flags.p);
+        P.map[l] = maps[l]->p;
+    }
+    Tmp<double> K(ctx);
+    Tmp<u64> ys(ctx);
+    GK_TRY(K.alloc((size_t)Nt * (size_t)Nf)); GK_TRY(ys.alloc(Nt));
+    const int lds = (TA_COLS + 2 * TA_SLOTS + 2 * GM_MAX_NODES) * 4;
+    GK_TRY(gk_func_lds(ctx, (const void*)tt_accumulate_kernel, lds));
+    tt_accumulate_kernel<<<dim3((unsigned)Nt), 1024, lds, ctx->stream>>>(P, tb->graph_ptr, w->L0, Nf, w->selfk, normalize, K.p, ys.p);
+    GK_HIP_CHECK(hipGetLastError());
+    u32 hf[4] = {0, 0, 0, 0};
+    GK_HIP_CHECK(hipMemcpyAsync(hf, flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipMemcpyAsync(out_K, K.p, (size_t)Nt * (size_t)Nf * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<u64> hy((size_t)Nt);
+    GK_HIP_CHECK(hipMemcpyAsync(hy.data(), ys.p, (size_t)Nt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (hf[0]) return GK_ERR_UNSUPPORTED;                  // a target representative above TF_MAXDEG neighbours
+    for (i64 i = 0; i < Nt; ++i) out_y_selfk[i] = (double)hy[i];
+    return GK_OK;
+}

@@ -156,6 +156,24 @@ class DeviceBatch(object):
             pass
 
 
+class FittedWL(object):
+    """Fitted WL dictionaries on the device (csrc/wl_transform.hip): what ``transform`` looks target signatures up in."""
+
+    def __init__(self, engine, handle, batch):
+        self.engine, self.handle, self.batch = engine, handle, batch
+
+    def close(self):
+        if self.handle is not None and self.engine.handle is not None:
+            self.engine.lib.gk_wl_fitted_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceFeatures(object):
     def __init__(self, engine, handle, batch, n_fit):
         self.engine, self.handle, self.batch, self.n_fit = engine, handle, batch, n_fit
@@ -346,6 +364,35 @@ class Engine(object):
         check(self.lib.gk_wl_route(db.handle, byref(route)))
         db.stream_route = bool(route.value)           # relabelled without host round trips (csrc/wl_stream.hip)
         return db.label_counts
+
+    GK_ERR_STATE, GK_ERR_UNSUPPORTED = -3, -4
+
+    def wl_fitted(self, db, n_iter):
+        """Fitted dictionaries of a batch relabelled with ``n_iter`` (``gk_wl_fitted_create``); None when the job needs the
+        joint transform route (GK_ERR_UNSUPPORTED)."""
+        h = c_void_p()
+        rc = self.lib.gk_wl_fitted_create(self.handle, db.handle, int(n_iter), byref(h))
+        if rc == self.GK_ERR_UNSUPPORTED:
+            return None
+        check(rc)
+        return FittedWL(self, h, db)
+
+    def wl_fitted_selfk(self, wf):
+        out = np.empty(wf.batch.n_graphs, dtype=np.float64)
+        check(self.lib.gk_wl_fitted_selfk(self.handle, wf.handle, _ptr(out)))
+        return out
+
+    def wl_transform(self, wf, tb, normalize=0):
+        """(K [n_targets x n_fitted], target diagonal) by look-up; "stale": rebuild the fitted state; None: unsupported job."""
+        K = self.pinned.empty((tb.n_graphs, wf.batch.n_graphs))       # pinned when large: the copy runs at the PCIe rate
+        yd = np.empty(tb.n_graphs, dtype=np.float64)
+        rc = self.lib.gk_wl_transform(self.handle, wf.handle, tb.handle, int(normalize), _ptr(K), _ptr(yd))
+        if rc == self.GK_ERR_STATE:
+            return "stale"                       # the fitted batch was relabelled since the state was built
+        if rc == self.GK_ERR_UNSUPPORTED:
+            return None
+        check(rc)
+        return K, yd
 
     def wl_labels(self, db, level):
         out = np.empty(db.n_nodes, dtype=np.int32)

@@ -19,7 +19,7 @@ from .engine import get_engine
 # normalisation modes of gk_gram (include/gk_hip.h)
 NORM_NONE, NORM_PLAIN, NORM_NAN_TO_NUM = 0, 1, 2
 
-_DEVICE_ATTRS = ("_dev_fit", "_dev_last")
+_DEVICE_ATTRS = ("_dev_fit", "_dev_last", "_dev_wlfit")
 
 
 class Kernel(BaseEstimator, TransformerMixin):

@@ -256,6 +256,7 @@ class WeisfeilerLehman(Kernel):
 
     def _after_fit(self):
         self.__dict__.pop("_reference_labels", None)
+        self.__dict__.pop("_lookup_declined", None)
         lvl0 = dict(self._label_map) if self._label_map is not None else \
             {int(i): int(i) for i in np.unique(self._fit_batch.node_label).tolist()}
         self._inv_labels = _LazyInvLabels(lvl0, self._all_inv_labels)
@@ -334,9 +335,62 @@ class WeisfeilerLehman(Kernel):
             self._X_diag, self._Y_diag = xd * float(self._n_iter), yd * float(self._n_iter)
             self._is_transformed = True
             return self._eh_scale(K, self._Y_diag, self._X_diag)
+        K = self._transform_lookup(X)
+        if K is not None:
+            self._is_transformed = True
+            return K
         eng, feat = self._gram_transform(X)
         self._is_transformed = True
         return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
+
+    # which transform route: "auto" = look-up while the targets are at most 1/32 of the fitted nodes (its work is
+    # proportional to the targets; the joint relabel of fitted graphs + targets is the MFMA route for large target sets),
+    # "lookup" / "joint" force one (tests).  Not a constructor parameter: get_params() stays the reference's.
+    transform_route = "auto"
+
+    def _transform_lookup(self, X):
+        """weisfeiler_lehman.py:435-498 the reference's way: relabel the targets alone and look their signatures up in the
+        fitted dictionaries kept on the device (csrc/wl_transform.hip).  None: take the joint route."""
+        if self._base_graph_kernel is not VertexHistogram or type(self)._feature_kind != 0 or self.transform_route == "joint":
+            return None
+        if self._n_iter > MAX_LEVELS or self.__dict__.get("_lookup_declined"):
+            return None
+        ybatch, _ = self._ingest(X, self._label_map if self._label_map is not None else {})
+        if self.transform_route != "lookup" and ybatch.n_nodes * 32 > self._fit_batch.n_nodes:
+            return None                               # measured at 10 000 fitted graphs: look-up wins up to a few hundred targets
+        eng = self._engine()
+        h = self._n_iter - 1
+        dfit = self._fitted_on_device(eng)
+        wf = self.__dict__.get("_dev_wlfit")
+        for attempt in range(2):
+            if wf is None or wf.handle is None or wf.batch is not dfit:
+                if getattr(dfit, "label_counts", None) is None or len(dfit.label_counts) != self._n_iter:
+                    eng.wl_relabel(dfit, h)
+                wf = eng.wl_fitted(dfit, h)
+                if wf is None:                        # hash collision among the fitted classes / a hub: joint route from now on
+                    self._lookup_declined = True
+                    return None
+                self._dev_wlfit = wf
+            yb = eng.upload(ybatch)
+            try:
+                eng.wl_relabel(yb, h)
+                out = eng.wl_transform(wf, yb, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
+            finally:
+                yb.close()
+            if out is None:                           # a target graph too large / a hub among the targets: joint route for this call
+                return None
+            if out != "stale":
+                break
+            wf.close()                                # the fitted batch was relabelled since (diagonal(), a second fit_transform)
+            wf = None
+            if attempt:
+                return None
+        K, ydiag = out
+        self._ny = ybatch.n_graphs
+        if not hasattr(self, "_X_diag"):
+            self._X_diag = eng.wl_fitted_selfk(wf)
+        self._Y_diag = ydiag
+        return K
 
     def diagonal(self):
         """weisfeiler_lehman.py:502-555."""

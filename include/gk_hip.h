@@ -156,6 +156,23 @@ int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits,
                   int64_t* out_label_counts, int* out_rounds);
 /* Level labels back to the host (parity tests: partition equality with the oracle). */
 int gk_wl_get_labels(gk_ctx* ctx, gk_batch* b, int level, int32_t* out_labels);
+/* ---- WeisfeilerLehman.transform as a look-up against the fitted dictionaries (csrc/wl_transform.hip) --------------
+ * Replaces weisfeiler_lehman.py:435-476 (relabel the targets, look their credentials up in the fitted _inv_labels[i]) and
+ * :493-498 + vertex_histogram.py:138-184 (the targets' label counts in the fitted columns, one rectangular product per
+ * level) for the VertexHistogram base kernel.  gk_wl_fitted_create: `fitted` is relabelled for n_iter (gk_wl_relabel) and
+ * must stay alive and NOT be relabelled again while the state is used (gk_wl_transform then returns GK_ERR_STATE).
+ * gk_wl_transform: `targets` relabelled ALONE with the same n_iter, their level-0 ids in the fit's id space (input labels
+ * the fit never saw: ids >= the fit's n_labels0); out_K host [n_targets x n_fitted] float64 (normalize as gk_gram: 0 none,
+ * 1 plain, 2 nan_to_num), out_y_selfk host [n_targets].  Work is proportional to the targets, not to the fit.
+ * GK_ERR_UNSUPPORTED: the job needs the joint route (gk_batch_concat + gk_wl_relabel + gk_features_build with n_fit):
+ * two fitted classes share a 64-bit signature hash, a representative node has more than 64 neighbours, a target graph has
+ * more than 1024 nodes, more than 48 levels. */
+typedef struct gk_wl_fitted gk_wl_fitted;
+int gk_wl_fitted_create(gk_ctx* ctx, gk_batch* fitted, int n_iter, gk_wl_fitted** out);
+int gk_wl_fitted_destroy(gk_wl_fitted* w);
+int gk_wl_fitted_selfk(gk_ctx* ctx, gk_wl_fitted* w, double* out_selfk);     /* host [n_fitted]: the fitted diagonal */
+int gk_wl_transform(gk_ctx* ctx, gk_wl_fitted* w, gk_batch* targets, int normalize, double* out_K, double* out_y_selfk);
+
 /* Which route the batch's last gk_wl_relabel took: *out_stream = 1 the route without host round trips (csrc/wl_stream.hip;
  * graph batches of small graphs with at most 256 input labels), 0 the host-driven route (everything else, option
  * "wl.no_stream", and the redo after a hash collision or a table overflow).  Same partitions, same matrices either way;

@@ -317,6 +317,62 @@ def test_stream_relabel_route_against_the_oracle(gk, gkopt, case):
     assert np.array_equal(eng.gram(eng.features(db2, h + 1)), K)
 
 
+@pytest.mark.parametrize("normalize", [False, True])
+def test_transform_by_lookup_against_the_oracle_and_the_joint_route(gk, normalize):
+    """WeisfeilerLehman.transform looks target signatures up in the fitted dictionaries kept on the device
+    (csrc/wl_transform.hip; weisfeiler_lehman.py:435-498): same matrix and diagonals as the joint relabel of fitted graphs
+    + targets and as the oracle -- targets that ARE fitted graphs, fresh ones, input labels the fit never saw, isolated
+    vertices, a one-vertex graph; the state survives diagonal() / a second fit_transform relabelling the fitted batch."""
+    X = er_dataset(300, 40, 0.08, 4, 1)
+    cases = {"fitted": X[:20], "fresh": er_dataset(25, 40, 0.08, 4, 99), "unseen labels": er_dataset(10, 40, 0.08, 6, 5),
+             "tiny": [[{0: []}, {0: 1}], [{0: [1], 1: [0]}, {0: 0, 1: 2}]] + er_dataset(5, 30, 0.05, 3, 8)}
+    ref = O.WLOracle(n_iter=4, normalize=normalize)
+    ref.fit_transform(X)
+    same = (lambda a, b: np.allclose(a, b, rtol=REL_TOL, atol=0)) if normalize else np.array_equal
+    est = gk.WeisfeilerLehman(n_iter=4, normalize=normalize)
+    est.transform_route = "lookup"
+    est.fit(X)
+    joint = gk.WeisfeilerLehman(n_iter=4, normalize=normalize)
+    joint.transform_route = "joint"
+    joint.fit(X)
+    for name, Y in cases.items():
+        K = est.transform(Y)
+        assert "_dev_wlfit" in est.__dict__, "the look-up route did not run"
+        assert same(K, ref.transform(Y)), name
+        assert same(K, joint.transform(Y)), name
+        assert all(np.array_equal(a, b) for a, b in zip(est.diagonal(), joint.diagonal())), name
+    # diagonal() after a fresh fit relabels the fitted batch: the fitted state is rebuilt, not used stale
+    est.fit(X)
+    est.transform(cases["fresh"])
+    wf = est._dev_wlfit
+    del est._X_diag
+    est._is_transformed = False
+    est.diagonal()
+    assert same(est.transform(cases["fresh"]), ref.transform(cases["fresh"])) and est._dev_wlfit is not wf
+    # default policy: a handful of targets against a larger fit take the look-up, a large target set the joint route
+    auto = gk.WeisfeilerLehman(n_iter=4, normalize=normalize).fit(X)
+    assert same(auto.transform(cases["fresh"][:3]), ref.transform(cases["fresh"][:3])) and "_dev_wlfit" in auto.__dict__
+    auto2 = gk.WeisfeilerLehman(n_iter=4, normalize=normalize).fit(X)
+    assert same(auto2.transform(X[:100]), ref.transform(X[:100])) and "_dev_wlfit" not in auto2.__dict__
+    import pickle
+    again = pickle.loads(pickle.dumps(est))
+    assert same(again.transform(cases["fresh"]), ref.transform(cases["fresh"]))
+
+
+def test_transform_lookup_declines_a_hub_and_takes_the_joint_route(gk):
+    """A class representative with more than 64 neighbours is outside the look-up's in-register signature comparison: the
+    fitted state declines (GK_ERR_UNSUPPORTED) and transform silently takes the joint route."""
+    star = {0: list(range(1, 80))}
+    star.update({i: [0] for i in range(1, 80)})
+    X = er_dataset(40, 20, 0.2, 3, 3) + [[star, {i: i % 3 for i in range(80)}]]
+    Y = er_dataset(3, 20, 0.2, 3, 4)
+    est = gk.WeisfeilerLehman(n_iter=3)
+    est.transform_route = "lookup"
+    ref = O.WLOracle(n_iter=3)
+    ref.fit_transform(X)
+    assert np.array_equal(est.fit(X).transform(Y), ref.transform(Y)) and est._lookup_declined
+
+
 @pytest.mark.parametrize("slots", [1, 8, 40])
 def test_bucket_dictionary_overflow_takes_the_sorting_path(gk, gkopt, slots):
     """A bucket of the sort-free dictionary that holds more distinct keys than its table (forced here by shrinking
