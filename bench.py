@@ -232,6 +232,42 @@ def config4_sp(eng, steps=5):
             "reference_cpu_s": {"floyd_warshall_route": 15.2, "dijkstra_route": 21.8}}
 
 
+def transform_bench(eng, cfg):
+    """`transform` of a few target graphs against the config-3 fit (never `value`): the look-up route (targets relabelled
+    alone, signatures looked up in the fitted dictionaries on the device, csrc/wl_transform.hip -- the reference's own
+    scheme, weisfeiler_lehman.py:435-498) against the joint route (fitted graphs + targets relabelled together), wall per
+    call through the estimator on Python dict graphs and the device phases of one call."""
+    import grakel_amd
+    from grakel_amd.synthetic import er_dataset
+    X = er_dataset(cfg["N"], cfg["n"], cfg["p"], cfg["L"], cfg["seed"])
+    out = {"fit": "%d graphs (the headline config)" % cfg["N"], "routes": {}}
+    sums = {}
+    for route in ("lookup", "joint"):
+        est = grakel_amd.WeisfeilerLehman(n_iter=cfg["n_iter"])
+        est.transform_route = route
+        est.fit(X)
+        res = {}
+        for nt in (1, 100, 1000):
+            Y = er_dataset(nt, cfg["n"], cfg["p"], cfg["L"], 4321)
+            est.transform(Y)
+            est.transform(Y)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                K = est.transform(Y)
+            dt = (time.perf_counter() - t0) / 3
+            eng.profile(True)
+            est.transform(Y)
+            ph = {k: round(eng.profile_get(k)[0], 4) for k in ("relabel", "features", "gram", "transform") if eng.profile_get(k)[1]}
+            eng.profile(False)
+            res["%d_targets" % nt] = {"wall_ms": round(dt * 1e3, 3), "device_phases_ms": ph}
+            sums.setdefault(nt, []).append(float(K.sum()))
+        out["routes"][route] = res
+    out["same_matrices"] = all(len(set(v)) == 1 for v in sums.values())
+    out["note"] = ("device_phases_ms.transform of the look-up route includes the device -> host copy of the n_targets x "
+                   "n_fitted float64 block; default policy: look-up while the targets hold at most 1/32 of the fitted nodes")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +280,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and the config-4 object")
     ap.add_argument("--plan", choices=["plain", "symmetric"], default="plain",
                     help="N > 1: Gram sharding plan (grakel_amd.dist.gram_plan; plain row blocks is the default)")
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="step = gk_wl_relabel + gk_features_build + gk_gram as three library calls instead of gk_wl_fit_transform")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="context option (gk_set_option, include/gk_hip.h), e.g. --opt wl.debug=1; A/B runs only")
     a = ap.parse_args()
@@ -319,9 +357,14 @@ def main():
                     f.close()
 
         def step():
-            eng.wl_relabel(db, h)
-            feat = eng.features(db, h + 1)
-            eng.gram(feat, 0, to_host=False)
+            # one library call: relabel (queued without a host round trip) -> features -> Gram (gk_wl_fit_transform; the
+            # three separate calls -- --separate-calls -- give the same matrix with two more host round trips)
+            if a.separate_calls:
+                eng.wl_relabel(db, h)
+                feat = eng.features(db, h + 1)
+                eng.gram(feat, 0, to_host=False)
+            else:
+                feat, _ = eng.wl_fit_transform(db, h, to_host=False)
             info.update(n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, dtype=feat.dtype, operand=feat.operand,
                         label_counts=db.label_counts, nnz=feat.nnz)
             collect()
@@ -484,6 +527,11 @@ def main():
                 out["extra"] = {"config4_sp": config4_sp(eng)}
             except Exception as e:                     # never lose the headline line to an extra
                 out["extra"] = {"config4_sp": {"error": repr(e)}}
+            if a.workload == "config3" and full_size:
+                try:
+                    out["extra"]["transform"] = transform_bench(eng, cfg)
+                except Exception as e:
+                    out["extra"]["transform"] = {"error": repr(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -51,6 +51,7 @@ SIGNATURES = {
     "gk_wl_relabel": (c_int, [c_void_p, c_void_p, c_int, c_int, _i64p, POINTER(c_int)]),
     "gk_wl_get_labels": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gk_wl_route": (c_int, [c_void_p, c_void_p]),
+    "gk_wl_fit_transform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, _i64p, POINTER(c_int), _vpp, c_void_p]),
     "gk_wl_fitted_create": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gk_wl_fitted_destroy": (c_int, [c_void_p]),
     "gk_wl_fitted_selfk": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -145,6 +145,28 @@ int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words) {
     return gk_mbox_wait(ctx, seq, dst_host, n_words);
 }
 
+__global__ void mbox_post2_kernel(const u32* __restrict__ src1, int n1, const u32* __restrict__ src2, int n2, u32* __restrict__ mbox, u32 seq) {
+    for (int i = threadIdx.x; i < n1 + n2; i += blockDim.x)
+        __hip_atomic_store(&mbox[1 + i], i < n1 ? src1[i] : src2[i - n1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int gk_readback2(gk_ctx* ctx, const u32* src1, int n1, const u32* src2, int n2, u32* dst_host) {
+    const u32 seq = n1 + n2 <= GK_MBOX_WORDS - 1 ? gk_mbox_begin(ctx) : 0;
+    if (!seq) {
+        GK_TRY(gk_readback(ctx, src1, dst_host, n1));
+        return gk_readback(ctx, src2, dst_host + n1, n2);
+    }
+    mbox_post2_kernel<<<1, 256, 0, ctx->stream>>>(src1, n1, src2, n2, ctx->mbox_dev, seq);
+    GK_HIP_CHECK(hipGetLastError());
+    return gk_mbox_wait(ctx, seq, dst_host, n1 + n2);
+}
+
 // Pinned host memory for Gram outputs: the float64 matrix is 8 N^2 bytes (800 MB at 10 k graphs) and a
 // device -> pageable copy runs at 12-18 GB/s, into pinned memory at 57 GB/s (tools/micro/pinbw.hip).
 extern "C" int gk_host_alloc(uint64_t bytes, void** out) {

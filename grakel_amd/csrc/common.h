@@ -238,6 +238,7 @@ struct gk_batch {
     // (sr_ctl, SR_CTL words per level) so that the feature builder can be queued without the host knowing them
     u64 relabel_gen = 0;               // bumped by every gk_wl_relabel: label ids of an earlier call are gone (wl_transform.hip)
     bool stream_layout = false;
+    int sr_pending = 0;                // > 0: a stream relabel of that many levels is queued, its control words not yet seen by the host
     u32* sr_ctl = nullptr;             // [cap of sr_ctl_levels][SR_CTL]
     int sr_ctl_levels = 0;
     std::vector<u32> sr_F, sr_S;       // host copies (after the job's one read-back)
@@ -356,6 +357,11 @@ int gk_bucket_dictionary(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i32*
 int gk_batch_ensure_levels(gk_batch* b, int n_levels);
 // wl_stream.hip: GK_ERR_UNSUPPORTED = not applicable to this job / a table overflowed / a hash collision: take the host-driven route
 int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits, std::vector<u32>& counts);
+int gk_sr_enqueue(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits);     // the same without the read-back ...
+int gk_sr_collect(gk_ctx* ctx, gk_batch* b, const u32* ctl_words);                                // ... which its caller hands in later
+#define GK_ERR_RETRY (-100)     // internal: the queued stream relabel turned out unusable (collision / overflow) at a later read-back
+// two device arrays in ONE mailbox round trip (n1 + n2 <= GK_MBOX_WORDS - 1; more: two copies)
+int gk_readback2(gk_ctx* ctx, const u32* src1, int n1, const u32* src2, int n2, u32* dst_host);
 int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level);
 int gk_sp_materialise(gk_ctx* ctx, gk_batch* pair_batch);            // sp.hip: item arrays of a histogram-form pair batch      // perm[level] on demand (sort-free dictionary levels)
 

@@ -552,12 +552,17 @@ extern "C" int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, i
     if (!b->is_pair_batch && V > 0 && b->max_graph_nodes <= GM_MAX_NODES && !ctx->opt.feat_no_gm) {
         r = gk_features_build_gm(ctx, b, f, n_levels, prim_max, wide_above);
         if (r == GK_OK) { *out = f; return GK_OK; }
-        if (r != GK_ERR_UNSUPPORTED) return fail(r);
+        if (r != GK_ERR_UNSUPPORTED) return fail(r);      // incl. GK_ERR_RETRY: the queued relabel was unusable
         for (void* p : f->arena)
             if (p) gk_dev_free(ctx, p);
         f->arena.clear();
         f->gm = false;
         if (gk_zero_async(ctx, f->meta, n_meta * 4) != GK_OK) return fail(GK_ERR_HIP);
+    }
+    if (b->sr_pending > 0) {          // a queued stream relabel nobody has looked at yet (the graph-major builder did not run)
+        std::vector<u32> hw((size_t)b->sr_pending * SR_CTL);
+        if ((r = gk_readback(ctx, b->sr_ctl, hw.data(), b->sr_pending * SR_CTL))) return fail(r);
+        if (gk_sr_collect(ctx, b, hw.data()) != GK_OK) return fail(GK_ERR_RETRY);
     }
     // ---- the level slots: a level only lists the nodes that can share a label (wl.hip: active-set
     // levels), a level that lists nothing adds one per node to the diagonal and nothing else

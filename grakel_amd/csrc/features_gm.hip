@@ -50,6 +50,7 @@ struct GmLabelArrays {
 
 #define GM_WAVES 8
 #define GM_FEW 24           // at most this many distinct labels: counted by ballots instead of the sort
+#define GM_FEW1 10          // ... for graphs of at most 64 nodes (one label per lane, 21 sorting steps)
 
 // One wave per graph (persistent workgroups: a wave walks graphs w, w + stride, ...), all levels.  Per level the
 // wave counts its graph's labels in a small open-addressing table in LDS (T slots, T >= 2 x the largest
@@ -207,7 +208,8 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                     if (lane == 0) *ne = 0;
                     continue;
                 }
-                if (__builtin_popcountll(Ma) + __builtin_popcountll(Mb) <= GM_FEW || space <= (u32)GM_FEW) {
+                // (the one-register sort of a small graph is ~200 instructions: cheaper than a ballot round per label beyond ~10)
+                if (__builtin_popcountll(Ma) + __builtin_popcountll(Mb) <= (n <= 64 ? GM_FEW1 : GM_FEW) || space <= (u32)(n <= 64 ? GM_FEW1 : GM_FEW)) {
                     // few distinct labels (deep levels: a handful of shared nodes per graph; level 0: a handful of
                     // labels): one wave-uniform round per distinct label -- take the first remaining node's label,
                     // ballot its equals; entry k lands in lane k
@@ -224,6 +226,33 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                     if (lane < k) el[lane] = qof(mx), ec[lane] = mc;
                     if (lane == 0) *ne = (u32)k;
                     if (lane < k) emit(mx, mc);
+                    continue;
+                }
+                if (n <= 64) {
+                    // ---- at most 64 nodes: ONE label per lane, 21 compare-exchange steps, none of the second register's work
+                    // (config 5: 50 000 graphs of 30 nodes spent most of this kernel sorting 64 empty positions each)
+#pragma unroll
+                    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                            const i32 pa = __shfl_xor(a, jj, 64);
+                            const bool lower = (lane & jj) == 0;
+                            const bool asc = k == 64 ? true : (lane & k) == 0;
+                            const i32 mna = a < pa ? a : pa, mxa = a < pa ? pa : a;
+                            a = (lower == asc) ? mna : mxa;
+                        }
+                    }
+                    const i32 up_a = __shfl_up(a, 1, 64);
+                    const bool ha = lane == 0 || a != up_a;
+                    const u64 Ha = __ballot(ha);
+                    const u64 above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+                    const u64 ma = Ha & above;
+                    const int next_a = ma ? __builtin_ctzll(ma) : 64;
+                    const u32 ca = (ha && a != BIG) ? (u32)(next_a - lane) : 0u;
+                    const u64 Va = __ballot(ca != 0);
+                    if (ca) { const int k = __builtin_popcountll(Va & ((1ull << lane) - 1ull)); el[k] = qof(a), ec[k] = ca; }
+                    if (lane == 0) *ne = (u32)__builtin_popcountll(Va);
+                    if (ca) emit(a, ca);
                     continue;
                 }
                 // ---- the graph's shared labels sorted in registers (two per lane: positions lane and lane + 64), a
@@ -351,10 +380,15 @@ __global__ __launch_bounds__(1024) void gm_reduce_kernel(const GmLabelArrays A, 
     const int t = blockIdx.x * 64 + lane;
     u32 c0 = 0, c1 = 0, fl = 0;
     if (t < words)
-        for (int g = w; g < n_wg; g += 16) {
-            const u32 x = part[(size_t)g * words + t];
-            c0 += x & GM_PRIV_COUNT_MASK, c1 += (x >> 16) & GM_PRIV_COUNT_MASK;
-            fl |= (x & 0xf000u) | ((x >> 16 & 0xf000u) << 16);
+        for (int g = w; g < n_wg; g += 64) {       // four rows in flight per wave (one load per trip was a chain of L2 latencies)
+            u32 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = g + 16 * u < n_wg ? part[(size_t)(g + 16 * u) * words + t] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                c0 += x[u] & GM_PRIV_COUNT_MASK, c1 += (x[u] >> 16) & GM_PRIV_COUNT_MASK;
+                fl |= (x[u] & 0xf000u) | ((x[u] >> 16 & 0xf000u) << 16);
+            }
         }
     sc0[w][lane] = c0, sc1[w][lane] = c1, sf[w][lane] = fl;
     __syncthreads();
@@ -561,12 +595,19 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
                                                            const u32* __restrict__ cnt, const u32* __restrict__ ent_n, i64 n_graphs,
                                                            int8_t* __restrict__ phi, i64 ld, i64 prim0, int fp4, int kind,
                                                            double* __restrict__ phi_w, i64 ldw, i32* __restrict__ low_graph,
-                                                           i32* __restrict__ low_cnt, i32* __restrict__ low_lab) {
+                                                           i32* __restrict__ low_cnt, i32* __restrict__ low_lab, i64 n_rows_pad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row_all[];
     __shared__ u32 slots_all[4][FEAT_MAX_LEVELS];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const i64 g = (i64)blockIdx.x * 4 + w;
-    if (g >= n_graphs) return;                                    // wave-uniform: no workgroup barrier below
+    if (g >= n_graphs) {                                          // wave-uniform: no workgroup barrier below
+        // the padding rows [n_graphs, n_rows_pad) of the operand are all zero (tile loads need no row guards)
+        if (g < n_rows_pad) {
+            uint4* dst = (uint4*)(phi + g * ld);
+            for (i64 i = lane; i < ld / 16; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
     unsigned char* row = row_all + (size_t)w * ld;
     u32* slots = slots_all[w];
     const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
@@ -629,7 +670,16 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
         if (nblk > 1) gm_scan_sums_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
         gm_scan_apply_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
     }
-    GK_TRY(gk_readback(ctx, f->meta, h.data(), GM_META_WORDS));     // one host sync: sizes of the operand
+    gk_batch* fb = f->batch;
+    if (fb && fb->sr_pending > 0) {
+        // the relabel in front of this job was only queued (gk_sr_enqueue): its control words ride on the same round trip
+        const int nw = fb->sr_pending * SR_CTL;
+        std::vector<u32> h2((size_t)GM_META_WORDS + (size_t)nw);
+        GK_TRY(gk_readback2(ctx, f->meta, GM_META_WORDS, fb->sr_ctl, nw, h2.data()));
+        std::copy(h2.begin(), h2.begin() + GM_META_WORDS, h.begin());
+        if (gk_sr_collect(ctx, fb, h2.data() + GM_META_WORDS) != GK_OK) return GK_ERR_RETRY;      // collision / overflow: the caller starts over
+    } else
+        GK_TRY(gk_readback(ctx, f->meta, h.data(), GM_META_WORDS));     // one host sync: sizes of the operand
     if (h[GM_META_OVF]) return GK_ERR_UNSUPPORTED;                  // a histogram table of gk_features_build_sp overflowed
     f->n_cols1 = h[GM_META_PRIM], f->n_cols8 = h[GM_META_INT8], f->n_cols = f->n_cols1 + f->n_cols8;
     f->n_cols_wide = h[GM_META_F64], f->n_low_cols = h[GM_META_RARE];
@@ -675,15 +725,16 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     // small rows AND few entries per graph: a wave per graph, four graphs per workgroup (config 5, ~100 entries per graph:
     // 112 -> 85 us; ShortestPath histograms with ~10x the entries per graph: 30 us by workgroups, 76 us by waves)
     if (f->n_cols_pad <= GM_ROW_WAVE_MAX && f->nnz <= 192 * N && !ctx->opt.gm_rows_wg)
-        gm_rows_wave_kernel<<<dim3((unsigned)cdiv(N, 4)), 256, (size_t)f->n_cols_pad * 4, ctx->stream>>>(
+        gm_rows_wave_kernel<<<dim3((unsigned)cdiv(f->n_rows_pad, 4)), 256, (size_t)f->n_cols_pad * 4, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-            f->n_cols_wide_pad, lg, lc, ll);
-    else
+            f->n_cols_wide_pad, lg, lc, ll, f->n_rows_pad);        // ... and zeroes the padding rows
+    else {
         gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
             f->n_cols_wide_pad, lg, lc, ll);
-    const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
-    gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
+        const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
+        gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
+    }
     GK_HIP_CHECK(hipGetLastError());
     // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries
     f->gm = true;

@@ -1232,6 +1232,10 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
 #define WS_ABL_CASE(X) if (abl_bits == X) kern = gram_ws_kernel<true, X>;
         WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(8) WS_ABL_CASE(9) WS_ABL_CASE(10) WS_ABL_CASE(11) WS_ABL_CASE(13)
         WS_ABL_CASE(24) WS_ABL_CASE(25) WS_ABL_CASE(32) WS_ABL_CASE(43) WS_ABL_CASE(107) WS_ABL_CASE(128) WS_ABL_CASE(136)
+        // round 4: the floor of the two memory streams alone -- 18 = no multiply, no K-step barrier: the operand DMA stream (L2 ->
+        // LDS) and the float64 tile-pattern store run free inside a tile and meet once per tile; 82 = the same without parking;
+        // 16 = everything but the K-step barrier (races: timing only); 26 / 17 = one of the two streams alone, free-running
+        WS_ABL_CASE(16) WS_ABL_CASE(18) WS_ABL_CASE(82) WS_ABL_CASE(26) WS_ABL_CASE(19)
 #undef WS_ABL_CASE
 #endif
         (void)abl_bits;

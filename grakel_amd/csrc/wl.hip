@@ -35,6 +35,7 @@
 // synchronisation.  HBM-bound integer work: algorithmic bytes per level 8E + 12V.
 #include "common.h"
 #include "scan_fn.h"
+#include "features.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1599,6 +1600,62 @@ extern "C" int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits
         b->label_counts[lvl] = h[lvl];
         if (out_label_counts) out_label_counts[lvl] = h[lvl];
     }
+    return GK_OK;
+}
+
+// ---- fit_transform in one call: relabel -> label-count features -> Gram matrix ---------------------------------------
+// (weisfeiler_lehman.py:292-328 + vertex_histogram.py:57-184 + kernel.py:195-204 in one piece.)  The three entry points
+// above each end in a host round trip and the caller's own glue sits between them; here the stream relabel is only QUEUED
+// (gk_sr_enqueue), the feature builder runs behind it on device-side counts, and the ONE round trip of the whole job -- the
+// operand sizes the Gram launch needs -- also carries the relabel's control words (collision / overflow flags, label counts).
+// Jobs the stream route declines, or that turn out to need the redo, take the three calls in sequence.
+extern "C" int gk_wl_fit_transform(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits, int kind, int normalize,
+                                   int64_t* out_label_counts, int* out_rounds, gk_feat** out_feat, double* out_host) {
+    GK_ARG(ctx && b && out_feat, "gk_wl_fit_transform: null argument");
+    GK_ARG(!b->is_pair_batch, "gk_wl_fit_transform: pair batches have no adjacency");
+    GK_ARG(n_iter >= 0 && n_iter < 4096, "gk_wl_fit_transform: bad n_iter");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    const int n_levels = n_iter + 1;
+    int bits = hash_bits;
+    const bool default_bits = bits <= 0 || bits > 64;
+    if (default_bits) {
+        int lg = bits_for((u64)(b->n_nodes > 1 ? b->n_nodes - 1 : 1));
+        bits = ((2 * lg + 8 + 7) / 8) * 8;
+        if (bits < 32) bits = 32;
+        if (bits > 64) bits = 64;
+    }
+    gk_feat* f = nullptr;
+    bool fused = false;
+    if (out_rounds) *out_rounds = 0;
+    if (n_levels >= 2 && n_levels <= FEAT_MAX_LEVELS) {
+        GK_TRY(gk_batch_ensure_levels(b, n_levels));
+        ++b->relabel_gen;
+        int r;
+        {
+            ProfScope prof(ctx, "relabel");
+            r = gk_sr_enqueue(ctx, b, n_levels, bits, default_bits);
+        }
+        if (r == GK_OK) {
+            r = gk_features_build_ex(ctx, b, n_levels, b->n_graphs, kind, &f);
+            if (r == GK_OK) fused = true;
+            else if (r != GK_ERR_RETRY) return r;
+        } else if (r != GK_ERR_UNSUPPORTED) return r;
+    }
+    if (!fused) {
+        b->sr_pending = 0;
+        const int keep = ctx->opt.wl_no_stream;
+        if (n_levels >= 2 && n_levels <= FEAT_MAX_LEVELS && !b->stream_layout && b->n_levels == 0) ctx->opt.wl_no_stream = 1;    // the redo: not the stream route again
+        int r = gk_wl_relabel(ctx, b, n_iter, hash_bits, nullptr, out_rounds);
+        ctx->opt.wl_no_stream = keep;
+        GK_TRY(r);
+        GK_ARG(n_levels <= FEAT_MAX_LEVELS, "gk_wl_fit_transform: at most 48 levels (deeper hierarchies: gk_features_build_range in chunks)");
+        GK_TRY(gk_features_build_ex(ctx, b, n_levels, b->n_graphs, kind, &f));
+    }
+    if (out_label_counts)
+        for (int l = 0; l < n_levels; ++l) out_label_counts[l] = b->label_counts[l];
+    const int r = gk_gram_rows(ctx, f, 0, b->n_graphs, normalize, out_host);
+    if (r != GK_OK) { gk_features_destroy(f); return r; }
+    *out_feat = f;
     return GK_OK;
 }
 

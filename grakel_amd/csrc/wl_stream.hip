@@ -666,7 +666,9 @@ int gk_sr_rebuild_order(gk_ctx* ctx, gk_batch* b, int level) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits, std::vector<u32>& counts) {
+// Queues the whole relabel (no host read-back).  GK_OK: queued, b->sr_pending = n_levels until gk_sr_collect has seen the
+// control words; GK_ERR_UNSUPPORTED: not a job for this route (nothing was queued).
+int gk_sr_enqueue(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits) {
     const i64 V = b->n_nodes;
     const i64 n_car = b->n_iso;
     // ---- is this the job this route is built for?  (graph batches of small graphs whose features the graph-major builder
@@ -742,15 +744,11 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
                                                                           node_of.p, seg.p, wg_cnt.p);
     }
     GK_HIP_CHECK(hipGetLastError());
-    std::vector<u32> h((size_t)n_levels * SR_CTL);
-    GK_TRY(gk_readback(ctx, ctl, h.data(), n_levels * SR_CTL));
-    for (int lvl = 1; lvl < n_levels; ++lvl)
-        if (h[(size_t)lvl * SR_CTL + SR_UNRES] || h[(size_t)lvl * SR_CTL + SR_OVF]) {
-            if (ctx->opt.wl_debug)
-                fprintf(stderr, "[gk] stream relabel: level %d unresolved %u overflow %u -> host-driven route\n", lvl,
-                        h[(size_t)lvl * SR_CTL + SR_UNRES], h[(size_t)lvl * SR_CTL + SR_OVF]);
-            return GK_ERR_UNSUPPORTED;
-        }
+    // provisionally a stream-layout batch: the feature builder can be queued behind this without the host knowing a count
+    b->sr_pending = n_levels;
+    b->stream_layout = true;
+    b->level0_hist = true;
+    b->n_levels = n_levels;
     if (dbg.p) {
         std::vector<u64> hd((size_t)n_levels * 2048);
         GK_HIP_CHECK(hipMemcpyAsync(hd.data(), dbg.p, hd.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -769,6 +767,25 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
                             lvl, nb, ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[3] / nb, ph[4] / nb, mx);
         }
     }
+    return GK_OK;
+}
+
+// The control words have reached the host (h = n_levels * SR_CTL words): a hash collision or a table overflow hands the job to
+// wl.hip's route (GK_ERR_UNSUPPORTED, the batch is no stream-layout batch any more); otherwise the host-side description of
+// the levels is filled in.
+int gk_sr_collect(gk_ctx* ctx, gk_batch* b, const u32* h) {
+    const int n_levels = b->sr_pending;
+    const i64 V = b->n_nodes, n_car = b->n_iso;
+    b->sr_pending = 0;
+    for (int lvl = 1; lvl < n_levels; ++lvl)
+        if (h[(size_t)lvl * SR_CTL + SR_UNRES] || h[(size_t)lvl * SR_CTL + SR_OVF]) {
+            if (ctx->opt.wl_debug)
+                fprintf(stderr, "[gk] stream relabel: level %d unresolved %u overflow %u -> host-driven route\n", lvl,
+                        h[(size_t)lvl * SR_CTL + SR_UNRES], h[(size_t)lvl * SR_CTL + SR_OVF]);
+            b->stream_layout = false;
+            b->n_levels = 0;
+            return GK_ERR_UNSUPPORTED;
+        }
     // ---- what the consumers on the host need
     b->stream_layout = true;
     b->level0_hist = true;
@@ -777,10 +794,11 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
     b->n_sorted.assign((size_t)n_levels, V);
     b->active_layout.assign((size_t)n_levels, 0);
     b->perm_valid.assign((size_t)n_levels, 0);
-    counts.assign((size_t)n_levels, 0);
+    b->n_levels = n_levels;
+    b->label_counts.assign((size_t)n_levels, 0);
     for (int lvl = 0; lvl < n_levels; ++lvl) {
-        const u32* c = h.data() + (size_t)lvl * SR_CTL;
-        counts[lvl] = c[SR_COUNT];
+        const u32* c = h + (size_t)lvl * SR_CTL;
+        b->label_counts[lvl] = c[SR_COUNT];
         b->sr_F[lvl] = c[SR_F], b->sr_S[lvl] = c[SR_S];
         if (lvl > 0) b->n_sorted[lvl] = (i64)c[SR_LISTED] + n_car;       // nodes that can share their label
         if (ctx->opt.wl_debug)
@@ -789,3 +807,14 @@ int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, 
     }
     return GK_OK;
 }
+
+int gk_wl_relabel_stream(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits, std::vector<u32>& counts) {
+    GK_TRY(gk_sr_enqueue(ctx, b, n_levels, hash_bits, default_bits));
+    std::vector<u32> h((size_t)n_levels * SR_CTL);
+    GK_TRY(gk_readback(ctx, b->sr_ctl, h.data(), n_levels * SR_CTL));
+    GK_TRY(gk_sr_collect(ctx, b, h.data()));
+    counts.assign((size_t)n_levels, 0);
+    for (int lvl = 0; lvl < n_levels; ++lvl) counts[lvl] = (u32)b->label_counts[lvl];
+    return GK_OK;
+}
+

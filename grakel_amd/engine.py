@@ -394,6 +394,22 @@ class Engine(object):
         check(rc)
         return K, yd
 
+    def wl_fit_transform(self, db, n_iter, kind=0, normalize=0, to_host=True, hash_bits=0):
+        """relabel + features (all graphs fitted) + Gram in one library call (``gk_wl_fit_transform``): the relabel is queued
+        without a host round trip when the job allows.  Returns (DeviceFeatures, K or None); ``db.label_counts`` is set."""
+        counts = (c_int64 * (n_iter + 1))()
+        rounds = c_int(0)
+        h = c_void_p()
+        out = self.pinned.empty((db.n_graphs, db.n_graphs)) if to_host else None
+        check(self.lib.gk_wl_fit_transform(self.handle, db.handle, int(n_iter), int(hash_bits), int(kind), int(normalize),
+                                           counts, byref(rounds), byref(h), _ptr(out)))
+        db.label_counts = [int(c) for c in counts]
+        db.refine_rounds = rounds.value
+        route = c_int(0)
+        check(self.lib.gk_wl_route(db.handle, byref(route)))
+        db.stream_route = bool(route.value)
+        return DeviceFeatures(self, h, db, db.n_graphs), out
+
     def wl_labels(self, db, level):
         out = np.empty(db.n_nodes, dtype=np.int32)
         check(self.lib.gk_wl_get_labels(self.handle, db.handle, int(level), _ptr(out)))

@@ -127,6 +127,19 @@ class Kernel(BaseEstimator, TransformerMixin):
                                dtype=feat.operand, label_counts=fb.label_counts)
         return eng, feat
 
+    def _fit_transform_fused(self, n_iter, norm):
+        """fit_transform of a WL-type kernel in one library call (``gk_wl_fit_transform``: the relabel is queued without a
+        host round trip, the feature builder runs behind it on device-side counts).  Sets what ``_gram_fit`` sets; returns
+        the host matrix."""
+        eng = self._engine()
+        db = self._fitted_on_device(eng)
+        feat, K = eng.wl_fit_transform(db, n_iter, kind=self._feature_kind, normalize=norm)
+        self._X_diag = eng.selfk(feat)
+        self._last_info = dict(n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, nnz=feat.nnz, max_count=feat.max_count,
+                               dtype=feat.operand, label_counts=db.label_counts)
+        feat.close()
+        return K
+
     def _gram_transform(self, Y):
         ybatch, _ = self._ingest(Y, self._label_map if self._label_map is not None else {})
         self._ny = ybatch.n_graphs

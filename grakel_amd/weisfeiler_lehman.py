@@ -313,6 +313,11 @@ class WeisfeilerLehman(Kernel):
             K = self._eh.fit_transform(X)
             self._X_diag = self._eh.diagonal() * float(self._n_iter)
             return self._eh_scale(K, self._X_diag, self._X_diag)
+        if self._base_graph_kernel is VertexHistogram and self._n_iter <= MAX_LEVELS:
+            K = self._fit_transform_fused(self._n_iter - 1, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
+            for i, c in enumerate(self._last_info["label_counts"]):
+                self.X[i].X.shape = (self._nx, c)
+            return K
         eng, feat = self._gram_fit()
         for i, c in enumerate(self._last_info["label_counts"]):
             self.X[i].X.shape = (self._nx, c)

@@ -73,6 +73,10 @@ class WeisfeilerLehmanOptimalAssignment(Kernel):
             raise ValueError('transform input cannot be None')
         self._fit_host(X)
         self._after_fit()
+        if self._n_iter <= 48:                      # one library call (kernel.Kernel._fit_transform_fused)
+            K = self._fit_transform_fused(self._n_iter - 1, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
+            self.X = FittedFeatures(self._nx, sum(self._last_info["label_counts"]))
+            return K
         eng, feat = self._gram_fit()
         self.X = FittedFeatures(self._nx, sum(self._last_info["label_counts"]))
         return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)

@@ -154,6 +154,15 @@ int gk_batch_info(gk_batch* b, int64_t* n_graphs, int64_t* n_nodes, int64_t* n_e
  *   out_rounds : total extra refinement rounds that were needed (0 in practice), may be NULL */
 int gk_wl_relabel(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits,
                   int64_t* out_label_counts, int* out_rounds);
+/* fit_transform of the WL-subtree kernel in ONE call: gk_wl_relabel + gk_features_build_ex (all graphs fitted) + gk_gram
+ * (weisfeiler_lehman.py:292-328, vertex_histogram.py:57-184, kernel.py:195-204).  For the jobs of the route without host
+ * round trips the relabel is only queued, the feature builder runs behind it on device-side counts, and the one host round
+ * trip of the job (the operand sizes) also carries the relabel's collision / overflow flags and label counts; everything
+ * else runs the three calls in sequence.  n_iter + 1 <= 48 levels.  out_host may be NULL (the matrix stays on the device:
+ * gk_gram_dev_ptr); *out_feat is the job's feature object (gk_features_selfk, gk_features_info, gk_gram_checksum, ...;
+ * release with gk_features_destroy).  kind: GK_FEAT_DOT | GK_FEAT_MINSUM; normalize as gk_gram. */
+int gk_wl_fit_transform(gk_ctx* ctx, gk_batch* b, int n_iter, int hash_bits, int kind, int normalize,
+                        int64_t* out_label_counts, int* out_rounds, gk_feat** out_feat, double* out_host);
 /* Level labels back to the host (parity tests: partition equality with the oracle). */
 int gk_wl_get_labels(gk_ctx* ctx, gk_batch* b, int level, int32_t* out_labels);
 /* ---- WeisfeilerLehman.transform as a look-up against the fitted dictionaries (csrc/wl_transform.hip) --------------
