@@ -93,11 +93,7 @@ class GraphBatch(object):
             fd = np.concatenate([da if da is not None else np.zeros(a.n_graphs, np.uint8),
                                  db_ if db_ is not None else np.zeros(b.n_graphs, np.uint8)])
         if fa is not None or fb is not None:
-            # one side has general float weights: the union counts in float64 (the other side's exact weights as floats),
-            # i.e. EVERY graph of the union goes through the LDS-resident float64 kernel -- same limit as at ingestion
-            for x in (a, b):
-                if x.n_graphs and int(np.diff(x.graph_ptr).max()) > MAX_FLOAT_WEIGHT_NODES:
-                    raise NotImplementedError(FLOAT_WEIGHT_LIMIT_MESSAGE)
+            # one side has general float weights: the union counts in float64 (the other side's exact weights as floats)
             def as_float(x, f):
                 if f is not None:
                     return f
@@ -130,10 +126,8 @@ class GraphBatch(object):
 
 
 MAX_EDGE_WEIGHT = 2 ** 20        # int32 distances: sp.hip guards (n - 1) * max weight < SP_INF per batch
-MAX_FLOAT_WEIGHT_NODES = 143     # general float weights: the float64 distance matrix of a graph lives in LDS (sp.hip)
-FLOAT_WEIGHT_LIMIT_MESSAGE = ('ShortestPath on MI355X supports general float edge weights on graphs of up to '
-                              '%d vertices (integer or power-of-two-multiple weights have no such limit)'
-                              % MAX_FLOAT_WEIGHT_NODES)
+MAX_FLOAT_WEIGHT_NODES = 143     # general float weights: up to here the float64 distance matrix of a graph lives in LDS, larger
+                                 # graphs work on it in HBM, one workgroup per graph (sp.hip: sp_f64_big_kernel) -- slower, no limit
 
 
 def quantise_weights(weights):
@@ -665,8 +659,6 @@ def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_ite
         flat = np.concatenate(wts) if wts else np.zeros(0)
         if flat.size and (not np.all(np.isfinite(flat)) or flat.min() <= 0 or flat.max() >= 1e300):
             raise
-        if max(sizes) > MAX_FLOAT_WEIGHT_NODES:
-            raise NotImplementedError(FLOAT_WEIGHT_LIMIT_MESSAGE)
         graph_ptr, row_ptr, col, w = _pack_csr(sizes, srcs, dsts, wts)
         return GraphBatch(graph_ptr, row_ptr, col, ids, max(n_labels, 1), float_weight=w, from_dict=fd), mapping
     graph_ptr, row_ptr, col, w = _pack_csr(sizes, srcs, dsts, qw)

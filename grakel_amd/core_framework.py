@@ -32,9 +32,15 @@ def induced_subbatch(gb, keep):
     graph_ptr = np.zeros(len(gidx) + 1, np.int64)
     np.cumsum(sizes[gidx], out=graph_ptr[1:])
     ew = gb.edge_weight[ekeep] if gb.edge_weight is not None and gb.edge_weight.size else gb.edge_weight
-    if getattr(gb, "float_weight", None) is not None:
-        raise NotImplementedError('CoreFramework on MI355X: general float edge weights are only supported by ShortestPath itself')
-    return GraphBatch(graph_ptr, row_ptr, new_id[gb.col_idx[ekeep]], gb.node_label[keep], gb.n_labels, ew), gidx
+    fw = getattr(gb, "float_weight", None)
+    if fw is not None:
+        # general float weights travel with the edges.  The reference turns every element into its dictionary format
+        # (core_framework.py:40,153) and cuts the subgraphs out in that format (graph.py:1379), so the base ShortestPath's
+        # "auto" runs dijkstra on every subgraph (graph.py:652-656): all flags 1
+        return GraphBatch(graph_ptr, row_ptr, new_id[gb.col_idx[ekeep]], gb.node_label[keep], gb.n_labels, None,
+                          1.0, fw[ekeep], np.ones(len(gidx), np.uint8)), gidx
+    return GraphBatch(graph_ptr, row_ptr, new_id[gb.col_idx[ekeep]], gb.node_label[keep], gb.n_labels, ew,
+                      getattr(gb, "weight_step", 1.0)), gidx
 
 
 class CoreFramework(Kernel):

@@ -777,6 +777,7 @@ __global__ __launch_bounds__(1024) void sp_f64_kernel(const i32* __restrict__ gr
     const int g = only_graph >= 0 ? only_graph : (int)blockIdx.x;
     const i32 v0 = graph_ptr[g];
     const int n = graph_ptr[g + 1] - v0, tid = threadIdx.x, nt = blockDim.x;
+    if (n > SPF_MAX_N) return;                             // sp_f64_big_kernel's graphs (the matrix does not fit LDS)
     const double inf = __longlong_as_double((long long)SPF_INF_BITS);
     for (int idx = tid; idx < n * n; idx += nt) spf_d[idx] = (idx / n == idx % n) ? 0.0 : inf;
     __syncthreads();
@@ -822,6 +823,69 @@ __global__ __launch_bounds__(1024) void sp_f64_kernel(const i32* __restrict__ gr
     for (int idx = tid; idx < n * n; idx += nt) o[idx] = spf_d[idx];
 }
 
+// The same for graphs ABOVE SPF_MAX_N vertices: the matrix stays in HBM (one workgroup per graph works on its block of D).
+// Floyd-Warshall order: one sweep per pivot, the sweeps separated by workgroup barriers -- row and column k are not written
+// in pivot k (D[k][k] = 0 and weights are positive: fl(D[i][k] + D[k][k]) = D[i][k]), so the in-place sweep reads what the
+// reference reads.  Dijkstra semantics: relaxation sweeps with 64-bit atomic minima until nothing changes.  All accesses
+// to D go to L2 (agent-scope relaxed atomics): the waves of the workgroup see each other's updates after a barrier.
+// O(n^3) by ONE workgroup per graph: a route for the occasional large graph, not a fast path.
+__global__ __launch_bounds__(1024) void sp_f64_big_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr,
+                                                          const i32* __restrict__ col_idx, const double* __restrict__ w,
+                                                          const unsigned char* __restrict__ algo, const u64* __restrict__ dist_ptr,
+                                                          double* __restrict__ out, int only_graph) {
+    __shared__ int changed;
+    const int g = only_graph >= 0 ? only_graph : (int)blockIdx.x;
+    const i32 v0 = graph_ptr[g];
+    const i64 n = graph_ptr[g + 1] - v0;
+    if (n <= SPF_MAX_N) return;                            // sp_f64_kernel's graphs
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const unsigned long long INF = SPF_INF_BITS;
+    unsigned long long* D = (unsigned long long*)(out + (only_graph >= 0 ? 0 : dist_ptr[g]));      // positive doubles order like their bit patterns
+    auto ld = [&](i64 i) __attribute__((always_inline)) { return __hip_atomic_load(&D[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto st = [&](i64 i, unsigned long long x) __attribute__((always_inline)) { __hip_atomic_store(&D[i], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (i64 idx = tid; idx < n * n; idx += nt) st(idx, (idx / n == idx % n) ? 0ull : INF);
+    __syncthreads();
+    if (algo[g] == 0) {
+        for (i64 u = tid; u < n; u += nt)
+            for (i32 e = row_ptr[v0 + u]; e < row_ptr[v0 + u + 1]; ++e) {
+                const i64 v = col_idx[e] - v0;
+                if (v != u) st(u * n + v, (unsigned long long)__double_as_longlong(w[e]));
+            }
+        __syncthreads();
+        for (i64 k = 0; k < n; ++k) {
+            for (i64 idx = tid; idx < n * n; idx += nt) {
+                const i64 i = idx / n, j = idx - i * n;
+                const double a = __longlong_as_double((long long)ld(i * n + k)), b = __longlong_as_double((long long)ld(k * n + j));
+                const double c = a + b;
+                if (c < __longlong_as_double((long long)ld(idx))) st(idx, (unsigned long long)__double_as_longlong(c));
+            }
+            __syncthreads();
+        }
+    } else {
+        for (;;) {
+            if (tid == 0) changed = 0;
+            __syncthreads();
+            for (i64 idx = tid; idx < n * n; idx += nt) {              // idx = (source, v): relax the out-edges of v
+                const i64 src = idx / n, v = idx - src * n;
+                const unsigned long long bv = ld(idx);
+                if (bv >= INF) continue;
+                const double dv = __longlong_as_double((long long)bv);
+                for (i32 e = row_ptr[v0 + v]; e < row_ptr[v0 + v + 1]; ++e) {
+                    const i64 t = col_idx[e] - v0;
+                    const unsigned long long c = (unsigned long long)__double_as_longlong(dv + w[e]);
+                    if (c < ld(src * n + t)) {
+                        atomicMin(&D[src * n + t], c);
+                        changed = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!changed) break;
+            __syncthreads();
+        }
+    }
+}
+
 // sort keys of the ranking: the bit pattern of a finite off-diagonal distance, +inf's pattern otherwise
 __global__ void spf_keys_kernel(const i32* __restrict__ graph_ptr, const u64* __restrict__ dist_ptr, const double* __restrict__ D,
                                 u64* __restrict__ keys, i64 n_graphs) {
@@ -858,11 +922,6 @@ __global__ __launch_bounds__(256) void spf_finish_kernel(const i32* __restrict__
 static int sp_compute_dist_f64(gk_ctx* ctx, gk_batch* b, const double* edge_weight, const unsigned char* graph_algo, SpDist& s,
                                u64* total_sq) {
     const i64 N = b->n_graphs;
-    if (b->max_graph_nodes > SPF_MAX_N) {
-        gk_set_error("ShortestPath with non-dyadic float edge weights: graphs above %d vertices are not supported (largest: %d)",
-                     SPF_MAX_N, b->max_graph_nodes);
-        return GK_ERR_UNSUPPORTED;
-    }
     for (i64 e = 0; e < b->n_edges; ++e)
         GK_ARG(edge_weight[e] > 0.0 && edge_weight[e] < 1.0e300, "ShortestPath: float edge weights must be positive and finite");
     GK_TRY(s.sq.alloc(N)); GK_TRY(s.dist_ptr.alloc(N)); GK_TRY(s.total.alloc(1));
@@ -887,11 +946,14 @@ static int sp_compute_dist_f64(gk_ctx* ctx, gk_batch* b, const double* edge_weig
     if (N > 0) GK_HIP_CHECK(hipMemcpyAsync(adev.p, graph_algo, (size_t)N, hipMemcpyHostToDevice, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));          // the host arrays may go away
     if (N == 0 || *total_sq == 0) return GK_OK;
-    const int nmax = b->max_graph_nodes;
+    const int nmax = b->max_graph_nodes < SPF_MAX_N ? b->max_graph_nodes : SPF_MAX_N;
     const size_t lds = (size_t)nmax * nmax * 8;
     GK_TRY(gk_func_lds(ctx, (const void*)sp_f64_kernel, (int)lds));
     sp_f64_kernel<<<dim3((unsigned)N), 1024, lds, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, wdev.p, adev.p, s.dist_ptr.p,
                                                                D.p, -1);
+    if (b->max_graph_nodes > SPF_MAX_N)          // graphs whose matrix does not fit LDS: in HBM, one workgroup each
+        sp_f64_big_kernel<<<dim3((unsigned)N), 1024, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, wdev.p, adev.p, s.dist_ptr.p,
+                                                                       D.p, -1);
     spf_keys_kernel<<<dim3((unsigned)N), 256, 0, ctx->stream>>>(b->graph_ptr, s.dist_ptr.p, D.p, keys.p, N);
     GK_HIP_CHECK(hipGetLastError());
     GK_TRY(gk_dictionary_from_keys(ctx, keys.p, (i64)*total_sq, 63, lab.p, perm.p, cnt.p));
@@ -1128,10 +1190,6 @@ extern "C" int gk_sp_debug_apsp_f64(gk_ctx* ctx, gk_batch* b, const double* edge
     GK_ARG(ctx && b && out_dist && edge_weight && graph_algo, "gk_sp_debug_apsp_f64: null argument");
     GK_ARG(graph >= 0 && graph < b->n_graphs && !b->is_pair_batch, "gk_sp_debug_apsp_f64: bad graph index");
     GK_HIP_CHECK(hipSetDevice(ctx->device));
-    if (b->max_graph_nodes > SPF_MAX_N) {
-        gk_set_error("ShortestPath with non-dyadic float edge weights: graphs above %d vertices are not supported", SPF_MAX_N);
-        return GK_ERR_UNSUPPORTED;
-    }
     std::vector<i32> gp(2);
     GK_HIP_CHECK(hipMemcpyAsync(gp.data(), b->graph_ptr + graph, 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1142,9 +1200,12 @@ extern "C" int gk_sp_debug_apsp_f64(gk_ctx* ctx, gk_batch* b, const double* edge
     GK_TRY(wdev.alloc(b->n_edges > 0 ? (size_t)b->n_edges : 1)); GK_TRY(adev.alloc((size_t)b->n_graphs)); GK_TRY(D.alloc((size_t)(n * n)));
     if (b->n_edges > 0) GK_HIP_CHECK(hipMemcpyAsync(wdev.p, edge_weight, (size_t)b->n_edges * 8, hipMemcpyHostToDevice, ctx->stream));
     GK_HIP_CHECK(hipMemcpyAsync(adev.p, graph_algo, (size_t)b->n_graphs, hipMemcpyHostToDevice, ctx->stream));
-    const size_t lds = (size_t)n * n * 8;
-    GK_TRY(gk_func_lds(ctx, (const void*)sp_f64_kernel, (int)lds));
-    sp_f64_kernel<<<dim3(1), 1024, lds, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, wdev.p, adev.p, nullptr, D.p, (int)graph);
+    if (n <= SPF_MAX_N) {
+        const size_t lds = (size_t)n * n * 8;
+        GK_TRY(gk_func_lds(ctx, (const void*)sp_f64_kernel, (int)lds));
+        sp_f64_kernel<<<dim3(1), 1024, lds, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, wdev.p, adev.p, nullptr, D.p, (int)graph);
+    } else
+        sp_f64_big_kernel<<<dim3(1), 1024, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, b->col_idx, wdev.p, adev.p, nullptr, D.p, (int)graph);
     GK_HIP_CHECK(hipGetLastError());
     GK_HIP_CHECK(hipMemcpyAsync(out_dist, D.p, (size_t)(n * n) * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -31,7 +31,7 @@ shard/gather/rebuild logic.
 """
 import numpy as np
 
-from .batch import GraphBatch, MAX_EDGE_WEIGHT, MAX_FLOAT_WEIGHT_NODES, FLOAT_WEIGHT_LIMIT_MESSAGE
+from .batch import GraphBatch, MAX_EDGE_WEIGHT
 
 
 def shard_bounds(n_graphs, world_size):
@@ -181,15 +181,6 @@ class ShardExchange(object):
         self.weights, self.float_weights, self.from_dict = None, None, None
         mode = int(has_w.item())
         if mode == 2:
-            # the union counts in float64: EVERY graph of the job then goes through the LDS-resident float64 kernel
-            # (sp.hip: sp_f64_kernel), whatever its own weights were -- same limit, same error as the ingestion's
-            if int(a[:, 0].sum()) and int(np.diff(local.graph_ptr).max(initial=0)) > MAX_FLOAT_WEIGHT_NODES:
-                big = torch.tensor([1], dtype=torch.int64, device=dev)
-            else:
-                big = torch.tensor([0], dtype=torch.int64, device=dev)
-            dist.all_reduce(big, op=dist.ReduceOp.MAX, group=group)
-            if int(big.item()):
-                raise NotImplementedError(FLOAT_WEIGHT_LIMIT_MESSAGE)
             if fw_local is None:
                 fw_local = (np.ones(local.n_edges, np.float64) if local.edge_weight is None
                             else local.edge_weight.astype(np.float64) * float(getattr(local, "weight_step", 1.0)))

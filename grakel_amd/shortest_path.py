@@ -117,7 +117,7 @@ class ShortestPath(Kernel):
     that unit (batch.quantise_weights) and ``_enum`` keys are the reference's float distances.  Other positive
     float weights (0.1, ...): the reference's features then depend on how it rounds, so the device reproduces its
     float distances bit for bit -- its floyd_warshall for adjacency input, its dijkstra for dictionary input, as
-    ``algorithm_type`` says (sp.hip: gk_sp_build_f64) -- on graphs of up to 143 vertices.
+    ``algorithm_type`` says (sp.hip: gk_sp_build_f64; graphs above 143 vertices work on their float64 matrix in HBM: slower, no limit).
     """
 
     def __init__(self, n_jobs=None, normalize=False, verbose=False, with_labels=True,

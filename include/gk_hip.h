@@ -294,7 +294,7 @@ int gk_sp_build_levels(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int
  * graph_algo[g] = 0 runs the reference's floyd_warshall (graph.py:1767-1794: adjacency input, or algorithm_type
  * "floyd_warshall"), 1 its dijkstra (graph.py:1712-1764: dictionary input, or "dijkstra") -- see sp.hip for why a float64
  * pivot sweep / relaxation to the fixed point give the same bits.  The distinct distances of the batch are ranked and the
- * ranks stand in for integer distances from there on.  Graphs of up to 143 vertices (GK_ERR_UNSUPPORTED beyond). */
+ * ranks stand in for integer distances from there on.  Graphs of up to 143 vertices keep their float64 matrix in LDS; larger ones work on it in HBM, one workgroup per graph (slower, no limit). */
 int gk_sp_build_f64(gk_ctx* ctx, gk_batch* b, const double* edge_weight, const uint8_t* graph_algo, int with_labels, int n_levels,
                     gk_batch** out_pair_batch, int64_t* out_n_pairs, int64_t* out_n_keys);
 /* float64 distance matrix of one graph as gk_sp_build_f64 computes it (n x n, -1 = unreachable): the lazy `_enum` state */

@@ -33,7 +33,7 @@ from grakel.datasets.base import read_data  # noqa: E402
 
 from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs  # noqa: E402
 sys.path.insert(0, HERE)
-from small_sets import SMALL_SETS, split, sp_inputs, sp_dyadic_graphs, sp_float_graphs  # noqa: E402
+from small_sets import SMALL_SETS, split, sp_inputs, sp_dyadic_graphs, sp_float_graphs, sp_float_big_graphs  # noqa: E402
 
 warnings.filterwarnings("ignore")
 
@@ -201,6 +201,34 @@ def sp_float():
           int(out["K_fit_dij"].sum()), "features", len(out["enum_labels_auto"]),
           "auto == fw:", bool(np.array_equal(out["K_fit_auto"], out["K_fit_fw"])),
           "fw == dij:", bool(np.array_equal(out["K_fit_fw"], out["K_fit_dij"])))
+
+
+def sp_float_big():
+    """Round 4: general float edge weights on graphs above 143 vertices (all three algorithm settings, fit + transform, the
+    float distances of the _enum keys), and CoreFramework over ShortestPath on general float weights (its subgraphs are
+    dictionary-format Graph objects: dijkstra under "auto")."""
+    G = sp_float_big_graphs()
+    tr, te = G[:6], G[6:]
+    out = {}
+    for name, kw in (("auto", {}), ("fw", dict(algorithm_type="floyd_warshall")), ("dij", dict(algorithm_type="dijkstra"))):
+        sp = ShortestPath(normalize=False, **kw)
+        out["K_fit_" + name] = as_int(sp.fit_transform(tr))
+        out["K_tr_" + name] = as_int(sp.transform(te))
+        keys = sorted(sp._enum.items(), key=lambda kv: kv[1])
+        out["enum_n_" + name] = np.array([len(keys)])
+        out["enum_dist_bits_" + name] = np.array([float(k[2]) for k, _ in keys], np.float64).view(np.int64)
+    from grakel import CoreFramework
+    S = [g for i, g in enumerate(sp_float_graphs()) if i < 4 or i % 7]      # undirected only: the reference's core_number needs symmetric neighbourhoods
+    ctr, cte = S[:24], S[24:]
+    for name, kw in (("auto", {}), ("fw", dict(algorithm_type="floyd_warshall"))):
+        cf = CoreFramework(base_graph_kernel=(ShortestPath, kw))
+        out["K_core_fit_" + name] = as_int(cf.fit_transform(ctr))
+        out["K_core_tr_" + name] = as_int(cf.transform(cte))
+    cfn = CoreFramework(normalize=True)
+    out["K_core_fit_norm"] = cfn.fit_transform(ctr)
+    np.savez_compressed(os.path.join(HERE, "sp_float_big.npz"), **out)
+    print("sp_float_big: sums auto / fw / dij", int(out["K_fit_auto"].sum()), int(out["K_fit_fw"].sum()), int(out["K_fit_dij"].sum()),
+          "features", int(out["enum_n_auto"][0]), "core sums", int(out["K_core_fit_auto"].sum()), int(out["K_core_fit_fw"].sum()))
 
 
 def mutag_state(n_graphs=60):
@@ -371,6 +399,7 @@ if __name__ == "__main__":
     ap.add_argument("--only-dyadic", action="store_true", help="only the float-weight ShortestPath fixture (sp_dyadic.npz)")
     ap.add_argument("--only-round3", action="store_true", help="only round3.npz (WL over EdgeHistogram, more than 48 levels)")
     ap.add_argument("--only-float", action="store_true", help="only sp_float.npz (ShortestPath on general float edge weights)")
+    ap.add_argument("--only-float-big", action="store_true", help="only sp_float_big.npz (general float weights above 143 vertices, CoreFramework)")
     a = ap.parse_args()
     print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
     if a.only_round3:
@@ -378,6 +407,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only_float:
         sp_float()
+        sys.exit(0)
+    if a.only_float_big:
+        sp_float_big()
         sys.exit(0)
     sp_dyadic()
     if a.only_dyadic:
@@ -396,4 +428,5 @@ if __name__ == "__main__":
         er_config("config3", 10000, 100, 0.05, 5, 0, 5, 20000, with_oa=False)
     round3()
     sp_float()
+    sp_float_big()
 

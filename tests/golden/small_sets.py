@@ -86,3 +86,30 @@ def sp_dyadic_graphs(n_graphs=24, seed=11):
         else:
             out.append([A, lab])
     return out
+
+
+def sp_float_big_graphs(seed=5):
+    """General float edge weights on graphs ABOVE 143 vertices (round 4: the float64 distance matrix no longer has to fit
+    LDS): three sparse graphs of 150-200 vertices -- a symmetric adjacency matrix (the reference's floyd_warshall under
+    "auto"), an edge dictionary (its dijkstra), a directed adjacency matrix -- and five small ones so that features are
+    shared.  Sparse on purpose: the reference's floyd_warshall is a Python triple loop."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for g, n in enumerate((150, 180, 200, 9, 10, 11, 12, 8)):
+        A = np.zeros((n, n))
+        p = 2.2 / n if n > 100 else 0.3
+        for i in range(n):
+            for j in range(n):
+                if i == j or (g != 2 and j < i):
+                    continue
+                if rs.rand() < p:
+                    w = [rs.randint(1, 20) / 10.0, round(rs.rand() * 2 + 0.01, 2)][g % 2]
+                    A[i, j] = w
+                    if g != 2:
+                        A[j, i] = w
+        lab = {i: "xy"[int(rs.randint(0, 2))] for i in range(n)}
+        if g == 1 or g == 4:
+            out.append([{i: {j: float(A[i, j]) for j in range(n) if A[i, j] > 0} for i in range(n)}, lab])
+        else:
+            out.append([A, lab])
+    return out

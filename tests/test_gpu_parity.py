@@ -891,10 +891,31 @@ def test_sp_general_float_weights_against_reference_goldens(gk, gkopt, route):
     sp, spo = gk.ShortestPath(), O.SPOracle()
     sp.fit(ints), spo.fit_transform(ints)
     assert np.array_equal(sp.transform(te), spo.transform(te))
-    big = np.zeros((150, 150))
-    big[0, 1] = big[1, 0] = 0.1
-    with pytest.raises(NotImplementedError):                  # the float64 matrix of a graph has to fit LDS
-        gk.ShortestPath().fit_transform([[big, {i: 'a' for i in range(150)}]])
+
+
+def test_sp_general_float_weights_above_143_vertices_and_core_framework(gk):
+    """Round 4: a graph whose float64 distance matrix does not fit LDS works on it in HBM (sp.hip: sp_f64_big_kernel) -- the
+    reference's three different matrices on graphs of 150-200 vertices, the float distances of the feature keys bit for bit;
+    CoreFramework over ShortestPath on general float weights (its subgraphs: dijkstra under "auto").  Goldens from the real
+    reference (tests/golden/sp_float_big.npz)."""
+    from golden.small_sets import sp_float_big_graphs, sp_float_graphs
+    z = load_golden("sp_float_big.npz")
+    G = sp_float_big_graphs()
+    tr, te = G[:6], G[6:]
+    for name, kw in (("auto", {}), ("fw", dict(algorithm_type="floyd_warshall")), ("dij", dict(algorithm_type="dijkstra"))):
+        sp = gk.ShortestPath(**kw)
+        assert np.array_equal(sp.fit_transform(tr), z["K_fit_" + name]), name
+        assert np.array_equal(sp.transform(te), z["K_tr_" + name]), name
+        keys = sorted(sp._enum.items(), key=lambda kv: kv[1])
+        assert np.array([float(k[2]) for k, _ in keys]).view(np.int64).tolist() == z["enum_dist_bits_" + name].tolist()
+    S = [g for i, g in enumerate(sp_float_graphs()) if i < 4 or i % 7]
+    ctr, cte = S[:24], S[24:]
+    for name, kw in (("auto", {}), ("fw", dict(algorithm_type="floyd_warshall"))):
+        cf = gk.CoreFramework(base_graph_kernel=(gk.ShortestPath, kw))
+        assert np.array_equal(cf.fit_transform(ctr), z["K_core_fit_" + name]), name
+        assert np.array_equal(cf.transform(cte), z["K_core_tr_" + name]), name
+    with np.errstate(divide="ignore", invalid="ignore"):
+        assert np.allclose(gk.CoreFramework(normalize=True).fit_transform(ctr), z["K_core_fit_norm"], rtol=1e-12, atol=0, equal_nan=True)
 
 
 def test_errors_match_reference(gk):

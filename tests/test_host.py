@@ -337,8 +337,8 @@ def test_sp_ingestion_vertex_order_weights_and_errors():
     assert u.edge_weight is None and u.float_weight.tolist() == [2.0, 2.0, 0.1, 0.3, 0.3] and u.from_dict.tolist() == [0, 1, 0]
     assert u.slice_graphs(1, 3).float_weight.tolist() == [0.1, 0.3, 0.3]
     big = np.zeros((150, 150)); big[0, 1] = big[1, 0] = 0.1
-    with pytest.raises(NotImplementedError):             # general floats: the float64 matrix of a graph has to fit LDS
-        sp_batch_from_input([[big, {i: 0 for i in range(150)}]], True)
+    gbig, _ = sp_batch_from_input([[big, {i: 0 for i in range(150)}]], True)      # round 4: no size limit for general floats any more
+    assert gbig.float_weight.tolist() == [0.1, 0.1] and gbig.n_nodes == 150
     with pytest.raises(NotImplementedError):
         sp_batch_from_input([[np.array([[0, -0.1], [-0.1, 0]]), {0: 1, 1: 1}]], True)
     gb, _ = sp_batch_from_input([[np.array([[0, 3], [0, 0]])]], False)

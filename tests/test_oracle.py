@@ -220,6 +220,24 @@ def test_sp_general_float_weights_against_reference():
     assert np.array_equal(O.SPOracle(with_labels=False).fit_transform([[g[0]] for g in tr]), z["K_fit_unlabelled"])
 
 
+def test_sp_general_float_weights_above_143_vertices_against_reference():
+    """Round 4 golden (tests/golden/sp_float_big.npz, from the real reference): general float weights on graphs of 150-200
+    vertices, the three algorithm settings -- three different matrices again -- with the float distances of the feature keys."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from small_sets import sp_float_big_graphs
+    z = load_golden("sp_float_big.npz")
+    G = sp_float_big_graphs()
+    tr, te = G[:6], G[6:]
+    assert not np.array_equal(z["K_fit_auto"], z["K_fit_fw"]) and not np.array_equal(z["K_fit_fw"], z["K_fit_dij"])
+    for name, algo in (("auto", "auto"), ("fw", "floyd_warshall"), ("dij", "dijkstra")):
+        sp = O.SPOracle(algorithm_type=algo)
+        assert np.array_equal(sp.fit_transform(tr), z["K_fit_" + name]), name
+        assert np.array_equal(sp.transform(te), z["K_tr_" + name]), name
+        keys = sorted(sp.enum.items(), key=lambda kv: kv[1])
+        assert np.array([float(k[2]) for k, _ in keys]).view(np.int64).tolist() == z["enum_dist_bits_" + name].tolist()
+
+
 def test_what_general_float_weights_mean_in_the_reference():
     """The reference keys ShortestPath features by the float distance as computed (shortest_path.py:389,412-499): with
     weights like 0.1 the key depends on rounding -- a path 0.1 + 0.2 (0.30000000000000004) and an edge 0.3 are DIFFERENT
