@@ -44,7 +44,8 @@ I8_DENSE_PEAK_TOPS = 5000.0
 # (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, summarised by
 # tools/pmc_summary.py): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read,
 # MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.  NOT measured in this run.
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_bytes.csv")
+PMC_FILES = [os.path.join(ROOT, "profiles", "r04_pmc_hbm_bytes.csv"), os.path.join(ROOT, "profiles", "r03_pmc_hbm_bytes.csv")]
+PMC_FILE = next((p for p in PMC_FILES if os.path.exists(p)), PMC_FILES[0])
 GRAM_KERNELS = ("gram_ws_kernel", "gram_tile_kernel")
 
 
@@ -466,7 +467,7 @@ def main():
                             "frac_of_8TBps": rb / (phases["relabel"] * 1e-3) / 8e12},
                 "features": {"algorithmic_bytes": fb, "GB_per_s": fb / (phases["features"] * 1e-3) / 1e9,
                              "frac_of_8TBps": fb / (phases["features"] * 1e-3) / 8e12},
-                "note": "dependent launches of 3-60 us over <= 1 M-element arrays: latency bound (DESIGN.md 4)"}
+                "note": "dependent launches of 3-70 us over <= 1 M-element arrays, 4 per WL level: launch / latency bound (DESIGN.md 4)"}
         traffic = gram_pmc_traffic_bytes(a.workload if full_size else "", world)
         out = {
             "metric": "graph-pairs/sec for NxN WL-subtree(h=%d) fit_transform" % h,
@@ -503,8 +504,8 @@ def main():
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r03_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE, KiB) -- a committed PMC "
-                                  "pass of this script, NOT measured in this run" if traffic else None,
+                "traffic_source": "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE, KiB) -- a committed PMC "
+                                  "pass of this script, NOT measured in this run" % os.path.basename(PMC_FILE) if traffic else None,
                 "algorithmic_bytes_per_launch": gram_bytes, "avg_launch_ms": gram_avg_ms,
                 "mfma_view": {
                     # the same launch priced against the matrix pipe: with fp4 operands its floor (flops / peak)

@@ -82,6 +82,9 @@ extern "C" int gk_destroy(gk_ctx* ctx) {
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     cache_release_all(ctx);
     for (auto& kv : ctx->cache.live) (void)hipFree(kv.first);   // leaked by the caller: reclaim
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return GK_OK;
@@ -165,6 +168,24 @@ int gk_readback2(gk_ctx* ctx, const u32* src1, int n1, const u32* src2, int n2, 
     mbox_post2_kernel<<<1, 256, 0, ctx->stream>>>(src1, n1, src2, n2, ctx->mbox_dev, seq);
     GK_HIP_CHECK(hipGetLastError());
     return gk_mbox_wait(ctx, seq, dst_host, n1 + n2);
+}
+
+int gk_side_fork(gk_ctx* ctx, hipStream_t* side) {
+    if (!ctx->side_stream) {
+        GK_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        GK_HIP_CHECK(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+        GK_HIP_CHECK(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+    }
+    GK_HIP_CHECK(hipEventRecord(ctx->side_fork, ctx->stream));
+    GK_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+    *side = ctx->side_stream;
+    return GK_OK;
+}
+
+int gk_side_join(gk_ctx* ctx) {
+    GK_HIP_CHECK(hipEventRecord(ctx->side_join, ctx->side_stream));
+    GK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    return GK_OK;
 }
 
 // Pinned host memory for Gram outputs: the float64 matrix is 8 N^2 bytes (800 MB at 10 k graphs) and a

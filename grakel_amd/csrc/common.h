@@ -96,6 +96,10 @@ struct gk_ctx {
     BlockCache cache;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
+    // second stream for kernels that are independent of what the main stream runs next and too small to fill the chip alone
+    // (sp.hip: the two register Floyd-Warshall kernels side by side); fork / join by events, created on first use
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // user timer
     hipEvent_t pv0 = nullptr, pv1 = nullptr;   // profile timer
     bool profile = false;
@@ -117,6 +121,9 @@ struct gk_ctx {
 // Read n_words (<= GK_MBOX_WORDS - 1) u32 values at device address src back to dst_host, ordered after
 // everything queued on the context's stream so far.  Returns when the values have arrived.
 int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words);
+// fork: the side stream waits for everything queued on the main stream so far; join: the main stream waits for the side stream
+int gk_side_fork(gk_ctx* ctx, hipStream_t* side);
+int gk_side_join(gk_ctx* ctx);
 u32 gk_mbox_begin(gk_ctx* ctx);                                     // 0: no mailbox, use gk_readback
 int gk_mbox_wait(gk_ctx* ctx, u32 seq, u32* dst_host, int n_words);
 

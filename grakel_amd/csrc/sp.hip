@@ -668,9 +668,12 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     if (use_pk) sp_bin_pk_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, N, cap, cls_count.p, cls_list.p);
     else sp_bin_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, N, cap, cls_count.p, cls_list.p);
     u32 h_cls[10];
-    GK_HIP_CHECK(hipMemcpyAsync(total_sq, s.total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP_CHECK(hipMemcpyAsync(h_cls, cls_count.p, 40, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    {   // one mailbox round trip (a hipMemcpyAsync + stream drain pair costs a staging-copy kernel and ~25 us of idle device)
+        u32 hb[12];
+        GK_TRY(gk_readback2(ctx, (const u32*)s.total.p, 2, cls_count.p, 10, hb));
+        *total_sq = (u64)hb[0] | ((u64)hb[1] << 32);
+        for (int k = 0; k < 10; ++k) h_cls[k] = hb[2 + k];
+    }
     GK_ARG(*total_sq < (1ull << 31), "ShortestPath: sum of n^2 exceeds int32 item indexing");
     GK_TRY(s.dist.alloc(*total_sq));
     const i32* w = nullptr;
@@ -690,12 +693,17 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
             wg += (int)cdiv(h_cls[c], SP_REG_WAVES);
         }
         C.first[8] = wg;
+        const u32 n_big = h_cls[4] + h_cls[5] + h_cls[6] + h_cls[7];
+        // the two register kernels work on disjoint graphs and neither fills the chip (a few thousand waves, each one long
+        // dependent chain): side by side on two streams instead of one after the other (config 4: 65 + 58 us -> their maximum)
+        const bool both = C.first[4] > 0 && n_big > 0;
+        hipStream_t st_pk = ctx->stream;
+        if (both) GK_TRY(gk_side_fork(ctx, &st_pk));
         if (C.first[4] > 0) {
-            sp_fw_pk_kernel<0><<<dim3((unsigned)C.first[4]), 64 * SP_REG_WAVES, SP_REG_WAVES * 64 * 72 * 2, ctx->stream>>>(
+            sp_fw_pk_kernel<0><<<dim3((unsigned)C.first[4]), 64 * SP_REG_WAVES, SP_REG_WAVES * 64 * 72 * 2, st_pk>>>(
                 C, cls_list.p, N, b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p);
             ++n_launch;
         }
-        const u32 n_big = h_cls[4] + h_cls[5] + h_cls[6] + h_cls[7];
         if (n_big > 0) {                     // 65..128 vertices: a workgroup per graph, columns split over its four waves
             const int lds = (128 * 136 + 256) * 2;
             sp_fw_pkw_kernel<<<dim3(n_big), 256, lds, ctx->stream>>>(
@@ -703,6 +711,7 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
                 s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p);
             ++n_launch;
         }
+        if (both) GK_TRY(gk_side_join(ctx));
         if (h_cls[8] > 0 && nmax > 128) {
             const int nfw = nmax < cap ? nmax : cap;
             const size_t lds = (size_t)nfw * (nfw | 1) * 4;
@@ -1032,9 +1041,11 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
     GK_TRY(gk_scan_u32(ctx, s.pair_count.p, pair_base, N, true, ptotal.p));
     GK_HIP_CHECK(hipMemcpyAsync(pair_base + N, ptotal.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
     u32 h_pairs = 0, h_maxd = 0;
-    GK_HIP_CHECK(hipMemcpyAsync(&h_pairs, ptotal.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP_CHECK(hipMemcpyAsync(&h_maxd, s.maxd.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    {
+        u32 hb[2];
+        GK_TRY(gk_readback2(ctx, ptotal.p, 1, s.maxd.p, 1, hb));
+        h_pairs = hb[0], h_maxd = hb[1];
+    }
     const u64 d1 = (u64)h_maxd + 1;
     gk_batch* pb = new gk_batch();
     pb->ctx = ctx, pb->is_pair_batch = true;
@@ -1074,12 +1085,11 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
             pb->sp_node_label = (i32*)q;
             u32 h_nk = 0;
             if (hipMemcpyAsync(pb->sp_node_ptr, b->graph_ptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-                (V > 0 && hipMemcpyAsync(pb->sp_node_label, b->labels, (size_t)V * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) ||
-                hipMemcpyAsync(&h_nk, nk.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                (V > 0 && hipMemcpyAsync(pb->sp_node_label, b->labels, (size_t)V * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)) {
                 gk_set_error("gk_sp_build: %s", hipGetErrorString(hipGetLastError()));
                 return fail(GK_ERR_HIP);
             }
+            if ((r = gk_readback(ctx, nk.p, &h_nk, 1))) return fail(r);
             pb->sp_dist = s.dist.p, s.dist.p = nullptr;             // the matrices move into the pair batch
             pb->sp_dist_ptr = s.dist_ptr.p, s.dist_ptr.p = nullptr;
             pb->sp_hist = true, pb->sp_L = (i64)L0, pb->sp_dcap = (i64)d1, pb->sp_keyspace = (i64)keyspace, pb->sp_src_nodes = V;

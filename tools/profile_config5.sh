@@ -2,7 +2,7 @@
 # Kernel-level profile of the config-5 step (50 000 graphs, n=30): kernel stats, step timeline, HBM counter passes.
 #   tools/profile_config5.sh r03   -> gpurun_out/r03/config5_{kernel_stats.csv,step_timeline.txt,pmc_hbm_bytes.csv,levels.txt}
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"

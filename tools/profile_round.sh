@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's profiles of the config-3 bench on the GPU box (run from the repo root):
-#   tools/profile_round.sh r02        -> gpurun_out/r02/{kernel_stats.csv, step_timeline.txt, pmc_*.csv, bench_n1.json}
+#   tools/profile_round.sh r04        -> gpurun_out/r04/{kernel_stats.csv, step_timeline.txt, pmc_*.csv, bench_n1.json}
 # Kernel trace and every counter group are separate rocprofv3 runs (--pmc is never combined with other traces).
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
