@@ -1758,3 +1758,8 @@ def test_integration_md_ctypes_stub_runs_verbatim(gk, mutag_graphs):
     Kn, _ = ns["wl_gram"](gb.graph_ptr, gb.row_ptr, gb.col_idx, gb.node_label, gb.n_labels, 5, True)
     d = np.sqrt(np.diagonal(K))
     assert np.allclose(Kn, K / np.outer(d, d), rtol=REL_TOL, atol=0)
+    # ... and its transform stub: the first 150 graphs fitted, the rest looked up in their dictionaries
+    fit, tgt = gb.slice_graphs(0, 150), gb.slice_graphs(150, gb.n_graphs)
+    Kt = ns["wl_transform"]((fit.graph_ptr, fit.row_ptr, fit.col_idx, fit.node_label),
+                            (tgt.graph_ptr, tgt.row_ptr, tgt.col_idx, tgt.node_label), gb.n_labels, 5)
+    assert Kt is not None and np.array_equal(Kt, K[150:, :150])
