@@ -78,6 +78,7 @@ struct gk_opts {
     int gram_pair_cap = 0;       // test hook: capacity of the per-tile pair buckets (0: four times the mean load + 128)
     int gram_fold = 0;           // rare labels' pair updates INSIDE the tile kernel (which then normalises in its epilogue as well):
                                  // 0 = when it pays (normalised jobs whose separate normalisation pass costs more than the binning), 1 = whenever legal, 2 = never
+    int gram_no_split8 = 0;      // counts above 127: 1 = float64 side operand (gram_f64_kernel) instead of split int8 columns
     int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
     int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
     // ShortestPath
@@ -320,6 +321,11 @@ struct gk_feat {
     // narrow) float64 side operand whose product is accumulated onto K after the int8 GEMM
     i64 n_cols_wide = 0, n_cols_wide_pad = 0;
     double* phi_w = nullptr;    // [n_rows_pad][n_cols_wide_pad]
+    // labels with counts above 127 as split int8 columns (features.h: COL_SPLIT_BASE): phi is the LEFT operand of the
+    // Gram product, phi_r the RIGHT one (same layout; the rows differ in the split columns only).  nullptr: phi on both sides
+    void* phi_r = nullptr;
+    int split_parts = 0;
+    i64 n_split_labels = 0;
     // graph-major builder (features_gm.hip): the rare labels as lists instead of label-major triples
     bool gm = false;
     i32* gm_low_q = nullptr;    // [n_low_cols] label index of each rare label

@@ -12,6 +12,12 @@
 
 #define FEAT_MAX_LEVELS 48
 #define COL_BYTE_BASE (1 << 30)   // colid >= this: column (colid - base) of the int8 region
+// colid >= this: a label whose counts exceed 127, SPLIT into parts^2 int8 columns starting at (colid - base) of the int8
+// region.  A count c is written as parts digits a_0..a_{parts-1} <= 127 with sum c; the LEFT operand row holds
+// a_p at column p*parts+r, the RIGHT operand row holds a_r there, so that the dot product of a left row with a right
+// row contributes sum_p sum_r a_p(i) a_r(j) = c(i) c(j): the exact product, in the int8 GEMM, no float64 side operand.
+#define COL_SPLIT_BASE ((1 << 30) + (1 << 29))
+#define GM_SPLIT_MAX_PARTS 3
 
 // graph-major builder: meta layout
 #define GM_META_PRIM 0
@@ -19,6 +25,7 @@
 #define GM_META_F64 2
 #define GM_META_RARE 3
 #define GM_META_RARE_ENTRIES 4
+#define GM_META_SPLIT 5           // parts of the split columns (0: labels with counts above 127 go to the float64 operand)
 #define GM_META_MAXC 8            // 64 partial maxima
 #define GM_META_NNZ 72            // 64 partial sums
 #define GM_META_WORDS 136

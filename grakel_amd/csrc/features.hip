@@ -457,7 +457,7 @@ extern "C" int gk_features_destroy(gk_feat* f) {
     if (f->ev1) (void)hipEventDestroy(f->ev1);
     for (void* p : f->arena)
         if (p) gk_dev_free(ctx, p);
-    void* ptrs[] = {f->meta, f->selfk, f->phi, f->phi_w, f->K};
+    void* ptrs[] = {f->meta, f->selfk, f->phi, f->phi_r, f->phi_w, f->K};
     for (void* p : ptrs)
         if (p) gk_dev_free(ctx, p);
     delete f;
@@ -731,13 +731,12 @@ extern "C" int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk) {
     return GK_OK;
 }
 
-extern "C" int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi) {
-    GK_ARG(ctx && f && out_phi, "gk_features_debug_phi: null argument");
+static int debug_operand(gk_ctx* ctx, gk_feat* f, const void* operand, double* out_phi) {
     const i64 N = f->n_graphs, D = f->n_cols, ld = f->n_cols_pad, n1 = f->n_cols1;
     const i64 prim0 = (i64)f->k8_steps * 128;      // first byte of the primary region
     static const double fp4_value[16] = {0, 0.5, 1, 1.5, 2, 3, 4, 6, -0.0, -0.5, -1, -1.5, -2, -3, -4, -6};
     std::vector<unsigned char> h((size_t)N * ld);
-    GK_HIP_CHECK(hipMemcpyAsync(h.data(), f->phi, h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipMemcpyAsync(h.data(), operand, h.size(), hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (i64 i = 0; i < N; ++i)
         for (i64 j = 0; j < D; ++j) {       // columns: primary class first, then the secondary int8 class
@@ -747,4 +746,15 @@ extern "C" int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi) {
             else out_phi[i * D + j] = (double)((const int8_t*)row)[prim0 + j];
         }
     return GK_OK;
+}
+
+extern "C" int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi) {
+    GK_ARG(ctx && f && out_phi, "gk_features_debug_phi: null argument");
+    return debug_operand(ctx, f, f->phi, out_phi);
+}
+
+extern "C" int gk_features_debug_phi_right(gk_ctx* ctx, gk_feat* f, double* out_phi, int* split_parts) {
+    GK_ARG(ctx && f && out_phi, "gk_features_debug_phi_right: null argument");
+    if (split_parts) *split_parts = f->split_parts;
+    return debug_operand(ctx, f, f->phi_r ? f->phi_r : f->phi, out_phi);
 }

@@ -430,7 +430,20 @@ __device__ __forceinline__ Gm3 gm3_shfl_down(const Gm3& x, int off) {
 struct GmColumns {
     GmLabelArrays A; const GmTable* Tb; int symmetric; int low_df; int kind; int prim_max; int wide_above; u32* meta;
     const u32* wgmeta; int n_wg;                  // gm_pairs_kernel's per-workgroup (largest count, entries)
-    __device__ __forceinline__ Gm3 value(i64 q) const {
+    int allow_split;                              // labels with counts above wide_above: split int8 columns (features.h) when <= GM_SPLIT_MAX_PARTS parts do
+    // parts of the split columns from the largest count of the job (one wave; every workgroup of the scans derives the same)
+    __device__ __forceinline__ int parts_by_wave(int lane) const {
+        if (!allow_split) return 0;
+        u32 m = 0;
+        for (int k = lane; k < n_wg; k += 64) m = wgmeta[2 * k] > m ? wgmeta[2 * k] : m;
+        for (int off = 32; off > 0; off >>= 1) {
+            const u32 o = __shfl_xor(m, off, 64);
+            m = o > m ? o : m;
+        }
+        const u32 p = (m + 126u) / 127u;
+        return (p >= 2u && p <= (u32)GM_SPLIT_MAX_PARTS) ? (int)p : 0;
+    }
+    __device__ __forceinline__ Gm3 value(i64 q, int parts) const {
         Gm3 v{0, 0, 0};
         const u32 df = A.df[q];
         if (df == 0) return v;
@@ -441,6 +454,7 @@ struct GmColumns {
         if (kind) v.a = m;                                   // unary expansion: one 0/1 column per count level
         else if ((int)m <= prim_max) v.a = 1;
         else if ((int)m <= wide_above) v.a = 1ull << 32;
+        else if (parts) v.a = (u64)(parts * parts) << 32, v.b = 1;      // split: parts^2 int8 columns (v.b counts the labels)
         else v.b = 1;
         return v;
     }
@@ -451,11 +465,13 @@ struct GmColumns {
             A.roff[q] = (u32)(incl.c - v.c);
             A.low_q[(u32)(incl.b >> 32) - 1] = (i32)q;
         } else if (v.a & 0xffffffffull) c = (i32)((u32)(incl.a & 0xffffffffull) - (u32)(v.a & 0xffffffffull));
+        else if ((v.a >> 32) > 1) c = COL_SPLIT_BASE + (i32)((u32)(incl.a >> 32) - (u32)(v.a >> 32));
         else if (v.a >> 32) c = COL_BYTE_BASE + (i32)((u32)(incl.a >> 32) - 1);
         else if (v.b & 0xffffffffull) c = -4 - (i32)((u32)(incl.b & 0xffffffffull) - 1);
         A.colid[q] = c;
     }
-    __device__ __forceinline__ void finish(const Gm3& t) const {
+    __device__ __forceinline__ void finish(const Gm3& t, int parts) const {
+        meta[GM_META_SPLIT] = (u32)parts;
         meta[GM_META_PRIM] = (u32)(t.a & 0xffffffffull), meta[GM_META_INT8] = (u32)(t.a >> 32);
         meta[GM_META_F64] = (u32)(t.b & 0xffffffffull), meta[GM_META_RARE] = (u32)(t.b >> 32);
         meta[GM_META_RARE_ENTRIES] = (u32)t.c;
@@ -470,11 +486,12 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_sums_kernel(const GmColumn
     __shared__ Gm3 wsum[G3_THREADS / 64];
     const i64 base = (i64)blockIdx.x * G3_TILE;
     const i64 Q = f.Tb->Q;                      // the grid covers the bound the arrays were allocated for
+    const int parts = f.parts_by_wave(threadIdx.x & 63);
     Gm3 s{0, 0, 0};
 #pragma unroll
     for (int i = 0; i < G3_ITEMS; ++i) {
         const i64 idx = base + (i64)i * G3_THREADS + threadIdx.x;
-        if (idx < Q) s += f.value(idx);
+        if (idx < Q) s += f.value(idx, parts);
     }
     for (int off = 32; off > 0; off >>= 1) s += gm3_shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
@@ -493,6 +510,7 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
     const i64 Q = f.Tb->Q;
     const i64 last_tile = Q > 0 ? (Q - 1) / G3_TILE : 0;
     if ((i64)blockIdx.x > last_tile) return;         // the grid covers the bound the arrays were allocated for
+    const int parts = f.parts_by_wave(lane);
     if (blockIdx.x == 0 && w == 0) {                  // fold the pair kernel's per-workgroup statistics
         u32 m = 0, e = 0;
         for (int k = lane; k < f.n_wg; k += 64) m = f.wgmeta[2 * k] > m ? f.wgmeta[2 * k] : m, e += f.wgmeta[2 * k + 1];
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
     for (int i = 0; i < G3_ITEMS; ++i) {
         const i64 idx = tile0 + (i64)i * G3_THREADS + threadIdx.x;
         Gm3 v{0, 0, 0};
-        if (idx < Q) v = f.value(idx);
+        if (idx < Q) v = f.value(idx, parts);
         Gm3 inc = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -538,7 +556,16 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
         carry += row;
         __syncthreads();
     }
-    if ((i64)blockIdx.x == last_tile && threadIdx.x == 0) f.finish(carry);
+    if ((i64)blockIdx.x == last_tile && threadIdx.x == 0) f.finish(carry, parts);
+}
+
+// digits of a split column group (features.h: COL_SPLIT_BASE): left rows hold digit p at p*parts+r, right rows digit r
+__device__ __forceinline__ void gm_split_write(unsigned char* row, i32 base, u32 c, int parts, int right) {
+    for (int p = 0; p < parts; ++p) {
+        const u32 lo = 127u * (u32)p;
+        const unsigned char a = (unsigned char)(c > lo ? (c - lo > 127u ? 127u : c - lo) : 0u);
+        for (int r = 0; r < parts; ++r) row[base + (right ? r * parts + p : p * parts + r)] = a;
+    }
 }
 
 // one workgroup per graph: the operand row in LDS (row_bytes <= GM_ROW_LDS_MAX), written once
@@ -547,7 +574,8 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
                                                       const u32* __restrict__ cnt, const u32* __restrict__ ent_n, i64 n_graphs,
                                                       int8_t* __restrict__ phi, i64 ld, i64 prim0 /* first byte of the primary region */,
                                                       int fp4, int kind, double* __restrict__ phi_w, i64 ldw,
-                                                      i32* __restrict__ low_graph, i32* __restrict__ low_cnt, i32* __restrict__ low_lab) {
+                                                      i32* __restrict__ low_graph, i32* __restrict__ low_cnt, i32* __restrict__ low_lab,
+                                                      int8_t* __restrict__ phi_r, int parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row[];
     const i64 g = blockIdx.x;
     const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
@@ -556,6 +584,7 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
     for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) ((uint4*)row)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int n = v1 - v0;
+    int seen_split = 0;
     for (int t = threadIdx.x; t < n * P.L; t += blockDim.x) {
         const int j = t / n, i = t - j * n;
         if ((u32)i >= slots[j]) continue;
@@ -563,7 +592,8 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
         if (!c) continue;
         const i64 q = ent_lab[(i64)j * V + v0 + i];                                     // index in the concatenated label space
         const i32 col = A.colid[q];
-        if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;          // secondary int8 region: bytes [0, prim0)
+        if (col >= COL_SPLIT_BASE) gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 0), seen_split = 1;
+        else if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;     // secondary int8 region: bytes [0, prim0)
         else if (col >= 0) {
             if (kind) {                                                                 // unary run of ones
                 for (u32 x = 0; x < c; ++x) {
@@ -584,6 +614,21 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
     __syncthreads();
     uint4* dst = (uint4*)(phi + g * ld);
     for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) dst[i] = ((const uint4*)row)[i];
+    if (!phi_r) return;
+    // the right operand's row: the same but for the digits of the split columns
+    if (__syncthreads_or(seen_split)) {
+        for (int t = threadIdx.x; t < n * P.L; t += blockDim.x) {
+            const int j = t / n, i = t - j * n;
+            if ((u32)i >= slots[j]) continue;
+            const u32 c = cnt[(i64)j * V + v0 + i];
+            if (!c) continue;
+            const i32 col = A.colid[ent_lab[(i64)j * V + v0 + i]];
+            if (col >= COL_SPLIT_BASE) gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 1);
+        }
+        __syncthreads();
+    }
+    dst = (uint4*)(phi_r + g * ld);
+    for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) dst[i] = ((const uint4*)row)[i];
 }
 
 // The same with one WAVE per graph (four graphs per workgroup) for operand rows of up to GM_ROW_WAVE_MAX bytes: 50 000
@@ -595,7 +640,8 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
                                                            const u32* __restrict__ cnt, const u32* __restrict__ ent_n, i64 n_graphs,
                                                            int8_t* __restrict__ phi, i64 ld, i64 prim0, int fp4, int kind,
                                                            double* __restrict__ phi_w, i64 ldw, i32* __restrict__ low_graph,
-                                                           i32* __restrict__ low_cnt, i32* __restrict__ low_lab, i64 n_rows_pad) {
+                                                           i32* __restrict__ low_cnt, i32* __restrict__ low_lab, i64 n_rows_pad,
+                                                           int8_t* __restrict__ phi_r, int parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row_all[];
     __shared__ u32 slots_all[4][FEAT_MAX_LEVELS];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -605,6 +651,10 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
         if (g < n_rows_pad) {
             uint4* dst = (uint4*)(phi + g * ld);
             for (i64 i = lane; i < ld / 16; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+            if (phi_r) {
+                dst = (uint4*)(phi_r + g * ld);
+                for (i64 i = lane; i < ld / 16; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+            }
         }
         return;
     }
@@ -616,6 +666,7 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int n = v1 - v0;
+    int seen_split = 0;
     for (int t = lane; t < n * P.L; t += 64) {
         const int j = t / n, i = t - j * n;
         if ((u32)i >= slots[j]) continue;
@@ -623,7 +674,8 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
         if (!c) continue;
         const i64 q = ent_lab[(i64)j * V + v0 + i];
         const i32 col = A.colid[q];
-        if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;
+        if (col >= COL_SPLIT_BASE) gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 0), seen_split = 1;
+        else if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;
         else if (col >= 0) {
             if (kind) {
                 for (u32 x = 0; x < c; ++x) {
@@ -645,6 +697,23 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     uint4* dst = (uint4*)(phi + g * ld);
     for (i64 i = lane; i < ld / 16; i += 64) dst[i] = ((const uint4*)row)[i];
+    if (!phi_r) return;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (__any(seen_split)) {
+        for (int t = lane; t < n * P.L; t += 64) {
+            const int j = t / n, i = t - j * n;
+            if ((u32)i >= slots[j]) continue;
+            const u32 c = cnt[(i64)j * V + v0 + i];
+            if (!c) continue;
+            const i32 col = A.colid[ent_lab[(i64)j * V + v0 + i]];
+            if (col >= COL_SPLIT_BASE) gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    dst = (uint4*)(phi_r + g * ld);
+    for (i64 i = lane; i < ld / 16; i += 64) dst[i] = ((const uint4*)row)[i];
 }
 
 // rows [n_graphs, n_rows_pad) of the operand: zero
@@ -663,7 +732,9 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     void* q = nullptr;
     std::vector<u32> h(GM_META_WORDS, 0);
     if (Q > 0) {
-        GmColumns gc{A, Tb, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta, grid};
+        // counts above 127 under an int8 operand: split columns unless the option keeps the float64 side operand
+        const int allow_split = (kind == GK_FEAT_DOT && f->dtype == 0 && !ctx->opt.gram_no_split8) ? 1 : 0;
+        GmColumns gc{A, Tb, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta, grid, allow_split};
         const i64 nblk = cdiv(Q, G3_TILE);
         Tmp<Gm3> partial(ctx);
         GK_TRY(partial.alloc((size_t)nblk));
@@ -683,6 +754,9 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     if (h[GM_META_OVF]) return GK_ERR_UNSUPPORTED;                  // a histogram table of gk_features_build_sp overflowed
     f->n_cols1 = h[GM_META_PRIM], f->n_cols8 = h[GM_META_INT8], f->n_cols = f->n_cols1 + f->n_cols8;
     f->n_cols_wide = h[GM_META_F64], f->n_low_cols = h[GM_META_RARE];
+    f->split_parts = 0, f->n_split_labels = 0;
+    if (h[GM_META_SPLIT] >= 2 && f->n_cols_wide > 0)         // those labels live in parts^2 int8 columns each, not in a float64 operand
+        f->split_parts = (int)h[GM_META_SPLIT], f->n_split_labels = f->n_cols_wide, f->n_cols_wide = 0;
     f->max_count = 0, f->nnz = 0;
     for (int k = 0; k < 64; ++k) {
         f->max_count = std::max<i64>(f->max_count, h[GM_META_MAXC + k]);
@@ -701,6 +775,10 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     if (f->n_cols_pad > row_lds_max) return GK_ERR_UNSUPPORTED;              // caller falls back to features.hip
     GK_TRY(gk_dev_alloc(ctx, &q, (size_t)f->n_rows_pad * f->n_cols_pad));
     f->phi = q;
+    if (f->split_parts) {                                      // the right operand (its rows differ in the split columns only)
+        GK_TRY(gk_dev_alloc(ctx, &q, (size_t)f->n_rows_pad * f->n_cols_pad));
+        f->phi_r = q;
+    }
     if (f->n_cols_wide > 0) {
         f->n_cols_wide_pad = round_up(f->n_cols_wide, 16);
         const size_t wb = (size_t)f->n_rows_pad * f->n_cols_wide_pad * 8;
@@ -727,13 +805,15 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     if (f->n_cols_pad <= GM_ROW_WAVE_MAX && f->nnz <= 192 * N && !ctx->opt.gm_rows_wg)
         gm_rows_wave_kernel<<<dim3((unsigned)cdiv(f->n_rows_pad, 4)), 256, (size_t)f->n_cols_pad * 4, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-            f->n_cols_wide_pad, lg, lc, ll, f->n_rows_pad);        // ... and zeroes the padding rows
+            f->n_cols_wide_pad, lg, lc, ll, f->n_rows_pad, (int8_t*)f->phi_r, f->split_parts);        // ... and zeroes the padding rows
     else {
         gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-            f->n_cols_wide_pad, lg, lc, ll);
+            f->n_cols_wide_pad, lg, lc, ll, (int8_t*)f->phi_r, f->split_parts);
         const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
         gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
+        if (f->phi_r)
+            gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi_r + N * f->n_cols_pad, pad_bytes);
     }
     GK_HIP_CHECK(hipGetLastError());
     // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries

@@ -1441,7 +1441,7 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
     {
         const int8_t* phi = (const int8_t*)f->phi;
         const int8_t* pa = phi + first_row_graph * f->n_cols_pad;
-        const int8_t* pb = phi + col_lo * f->n_cols_pad;
+        const int8_t* pb = (f->phi_r ? (const int8_t*)f->phi_r : phi) + col_lo * f->n_cols_pad;       // split columns: right operand
         const int tri = (f->symmetric && row_lo == col_lo && row_hi == col_hi && !ctx->opt.gram_no_sym) ? 1 : 0;
         const int patch = ctx->opt.gram_no_patch ? 0 : 1;
         GK_TRY(launch_tiles(ctx, f, pa, pb, M, NC, row_lo, normalize, K, tri, patch, &entries_done, ldk, col_lo, want_fold, &folded));

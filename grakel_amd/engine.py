@@ -452,6 +452,13 @@ class Engine(object):
         check(self.lib.gk_features_debug_phi(self.handle, feat.handle, _ptr(out)))
         return out
 
+    def debug_phi_right(self, feat):
+        """(right operand, parts): differs from debug_phi only in split columns (counts of 128..381 as int8 digits)"""
+        out = np.empty((feat.batch.n_graphs, feat.n_cols), dtype=np.float64)
+        parts = ctypes.c_int(0)
+        check(self.lib.gk_features_debug_phi_right(self.handle, feat.handle, _ptr(out), ctypes.byref(parts)))
+        return out, parts.value
+
     def gram(self, feat, normalize=0, rows=None, to_host=True):
         if isinstance(feat, ChunkedFeatures):
             if not to_host:

@@ -82,6 +82,7 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "gram.fold" (the rare labels' pair updates inside the tile kernel, which then normalises in its epilogue too, instead of float64
  *             atomics + a normalisation pass afterwards: 0 when it pays, 1 whenever legal, 2 never)
  *             "gram.pair_cap" (test hook: capacity of the per-tile pair buckets of that fold-in)
+ *             "gram.no_split8" (labels with counts above 127 in a float64 side operand instead of split int8 columns)
  *             "gram.no_compact" (host copies of integer-valued matrices as plain float64 instead of uint16 / int32 + widening)
  *             "gram.copy_threads" (host threads of that widening; 0: min(hardware threads, 16))
  *   paths:    "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
@@ -233,6 +234,10 @@ int gk_features_operand(gk_feat* f, int* fp4, int* k_steps_primary, int* k_steps
 int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk /* [n_graphs] */);
 /* Test hook: the dense column-compacted Phi_s as float64 [n_graphs x n_cols_kept]. */
 int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi);
+/* Test hook: the RIGHT operand of the dense product in the same form.  It differs from the left one (above) only when
+ * labels with counts of 128 .. 381 were split into parts^2 int8 columns (*split_parts = 2 or 3; 0 = no split columns, both
+ * operands are the same matrix): the off-diagonal dense term of K is left . right^T. */
+int gk_features_debug_phi_right(gk_ctx* ctx, gk_feat* f, double* out_phi, int* split_parts);
 
 /* ---- Gram matrix ---------------------------------------------------------------------- */
 /* Replaces VertexHistogram._calculate_kernel_matrix (vertex_histogram.py:156-184: X.dot(X.T)

@@ -685,6 +685,62 @@ def test_counts_above_127_take_the_f64_path(gk):
     assert np.array_equal(gk.VertexHistogram().fit_transform(G), O.VHOracle().fit_transform(G))
 
 
+@pytest.mark.parametrize("n,n_labels,parts", [(300, 2, 2), (900, 3, 3)])
+def test_counts_of_128_to_381_are_split_into_int8_digit_columns(gk, gkopt, n, n_labels, parts):
+    """A label with counts above 127 but at most 3 x 127 stays in the int8 GEMM: parts^2 columns holding the digits of
+    the count, digit p on the left and digit r on the right at column (p, r), so that left . right^T is the exact product.
+    The dense term against the host product of the two operands, then the public API against the oracle with and
+    without the split (option gram.no_split8 = the float64 side operand), normalised and as fit + transform."""
+    from grakel_amd import GraphBatch
+    from grakel_amd.engine import get_engine
+    gkopt("feat.low_df", 2)
+    eng = get_engine()
+    N = 70
+    db = eng.upload(GraphBatch(*er_dataset_csr(N, n, 2.0 / n, n_labels, 5), n_labels))
+    eng.wl_relabel(db, 1)
+    feat = eng.features(db, 2)
+    assert 127 * (parts - 1) < feat.max_count <= 127 * parts and feat.n_cols_low == 0
+    left = eng.debug_phi(feat)
+    right, got_parts = eng.debug_phi_right(feat)
+    assert got_parts == parts and left.max() <= 127 and right.max() <= 127 and not np.array_equal(left, right)
+    assert eng.lib.gk_features_operand is not None and "f64" not in feat.operand
+    K = eng.gram(feat, 0)
+    R = left @ right.T
+    assert np.array_equal(R, R.T)
+    np.fill_diagonal(R, eng.selfk(feat))
+    assert np.array_equal(K, R)
+    d = eng.selfk(feat)
+    Kn = eng.gram(feat, 2, rows=(3, N - 2))
+    assert np.allclose(Kn, R[3:N - 2] / np.sqrt(np.outer(d[3:N - 2], d)), rtol=1e-13, atol=0)
+    gkopt("gram.no_split8", 1)
+    feat2 = eng.features(db, 2)
+    assert "f64" in feat2.operand and np.array_equal(eng.gram(feat2, 0), K)
+    gkopt("gram.no_split8", 0)
+    # public API
+    rs = np.random.RandomState(n)
+    G = []
+    for k in range(24):
+        m = n - 10 * (k % 5)
+        A = np.triu((rs.rand(m, m) < 2.0 / m).astype(int), 1)
+        G.append([A + A.T, {i: int(rs.randint(n_labels)) for i in range(m)}])
+    for norm in (False, True):
+        want_fit = O.WLOracle(n_iter=2, normalize=norm)
+        Kf = want_fit.fit_transform(G[:16])
+        Kt = want_fit.transform(G[16:])
+        for no_split in (0, 1):
+            gkopt("gram.no_split8", no_split)
+            wl = gk.WeisfeilerLehman(n_iter=2, normalize=norm)
+            got = wl.fit_transform(G[:16])
+            assert ("f64" in wl._last_info["dtype"]) == bool(no_split)
+            if norm:
+                assert np.allclose(got, Kf, rtol=1e-13, atol=0) and np.allclose(wl.transform(G[16:]), Kt, rtol=1e-13, atol=0)
+            else:
+                assert np.array_equal(got, Kf) and np.array_equal(wl.transform(G[16:]), Kt)
+    gkopt("gram.no_split8", 0)
+    sp_graphs = [[g[0], {i: 0 for i in range(len(g[1]))}] for g in G[:6]]          # one label: pair counts far above 381 stay float64
+    assert np.array_equal(gk.ShortestPath().fit_transform(sp_graphs), O.SPOracle().fit_transform(sp_graphs))
+
+
 def test_apsp_known_answer_and_large_graphs(gk):
     from grakel_amd.batch import sp_batch_from_input
     from grakel_amd.engine import get_engine
