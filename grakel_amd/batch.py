@@ -26,6 +26,10 @@ try:                                   # optional C fast path of the dict-of-lis
 except ImportError:                    # not built: the Python path below does everything
     _gk_ingest = None
 
+# host threads of the C walk over `[{u: [v, ...]}, {u: label}]` elements (csrc/ingest.c: wl_ingest_threads):
+# 0 = one per host core (at most 16), 1 = the calling thread only.  The result does not depend on it.
+INGEST_THREADS = 0
+
 
 class GraphBatch(object):
     """A set of graphs packed as CSR (int32), the unit the HIP library consumes.
@@ -507,7 +511,7 @@ def wl_batch_from_input(X, fitted_labels=None, min_len=2, not_iterable=TypeError
     if _gk_ingest is not None and type(X) in (list, tuple):
         # plain `[edge dict, label dict, ...]` elements: the same walk in C; anything it does not
         # recognise makes it return None and the Python path below takes the whole input
-        r = _gk_ingest.wl_ingest(X, int(min_len))
+        r = _gk_ingest.wl_ingest(X, int(min_len), False, 0, int(INGEST_THREADS))
         if r is not None:
             sizes, row_ptr, col, values = r
             ids, mapping = compress_labels(values, fitted_labels)

@@ -158,6 +158,48 @@ def test_c_ingestion_fast_path_equals_the_python_path():
     assert _both_paths(cases["unlabelled_neighbour"])[0][:2] == ("raise", KeyError)
 
 
+def test_threaded_ingestion_equals_the_one_thread_walk_and_the_python_path():
+    """csrc/ingest.c: wl_ingest_threads takes inputs of 256 or more elements of the one common form (identity numbering,
+    neighbour lists, small int labels); anything else falls back to the one-thread walk, which falls back to Python.
+    Whatever the route, the batch -- or the exception -- is the same."""
+    from grakel_amd import batch as B
+    rs = np.random.RandomState(11)
+    base = er_dataset(400, 12, 0.3, 4, 2)
+    cases = {"common_form": base}
+    messy = [[{u: list(nb) for u, nb in g.items()}, dict(lab)] for g, lab in base]
+    for g, _ in messy[::7]:
+        for u in g:
+            g[u] = g[u][::-1] + g[u][:1]                      # descending, with a duplicate: sorted and deduplicated
+    cases["unsorted_duplicates"] = messy
+    cases["string_label_at_the_end"] = base[:-1] + [[base[-1][0], {u: "x%d" % l for u, l in base[-1][1].items()}]]
+    cases["big_and_negative_labels"] = [[g, {u: (l - 2) * 2 ** 40 for u, l in lab.items()}] for g, lab in base]
+    cases["dict_of_dicts_in_the_middle"] = base[:200] + [[{u: {v: 1 for v in nb} for u, nb in base[200][0].items()}, base[200][1]]] + base[201:]
+    cases["tuple_elements_with_extras"] = [(g, lab, None) for g, lab in base]
+    cases["unlabelled_neighbour_near_the_end"] = base[:-2] + [[{0: [1, 77], 1: [0]}, {0: 1, 1: 2}]] + base[-2:]
+    cases["vertex_without_entry"] = base[:300] + [[{0: [1], 1: [0]}, {0: 1, 1: 2, 2: 3}]] + base[300:]
+    cases["shuffled_label_order"] = base[:50] + [[g, dict(sorted(lab.items(), key=lambda kv: -kv[0]))] for g, lab in base[50:60]] + base[60:]
+    cases["numpy_neighbours"] = base[:399] + [[{0: [np.int64(1)], 1: [np.int64(0)]}, {0: 3, 1: 1}]]
+    saved = B.INGEST_THREADS
+    try:
+        for name, X in cases.items():
+            B.INGEST_THREADS = 4
+            fast, slow = _both_paths(X)
+            assert fast == slow, name
+            B.INGEST_THREADS = 1
+            one, _ = _both_paths(X[:1])                       # (builds the module if needed)
+            one = _both_paths(X)[0]
+            assert one == fast, name
+        # the threaded walk itself against the one-thread walk, array by array (the common form is taken by the threads)
+        r4 = B._gk_ingest.wl_ingest(base, 2, False, 0, 4)
+        r1 = B._gk_ingest.wl_ingest(base, 2, False, 0, 1)
+        assert len(r4) == 4 and all(bytes(a) == bytes(b) for a, b in zip(r4, r1))
+        rm4 = B._gk_ingest.wl_ingest(messy, 2, False, 0, 3)
+        rm1 = B._gk_ingest.wl_ingest(messy, 2, False, 0, 1)
+        assert all(bytes(a) == bytes(b) for a, b in zip(rm4, rm1))
+    finally:
+        B.INGEST_THREADS = saved
+
+
 def test_c_sp_ingestion_fast_path_equals_the_python_path():
     from grakel_amd import batch as B
     from grakel_amd.synthetic import nci1_like
