@@ -65,6 +65,15 @@ SIGNATURES = {
     "gk_features_operand": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), _i64p]),
     "gk_features_selfk": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gk_features_debug_phi": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gk_comm_unique_id": (c_int, [c_void_p]),
+    "gk_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "gk_comm_destroy": (c_int, [c_void_p]),
+    "gk_comm_info": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gk_batch_allgather": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int32, c_void_p, c_void_p]),
+    "gk_shard_message": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                 c_void_p]),
+    "gk_gram_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gk_features_debug_phi_right": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "gk_gram": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gk_gram_dev_ptr": (c_int, [c_void_p, _vpp, _i64p, _i64p]),

@@ -116,6 +116,7 @@ struct gk_ctx {
     int n_cu = 0;                              // compute units of the device (persistent-kernel grids)
     std::map<const void*, int> func_lds;       // kernel -> dynamic LDS limit already set for THIS context's device (gk_func_lds)
 };
+#define GK_MAX_RANKS 64          // shards of gk_batch_from_shards / ranks of a gk_comm
 #define GK_MBOX_WORDS 512
 #define GK_HIST0_MAX_LABELS 256
 

@@ -922,7 +922,6 @@ extern "C" int gk_batch_create(gk_ctx* ctx, int64_t n_graphs, int64_t n_nodes, i
 // Rank r's message (msg_stride int32 words, as grakel_amd/dist.py packs it) is
 //   [graph sizes, padded to mg | node degrees, padded to mv | node labels, padded to mv | col_idx (LOCAL node ids), padded to me]
 // The shards are concatenated in rank order; col_idx is shifted to global node ids.
-#define GK_MAX_RANKS 64
 struct ShardMap {
     int R;
     i64 g0[GK_MAX_RANKS + 1], v0[GK_MAX_RANKS + 1], e0[GK_MAX_RANKS + 1];   // prefix sums of the shard sizes

@@ -156,6 +156,24 @@ class DeviceBatch(object):
             pass
 
 
+class Comm(object):
+    """A communicator of the C ABI (``gk_comm``): one process per GPU, RCCL underneath."""
+
+    def __init__(self, engine, handle, rank, n_ranks):
+        self.engine, self.handle, self.rank, self.n_ranks = engine, handle, rank, n_ranks
+
+    def close(self):
+        if self.handle is not None and self.engine.handle is not None:
+            self.engine.lib.gk_comm_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FittedWL(object):
     """Fitted WL dictionaries on the device (csrc/wl_transform.hip): what ``transform`` looks target signatures up in."""
 
@@ -335,6 +353,43 @@ class Engine(object):
         check(self.lib.gk_batch_from_shards(self.handle, int(sizes.shape[0]), sizes.ctypes.data_as(ctypes.POINTER(c_int64)),
                                             int(mg), int(mv), int(me), c_void_p(int(gathered_ptr)), int(n_labels), byref(h)))
         return DeviceBatch(self, h, int(sizes[:, 0].sum()), int(sizes[:, 1].sum()), int(sizes[:, 2].sum()))
+
+    # -- multi-GPU through the C ABI (csrc/comm.hip; grakel_amd.dist is the torch.distributed form of the same scheme) ----
+    def comm_unique_id(self):
+        """128 bytes rank 0 creates and hands to the other processes (``ncclGetUniqueId``)."""
+        buf = ctypes.create_string_buffer(128)
+        check(self.lib.gk_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, n_ranks, unique_id):
+        """Collective: every rank calls it with rank 0's id.  Returns a ``Comm``."""
+        h = c_void_p()
+        check(self.lib.gk_comm_init(self.handle, int(rank), int(n_ranks), ctypes.c_char_p(bytes(unique_id)), byref(h)))
+        return Comm(self, h, int(rank), int(n_ranks))
+
+    def batch_allgather(self, comm, gb):
+        """Collective: this rank's ``GraphBatch`` shard (local numbering, global level-0 label ids) -> (the batch of all
+        graphs in rank order on this rank's device, graph bounds of the ranks)."""
+        h = c_void_p()
+        bounds = np.zeros(comm.n_ranks + 1, dtype=np.int64)
+        check(self.lib.gk_batch_allgather(self.handle, comm.handle, gb.n_graphs, gb.n_nodes, gb.n_edges,
+                                          _ptr(np.ascontiguousarray(gb.graph_ptr, dtype=np.int32)), _ptr(gb.row_ptr),
+                                          _ptr(gb.col_idx), _ptr(gb.node_label), int(gb.n_labels), byref(h), _ptr(bounds)))
+        ng, nv, ne = c_int64(), c_int64(), c_int64()
+        check(self.lib.gk_batch_info(h, byref(ng), byref(nv), byref(ne)))
+        return DeviceBatch(self, h, ng.value, nv.value, ne.value), bounds
+
+    def gram_sharded(self, comm, feat, bounds, normalize=0):
+        """The rows of K that belong to this rank's graphs, float64 [n_own x n_cols] on the host."""
+        bounds = np.ascontiguousarray(bounds, dtype=np.int64)
+        lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
+        n_cols = feat.n_fit if feat.n_fit else feat.batch.n_graphs
+        out = np.empty((hi - lo, n_cols), dtype=np.float64)
+        rl, rh = c_int64(), c_int64()
+        check(self.lib.gk_gram_sharded(self.handle, comm.handle, feat.handle, _ptr(bounds), int(normalize), _ptr(out),
+                                       byref(rl), byref(rh)))
+        assert (rl.value, rh.value) == (lo, hi)
+        return out
 
     def export_state(self, db):
         """The fitted batch as one self-describing blob (``gk_export_state``): what a consumer of the C ABI persists."""

@@ -316,6 +316,43 @@ int gk_sp_debug_apsp(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, int64
  * subgraphs, matrices summed) runs the base-kernel entry points above on sub-batches. */
 int gk_core_numbers(gk_ctx* ctx, gk_batch* b, int32_t* out_core);
 
+/* ---- multi-GPU: one process per GPU ----------------------------------------------------------------- */
+/* SURVEY.md 8b / 8e.  Graphs are sharded over the ranks (rank r ingests and holds only its own), and so are the rows of
+ * K.  The reference computes its label dictionaries over ALL graphs (weisfeiler_lehman.py:224-246), so the one exchange
+ * step is an all-gather of the packed CSR shards (RCCL, over xGMI inside a node); relabel + features then run replicated
+ * and every rank multiplies and stores the row block of its own graphs -- no collective after the all-gather.
+ * grakel_amd/dist.py is the same scheme over torch.distributed; these entry points serve consumers without Python.
+ * RCCL (librccl.so.1) is loaded on the first gk_comm_* call; GK_ERR_UNSUPPORTED when the host has none.
+ *
+ *   rank 0:     gk_comm_unique_id(id)  ... hand the 128 bytes to the other processes (file, socket, MPI_Bcast, ...)
+ *   every rank: gk_comm_init(ctx, rank, n_ranks, id, &comm)                       (collective: all ranks must call it)
+ *               gk_batch_allgather(ctx, comm, <its shard>, &batch, bounds)        (collective)
+ *               gk_wl_fit_transform / gk_wl_relabel + gk_features_build           (replicated, no communication)
+ *               gk_gram_sharded(ctx, comm, feat, bounds, normalize, K_rows, ...)  (rows bounds[rank] .. bounds[rank + 1])
+ */
+#define GK_COMM_ID_BYTES 128
+typedef struct gk_comm gk_comm;
+int gk_comm_unique_id(void* out_id /* GK_COMM_ID_BYTES */);
+int gk_comm_init(gk_ctx* ctx, int rank, int n_ranks, const void* id, gk_comm** out);
+int gk_comm_destroy(gk_comm* c);
+int gk_comm_info(gk_comm* c, int* rank, int* n_ranks);
+/* This rank's shard as for gk_batch_create, host arrays in LOCAL numbering (graph_ptr[0] = 0, col_idx = node ids within
+ * the shard); the level-0 label ids must mean the same label on every rank.  *out = the batch of ALL graphs in rank
+ * order on this rank's device; graph_bounds[n_ranks + 1] = first graph of every rank.  A rank may hold no graph. */
+int gk_batch_allgather(gk_ctx* ctx, gk_comm* c, int64_t n_graphs, int64_t n_nodes, int64_t n_edges,
+                       const int32_t* graph_ptr, const int32_t* row_ptr, const int32_t* col_idx,
+                       const int32_t* node_label, int32_t n_labels0, gk_batch** out, int64_t* graph_bounds);
+/* Bring your own transport (MPI, a socket, ...): this rank's shard as the int32 message gk_batch_from_shards consumes,
+ * out_msg[mg + 2*mv + me] on the host, mg / mv / me = the largest shard's graphs / nodes / edges over all ranks.  All-gather
+ * the messages in rank order, put them on the device back to back and call gk_batch_from_shards: that is what
+ * gk_batch_allgather does over RCCL.  No device work, no communicator. */
+int gk_shard_message(int64_t n_graphs, int64_t n_nodes, int64_t n_edges, const int32_t* graph_ptr, const int32_t* row_ptr,
+                     const int32_t* col_idx, const int32_t* node_label, int64_t mg, int64_t mv, int64_t me, int32_t* out_msg);
+/* The rows of the job's matrix that belong to this rank's graphs: gk_gram_rows on [graph_bounds[rank], graph_bounds[rank + 1]);
+ * out_host [(row_hi - row_lo) x n_cols] or NULL (the block stays on the device: gk_gram_dev_ptr). */
+int gk_gram_sharded(gk_ctx* ctx, gk_comm* c, gk_feat* f, const int64_t* graph_bounds, int normalize, double* out_host,
+                    int64_t* row_lo, int64_t* row_hi);
+
 #ifdef __cplusplus
 }
 #endif

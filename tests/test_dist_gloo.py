@@ -39,6 +39,18 @@ def _worker(rank, world, port, out_dir):
         ex = ShardExchange(local)
         flat = ex.gather_flat().numpy()
         stride = ex.mg + 2 * ex.mv + ex.me
+        # the C ABI's own form of this rank's message (csrc/comm.hip: gk_shard_message, what gk_batch_allgather sends over
+        # RCCL) is word for word the message this exchange sent -- a host function, no device
+        from ctypes import c_void_p
+        from grakel_amd import _lib
+        cmsg = np.full(stride, -1, dtype=np.int32)
+
+        def ptr(a):
+            return np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(c_void_p)
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (local.graph_ptr, local.row_ptr, local.col_idx, local.node_label)]
+        _lib.check(_lib.load().gk_shard_message(local.n_graphs, local.n_nodes, local.n_edges, *[a.ctypes.data_as(c_void_p) for a in arrs],
+                                                ex.mg, ex.mv, ex.me, cmsg.ctypes.data_as(c_void_p)))
+        ok = ok and np.array_equal(cmsg, ex.msg.numpy()) and np.array_equal(cmsg, flat[rank * stride:(rank + 1) * stride])
         gs, dg, lb, cc, v0 = [], [], [], [], 0
         for r in range(world):
             ng, nv, ne = (int(x) for x in ex.all_sizes[r, :3])

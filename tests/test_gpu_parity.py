@@ -1024,6 +1024,43 @@ def test_sharded_path_single_rank_matches_plain_path(gk):
             dist.destroy_process_group()
 
 
+def test_c_abi_collectives_with_a_world_of_one(gk):
+    """include/gk_hip.h "multi-GPU" (csrc/comm.hip): gk_comm_unique_id / gk_comm_init / gk_batch_allgather /
+    gk_gram_sharded through RCCL itself -- a communicator of one rank (this box has one GPU; RCCL wants one GPU per
+    rank).  The message layout and the device-side rebuild are the ones the two-process tests below drive over gloo."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    from grakel_amd import _lib
+    eng = get_engine()
+    X = er_dataset(257, 25, 0.12, 4, 8)
+    K = gk.WeisfeilerLehman(n_iter=3).fit_transform(X)
+    Kn = gk.WeisfeilerLehman(n_iter=3, normalize=True).fit_transform(X)
+    gb, _ = wl_batch_from_input(X)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128
+    comm = eng.comm_init(0, 1, uid)
+    try:
+        for _ in range(2):
+            db, bounds = eng.batch_allgather(comm, gb)
+            assert bounds.tolist() == [0, 257] and (db.n_graphs, db.n_nodes, db.n_edges) == (gb.n_graphs, gb.n_nodes, gb.n_edges)
+            eng.wl_relabel(db, 3)
+            feat = eng.features(db, 4)
+            assert np.array_equal(eng.gram_sharded(comm, feat, bounds, 0), K)
+            assert np.allclose(eng.gram_sharded(comm, feat, bounds, 2), Kn, rtol=REL_TOL, atol=0)
+            # the rows of another split of the same job (what rank 1 of 3 would own)
+            assert np.array_equal(eng.gram(feat, 0, rows=(86, 172)), K[86:172])
+            feat.close()
+            db.close()
+        with pytest.raises(_lib.GkError):                         # a shard that does not start at 0
+            bad = type("B", (), dict(n_graphs=gb.n_graphs, n_nodes=gb.n_nodes, n_edges=gb.n_edges, graph_ptr=gb.graph_ptr + 1,
+                                     row_ptr=gb.row_ptr, col_idx=gb.col_idx, node_label=gb.node_label, n_labels=gb.n_labels))
+            eng.batch_allgather(comm, bad)
+        with pytest.raises(_lib.GkError):
+            eng.comm_init(2, 2, uid)                                  # rank outside [0, n_ranks)
+    finally:
+        comm.close()
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     """One of two processes sharing cuda:0 (gloo moves the shard messages; RCCL needs one GPU per rank)."""
     import sys
