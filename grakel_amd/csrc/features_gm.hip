@@ -123,6 +123,16 @@ __global__ __launch_bounds__(256) void gm_prep_kernel(const u32* __restrict__ ct
     for (u32 i = blockIdx.x * 256u + threadIdx.x; i < (Q + 3u) / 4u; i += stride) side_words[i] = 0u;
 }
 
+#ifdef GK_ABLATION
+// tools' build only (make abl; tools/dev/feat_ablate.py): timing ablations of gm_pairs_kernel, WRONG results by construction.
+// GK_GM_ABL bit 1: no df / class counting (emit), 2: no sort network, 4: no entry stores, 8: label loads only, 16 / 32: no
+// counting in the private histograms / by global atomics, 64: global counting without its read-modify-writes, 128: without its guard reads
+__device__ int g_gm_abl;
+#define GM_ABL(bit) (g_gm_abl & (bit))
+#else
+#define GM_ABL(bit) 0
+#endif
+
 template <int WAVES>
 __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArrays A, const GmTable* __restrict__ Tb, int priv_cap_words,
                                                                 const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
@@ -174,6 +184,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
             auto qof = [&](i32 x) __attribute__((always_inline)) { return (i32)(qoff + ((u32)x < ncc ? (u32)x : ncc + ((u32)x - lo))); };
             // one (label, graph, count) entry: df / class flags of the label, the graph's self similarity
             auto emit = [&](i32 x, u32 c) __attribute__((always_inline)) {
+                if (GM_ABL(1) || (GM_ABL(16) && poff >= 0) || (GM_ABL(32) && poff < 0)) { extra += c; return; }
                 if (poff >= 0) {
                     const u32 bin = (u32)poff + ((u32)qof(x) - qoff);
                     const int sh = 16 * (bin & 1u);
@@ -189,8 +200,10 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                     const i64 q = qof(x);
                     // guarded global atomics (device-scope atomics execute memory-side: slow, and a label present
                     // in thousands of graphs would queue thousands of them on one address): add only while df counts
-                    if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
-                    if (c >= 2u && __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) atomicMax(&A.cmax[q], c);
+                    // (the cost is the read-modify-writes themselves, ~0.2 ns each at config 5's half a million entries of low-df
+                    // classes; the guard reads are free next to them and unguarded adds on the hot labels cost three times more)
+                    if ((GM_ABL(128) ? 0u : __hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < df_cap && !GM_ABL(64)) atomicAdd(&A.df[q], 1u);
+                    if (c >= 2u && (GM_ABL(128) ? 0u : __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < c && !GM_ABL(64)) atomicMax(&A.cmax[q], c);
                     if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
                 }
                 if (!kind) extra += (u64)c * c - c;
@@ -204,6 +217,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                 i32 a = (fa && shareable(ra)) ? ra : BIG, b2 = (fb && shareable(rb)) ? rb : BIG;
                 if (j + 1 < P.L) fetch(j + 1);
                 u64 Ma = __ballot(a != BIG), Mb = __ballot(b2 != BIG);
+                if (GM_ABL(8)) { extra += (u64)(a ^ b2); continue; }
                 if (!(Ma | Mb)) {                                    // nothing shared in this graph at this level
                     if (lane == 0) *ne = 0;
                     continue;
@@ -233,6 +247,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                     // (config 5: 50 000 graphs of 30 nodes spent most of this kernel sorting 64 empty positions each)
 #pragma unroll
                     for (int k = 2; k <= 64; k <<= 1) {
+                        if (GM_ABL(2)) break;
 #pragma unroll
                         for (int jj = k >> 1; jj > 0; jj >>= 1) {
                             const i32 pa = __shfl_xor(a, jj, 64);
@@ -259,6 +274,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                 // bitonic network of 28 compare-exchange steps on wave shuffles; equal labels are then neighbours
 #pragma unroll
                 for (int k = 2; k <= 128; k <<= 1) {
+                    if (GM_ABL(2)) break;
 #pragma unroll
                     for (int jj = k >> 1; jj > 0; jj >>= 1) {
                         if (jj == 64) {                      // partner = the lane's other register (only k == 128: ascending)
@@ -292,8 +308,8 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                 const u64 Va = __ballot(ca != 0), Vb = __ballot(cb != 0);
                 const u64 below = (1ull << lane) - 1ull;
                 const int na = __builtin_popcountll(Va);
-                if (ca) { const int k = __builtin_popcountll(Va & below); el[k] = qof(a), ec[k] = ca; }
-                if (cb) { const int k = na + __builtin_popcountll(Vb & below); el[k] = qof(b2), ec[k] = cb; }
+                if (ca && !GM_ABL(4)) { const int k = __builtin_popcountll(Va & below); el[k] = qof(a), ec[k] = ca; }
+                if (cb && !GM_ABL(4)) { const int k = na + __builtin_popcountll(Vb & below); el[k] = qof(b2), ec[k] = cb; }
                 if (lane == 0) *ne = (u32)(na + __builtin_popcountll(Vb));
                 if (ca) emit(a, ca);
                 if (cb) emit(b2, cb);
@@ -841,6 +857,13 @@ static int gm_label_arrays(gk_ctx* ctx, gk_feat* f, size_t qa, GmLabelArrays& A,
 
 // ---------------------------------------------------------------------------------------------------
 int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int prim_max, int wide_above) {
+#ifdef GK_ABLATION
+    {
+        const char* e = getenv("GK_GM_ABL");
+        const int v = e ? atoi(e) : 0;
+        GK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gm_abl), &v, sizeof v));
+    }
+#endif
     const i64 V = b->n_nodes, N = b->n_graphs;
     const int kind = f->kind;
     const bool stream = b->stream_layout;                     // the label counts of the levels only exist on the device
@@ -889,8 +912,11 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     Tmp<u32> ent_n(ctx);         // entries (slots in use) per level and graph
     GK_TRY(ent_n.alloc((size_t)(P.L > 0 ? P.L : 1) * (size_t)(N > 0 ? N : 1)));
     const int rectangular = f->symmetric ? 0 : 1;
+    // counting table per wave: only graphs of more than 128 nodes use it (smaller ones sort in registers), so a job without
+    // such graphs leaves the LDS to the private histograms (config 3: level 2's 6 799 shared classes then count in LDS too)
     int T = 64;
-    while (T < 2 * b->max_graph_nodes) T <<= 1;
+    if (b->max_graph_nodes > 128)
+        while (T < 2 * b->max_graph_nodes) T <<= 1;
     // ---- which levels count in workgroup-private histograms (small label spaces first come, 32 K bins in all)
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     const int waves = GM_WAVES, per_cu = 3;
