@@ -584,6 +584,67 @@ __device__ __forceinline__ void gm_split_write(unsigned char* row, i32 base, u32
     }
 }
 
+__device__ __forceinline__ u32 gm_wave_incl_scan(u32 x) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(x, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) x += y;
+    }
+    return x;
+}
+
+// One entry (label q with column id col, count c) of graph g into the operand row being assembled in LDS (or, for the float64
+// side operand and the rare lists, to their places in HBM).  Returns 1 for a split column.
+__device__ __forceinline__ int gm_row_entry(unsigned char* row, const GmLabelArrays& A, i64 g, i64 q, i32 col, u32 c, i64 prim0, int fp4,
+                                            int kind, int parts, double* __restrict__ phi_w, i64 ldw, i32* __restrict__ low_graph,
+                                            i32* __restrict__ low_cnt, i32* __restrict__ low_lab) {
+    if (col >= COL_SPLIT_BASE) { gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 0); return 1; }
+    if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;              // secondary int8 region: bytes [0, prim0)
+    else if (col >= 0) {
+        if (kind) {                                                                     // unary run of ones
+            for (u32 x = 0; x < c; ++x) {
+                const i64 cc = col + x;
+                if (fp4) atomicOr((u32*)(row + prim0 + ((cc >> 1) & ~3ll)), 2u << (8 * ((cc >> 1) & 3) + 4 * (cc & 1)));
+                else row[prim0 + cc] = 1;
+            }
+        } else if (fp4) {
+            const u32 code = (0x65420u >> (4 * c)) & 15u;
+            atomicOr((u32*)(row + prim0 + ((col >> 1) & ~3)), code << (8 * ((col >> 1) & 3) + 4 * (col & 1)));
+        } else row[prim0 + col] = (unsigned char)c;
+    } else if (col <= -4) phi_w[g * ldw + (-4 - col)] = (double)c;
+    else if (col == -2) {
+        const u32 pos = A.roff[q] + atomicAdd(&A.cursor[q], 1u);
+        low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c, low_lab[pos] = (i32)q;
+    }
+    return 0;
+}
+
+// The graphs' entries are read in trips of GM_ROW_BATCH per thread: first every (count, label) pair of the trip, then every
+// column id, then the writes.  One entry at a time is a chain of three dependent memory latencies (slot -> label -> column id)
+// per loop trip, and that chain, not bandwidth, bound these kernels (30 us at config 3 for a 25 MB operand).
+// The entry slots of level j are [0, slots[j]) of the graph's node range: entry k of the graph (all levels back to back) is
+// slot k - pre[j] of the level with pre[j] <= k < pre[j + 1].
+#define GM_ROW_BATCH 4
+#define GM_ROWS_GATHER(TID, STRIDE)                                                                                                  \
+    for (int k0 = 0; k0 < n_ent; k0 += GM_ROW_BATCH * (STRIDE)) {                                                                    \
+        u32 cc[GM_ROW_BATCH];                                                                                                        \
+        i64 qq[GM_ROW_BATCH];                                                                                                        \
+        i32 col[GM_ROW_BATCH];                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < GM_ROW_BATCH; ++u) {                                                                   \
+            const int k = k0 + u * (STRIDE) + (TID);                                                                                 \
+            cc[u] = 0u, qq[u] = 0;                                                                                                   \
+            if (k < n_ent) {                                                                                                         \
+                int j = 0;                                                                                                           \
+                while (j + 1 < P.L && (int)pre[j + 1] <= k) ++j;                                                                     \
+                const i64 at = (i64)j * V + v0 + (k - (int)pre[j]);                                                                  \
+                cc[u] = cnt[at], qq[u] = ent_lab[at];                                                                                \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < GM_ROW_BATCH; ++u) col[u] = cc[u] ? A.colid[qq[u]] : -1;                               \
+        _Pragma("unroll") for (int u = 0; u < GM_ROW_BATCH; ++u)                                                                     \
+            if (cc[u]) { GM_ROWS_BODY(qq[u], col[u], cc[u]) }                                                                        \
+    }
+
 // one workgroup per graph: the operand row in LDS (row_bytes <= GM_ROW_LDS_MAX), written once
 __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const GmLabelArrays A,
                                                       const i32* __restrict__ graph_ptr, i64 V, const i32* __restrict__ ent_lab,
@@ -594,53 +655,30 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
                                                       int8_t* __restrict__ phi_r, int parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row[];
     const i64 g = blockIdx.x;
-    const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
-    __shared__ u32 slots[FEAT_MAX_LEVELS];                       // entries of this graph per level
-    if ((int)threadIdx.x < P.L) slots[threadIdx.x] = ent_n[(i64)threadIdx.x * n_graphs + g];
+    const i32 v0 = graph_ptr[g];
+    __shared__ u32 pre[FEAT_MAX_LEVELS + 1];                     // entries of this graph in the levels before level j
+    if (threadIdx.x < 64) {
+        const u32 sl = (int)threadIdx.x < P.L ? ent_n[(i64)threadIdx.x * n_graphs + g] : 0u;
+        const u32 inc = gm_wave_incl_scan(sl);
+        if ((int)threadIdx.x < P.L) pre[threadIdx.x] = inc - sl;
+        if ((int)threadIdx.x == P.L - 1) pre[P.L] = inc;
+    }
     for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) ((uint4*)row)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const int n = v1 - v0;
+    const int n_ent = P.L > 0 ? (int)pre[P.L] : 0;
     int seen_split = 0;
-    for (int t = threadIdx.x; t < n * P.L; t += blockDim.x) {
-        const int j = t / n, i = t - j * n;
-        if ((u32)i >= slots[j]) continue;
-        const u32 c = cnt[(i64)j * V + v0 + i];
-        if (!c) continue;
-        const i64 q = ent_lab[(i64)j * V + v0 + i];                                     // index in the concatenated label space
-        const i32 col = A.colid[q];
-        if (col >= COL_SPLIT_BASE) gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 0), seen_split = 1;
-        else if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;     // secondary int8 region: bytes [0, prim0)
-        else if (col >= 0) {
-            if (kind) {                                                                 // unary run of ones
-                for (u32 x = 0; x < c; ++x) {
-                    const i64 cc = col + x;
-                    if (fp4) atomicOr((u32*)(row + prim0 + ((cc >> 1) & ~3ll)), 2u << (8 * ((cc >> 1) & 3) + 4 * (cc & 1)));
-                    else row[prim0 + cc] = 1;
-                }
-            } else if (fp4) {
-                const u32 code = (0x65420u >> (4 * c)) & 15u;
-                atomicOr((u32*)(row + prim0 + ((col >> 1) & ~3)), code << (8 * ((col >> 1) & 3) + 4 * (col & 1)));
-            } else row[prim0 + col] = (unsigned char)c;
-        } else if (col <= -4) phi_w[g * ldw + (-4 - col)] = (double)c;
-        else if (col == -2) {
-            const u32 pos = A.roff[q] + atomicAdd(&A.cursor[q], 1u);
-            low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c, low_lab[pos] = (i32)q;
-        }
-    }
+#define GM_ROWS_BODY(Q_, COL_, C_) seen_split |= gm_row_entry(row, A, g, Q_, COL_, C_, prim0, fp4, kind, parts, phi_w, ldw, low_graph, low_cnt, low_lab);
+    GM_ROWS_GATHER((int)threadIdx.x, (int)blockDim.x)
+#undef GM_ROWS_BODY
     __syncthreads();
     uint4* dst = (uint4*)(phi + g * ld);
     for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) dst[i] = ((const uint4*)row)[i];
     if (!phi_r) return;
     // the right operand's row: the same but for the digits of the split columns
     if (__syncthreads_or(seen_split)) {
-        for (int t = threadIdx.x; t < n * P.L; t += blockDim.x) {
-            const int j = t / n, i = t - j * n;
-            if ((u32)i >= slots[j]) continue;
-            const u32 c = cnt[(i64)j * V + v0 + i];
-            if (!c) continue;
-            const i32 col = A.colid[ent_lab[(i64)j * V + v0 + i]];
-            if (col >= COL_SPLIT_BASE) gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 1);
-        }
+#define GM_ROWS_BODY(Q_, COL_, C_) if (COL_ >= COL_SPLIT_BASE) gm_split_write(row, COL_ - COL_SPLIT_BASE, C_, parts, 1);
+        GM_ROWS_GATHER((int)threadIdx.x, (int)blockDim.x)
+#undef GM_ROWS_BODY
         __syncthreads();
     }
     dst = (uint4*)(phi_r + g * ld);
@@ -659,7 +697,7 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
                                                            i32* __restrict__ low_cnt, i32* __restrict__ low_lab, i64 n_rows_pad,
                                                            int8_t* __restrict__ phi_r, int parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row_all[];
-    __shared__ u32 slots_all[4][FEAT_MAX_LEVELS];
+    __shared__ u32 pre_all[4][FEAT_MAX_LEVELS + 1];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const i64 g = (i64)blockIdx.x * 4 + w;
     if (g >= n_graphs) {                                          // wave-uniform: no workgroup barrier below
@@ -675,40 +713,22 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
         return;
     }
     unsigned char* row = row_all + (size_t)w * ld;
-    u32* slots = slots_all[w];
-    const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
-    if (lane < P.L) slots[lane] = ent_n[(i64)lane * n_graphs + g];
+    u32* pre = pre_all[w];
+    const i32 v0 = graph_ptr[g];
+    {
+        const u32 sl = lane < P.L ? ent_n[(i64)lane * n_graphs + g] : 0u;
+        const u32 inc = gm_wave_incl_scan(sl);
+        if (lane < P.L) pre[lane] = inc - sl;
+        if (lane == P.L - 1) pre[P.L] = inc;
+    }
     for (i64 i = lane; i < ld / 16; i += 64) ((uint4*)row)[i] = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int n = v1 - v0;
+    const int n_ent = P.L > 0 ? (int)pre[P.L] : 0;
     int seen_split = 0;
-    for (int t = lane; t < n * P.L; t += 64) {
-        const int j = t / n, i = t - j * n;
-        if ((u32)i >= slots[j]) continue;
-        const u32 c = cnt[(i64)j * V + v0 + i];
-        if (!c) continue;
-        const i64 q = ent_lab[(i64)j * V + v0 + i];
-        const i32 col = A.colid[q];
-        if (col >= COL_SPLIT_BASE) gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 0), seen_split = 1;
-        else if (col >= COL_BYTE_BASE) row[col - COL_BYTE_BASE] = (unsigned char)c;
-        else if (col >= 0) {
-            if (kind) {
-                for (u32 x = 0; x < c; ++x) {
-                    const i64 cc = col + x;
-                    if (fp4) atomicOr((u32*)(row + prim0 + ((cc >> 1) & ~3ll)), 2u << (8 * ((cc >> 1) & 3) + 4 * (cc & 1)));
-                    else row[prim0 + cc] = 1;
-                }
-            } else if (fp4) {
-                const u32 code = (0x65420u >> (4 * c)) & 15u;
-                atomicOr((u32*)(row + prim0 + ((col >> 1) & ~3)), code << (8 * ((col >> 1) & 3) + 4 * (col & 1)));
-            } else row[prim0 + col] = (unsigned char)c;
-        } else if (col <= -4) phi_w[g * ldw + (-4 - col)] = (double)c;
-        else if (col == -2) {
-            const u32 pos = A.roff[q] + atomicAdd(&A.cursor[q], 1u);
-            low_graph[pos] = (i32)g, low_cnt[pos] = (i32)c, low_lab[pos] = (i32)q;
-        }
-    }
+#define GM_ROWS_BODY(Q_, COL_, C_) seen_split |= gm_row_entry(row, A, g, Q_, COL_, C_, prim0, fp4, kind, parts, phi_w, ldw, low_graph, low_cnt, low_lab);
+    GM_ROWS_GATHER(lane, 64)
+#undef GM_ROWS_BODY
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     uint4* dst = (uint4*)(phi + g * ld);
@@ -717,14 +737,9 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (__any(seen_split)) {
-        for (int t = lane; t < n * P.L; t += 64) {
-            const int j = t / n, i = t - j * n;
-            if ((u32)i >= slots[j]) continue;
-            const u32 c = cnt[(i64)j * V + v0 + i];
-            if (!c) continue;
-            const i32 col = A.colid[ent_lab[(i64)j * V + v0 + i]];
-            if (col >= COL_SPLIT_BASE) gm_split_write(row, col - COL_SPLIT_BASE, c, parts, 1);
-        }
+#define GM_ROWS_BODY(Q_, COL_, C_) if (COL_ >= COL_SPLIT_BASE) gm_split_write(row, COL_ - COL_SPLIT_BASE, C_, parts, 1);
+        GM_ROWS_GATHER(lane, 64)
+#undef GM_ROWS_BODY
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
