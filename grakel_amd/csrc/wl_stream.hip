@@ -250,8 +250,9 @@ __global__ __launch_bounds__(1024) void sr_part_kernel(const u64* __restrict__ k
                                                        u32* __restrict__ pos_of, i64 V, int shift, u32* __restrict__ runs, int nblk,
                                                        const u32* __restrict__ ctl_prev, const u32* __restrict__ node_of) {
     constexpr int THREADS = 1024, NWAVE = THREADS / 64, ROUNDS = SR_TILE / THREADS, NQ = ROUNDS * NWAVE;   // NQ == 32
-    __shared__ u32 cnt[NQ * 256];     // 32 KiB
+    __shared__ __attribute__((aligned(16))) u32 cnt[NQ * 256];     // 32 KiB
     __shared__ u32 dsum[4];
+    __shared__ u32 n_act;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const i64 tile0 = (i64)blockIdx.x * SR_TILE;
     i64 n;
@@ -303,21 +304,33 @@ __global__ __launch_bounds__(1024) void sr_part_kernel(const u64* __restrict__ k
             run += c;
         }
     }
+    if (tid == 0) n_act = dsum[0] + dsum[1] + dsum[2] + dsum[3];          // active keys of the tile
     __syncthreads();
+    // the grouped tile is assembled in LDS (over the counters, once every thread has its position) and leaves as coalesced
+    // rows: a lane's keys go to 256 different runs, i.e. 64 separate 8-byte stores per wave instruction when written directly
+    u32 local[ROUNDS], val[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const i64 idx = tile0 + r * THREADS + tid;
-        if (idx < n) {
-            u32 pos = 0xffffffffu;
-            if (act[r]) {
-                const u32 d = (u32)(key[r] >> shift) & 255u;
-                pos = (u32)tile0 + cnt[(r * NWAVE + w) * 256 + d] + rank[r];
-                kout[pos] = key[r];
-                vout[pos] = dense ? (u32)idx : node_of[idx];
-            }
-            pos_of[idx] = pos;
+        local[r] = 0xffffffffu, val[r] = 0u;
+        if (act[r]) {
+            const u32 d = (u32)(key[r] >> shift) & 255u;
+            local[r] = cnt[(r * NWAVE + w) * 256 + d] + rank[r];
+            val[r] = dense ? (u32)idx : node_of[idx];
         }
     }
+    __syncthreads();
+    u64* stage_k = (u64*)cnt;                      // [SR_TILE] 16 KiB
+    u32* stage_v = cnt + 2 * SR_TILE;              // [SR_TILE]  8 KiB
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const i64 idx = tile0 + r * THREADS + tid;
+        if (act[r]) stage_k[local[r]] = key[r], stage_v[local[r]] = val[r];
+        if (idx < n) pos_of[idx] = act[r] ? (u32)tile0 + local[r] : 0xffffffffu;
+    }
+    __syncthreads();
+    const u32 na = n_act;
+    for (u32 i = tid; i < na; i += THREADS) kout[tile0 + i] = stage_k[i], vout[tile0 + i] = stage_v[i];
 }
 
 // ---- dictionary of one top-digit bucket (scan_sort.hip: bucket_dict_kernel, ranked for the stream layout) ------------
