@@ -161,10 +161,22 @@ __global__ __launch_bounds__(SIG_THREADS) void sr_sig_kernel(
         const i32 e0 = row_ptr[v0], e1 = row_ptr[v1];
         const int cnt = e1 - e0;
         const bool use_lds = cnt <= SIG_LDS_CAP;
-        for (int i = tid; i < cnt; i += SIG_THREADS) {
-            const i32 l = lab_prev[col_idx[e0 + i]];
-            if (use_lds) buf[i] = l;
-            else nbr_sorted[e0 + i] = l;
+        // four neighbours per thread and trip: the four column indices first, then the four labels they point at (one
+        // neighbour per trip is a chain of two dependent memory latencies per trip)
+        for (int i0 = tid; i0 < cnt; i0 += 4 * SIG_THREADS) {
+            i32 cc[4], ll[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cc[u] = i0 + u * SIG_THREADS < cnt ? col_idx[e0 + i0 + u * SIG_THREADS] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ll[u] = i0 + u * SIG_THREADS < cnt ? lab_prev[cc[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * SIG_THREADS;
+                if (i < cnt) {
+                    if (use_lds) buf[i] = ll[u];
+                    else nbr_sorted[e0 + i] = ll[u];
+                }
+            }
         }
         __syncthreads();
         int dwave = act ? d : 0;
@@ -227,10 +239,19 @@ __global__ __launch_bounds__(256) void sr_sig_exact_kernel(
     const u32 own = (u32)lab_prev[v];
     bool in_range = own < (u32)L;
     u64 key = (u64)own * pw[L];
-    for (i32 k = s; k < e; ++k) {
-        const u32 l = (u32)lab_prev[col_idx[k]];
-        in_range = in_range && l < (u32)L;
-        key += pw[l < (u32)L ? l : 0];
+    for (i32 k0 = s; k0 < e; k0 += 8) {              // eight neighbours per trip: column indices, then labels, then the code
+        i32 cc[8];
+        u32 ll[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cc[u] = k0 + u < e ? col_idx[k0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ll[u] = cc[u] >= 0 ? (u32)lab_prev[cc[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (cc[u] < 0) continue;
+            in_range = in_range && ll[u] < (u32)L;
+            key += pw[ll[u] < (u32)L ? ll[u] : 0];
+        }
     }
     if (!in_range) atomicAdd(unresolved, 1u);
     u32 x = (u32)key;                    // bijective scramble: the partition's top digit stays balanced
