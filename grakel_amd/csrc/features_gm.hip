@@ -447,15 +447,21 @@ struct GmColumns {
     GmLabelArrays A; const GmTable* Tb; int symmetric; int low_df; int kind; int prim_max; int wide_above; u32* meta;
     const u32* wgmeta; int n_wg;                  // gm_pairs_kernel's per-workgroup (largest count, entries)
     int allow_split;                              // labels with counts above wide_above: split int8 columns (features.h) when <= GM_SPLIT_MAX_PARTS parts do
-    // parts of the split columns from the largest count of the job (one wave; every workgroup of the scans derives the same)
-    __device__ __forceinline__ int parts_by_wave(int lane) const {
+    // parts of the split columns from the largest count of the job: every workgroup of the scans derives the same from the pair
+    // kernel's per-workgroup maxima, all of its threads loading at once (a single wave walking the list was 3 us per workgroup)
+    __device__ __forceinline__ int parts_by_block(u32* red /* [G3_THREADS / 64] shared */) const {
         if (!allow_split) return 0;
         u32 m = 0;
-        for (int k = lane; k < n_wg; k += 64) m = wgmeta[2 * k] > m ? wgmeta[2 * k] : m;
+        for (int k = threadIdx.x; k < n_wg; k += blockDim.x) m = wgmeta[2 * k] > m ? wgmeta[2 * k] : m;
         for (int off = 32; off > 0; off >>= 1) {
             const u32 o = __shfl_xor(m, off, 64);
             m = o > m ? o : m;
         }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = red[w] > m ? red[w] : m;
+        __syncthreads();
         const u32 p = (m + 126u) / 127u;
         return (p >= 2u && p <= (u32)GM_SPLIT_MAX_PARTS) ? (int)p : 0;
     }
@@ -502,7 +508,9 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_sums_kernel(const GmColumn
     __shared__ Gm3 wsum[G3_THREADS / 64];
     const i64 base = (i64)blockIdx.x * G3_TILE;
     const i64 Q = f.Tb->Q;                      // the grid covers the bound the arrays were allocated for
-    const int parts = f.parts_by_wave(threadIdx.x & 63);
+    if (base >= Q) return;                      // (gm_scan_apply_kernel only reads the sums of the tiles in use)
+    __shared__ u32 pred[G3_THREADS / 64];
+    const int parts = f.parts_by_block(pred);
     Gm3 s{0, 0, 0};
 #pragma unroll
     for (int i = 0; i < G3_ITEMS; ++i) {
@@ -526,7 +534,8 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColum
     const i64 Q = f.Tb->Q;
     const i64 last_tile = Q > 0 ? (Q - 1) / G3_TILE : 0;
     if ((i64)blockIdx.x > last_tile) return;         // the grid covers the bound the arrays were allocated for
-    const int parts = f.parts_by_wave(lane);
+    __shared__ u32 pred[G3_THREADS / 64];
+    const int parts = f.parts_by_block(pred);
     if (blockIdx.x == 0 && w == 0) {                  // fold the pair kernel's per-workgroup statistics
         u32 m = 0, e = 0;
         for (int k = lane; k < f.n_wg; k += 64) m = f.wgmeta[2 * k] > m ? f.wgmeta[2 * k] : m, e += f.wgmeta[2 * k + 1];

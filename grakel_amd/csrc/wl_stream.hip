@@ -87,6 +87,17 @@ __global__ __launch_bounds__(256) void sr_init_kernel(u32* __restrict__ ctl, int
     for (int l = 1; l < n_levels; ++l) labels[(size_t)l * V + v] = id;
 }
 
+#ifdef GK_ABLATION
+// tools' build only: timing ablations of the stream relabel's kernels (WRONG results by construction, the job falls back to the
+// host-driven route or fails its checks).  GK_SR_ABL bit 1: signatures without the neighbour-list write-back, 2: without
+// the per-node sort, 4: without the gather (labels = column indices), 8: finish without the verification, 16: finish without the
+// frozen nodes' later-level writes
+__device__ int g_sr_abl;
+#define SR_ABL(bit) (g_sr_abl & (bit))
+#else
+#define SR_ABL(bit) 0
+#endif
+
 // ---- signatures -------------------------------------------------------------------------------------------------------
 template <bool LEVEL1>
 __global__ __launch_bounds__(SIG_THREADS) void sr_sig_kernel(
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(SIG_THREADS) void sr_sig_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u) cc[u] = i0 + u * SIG_THREADS < cnt ? col_idx[e0 + i0 + u * SIG_THREADS] : 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ll[u] = i0 + u * SIG_THREADS < cnt ? lab_prev[cc[u]] : 0;
+            for (int u = 0; u < 4; ++u) ll[u] = i0 + u * SIG_THREADS < cnt ? (SR_ABL(4) ? cc[u] : lab_prev[cc[u]]) : 0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * SIG_THREADS;
@@ -188,7 +199,8 @@ __global__ __launch_bounds__(SIG_THREADS) void sr_sig_kernel(
                 i32 r[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) r[k] = (k < d && (k < 8 || dwave > 8)) ? x[k] : 0x7fffffff;
-                if (dwave <= 8) sort_regs<8>(r);
+                if (SR_ABL(2)) {}
+                else if (dwave <= 8) sort_regs<8>(r);
                 else sort_regs<16>(r);
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(SIG_THREADS) void sr_sig_kernel(
             }
         }
         __syncthreads();
-        if (use_lds)
+        if (use_lds && !SR_ABL(1))
             for (int i = tid; i < cnt; i += SIG_THREADS) nbr_sorted[e0 + i] = buf[i];
     } else if (act) {
         // sparse chunk: the few active nodes gather their own lists
@@ -642,11 +654,12 @@ __global__ __launch_bounds__(1024) void sr_finish_kernel(const u32* __restrict__
             const u32 id = ncc + F + S + bsi[lo] + rank;
             lab[v] = (i32)id;
             const i32 fin = (i32)(id - S);       // = n_cc + F_{l+1} slot: the node's id at every later level
-            for (int l2 = level + 1; l2 < n_levels; ++l2) labels[(size_t)l2 * V + v] = fin;
+            if (!SR_ABL(16))
+                for (int l2 = level + 1; l2 < n_levels; ++l2) labels[(size_t)l2 * V + v] = fin;
         } else {
             shared = true;
             lab[v] = (i32)(ncc + F + bsh[lo] + rank);
-            if (verify) {
+            if (verify && !SR_ABL(8)) {
                 const i32 r = rep2[(size_t)lo * SRD_SLOTS + rank];
                 if (r != v) {
                     const i32* lab_prev = labels + (size_t)(level - 1) * V;
@@ -703,6 +716,13 @@ int gk_sr_rebuild_order(gk_ctx* ctx, gk_batch* b, int level) {
 // Queues the whole relabel (no host read-back).  GK_OK: queued, b->sr_pending = n_levels until gk_sr_collect has seen the
 // control words; GK_ERR_UNSUPPORTED: not a job for this route (nothing was queued).
 int gk_sr_enqueue(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool default_bits) {
+#ifdef GK_ABLATION
+    {
+        const char* e = getenv("GK_SR_ABL");
+        const int v = e ? atoi(e) : 0;
+        GK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sr_abl), &v, sizeof v));
+    }
+#endif
     const i64 V = b->n_nodes;
     const i64 n_car = b->n_iso;
     // ---- is this the job this route is built for?  (graph batches of small graphs whose features the graph-major builder
