@@ -622,3 +622,22 @@ def test_limits_fail_early_and_reference_base_classes_are_accepted():
     wl = WeisfeilerLehman(base_graph_kernel=(fake_sp, {"with_labels": True}))
     wl.initialize()
     assert wl._base_graph_kernel is ShortestPath
+
+
+def test_c_header_is_plain_c_and_the_multi_gpu_stub_type_checks():
+    """include/gk_hip.h must be consumable by a C compiler (the boundary is a C ABI), and INTEGRATION.md's section C --
+    kept as tests/c_abi/multi_gpu_stub.c -- must match the declared signatures (gcc -fsyntax-only; nothing runs)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = os.path.join(ROOT, "tests", "c_abi", "multi_gpu_stub.c")
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    # the calls of INTEGRATION.md's section C are the calls of the stub
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = text[text.index("## C. Multi-GPU without Python"):text.index("## Build / deploy")]
+    stub = open(src).read()
+    for call in re.findall(r"\b(gk_[a-z0-9_]+)\(", section.split("```c")[1].split("```")[0]):
+        assert call + "(" in stub, call
