@@ -716,6 +716,14 @@ def test_counts_of_128_to_381_are_split_into_int8_digit_columns(gk, gkopt, n, n_
     feat2 = eng.features(db, 2)
     assert "f64" in feat2.operand and np.array_equal(eng.gram(feat2, 0), K)
     gkopt("gram.no_split8", 0)
+    # every form of the tile kernel takes the two operands (left rows x right rows), also without the symmetric shortcut
+    for form in (("gram.no_ws",), ("gram.dd",), ("gram.dd=2",), ("gram.no_sym",), ("gram.no_patch",), ("gram.no_ws", "gram.no_sym")):
+        for k in form:
+            gkopt(k.split("=")[0], int(k.split("=")[1]) if "=" in k else 1)
+        assert np.array_equal(eng.gram(feat, 0), K), form
+        assert np.array_equal(eng.gram(feat, 0, rows=(5, N - 9)), K[5:N - 9]), form
+        for k in form:
+            gkopt(k.split("=")[0], 0)
     # public API
     rs = np.random.RandomState(n)
     G = []
