@@ -1669,8 +1669,190 @@ static int gram_copy_out_narrow(gk_ctx* ctx, const double* K_dev, i64 n_entries,
     return GK_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Triangle form of the compact copy (round 5): the WHOLE symmetric matrix of a fit_transform.  Only the 256 x 256 blocks
+// on and above the diagonal cross PCIe (half the bytes of the rectangular form: config 3 105 MB instead of 200), block-major
+// so that a host thread owns a whole block: it widens the block into its own rows of the caller's matrix and -- off the
+// diagonal -- writes the mirrored block from the same 128 KiB (L2-resident) staging data, rows of 256 float64 with
+// non-temporal stores.  NORMALISED jobs take the same road: the device matrix stays the exact integer one (the lean,
+// unnormalised tile kernel), the 8 N-byte self-similarity vector comes along, and the widening threads multiply every
+// entry by rs[i] * rs[j], rs = 1 / sqrt(self similarity) -- the product is formed first, so the result is exactly
+// symmetric; the diagonal is exactly 1 (a graph without features: NaN, or 0 under nan_to_num, as the reference's 0/0).
+// Normalised host matrices then cost what unnormalised ones do (before: the FULL tile kernel + a plain 8 N^2-byte copy).
+// ---------------------------------------------------------------------------------------
+#define GC_TB 256
+template <typename T>
+__global__ __launch_bounds__(256) void gram_pack_tri_kernel(const double* __restrict__ K, i64 N, int nb, T* __restrict__ out) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const i64 p = (i64)bi * nb - (i64)bi * (bi - 1) / 2 + (bj - bi);
+    T* __restrict__ o = out + p * (i64)(GC_TB * GC_TB);
+    const i64 col = (i64)bj * GC_TB + threadIdx.x;
+    const bool col_ok = col < N;
+    const i64 r0 = (i64)bi * GC_TB;
+#pragma unroll 4
+    for (int r = 0; r < GC_TB; ++r) {
+        const i64 row = r0 + r;
+        const double v = (col_ok && row < N) ? __builtin_nontemporal_load(K + row * N + col) : 0.0;
+        o[(i64)r * GC_TB + threadIdx.x] = (T)v;
+    }
+}
+
+// one block of the triangle: staging data `src` [256][256] -> rows [r0, r0 + nr) x columns [c0, c0 + nc) of `out` and, when
+// mirror, rows [c0, c0 + nc) x columns [r0, r0 + nr).  rs == nullptr: plain widening
+template <typename T>
+static void widen_tri_block(const T* __restrict__ src, double* __restrict__ out, i64 N, i64 r0, int nr, i64 c0, int nc, bool mirror,
+                            const double* __restrict__ rs, const double* __restrict__ diag_val) {
+    alignas(64) double line[GC_TB];
+    for (int r = 0; r < nr; ++r) {
+        const T* __restrict__ s = src + (size_t)r * GC_TB;
+        double* __restrict__ d = out + (size_t)(r0 + r) * (size_t)N + (size_t)c0;
+        if (rs) {
+            const double fr = rs[r0 + r];
+            for (int c = 0; c < nc; ++c) line[c] = (double)s[c] * (fr * rs[c0 + c]);
+            if (!mirror) line[r] = diag_val[r0 + r];              // a diagonal block: entry (r, r)
+        } else {
+            for (int c = 0; c < nc; ++c) line[c] = (double)s[c];
+        }
+        int c = 0;
+        for (; c < nc && ((uintptr_t)(d + c) & 15); ++c) d[c] = line[c];
+        for (; c + 2 <= nc; c += 2) _mm_stream_pd(d + c, _mm_loadu_pd(line + c));
+        for (; c < nc; ++c) d[c] = line[c];
+    }
+    if (!mirror) return;
+    for (int c = 0; c < nc; ++c) {
+        const T* __restrict__ s = src + c;
+        double* __restrict__ d = out + (size_t)(c0 + c) * (size_t)N + (size_t)r0;
+        if (rs) {
+            const double fc = rs[c0 + c];
+            for (int r = 0; r < nr; ++r) line[r] = (double)s[(size_t)r * GC_TB] * (rs[r0 + r] * fc);
+        } else {
+            for (int r = 0; r < nr; ++r) line[r] = (double)s[(size_t)r * GC_TB];
+        }
+        int r = 0;
+        for (; r < nr && ((uintptr_t)(d + r) & 15); ++r) d[r] = line[r];
+        for (; r + 2 <= nr; r += 2) _mm_stream_pd(d + r, _mm_loadu_pd(line + r));
+        for (; r < nr; ++r) d[r] = line[r];
+    }
+}
+
+template <typename T>
+static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N, int normalize, double* out_host) {
+    if (!ctx->stage_host) {
+        void* h = nullptr;
+        GK_HIP_CHECK(hipHostMalloc(&h, GC_CHUNK * GC_SLOTS, hipHostMallocDefault));
+        ctx->stage_host = h;
+        for (int i = 0; i < GC_SLOTS; ++i) GK_HIP_CHECK(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+    }
+    const int nb = (int)cdiv(N, GC_TB);
+    const i64 n_blocks = (i64)nb * (nb + 1) / 2;
+    const size_t block_elems = (size_t)GC_TB * GC_TB;
+    Tmp<T> packed(ctx);
+    GK_TRY(packed.alloc((size_t)n_blocks * block_elems));
+    gram_pack_tri_kernel<T><<<dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, ctx->stream>>>(K_dev, N, nb, packed.p);
+    GK_HIP_CHECK(hipGetLastError());
+    // normalised: the factors from the exact self similarities (they come back with the first chunk's synchronisation)
+    std::vector<double> rs, dv;
+    std::vector<u64> sk;
+    if (normalize) {
+        sk.resize((size_t)N);
+        GK_HIP_CHECK(hipMemcpyAsync(sk.data(), f->selfk, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    const int per_chunk = (int)(GC_CHUNK / (block_elems * sizeof(T)));            // blocks per chunk: 64 (uint16) / 32 (int32)
+    const int n_chunks = (int)cdiv(n_blocks, (i64)per_chunk);
+    int n_thr = ctx->opt.gram_copy_threads > 0 ? ctx->opt.gram_copy_threads : (int)std::thread::hardware_concurrency();
+    if (ctx->opt.gram_copy_threads <= 0 && n_thr > 16) n_thr = 16;
+    if (n_thr < 1) n_thr = 1;
+    // block index -> (bi, bj): first block of every block row
+    std::vector<i64> row_first((size_t)nb + 1);
+    for (int bi = 0; bi <= nb; ++bi) row_first[(size_t)bi] = (i64)bi * nb - (i64)bi * (bi - 1) / 2;
+    std::atomic<int> ready(0), stop(0);
+    std::vector<std::atomic<int>> done((size_t)n_chunks);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    const T* stage = (const T*)ctx->stage_host;
+    const double* rsp = nullptr;
+    const double* dvp = nullptr;
+    auto chunk_blocks = [&](int c) { return (int)std::min<i64>((i64)per_chunk, n_blocks - (i64)c * per_chunk); };
+    auto worker = [&](int w) {
+        int bi = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            for (unsigned spins = 0; ready.load(std::memory_order_acquire) <= c; ++spins) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                if (spins < 4096) _mm_pause(); else std::this_thread::yield();
+            }
+            const int nbk = chunk_blocks(c);
+            for (int k = w; k < nbk; k += n_thr) {
+                const i64 p = (i64)c * per_chunk + k;
+                while (row_first[(size_t)bi + 1] <= p) ++bi;
+                const int bj = bi + (int)(p - row_first[(size_t)bi]);
+                const i64 r0 = (i64)bi * GC_TB, c0 = (i64)bj * GC_TB;
+                widen_tri_block<T>(stage + ((size_t)(c % GC_SLOTS) * per_chunk + (size_t)k) * block_elems, out_host, N, r0,
+                                   (int)std::min<i64>(GC_TB, N - r0), c0, (int)std::min<i64>(GC_TB, N - c0), bj != bi, rsp, dvp);
+            }
+            _mm_sfence();
+            done[(size_t)c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    int rc = GK_OK;
+    auto queue_chunk = [&](int c) -> bool {
+        const int slot = c % GC_SLOTS;
+        return hipMemcpyAsync((char*)ctx->stage_host + (size_t)slot * GC_CHUNK, packed.p + (size_t)c * per_chunk * block_elems,
+                              (size_t)chunk_blocks(c) * block_elems * sizeof(T), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+               hipEventRecord(ctx->stage_ev[slot], ctx->stream) == hipSuccess;
+    };
+    for (int c = 0; c < n_chunks && c < GC_SLOTS; ++c)
+        if (!queue_chunk(c)) { rc = GK_ERR_HIP; break; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)n_thr);
+    for (int c = 0; c < n_chunks && rc == GK_OK; ++c) {
+        if (hipEventSynchronize(ctx->stage_ev[c % GC_SLOTS]) != hipSuccess) { rc = GK_ERR_HIP; break; }
+        if (c == 0) {          // the self similarities are on the host now (same stream, queued before chunk 0)
+            if (normalize) {
+                rs.resize((size_t)N), dv.resize((size_t)N);
+                const double nan = std::numeric_limits<double>::quiet_NaN();
+                for (i64 i = 0; i < N; ++i) {
+                    const u64 s = sk[(size_t)i];
+                    // a graph without features: the reference's 0 / 0 (NaN; 0 after numpy.nan_to_num, mode 2)
+                    rs[(size_t)i] = s ? 1.0 / std::sqrt((double)s) : (normalize == 2 ? 0.0 : nan);
+                    dv[(size_t)i] = s ? 1.0 : (normalize == 2 ? 0.0 : nan);
+                }
+                rsp = rs.data(), dvp = dv.data();
+            }
+            for (int w = 0; w < n_thr; ++w) pool.emplace_back(worker, w);
+        }
+        ready.store(c + 1, std::memory_order_release);
+        if (c + GC_SLOTS < n_chunks) {          // the slot is refilled once every thread is done with chunk c
+            for (unsigned spins = 0; done[(size_t)c].load(std::memory_order_acquire) < n_thr; ++spins)
+                if (spins < 4096) _mm_pause(); else std::this_thread::yield();
+            if (!queue_chunk(c + GC_SLOTS)) { rc = GK_ERR_HIP; break; }
+        }
+    }
+    if (rc != GK_OK) stop.store(1);
+    for (auto& t : pool) t.join();
+    if (rc != GK_OK) {
+        (void)hipGetLastError();
+        gk_set_error("gk_gram: the compact device-to-host copy failed");
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return GK_OK;
+}
+
+// does a host-output job of these rows take the triangle form?  (gk_gram_rows then leaves a NORMALISED job's device
+// matrix unnormalised: the factors are applied by the host threads)
+static bool gram_copy_is_tri(const gk_ctx* ctx, const gk_feat* f, i64 row_lo, i64 M) {
+    const i64 N = f->n_graphs;
+    return f->symmetric && row_lo == 0 && M == N && !ctx->opt.gram_no_compact && !ctx->opt.gram_no_tri && N >= 2048 &&
+           f->k_bound > 0.0 && f->k_bound < 2147483647.0;
+}
+
 // K_dev [n_entries] float64 on the device -> out_host; integer-valued matrices below the job's bound go compact
-static int gram_copy_out(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 n_entries, int normalize, double* out_host) {
+static int gram_copy_out(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 n_entries, int normalize, double* out_host, bool tri) {
+    if (tri) {
+        if (f->k_bound < 65536.0) return gram_copy_out_tri<uint16_t>(ctx, f, K_dev, f->n_graphs, normalize, out_host);
+        return gram_copy_out_tri<int32_t>(ctx, f, K_dev, f->n_graphs, normalize, out_host);
+    }
     const bool compact = normalize == 0 && !ctx->opt.gram_no_compact && n_entries >= ((i64)4 << 20) && f->k_bound > 0.0 &&
                          f->k_bound < 2147483647.0;
     if (compact && f->k_bound < 65536.0) return gram_copy_out_narrow<uint16_t>(ctx, K_dev, n_entries, out_host);
@@ -1694,8 +1876,11 @@ extern "C" int gk_gram_rows(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row
     void* q = nullptr;
     GK_TRY(gk_dev_alloc(ctx, &q, (size_t)(M > 0 ? M : 1) * n_cols * 8));
     f->K = (double*)q, f->K_rows = M, f->K_cols = n_cols;
-    GK_TRY(gk_gram_launch(ctx, f, row_lo, row_hi, normalize, f->K));
-    if (out_host && M > 0) GK_TRY(gram_copy_out(ctx, f, f->K, M * n_cols, normalize, out_host));
+    // a whole symmetric matrix bound for the host: the triangle form of the compact copy, which also normalises -- the
+    // device matrix of such a job stays the exact integer one (gk_gram_checksum / gk_gram_dev_ptr then see THAT matrix)
+    const bool tri = out_host && M > 0 && gram_copy_is_tri(ctx, f, row_lo, M);
+    GK_TRY(gk_gram_launch(ctx, f, row_lo, row_hi, tri ? 0 : normalize, f->K));
+    if (out_host && M > 0) GK_TRY(gram_copy_out(ctx, f, f->K, M * n_cols, normalize, out_host, tri));
     return GK_OK;
 }
 

@@ -197,12 +197,16 @@ class ShardExchange(object):
             self.weight_step = float(st.item())
             w = (np.asarray(local.edge_weight, dtype=np.int64) if local.edge_weight is not None
                  else np.ones(local.n_edges, dtype=np.int64))
-            w = w * int(round(step_local / self.weight_step))
-            too_big = torch.tensor([1 if (w.size and int(w.max()) >= MAX_EDGE_WEIGHT) else 0], dtype=torch.int64, device=dev)
-            dist.all_reduce(too_big, op=dist.ReduceOp.MAX, group=group)          # every rank raises, or none does
+            # the ratio of two powers of two, as a Python int: the check below cannot overflow, and it runs BEFORE any
+            # int64 multiply so that every rank reaches the collective (every rank raises, or none does)
+            ratio = int(round(step_local / self.weight_step))
+            wmax = int(w.max()) if w.size else 0
+            too_big = torch.tensor([1 if ratio * wmax >= MAX_EDGE_WEIGHT else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(too_big, op=dist.ReduceOp.MAX, group=group)
             if int(too_big.item()):
                 raise NotImplementedError('edge weights of the shards need more than 20 bits at their common '
                                           'power-of-two step')
+            w = w * ratio
             self.weights = _pad_to(T(w.astype(np.int32)), me, torch)
 
     def gather_weights(self):
@@ -362,10 +366,15 @@ class ShardedWL(object):
             self.engine.set_stream(0)
             self._stream = None
 
-    def step(self, local_batch, to_host=False, label_map=None, keep=False):
+    def step(self, local_batch, to_host=False, label_map=None, keep=False, block_rows=0, on_block=None):
         """One fit_transform: returns (row block [n_local x N] or None, info dict).  ``label_map``: see
         ``ShardExchange`` (needed when the shard was ingested on its own).  ``keep``: leave the features (and
-        with them the rank's row block in HBM) alive as info["feat"] / info["batch"]; the caller closes them."""
+        with them the rank's row block in HBM) alive as info["feat"] / info["batch"]; the caller closes them.
+        ``block_rows`` > 0: the rank's rows are multiplied in sub-blocks of at most that many rows which REUSE one device
+        buffer (a row block that does not fit HBM: 200 000 graphs are 320 GB of float64); ``on_block(feat, (lo, hi))`` is
+        called after each sub-block is queued (checksums, a copy to a pinned buffer) -- nothing is returned then.
+        ``self.phase_events`` = four events on the shared stream: start | exchange + rebuild of the global batch | relabel +
+        features (replicated) | the rank's Gram rows."""
         import torch
         import torch.distributed as dist
         rank = dist.get_rank(self.group)
@@ -376,16 +385,31 @@ class ShardedWL(object):
         s.wait_stream(torch.cuda.current_stream(dev))   # the shard message was built on the caller's stream
         ex = self._exchange
         eng = self.engine
+        pe = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         with torch.cuda.stream(s):
+            pe[0].record()
             flat = ex.gather_flat()
             n_labels, bounds = ex.n_labels, ex.bounds
             # the global CSR is rebuilt from the gathered messages by the library (two scans + one copy kernel)
             db = eng.batch_from_shards(ex.all_sizes[:, :3], ex.mg, ex.mv, ex.me, flat.data_ptr(), n_labels)
+            pe[1].record()
             counts = eng.wl_relabel(db, self.n_iter)
             feat = eng.features(db, self.n_iter + 1)
+            pe[2].record()
             rows = (bounds[rank], bounds[rank + 1])
             N = db.n_graphs
-            if self.symmetric and self.ws > 1:
+            if block_rows and block_rows > 0:
+                K, info, gms, gfl = None, dict(), 0.0, 0.0
+                for lo in range(rows[0], rows[1], int(block_rows)):
+                    sub = (lo, min(lo + int(block_rows), rows[1]))
+                    eng.gram(feat, 2 if self.normalize else 0, rows=sub, to_host=False)
+                    if on_block is not None:
+                        on_block(feat, sub)
+                    fl, ms = eng.gram_stats(feat)         # (reads the block's events: the sub-blocks run back to back anyway)
+                    gms, gfl = gms + ms, gfl + fl
+                info["gram_blocks"] = -(-(rows[1] - rows[0]) // int(block_rows))
+                info["gram_sum"] = (gfl, gms)
+            elif self.symmetric and self.ws > 1:
                 Kdev = self._symmetric_rows(eng, feat, bounds, rank, N, dev)
                 if self.normalize:
                     eng.gram_normalize_rows(feat, rows, Kdev.data_ptr(), 2)
@@ -394,8 +418,10 @@ class ShardedWL(object):
             else:
                 K = eng.gram(feat, 2 if self.normalize else 0, rows=rows, to_host=to_host)
                 info = dict()
+            pe[3].record()
+            self.phase_events = pe
             info.update(label_counts=counts, n_cols=feat.n_cols, n_cols_low=feat.n_cols_low, rows=rows,
-                        n_graphs=N, gram=eng.gram_stats(feat), dtype=feat.dtype, operand=feat.operand)
+                        n_graphs=N, gram=info.pop("gram_sum", None) or eng.gram_stats(feat), dtype=feat.dtype, operand=feat.operand)
             if keep:
                 info["feat"], info["batch"] = feat, db
             else:

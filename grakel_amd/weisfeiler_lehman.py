@@ -340,11 +340,14 @@ class WeisfeilerLehman(Kernel):
             self._X_diag, self._Y_diag = xd * float(self._n_iter), yd * float(self._n_iter)
             self._is_transformed = True
             return self._eh_scale(K, self._Y_diag, self._X_diag)
-        K = self._transform_lookup(X)
+        # ONE ingestion for both routes (a one-shot iterable is exhausted by the first walk; a list would pay the host
+        # walk twice): `_ingest` hands a ready GraphBatch back unchanged
+        ybatch, _ = self._ingest(X, self._label_map if self._label_map is not None else {})
+        K = self._transform_lookup(ybatch)
         if K is not None:
             self._is_transformed = True
             return K
-        eng, feat = self._gram_transform(X)
+        eng, feat = self._gram_transform(ybatch)
         self._is_transformed = True
         return eng.gram(feat, NORM_NAN_TO_NUM if self.normalize else NORM_NONE)
 

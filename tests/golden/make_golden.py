@@ -392,16 +392,69 @@ def round3():
     print("round3.npz", {k: v.shape for k, v in out.items()})
 
 
+def published_like(only=None):
+    """Round-5 fixtures: stand-ins for the TU datasets the reference publishes its running times on
+    (grakel_amd/synthetic.py: PUBLISHED_LIKE; doc/benchmarks/evaluation.rst:19-73).  WL-subtree h=5 on the FULL sets
+    through the real reference, ShortestPath (labels, adjacency input -> its Floyd-Warshall) on a leading subsample
+    (the full sets take the reference an hour and more: evaluation.rst:25,69)."""
+    from grakel_amd import synthetic as S
+    sp_sample = {"nci1": 0, "dd": 40, "reddit": 24, "collab": 64}
+    for name, (gen, pub) in S.PUBLISHED_LIKE.items():
+        if only and name not in only:
+            continue
+        graphs = gen()
+        G = S.as_grakel(graphs)
+        t0 = time.perf_counter()
+        wl = WeisfeilerLehman(n_iter=5)
+        K = wl.fit_transform(G)
+        dt = time.perf_counter() - t0
+        Ki = as_int(K)
+        del K
+        i, j, v = sample_entries(Ki, 20000, 123)
+        out = dict(n_graphs=np.array([len(G)], np.int64),
+                   label_counts=np.array([len(wl._inv_labels[k]) for k in range(6)], np.int64),
+                   K_sum=np.array([Ki.sum()], np.int64), K_trace=np.array([np.trace(Ki)], np.int64),
+                   K_max=np.array([Ki.max()], np.int64), diag=np.diagonal(Ki).astype(np.int64),
+                   K_block=Ki[:64, :64].astype(np.int64), row_sums=Ki.sum(axis=1).astype(np.int64),
+                   samp_i=i, samp_j=j, samp_v=v.astype(np.int64), ref_seconds=np.array([dt]))
+        print("published-like", name, "WL h=5 ref %.1fs" % dt, "sum", Ki.sum(), "trace", np.trace(Ki), "max", Ki.max(),
+              "counts", out["label_counts"].tolist(), flush=True)
+        # a transform block: the last 20 graphs against a fit on the 200 before them
+        wl2 = WeisfeilerLehman(n_iter=5)
+        wl2.fit(G[-220:-20])
+        out["tr_block"] = as_int(wl2.transform(G[-20:]))
+        del Ki
+        m = sp_sample[name]
+        if m:
+            sub = [g for g in graphs[:4 * m] if g[0] <= 700][:m]
+            out["sp_index"] = np.array([k for k, g in enumerate(graphs[:4 * m]) if g[0] <= 700][:m], np.int64)
+            Ga = S.as_grakel(sub, adjacency=True)
+            t0 = time.perf_counter()
+            sp = ShortestPath()
+            Ks = sp.fit_transform(Ga)
+            sdt = time.perf_counter() - t0
+            out["sp_K"] = as_int(Ks)
+            out["sp_n_features"] = np.array([len(sp._enum)], np.int64)
+            out["sp_ref_seconds"] = np.array([sdt])
+            print("   SP on", len(sub), "graphs ref %.1fs" % sdt, "sum", out["sp_K"].sum(), "features", len(sp._enum), flush=True)
+        np.savez_compressed(os.path.join(HERE, "pub_%s.npz" % name), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip config 3 (~100 s) and NCI1-4110")
     ap.add_argument("--only-state", action="store_true", help="only the fitted-state fixture (mutag_state.npz)")
     ap.add_argument("--only-dyadic", action="store_true", help="only the float-weight ShortestPath fixture (sp_dyadic.npz)")
+    ap.add_argument("--only-published", nargs="*", default=None, metavar="SET",
+                    help="only the round-5 published-dataset stand-ins (pub_<set>.npz); no names = all four")
     ap.add_argument("--only-round3", action="store_true", help="only round3.npz (WL over EdgeHistogram, more than 48 levels)")
     ap.add_argument("--only-float", action="store_true", help="only sp_float.npz (ShortestPath on general float edge weights)")
     ap.add_argument("--only-float-big", action="store_true", help="only sp_float_big.npz (general float weights above 143 vertices, CoreFramework)")
     a = ap.parse_args()
     print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
+    if a.only_published is not None:
+        published_like(a.only_published or None)
+        sys.exit(0)
     if a.only_round3:
         round3()
         sys.exit(0)

@@ -622,14 +622,62 @@ def test_compact_host_copy_is_the_plain_copy(gk, gkopt, n, form):
     plain_rows = eng.gram(feat, 0, rows=(7, N - 3)).copy()
     norm = eng.gram(feat, 2).copy()
     gkopt("gram.no_compact", 0)
-    for threads in (0, 1, 3, 7):
+    # the whole symmetric matrix takes the TRIANGLE form (round 5: only the 256 x 256 blocks on / above the diagonal cross
+    # PCIe, the host threads widen and mirror them); gram.no_tri = 1 keeps the rectangular form of rounds 3-4
+    for no_tri in (0, 1):
+        gkopt("gram.no_tri", no_tri)
+        for threads in (0, 1, 3, 7):
+            gkopt("gram.copy_threads", threads)
+            K = eng.gram(feat, 0)
+            assert np.array_equal(K, plain), (no_tri, threads)
+            del K
+        assert np.array_equal(eng.gram(feat, 0, rows=(7, N - 3)), plain_rows)
+    assert np.array_equal(eng.gram(feat, 2), norm)            # rectangular form: a normalised matrix goes plain
+    # triangle form, normalised: the device keeps the exact integer matrix, the widening threads apply
+    # rs[i] * rs[j] (rs = 1 / sqrt(K_ii)) -- exactly symmetric, diagonal exactly 1, within 2 ulp of the device's own
+    gkopt("gram.no_tri", 0)
+    for threads in (0, 5):
         gkopt("gram.copy_threads", threads)
-        K = eng.gram(feat, 0)
-        assert np.array_equal(K, plain), threads
-        del K
-    assert np.array_equal(eng.gram(feat, 0, rows=(7, N - 3)), plain_rows)
-    assert np.array_equal(eng.gram(feat, 2), norm)
+        Kn = eng.gram(feat, 2)
+        assert np.array_equal(Kn, Kn.T) and np.all(np.diagonal(Kn) == 1.0)
+        assert np.abs(Kn - norm).max() <= 4 * np.finfo(np.float64).eps
+        d = np.sqrt(np.diagonal(plain))
+        assert np.abs(Kn - plain / np.outer(d, d)).max() <= 4 * np.finfo(np.float64).eps
+        del Kn
     assert plain.max() < (65536 if form == "uint16" else 2 ** 31) and np.array_equal(plain, plain.T)
+
+
+def test_triangle_copy_edge_blocks_and_graphs_without_features(gk, gkopt):
+    """The triangle form of the compact copy on a matrix whose size is NOT a multiple of its 256-entry blocks, with graphs
+    that have no ShortestPath feature at all (one vertex: self similarity 0 -> the reference's 0 / 0): NaN rows and columns
+    under ShortestPath's plain normalisation, zeros under WL's nan_to_num, everything else as the plain copy's."""
+    from grakel_amd.batch import sp_batch_from_input
+    from grakel_amd.engine import get_engine
+    eng = get_engine()
+    rs = np.random.RandomState(11)
+    X = []
+    for g in range(2085):                                     # 8 full blocks + 37 rows
+        n = 1 if g % 97 == 5 else int(rs.randint(2, 7))
+        A = np.triu((rs.rand(n, n) < 0.6).astype(int), 1)
+        X.append([A + A.T, dict(enumerate(rs.randint(0, 3, n).tolist()))])
+    gb, _ = sp_batch_from_input(X, True)
+    db = eng.upload(gb)
+    pb = eng.sp_build(db, None, True)
+    feat = eng.features(pb, 1)
+    gkopt("gram.no_compact", 1)
+    plain = eng.gram(feat, 0).copy()
+    n1 = eng.gram(feat, 1).copy()
+    n2 = eng.gram(feat, 2).copy()
+    gkopt("gram.no_compact", 0)
+    assert np.array_equal(eng.gram(feat, 0), plain)
+    for mode, ref in ((1, n1), (2, n2)):
+        K = eng.gram(feat, mode)
+        assert np.array_equal(np.isnan(K), np.isnan(ref)) and np.isnan(ref).any() == (mode == 1)
+        ok = ~np.isnan(ref)
+        assert np.abs(K[ok] - ref[ok]).max() <= 4 * np.finfo(np.float64).eps
+        assert np.array_equal(np.nan_to_num(K), np.nan_to_num(K).T)
+    empty = np.flatnonzero(np.diagonal(plain) == 0)
+    assert len(empty) >= 20 and np.all(n2[empty] == 0) and np.all(np.isnan(n1[empty]))
 
 
 @pytest.mark.parametrize("opts", [(), ("gram.no_fp4",), ("feat.low_df=200",), ("feat.low_df=200", "gram.no_fp4"), ("kind=1",),
@@ -1864,3 +1912,60 @@ def test_integration_md_ctypes_stub_runs_verbatim(gk, mutag_graphs):
     Kt = ns["wl_transform"]((fit.graph_ptr, fit.row_ptr, fit.col_idx, fit.node_label),
                             (tgt.graph_ptr, tgt.row_ptr, tgt.col_idx, tgt.node_label), gb.n_labels, 5)
     assert Kt is not None and np.array_equal(Kt, K[150:, :150])
+
+
+# ------------------------------------------------------------------------------------------
+# round 5: stand-ins for the TU datasets the reference PUBLISHES its running times on
+# (grakel_amd/synthetic.py PUBLISHED_LIKE; goldens by the real grakel 0.1.11, tests/golden/pub_*.npz)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["nci1", "dd", "reddit", "collab"])
+def test_published_like_sets_against_reference_goldens(gk, name):
+    """WL-subtree h=5 on the FULL set (packed CSR through the C ABI: label counts, checksums, diagonal, a corner, 20 000
+    sampled entries and every row sum of the reference's matrix), normalised, `transform` of 20 graphs against a fit on 200
+    through the estimator on Python objects, and ShortestPath on the subsample the reference finished.  These sets leave
+    the Erdos-Renyi sweet spot: thousands of vertices per graph (D&D), hubs of degree > 1 000 and > 256 input labels
+    (REDDIT), mean degree ~ 60 (COLLAB), most WL labels shared by many graphs (NCI1)."""
+    from grakel_amd import GraphBatch, synthetic as S
+    from grakel_amd.engine import get_engine
+    z = load_golden("pub_%s.npz" % name)
+    graphs = S.PUBLISHED_LIKE[name][0]()
+    gp, rp, ci, lab, nl = S.as_csr(graphs)
+    eng = get_engine()
+    db = eng.upload(GraphBatch(gp, rp, ci, lab, nl))
+    feat, K = eng.wl_fit_transform(db, 5, to_host=True)
+    assert db.label_counts == z["label_counts"].tolist()
+    assert K.sum() == float(z["K_sum"][0]) and np.trace(K) == float(z["K_trace"][0]) and K.max() == float(z["K_max"][0])
+    assert np.array_equal(np.diagonal(K), z["diag"]) and np.array_equal(K[:64, :64], z["K_block"])
+    assert np.array_equal(K[z["samp_i"], z["samp_j"]], z["samp_v"])
+    assert np.array_equal(K.sum(axis=1), z["row_sums"]) and np.array_equal(K, K.T)
+    feat.close()
+    feat, Kn = eng.wl_fit_transform(db, 5, normalize=2, to_host=True)
+    d = np.sqrt(np.diagonal(K))
+    assert np.abs(Kn - K / np.outer(d, d)).max() <= REL_TOL and np.all(np.diagonal(Kn) == 1.0)
+    feat.close()
+    db.close()
+    del K, Kn
+    Gt = S.as_grakel(graphs[-220:])
+    est = gk.WeisfeilerLehman(n_iter=5)
+    est.fit(Gt[:200])
+    assert np.array_equal(est.transform(Gt[200:]), z["tr_block"])
+    assert np.array_equal(est.transform(iter(Gt[200:])), z["tr_block"])      # a one-shot iterable: ONE ingestion per call
+    if "sp_K" in z.files:
+        sub = S.as_grakel([graphs[i] for i in z["sp_index"].tolist()], adjacency=True)
+        sp = gk.ShortestPath()
+        assert np.array_equal(sp.fit_transform(sub), z["sp_K"])
+        assert len(sp._enum) == int(z["sp_n_features"][0])
+
+
+def test_transform_of_a_generator_above_the_lookup_threshold(gk):
+    """`transform` ingests its input ONCE: a generator whose targets hold more than 1/32 of the fitted nodes (the look-up
+    route declines, the joint route takes over) used to be exhausted by the first ingestion."""
+    X = er_dataset(60, 20, 0.2, 3, 9)
+    ref = O.WLOracle(n_iter=3)
+    ref.fit_transform(X[:40])
+    Kt = ref.transform(X[40:])
+    est = gk.WeisfeilerLehman(n_iter=3)
+    est.fit(X[:40])
+    assert np.array_equal(est.transform(x for x in X[40:]), Kt)
+    est.transform_route = "lookup"
+    assert np.array_equal(est.transform(x for x in X[40:]), Kt)

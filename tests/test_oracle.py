@@ -292,3 +292,35 @@ def test_oracle_matches_round3_goldens(mutag_graphs):
     eh = O.EHOracle()
     assert np.array_equal(4 * eh.fit_transform(G[:100]), z["wleh_fit"])
     assert np.array_equal(4 * eh.transform(G[100:130]), z["wleh_tr"])
+
+
+@pytest.mark.parametrize("name", ["nci1", "collab"])
+def test_oracle_against_the_published_like_goldens(name):
+    """Round 5: stand-ins for the TU datasets the reference publishes its running times on (grakel_amd/synthetic.py
+    PUBLISHED_LIKE; goldens by the real grakel, tests/golden/make_golden.py --only-published).  The oracle is pinned on the
+    full NCI1-like set (WL h=5) and, for the dense unlabelled kind, on a 600-graph COLLAB-like prefix through the property
+    that K[i, j] only depends on graphs i and j (the prefix's matrix is the corner of the full set's), on the transform
+    block, and on the ShortestPath subsample."""
+    from grakel_amd import synthetic as S
+    z = load_golden("pub_%s.npz" % name)
+    graphs = S.PUBLISHED_LIKE[name][0]()
+    m = len(graphs) if name == "nci1" else 600
+    G = S.as_grakel(graphs[:m])
+    wl = O.WLOracle(n_iter=5)
+    K = wl.fit_transform(G)
+    if m == len(graphs):
+        assert int(K.sum()) == int(z["K_sum"][0]) and int(np.trace(K)) == int(z["K_trace"][0])
+        assert wl.label_counts == z["label_counts"].tolist()
+        assert np.array_equal(K[z["samp_i"], z["samp_j"]], z["samp_v"])
+        assert np.array_equal(K.sum(axis=1), z["row_sums"])
+    else:
+        sel = (z["samp_i"] < m) & (z["samp_j"] < m)
+        assert sel.sum() > 100 and np.array_equal(K[z["samp_i"][sel], z["samp_j"][sel]], z["samp_v"][sel])
+    assert np.array_equal(np.diagonal(K), z["diag"][:m]) and np.array_equal(K[:64, :64], z["K_block"])
+    Gt = S.as_grakel(graphs[-220:])
+    wl2 = O.WLOracle(n_iter=5)
+    wl2.fit_transform(Gt[:200])
+    assert np.array_equal(wl2.transform(Gt[200:]), z["tr_block"])
+    if "sp_K" in z.files:
+        sub = S.as_grakel([graphs[i] for i in z["sp_index"].tolist()], adjacency=True)
+        assert np.array_equal(O.SPOracle().fit_transform(sub), z["sp_K"])
