@@ -54,6 +54,17 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     const i32 e0 = row_ptr[v0], e1 = row_ptr[v1];
     const int cnt = e1 - e0;
     const bool use_lds = cnt <= SIG_LDS_CAP;   // block-uniform
+    const i64 v = v0 + tid;
+    // a chunk whose nodes all belong to the wave / workgroup kernels below (degree > WL_DEG_SMALL: ego networks, cliques)
+    // has nothing to stage here -- round 5: a COLLAB-like batch streamed its 21 M neighbour labels through this loop for
+    // nothing, 130 us per level
+    {
+        const int dv = v < v1 ? row_ptr[v + 1] - row_ptr[v] : 0;
+        if (!__syncthreads_or(dv >= 1 && dv <= WL_DEG_SMALL)) {
+            if (v < v1 && dv == 0) hash[v] = mix64(sig_head((u32)lab_prev[v], 0u, seed)) & mask;
+            return;
+        }
+    }
     // coalesced stream over the chunk's col_idx; the label gather hits L2 (4 B x V table)
     for (int i = tid; i < cnt; i += SIG_THREADS) {
         i32 l = lab_prev[col_idx[e0 + i]];
@@ -61,7 +72,6 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
         else nbr_sorted[e0 + i] = l;
     }
     __syncthreads();
-    const i64 v = v0 + tid;
     // largest degree of the wave: up to 16 neighbours per node are sorted in registers (a fixed network: no
     // dependent LDS round trip per insertion step, no divergence); the multiset hash is a sum, so the order in
     // which the elements are added does not matter
@@ -129,16 +139,123 @@ __device__ __forceinline__ void block_bitonic_sort(P x, int n) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Nodes of degree WL_DEG_SMALL + 1 .. WAVE_DEG_MAX (round 5): ONE WAVE per node, the neighbour labels in registers
+// (striped: element i = 64 r + lane, R = 1, 2, 4, 8 or 16 registers per lane), a bitonic network over the wave -- partners
+// less than 64 apart by a lane shuffle, farther apart in the lane's own registers (static indices) -- coalesced gather and
+// coalesced write of the sorted list, wave reduction of the multiset hash.  No LDS, no workgroup barrier: the workgroup
+// form below (64 KiB of LDS and ~log^2 barriers per NODE) took 3.5 ms per level on a COLLAB-like batch (360 k nodes of
+// degree ~ 60), this one is bound by the gather.
+// ---------------------------------------------------------------------------------------
+#define WAVE_DEG_MAX 1024
+template <int R>
+__device__ __forceinline__ void wave_bitonic_sort(i32 (&x)[R], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int q = r ^ (j >> 6);
+                    if (q > r) {
+                        const bool up = ((r * 64) & k) == 0;          // k >= 128 here: the bit only depends on r
+                        const i32 a = x[r], b = x[q];
+                        const i32 lo = a < b ? a : b, hi = a < b ? b : a;
+                        x[r] = up ? lo : hi, x[q] = up ? hi : lo;
+                    }
+                }
+            } else {
+                const bool lower = (lane & j) == 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const i32 a = x[r];
+                    const i32 b = __shfl_xor(a, j, 64);
+                    const bool up = ((r * 64 + lane) & k) == 0;
+                    x[r] = (lower == up) ? (a < b ? a : b) : (a < b ? b : a);
+                }
+            }
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ u64 wave_node_signature(const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+                                                   i32* __restrict__ nbr_sorted, i32 e0, int d, int lane, u64 seed) {
+    i32 x[R];
+    u64 part = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = r * 64 + lane;
+        x[r] = 0x7fffffff;
+        if (i < d) {
+            x[r] = lab_prev[col_idx[e0 + i]];
+            part += sig_elem((u32)x[r], seed);
+        }
+    }
+    wave_bitonic_sort<R>(x, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = r * 64 + lane;
+        if (i < d) nbr_sorted[e0 + i] = x[r];
+    }
+    return part;
+}
+
+__global__ __launch_bounds__(256) void wl_signature_wave_kernel(
+    const i32* __restrict__ big_nodes, i64 n_big, const i32* __restrict__ row_ptr,
+    const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+    i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask) {
+    const i64 w = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_big) return;
+    const i32 v = big_nodes[w];
+    const i32 e0 = row_ptr[v];
+    const int d = row_ptr[v + 1] - e0;
+    if (d > WAVE_DEG_MAX) return;                 // the workgroup kernel's
+    u64 part;
+    if (d <= 64) part = wave_node_signature<1>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else if (d <= 128) part = wave_node_signature<2>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else if (d <= 256) part = wave_node_signature<4>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else if (d <= 512) part = wave_node_signature<8>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else part = wave_node_signature<16>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) hash[v] = mix64(sig_head((u32)lab_prev[v], (u32)d, seed) + part) & mask;
+}
+
+// the verifier's half for the same nodes: a wave compares the node's sorted list with its class representative's,
+// 64 entries per step (verify_kernel walks a list with ONE thread: 200 us per level on the COLLAB-like batch)
+__global__ __launch_bounds__(256) void verify_big_kernel(const i32* __restrict__ big_nodes, i64 n_big, const i32* __restrict__ row_ptr,
+                                                         const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
+                                                         const i32* __restrict__ lab, const i32* __restrict__ rep,
+                                                         u32* __restrict__ unresolved, const unsigned char* __restrict__ shared) {
+    const i64 w = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_big) return;
+    const i32 v = big_nodes[w];
+    if (shared && !shared[v]) return;              // a singleton is its own representative (rep[] has no entry for it)
+    const i32 r = rep[lab[v] & 0x7fffffff];
+    if (r == v) return;
+    const i32 s = row_ptr[v], sr = row_ptr[r];
+    const int d = row_ptr[v + 1] - s;
+    bool ok = lab_prev[v] == lab_prev[r] && d == row_ptr[r + 1] - sr;
+    if (ok)
+        for (int k = lane; k < d; k += 64)
+            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull && lane == 0) atomicAdd(unresolved, 1u);
+}
+
 __global__ __launch_bounds__(BIG_THREADS) void wl_signature_big_kernel(
     const i32* __restrict__ big_nodes, const i32* __restrict__ row_ptr,
     const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
-    i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask) {
+    i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask, int wave_done) {
     __shared__ i32 buf[BIG_LDS_CAP];
     __shared__ u64 red[BIG_THREADS / 64];
     const int tid = threadIdx.x;
     const i32 v = big_nodes[blockIdx.x];
     const i32 e0 = row_ptr[v];
     const int d = row_ptr[v + 1] - e0;
+    if (wave_done && d <= WAVE_DEG_MAX) return;        // wl_signature_wave_kernel's
     u64 part = 0;
     if (d <= BIG_LDS_CAP) {
         for (int i = tid; i < d; i += BIG_THREADS) {
@@ -636,7 +753,7 @@ __global__ void frozen_assign_verify_kernel(const u32* __restrict__ fidx, const 
 __global__ void verify_kernel(const i32* __restrict__ row_ptr, const i32* __restrict__ lab_prev,
                               const i32* __restrict__ nbr_sorted, i32* __restrict__ lab,
                               const i32* __restrict__ rep, u32* __restrict__ unresolved, i64 n,
-                              unsigned char* __restrict__ shared_out) {
+                              unsigned char* __restrict__ shared_out, int skip_big) {
     i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     i32 l = lab[v];
@@ -647,11 +764,13 @@ __global__ void verify_kernel(const i32* __restrict__ row_ptr, const i32* __rest
             return;
         }
     }
+    i32 s = row_ptr[v];
+    int d = row_ptr[v + 1] - s;
+    if (skip_big && d > WL_DEG_SMALL) return;          // verify_big_kernel's (a wave per node)
     const i32 r = rep[l];
     if (r == (i32)v) return;
     bool ok = lab_prev[v] == lab_prev[r];
-    i32 s = row_ptr[v], sr = row_ptr[r];
-    int d = row_ptr[v + 1] - s;
+    i32 sr = row_ptr[r];
     ok = ok && (d == row_ptr[r + 1] - sr);
     if (ok)
         for (int k = 0; k < d; ++k)
@@ -1140,15 +1259,27 @@ int gk_batch_ensure_levels(gk_batch* b, int n_levels) {
 }
 
 
+// nodes of degree > WL_DEG_SMALL: a wave per node up to WAVE_DEG_MAX neighbours, a workgroup per node beyond (hubs);
+// option wl.no_wave_sig keeps everything in the workgroup kernel (rounds 1-4)
+static int launch_signature_big(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash_by_node, u64 seed, u64 mask) {
+    const int wave = ctx->opt.wl_no_wave_sig ? 0 : 1;
+    if (wave)
+        wl_signature_wave_kernel<<<grid_for(b->n_big * 64, 256), 256, 0, ctx->stream>>>(
+            b->big_nodes, b->n_big, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask);
+    if (!wave || b->max_degree > WAVE_DEG_MAX)
+        wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
+            b->big_nodes, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask, wave);
+    GK_HIP_CHECK(hipGetLastError());
+    return GK_OK;
+}
+
 static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash, u64 seed, u64 mask) {
     i64 V = b->n_nodes;
     if (V == 0) return GK_OK;
     const int sig_regs = ctx->opt.wl_sig_no_regs ? 0 : 1;      // route option: insertion sort in LDS instead
     wl_signature_small_kernel<<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
         b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask, sig_regs);
-    if (b->n_big > 0)
-        wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
-            b->big_nodes, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, seed, mask);
+    if (b->n_big > 0) GK_TRY(launch_signature_big(ctx, b, lab_prev, hash, seed, mask));
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }
@@ -1390,8 +1521,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             st.act_cur, n_act, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_act.p, seed, mask);
         if (b->n_big > 0) {
             GK_TRY(hash_node.alloc(V));
-            wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
-                b->big_nodes, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_node.p, seed, mask);
+            GK_TRY(launch_signature_big(ctx, b, prev, hash_node.p, seed, mask));
             gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act_cur, n_act, b->row_ptr, hash_node.p, hash_act.p);
         }
         GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act_cur, st.frozen.p, 0,
@@ -1464,8 +1594,13 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         b->perm_valid[level] = no_order_taken ? 0 : 1;
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
+        const int big_apart = (b->n_big > 0 && !ctx->opt.wl_no_wave_sig) ? 1 : 0;
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V,
-                                                                  flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr);
+                                                                  flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr, big_apart);
+        if (big_apart)
+            verify_big_kernel<<<grid_for(b->n_big * 64, 256), 256, 0, ctx->stream>>>(
+                b->big_nodes, b->n_big, b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev,
+                flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr);
         GK_HIP_CHECK(hipGetLastError());
         if (!exact) break;
         u32 un = 0;

@@ -93,8 +93,9 @@ def test_signature_kernel_matches_numpy(gk):
     from grakel_amd.batch import wl_batch_from_input
     from grakel_amd.engine import get_engine
     G = random_labelled_graphs(60, 2, 25, 0.3, 4, 5, fmt="dict")
-    # a hub of degree 40 (> WL_DEG_SMALL: workgroup bitonic path) and one of degree 20000
-    for hub in (40, 20000):
+    # hubs of degree 40 .. 20000 (> WL_DEG_SMALL)
+    # degree 33..1024: the wave-per-node kernel (1, 2, 4, 8, 16 registers per lane: every boundary), beyond: the workgroup one
+    for hub in (40, 64, 65, 128, 129, 300, 512, 513, 1000, 1024, 1025, 20000):
         ed = {0: list(range(1, hub + 1))}
         ed.update({i: [0] for i in range(1, hub + 1)})
         G.append([ed, {i: (i * 7) % 5 for i in range(hub + 1)}])
@@ -1969,3 +1970,36 @@ def test_transform_of_a_generator_above_the_lookup_threshold(gk):
     assert np.array_equal(est.transform(x for x in X[40:]), Kt)
     est.transform_route = "lookup"
     assert np.array_equal(est.transform(x for x in X[40:]), Kt)
+
+
+@pytest.mark.parametrize("no_wave", [0, 1])
+def test_dense_graphs_and_hubs_through_the_wave_signature_kernels(gk, gkopt, no_wave):
+    """Graphs whose vertices have 33..1024 neighbours (near-cliques, ego networks: the COLLAB kind) take the wave-per-node
+    signature and verification kernels (round 5), hubs beyond 1024 the workgroup kernel; option wl.no_wave_sig = 1 keeps the
+    rounds 1-4 kernels.  Partitions, matrix and transform against the oracle either way."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    gkopt("wl.no_wave_sig", no_wave)
+    rs = np.random.RandomState(3)
+    X = random_labelled_graphs(12, 60, 90, 0.7, 3, 17, fmt="dict")                  # degree ~ 50
+    X += random_labelled_graphs(3, 150, 160, 0.9, 2, 18, fmt="dict")                # degree ~ 140 (R = 4)
+    for hub in (70, 600, 1500):                                                      # stars with a few cross links
+        ed = {0: list(range(1, hub + 1))}
+        ed.update({i: [0] + ([i % hub + 1] if i % 3 == 0 else []) for i in range(1, hub + 1)})
+        for i in range(1, hub + 1):                                                  # make the cross links symmetric
+            for j in ed[i][1:]:
+                if i not in ed[j]:
+                    ed[j].append(i)
+        X.append([ed, {i: int(rs.randint(0, 2)) for i in range(hub + 1)}])
+    X.append(X[0]), X.append(X[-2])                                                  # isomorphic copies: shared classes everywhere
+    wl, K, levels = _oracle_levels(X, 3)
+    gb, _ = wl_batch_from_input(X)
+    eng = get_engine()
+    db = eng.upload(gb)
+    counts = eng.wl_relabel(db, 3)
+    assert counts == [len(set(l.tolist())) for l in levels]
+    for lvl in range(4):
+        assert same_partition(eng.wl_labels(db, lvl), levels[lvl])
+    est = gk.WeisfeilerLehman(n_iter=3)
+    assert np.array_equal(est.fit_transform(X), K)
+    assert np.array_equal(est.transform(X[3:9]), K[3:9])

@@ -15,7 +15,7 @@ for s in $sets; do
       || echo "{\"error\": \"rc $? (timeout ${PUB_TIMEOUT:-150}s or failure)\"}" >> "$out/pub_${s}_${mode}.json"
     tail -c 700 "$out/pub_${s}_${mode}.json"; echo
   done
-  for mode in wl sp; do
+  for mode in ${PUB_TRACE:-wl sp}; do
     timeout ${PUB_TIMEOUT:-150} rocprofv3 --kernel-trace --stats --output-format csv -d "$out/pt_${s}_${mode}" -- \
       python $root/tools/published_like.py $s $mode 3 > /dev/null 2> "$out/pt_${s}_${mode}.log"
     cp "$(ls $out/pt_${s}_${mode}/*/*kernel_stats.csv 2>/dev/null | head -1)" "$out/pub_${s}_${mode}_kernel_stats.csv" 2>/dev/null
