@@ -82,6 +82,7 @@ struct gk_opts {
     int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
     int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
     int wl_no_wave_sig = 0;      // 1: nodes of degree 33..1024 keep the workgroup signature kernel and the one-thread verifier (rounds 1-4) instead of the wave-per-node kernels
+    int gram_no_avx2 = 0;        // 1: the widening threads keep to SSE2 (what a CPU without AVX2 runs)
     int gram_no_tri = 0;         // 1: a full symmetric matrix does NOT take the triangle form of the compact copy (blocks on / above the diagonal over PCIe, mirrored -- and, for normalised jobs, scaled -- by the host threads)
     // ShortestPath
     int sp_no_hist = 0;          // pair features through explicit pair items + the sorting dictionary instead of per-graph histograms
@@ -93,6 +94,8 @@ struct gk_opts {
     int poison = 0;              // debug: fill every block handed out by the allocator with this byte pattern (| 0x100)
 };
 
+struct GkHostPool;
+void gk_host_pool_destroy(GkHostPool* p);
 struct gk_ctx {
     int device = 0;
     gk_opts opt;
@@ -114,6 +117,7 @@ struct gk_ctx {
     // pinned staging ring + events of the compact device -> host copy of a Gram matrix (gram.hip: gram_copy_out)
     void* stage_host = nullptr;
     hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    struct GkHostPool* host_pool = nullptr;    // host threads of that copy's widening (created on first use, joined by gk_destroy)
     u32 mbox_seq = 0;
     int n_cu = 0;                              // compute units of the device (persistent-kernel grids)
     std::map<const void*, int> func_lds;       // kernel -> dynamic LDS limit already set for THIS context's device (gk_func_lds)
@@ -238,6 +242,7 @@ struct gk_batch {
     i32* sp_dist = nullptr;            // the n x n matrices (SP_INF = unreachable)
     u32* sp_idtab = nullptr;           // [sp_keyspace] key -> dense feature id
     i64 sp_L = 0, sp_dcap = 0, sp_keyspace = 0, sp_src_nodes = 0;
+    i32 sp_max_nodes = 0;       // largest source graph (sp_emit_kernel's slab grid)
     int sp_with_labels = 0;
     // level 0 of a batch with at most GK_HIST0_MAX_LABELS input labels is never sorted: the label-count
     // features of that level come from one LDS histogram per graph (features.hip), perm[0] stays unused

@@ -29,10 +29,16 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
-#include <emmintrin.h>
+#include <immintrin.h>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -1698,42 +1704,132 @@ __global__ __launch_bounds__(256) void gram_pack_tri_kernel(const double* __rest
     }
 }
 
+// ---- host side of the triangle form.  The widening is CPU work (2-4 cycles per entry in plain SSE2: 16 threads took 5.6 ms
+// for the 10^8 entries of config 3 while the 105 MB crossed PCIe in 1.9 ms -- tools/micro/hostwrite.hip: the 800 MB can be
+// written in 2.7 ms), so: AVX2 rows (4 entries per convert, 32-byte non-temporal stores) when the CPU has it, the mirrored
+// block through eight column buffers (every staging cache line read once per eight columns), blocks handed out one by one
+// from an atomic counter (a diagonal block costs half a mirrored one), and a thread pool that outlives the call.
+struct GkHostPool {
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> threads;
+    std::function<void(int)> fn;
+    u64 gen = 0;
+    int active = 0, finished = 0;
+    bool quit = false;
+    void ensure(int n) {
+        while ((int)threads.size() < n) {
+            const int idx = (int)threads.size();
+            threads.emplace_back([this, idx] {
+                u64 seen = 0;
+                for (;;) {
+                    std::function<void(int)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_go.wait(lk, [&] { return quit || (gen != seen && idx < active); });
+                        if (quit) return;
+                        seen = gen;
+                        f = fn;
+                    }
+                    f(idx);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        ++finished;
+                    }
+                    cv_done.notify_all();
+                }
+            });
+        }
+    }
+    void start(int n, std::function<void(int)> f) {
+        ensure(n);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = std::move(f), active = n, finished = 0, ++gen;
+        }
+        cv_go.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return finished >= active; });
+        active = 0;
+    }
+    ~GkHostPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv_go.notify_all();
+        for (auto& t : threads) t.join();
+    }
+};
+void gk_host_pool_destroy(GkHostPool* p) { delete p; }
+
+// one row: dst[c] = (double)src[c] (* fr * rs[c] when rs); SSE2 baseline
+template <typename T>
+static void widen_row_sse2(const T* __restrict__ s, double* __restrict__ d, int n, const double* __restrict__ rs, double fr) {
+    int c = 0;
+    if (rs) {
+        for (; c < n && ((uintptr_t)(d + c) & 15); ++c) d[c] = (double)s[c] * (fr * rs[c]);
+        for (; c + 2 <= n; c += 2)
+            _mm_stream_pd(d + c, _mm_mul_pd(_mm_set_pd((double)s[c + 1], (double)s[c]), _mm_mul_pd(_mm_set1_pd(fr), _mm_loadu_pd(rs + c))));
+        for (; c < n; ++c) d[c] = (double)s[c] * (fr * rs[c]);
+    } else {
+        for (; c < n && ((uintptr_t)(d + c) & 15); ++c) d[c] = (double)s[c];
+        for (; c + 2 <= n; c += 2) _mm_stream_pd(d + c, _mm_set_pd((double)s[c + 1], (double)s[c]));
+        for (; c < n; ++c) d[c] = (double)s[c];
+    }
+}
+__attribute__((target("avx2"))) static inline __m256d cvt4_avx2(const uint16_t* s) {
+    return _mm256_cvtepi32_pd(_mm_cvtepu16_epi32(_mm_loadl_epi64((const __m128i*)s)));
+}
+__attribute__((target("avx2"))) static inline __m256d cvt4_avx2(const int32_t* s) {
+    return _mm256_cvtepi32_pd(_mm_loadu_si128((const __m128i*)s));
+}
+template <typename T>
+__attribute__((target("avx2"))) static void widen_row_avx2(const T* __restrict__ s, double* __restrict__ d, int n,
+                                                           const double* __restrict__ rs, double fr) {
+    int c = 0;
+    if (rs) {
+        const __m256d f = _mm256_set1_pd(fr);
+        for (; c < n && ((uintptr_t)(d + c) & 31); ++c) d[c] = (double)s[c] * (fr * rs[c]);
+        for (; c + 4 <= n; c += 4) _mm256_stream_pd(d + c, _mm256_mul_pd(cvt4_avx2(s + c), _mm256_mul_pd(f, _mm256_loadu_pd(rs + c))));
+        for (; c < n; ++c) d[c] = (double)s[c] * (fr * rs[c]);
+    } else {
+        for (; c < n && ((uintptr_t)(d + c) & 31); ++c) d[c] = (double)s[c];
+        for (; c + 4 <= n; c += 4) _mm256_stream_pd(d + c, cvt4_avx2(s + c));
+        for (; c < n; ++c) d[c] = (double)s[c];
+    }
+}
+
 // one block of the triangle: staging data `src` [256][256] -> rows [r0, r0 + nr) x columns [c0, c0 + nc) of `out` and, when
 // mirror, rows [c0, c0 + nc) x columns [r0, r0 + nr).  rs == nullptr: plain widening
 template <typename T>
 static void widen_tri_block(const T* __restrict__ src, double* __restrict__ out, i64 N, i64 r0, int nr, i64 c0, int nc, bool mirror,
-                            const double* __restrict__ rs, const double* __restrict__ diag_val) {
-    alignas(64) double line[GC_TB];
+                            const double* __restrict__ rs, const double* __restrict__ diag_val, bool avx2) {
     for (int r = 0; r < nr; ++r) {
-        const T* __restrict__ s = src + (size_t)r * GC_TB;
-        double* __restrict__ d = out + (size_t)(r0 + r) * (size_t)N + (size_t)c0;
-        if (rs) {
-            const double fr = rs[r0 + r];
-            for (int c = 0; c < nc; ++c) line[c] = (double)s[c] * (fr * rs[c0 + c]);
-            if (!mirror) line[r] = diag_val[r0 + r];              // a diagonal block: entry (r, r)
-        } else {
-            for (int c = 0; c < nc; ++c) line[c] = (double)s[c];
-        }
-        int c = 0;
-        for (; c < nc && ((uintptr_t)(d + c) & 15); ++c) d[c] = line[c];
-        for (; c + 2 <= nc; c += 2) _mm_stream_pd(d + c, _mm_loadu_pd(line + c));
-        for (; c < nc; ++c) d[c] = line[c];
+        double* d = out + (size_t)(r0 + r) * (size_t)N + (size_t)c0;
+        const double fr = rs ? rs[r0 + r] : 1.0;
+        if (avx2) widen_row_avx2<T>(src + (size_t)r * GC_TB, d, nc, rs ? rs + c0 : nullptr, fr);
+        else widen_row_sse2<T>(src + (size_t)r * GC_TB, d, nc, rs ? rs + c0 : nullptr, fr);
+        if (rs && !mirror) d[r] = diag_val[r0 + r];                 // a diagonal block: entry (r, r)
     }
     if (!mirror) return;
-    for (int c = 0; c < nc; ++c) {
-        const T* __restrict__ s = src + c;
-        double* __restrict__ d = out + (size_t)(c0 + c) * (size_t)N + (size_t)r0;
-        if (rs) {
-            const double fc = rs[c0 + c];
-            for (int r = 0; r < nr; ++r) line[r] = (double)s[(size_t)r * GC_TB] * (rs[r0 + r] * fc);
-        } else {
-            for (int r = 0; r < nr; ++r) line[r] = (double)s[(size_t)r * GC_TB];
+    alignas(64) T cb[8][GC_TB];
+    for (int cg = 0; cg < nc; cg += 8) {
+        const int w = nc - cg < 8 ? nc - cg : 8;
+        for (int r = 0; r < nr; ++r) {
+            const T* __restrict__ s = src + (size_t)r * GC_TB + cg;
+            for (int k = 0; k < 8; ++k) cb[k][r] = s[k];            // (the staging block is padded to 256 x 256: k < 8 is in range)
         }
-        int r = 0;
-        for (; r < nr && ((uintptr_t)(d + r) & 15); ++r) d[r] = line[r];
-        for (; r + 2 <= nr; r += 2) _mm_stream_pd(d + r, _mm_loadu_pd(line + r));
-        for (; r < nr; ++r) d[r] = line[r];
+        for (int k = 0; k < w; ++k) {
+            double* d = out + (size_t)(c0 + cg + k) * (size_t)N + (size_t)r0;
+            const double fc = rs ? rs[c0 + cg + k] : 1.0;
+            if (avx2) widen_row_avx2<T>(cb[k], d, nr, rs ? rs + r0 : nullptr, fc);
+            else widen_row_sse2<T>(cb[k], d, nr, rs ? rs + r0 : nullptr, fc);
+        }
     }
+    _mm_sfence();
 }
 
 template <typename T>
@@ -1761,34 +1857,35 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
     const int per_chunk = (int)(GC_CHUNK / (block_elems * sizeof(T)));            // blocks per chunk: 64 (uint16) / 32 (int32)
     const int n_chunks = (int)cdiv(n_blocks, (i64)per_chunk);
     int n_thr = ctx->opt.gram_copy_threads > 0 ? ctx->opt.gram_copy_threads : (int)std::thread::hardware_concurrency();
-    if (ctx->opt.gram_copy_threads <= 0 && n_thr > 16) n_thr = 16;
+    if (ctx->opt.gram_copy_threads <= 0 && n_thr > 32) n_thr = 32;      // measured (tools/micro/hostwrite.hip): 32-64 threads write at the memory rate
     if (n_thr < 1) n_thr = 1;
+    if ((i64)n_thr > n_blocks) n_thr = (int)n_blocks;
+    const bool avx2 = __builtin_cpu_supports("avx2") && !ctx->opt.gram_no_avx2;
     // block index -> (bi, bj): first block of every block row
     std::vector<i64> row_first((size_t)nb + 1);
     for (int bi = 0; bi <= nb; ++bi) row_first[(size_t)bi] = (i64)bi * nb - (i64)bi * (bi - 1) / 2;
     std::atomic<int> ready(0), stop(0);
-    std::vector<std::atomic<int>> done((size_t)n_chunks);
+    std::atomic<i64> next_block(0);
+    std::vector<std::atomic<int>> done((size_t)n_chunks);              // blocks of the chunk that have been widened
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     const T* stage = (const T*)ctx->stage_host;
     const double* rsp = nullptr;
     const double* dvp = nullptr;
     auto chunk_blocks = [&](int c) { return (int)std::min<i64>((i64)per_chunk, n_blocks - (i64)c * per_chunk); };
-    auto worker = [&](int w) {
-        int bi = 0;
-        for (int c = 0; c < n_chunks; ++c) {
+    auto worker = [&](int) {
+        for (;;) {
+            const i64 p = next_block.fetch_add(1, std::memory_order_relaxed);
+            if (p >= n_blocks) return;
+            const int c = (int)(p / per_chunk), k = (int)(p - (i64)c * per_chunk);
             for (unsigned spins = 0; ready.load(std::memory_order_acquire) <= c; ++spins) {
                 if (stop.load(std::memory_order_relaxed)) return;
                 if (spins < 4096) _mm_pause(); else std::this_thread::yield();
             }
-            const int nbk = chunk_blocks(c);
-            for (int k = w; k < nbk; k += n_thr) {
-                const i64 p = (i64)c * per_chunk + k;
-                while (row_first[(size_t)bi + 1] <= p) ++bi;
-                const int bj = bi + (int)(p - row_first[(size_t)bi]);
-                const i64 r0 = (i64)bi * GC_TB, c0 = (i64)bj * GC_TB;
-                widen_tri_block<T>(stage + ((size_t)(c % GC_SLOTS) * per_chunk + (size_t)k) * block_elems, out_host, N, r0,
-                                   (int)std::min<i64>(GC_TB, N - r0), c0, (int)std::min<i64>(GC_TB, N - c0), bj != bi, rsp, dvp);
-            }
+            int bi = (int)(std::upper_bound(row_first.begin(), row_first.end(), p) - row_first.begin()) - 1;
+            const int bj = bi + (int)(p - row_first[(size_t)bi]);
+            const i64 r0 = (i64)bi * GC_TB, c0 = (i64)bj * GC_TB;
+            widen_tri_block<T>(stage + ((size_t)(c % GC_SLOTS) * per_chunk + (size_t)k) * block_elems, out_host, N, r0,
+                               (int)std::min<i64>(GC_TB, N - r0), c0, (int)std::min<i64>(GC_TB, N - c0), bj != bi, rsp, dvp, avx2);
             _mm_sfence();
             done[(size_t)c].fetch_add(1, std::memory_order_release);
         }
@@ -1802,8 +1899,8 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
     };
     for (int c = 0; c < n_chunks && c < GC_SLOTS; ++c)
         if (!queue_chunk(c)) { rc = GK_ERR_HIP; break; }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)n_thr);
+    if (!ctx->host_pool) ctx->host_pool = new GkHostPool();
+    bool started = false;
     for (int c = 0; c < n_chunks && rc == GK_OK; ++c) {
         if (hipEventSynchronize(ctx->stage_ev[c % GC_SLOTS]) != hipSuccess) { rc = GK_ERR_HIP; break; }
         if (c == 0) {          // the self similarities are on the host now (same stream, queued before chunk 0)
@@ -1818,17 +1915,19 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
                 }
                 rsp = rs.data(), dvp = dv.data();
             }
-            for (int w = 0; w < n_thr; ++w) pool.emplace_back(worker, w);
+            ctx->host_pool->start(n_thr, worker);
+            started = true;
         }
         ready.store(c + 1, std::memory_order_release);
-        if (c + GC_SLOTS < n_chunks) {          // the slot is refilled once every thread is done with chunk c
-            for (unsigned spins = 0; done[(size_t)c].load(std::memory_order_acquire) < n_thr; ++spins)
+        if (c + GC_SLOTS < n_chunks) {          // the slot is refilled once every block of chunk c is done
+            const int need = chunk_blocks(c);
+            for (unsigned spins = 0; done[(size_t)c].load(std::memory_order_acquire) < need; ++spins)
                 if (spins < 4096) _mm_pause(); else std::this_thread::yield();
             if (!queue_chunk(c + GC_SLOTS)) { rc = GK_ERR_HIP; break; }
         }
     }
     if (rc != GK_OK) stop.store(1);
-    for (auto& t : pool) t.join();
+    if (started) ctx->host_pool->wait();
     if (rc != GK_OK) {
         (void)hipGetLastError();
         gk_set_error("gk_gram: the compact device-to-host copy failed");

@@ -537,31 +537,43 @@ __global__ void sp_bin_kernel(const i32* __restrict__ graph_ptr, i64 n_graphs, i
     }
 }
 
-// grid (n_graphs, max_n): block (g, src) for graphs larger than the Floyd-Warshall LDS cap
+// local source vertex of every adjacency entry (the row index of the CSR entry inside its graph): what makes the
+// relaxation below edge-parallel
+__global__ void sp_edge_src_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ node_graph,
+                                   const i32* __restrict__ row_ptr, i32* __restrict__ esrc, i64 V) {
+    const i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const i32 u = (i32)v - graph_ptr[node_graph[v]];
+    for (i32 e = row_ptr[v]; e < row_ptr[v + 1]; ++e) esrc[e] = u;
+}
+
+// Graphs larger than the Floyd-Warshall LDS cap: grid (graphs of size class 9, max_n), block (g, src) relaxes the distance
+// row of ONE source in LDS to its fixed point.  Round 5: the sweeps run over the graph's ADJACENCY ENTRIES (a thread per
+// entry) instead of over its vertices (a thread per vertex walking its neighbour list): a hub of 2 500 neighbours was one
+// thread's 2 500-trip loop in every sweep of every source -- 155 ms on the REDDIT-like set.
 __global__ __launch_bounds__(SP_THREADS) void sp_relax_kernel(
-    const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
-    const i32* __restrict__ w, const u64* __restrict__ dist_ptr, i32* __restrict__ dist,
+    const i32* __restrict__ big_list, const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
+    const i32* __restrict__ esrc, const i32* __restrict__ w, const u64* __restrict__ dist_ptr, i32* __restrict__ dist,
     u32* __restrict__ pair_count, u32* __restrict__ maxd, int cap) {
     extern __shared__ __attribute__((aligned(16))) i32 row[];
     __shared__ int changed;
-    const int g = blockIdx.x, src = blockIdx.y, tid = threadIdx.x;
+    const int g = big_list[blockIdx.x], src = blockIdx.y, tid = threadIdx.x;
     const i32 v0 = graph_ptr[g];
     const int n = graph_ptr[g + 1] - v0;
     if (n <= cap || src >= n) return;
     for (int i = tid; i < n; i += SP_THREADS) row[i] = i == src ? 0 : SP_INF;
+    const i32 e0 = row_ptr[v0];
+    const int m = row_ptr[v0 + n] - e0;
     __syncthreads();
     for (int sweep = 0; sweep < n; ++sweep) {
         if (tid == 0) changed = 0;
         __syncthreads();
-        for (int u = tid; u < n; u += SP_THREADS) {
-            const i32 du = row[u];
+        for (int e = tid; e < m; e += SP_THREADS) {
+            const i32 du = row[esrc[e0 + e]];
             if (du < SP_INF) {
-                const i32 e0 = row_ptr[v0 + u], e1 = row_ptr[v0 + u + 1];
-                for (i32 e = e0; e < e1; ++e) {
-                    int v = col_idx[e] - v0;
-                    i32 nd = du + (w ? w[e] : 1);
-                    if (nd < row[v]) { atomicMin(&row[v], nd); changed = 1; }
-                }
+                const int v = col_idx[e0 + e] - v0;
+                const i32 nd = du + (w ? w[e0 + e] : 1);
+                if (nd < row[v]) { atomicMin(&row[v], nd); changed = 1; }
             }
         }
         __syncthreads();
@@ -578,26 +590,60 @@ __global__ __launch_bounds__(SP_THREADS) void sp_relax_kernel(
     block_count_max(cnt, mx, &pair_count[g], maxd);
 }
 
+// Pair items / key marks of a graph in SLABS of SP_SLAB rows, grid (graph, slab): a 5 748-vertex graph (D&D has one) is 33 M
+// pairs -- one workgroup walking them alone took 90-120 ms per pass (round 5: 90 workgroups).  Item slots: a slab counts its
+// finite pairs, reserves its range in the graph's item range with ONE atomic on the graph's cursor, and numbers its items
+// inside (the order of the items of a graph is immaterial: they are sorted by key afterwards).
+#define SP_SLAB 64
 __global__ __launch_bounds__(SP_THREADS) void sp_emit_kernel(
     const i32* __restrict__ graph_ptr, const i32* __restrict__ node_label, const u64* __restrict__ dist_ptr,
     const i32* __restrict__ dist, const u32* __restrict__ pair_base, u64* __restrict__ keys,
-    i32* __restrict__ item_graph, u64 n_labels, u64 d1, int with_labels) {
-    __shared__ u32 cursor;
+    i32* __restrict__ item_graph, u64 n_labels, u64 d1, int with_labels, u32* __restrict__ graph_cursor) {
+    __shared__ u32 cursor, wsum[SP_THREADS / 64];
     const int g = blockIdx.x, tid = threadIdx.x;
     const i32 v0 = graph_ptr[g];
     const int n = graph_ptr[g + 1] - v0;
-    if (tid == 0) cursor = 0;
-    __syncthreads();
+    const int r0 = blockIdx.y * SP_SLAB;
+    if (r0 >= n) return;
+    const int r1 = r0 + SP_SLAB < n ? r0 + SP_SLAB : n;
     const i32* dg = dist + dist_ptr[g];
+    const i64 lo = (i64)r0 * n, hi = (i64)r1 * n;
+    u32 mine = 0;
+    for (i64 idx = lo + tid; idx < hi; idx += SP_THREADS) {
+        const int i = (int)(idx / n), j = (int)(idx - (i64)i * n);
+        if (i != j && dg[idx] < SP_INF) ++mine;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        u32 t = 0;
+        for (int k = 0; k < SP_THREADS / 64; ++k) t += wsum[k];
+        cursor = t ? atomicAdd(&graph_cursor[g], t) : 0u;
+    }
+    __syncthreads();
     const u32 base = pair_base[g];
-    for (int idx = tid; idx < n * n; idx += SP_THREADS) {
-        const int i = idx / n, j = idx - i * n;
-        const i32 x = dg[idx];
-        if (i != j && x < SP_INF) {
-            u64 key = (u64)x;
-            if (with_labels)
-                key += d1 * ((u64)(u32)node_label[v0 + i] * n_labels + (u64)(u32)node_label[v0 + j]);
-            u32 slot = base + atomicAdd(&cursor, 1u);
+    for (i64 idx0 = lo; idx0 < hi; idx0 += SP_THREADS) {
+        const i64 idx = idx0 + tid;
+        bool ok = false;
+        u64 key = 0;
+        if (idx < hi) {
+            const int i = (int)(idx / n), j = (int)(idx - (i64)i * n);
+            const i32 x = dg[idx];
+            if (i != j && x < SP_INF) {
+                ok = true;
+                key = (u64)x;
+                if (with_labels)
+                    key += d1 * ((u64)(u32)node_label[v0 + i] * n_labels + (u64)(u32)node_label[v0 + j]);
+            }
+        }
+        const u64 mask = __ballot(ok);               // one LDS atomic per wave and trip
+        u32 wbase = 0;
+        const int lane = tid & 63;
+        if (lane == 0 && mask) wbase = atomicAdd(&cursor, (u32)__popcll(mask));
+        wbase = __shfl(wbase, 0, 64);
+        if (ok) {
+            const u32 slot = base + wbase + (u32)__popcll(mask & ((1ull << lane) - 1ull));
             keys[slot] = key;
             item_graph[slot] = g;
         }
@@ -611,9 +657,12 @@ __global__ __launch_bounds__(SP_THREADS) void sp_mark_kernel(
     const int g = blockIdx.x, tid = threadIdx.x;
     const i32 v0 = graph_ptr[g];
     const int n = graph_ptr[g + 1] - v0;
+    const int r0 = blockIdx.y * SP_SLAB;
+    if (r0 >= n) return;
+    const int r1 = r0 + SP_SLAB < n ? r0 + SP_SLAB : n;
     const i32* dg = dist + dist_ptr[g];
-    for (int idx = tid; idx < n * n; idx += SP_THREADS) {
-        const int i = idx / n, j = idx - i * n;
+    for (i64 idx = (i64)r0 * n + tid; idx < (i64)r1 * n; idx += SP_THREADS) {
+        const int i = (int)(idx / n), j = (int)(idx - (i64)i * n);
         const i32 x = dg[idx];
         if (i != j && x < SP_INF) {
             u64 key = (u64)x;
@@ -640,9 +689,9 @@ static int bits_for64(u64 v) {
 
 struct SpDist {
     Tmp<u64> sq, dist_ptr, total;
-    Tmp<i32> dist, wdev;
+    Tmp<i32> dist, wdev, esrc;
     Tmp<u32> pair_count, maxd;
-    explicit SpDist(gk_ctx* c) : sq(c), dist_ptr(c), total(c), dist(c), wdev(c), pair_count(c), maxd(c) {}
+    explicit SpDist(gk_ctx* c) : sq(c), dist_ptr(c), total(c), dist(c), wdev(c), esrc(c), pair_count(c), maxd(c) {}
 };
 
 static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, SpDist& s, u64* total_sq) {
@@ -751,8 +800,11 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
         size_t lds = (size_t)nmax * 4;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_relax_kernel, (int)lds));
         GK_ARG(nmax <= 65535, "ShortestPath: grid.y overflow");
-        sp_relax_kernel<<<dim3((unsigned)N, (unsigned)nmax), SP_THREADS, lds, ctx->stream>>>(
-            b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, cap);
+        GK_TRY(s.esrc.alloc(b->n_edges > 0 ? b->n_edges : 1));
+        sp_edge_src_kernel<<<grid_for(b->n_nodes, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->node_graph, b->row_ptr, s.esrc.p, b->n_nodes);
+        sp_relax_kernel<<<dim3((unsigned)h_cls[9], (unsigned)nmax), SP_THREADS, lds, ctx->stream>>>(
+            cls_list.p + (size_t)9 * (size_t)N, b->graph_ptr, b->row_ptr, b->col_idx, s.esrc.p, w, s.dist_ptr.p, s.dist.p,
+            s.pair_count.p, s.maxd.p, cap);
     }
     (void)n_launch;
     GK_HIP_CHECK(hipGetLastError());
@@ -1073,8 +1125,8 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
             Tmp<u32> nk(ctx);
             if ((r = present.alloc((size_t)keyspace)) || (r = nk.alloc(1))) return fail(r);
             if ((r = gk_zero_async(ctx, present.p, (size_t)keyspace))) return fail(r);
-            sp_mark_kernel<<<dim3((unsigned)N), SP_THREADS, 0, ctx->stream>>>(b->graph_ptr, b->labels, s.dist_ptr.p, s.dist.p, present.p,
-                                                                            L0, d1, with_labels ? 1 : 0);
+            sp_mark_kernel<<<dim3((unsigned)N, (unsigned)cdiv(b->max_graph_nodes > 0 ? b->max_graph_nodes : 1, SP_SLAB)), SP_THREADS, 0, ctx->stream>>>(
+                b->graph_ptr, b->labels, s.dist_ptr.p, s.dist.p, present.p, L0, d1, with_labels ? 1 : 0);
             if ((r = gk_dev_alloc(ctx, &q, (size_t)keyspace * 4))) return fail(r);
             pb->sp_idtab = (u32*)q;
             SpIdScan sc{present.p, pb->sp_idtab, nk.p};
@@ -1094,6 +1146,7 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
             pb->sp_dist_ptr = s.dist_ptr.p, s.dist_ptr.p = nullptr;
             pb->sp_hist = true, pb->sp_L = (i64)L0, pb->sp_dcap = (i64)d1, pb->sp_keyspace = (i64)keyspace, pb->sp_src_nodes = V;
             pb->sp_with_labels = with_labels ? 1 : 0;
+            pb->sp_max_nodes = b->max_graph_nodes;
             pb->n_levels = 1, pb->cap_levels = 0;
             pb->label_counts.assign(1, (i64)h_nk);
             *out_pair_batch = pb;
@@ -1110,8 +1163,8 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
     pb->perm = (i32*)q;
     pb->cap_levels = n_levels;
     Tmp<u64> keys(ctx);
-    Tmp<u32> nkeys(ctx);
-    if ((r = keys.alloc(np)) || (r = nkeys.alloc((size_t)n_levels))) return fail(r);
+    Tmp<u32> nkeys(ctx), emit_cursor(ctx);
+    if ((r = keys.alloc(np)) || (r = nkeys.alloc((size_t)n_levels)) || (r = emit_cursor.alloc((size_t)N))) return fail(r);
     for (int l = 0; l < n_levels; ++l) {
         u64 L = 1;
         if (with_labels) {
@@ -1124,9 +1177,10 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
             return fail(GK_ERR_ARG);
         }
         const int key_bits = bits_for64(d1 * L * L - 1);
-        sp_emit_kernel<<<dim3((unsigned)N), SP_THREADS, 0, ctx->stream>>>(
+        if ((r = gk_zero_async(ctx, emit_cursor.p, (size_t)N * 4))) return fail(r);
+        sp_emit_kernel<<<dim3((unsigned)N, (unsigned)cdiv(b->max_graph_nodes > 0 ? b->max_graph_nodes : 1, SP_SLAB)), SP_THREADS, 0, ctx->stream>>>(
             b->graph_ptr, b->labels + (size_t)l * V, s.dist_ptr.p, s.dist.p, pair_base, keys.p, pb->node_graph,
-            L, d1, with_labels ? 1 : 0);
+            L, d1, with_labels ? 1 : 0, emit_cursor.p);
         if ((r = gk_dictionary_from_keys(ctx, keys.p, h_pairs, key_bits, pb->labels + (size_t)l * np,
                                          pb->perm + (size_t)l * np, nkeys.p + l)))
             return fail(r);
@@ -1164,9 +1218,12 @@ int gk_sp_materialise(gk_ctx* ctx, gk_batch* pb) {
     Tmp<u32> nkeys(ctx);
     GK_TRY(keys.alloc(np)); GK_TRY(nkeys.alloc(1));
     const u64 L = (u64)pb->sp_L, d1 = (u64)pb->sp_dcap;
-    sp_emit_kernel<<<dim3((unsigned)N), SP_THREADS, 0, ctx->stream>>>(
+    Tmp<u32> emit_cursor(ctx);
+    GK_TRY(emit_cursor.alloc((size_t)N));
+    GK_TRY(gk_zero_async(ctx, emit_cursor.p, (size_t)N * 4));
+    sp_emit_kernel<<<dim3((unsigned)N, (unsigned)cdiv(pb->sp_max_nodes > 0 ? pb->sp_max_nodes : 1, SP_SLAB)), SP_THREADS, 0, ctx->stream>>>(
         pb->sp_node_ptr, pb->sp_node_label, pb->sp_dist_ptr, pb->sp_dist, (const u32*)pb->graph_ptr, keys.p, pb->node_graph, L, d1,
-        pb->sp_with_labels);
+        pb->sp_with_labels, emit_cursor.p);
     GK_TRY(gk_dictionary_from_keys(ctx, keys.p, pb->n_nodes, bits_for64(d1 * L * L - 1), pb->labels, pb->perm, nkeys.p));
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;

@@ -65,6 +65,27 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
             return;
         }
     }
+    // a chunk that ALSO holds nodes of the wave / workgroup kernels (mixed degrees: the few low-degree members of an ego
+    // network) does not stream their lists through here: its small nodes gather their own neighbours, as the list kernel does
+    {
+        const int dv = v < v1 ? row_ptr[v + 1] - row_ptr[v] : 0;
+        if (__syncthreads_or(dv > WL_DEG_SMALL)) {
+            if (v < v1 && dv <= WL_DEG_SMALL) {
+                const i32 s = row_ptr[v];
+                i32* x = nbr_sorted + s;
+                u64 acc;
+                if (dv <= 16) acc = node_key_regs(col_idx, lab_prev, x, s, dv, (u32)lab_prev[v], seed);
+                else {
+                    for (int k = 0; k < dv; ++k) x[k] = lab_prev[col_idx[s + k]];
+                    insertion_sort(x, dv);
+                    acc = sig_head((u32)lab_prev[v], (u32)dv, seed);
+                    for (int k = 0; k < dv; ++k) acc += sig_elem((u32)x[k], seed);
+                }
+                hash[v] = mix64(acc) & mask;
+            }
+            return;
+        }
+    }
     // coalesced stream over the chunk's col_idx; the label gather hits L2 (4 B x V table)
     for (int i = tid; i < cnt; i += SIG_THREADS) {
         i32 l = lab_prev[col_idx[e0 + i]];
@@ -218,7 +239,9 @@ __global__ __launch_bounds__(256) void wl_signature_wave_kernel(
     else if (d <= 128) part = wave_node_signature<2>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
     else if (d <= 256) part = wave_node_signature<4>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
     else if (d <= 512) part = wave_node_signature<8>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
-    else part = wave_node_signature<16>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else part = wave_node_signature<16>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);      // (32 or 64 registers per lane:
+    // the fully unrolled network no longer compiles to registers -- 272 B of scratch per lane, tried; hubs beyond 1024
+    // neighbours keep the workgroup kernel, now 1024 threads wide)
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     if (lane == 0) hash[v] = mix64(sig_head((u32)lab_prev[v], (u32)d, seed) + part) & mask;
 }

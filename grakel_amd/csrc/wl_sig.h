@@ -6,7 +6,7 @@
 #define WL_DEG_SMALL 32       // nodes up to this degree: one thread sorts its list in LDS
 #define SIG_THREADS 256
 #define SIG_LDS_CAP 6144      // ints staged per 256-node chunk (24 KiB)
-#define BIG_THREADS 256
+#define BIG_THREADS 1024     // (round 5: 256 -> 1024: a hub's bitonic network is ~80 barrier-separated stages whatever the width)
 #define BIG_LDS_CAP 16384     // ints: one workgroup bitonic-sorts a big node's list in LDS
 
 __device__ __forceinline__ u64 mix64(u64 z) {

@@ -637,8 +637,10 @@ def test_compact_host_copy_is_the_plain_copy(gk, gkopt, n, form):
     # triangle form, normalised: the device keeps the exact integer matrix, the widening threads apply
     # rs[i] * rs[j] (rs = 1 / sqrt(K_ii)) -- exactly symmetric, diagonal exactly 1, within 2 ulp of the device's own
     gkopt("gram.no_tri", 0)
-    for threads in (0, 5):
+    for threads, no_avx2 in ((0, 0), (5, 0), (3, 1)):
         gkopt("gram.copy_threads", threads)
+        gkopt("gram.no_avx2", no_avx2)                       # the SSE2 rows of a CPU without AVX2
+        assert np.array_equal(eng.gram(feat, 0), plain)
         Kn = eng.gram(feat, 2)
         assert np.array_equal(Kn, Kn.T) and np.all(np.diagonal(Kn) == 1.0)
         assert np.abs(Kn - norm).max() <= 4 * np.finfo(np.float64).eps
