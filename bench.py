@@ -511,6 +511,8 @@ def main():
                     help="N > 1: Gram sharding plan (grakel_amd.dist.gram_plan; plain row blocks is the default)")
     ap.add_argument("--separate-calls", action="store_true",
                     help="step = gk_wl_relabel + gk_features_build + gk_gram as three library calls instead of gk_wl_fit_transform")
+    ap.add_argument("--block-rows", type=int, default=-1,
+                    help="rows per Gram sub-block (default: the workload's, and only when a rank's row block exceeds 64 GB; tests force it)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="context option (gk_set_option, include/gk_hip.h), e.g. --opt wl.debug=1; A/B runs only")
     a = ap.parse_args()
@@ -565,6 +567,8 @@ def main():
     block_rows = int(cfg.get("block_rows") or 0)
     if block_rows and N * N * 8 // world <= 64 << 30:          # the rank's row block fits comfortably: one block
         block_rows = 0
+    if a.block_rows >= 0:
+        block_rows = a.block_rows
     info = {}
     keep = {}
     block_sums = {}

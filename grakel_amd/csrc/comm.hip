@@ -154,24 +154,31 @@ extern "C" int gk_batch_allgather(gk_ctx* ctx, gk_comm* c, int64_t n_graphs, int
                                   const int32_t* node_label, int32_t n_labels0, gk_batch** out, int64_t* graph_bounds) {
     GK_ARG(ctx && c && out && graph_bounds, "gk_batch_allgather: null argument");
     GK_ARG(c->ctx == ctx, "gk_batch_allgather: communicator of another context");
-    GK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_edges >= 0 && n_labels0 >= 1, "gk_batch_allgather: negative size");
-    GK_ARG(n_graphs == 0 || (graph_ptr && row_ptr), "gk_batch_allgather: null shard arrays");
-    GK_ARG(n_nodes == 0 || node_label, "gk_batch_allgather: null labels");
-    GK_ARG(n_edges == 0 || col_idx, "gk_batch_allgather: null col_idx");
+    // The shard is validated BEFORE the first collective, but a rank whose shard is malformed must not return while the
+    // others block in ncclAllGather: the verdict travels in the size exchange (n_graphs = -1) and EVERY rank returns
+    // GK_ERR_ARG after it, together.
+    const char* bad = nullptr;
+    if (!(n_graphs >= 0 && n_nodes >= 0 && n_edges >= 0 && n_labels0 >= 1)) bad = "gk_batch_allgather: negative size";
+    else if (!(n_graphs == 0 || (graph_ptr && row_ptr))) bad = "gk_batch_allgather: null shard arrays";
+    else if (!(n_nodes == 0 || node_label)) bad = "gk_batch_allgather: null labels";
+    else if (!(n_edges == 0 || col_idx)) bad = "gk_batch_allgather: null col_idx";
     // the shard in LOCAL numbering: the same checks gk_batch_create applies happen on the gathered batch (batch_finish)
-    GK_ARG(n_graphs == 0 || (graph_ptr[0] == 0 && graph_ptr[n_graphs] == n_nodes), "gk_batch_allgather: graph_ptr must run from 0 to n_nodes");
-    GK_ARG(n_nodes == 0 || (row_ptr[0] == 0 && row_ptr[n_nodes] == n_edges), "gk_batch_allgather: row_ptr must run from 0 to n_edges");
+    else if (!(n_graphs == 0 || (graph_ptr[0] == 0 && graph_ptr[n_graphs] == n_nodes))) bad = "gk_batch_allgather: graph_ptr must run from 0 to n_nodes";
+    else if (!(n_nodes == 0 || (row_ptr[0] == 0 && row_ptr[n_nodes] == n_edges))) bad = "gk_batch_allgather: row_ptr must run from 0 to n_edges";
     GK_HIP_CHECK(hipSetDevice(ctx->device));
     const int R = c->n_ranks;
     // ---- sizes of every shard (4 int64 per rank): one small all-gather, read back
     Tmp<i64> sz_dev(ctx);
     GK_TRY(sz_dev.alloc((size_t)4 * (R + 1)));
-    const i64 mine[4] = {n_graphs, n_nodes, n_edges, (i64)n_labels0};
+    const i64 mine[4] = {bad ? -1 : n_graphs, bad ? 0 : n_nodes, bad ? 0 : n_edges, (i64)(n_labels0 >= 1 ? n_labels0 : 1)};
     GK_HIP_CHECK(hipMemcpyAsync(sz_dev.p + 4 * R, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
     GK_RCCL_CHECK(g_rccl.AllGather(sz_dev.p + 4 * R, sz_dev.p, 4, ncclInt64, c->comm, ctx->stream));
     std::vector<i64> sz((size_t)4 * R);
     GK_HIP_CHECK(hipMemcpyAsync(sz.data(), sz_dev.p, sz.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (bad) { gk_set_error(bad); return GK_ERR_ARG; }
+    for (int r = 0; r < R; ++r)
+        GK_ARG(sz[4 * r] >= 0, "gk_batch_allgather: another rank's shard failed its validation");
     i64 mg = 0, mv = 0, me = 0, labels = 1;
     std::vector<i64> shard_sizes((size_t)3 * R);
     graph_bounds[0] = 0;

@@ -1782,7 +1782,7 @@ extern "C" int gk_wl_fit_transform(gk_ctx* ctx, gk_batch* b, int n_iter, int has
         if (bits > 64) bits = 64;
     }
     gk_feat* f = nullptr;
-    bool fused = false;
+    bool fused = false, no_stream_once = false;
     if (out_rounds) *out_rounds = 0;
     if (n_levels >= 2 && n_levels <= FEAT_MAX_LEVELS) {
         GK_TRY(gk_batch_ensure_levels(b, n_levels));
@@ -1792,16 +1792,27 @@ extern "C" int gk_wl_fit_transform(gk_ctx* ctx, gk_batch* b, int n_iter, int has
             ProfScope prof(ctx, "relabel");
             r = gk_sr_enqueue(ctx, b, n_levels, bits, default_bits);
         }
+        bool redo_host_driven = false;
         if (r == GK_OK) {
             r = gk_features_build_ex(ctx, b, n_levels, b->n_graphs, kind, &f);
             if (r == GK_OK) fused = true;
-            else if (r != GK_ERR_RETRY) return r;
+            else {
+                // the queued relabel was not collected (or asked for the redo): whatever the error, the batch must not keep a
+                // stream layout whose control words nobody read -- it goes back to "not relabelled"
+                if (b->sr_pending > 0 || r == GK_ERR_RETRY) {
+                    (void)hipStreamSynchronize(ctx->stream);
+                    b->sr_pending = 0, b->stream_layout = false, b->n_levels = 0;
+                    redo_host_driven = true;
+                }
+                if (r != GK_ERR_RETRY) return r;
+            }
         } else if (r != GK_ERR_UNSUPPORTED) return r;
+        if (redo_host_driven && !fused) no_stream_once = true;
     }
     if (!fused) {
         b->sr_pending = 0;
         const int keep = ctx->opt.wl_no_stream;
-        if (n_levels >= 2 && n_levels <= FEAT_MAX_LEVELS && !b->stream_layout && b->n_levels == 0) ctx->opt.wl_no_stream = 1;    // the redo: not the stream route again
+        if (no_stream_once || (n_levels >= 2 && n_levels <= FEAT_MAX_LEVELS && !b->stream_layout && b->n_levels == 0)) ctx->opt.wl_no_stream = 1;    // the redo: not the stream route again
         int r = gk_wl_relabel(ctx, b, n_iter, hash_bits, nullptr, out_rounds);
         ctx->opt.wl_no_stream = keep;
         GK_TRY(r);

@@ -140,6 +140,10 @@ extern "C" int gk_wl_fitted_create(gk_ctx* ctx, gk_batch* fit, int n_iter, gk_wl
     const i64 V = fit->n_nodes, N = fit->n_graphs;
     const int L = n_iter + 1;
     if (V <= 0) return GK_ERR_UNSUPPORTED;
+    // tt_accumulate_kernel adds count_target * count_fitted per level in 32-bit LDS words: K[t, f] <= levels * 1024 (the
+    // largest target graph of the look-up route) * the largest fitted graph must stay below 2^32, else the joint route
+    // (whose Gram picks its accumulator from the job's bound) takes the job
+    if ((double)L * (double)GM_MAX_NODES * (double)fit->max_graph_nodes >= 4294967296.0) return GK_ERR_UNSUPPORTED;
     gk_wl_fitted* w = new gk_wl_fitted();
     w->ctx = ctx, w->fit = fit, w->fit_gen = fit->relabel_gen, w->n_levels = L, w->N = N, w->V = V, w->L0 = fit->n_labels0;
     w->table.assign(L, nullptr), w->tval.assign(L, nullptr), w->mask.assign(L, 0), w->rep.assign(L, nullptr);

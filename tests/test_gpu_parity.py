@@ -2005,3 +2005,74 @@ def test_dense_graphs_and_hubs_through_the_wave_signature_kernels(gk, gkopt, no_
     est = gk.WeisfeilerLehman(n_iter=3)
     assert np.array_equal(est.fit_transform(X), K)
     assert np.array_equal(est.transform(X[3:9]), K[3:9])
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_config6_subsampled_against_the_oracle(gk, gpus):
+    """bench.py --workload config6 (200 000 graphs: a 320 GB matrix that no single GPU holds) multiplies every rank's rows
+    in sub-blocks that reuse one device buffer.  Here the same code path on a 2 400-graph prefix of the same generator with
+    forced 500-row sub-blocks, on one rank and -- `bench.py --gpus 2` launching ITSELF under torch.distributed.run, both
+    ranks on cuda:0 over gloo (test hook) -- on two: the sum over all sub-blocks of all ranks must be the oracle's sum of K
+    (K[i, j] only depends on graphs i and j, so the prefix's matrix is the corner of the full set's)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GK_BENCH_BACKEND="gloo", GK_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--workload", "config6", "--graphs", "2400",
+                          "--block-rows", "500", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-3000:]
+    d = json.loads(lines[0])
+    K = O.WLOracle(n_iter=5).fit_transform(er_dataset(2400, 30, 0.1, 5, 0))
+    assert d["n_gpus"] == gpus and d["checks"]["K_sum_over_sub_blocks"] == float(K.sum())
+    assert d["checks"]["sub_blocks_this_rank"] == (5 if gpus == 1 else 3) and d["checks"]["two_passes_agree"]
+    if gpus == 2:
+        assert d["rccl"]["ranks"] == 2 and len(d["per_rank"]) == 2 and all(r["gram_rows_ms"] > 0 for r in d["per_rank"])
+
+
+def test_integration_md_section_c_runs_with_one_process_per_gpu(gk, tmp_path):
+    """INTEGRATION.md section C as a RUNNING C program (tests/c_abi/multi_gpu_run.c + the section's own code,
+    tests/c_abi/multi_gpu_stub.c): one process per visible GPU, every process with its own shard file, the communicator id
+    handed over through a file, gk_comm_init / gk_batch_allgather / gk_gram_sharded over RCCL.  On a one-GPU box this is a
+    communicator of one rank; on an 8-GPU node it is the first run of the C path with real ranks.  The rows the processes
+    write must be the oracle's matrix."""
+    import subprocess
+    from grakel_amd import GraphBatch, _lib
+    from grakel_amd.dist import shard_bounds
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "multi_gpu_run")
+    libdir = os.path.join(root, "grakel_amd")
+    cc = subprocess.run(["gcc", "-O1", "-DGK_STUB_ID_IS_DISTRIBUTED", "-I", os.path.join(root, "include"),
+                         os.path.join(root, "tests", "c_abi", "multi_gpu_run.c"), os.path.join(root, "tests", "c_abi", "multi_gpu_stub.c"),
+                         "-o", exe, "-L", libdir, "-l:libgk_hip.so", "-Wl,-rpath," + libdir,
+                         "-Wl,--unresolved-symbols=ignore-in-shared-libs"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    n_ranks = max(1, min(_lib.device_count(), 8))
+    N, n_iter = 96, 3
+    X = er_dataset(N, 24, 0.15, 4, 21)
+    full = GraphBatch(*er_dataset_csr(N, 24, 0.15, 4, 21), 4)
+    b = shard_bounds(N, n_ranks)
+    procs = []
+    for r in range(n_ranks):
+        sh = full.slice_graphs(b[r], b[r + 1])
+        path = str(tmp_path / ("shard%d.bin" % r))
+        with open(path, "wb") as f:
+            np.array([sh.n_graphs, sh.n_nodes, sh.n_edges, sh.n_labels], np.int64).tofile(f)
+            for arr in (sh.graph_ptr, sh.row_ptr, sh.col_idx, sh.node_label):
+                np.ascontiguousarray(arr, np.int32).tofile(f)
+        np.array([N], np.int64).tofile(path + ".total")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([exe, str(r), str(n_ranks), str(r), str(tmp_path / "comm.id"), path,
+                                       str(tmp_path / ("rows%d.bin" % r)), str(n_iter)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    K = O.WLOracle(n_iter=n_iter).fit_transform(X)
+    for r in range(n_ranks):
+        raw = np.fromfile(str(tmp_path / ("rows%d.bin" % r)), np.uint8)
+        lo, hi, total = raw[:24].view(np.int64).tolist()
+        assert (lo, hi, total) == (b[r], b[r + 1], N)
+        assert np.array_equal(raw[24:].view(np.float64).reshape(hi - lo, N), K[lo:hi])

@@ -49,3 +49,22 @@ gk = med(lambda: eng.gram(feat, 0, to_host=False))
 print("gram alone (device): %.3f ms" % gk)
 full = med(lambda: (lambda d: (eng.wl_fit_transform(d, h, to_host=True)[0].close(), d.close()))(eng.upload(wl.batch)))
 print("host to host, one call sequence: %.3f ms" % full)
+
+# ---- what the bus does alone: 105 MB (the triangle's uint16 blocks) device -> pinned host, in one piece and in pieces
+import torch  # noqa: E402
+src = torch.empty(105 << 20, dtype=torch.uint8, device="cuda")
+dst = torch.empty(105 << 20, dtype=torch.uint8).pin_memory()
+for piece_mb in (105, 32, 16, 8, 4):
+    piece = piece_mb << 20
+    def run():
+        for o in range(0, 105 << 20, piece):
+            dst[o:o + piece].copy_(src[o:o + piece], non_blocking=True)
+        torch.cuda.synchronize()
+    run()
+    t = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        t.append((time.perf_counter() - t0) * 1e3)
+    print("D2H of 105 MB into pinned memory in %3d MB pieces: %.3f ms (%.1f GB/s)" % (piece_mb, min(t), 105 * 1.048576 / min(t)))
