@@ -200,6 +200,62 @@ def test_threaded_ingestion_equals_the_one_thread_walk_and_the_python_path():
         B.INGEST_THREADS = saved
 
 
+def test_pair_and_matrix_ingestion_in_c_equals_the_python_path():
+    """Round 5, csrc/ingest.c: the forms real data arrives as -- a set / list of `(u, v)` tuples or a dict keyed by them with
+    labels keyed by arbitrary (global) vertex ids, which is what `fetch_dataset` / `read_data` produce
+    (datasets/base.py:273-279), and numpy adjacency matrices -- take the threaded C walk; everything unusual (an unlabelled
+    neighbour = the reference's KeyError, weighted 3-tuples, string ids, a matrix that is not square or not C-contiguous,
+    labels that are not keyed 0 .. n-1) still gets the Python path's batch or exception."""
+    from grakel_amd import batch as B
+    base = er_dataset(330, 14, 0.3, 4, 6)
+    off, sets, lists, dicts, mats = 1, [], [], [], []
+    for ed, lab in base:
+        n = len(lab)
+        es = {(u + off, v + off) for u, l in ed.items() for v in l}
+        L = {u + off: lab[u] for u in sorted(lab, key=lambda u: (u * 7) % n)}          # label order != id order
+        sets.append([es, L, {e: 0 for e in es}])
+        lists.append([sorted(es) + sorted(es)[:2], L])                                 # duplicates collapse
+        dicts.append([{e: 2.0 for e in es}, L])
+        A = np.zeros((n, n), int)
+        for u, l in ed.items():
+            A[u, l] = 1
+        mats.append([A, lab])
+        off += n
+    cases = {"sets_global_ids": sets, "frozensets": [[frozenset(g), L] for g, L, _ in sets], "lists": lists,
+             "tuples_of_tuples": [(tuple(g), L) for g, L in lists], "dict_of_pairs": dicts, "few_elements": sets[:5],
+             "unlabelled_neighbour": sets[:100] + [[{(1, 2), (2, 1), (2, 3)}, {1: 0, 2: 1}]] + sets[100:],
+             "unlabelled_source_is_ignored": sets[:3] + [[{(1, 2), (2, 1), (3, 1)}, {1: 0, 2: 1}]],
+             "weighted_triples_in_the_middle": lists[:40] + [[[(1, 2, 0.5), (2, 1, 0.5)], {1: 0, 2: 1}]] + lists[40:],
+             "string_vertices": sets[:20] + [[{("a", "b"), ("b", "a")}, {"a": 1, "b": 2}]],
+             "string_labels": [[g, {k: "L%d" % v for k, v in L.items()}] for g, L, _ in sets[:30]],
+             "big_ids": [[{(10 ** 12, 5), (5, 10 ** 12)}, {10 ** 12: 1, 5: 2}]] + sets[:10],
+             "empty_edge_set": sets[:4] + [[set(), {1: 0}]],
+             "matrices_int64": mats, "matrices_bool": [[a.astype(bool), l] for a, l in mats],
+             "matrices_float32_weights_and_negatives": [[(a * 2.5 - (1 - a)).astype(np.float32), l] for a, l in mats],
+             "matrices_uint8": [[a.astype(np.uint8), l] for a, l in mats],
+             "matrix_fortran_order": mats[:10] + [[np.asfortranarray(mats[10][0]), mats[10][1]]],
+             "matrix_not_square": mats[:5] + [[np.ones((3, 4), int), {0: 1, 1: 1, 2: 1}]],
+             "matrix_labels_not_identity": mats[:5] + [[mats[5][0], dict(reversed(list(mats[5][1].items())))]],
+             "matrix_fewer_labels": mats[:5] + [[np.ones((3, 3), int), {0: 1, 1: 1}]]}
+    saved = B.INGEST_THREADS
+    try:
+        for threads in (0, 1, 3):
+            B.INGEST_THREADS = threads
+            for name, X in cases.items():
+                fast, slow = _both_paths(X)
+                assert fast == slow, (name, threads)
+        B.INGEST_THREADS = 0
+        # ... and they are the graphs of the dict-of-lists form
+        ref = _both_paths(base)[0]
+        plain_sets = [[{(u + 5, v + 5) for u, l in ed.items() for v in l}, {u + 5: x for u, x in lab.items()}] for ed, lab in base]
+        assert _both_paths(plain_sets)[0][1:5] == ref[1:5] and _both_paths(mats)[0][1:5] == ref[1:5]
+        # the C module really took them (None = declined)
+        assert B._gk_ingest.wl_ingest(sets, 2, False, 0, 0) is not None and B._gk_ingest.wl_ingest(mats, 2, False, 0, 0) is not None
+        assert B._gk_ingest.wl_ingest(cases["string_vertices"], 2, False, 0, 0) is None
+    finally:
+        B.INGEST_THREADS = saved
+
+
 def test_c_sp_ingestion_fast_path_equals_the_python_path():
     from grakel_amd import batch as B
     from grakel_amd.synthetic import nci1_like
