@@ -7,6 +7,8 @@
 
 static thread_local char g_err[1024] = "";
 static void cache_release_all(gk_ctx* ctx);
+static void* block_base(gk_ctx* ctx, void* user);
+static int guard_verdict(gk_ctx* ctx);
 
 void gk_set_error(const char* fmt, ...) {
     va_list ap;
@@ -82,7 +84,8 @@ extern "C" int gk_destroy(gk_ctx* ctx) {
     for (int i = 0; i < 4; ++i)
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     cache_release_all(ctx);
-    for (auto& kv : ctx->cache.live) (void)hipFree(kv.first);   // leaked by the caller: reclaim
+    for (auto& kv : ctx->cache.live) (void)hipFree(block_base(ctx, kv.first));   // leaked by the caller: reclaim
+    if (ctx->cache.guard_faults) (void)hipFree(ctx->cache.guard_faults);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
@@ -221,7 +224,7 @@ static const OptName g_opt_names[] = {
     {"feat.low_df", &gk_opts::low_df}, {"feat.gm_row_lds_max", &gk_opts::gm_row_lds_max},
     {"gram.dd", &gk_opts::gram_dd}, {"gram.no_fp4", &gk_opts::gram_no_fp4}, {"gram.no_ws", &gk_opts::gram_no_ws}, {"gram.no_sym", &gk_opts::gram_no_sym},
     {"gram.no_patch", &gk_opts::gram_no_patch}, {"gram.xcc", &gk_opts::gram_xcc}, {"gram.no_compact", &gk_opts::gram_no_compact}, {"gram.no_split8", &gk_opts::gram_no_split8}, {"gram.fold", &gk_opts::gram_fold}, {"gram.pair_cap", &gk_opts::gram_pair_cap}, {"gram.copy_threads", &gk_opts::gram_copy_threads}, {"gram.no_tri", &gk_opts::gram_no_tri}, {"gram.no_avx2", &gk_opts::gram_no_avx2}, {"wl.no_wave_sig", &gk_opts::wl_no_wave_sig}, {"sp.no_reg", &gk_opts::sp_no_reg}, {"sp.no_pk", &gk_opts::sp_no_pk}, {"sp.no_hist", &gk_opts::sp_no_hist}, {"no_mailbox", &gk_opts::no_mailbox},
-    {"debug.poison", &gk_opts::poison},
+    {"debug.poison", &gk_opts::poison}, {"debug.guard", &gk_opts::guard},
 };
 
 extern "C" int gk_set_option(gk_ctx* ctx, const char* name, int64_t value) {
@@ -256,6 +259,7 @@ extern "C" int gk_set_stream(gk_ctx* ctx, void* hip_stream) {
 
 extern "C" int gk_synchronize(gk_ctx* ctx) {
     GK_ARG(ctx, "gk_synchronize: null ctx");
+    if (ctx->cache.guard_faults) return guard_verdict(ctx);
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return GK_OK;
 }
@@ -317,9 +321,75 @@ static size_t bucket_size(size_t bytes) {
     return (bytes + g - 1) / g * g;
 }
 
+static void* block_base(gk_ctx* ctx, void* user) {
+    return ctx->cache.guarded.count(user) ? (void*)((char*)user - GK_GUARD_BYTES) : user;
+}
 static void cache_release_all(gk_ctx* ctx) {
-    for (auto& kv : ctx->cache.free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : ctx->cache.free_blocks) {
+        (void)hipFree(block_base(ctx, kv.second));
+        ctx->cache.guarded.erase(kv.second);
+    }
     ctx->cache.free_blocks.clear();
+}
+
+// ---- debug.guard: red zones (the round-2 device fault was never reproduced; a write outside a block would be one way to
+// produce it, and this makes such a write an ERROR at the next gk_synchronize instead of a corruption somewhere else)
+#define GK_GUARD_WORD 0xA5C3F00Du
+__global__ void guard_fill_kernel(u32* __restrict__ a, size_t na, u32* __restrict__ b, size_t nb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] = GK_GUARD_WORD;
+    if (i < nb) b[i] = GK_GUARD_WORD;
+}
+__global__ void guard_check_kernel(const u32* __restrict__ a, size_t na, const u32* __restrict__ b, size_t nb, u32 req_kib,
+                                   u32* __restrict__ faults) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 bad = 0;
+    if (i < na && a[i] != GK_GUARD_WORD) ++bad;
+    if (i < nb && b[i] != GK_GUARD_WORD) ++bad;
+    if (bad) {
+        if (atomicAdd(&faults[0], bad) == 0) faults[1] = req_kib;
+    }
+}
+// the zones of a guarded block: [user - GUARD, user) and [user + round16(requested), + min(slack + GUARD, TAIL_MAX))
+static void guard_zones(void* user, size_t cap, size_t bytes, u32** a, size_t* na, u32** b, size_t* nb) {
+    const size_t r = (bytes + 15) & ~(size_t)15;
+    size_t tail = cap - r + GK_GUARD_BYTES;
+    if (tail > GK_GUARD_TAIL_MAX) tail = GK_GUARD_TAIL_MAX;
+    *a = (u32*)((char*)user - GK_GUARD_BYTES), *na = GK_GUARD_BYTES / 4;
+    *b = (u32*)((char*)user + r), *nb = tail / 4;
+}
+static void guard_fill(gk_ctx* ctx, void* user, size_t cap, size_t bytes) {
+    u32 *a, *b;
+    size_t na, nb;
+    guard_zones(user, cap, bytes, &a, &na, &b, &nb);
+    const size_t n = na > nb ? na : nb;
+    guard_fill_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(a, na, b, nb);
+}
+static void guard_check(gk_ctx* ctx, void* user, size_t cap, size_t bytes) {
+    if (!ctx->cache.guard_faults) return;
+    u32 *a, *b;
+    size_t na, nb;
+    guard_zones(user, cap, bytes, &a, &na, &b, &nb);
+    const size_t n = na > nb ? na : nb;
+    guard_check_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(a, na, b, nb, (u32)(bytes >> 10), ctx->cache.guard_faults);
+}
+// every live guarded block is checked, then the fault words are read: GK_ERR_STATE when a red zone was written
+static int guard_verdict(gk_ctx* ctx) {
+    BlockCache& c = ctx->cache;
+    if (!c.guard_faults) return GK_OK;
+    for (auto& kv : c.guarded) {
+        auto it = c.live.find(kv.first);
+        if (it != c.live.end()) guard_check(ctx, kv.first, it->second, kv.second);
+    }
+    u32 h[2] = {0, 0};
+    GK_HIP_CHECK(hipMemcpyAsync(h, c.guard_faults, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (h[0]) {
+        gk_set_error("debug.guard: %u words of a red zone were overwritten (first hit: a block requested with ~%u KiB)", h[0], h[1]);
+        (void)hipMemsetAsync(c.guard_faults, 0, 8, ctx->stream);
+        return GK_ERR_STATE;
+    }
+    return GK_OK;
 }
 
 // debug.poison: every block the allocator hands out is filled with a byte pattern first, so that a kernel
@@ -341,20 +411,27 @@ static void poison_block(gk_ctx* ctx, void* p, size_t cap) {
 int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes) {
     const size_t cap = bucket_size(bytes);
     BlockCache& c = ctx->cache;
-    auto it = c.free_blocks.lower_bound(cap);
-    if (it != c.free_blocks.end() && it->first <= cap + cap / 2) {   // bounded internal waste
+    const bool guard = ctx->opt.guard != 0;
+    if (guard && !c.guard_faults) {
+        if (hipMalloc((void**)&c.guard_faults, 8) != hipSuccess) { (void)hipGetLastError(); c.guard_faults = nullptr; }
+        else (void)hipMemsetAsync(c.guard_faults, 0, 8, ctx->stream);
+    }
+    for (auto it = c.free_blocks.lower_bound(cap); it != c.free_blocks.end() && it->first <= cap + cap / 2; ++it) {   // bounded internal waste
+        if ((c.guarded.count(it->second) != 0) != guard) continue;       // blocks with and without red zones do not mix
         *p = it->second;
         c.live[*p] = it->first;
         poison_block(ctx, *p, it->first);
+        if (guard) { c.guarded[*p] = bytes; guard_fill(ctx, *p, it->first, bytes); }
         c.free_blocks.erase(it);
         return GK_OK;
     }
-    hipError_t e = hipMalloc(p, cap);
+    const size_t extra = guard ? 2 * (size_t)GK_GUARD_BYTES : 0;
+    hipError_t e = hipMalloc(p, cap + extra);
     if (e != hipSuccess) {       // give cached blocks back to the driver and retry once
         (void)hipGetLastError();
         (void)hipStreamSynchronize(ctx->stream);
         cache_release_all(ctx);
-        e = hipMalloc(p, cap);
+        e = hipMalloc(p, cap + extra);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -362,9 +439,11 @@ int gk_dev_alloc(gk_ctx* ctx, void** p, size_t bytes) {
         *p = nullptr;
         return GK_ERR_HIP;
     }
+    if (guard) *p = (char*)*p + GK_GUARD_BYTES;
     c.live[*p] = cap;
     c.bytes_total += cap;
     poison_block(ctx, *p, cap);
+    if (guard) { c.guarded[*p] = bytes; guard_fill(ctx, *p, cap, bytes); }
     return GK_OK;
 }
 
@@ -373,6 +452,8 @@ void gk_dev_free(gk_ctx* ctx, void* p) {
     BlockCache& c = ctx->cache;
     auto it = c.live.find(p);
     if (it == c.live.end()) return;   // not ours / double free: ignore rather than corrupt
+    auto g = c.guarded.find(p);
+    if (g != c.guarded.end()) guard_check(ctx, p, it->second, g->second);      // queued behind the block's last user (stream order)
     c.free_blocks.insert({it->second, p});
     c.live.erase(it);
 }

@@ -56,7 +56,14 @@ struct BlockCache {
     std::multimap<size_t, void*> free_blocks;   // capacity -> block
     std::map<void*, size_t> live;               // block -> capacity
     size_t bytes_total = 0;
+    // option debug.guard: blocks with a red zone on either side (GK_GUARD_BYTES before the block, and from the end of the
+    // REQUESTED size to GK_GUARD_BYTES behind the capacity), filled with a pattern when the block is handed out and checked
+    // when it comes back and at gk_synchronize
+    std::map<void*, size_t> guarded;            // block (user pointer) -> requested bytes; in `live` or `free_blocks` as well
+    u32* guard_faults = nullptr;                // device: [0] overwritten words, [1] requested size (KiB) of the first block hit
 };
+#define GK_GUARD_BYTES 4096
+#define GK_GUARD_TAIL_MAX (64u << 10)           // bytes of the slack behind the requested size that are checked
 
 // Route / tuning options of a context (gk_set_option, include/gk_hip.h).  Every option leaves the results
 // unchanged: each one removes or forces one of several equivalent routes (the parity tests run the job through
@@ -91,6 +98,7 @@ struct gk_opts {
     // plumbing
     int wl_no_stream = 0;        // never the relabel route without host round trips (wl_stream.hip)
     int no_mailbox = 0;
+    int guard = 0;               // debug: red zones around every block of the allocator, checked at release and at gk_synchronize (GK_ERR_STATE)
     int poison = 0;              // debug: fill every block handed out by the allocator with this byte pattern (| 0x100)
 };
 

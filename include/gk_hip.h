@@ -72,6 +72,8 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "wl.no_bucket_dict" "wl.no_hist0" "wl.frozen_words" "wl.flag_bytes" "wl.sig_no_regs" "wl.debug"
  *             "wl.no_stream" (never the relabel route without host round trips, wl_stream.hip: the host-driven
  *             route of wl.hip, which all the other "wl.*" switches select within)
+ *             "wl.no_wave_sig" (vertices of degree 33..1024 by the workgroup-per-vertex signature kernel and the
+ *             thread-per-vertex verifier of rounds 1-4 instead of the wave-per-vertex kernels)
  *             "sort.buckets" (1 never / 2 always the per-bucket finish of the sort)
  *             "wl.bd_slots" (distinct keys a bucket of the sort-free dictionary accepts: small values force its
  *             overflow and with it the second, sorting attempt)
@@ -84,14 +86,21 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "gram.pair_cap" (test hook: capacity of the per-tile pair buckets of that fold-in)
  *             "gram.no_split8" (labels with counts above 127 in a float64 side operand instead of split int8 columns)
  *             "gram.no_compact" (host copies of integer-valued matrices as plain float64 instead of uint16 / int32 + widening)
- *             "gram.copy_threads" (host threads of that widening; 0: min(hardware threads, 16))
+ *             "gram.copy_threads" (host threads of that widening; 0: min(hardware threads, 32))
+ *             "gram.no_tri" (a WHOLE symmetric matrix bound for the host normally crosses PCIe as the 256 x 256 blocks on and
+ *             above its diagonal only, the host threads widen AND mirror them and -- for a normalised job -- apply the
+ *             1 / sqrt(K_ii K_jj) factors; 1 = the rectangular narrow copy, normalised matrices as plain float64)
+ *             "gram.no_avx2" (those host threads keep to SSE2, what a CPU without AVX2 runs)
  *   paths:    "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
  *             histograms of the distance matrices),
  *             "sp.no_pk" (all-pairs distances never in the 16-bit packed register kernel: 32-bit registers up to 64
  *             vertices, the LDS workgroup kernel beyond), "sp.no_reg" (the LDS workgroup kernel for every graph)
  *   plumbing: "no_mailbox" (small read-backs by hipMemcpy instead of the mapped mailbox),
  *             "debug.poison" (the allocator fills every block it hands out with this byte: uninitialised reads
- *             then see the same garbage in every run)
+ *             then see the same garbage in every run),
+ *             "debug.guard" (red zones before every block of the allocator and behind its requested size, checked when the
+ *             block is released and at gk_synchronize, which then returns GK_ERR_STATE: a kernel writing outside its block
+ *             becomes an error instead of a corruption somewhere else; set it before the first allocation of a job)
  * Unknown names return GK_ERR_ARG.  The reference has no counterpart (its route is fixed). */
 int gk_set_option(gk_ctx* ctx, const char* name, int64_t value);
 int gk_get_option(gk_ctx* ctx, const char* name, int64_t* out_value);
@@ -249,7 +258,10 @@ int gk_features_debug_phi_right(gk_ctx* ctx, gk_feat* f, double* out_phi, int* s
  * normalize: 0 none; 1 divide by sqrt(selfk_row*selfk_col) leaving 0/0 = NaN (Kernel);
  *            2 same with nan_to_num -> 0 (WeisfeilerLehman).
  * out_host may be NULL: the matrix then stays on the device (gk_gram_dev_ptr), which is what
- * bench.py times. */
+ * bench.py times.  With out_host set, a WHOLE symmetric integer-valued matrix crosses PCIe as its upper
+ * triangle in uint16 / int32 blocks and the normalisation factors are applied by the host threads that widen
+ * it (option "gram.no_tri"): after such a call the DEVICE copy (gk_gram_dev_ptr, gk_gram_checksum) is the exact
+ * unnormalised matrix, whatever `normalize` was. */
 int gk_gram(gk_ctx* ctx, gk_feat* f, int normalize, double* out_host);
 int gk_gram_dev_ptr(gk_feat* f, void** out_dev_ptr, int64_t* n_rows, int64_t* n_cols);
 /* Row-sharded Gram (multi-GPU): only rows [row_lo,row_hi) of the job's matrix are computed;

@@ -48,6 +48,15 @@ def reference_available():
 def _poisoned_allocator():
     """GK_TEST_POISON=<byte> (tests/tools/poison_suite.sh): every device block the library hands out is filled with
     that byte first, in every engine of this process -- uninitialised reads become deterministic."""
+    if os.environ.get("GK_TEST_GUARD"):              # tests/tools/guard_suite.sh: red zones around every device block,
+        from grakel_amd import engine as E            # checked when a block is released and at every gk_synchronize
+        orig_g = E.Engine.__init__
+
+        def init_g(self, device=0):
+            orig_g(self, device)
+            self.set_option("debug.guard", 1)
+
+        E.Engine.__init__ = init_g
     pat = os.environ.get("GK_TEST_POISON")
     if pat:
         from grakel_amd import engine as E
@@ -59,3 +68,14 @@ def _poisoned_allocator():
 
         E.Engine.__init__ = init
     yield
+
+
+@pytest.fixture(autouse=True)
+def _guard_verdict_after_every_test():
+    """GK_TEST_GUARD=1: a write into a red zone during the test fails THAT test (gk_synchronize -> GK_ERR_STATE)."""
+    yield
+    if os.environ.get("GK_TEST_GUARD"):
+        from grakel_amd import engine as E
+        for eng in list(E._engines.values()):
+            if eng.handle is not None:
+                eng.synchronize()

@@ -2076,3 +2076,30 @@ def test_integration_md_section_c_runs_with_one_process_per_gpu(gk, tmp_path):
         lo, hi, total = raw[:24].view(np.int64).tolist()
         assert (lo, hi, total) == (b[r], b[r + 1], N)
         assert np.array_equal(raw[24:].view(np.float64).reshape(hi - lo, N), K[lo:hi])
+
+
+def test_debug_guard_catches_a_write_behind_a_block(gk, gkopt):
+    """Option debug.guard (round 5): every block of the context's allocator gets a red zone on
+    either side; a kernel that writes outside its block -- provoked here with gk_block_copy aimed 32 bytes behind the end of
+    a Gram matrix -- turns the next gk_synchronize into GK_ERR_STATE instead of a silent corruption.  The whole GPU suite
+    runs under it in tests/tools/guard_suite.sh (profiles/r05_guard_suite.txt)."""
+    import ctypes
+    from grakel_amd import GraphBatch, _lib
+    from grakel_amd.engine import get_engine
+    eng = get_engine()
+    gkopt("debug.guard", 1)
+    N = 37
+    db = eng.upload(GraphBatch(*er_dataset_csr(N, 12, 0.3, 3, 4), 3))
+    eng.wl_relabel(db, 2)
+    feat = eng.features(db, 3)
+    eng.gram(feat, 0, to_host=False)
+    eng.synchronize()                                            # nothing wrong so far
+    p, r, c = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(eng.lib.gk_gram_dev_ptr(feat.handle, ctypes.byref(p), ctypes.byref(r), ctypes.byref(c)))
+    assert (r.value, c.value) == (N, N)
+    eng.block_copy(p.value, 1, 4, N, p.value + N * N * 8, 4)     # four float64 just behind the matrix
+    with pytest.raises(_lib.GkError, match="red zone"):
+        eng.synchronize()
+    eng.synchronize()                                            # reported once; the context stays usable
+    assert np.array_equal(eng.gram(feat, 0), O.WLOracle(n_iter=2).fit_transform(er_dataset(N, 12, 0.3, 3, 4)))
+    feat.close(), db.close()
