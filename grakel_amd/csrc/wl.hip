@@ -43,6 +43,37 @@
 
 #include "wl_sig.h"
 
+// ---------------------------------------------------------------------------------------
+// Nodes of degree WL_DEG_SMALL + 1 .. WAVE_DEG_MAX (round 5): ONE WAVE per node, the neighbour labels in registers
+// (striped: element i = 64 r + lane, R = 1, 2, 4, 8 or 16 registers per lane), a bitonic network over the wave -- partners
+// less than 64 apart by a lane shuffle, farther apart in the lane's own registers (static indices) -- coalesced gather and
+// coalesced write of the sorted list, wave reduction of the multiset hash.  No LDS, no workgroup barrier: the workgroup
+// form below (64 KiB of LDS and ~log^2 barriers per NODE) took 3.5 ms per level on a COLLAB-like batch (360 k nodes of
+// degree ~ 60), this one is bound by the gather.
+// ---------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ u64 wave_node_signature(const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
+                                                   i32* __restrict__ nbr_sorted, i32 e0, int d, int lane, u64 seed) {
+    i32 x[R];
+    u64 part = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = r * 64 + lane;
+        x[r] = 0x7fffffff;
+        if (i < d) {
+            x[r] = lab_prev[col_idx[e0 + i]];
+            part += sig_elem((u32)x[r], seed);
+        }
+    }
+    wave_bitonic_sort<R>(x, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = r * 64 + lane;
+        if (i < d) nbr_sorted[e0 + i] = x[r];
+    }
+    return part;
+}
+
 __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
     const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted, u64* __restrict__ hash,
@@ -70,18 +101,21 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     {
         const int dv = v < v1 ? row_ptr[v + 1] - row_ptr[v] : 0;
         if (__syncthreads_or(dv > WL_DEG_SMALL)) {
-            if (v < v1 && dv <= WL_DEG_SMALL) {
-                const i32 s = row_ptr[v];
-                i32* x = nbr_sorted + s;
-                u64 acc;
-                if (dv <= 16) acc = node_key_regs(col_idx, lab_prev, x, s, dv, (u32)lab_prev[v], seed);
-                else {
-                    for (int k = 0; k < dv; ++k) x[k] = lab_prev[col_idx[s + k]];
-                    insertion_sort(x, dv);
-                    acc = sig_head((u32)lab_prev[v], (u32)dv, seed);
-                    for (int k = 0; k < dv; ++k) acc += sig_elem((u32)x[k], seed);
-                }
-                hash[v] = mix64(acc) & mask;
+            const i32 s = v < v1 ? row_ptr[v] : 0;
+            if (v < v1 && dv <= 16) hash[v] = mix64(node_key_regs(col_idx, lab_prev, nbr_sorted + s, s, dv, (u32)lab_prev[v], seed)) & mask;
+            // 17 .. WL_DEG_SMALL neighbours: the wave sorts such a list together, one node after the other (an insertion
+            // sort by the node's own thread is ~d^2 / 4 dependent steps in global memory: 107 us per level on the COLLAB-like set)
+            const int lane = tid & 63;
+            u64 todo = __ballot(v < v1 && dv > 16 && dv <= WL_DEG_SMALL);
+            while (todo) {
+                const int src = (int)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const i32 ns = __shfl(s, src, 64);
+                const int nd = __shfl(dv, src, 64);
+                u64 part = wave_node_signature<1>(col_idx, lab_prev, nbr_sorted, ns, nd, lane, seed);
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+                const i64 node = v0 + (tid & ~63) + src;
+                if (lane == 0) hash[node] = mix64(sig_head((u32)lab_prev[node], (u32)nd, seed) + part) & mask;
             }
             return;
         }
@@ -158,69 +192,6 @@ __device__ __forceinline__ void block_bitonic_sort(P x, int n) {
             __syncthreads();
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// Nodes of degree WL_DEG_SMALL + 1 .. WAVE_DEG_MAX (round 5): ONE WAVE per node, the neighbour labels in registers
-// (striped: element i = 64 r + lane, R = 1, 2, 4, 8 or 16 registers per lane), a bitonic network over the wave -- partners
-// less than 64 apart by a lane shuffle, farther apart in the lane's own registers (static indices) -- coalesced gather and
-// coalesced write of the sorted list, wave reduction of the multiset hash.  No LDS, no workgroup barrier: the workgroup
-// form below (64 KiB of LDS and ~log^2 barriers per NODE) took 3.5 ms per level on a COLLAB-like batch (360 k nodes of
-// degree ~ 60), this one is bound by the gather.
-// ---------------------------------------------------------------------------------------
-#define WAVE_DEG_MAX 1024
-template <int R>
-__device__ __forceinline__ void wave_bitonic_sort(i32 (&x)[R], int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64 * R; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int q = r ^ (j >> 6);
-                    if (q > r) {
-                        const bool up = ((r * 64) & k) == 0;          // k >= 128 here: the bit only depends on r
-                        const i32 a = x[r], b = x[q];
-                        const i32 lo = a < b ? a : b, hi = a < b ? b : a;
-                        x[r] = up ? lo : hi, x[q] = up ? hi : lo;
-                    }
-                }
-            } else {
-                const bool lower = (lane & j) == 0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const i32 a = x[r];
-                    const i32 b = __shfl_xor(a, j, 64);
-                    const bool up = ((r * 64 + lane) & k) == 0;
-                    x[r] = (lower == up) ? (a < b ? a : b) : (a < b ? b : a);
-                }
-            }
-        }
-    }
-}
-
-template <int R>
-__device__ __forceinline__ u64 wave_node_signature(const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
-                                                   i32* __restrict__ nbr_sorted, i32 e0, int d, int lane, u64 seed) {
-    i32 x[R];
-    u64 part = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = r * 64 + lane;
-        x[r] = 0x7fffffff;
-        if (i < d) {
-            x[r] = lab_prev[col_idx[e0 + i]];
-            part += sig_elem((u32)x[r], seed);
-        }
-    }
-    wave_bitonic_sort<R>(x, lane);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = r * 64 + lane;
-        if (i < d) nbr_sorted[e0 + i] = x[r];
-    }
-    return part;
 }
 
 __global__ __launch_bounds__(256) void wl_signature_wave_kernel(

@@ -58,6 +58,41 @@ __device__ __forceinline__ void sort_regs(i32 (&x)[16]) {
             }
 }
 
+// Bitonic network over ONE WAVE, 64 R elements striped over the lanes (element i = 64 r + lane): partners less than 64
+// apart by a lane shuffle, farther apart in the lane's own registers (static indices).  Pad with 0x7fffffff.
+#define WAVE_DEG_MAX 1024
+template <int R>
+__device__ __forceinline__ void wave_bitonic_sort(i32 (&x)[R], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int q = r ^ (j >> 6);
+                    if (q > r) {
+                        const bool up = ((r * 64) & k) == 0;          // k >= 128 here: the bit only depends on r
+                        const i32 a = x[r], b = x[q];
+                        const i32 lo = a < b ? a : b, hi = a < b ? b : a;
+                        x[r] = up ? lo : hi, x[q] = up ? hi : lo;
+                    }
+                }
+            } else {
+                const bool lower = (lane & j) == 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const i32 a = x[r];
+                    const i32 b = __shfl_xor(a, j, 64);
+                    const bool up = ((r * 64 + lane) & k) == 0;
+                    x[r] = (lower == up) ? (a < b ? a : b) : (a < b ? b : a);
+                }
+            }
+        }
+    }
+}
+
+
 // One node's signature key with its neighbour labels gathered straight into registers (degree <= 16): the 16
 // gathers are independent loads, the sort is the fixed network, the sorted list goes to nbr_sorted for the verifier.
 // (An insertion sort in global memory pays two memory latencies per step.)

@@ -211,58 +211,96 @@ extern "C" int gk_wl_fitted_create(gk_ctx* ctx, gk_batch* fit, int n_iter, gk_wl
 
 // ---- transform ----------------------------------------------------------------------------------------------------------
 // target class k of a level >= 1 -> fitted class or -1.  xlat of the level before: level 0 is the identity below L0 (the
-// targets' input labels are ids of the fit's label map, unseen ones above it), later levels go through map_prev
-__global__ void tt_match_kernel(const i32* __restrict__ t_row_ptr, const i32* __restrict__ t_col_idx, const i32* __restrict__ t_lab_prev,
-                                const i32* __restrict__ t_rep, i64 t_count, const i32* __restrict__ map_prev, i32 L0, int prev_is_level0,
-                                const u64* __restrict__ table, const i32* __restrict__ tval, u64 mask, u64 seed,
-                                const i32* __restrict__ f_row_ptr, const i32* __restrict__ f_col_idx, const i32* __restrict__ f_lab_prev,
-                                const i32* __restrict__ f_rep, i32* __restrict__ map_cur, u32* __restrict__ flags) {
-    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= t_count) return;
-    auto xlat = [&](i32 x) __attribute__((always_inline)) { return prev_is_level0 ? (x < L0 ? x : -1) : map_prev[x]; };
-    const i32 r = t_rep[k];
+// targets' input labels are ids of the fit's label map, unseen ones above it), later levels go through map_prev.
+// Round 5: ONE WAVE per target class, lane i holds neighbour i (at most TF_MAXDEG = 64): the translated labels, the hash
+// (wave sum) and -- when the hash is in the table -- both sorted neighbour lists live in one register per lane
+// (wave_bitonic_sort<1>); the thread-per-class form of round 4 kept two int[64] arrays in scratch (528 bytes per lane) and
+// sorted them by insertion.
+struct TmLevel {
+    const i32* t_lab_prev; const i32* t_lab; i32* t_rep; i64 t_count; const i32* map_prev; i32* map_cur; int prev_is_level0;
+    const u64* table; const i32* tval; u64 mask, seed; const i32* f_lab_prev; const i32* f_rep;
+};
+__device__ __forceinline__ void tt_match_class(const TmLevel& Q, i64 k, int lane, const i32* __restrict__ t_row_ptr,
+                                               const i32* __restrict__ t_col_idx, i32 L0, const i32* __restrict__ f_row_ptr,
+                                               const i32* __restrict__ f_col_idx, u32* __restrict__ flags) {
+    const i32 r = Q.t_rep[k];
     const i32 s = t_row_ptr[r];
     const int d = t_row_ptr[r + 1] - s;
-    i32 res = -1;
-    const i32 own = xlat(t_lab_prev[r]);
-    if (d > TF_MAXDEG) { atomicOr(flags, 2u); map_cur[k] = -1; return; }
-    i32 x[TF_MAXDEG];
-    bool all = own >= 0;
-    u64 acc = sig_head((u32)own, (u32)d, seed);
-    for (int i = 0; i < d && all; ++i) {
-        const i32 y = xlat(t_lab_prev[t_col_idx[s + i]]);
-        x[i] = y;
-        all = y >= 0;
-        acc += sig_elem((u32)y, seed);
+    if (d > TF_MAXDEG) {                                   // wave-uniform
+        if (lane == 0) { atomicOr(flags, 2u); Q.map_cur[k] = -1; }
+        return;
     }
-    if (all) {
-        u64 h = mix64(acc);
+    const i32 own_raw = Q.t_lab_prev[r];
+    const i32 own = Q.prev_is_level0 ? (own_raw < L0 ? own_raw : -1) : Q.map_prev[own_raw];
+    i32 x[1] = {0x7fffffff};
+    bool mine_ok = true;
+    u64 part = 0;
+    if (lane < d) {
+        const i32 raw = Q.t_lab_prev[t_col_idx[s + lane]];
+        const i32 y = Q.prev_is_level0 ? (raw < L0 ? raw : -1) : Q.map_prev[raw];
+        mine_ok = y >= 0;
+        x[0] = y;
+        part = sig_elem((u32)y, Q.seed);
+    }
+    const bool all = own >= 0 && __builtin_amdgcn_ballot_w64(!mine_ok) == 0ull;
+    i32 res = -1;
+    if (all) {                                             // wave-uniform
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        u64 h = mix64(sig_head((u32)own, (u32)d, Q.seed) + part);
         if (h == 0) h = 1;
-        u64 slot = h & mask;
+        u64 slot = h & Q.mask;
         for (;;) {
-            const u64 t = table[slot];
+            const u64 t = Q.table[slot];
             if (t == 0) break;
             if (t == h) {
                 // the hash proposes, the full signature of the fitted representative decides
-                const i32 c = tval[slot];
-                const i32 rf = f_rep[c];
+                const i32 c = Q.tval[slot];
+                const i32 rf = Q.f_rep[c];
                 const i32 sf = f_row_ptr[rf];
-                bool ok = f_lab_prev[rf] == own && f_row_ptr[rf + 1] - sf == d;
+                bool ok = Q.f_lab_prev[rf] == own && f_row_ptr[rf + 1] - sf == d;
                 if (ok) {
-                    i32 y[TF_MAXDEG];
-                    for (int i = 0; i < d; ++i) y[i] = f_lab_prev[f_col_idx[sf + i]];
-                    insertion_sort(x, d);
-                    insertion_sort(y, d);
-                    for (int i = 0; i < d; ++i)
-                        if (x[i] != y[i]) { ok = false; break; }
+                    i32 y[1] = {0x7fffffff};
+                    if (lane < d) y[0] = Q.f_lab_prev[f_col_idx[sf + lane]];
+                    wave_bitonic_sort<1>(x, lane);
+                    wave_bitonic_sort<1>(y, lane);
+                    ok = __builtin_amdgcn_ballot_w64(x[0] != y[0]) == 0ull;
                 }
                 if (ok) res = c;
                 break;
             }
-            slot = (slot + 1) & mask;
+            slot = (slot + 1) & Q.mask;
         }
     }
-    map_cur[k] = res;
+    if (lane == 0) Q.map_cur[k] = res;
+}
+
+__global__ __launch_bounds__(256) void tt_match_kernel(const TmLevel Q, const i32* __restrict__ t_row_ptr, const i32* __restrict__ t_col_idx,
+                                                       i32 L0, const i32* __restrict__ f_row_ptr, const i32* __restrict__ f_col_idx,
+                                                       u32* __restrict__ flags) {
+    const i64 k = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (k >= Q.t_count) return;
+    tt_match_class(Q, k, threadIdx.x & 63, t_row_ptr, t_col_idx, L0, f_row_ptr, f_col_idx, flags);
+}
+
+// A handful of targets (one graph to classify: the serving case): ALL levels in one single-workgroup launch -- per level the
+// representatives (any writer wins), a workgroup barrier, the classes dealt to the 16 waves, a barrier -- instead of two
+// launches per level (ten dependent launches of ~5 us for h = 5).
+#define TM_MAX_LEVELS 16
+#define TM_MAX_NODES 8192
+struct TmLevels { TmLevel lv[TM_MAX_LEVELS]; int L; };
+__global__ __launch_bounds__(1024) void tt_match_levels_kernel(const TmLevels P, i64 Vt, const i32* __restrict__ t_row_ptr,
+                                                               const i32* __restrict__ t_col_idx, i32 L0, const i32* __restrict__ f_row_ptr,
+                                                               const i32* __restrict__ f_col_idx, u32* __restrict__ flags) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int l = 1; l < P.L; ++l) {
+        const TmLevel& Q = P.lv[l];
+        for (i64 v = tid; v < Vt; v += 1024) Q.t_rep[Q.t_lab[v]] = (i32)v;
+        __threadfence_block();
+        __syncthreads();
+        for (i64 k = w; k < Q.t_count; k += 16) tt_match_class(Q, k, lane, t_row_ptr, t_col_idx, L0, f_row_ptr, f_col_idx, flags);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 struct TaLevels {
@@ -405,12 +443,30 @@ extern "C" int gk_wl_transform(gk_ctx* ctx, gk_wl_fitted* w, gk_batch* tb, int n
         const i64 tc = tb->label_counts[l];
         maps[l].reset(new Tmp<i32>(ctx)), reps[l].reset(new Tmp<i32>(ctx));
         GK_TRY(maps[l]->alloc(tc)); GK_TRY(reps[l]->alloc(tc));
-        tf_rep_kernel<<<grid_for(Vt, 256), 256, 0, ctx->stream>>>(P.t_lab[l], reps[l]->p, Vt);
-        tt_match_kernel<<<grid_for(tc, 128), 128, 0, ctx->stream>>>(
-            tb->row_ptr, tb->col_idx, P.t_lab[l - 1], reps[l]->p, tc, l >= 2 ? maps[l - 1]->p : nullptr, w->L0, l == 1 ? 1 : 0,
-            w->table[l], w->tval[l], w->mask[l], tf_seed(l), fb->row_ptr, fb->col_idx,
-            fb->labels + (size_t)(l - 1) * fb->n_nodes, w->rep[l], maps[l]->p, flags.p);
         P.map[l] = maps[l]->p;
+    }
+    {
+        auto level = [&](int l) {
+            TmLevel Q;
+            Q.t_lab_prev = P.t_lab[l - 1], Q.t_lab = P.t_lab[l], Q.t_rep = reps[l]->p, Q.t_count = tb->label_counts[l];
+            Q.map_prev = l >= 2 ? maps[l - 1]->p : nullptr, Q.map_cur = maps[l]->p, Q.prev_is_level0 = l == 1 ? 1 : 0;
+            Q.table = w->table[l], Q.tval = w->tval[l], Q.mask = w->mask[l], Q.seed = tf_seed(l);
+            Q.f_lab_prev = fb->labels + (size_t)(l - 1) * fb->n_nodes, Q.f_rep = w->rep[l];
+            return Q;
+        };
+        if (Vt > 0 && L >= 2 && L <= TM_MAX_LEVELS && Vt <= TM_MAX_NODES && !ctx->opt.tt_no_fused) {
+            TmLevels A = {};
+            A.L = L;
+            for (int l = 1; l < L; ++l) A.lv[l] = level(l);
+            tt_match_levels_kernel<<<dim3(1), 1024, 0, ctx->stream>>>(A, Vt, tb->row_ptr, tb->col_idx, w->L0, fb->row_ptr, fb->col_idx, flags.p);
+        } else if (Vt > 0) {
+            for (int l = 1; l < L; ++l) {
+                const TmLevel Q = level(l);
+                tf_rep_kernel<<<grid_for(Vt, 256), 256, 0, ctx->stream>>>(Q.t_lab, Q.t_rep, Vt);
+                tt_match_kernel<<<grid_for(Q.t_count * 64, 256), 256, 0, ctx->stream>>>(Q, tb->row_ptr, tb->col_idx, w->L0, fb->row_ptr, fb->col_idx,
+                                                                                      flags.p);
+            }
+        }
     }
     Tmp<double> K(ctx);
     Tmp<u64> ys(ctx);

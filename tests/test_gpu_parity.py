@@ -2103,3 +2103,30 @@ def test_debug_guard_catches_a_write_behind_a_block(gk, gkopt):
     eng.synchronize()                                            # reported once; the context stays usable
     assert np.array_equal(eng.gram(feat, 0), O.WLOracle(n_iter=2).fit_transform(er_dataset(N, 12, 0.3, 3, 4)))
     feat.close(), db.close()
+
+
+@pytest.mark.parametrize("no_fused", [0, 1])
+def test_lookup_transform_match_kernels_fused_and_per_level(gk, gkopt, no_fused):
+    """The look-up transform matches target classes to fitted classes with one wave per class (round 5: neighbour lists in
+    registers, no scratch); a handful of targets run all levels in ONE single-workgroup launch, larger sets (or option
+    transform.no_fused) two launches per level.  Degrees up to the 64-neighbour limit, unseen labels, isolated vertices."""
+    gkopt("transform.no_fused", no_fused)
+    X = random_labelled_graphs(40, 5, 30, 0.35, 3, 31, fmt="dict")
+    hub = {0: list(range(1, 61))}
+    hub.update({i: [0] for i in range(1, 61)})
+    X.append([hub, {i: i % 3 for i in range(61)}])               # a representative with 60 neighbours
+    Y = X[5:9] + [[{0: [1], 1: [0], 2: []}, {0: 0, 1: 7, 2: 1}]] + [X[-1]] + random_labelled_graphs(6, 5, 30, 0.35, 3, 77, fmt="dict")
+    ref = O.WLOracle(n_iter=4)
+    ref.fit_transform(X)
+    Kt = ref.transform(Y)
+    est = gk.WeisfeilerLehman(n_iter=4)
+    est.transform_route = "lookup"
+    est.fit(X)
+    assert np.array_equal(est.transform(Y), Kt)
+    assert np.array_equal(est.transform(Y[:1]), Kt[:1])
+    estn = gk.WeisfeilerLehman(n_iter=4, normalize=True)
+    estn.transform_route = "lookup"
+    estn.fit(X)
+    refn = O.WLOracle(n_iter=4, normalize=True)
+    refn.fit_transform(X)
+    assert np.abs(estn.transform(Y) - refn.transform(Y)).max() <= REL_TOL
