@@ -81,6 +81,7 @@ extern "C" int gk_destroy(gk_ctx* ctx) {
     if (ctx->mbox_host) (void)hipHostFree(ctx->mbox_host);
     if (ctx->host_pool) gk_host_pool_destroy(ctx->host_pool);
     if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
+    if (ctx->xfer_host) (void)hipHostFree(ctx->xfer_host);
     for (int i = 0; i < 4; ++i)
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     cache_release_all(ctx);

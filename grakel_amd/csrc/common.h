@@ -126,11 +126,13 @@ struct gk_ctx {
     // pinned staging ring + events of the compact device -> host copy of a Gram matrix (gram.hip: gram_copy_out)
     void* stage_host = nullptr;
     hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* xfer_host = nullptr;                 // pinned block for small results that come back in one copy (wl_transform.hip)
     struct GkHostPool* host_pool = nullptr;    // host threads of that copy's widening (created on first use, joined by gk_destroy)
     u32 mbox_seq = 0;
     int n_cu = 0;                              // compute units of the device (persistent-kernel grids)
     std::map<const void*, int> func_lds;       // kernel -> dynamic LDS limit already set for THIS context's device (gk_func_lds)
 };
+#define GK_XFER_BYTES ((size_t)8 << 20)
 #define GK_MAX_RANKS 64          // shards of gk_batch_from_shards / ranks of a gk_comm
 #define GK_MBOX_WORDS 512
 #define GK_HIST0_MAX_LABELS 256
@@ -210,7 +212,8 @@ struct gk_batch {
     i32* row_ptr = nullptr;     // [n_nodes+1]
     i32* col_idx = nullptr;     // [n_edges]
     i32* node_graph = nullptr;  // [n_nodes]
-    i32* big_nodes = nullptr;   // [n_big] nodes with degree > WL_DEG_SMALL
+    i32* big_nodes = nullptr;   // [n_big] nodes with degree > deg_small
+    int deg_small = 32;         // WL_DEG_SMALL, or 16 once the batch has any vertex above WL_DEG_SMALL (wl.hip: batch_finish)
     i64 n_big = 0;
     i32 max_degree = 0;
     // isolated vertices (degree 0): their WL class is "all isolated vertices with the same input

@@ -77,7 +77,7 @@ __device__ __forceinline__ u64 wave_node_signature(const i32* __restrict__ col_i
 __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
     const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted, u64* __restrict__ hash,
-    i64 V, u64 seed, u64 mask, int sig_regs) {
+    i64 V, u64 seed, u64 mask, int sig_regs, int deg_small) {
     __shared__ i32 buf[SIG_LDS_CAP];
     const int tid = threadIdx.x;
     const i64 v0 = (i64)blockIdx.x * SIG_THREADS;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     // nothing, 130 us per level
     {
         const int dv = v < v1 ? row_ptr[v + 1] - row_ptr[v] : 0;
-        if (!__syncthreads_or(dv >= 1 && dv <= WL_DEG_SMALL)) {
+        if (!__syncthreads_or(dv >= 1 && dv <= deg_small)) {
             if (v < v1 && dv == 0) hash[v] = mix64(sig_head((u32)lab_prev[v], 0u, seed)) & mask;
             return;
         }
@@ -100,13 +100,13 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     // network) does not stream their lists through here: its small nodes gather their own neighbours, as the list kernel does
     {
         const int dv = v < v1 ? row_ptr[v + 1] - row_ptr[v] : 0;
-        if (__syncthreads_or(dv > WL_DEG_SMALL)) {
+        if (__syncthreads_or(dv > deg_small)) {
             const i32 s = v < v1 ? row_ptr[v] : 0;
             if (v < v1 && dv <= 16) hash[v] = mix64(node_key_regs(col_idx, lab_prev, nbr_sorted + s, s, dv, (u32)lab_prev[v], seed)) & mask;
             // 17 .. WL_DEG_SMALL neighbours: the wave sorts such a list together, one node after the other (an insertion
             // sort by the node's own thread is ~d^2 / 4 dependent steps in global memory: 107 us per level on the COLLAB-like set)
             const int lane = tid & 63;
-            u64 todo = __ballot(v < v1 && dv > 16 && dv <= WL_DEG_SMALL);
+            u64 todo = __ballot(v < v1 && dv > 16 && dv <= deg_small);
             while (todo) {
                 const int src = (int)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
     if (v < v1) {
         const i32 s = row_ptr[v];
         const int d = row_ptr[v + 1] - s;
-        if (d <= WL_DEG_SMALL) {
+        if (d <= deg_small) {
             u64 acc = sig_head((u32)lab_prev[v], (u32)d, seed);
             if (use_lds && dwave <= 16 && sig_regs) {
                 i32* x = buf + (s - e0);
@@ -401,13 +401,13 @@ struct ActiveScan {
 __global__ void wl_signature_list_kernel(const u32* __restrict__ act, i64 n_act,
                                          const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
                                          const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted,
-                                         u64* __restrict__ hash_out, u64 seed, u64 mask) {
+                                         u64* __restrict__ hash_out, u64 seed, u64 mask, int deg_small) {
     i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_act) return;
     const u32 v = act[j];
     const i32 s = row_ptr[v];
     const int d = row_ptr[v + 1] - s;
-    if (d > WL_DEG_SMALL) return;               // hubs: wl_signature_big_kernel (writes hash_node[v])
+    if (d > deg_small) return;                  // the wave / workgroup kernels' (they write hash_node[v])
     i32* x = nbr_sorted + s;
     u64 acc;
     if (d <= 16) acc = node_key_regs(col_idx, lab_prev, x, s, d, (u32)lab_prev[v], seed);
@@ -458,11 +458,11 @@ __global__ __launch_bounds__(256) void wl_signature_exact_kernel(
 
 // hubs write their hash indexed by node: move it to the active-list slot
 __global__ void gather_big_hash_kernel(const u32* __restrict__ act, i64 n_act, const i32* __restrict__ row_ptr,
-                                       const u64* __restrict__ hash_node, u64* __restrict__ hash_out) {
+                                       const u64* __restrict__ hash_node, u64* __restrict__ hash_out, int deg_small) {
     i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_act) return;
     const u32 v = act[j];
-    if (row_ptr[v + 1] - row_ptr[v] > WL_DEG_SMALL) hash_out[j] = hash_node[v];
+    if (row_ptr[v + 1] - row_ptr[v] > deg_small) hash_out[j] = hash_node[v];
 }
 
 
@@ -760,7 +760,7 @@ __global__ void verify_kernel(const i32* __restrict__ row_ptr, const i32* __rest
     }
     i32 s = row_ptr[v];
     int d = row_ptr[v + 1] - s;
-    if (skip_big && d > WL_DEG_SMALL) return;          // verify_big_kernel's (a wave per node)
+    if (skip_big && d > skip_big) return;              // verify_big_kernel's (a wave per node); skip_big = the batch's threshold
     const i32 r = rep[l];
     if (r == (i32)v) return;
     bool ok = lab_prev[v] == lab_prev[r];
@@ -867,6 +867,11 @@ __global__ __launch_bounds__(1024) void batch_stats_reduce_kernel(const i32* __r
     }
 }
 
+__global__ void big_flag_kernel(const i32* __restrict__ row_ptr, i64 n, int thr, u32* __restrict__ big_flag) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) big_flag[i] = row_ptr[i + 1] - row_ptr[i] > thr ? 1u : 0u;
+}
+
 __global__ void compact_big_kernel(const u32* __restrict__ big_flag, const u32* __restrict__ excl,
                                    i32* __restrict__ big_nodes, i64 n) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -945,6 +950,20 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
         return GK_ERR_ARG;
     }
     b->max_graph_nodes = (i32)h[0], b->max_degree = (i32)h[1], b->n_big = h[2];
+    b->deg_small = WL_DEG_SMALL;
+    if (b->n_big > 0 && !ctx->opt.wl_no_wave_sig) {
+        // A batch with vertices above WL_DEG_SMALL neighbours is off the route without host round trips anyway; its
+        // vertices of 17 .. 32 neighbours then go to the wave-per-vertex kernels as well (the thread-per-vertex kernel sorts
+        // up to 16 in registers; beyond it had an insertion sort per thread, or -- in a chunk shared with high degrees -- one
+        // wave sorting the chunk's lists one after the other: 107 us per level on the COLLAB-like set).  One more flag pass,
+        // scan and 4-byte read-back per batch.
+        b->deg_small = 16;
+        big_flag_kernel<<<grid_for(n_nodes, 256), 256, 0, ctx->stream>>>(b->row_ptr, n_nodes, b->deg_small, flag.p);
+        GK_TRY(gk_scan_u32(ctx, flag.p, excl.p, n_nodes, true, (u32*)stats.p + 2));
+        u32 nb = 0;
+        GK_TRY(gk_readback(ctx, (const u32*)stats.p + 2, &nb, 1));
+        b->n_big = nb;
+    }
     b->n_labels0_present = few_labels ? (i32)h[4] : 0;
     b->n_iso = 0;
     b->n_isolated = h[3];
@@ -1272,7 +1291,7 @@ static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* 
     if (V == 0) return GK_OK;
     const int sig_regs = ctx->opt.wl_sig_no_regs ? 0 : 1;      // route option: insertion sort in LDS instead
     wl_signature_small_kernel<<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
-        b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask, sig_regs);
+        b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask, sig_regs, b->deg_small);
     if (b->n_big > 0) GK_TRY(launch_signature_big(ctx, b, lab_prev, hash, seed, mask));
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
@@ -1512,11 +1531,11 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         GK_TRY(hash_act.alloc(n_act)); GK_TRY(rep.alloc(n_act));
         const u64 seed = level_seed(level, 0);
         wl_signature_list_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(
-            st.act_cur, n_act, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_act.p, seed, mask);
+            st.act_cur, n_act, b->row_ptr, b->col_idx, prev, b->nbr_sorted, hash_act.p, seed, mask, b->deg_small);
         if (b->n_big > 0) {
             GK_TRY(hash_node.alloc(V));
             GK_TRY(launch_signature_big(ctx, b, prev, hash_node.p, seed, mask));
-            gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act_cur, n_act, b->row_ptr, hash_node.p, hash_act.p);
+            gather_big_hash_kernel<<<grid_for(n_act, 256), 256, 0, ctx->stream>>>(st.act_cur, n_act, b->row_ptr, hash_node.p, hash_act.p, b->deg_small);
         }
         GK_TRY(dictionary_from_keys(ctx, hash_act.p, n_act, bits, cur, perm, rep.p, st.scratch.p, st.act_cur, st.frozen.p, 0,
                                     sort_buckets_ok(ctx, st.prev_top_max, n_act, exact), st.scratch.p + 2, nullptr, nullptr,
@@ -1588,7 +1607,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         b->perm_valid[level] = no_order_taken ? 0 : 1;
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
-        const int big_apart = (b->n_big > 0 && !ctx->opt.wl_no_wave_sig) ? 1 : 0;
+        const int big_apart = (b->n_big > 0 && !ctx->opt.wl_no_wave_sig) ? b->deg_small : 0;
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V,
                                                                   flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr, big_apart);
         if (big_apart)

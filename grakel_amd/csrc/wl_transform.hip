@@ -17,6 +17,7 @@
 // Declines (GK_ERR_UNSUPPORTED; the caller takes the joint route): two fitted classes with one 64-bit hash, a node of more than
 // TF_MAXDEG neighbours among the representatives, a target graph above GM_MAX_NODES nodes.
 #include "common.h"
+#include <string.h>
 #include "features.h"
 #include "scan_fn.h"
 #include "wl_sig.h"
@@ -25,6 +26,7 @@
 
 #define TF_MAXDEG 64
 #define TA_COLS 32768            // fitted graphs per accumulator block (u32 in LDS)
+#define TT_SPLIT_MAX_TARGETS 16  // up to here the accumulation is spread over the chip (tt_items / tt_walk / tt_finish)
 #define TA_SLOTS 2048            // label-count table of one target graph (n <= GM_MAX_NODES)
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
@@ -404,6 +406,96 @@ __global__ __launch_bounds__(1024) void tt_accumulate_kernel(const TaLevels P, c
     if (tid == 0) y_selfk[t] = self_s;
 }
 
+// ---- a handful of targets: the accumulation spread over the chip.  tt_accumulate_kernel gives a target graph ONE workgroup,
+// which walks every fitted (graph, count) entry of every matched label alone (~0.1 ms for one config-3 target against 10 000
+// fitted graphs: the serving case).  Here: (1) a workgroup per target lists its items (level, fitted class, count in the
+// target) and its self similarity, (2) waves from all over the chip take the items one by one and add count_t * count_f to a
+// 32-bit accumulator row in HBM (the fitted entries of a class are distinct graphs: no contention inside a wave),
+// (3) one pass turns the accumulators into the float64 / normalised row.
+__global__ __launch_bounds__(1024) void tt_items_kernel(const TaLevels P, const i32* __restrict__ t_graph_ptr, i32 L0, int3* __restrict__ items,
+                                                        u32* __restrict__ n_items, i64 item_cap, u64* __restrict__ y_selfk) {
+    extern __shared__ __attribute__((aligned(16))) u32 ti_lds[];
+    i32* keys = (i32*)ti_lds;                            // [TA_SLOTS]
+    u32* cnt = (u32*)(keys + TA_SLOTS);                  // [TA_SLOTS]
+    __shared__ unsigned long long self_s;
+    const int tid = threadIdx.x;
+    const i64 t = blockIdx.x;
+    const i32 v0 = t_graph_ptr[t];
+    const int n = t_graph_ptr[t + 1] - v0;
+    u32 T = 64;
+    while (T < 2u * (u32)n) T <<= 1;
+    const u32 tmask = T - 1u;
+    if (tid == 0) self_s = 0ull;
+    for (int l = 0; l < P.L; ++l) {
+        __syncthreads();
+        for (u32 i = tid; i < T; i += 1024) keys[i] = -1, cnt[i] = 0u;
+        __syncthreads();
+        const i32* __restrict__ lab = P.t_lab[l];
+        for (int i = tid; i < n; i += 1024) {
+            const i32 x = lab[v0 + i];
+            u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+            for (;;) {
+                const i32 old = atomicCAS(&keys[h], -1, x);
+                if (old == -1 || old == x) { atomicAdd(&cnt[h], 1u); break; }
+                h = (h + 1u) & tmask;
+            }
+        }
+        __syncthreads();
+        unsigned long long sq = 0ull;
+        for (u32 i = tid; i < T; i += 1024) {
+            const i32 x = keys[i];
+            if (x < 0) continue;
+            const u32 c = cnt[i];
+            sq += (unsigned long long)c * c;
+            const i32 fc = P.map[l] ? P.map[l][x] : (x < L0 ? x : -1);
+            if (fc >= 0) {
+                const u32 e = atomicAdd(&n_items[t], 1u);
+                if ((i64)e < item_cap) items[t * item_cap + e] = make_int3(l, fc, (int)c);
+            }
+        }
+        if (sq) atomicAdd(&self_s, sq);
+    }
+    __syncthreads();
+    if (tid == 0) y_selfk[t] = self_s;
+}
+
+__global__ __launch_bounds__(256) void tt_walk_kernel(const TaLevels P, const int3* __restrict__ items, const u32* __restrict__ n_items,
+                                                      i64 item_cap, i64 n_fit, u32* __restrict__ acc) {
+    const i64 t = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const u32 ni = n_items[t];
+    const u32 waves = gridDim.x * 4u;
+    for (u32 it = blockIdx.x * 4u + (threadIdx.x >> 6); it < ni; it += waves) {
+        const int3 q = items[t * item_cap + it];
+        const i32 lo = P.cls_ptr[q.x][q.y], hi = P.cls_ptr[q.x][q.y + 1];
+        const uint2* __restrict__ en = P.ent[q.x];
+        for (i32 e0 = lo + lane; e0 < hi; e0 += 256) {
+            uint2 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = e0 + 64 * u < hi ? en[e0 + 64 * u] : make_uint2(0xffffffffu, 0u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (x[u].x != 0xffffffffu) atomicAdd(&acc[t * n_fit + (i64)x[u].x], (u32)q.z * x[u].y);
+        }
+    }
+}
+
+__global__ void tt_finish_kernel(const u32* __restrict__ acc, i64 n_targets, i64 n_fit, const u64* __restrict__ x_selfk,
+                                 const u64* __restrict__ y_selfk, int normalize, double* __restrict__ K) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_targets * n_fit) return;
+    const i64 t = i / n_fit, f = i - t * n_fit;
+    double v = (double)acc[i];
+    if (normalize) {
+        v = v / sqrt((double)y_selfk[t] * (double)x_selfk[f]);
+        if (normalize == 2) {
+            if (v != v) v = 0.0;
+            else if (v > 1.7976931348623157e308) v = 1.7976931348623157e308;
+        }
+    }
+    K[i] = v;
+}
+
 extern "C" int gk_wl_fitted_selfk(gk_ctx* ctx, gk_wl_fitted* w, double* out_selfk) {
     GK_ARG(ctx && w && out_selfk, "gk_wl_fitted_selfk: null argument");
     std::vector<u64> h((size_t)w->N);
@@ -429,8 +521,22 @@ extern "C" int gk_wl_transform(gk_ctx* ctx, gk_wl_fitted* w, gk_batch* tb, int n
     const i64 Vt = tb->n_nodes, Nt = tb->n_graphs, Nf = w->N;
     const int L = w->n_levels;
     gk_batch* fb = w->fit;
-    Tmp<u32> flags(ctx);
-    GK_TRY(flags.alloc(4));
+    // small results (one graph to classify: an 80 KB row) come back in ONE copy through the context's pinned block: K, the
+    // targets' self similarities and the flag words sit in one device block.  (Three hipMemcpyAsync into pageable memory
+    // cost ~0.1 ms of the 0.17 ms the call took for one target.)
+    const size_t k_bytes = (size_t)Nt * (size_t)Nf * 8, ys_bytes = (size_t)Nt * 8;
+    const bool one_copy = k_bytes + ys_bytes + 16 <= GK_XFER_BYTES;
+    Tmp<char> block(ctx);
+    Tmp<u32> flags_own(ctx);
+    u32* flags_p = nullptr;
+    if (one_copy) {
+        GK_TRY(block.alloc(k_bytes + ys_bytes + 16));
+        flags_p = (u32*)(block.p + k_bytes + ys_bytes);
+    } else {
+        GK_TRY(flags_own.alloc(4));
+        flags_p = flags_own.p;
+    }
+    struct { u32* p; } flags = {flags_p};
     GK_TRY(gk_zero_async(ctx, flags.p, 16));
     std::vector<std::unique_ptr<Tmp<i32>>> maps((size_t)L), reps((size_t)L);
     TaLevels P = {};
@@ -468,19 +574,48 @@ extern "C" int gk_wl_transform(gk_ctx* ctx, gk_wl_fitted* w, gk_batch* tb, int n
             }
         }
     }
-    Tmp<double> K(ctx);
-    Tmp<u64> ys(ctx);
-    GK_TRY(K.alloc((size_t)Nt * (size_t)Nf)); GK_TRY(ys.alloc(Nt));
-    const int lds = (TA_COLS + 2 * TA_SLOTS + 2 * GM_MAX_NODES) * 4;
-    GK_TRY(gk_func_lds(ctx, (const void*)tt_accumulate_kernel, lds));
-    tt_accumulate_kernel<<<dim3((unsigned)Nt), 1024, lds, ctx->stream>>>(P, tb->graph_ptr, w->L0, Nf, w->selfk, normalize, K.p, ys.p);
+    Tmp<double> K_own(ctx);
+    Tmp<u64> ys_own(ctx);
+    struct { double* p; } K = {nullptr};
+    struct { u64* p; } ys = {nullptr};
+    if (one_copy) K.p = (double*)block.p, ys.p = (u64*)(block.p + k_bytes);
+    else {
+        GK_TRY(K_own.alloc((size_t)Nt * (size_t)Nf)); GK_TRY(ys_own.alloc(Nt));
+        K.p = K_own.p, ys.p = ys_own.p;
+    }
+    if (Nt <= TT_SPLIT_MAX_TARGETS && !ctx->opt.tt_no_fused) {
+        const i64 item_cap = (i64)tb->max_graph_nodes * L;           // distinct labels of a graph per level <= its vertices
+        Tmp<int3> items(ctx);
+        Tmp<u32> n_items(ctx), acc(ctx);
+        GK_TRY(items.alloc((size_t)Nt * (size_t)item_cap)); GK_TRY(n_items.alloc(Nt)); GK_TRY(acc.alloc((size_t)Nt * (size_t)Nf));
+        GK_TRY(gk_zero_async(ctx, n_items.p, (size_t)Nt * 4));
+        GK_TRY(gk_zero_async(ctx, acc.p, (size_t)Nt * (size_t)Nf * 4));
+        tt_items_kernel<<<dim3((unsigned)Nt), 1024, TA_SLOTS * 8, ctx->stream>>>(P, tb->graph_ptr, w->L0, items.p, n_items.p, item_cap, ys.p);
+        const unsigned per_target = (unsigned)std::max<i64>(1, 256 / Nt);
+        tt_walk_kernel<<<dim3(per_target, (unsigned)Nt), 256, 0, ctx->stream>>>(P, items.p, n_items.p, item_cap, Nf, acc.p);
+        tt_finish_kernel<<<grid_for(Nt * Nf, 256), 256, 0, ctx->stream>>>(acc.p, Nt, Nf, w->selfk, ys.p, normalize, K.p);
+    } else {
+        const int lds = (TA_COLS + 2 * TA_SLOTS + 2 * GM_MAX_NODES) * 4;
+        GK_TRY(gk_func_lds(ctx, (const void*)tt_accumulate_kernel, lds));
+        tt_accumulate_kernel<<<dim3((unsigned)Nt), 1024, lds, ctx->stream>>>(P, tb->graph_ptr, w->L0, Nf, w->selfk, normalize, K.p, ys.p);
+    }
     GK_HIP_CHECK(hipGetLastError());
     u32 hf[4] = {0, 0, 0, 0};
-    GK_HIP_CHECK(hipMemcpyAsync(hf, flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP_CHECK(hipMemcpyAsync(out_K, K.p, (size_t)Nt * (size_t)Nf * 8, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<u64> hy((size_t)Nt);
-    GK_HIP_CHECK(hipMemcpyAsync(hy.data(), ys.p, (size_t)Nt * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (one_copy) {
+        if (!ctx->xfer_host) GK_HIP_CHECK(hipHostMalloc(&ctx->xfer_host, GK_XFER_BYTES, hipHostMallocDefault));
+        GK_HIP_CHECK(hipMemcpyAsync(ctx->xfer_host, block.p, k_bytes + ys_bytes + 16, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const char* h = (const char*)ctx->xfer_host;
+        memcpy(out_K, h, k_bytes);
+        memcpy(hy.data(), h + k_bytes, ys_bytes);
+        memcpy(hf, h + k_bytes + ys_bytes, 16);
+    } else {
+        GK_HIP_CHECK(hipMemcpyAsync(hf, flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(out_K, K.p, k_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(hy.data(), ys.p, ys_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     if (hf[0]) return GK_ERR_UNSUPPORTED;                  // a target representative above TF_MAXDEG neighbours
     for (i64 i = 0; i < Nt; ++i) out_y_selfk[i] = (double)hy[i];
     return GK_OK;
