@@ -525,7 +525,8 @@ extern "C" int gk_wl_transform(gk_ctx* ctx, gk_wl_fitted* w, gk_batch* tb, int n
     // targets' self similarities and the flag words sit in one device block.  (Three hipMemcpyAsync into pageable memory
     // cost ~0.1 ms of the 0.17 ms the call took for one target.)
     const size_t k_bytes = (size_t)Nt * (size_t)Nf * 8, ys_bytes = (size_t)Nt * 8;
-    const bool one_copy = k_bytes + ys_bytes + 16 <= GK_XFER_BYTES;
+    // (larger outputs are pinned blocks of the caller's pool already -- engine.PinnedPool from 1 MB up -- and take the direct copy)
+    const bool one_copy = k_bytes + ys_bytes + 16 <= ((size_t)1 << 20);
     Tmp<char> block(ctx);
     Tmp<u32> flags_own(ctx);
     u32* flags_p = nullptr;
