@@ -194,117 +194,49 @@ __device__ __forceinline__ void block_bitonic_sort(P x, int n) {
     }
 }
 
-// A wave takes WAVE_BATCH consecutive entries of the list: the kernel is a chain of dependent memory round trips per node
-// (list entry -> row_ptr -> col_idx -> label gather), and with one node per wave the 8 wave slots of a SIMD bound it at
-// ~110 G gathers/s (COLLAB-like: 195 us per level).  The four nodes' loads of each step are issued together; nodes of up to
-// 64 neighbours (one register per lane) go through the batched path, larger ones one after the other.
-#define WAVE_BATCH 4
-__device__ __forceinline__ u64 wave_node_any(const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted,
-                                              i32 e0, int d, int lane, u64 seed) {
-    if (d <= 64) return wave_node_signature<1>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
-    if (d <= 128) return wave_node_signature<2>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
-    if (d <= 256) return wave_node_signature<4>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
-    if (d <= 512) return wave_node_signature<8>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
-    // (32 or 64 registers per lane: the fully unrolled network no longer compiles to registers -- 272 B of scratch per lane,
-    // tried; hubs beyond 1024 neighbours keep the workgroup kernel, now 1024 threads wide)
-    return wave_node_signature<16>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
-}
-
 __global__ __launch_bounds__(256) void wl_signature_wave_kernel(
     const i32* __restrict__ big_nodes, i64 n_big, const i32* __restrict__ row_ptr,
     const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
     i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask) {
-    const i64 w0 = (((i64)blockIdx.x * 256 + threadIdx.x) >> 6) * WAVE_BATCH;
+    const i64 w = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (w0 >= n_big) return;
-    i32 v[WAVE_BATCH], e0[WAVE_BATCH], own[WAVE_BATCH];
-    int d[WAVE_BATCH];
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) v[i] = w0 + i < n_big ? big_nodes[w0 + i] : -1;
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) {
-        e0[i] = v[i] >= 0 ? row_ptr[v[i]] : 0;
-        d[i] = v[i] >= 0 ? row_ptr[v[i] + 1] - e0[i] : 0;
-        own[i] = v[i] >= 0 ? lab_prev[v[i]] : 0;
-    }
-    bool small = true;
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) small = small && d[i] <= 64;
-    if (small) {                                  // wave-uniform
-        i32 c[WAVE_BATCH], x[WAVE_BATCH][1];
-#pragma unroll
-        for (int i = 0; i < WAVE_BATCH; ++i) c[i] = lane < d[i] ? col_idx[e0[i] + lane] : -1;
-#pragma unroll
-        for (int i = 0; i < WAVE_BATCH; ++i) x[i][0] = c[i] >= 0 ? lab_prev[c[i]] : 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < WAVE_BATCH; ++i) {
-            if (v[i] < 0) continue;               // wave-uniform
-            u64 part = lane < d[i] ? sig_elem((u32)x[i][0], seed) : 0ull;
-            wave_bitonic_sort<1>(x[i], lane);
-            if (lane < d[i]) nbr_sorted[e0[i] + lane] = x[i][0];
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-            if (lane == 0) hash[v[i]] = mix64(sig_head((u32)own[i], (u32)d[i], seed) + part) & mask;
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) {
-        if (v[i] < 0 || d[i] > WAVE_DEG_MAX) continue;       // beyond WAVE_DEG_MAX: the workgroup kernel's
-        u64 part = wave_node_any(col_idx, lab_prev, nbr_sorted, e0[i], d[i], lane, seed);
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-        if (lane == 0) hash[v[i]] = mix64(sig_head((u32)own[i], (u32)d[i], seed) + part) & mask;
-    }
+    if (w >= n_big) return;
+    const i32 v = big_nodes[w];
+    const i32 e0 = row_ptr[v];
+    const int d = row_ptr[v + 1] - e0;
+    if (d > WAVE_DEG_MAX) return;                 // the workgroup kernel's
+    u64 part;
+    if (d <= 64) part = wave_node_signature<1>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else if (d <= 128) part = wave_node_signature<2>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else if (d <= 256) part = wave_node_signature<4>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else if (d <= 512) part = wave_node_signature<8>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
+    else part = wave_node_signature<16>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);      // (32 or 64 registers per lane:
+    // the fully unrolled network no longer compiles to registers -- 272 B of scratch per lane, tried; hubs beyond 1024
+    // neighbours keep the workgroup kernel, now 1024 threads wide)
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) hash[v] = mix64(sig_head((u32)lab_prev[v], (u32)d, seed) + part) & mask;
 }
 
 // the verifier's half for the same nodes: a wave compares the node's sorted list with its class representative's,
-// 64 entries per step (verify_kernel walks a list with ONE thread: 200 us per level on the COLLAB-like batch); WAVE_BATCH
-// nodes per wave, their loads issued together
+// 64 entries per step (verify_kernel walks a list with ONE thread: 200 us per level on the COLLAB-like batch)
 __global__ __launch_bounds__(256) void verify_big_kernel(const i32* __restrict__ big_nodes, i64 n_big, const i32* __restrict__ row_ptr,
                                                          const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
                                                          const i32* __restrict__ lab, const i32* __restrict__ rep,
                                                          u32* __restrict__ unresolved, const unsigned char* __restrict__ shared) {
-    const i64 w0 = (((i64)blockIdx.x * 256 + threadIdx.x) >> 6) * WAVE_BATCH;
+    const i64 w = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (w0 >= n_big) return;
-    i32 v[WAVE_BATCH], r[WAVE_BATCH], s[WAVE_BATCH], sr[WAVE_BATCH];
-    int d[WAVE_BATCH];
-    bool ok[WAVE_BATCH];
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) v[i] = w0 + i < n_big ? big_nodes[w0 + i] : -1;
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) {
-        // a singleton is its own representative (rep[] has no entry for it)
-        if (v[i] >= 0 && shared && !shared[v[i]]) v[i] = -1;
-        r[i] = v[i] >= 0 ? rep[lab[v[i]] & 0x7fffffff] : -1;
-        if (r[i] == v[i]) v[i] = -1;
-    }
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) {
-        s[i] = sr[i] = 0, d[i] = 0, ok[i] = true;
-        if (v[i] < 0) continue;
-        s[i] = row_ptr[v[i]], sr[i] = row_ptr[r[i]];
-        d[i] = row_ptr[v[i] + 1] - s[i];
-        ok[i] = lab_prev[v[i]] == lab_prev[r[i]] && d[i] == row_ptr[r[i] + 1] - sr[i];
-    }
-    i32 a[WAVE_BATCH], b[WAVE_BATCH];
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) {
-        const bool in = v[i] >= 0 && ok[i] && lane < d[i];
-        a[i] = in ? nbr_sorted[s[i] + lane] : 0;
-        b[i] = in ? nbr_sorted[sr[i] + lane] : 0;
-    }
-    bool bad = false;
-#pragma unroll
-    for (int i = 0; i < WAVE_BATCH; ++i) {
-        if (v[i] < 0) continue;
-        bool good = ok[i] && a[i] == b[i];
-        if (good)
-            for (int k = lane + 64; k < d[i]; k += 64)
-                if (nbr_sorted[s[i] + k] != nbr_sorted[sr[i] + k]) { good = false; break; }
-        bad = bad || __builtin_amdgcn_ballot_w64(!good) != 0ull;
-        if (__builtin_amdgcn_ballot_w64(!good) != 0ull && lane == 0) atomicAdd(unresolved, 1u);
-    }
-    (void)bad;
+    if (w >= n_big) return;
+    const i32 v = big_nodes[w];
+    if (shared && !shared[v]) return;              // a singleton is its own representative (rep[] has no entry for it)
+    const i32 r = rep[lab[v] & 0x7fffffff];
+    if (r == v) return;
+    const i32 s = row_ptr[v], sr = row_ptr[r];
+    const int d = row_ptr[v + 1] - s;
+    bool ok = lab_prev[v] == lab_prev[r] && d == row_ptr[r + 1] - sr;
+    if (ok)
+        for (int k = lane; k < d; k += 64)
+            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull && lane == 0) atomicAdd(unresolved, 1u);
 }
 
 __global__ __launch_bounds__(BIG_THREADS) void wl_signature_big_kernel(
@@ -1345,7 +1277,7 @@ int gk_batch_ensure_levels(gk_batch* b, int n_levels) {
 static int launch_signature_big(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash_by_node, u64 seed, u64 mask) {
     const int wave = ctx->opt.wl_no_wave_sig ? 0 : 1;
     if (wave)
-        wl_signature_wave_kernel<<<grid_for(cdiv(b->n_big, WAVE_BATCH) * 64, 256), 256, 0, ctx->stream>>>(
+        wl_signature_wave_kernel<<<grid_for(b->n_big * 64, 256), 256, 0, ctx->stream>>>(
             b->big_nodes, b->n_big, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask);
     if (!wave || b->max_degree > WAVE_DEG_MAX)
         wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
@@ -1679,7 +1611,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V,
                                                                   flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr, big_apart);
         if (big_apart)
-            verify_big_kernel<<<grid_for(cdiv(b->n_big, WAVE_BATCH) * 64, 256), 256, 0, ctx->stream>>>(
+            verify_big_kernel<<<grid_for(b->n_big * 64, 256), 256, 0, ctx->stream>>>(
                 b->big_nodes, b->n_big, b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev,
                 flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr);
         GK_HIP_CHECK(hipGetLastError());
