@@ -19,7 +19,7 @@ rank; a direct all-gather at ~77 GB/s per link and direction takes tens of micro
 Why not the symmetric plan (multiply half, ship the mirrored blocks): the Gram kernel is bound by the float64
 STORE of K (3 TB/s measured, 17 % MFMA-busy), so the multiply-adds a rank would save are free, while the blocks
 it would receive instead arrive over xGMI at a small fraction of the rate at which it can produce them locally --
-``gram_plan`` puts numbers on both plans (config 5, 8 ranks: 0.8 ms plain against ~4.5 ms symmetric).  The
+``gram_plan`` puts numbers on both plans (config 5, 8 ranks: 1.1 ms plain against ~5.7 ms symmetric).  The
 symmetric plan stays available (``ShardedWL(symmetric=True)``) for a future MFMA-bound operand.
 
 ``ShardedSP`` is the same scheme for the ShortestPath kernel ("identical scheme; the ``_enum``
@@ -43,10 +43,12 @@ def shard_bounds(n_graphs, world_size):
     return b
 
 
-# measured on one MI355X (profiles/r03_*): float64 store rate of the Gram kernel, device-to-device transposed
-# placement (read + write), and the xGMI link rate per direction (MI355X_MICROARCH.md: 7 links x 153.6 GB/s
-# bidirectional, point to point -- a rank talking to p peers uses p links)
-GRAM_STORE_BPS = 3.0e12
+# measured on one MI355X: float64 store rate of the Gram kernel in ROW-BLOCK mode (a rank's rows x all columns: no tile is
+# shared with its mirror image, so the operand stream per output byte is twice the symmetric job's -- 320 GB in 143 ms on
+# config 6's 25 000 x 200 000 sub-blocks, profiles/r05_config6_1gpu.json; the symmetric whole-matrix job reaches 3.2-4.4 TB/s),
+# device-to-device transposed placement (read + write, profiles/r03_*), and the xGMI link rate per direction
+# (MI355X_MICROARCH.md: 7 links x 153.6 GB/s bidirectional, point to point -- a rank talking to p peers uses p links)
+GRAM_STORE_BPS = 2.2e12
 PLACE_BPS = 1.5e12
 XGMI_LINK_BPS = 76.8e9
 
