@@ -3,7 +3,7 @@
 import numpy as np
 from sklearn.utils.validation import check_is_fitted
 
-from .batch import GraphBatch, sp_batch_from_input, wl_batch_from_input
+from .batch import GraphBatch, _is_graph_object, iter_elements, sp_batch_from_input, wl_batch_from_input
 from .kernel import Kernel, NORM_NONE, NORM_NAN_TO_NUM
 from .shortest_path import ShortestPath
 from .vertex_histogram import EdgeHistogram, VertexHistogram, FittedFeatures, count_matrix, first_seen_columns
@@ -19,6 +19,15 @@ def _accelerated(base):
         return {"VertexHistogram": VertexHistogram, "ShortestPath": ShortestPath,
                 "EdgeHistogram": EdgeHistogram}.get(base.__name__, base)
     return base
+
+
+def _is_kernel_class(base):
+    """A base kernel class: one of ours, one of the reference's (`grakel.kernels.Kernel` subclasses: callers that only swapped
+    the WeisfeilerLehman import), or anything with the estimator methods the framework calls (weisfeiler_lehman.py:260-285,
+    :493, :519-541)."""
+    if type(base) is not type and not isinstance(base, type):
+        return False
+    return issubclass(base, Kernel) or all(callable(getattr(base, m, None)) for m in ("fit", "fit_transform", "transform", "diagonal"))
 
 
 class _LazyInvLabels(dict):
@@ -144,6 +153,7 @@ class WeisfeilerLehman(Kernel):
 
     _graph_format = "dictionary"
     _norm_mode = NORM_NAN_TO_NUM
+    _generic = False           # base kernel outside the accelerated set: relabel on the device, base kernels on the host
 
     def __init__(self, n_jobs=None, verbose=False, normalize=False, n_iter=5,
                  base_graph_kernel=VertexHistogram):
@@ -160,7 +170,7 @@ class WeisfeilerLehman(Kernel):
             base = self.base_graph_kernel
             if base is None:
                 base, params = VertexHistogram, dict()
-            elif type(base) is type and issubclass(_accelerated(base), Kernel):
+            elif _is_kernel_class(_accelerated(base)):
                 base, params = _accelerated(base), dict()
             else:
                 try:
@@ -169,7 +179,7 @@ class WeisfeilerLehman(Kernel):
                     raise TypeError('Base kernel was not formulated in the correct way. '
                                     'Check documentation.')
                 base = _accelerated(base)
-                if not (type(base) is type and issubclass(base, Kernel)):
+                if not _is_kernel_class(base):
                     raise TypeError('The first argument must be a valid grakel.kernel.kernel Object')
                 if type(params) is not dict:
                     raise ValueError('If the second argument of base kernel exists, it must be a '
@@ -182,10 +192,11 @@ class WeisfeilerLehman(Kernel):
                 self._sp_algorithm_type = probe.algorithm_type
             elif base is EdgeHistogram:
                 EdgeHistogram(**{k: v for k, v in params.items() if k != "normalize"}).initialize()
-            elif base is not VertexHistogram:
-                raise NotImplementedError(
-                    'grakel_amd accelerates WeisfeilerLehman with the VertexHistogram, ShortestPath and '
-                    'EdgeHistogram base kernels; other base kernels are outside the MI355X hot path')
+            # any OTHER base kernel (weisfeiler_lehman.py:77-109 accepts every grakel.Kernel; the reference's own regression
+            # test uses NeighborhoodSubgraphPairwiseDistance, grakel/tests/test_kernels.py:82-106): the relabelling runs on
+            # the MI355X, every level's relabelled graphs go back to the HOST base kernel exactly as the reference hands
+            # them over (`_generic_*` below).  The drop-in contract holds; only the relabel loop is accelerated.
+            self._generic = base not in (VertexHistogram, ShortestPath, EdgeHistogram)
             params["normalize"] = False
             params["verbose"] = self.verbose
             params["n_jobs"] = None
@@ -284,6 +295,95 @@ class WeisfeilerLehman(Kernel):
             self._all_inv_labels()
         return self._reference_labels[level]
 
+    # ---- any other base kernel (host side) -------------------------------------------------------------------------
+    _GENERIC_MSG = ('each element of X must be either a graph object or a list with at least a graph '
+                    'like object and node labels dict \n')
+
+    def _generic_elements(self, X, fitting):
+        """The validated elements as (graph object, label dict, extras) -- what weisfeiler_lehman.py:142-190 keeps per
+        graph (Gs_ed[j], L[j], extras[j]); the graph object itself is handed on (the base kernel parses it as it would
+        have parsed the reference's edge dictionary)."""
+        els = []
+        for x in iter_elements(X, lambda n: n >= 2, self._GENERIC_MSG, TypeError if fitting else ValueError):
+            if _is_graph_object(x):
+                if hasattr(x, "desired_format"):
+                    x.desired_format("dictionary")
+                els.append((x.get_edge_dictionary(), x.get_labels(purpose="dictionary"), tuple()))
+            else:
+                els.append((x[0], x[1], tuple(x[2:])))
+        return els
+
+    @staticmethod
+    def _generic_graphs(els, graph_ptr, ids):
+        gp = graph_ptr.tolist()
+        out = []
+        for j, (g, lab, extra) in enumerate(els):
+            out.append((g, dict(zip(lab.keys(), ids[gp[j]:gp[j + 1]].tolist()))) + extra)
+        return out
+
+    def _generic_fit(self, X, want_matrix):
+        """weisfeiler_lehman.py:212-290: WL levels by the device relabel (reference-identical label ids: `_inv_labels`),
+        one host base kernel per level fitted on the relabelled graphs; K = sum of their matrices."""
+        els = self._generic_elements(X, True)
+        self._fit_host([[g, lab] for g, lab, _ in els])
+        self._after_fit()
+        base, K = dict(), None
+        for l in range(self._n_iter):
+            graphs = self._generic_graphs(els, self._fit_batch.graph_ptr, self._level_reference_ids(l))
+            base[l] = self._base_graph_kernel(**self._params)
+            if want_matrix:
+                Kl = base[l].fit_transform(graphs)
+                K = Kl if K is None else K + Kl
+            else:
+                base[l].fit(graphs)
+        self.X = base
+        return K
+
+    def _generic_transform(self, X):
+        """weisfeiler_lehman.py:330-500: the targets are relabelled jointly with the fitted graphs on the device; a target
+        class that also occurs among the fitted graphs gets the fitted (reference-identical) id, every other class an id
+        above all fitted ones (the reference numbers those by sorted credential: any distinct ids give the same matrices)."""
+        els = self._generic_elements(X, False)
+        ybatch, _ = wl_batch_from_input([[g, lab] for g, lab, _ in els], self._label_map if self._label_map is not None else {})
+        self._ny = ybatch.n_graphs
+        eng = self._engine()
+        db = self._union_on_device(eng, ybatch)
+        eng.wl_relabel(db, self._n_iter - 1)
+        Vf = self._fit_batch.n_nodes
+        fresh = 1 + max(int(self._level_reference_ids(l).max()) for l in range(self._n_iter)) + int(ybatch.n_labels)
+        K = None
+        for l in range(self._n_iter):
+            if l == 0:
+                ids = ybatch.node_label.astype(np.int64)           # the fit's level-0 ids, unseen values above them
+            else:
+                dev = eng.wl_labels(db, l).astype(np.int64)
+                lut = np.full(int(dev.max()) + 1, -1, np.int64)
+                lut[dev[:Vf]] = self._level_reference_ids(l)
+                ids = lut[dev[Vf:]]
+                unseen = ids < 0
+                ids[unseen] = fresh + dev[Vf:][unseen]
+            Kl = self.X[l].transform(self._generic_graphs(els, ybatch.graph_ptr, ids))
+            K = Kl if K is None else K + Kl
+        db.close()
+        self._is_transformed = True
+        if self.normalize:
+            X_diag, Y_diag = self.diagonal()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                K = np.nan_to_num(np.divide(K, np.sqrt(np.outer(Y_diag, X_diag))))
+        return K
+
+    def _generic_diagonal(self):
+        """weisfeiler_lehman.py:502-555: the sum of the base kernels' diagonals."""
+        check_is_fitted(self, ['X'])
+        if getattr(self, "_is_transformed", False):
+            xs, ys = zip(*(self.X[i].diagonal() for i in range(self._n_iter)))
+            if not hasattr(self, "_X_diag"):
+                self._X_diag = np.sum(xs, axis=0)
+            return self._X_diag, np.sum(ys, axis=0)
+        if not hasattr(self, "_X_diag"):
+            self._X_diag = np.sum([self.X[i].diagonal() for i in range(self._n_iter)], axis=0)
+        return self._X_diag
+
     def fit(self, X, y=None):
         """kernel.py:86-121 with weisfeiler_lehman.py:117-290 as parse_input."""
         self._is_transformed = False
@@ -291,6 +391,9 @@ class WeisfeilerLehman(Kernel):
         self.initialize()
         if X is None:
             raise ValueError('`fit` input cannot be None')
+        if self._generic:
+            self._generic_fit(X, False)
+            return self
         X = list(X) if self._base_graph_kernel is EdgeHistogram and not isinstance(X, (list, tuple)) else X
         self._fit_host(X)
         self._after_fit()
@@ -305,6 +408,13 @@ class WeisfeilerLehman(Kernel):
         self.initialize()
         if X is None:
             raise ValueError('transform input cannot be None')
+        if self._generic:
+            K = self._generic_fit(X, True)
+            self._X_diag = np.diagonal(K).copy()
+            if self.normalize:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    K = np.nan_to_num(np.divide(K, np.sqrt(np.outer(self._X_diag, self._X_diag))))
+            return K
         X = list(X) if self._base_graph_kernel is EdgeHistogram and not isinstance(X, (list, tuple)) else X
         self._fit_host(X)
         self._after_fit()
@@ -331,6 +441,8 @@ class WeisfeilerLehman(Kernel):
         check_is_fitted(self, ['X', '_nx'])
         if X is None:
             raise ValueError('transform input cannot be None')
+        if self._generic:
+            return self._generic_transform(X)
         if self._base_graph_kernel is EdgeHistogram:
             X = list(X) if not isinstance(X, (list, tuple)) else X
             ybatch, _ = self._ingest(X, self._label_map if self._label_map is not None else {})     # WL's own input checks
@@ -402,6 +514,8 @@ class WeisfeilerLehman(Kernel):
 
     def diagonal(self):
         """weisfeiler_lehman.py:502-555."""
+        if getattr(self, "_generic", False):
+            return self._generic_diagonal()
         if getattr(self, "_base_graph_kernel", None) is EdgeHistogram:
             check_is_fitted(self, ['X'])
             if not hasattr(self, "_X_diag"):

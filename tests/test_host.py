@@ -507,8 +507,9 @@ def test_estimator_parameters_and_lazy_initialisation():
     weh = WeisfeilerLehman(base_graph_kernel=EdgeHistogram)
     weh.initialize()                                   # round 3: EdgeHistogram is an accelerated base kernel too
     assert weh._base_graph_kernel is EdgeHistogram
-    with pytest.raises(NotImplementedError):           # any other Kernel subclass is outside the hot path
-        WeisfeilerLehman(base_graph_kernel=WeisfeilerLehmanOptimalAssignment).initialize()
+    wany = WeisfeilerLehman(base_graph_kernel=WeisfeilerLehmanOptimalAssignment)
+    wany.initialize()                                  # round 5: any other kernel class: device relabel + host base kernels
+    assert wany._generic and wany._base_graph_kernel is WeisfeilerLehmanOptimalAssignment and not weh._generic
     with pytest.raises(ValueError):
         WeisfeilerLehman(base_graph_kernel=(ShortestPath, {"algorithm_type": "bfs"})).initialize()
     with pytest.raises(ValueError):
