@@ -1471,8 +1471,14 @@ def test_wl_with_shortest_path_base_against_reference_goldens(gk, mutag_graphs):
     assert np.array_equal(K, z["K_wlsp2"])
     with pytest.raises(ValueError):
         gk.WeisfeilerLehman(base_graph_kernel=(gk.ShortestPath, {"algorithm_type": "bfs"})).fit(G[:3])
-    with pytest.raises(NotImplementedError):               # base kernels outside the hot path (EdgeHistogram is inside: round 3)
-        gk.WeisfeilerLehman(base_graph_kernel=gk.WeisfeilerLehmanOptimalAssignment).fit(G[:3])
+    # round 5: any OTHER kernel class is a host base kernel over the device relabel (here: WL-OA under WL, on MUTAG's
+    # tuple-set graphs with global vertex ids): level l's matrix is that kernel on the oracle's level-l labels
+    ref = O.WLOracle(n_iter=1)
+    ref.fit_transform(G[:12], keep_levels=True)
+    want = sum(gk.WeisfeilerLehmanOptimalAssignment(n_iter=2).fit_transform([(g[0], ref.levels[l][j]) for j, g in enumerate(G[:12])])
+               for l in range(2))
+    woa = gk.WeisfeilerLehman(n_iter=1, base_graph_kernel=(gk.WeisfeilerLehmanOptimalAssignment, {"n_iter": 2}))
+    assert np.array_equal(woa.fit_transform(G[:12]), want)
 
 
 @pytest.mark.parametrize("name", ["dict_u", "adj_u", "adj_d", "tuples_d", "dense_big"])
