@@ -1185,12 +1185,17 @@ static int gram_build_pairs(gk_ctx* ctx, gk_feat* f) {
 // which kernel form launch_tiles takes for a job: 0 plain tile kernel, 1 gram_ws_kernel, 2 gram_dd_kernel
 static int tiles_kernel_form(gk_ctx* ctx, gk_feat* f, i64 M, i64 n_cols, int tri) {
     if (ctx->opt.gram_no_ws) return 0;
-    // the direct-store form wins while the job is a few tiles per CU (measured, fp4 operands: N = 2000 0.035 vs 0.050 ms,
+    // the direct-store form wins for small jobs (round 3, fp4 operands: N = 2000 0.035 vs 0.050 ms,
     // N = 4000 0.070 vs 0.079, N = 6000 0.132 vs 0.110; int8-only operands lose at 561 tiles: 0.170 vs 0.140);
     // option gram.dd: 0 = this rule, 1 = always, 2 = never
+    // Round 5 (tools/dev/dd_vs_ws.py): the rule was "up to 600 tiles"; with few K-steps per tile the direct-store form has no
+    // K loop to hide its stores under and loses as soon as a CU gets a second tile -- 528 tiles of 8 K-steps 0.083 vs 0.072 ms,
+    // the NCI1-like set (561 tiles, 8 K-steps, a ragged last tile row) 0.135 vs 0.065 ms; it still wins while every CU has at
+    // most ONE tile (136 tiles: 0.038 vs 0.054, 36 tiles: 0.028 vs 0.048)
     const i64 tiles_m = cdiv(M, GT_BM), tiles_n = cdiv(n_cols, GT_BM);
     const i64 real_tiles = tri ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
-    return (ctx->opt.gram_dd == 1 || (ctx->opt.gram_dd == 0 && f->phi_fp4 && real_tiles <= 600)) ? 2 : 1;
+    const i64 one_round = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    return (ctx->opt.gram_dd == 1 || (ctx->opt.gram_dd == 0 && f->phi_fp4 && real_tiles <= one_round)) ? 2 : 1;
 }
 
 static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* b, i64 M, i64 n_cols,
