@@ -820,6 +820,9 @@ __global__ void batch_check_kernel(const i32* __restrict__ graph_ptr, const i32*
                                    i32 n_labels0, u32* __restrict__ pres, u32* __restrict__ err) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 e = 0;
+    bool long_row = false;
+    i64 row0 = 0, row1 = 0;
+    i32 lo = 0, hi = 0;
     if (i < n_graphs) {
         const i64 a = graph_ptr[i], b = graph_ptr[i + 1];
         if (a < 0 || a > b || b > n_nodes || (i == 0 && a != 0) || (i == n_graphs - 1 && b != n_nodes)) e |= 1u;
@@ -832,11 +835,31 @@ __global__ void batch_check_kernel(const i32* __restrict__ graph_ptr, const i32*
         else if (pres && !pres[l]) pres[l] = 1u;          // same value from every writer
         if (!(e & 2u)) {
             const i32 g = node_graph[i];
-            const i32 lo = graph_ptr[g], hi = graph_ptr[g + 1];
-            for (i64 k = r0; k < r1; ++k) {
+            lo = graph_ptr[g], hi = graph_ptr[g + 1];
+            if (r1 - r0 <= 64) {
+                for (i64 k = r0; k < r1; ++k) {
+                    const i32 c = col_idx[k];
+                    if (c < lo || c >= hi) { e |= 8u; break; }
+                }
+            } else long_row = true, row0 = r0, row1 = r1;
+        }
+    }
+    // rows of more than 64 entries (hubs, ego networks): the wave walks them together, 64 entries per step -- a thread per
+    // vertex made a 2 500-neighbour hub one thread's loop and the whole check 0.3 ms on the REDDIT- / COLLAB-like sets
+    {
+        const int lane = threadIdx.x & 63;
+        u64 todo = __ballot(long_row);
+        while (todo) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const i64 a = __shfl(row0, src, 64), b = __shfl(row1, src, 64);
+            const i32 glo = __shfl(lo, src, 64), ghi = __shfl(hi, src, 64);
+            bool bad = false;
+            for (i64 k = a + lane; k < b; k += 64) {
                 const i32 c = col_idx[k];
-                if (c < lo || c >= hi) { e |= 8u; break; }
+                bad = bad || c < glo || c >= ghi;
             }
+            if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == src) e |= 8u;
         }
     }
     if (e) atomicOr(err, e);
