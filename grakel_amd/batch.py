@@ -619,6 +619,25 @@ def _sp_graph_arrays(gobj, labels, with_labels):
 def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_iterable=TypeError):
     if isinstance(X, GraphBatch):
         return X, None
+    if _gk_ingest is not None and with_labels and type(X) in (list, tuple) and len(X):
+        # round 5: unit-weight graphs whose vertex set IS the label keys in their (sorted) order -- dict of neighbour lists over
+        # 0 .. n-1, `(u, v)`-tuple sets / lists / dicts (the fetch_dataset form), 0/1 adjacency matrices -- take the threaded
+        # walks of the WL ingestion (csrc/ingest.c, sp_mode); None: weights, unlabelled or unsorted vertices, ... -> below
+        try:
+            r = _gk_ingest.wl_ingest(X, 2, False, 0 if len_ok is not None else 3, int(INGEST_THREADS), 1)
+        except TypeError:                      # an older build of the module without the sp_mode argument
+            r = None
+        if r is not None:
+            sizes, row_ptr, col, values = r
+            ids, mapping = compress_labels(values, fitted_labels)
+            n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
+            sizes = np.frombuffer(sizes, dtype=np.int32)
+            graph_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+            np.cumsum(sizes, out=graph_ptr[1:])
+            col = np.frombuffer(col, dtype=np.int32)
+            fd = np.fromiter((0 if (hasattr(x[0], "shape") or type(x[0]) is bytes) else 1 for x in X), np.uint8, len(X))
+            return GraphBatch(graph_ptr, np.frombuffer(row_ptr, dtype=np.int32), col, ids, max(n_labels, 1),
+                              edge_weight=np.ones(col.shape[0], np.int32), from_dict=fd), mapping
     if _gk_ingest is not None and len_ok is None and type(X) in (list, tuple) and hasattr(_gk_ingest, "sp_ingest"):
         # adjacency arrays / int-keyed edge dictionaries with integer weights: the same walk in C
         # (csrc/ingest.c); None = not recognised, the Python path below takes the whole input

@@ -196,6 +196,8 @@ typedef struct {
     int32_t *out_rowp, *out_col;
     int64_t* out_lab;
     const void* aux;                /* MATRIX form: the acquired buffer views */
+    int sp_mode;                    /* the batch must also be ShortestPath's (sp_batch_from_input): vertices = ALL vertices of the graph in
+                                     * sorted symbol order = the label keys in their order, unit weights */
 } par_job;
 
 static int par_grow(par_job* j, size_t need_deg, size_t need_col) {
@@ -414,9 +416,12 @@ static void* par_walk_pairs(void* arg) {
         {
             Py_ssize_t it = 0, i = 0;
             PyObject *k, *lv;
+            long long prev_key = -1;
             while (PyDict_Next(labels, &it, &k, &lv)) {
                 long long kv, iv;
                 if (!GK_SMALL_INT(k, kv) || !GK_SMALL_INT(lv, iv)) goto out;
+                if (j->sp_mode && kv <= prev_key) goto out;            /* ShortestPath numbers the vertices by sorted symbol */
+                prev_key = kv;
                 if (ps_insert(&s, mask, (int64_t)kv, (int32_t)i)) goto out;
                 j->lab[j->n_deg + (size_t)i] = (int64_t)iv;
                 ++i;
@@ -433,18 +438,30 @@ static void* par_walk_pairs(void* arg) {
                 else if (g_dict) {
                     if (!PyDict_Next(g, &it, &t, &w)) break;
                     if (!PyFloat_CheckExact(w) && !PyLong_CheckExact(w)) goto out;          /* {(u, v): weight}: numbers only */
+                    if (j->sp_mode && !(PyFloat_CheckExact(w) ? PyFloat_AS_DOUBLE(w) == 1.0 : (Py_SIZE(w) == 1 && ((PyLongObject*)w)->ob_digit[0] == 1)))
+                        goto out;                                                           /* weighted: sp_ingest / the Python path */
                 } else { if (q >= ne) break; t = PySequence_Fast_GET_ITEM(g, q++); }
                 long long a, b;
                 if (!PyTuple_CheckExact(t) || PyTuple_GET_SIZE(t) != 2) goto out;
                 if (!GK_SMALL_INT(PyTuple_GET_ITEM(t, 0), a) || !GK_SMALL_INT(PyTuple_GET_ITEM(t, 1), b)) goto out;
                 const int32_t ia = ps_find(&s, mask, (int64_t)a);
-                if (ia < 0) continue;                                  /* the source has no label: never visited (batch.py) */
+                if (ia < 0) {
+                    if (j->sp_mode) goto out;                          /* a vertex without a label: ShortestPath's KeyError */
+                    continue;                                          /* the source has no label: never visited (batch.py) */
+                }
                 const int32_t ib = ps_find(&s, mask, (int64_t)b);
                 if (ib < 0) goto out;                                  /* unlabelled neighbour: the reference's KeyError */
                 if (ps_edge(&s, ia, ib)) goto out;
             }
         }
         if (ps_rows(j, &s, n)) goto out;
+        if (j->sp_mode) {          /* every labelled vertex must BE a vertex of the graph (an endpoint of some edge) */
+            int32_t* touched = s.cnt;                                  /* n + 1 words, free again after ps_rows */
+            memset(touched, 0, (size_t)n * 4);
+            for (size_t q = 0; q < s.n_e; ++q) touched[s.src[q]] = 1, touched[s.dst[q]] = 1;
+            for (Py_ssize_t i = 0; i < n; ++i)
+                if (!touched[i]) goto out;
+        }
         j->n_deg += (size_t)n;
         j->sizes[e - j->e0] = (int32_t)n;
     }
@@ -456,6 +473,15 @@ out:
 
 /* MATRIX form: the buffers were acquired by the calling thread (PyObject_GetBuffer touches reference counts) */
 typedef struct { const char* p; Py_ssize_t n, itemsize; char kind; } mat_view;     /* kind: 'i' signed, 'u' unsigned, 'f' float, 'b' bool */
+static inline double mat_value(const mat_view* m, const char* q) {
+    switch (m->kind) {
+    case 'f': return m->itemsize == 8 ? *(const double*)q : (double)*(const float*)q;
+    case 'i': return m->itemsize == 8 ? (double)*(const int64_t*)q : m->itemsize == 4 ? (double)*(const int32_t*)q
+                   : m->itemsize == 2 ? (double)*(const int16_t*)q : (double)*(const int8_t*)q;
+    default:  return m->itemsize == 8 ? (double)*(const uint64_t*)q : m->itemsize == 4 ? (double)*(const uint32_t*)q
+                   : m->itemsize == 2 ? (double)*(const uint16_t*)q : (double)*(const uint8_t*)q;
+    }
+}
 static inline int mat_positive(const mat_view* m, const char* q) {
     switch (m->kind) {
     case 'f': return m->itemsize == 8 ? *(const double*)q > 0.0 : *(const float*)q > 0.0f;
@@ -489,8 +515,15 @@ static void* par_walk_matrix(void* arg) {
             int32_t* row = j->col + j->n_col;
             const char* q = m->p + (size_t)r * (size_t)n * (size_t)m->itemsize;
             size_t cnt = 0;
-            for (Py_ssize_t c = 0; c < n; ++c, q += m->itemsize)
-                if (mat_positive(m, q)) row[cnt++] = (int32_t)c;
+            if (j->sp_mode) {                      /* ShortestPath: any non-zero entry is an edge WITH that weight: units only here */
+                for (Py_ssize_t c = 0; c < n; ++c, q += m->itemsize) {
+                    const double v = mat_value(m, q);
+                    if (v == 1.0) row[cnt++] = (int32_t)c;
+                    else if (v != 0.0) return NULL;
+                }
+            } else
+                for (Py_ssize_t c = 0; c < n; ++c, q += m->itemsize)
+                    if (mat_positive(m, q)) row[cnt++] = (int32_t)c;
             j->n_col += cnt;
             j->deg[j->n_deg + (size_t)r] = (int32_t)cnt;
         }
@@ -503,7 +536,7 @@ static void* par_walk_matrix(void* arg) {
 
 /* NULL without an error set: not taken (the caller walks the input itself) */
 /* form: 0 = dict of neighbour lists under identity numbering (par_walk), 1 = PAIRS, 2 = MATRIX (aux = the buffer views) */
-static PyObject* wl_ingest_threads(PyObject* X, Py_ssize_t min_len, Py_ssize_t max_len, int n_threads, int form, const void* aux) {
+static PyObject* wl_ingest_threads(PyObject* X, Py_ssize_t min_len, Py_ssize_t max_len, int n_threads, int form, const void* aux, int sp_mode) {
     const Py_ssize_t n_el = PySequence_Fast_GET_SIZE(X);
     if (n_threads <= 0) {
         long c = sysconf(_SC_NPROCESSORS_ONLN);
@@ -512,8 +545,8 @@ static PyObject* wl_ingest_threads(PyObject* X, Py_ssize_t min_len, Py_ssize_t m
     if (n_threads > GK_PAR_MAX_THREADS) n_threads = GK_PAR_MAX_THREADS;
     if ((Py_ssize_t)n_threads > n_el / 64) n_threads = (int)(n_el / 64);
     if (n_threads < 2) {
-        if (form == 0) return NULL;          /* the one-thread walk of wl_ingest knows this form (and more) */
-        n_threads = 1;                       /* the new forms: this walk on the calling thread */
+        if (form == 0 && !sp_mode) return NULL;      /* the one-thread walk of wl_ingest knows this form (and more) */
+        n_threads = 1;                               /* the new forms / ShortestPath: this walk on the calling thread */
     }
     void* (*walk)(void*) = form == 1 ? par_walk_pairs : (form == 2 ? par_walk_matrix : par_walk);
     par_job jobs[GK_PAR_MAX_THREADS];
@@ -523,7 +556,7 @@ static PyObject* wl_ingest_threads(PyObject* X, Py_ssize_t min_len, Py_ssize_t m
     int ok = 1;
     for (int t = 0; t < n_threads; ++t) {
         par_job* j = &jobs[t];
-        j->X = X, j->min_len = min_len, j->max_len = max_len, j->aux = aux;
+        j->X = X, j->min_len = min_len, j->max_len = max_len, j->aux = aux, j->sp_mode = sp_mode;
         j->e0 = n_el * t / n_threads, j->e1 = n_el * (t + 1) / n_threads;
         j->sizes = (int32_t*)malloc((size_t)(j->e1 - j->e0 + 1) * 4);
         if (!j->sizes) { ok = 0; break; }
@@ -577,8 +610,8 @@ static PyObject* wl_ingest_threads(PyObject* X, Py_ssize_t min_len, Py_ssize_t m
 static PyObject* wl_ingest(PyObject* self, PyObject* args) {
     PyObject* X;
     Py_ssize_t min_len = 2, max_len = 0;
-    int want_mask = 0, n_threads = 0;
-    if (!PyArg_ParseTuple(args, "O|npni", &X, &min_len, &want_mask, &max_len, &n_threads)) return NULL;
+    int want_mask = 0, n_threads = 0, sp_mode = 0;
+    if (!PyArg_ParseTuple(args, "O|npnii", &X, &min_len, &want_mask, &max_len, &n_threads, &sp_mode)) return NULL;
     if (!PyList_CheckExact(X) && !PyTuple_CheckExact(X)) Py_RETURN_NONE;
     const Py_ssize_t n_el = PySequence_Fast_GET_SIZE(X);
     if (n_el == 0) Py_RETURN_NONE;
@@ -599,11 +632,13 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
             if ((PyList_CheckExact(g0) || PyTuple_CheckExact(g0)) && PySequence_Fast_GET_SIZE(g0) > 0 &&
                 !PyTuple_CheckExact(PySequence_Fast_GET_ITEM(g0, 0))) form = -1;
         } else if (g0 && PyObject_CheckBuffer(g0)) form = 2;
-        if (form == 0 && n_threads != 1 && n_el >= GK_PAR_MIN_ELEMENTS) {
-            PyObject* r = wl_ingest_threads(X, min_len, max_len, n_threads, 0, NULL);
+        if (sp_mode && form < 0) Py_RETURN_NONE;
+        if (form == 0 && (sp_mode || (n_threads != 1 && n_el >= GK_PAR_MIN_ELEMENTS))) {
+            PyObject* r = wl_ingest_threads(X, min_len, max_len, n_threads, 0, NULL, sp_mode);
             if (r) return r;
+            if (sp_mode) Py_RETURN_NONE;     /* not ShortestPath's vertex set / weights: sp_ingest or the Python path */
         } else if (form == 1) {
-            PyObject* r = wl_ingest_threads(X, min_len, max_len, n_threads, 1, NULL);
+            PyObject* r = wl_ingest_threads(X, min_len, max_len, n_threads, 1, NULL, sp_mode);
             if (r) return r;
             Py_RETURN_NONE;                  /* not the plain form after all: batch.py's Python path */
         } else if (form == 2) {
@@ -635,7 +670,7 @@ static PyObject* wl_ingest(PyObject* self, PyObject* args) {
                     (kind == 'f' && b->itemsize < 4)) { ++got; good = 0; break; }
                 views[got].p = (const char*)b->buf, views[got].n = b->shape[0], views[got].itemsize = b->itemsize, views[got].kind = kind;
             }
-            PyObject* r = good ? wl_ingest_threads(X, min_len, max_len, n_threads, 2, views) : NULL;
+            PyObject* r = good ? wl_ingest_threads(X, min_len, max_len, n_threads, 2, views, sp_mode) : NULL;
             for (Py_ssize_t q = 0; q < got; ++q)
                 if (bufs && bufs[q].obj) PyBuffer_Release(&bufs[q]);
             free(views); free(bufs);

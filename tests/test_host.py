@@ -307,10 +307,32 @@ def test_c_sp_ingestion_fast_path_equals_the_python_path():
         "extras": [(A, lab6, {}), (A * 2, lab6)],
         "too_long": [(A, lab6, {}, "x")],
         "mixed": nci1_like(5, 1, as_adj=True) + nci1_like(5, 2, as_adj=False),
+        # round 5: the threaded walks of the WL ingestion take unit-weight inputs whose vertex set is the label keys in sorted
+        # order (csrc/ingest.c sp_mode); everything else must still end where it ended before
+        "tuple_sets_global_ids": [[{(10, 11), (11, 10), (11, 12), (12, 11)}, {10: 'a', 11: 'b', 12: 'a'}],
+                                  [[(20, 21), (21, 20)], {20: 1, 21: 1}, {(20, 21): 0}]],
+        "tuple_set_int_labels": [[{(10, 11), (11, 10), (11, 12), (12, 11)}, {10: 3, 11: 4, 12: 3}]] * 3,
+        "tuple_set_unsorted_label_keys": [[{(10, 11), (11, 10)}, {11: 3, 10: 4}]],
+        "tuple_set_labelled_vertex_without_edge": [[{(10, 11), (11, 10)}, {10: 3, 11: 4, 12: 5}]],
+        "tuple_set_unlabelled_source": [[{(10, 11), (11, 10), (12, 10)}, {10: 3, 11: 4}]],
+        "tuple_dict_unit_weights": [[{(1, 2): 1, (2, 1): 1.0}, {1: 0, 2: 1}]],
+        "tuple_dict_weights": [[{(1, 2): 2, (2, 1): 2}, {1: 0, 2: 1}]],
+        "er_dict_of_lists_with_isolated_vertices": er_dataset(30, 12, 0.15, 3, 4),
+        "matrix_01_int_labels": [[A, {i: i % 2 for i in range(6)}], [A.astype(np.uint8), {i: 1 for i in range(6)}]],
     }
     for name, X in cases.items():
         fast, slow = both(X)
         assert fast == slow, name
+    saved_threads = B.INGEST_THREADS
+    try:
+        for B.INGEST_THREADS in (1, 3):
+            for name in ("tuple_set_int_labels", "er_dict_of_lists_with_isolated_vertices", "matrix_01_int_labels", "nci1_dicts"):
+                fast, slow = both(cases[name] * 40)
+                assert fast == slow and fast[0] == "ok", name
+    finally:
+        B.INGEST_THREADS = saved_threads
+    assert B._gk_ingest.wl_ingest(cases["tuple_set_int_labels"], 2, False, 3, 0, 1) is not None       # taken by the threaded walk
+    assert B._gk_ingest.wl_ingest(cases["tuple_set_unsorted_label_keys"], 2, False, 3, 0, 1) is None
     for name in ("nci1_adjacency", "nci1_dicts", "missing_label_matrix", "empty_labels"):
         X = [[x[0]] for x in cases[name]]                     # unlabelled: one-element inputs are fine
         assert both(X, False)[0] == both(X, False)[1], name
