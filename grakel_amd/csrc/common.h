@@ -88,7 +88,6 @@ struct gk_opts {
     int gram_no_split8 = 0;      // counts above 127: 1 = float64 side operand (gram_f64_kernel) instead of split int8 columns
     int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
     int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
-    int wl_no_graph_sig = 0;     // 1: the wave-per-vertex signatures always through the vertex list (labels gathered from L2), never graph by graph with the labels in LDS
     int wl_no_wave_sig = 0;      // 1: nodes of degree 33..1024 keep the workgroup signature kernel and the one-thread verifier (rounds 1-4) instead of the wave-per-node kernels
     int tt_no_fused = 0;         // look-up transform: the target classes matched level by level (two launches per level) even for a handful of targets
     int gram_no_avx2 = 0;        // 1: the widening threads keep to SSE2 (what a CPU without AVX2 runs)

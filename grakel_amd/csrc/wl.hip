@@ -217,68 +217,6 @@ __global__ __launch_bounds__(256) void wl_signature_wave_kernel(
     if (lane == 0) hash[v] = mix64(sig_head((u32)lab_prev[v], (u32)d, seed) + part) & mask;
 }
 
-// The same work graph by graph (round 5, second half): a workgroup stages ITS GRAPH's previous labels and row offsets in LDS,
-// its four waves then take the graph's vertices of degree_small < d <= WAVE_DEG_MAX in turn -- the neighbour labels come
-// out of LDS instead of one L2 request per neighbour (the list-based kernel above is bound by those: 21.5 M uncoalesced
-// 4-byte gathers per level on the COLLAB-like set = 195 us, a third of the L2s' request rate); what is left is the coalesced
-// stream over col_idx and the write of the sorted lists.  Graphs of up to GS_MAX_NODES vertices (64 KiB of LDS).
-#define GS_MAX_NODES 8190
-template <int R>
-__device__ __forceinline__ u64 wave_node_signature_lds(const i32* __restrict__ col_idx, const i32* glab, i32 v0,
-                                                       i32* __restrict__ nbr_sorted, i32 e0, int d, int lane, u64 seed) {
-    i32 x[R];
-    u64 part = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = r * 64 + lane;
-        x[r] = 0x7fffffff;
-        if (i < d) {
-            x[r] = glab[col_idx[e0 + i] - v0];
-            part += sig_elem((u32)x[r], seed);
-        }
-    }
-    wave_bitonic_sort<R>(x, lane);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = r * 64 + lane;
-        if (i < d) nbr_sorted[e0 + i] = x[r];
-    }
-    return part;
-}
-
-__global__ __launch_bounds__(256) void wl_signature_graph_kernel(
-    const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
-    const i32* __restrict__ lab_prev, i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask, int deg_small) {
-    extern __shared__ __attribute__((aligned(16))) i32 gs_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const i32 v0 = graph_ptr[blockIdx.x];
-    const int n = graph_ptr[blockIdx.x + 1] - v0;
-    i32* glab = gs_lds;                 // [n]
-    i32* grow = gs_lds + n;             // [n + 1] absolute row offsets
-    bool any = false;
-    for (int i = tid; i <= n; i += 256) {
-        const i32 r = row_ptr[v0 + i];
-        grow[i] = r;
-        if (i < n) glab[i] = lab_prev[v0 + i];
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) any = any || grow[i + 1] - grow[i] > deg_small;
-    if (!__syncthreads_or(any)) return;              // a graph without such a vertex
-    for (int i = w; i < n; i += 4) {                 // wave-uniform loop
-        const i32 e0 = grow[i];
-        const int d = grow[i + 1] - e0;
-        if (d <= deg_small || d > WAVE_DEG_MAX) continue;
-        u64 part;
-        if (d <= 64) part = wave_node_signature_lds<1>(col_idx, glab, v0, nbr_sorted, e0, d, lane, seed);
-        else if (d <= 128) part = wave_node_signature_lds<2>(col_idx, glab, v0, nbr_sorted, e0, d, lane, seed);
-        else if (d <= 256) part = wave_node_signature_lds<4>(col_idx, glab, v0, nbr_sorted, e0, d, lane, seed);
-        else if (d <= 512) part = wave_node_signature_lds<8>(col_idx, glab, v0, nbr_sorted, e0, d, lane, seed);
-        else part = wave_node_signature_lds<16>(col_idx, glab, v0, nbr_sorted, e0, d, lane, seed);
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-        if (lane == 0) hash[v0 + i] = mix64(sig_head((u32)glab[i], (u32)d, seed) + part) & mask;
-    }
-}
-
 // the verifier's half for the same nodes: a wave compares the node's sorted list with its class representative's,
 // 64 entries per step (verify_kernel walks a list with ONE thread: 200 us per level on the COLLAB-like batch)
 __global__ __launch_bounds__(256) void verify_big_kernel(const i32* __restrict__ big_nodes, i64 n_big, const i32* __restrict__ row_ptr,
@@ -1361,15 +1299,7 @@ int gk_batch_ensure_levels(gk_batch* b, int n_levels) {
 // option wl.no_wave_sig keeps everything in the workgroup kernel (rounds 1-4)
 static int launch_signature_big(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash_by_node, u64 seed, u64 mask) {
     const int wave = ctx->opt.wl_no_wave_sig ? 0 : 1;
-    // graph by graph with the labels in LDS when most of the batch is such vertices (a few hubs in a sea of small degrees are
-    // cheaper through the list: a workgroup per graph would stage every graph for nothing)
-    const bool by_graph = wave && !ctx->opt.wl_no_graph_sig && b->max_graph_nodes <= GS_MAX_NODES && b->n_big * 8 >= b->n_nodes;
-    if (by_graph) {
-        const int lds = (2 * b->max_graph_nodes + 2) * 4;
-        GK_TRY(gk_func_lds(ctx, (const void*)wl_signature_graph_kernel, lds));
-        wl_signature_graph_kernel<<<dim3((unsigned)b->n_graphs), 256, lds, ctx->stream>>>(
-            b->graph_ptr, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask, b->deg_small);
-    } else if (wave)
+    if (wave)
         wl_signature_wave_kernel<<<grid_for(b->n_big * 64, 256), 256, 0, ctx->stream>>>(
             b->big_nodes, b->n_big, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask);
     if (!wave || b->max_degree > WAVE_DEG_MAX)

@@ -74,8 +74,6 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             route of wl.hip, which all the other "wl.*" switches select within)
  *             "wl.no_wave_sig" (vertices of degree 33..1024 by the workgroup-per-vertex signature kernel and the
  *             thread-per-vertex verifier of rounds 1-4 instead of the wave-per-vertex kernels)
- *             "wl.no_graph_sig" (those wave-per-vertex signatures always through the vertex list, labels gathered from L2,
- *             never graph by graph with the graph's labels staged in LDS)
  *             "transform.no_fused" (look-up transform: the target classes matched by two launches per level even when the
  *             targets are few enough for the single-workgroup all-levels kernel)
  *             "sort.buckets" (1 never / 2 always the per-bucket finish of the sort)

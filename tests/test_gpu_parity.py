@@ -1980,15 +1980,14 @@ def test_transform_of_a_generator_above_the_lookup_threshold(gk):
     assert np.array_equal(est.transform(x for x in X[40:]), Kt)
 
 
-@pytest.mark.parametrize("no_wave,no_graph", [(0, 0), (0, 1), (1, 0)], ids=["by_graph", "by_vertex_list", "workgroup_kernel"])
-def test_dense_graphs_and_hubs_through_the_wave_signature_kernels(gk, gkopt, no_wave, no_graph):
+@pytest.mark.parametrize("no_wave", [0, 1])
+def test_dense_graphs_and_hubs_through_the_wave_signature_kernels(gk, gkopt, no_wave):
     """Graphs whose vertices have 33..1024 neighbours (near-cliques, ego networks: the COLLAB kind) take the wave-per-node
     signature and verification kernels (round 5), hubs beyond 1024 the workgroup kernel; option wl.no_wave_sig = 1 keeps the
     rounds 1-4 kernels.  Partitions, matrix and transform against the oracle either way."""
     from grakel_amd.batch import wl_batch_from_input
     from grakel_amd.engine import get_engine
     gkopt("wl.no_wave_sig", no_wave)
-    gkopt("wl.no_graph_sig", no_graph)       # 0: graph by graph, the graph's labels staged in LDS; 1: through the vertex list
     rs = np.random.RandomState(3)
     X = random_labelled_graphs(12, 60, 90, 0.7, 3, 17, fmt="dict")                  # degree ~ 50
     X += random_labelled_graphs(3, 150, 160, 0.9, 2, 18, fmt="dict")                # degree ~ 140 (R = 4)
