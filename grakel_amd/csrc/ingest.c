@@ -182,7 +182,8 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
 #include <pthread.h>
 #include <unistd.h>
 #define GK_PAR_MIN_ELEMENTS 256
-#define GK_PAR_MAX_THREADS 16
+#define GK_PAR_MAX_THREADS 64          /* an explicit n_threads may go this far */
+#define GK_PAR_DEFAULT_THREADS 16      /* n_threads = 0: one per host core, at most this many (measured: tools/dev/ingest_scaling.py) */
 typedef struct {
     PyObject* X;
     Py_ssize_t e0, e1, min_len, max_len;
@@ -541,6 +542,7 @@ static PyObject* wl_ingest_threads(PyObject* X, Py_ssize_t min_len, Py_ssize_t m
     if (n_threads <= 0) {
         long c = sysconf(_SC_NPROCESSORS_ONLN);
         n_threads = c > 0 ? (int)c : 1;
+        if (n_threads > GK_PAR_DEFAULT_THREADS) n_threads = GK_PAR_DEFAULT_THREADS;
     }
     if (n_threads > GK_PAR_MAX_THREADS) n_threads = GK_PAR_MAX_THREADS;
     if ((Py_ssize_t)n_threads > n_el / 64) n_threads = (int)(n_el / 64);
