@@ -27,7 +27,7 @@ except ImportError:                    # not built: the Python path below does e
     _gk_ingest = None
 
 # host threads of the C walk over `[{u: [v, ...]}, {u: label}]` elements (csrc/ingest.c: wl_ingest_threads):
-# 0 = one per host core (at most 16), 1 = the calling thread only.  The result does not depend on it.
+# 0 = one per host core (at most 32; 64 for the tuple-set form), 1 = the calling thread only.  The result does not depend on it.
 INGEST_THREADS = 0
 
 

@@ -12,7 +12,7 @@
  * paths produce identical batches.
  *
  *   wl_ingest(X: list, min_len: int, want_mask=False, max_len=0, n_threads=0) -> None | (sizes, row_ptr, col_idx, values[, mask])
- *       n_threads: 0 = as many as the host has (at most 16), 1 = the calling thread only
+ *       n_threads: 0 = as many as the host has (at most 32; 64 for the tuple-set form), 1 = the calling thread only
  *       sizes   bytearray of int32[n_graphs]     nodes per graph (= labelled vertices)
  *       row_ptr bytearray of int32[V + 1]
  *       col_idx bytearray of int32[E]            GLOBAL node ids, ascending and unique per row
@@ -183,7 +183,11 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
 #include <unistd.h>
 #define GK_PAR_MIN_ELEMENTS 256
 #define GK_PAR_MAX_THREADS 64          /* an explicit n_threads may go this far */
-#define GK_PAR_DEFAULT_THREADS 16      /* n_threads = 0: one per host core, at most this many (measured: tools/dev/ingest_scaling.py) */
+#define GK_PAR_DEFAULT_THREADS 32      /* n_threads = 0: one per host core, at most this many -- measured on the 256-thread box
+                                        * (tools/dev/ingest_scaling.py, 10 000 graphs of 100 vertices): dict of lists 40 / 7.5 / 4.1 / 3.1 / 3.8 ms
+                                        * on 1 / 8 / 16 / 32 / 64 threads, adjacency matrices 113 / 18 / 11 / 7.8 / 8.8 ms; the tuple-set walk
+                                        * is memory-latency bound (a tuple and two int objects per edge) and keeps scaling: 440 / 93 / 47 /
+                                        * 25 / 15 ms -- it takes up to 64 */
 typedef struct {
     PyObject* X;
     Py_ssize_t e0, e1, min_len, max_len;
@@ -542,7 +546,7 @@ static PyObject* wl_ingest_threads(PyObject* X, Py_ssize_t min_len, Py_ssize_t m
     if (n_threads <= 0) {
         long c = sysconf(_SC_NPROCESSORS_ONLN);
         n_threads = c > 0 ? (int)c : 1;
-        if (n_threads > GK_PAR_DEFAULT_THREADS) n_threads = GK_PAR_DEFAULT_THREADS;
+        if (n_threads > (form == 1 ? GK_PAR_MAX_THREADS : GK_PAR_DEFAULT_THREADS)) n_threads = form == 1 ? GK_PAR_MAX_THREADS : GK_PAR_DEFAULT_THREADS;
     }
     if (n_threads > GK_PAR_MAX_THREADS) n_threads = GK_PAR_MAX_THREADS;
     if ((Py_ssize_t)n_threads > n_el / 64) n_threads = (int)(n_el / 64);
