@@ -350,7 +350,7 @@ def python_objects(eng, wl, Ku, reps=3):
             "normalised_ms_per_call": dt_objn * 1e3, "calls_ms": [round(c, 3) for c in calls],
             "normalised_calls_ms": [round(c, 3) for c in calls_n],
             "of_which_host_ingestion_ms": dt_ingest * 1e3, "host_ingestion_one_thread_ms": dt_ingest_1 * 1e3,
-            "host_ingestion_threads": min(32, os.cpu_count() or 1),
+            "host_ingestion_threads": "min(32, host CPUs, the container's cgroup CPU quota)",
             "same_matrix": bool(np.array_equal(Ku, Kobj)),
             "note": "grakel_amd.WeisfeilerLehman(n_iter=%d).fit_transform on %d dict graphs" % (h, N)}
 

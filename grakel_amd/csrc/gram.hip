@@ -39,6 +39,8 @@
 #include <thread>
 #include <vector>
 #include <immintrin.h>
+#include <sched.h>
+#include <stdio.h>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -1601,6 +1603,7 @@ __global__ void gram_narrow_kernel(const double* __restrict__ K, i64 n, T* __res
     }
 }
 
+static int host_cpu_budget();
 template <typename T>
 static void widen_slice(const T* __restrict__ src, double* __restrict__ dst, size_t n) {
     size_t i = 0;
@@ -1626,7 +1629,7 @@ static int gram_copy_out_narrow(gk_ctx* ctx, const double* K_dev, i64 n_entries,
     GK_HIP_CHECK(hipGetLastError());
     const size_t per_chunk = GC_CHUNK / sizeof(T);
     const int n_chunks = (int)cdiv(n_entries, (i64)per_chunk);
-    int n_thr = ctx->opt.gram_copy_threads > 0 ? ctx->opt.gram_copy_threads : (int)std::thread::hardware_concurrency();
+    int n_thr = ctx->opt.gram_copy_threads > 0 ? ctx->opt.gram_copy_threads : host_cpu_budget();
     if (ctx->opt.gram_copy_threads <= 0 && n_thr > 16) n_thr = 16;      // measured: 8 threads keep up with the bus, 48 are slower
     if (n_thr < 1) n_thr = 1;
     std::atomic<int> ready(0), stop(0);
@@ -1714,6 +1717,38 @@ __global__ __launch_bounds__(256) void gram_pack_tri_kernel(const double* __rest
 // written in 2.7 ms), so: AVX2 rows (4 entries per convert, 32-byte non-temporal stores) when the CPU has it, the mirrored
 // block through eight column buffers (every staging cache line read once per eight columns), blocks handed out one by one
 // from an atomic counter (a diagonal block costs half a mirrored one), and a thread pool that outlives the call.
+// How many host threads may run at once: the hardware threads, the affinity mask, and -- what matters on a shared box -- the
+// CPU quota of the container's cgroup (cpu.max: "1600000 100000" = 16 CPUs on the MI355X boxes of this project, which show
+// 256 hardware threads).  More runnable threads than the quota do not go faster, they get the whole cgroup THROTTLED for the
+// rest of the 100 ms period: with 32 widening threads one call in twenty took 30-36 ms instead of 5 (round 5,
+// profiles/r05_cpu_quota.txt).
+static int host_cpu_budget() {
+    static int cached = 0;
+    if (cached) return cached;
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c >= 1 && c < n) n = c;
+    }
+    long long quota = 0, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // cgroup v2
+        char a[64];
+        if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0) quota = atoll(a);
+        fclose(f);
+    } else {                                                               // cgroup v1
+        if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(q, "%lld", &quota) != 1) quota = 0; fclose(q); }
+        if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(q, "%lld", &period) != 1) period = 0; fclose(q); }
+    }
+    if (quota > 0 && period > 0) {
+        const int c = (int)((quota + period - 1) / period);
+        if (c >= 1 && c < n) n = c;
+    }
+    cached = n;
+    return n;
+}
+
 struct GkHostPool {
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
@@ -1861,7 +1896,7 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
     }
     const int per_chunk = (int)(GC_CHUNK / (block_elems * sizeof(T)));            // blocks per chunk: 64 (uint16) / 32 (int32)
     const int n_chunks = (int)cdiv(n_blocks, (i64)per_chunk);
-    int n_thr = ctx->opt.gram_copy_threads > 0 ? ctx->opt.gram_copy_threads : (int)std::thread::hardware_concurrency();
+    int n_thr = ctx->opt.gram_copy_threads > 0 ? ctx->opt.gram_copy_threads : host_cpu_budget();
     if (ctx->opt.gram_copy_threads <= 0 && n_thr > 32) n_thr = 32;      // measured (tools/micro/hostwrite.hip): 32-64 threads write at the memory rate
     if (n_thr < 1) n_thr = 1;
     if ((i64)n_thr > n_blocks) n_thr = (int)n_blocks;

@@ -180,6 +180,7 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
  * ------------------------------------------------------------------------------------------ */
 #if PY_VERSION_HEX < 0x030C0000
 #include <pthread.h>
+#include <stdio.h>
 #include <unistd.h>
 #define GK_PAR_MIN_ELEMENTS 256
 #define GK_PAR_MAX_THREADS 64          /* an explicit n_threads may go this far */
@@ -188,6 +189,33 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
                                         * on 1 / 8 / 16 / 32 / 64 threads, adjacency matrices 113 / 18 / 11 / 7.8 / 8.8 ms; the tuple-set walk
                                         * is memory-latency bound (a tuple and two int objects per edge) and keeps scaling: 440 / 93 / 47 /
                                         * 25 / 15 ms -- it takes up to 64 */
+/* runnable threads this process may have at once: online CPUs, the affinity mask, the cgroup's CPU quota (see gram.hip:
+ * host_cpu_budget -- more threads than the quota get the whole container throttled for the rest of the 100 ms period) */
+static int cpu_budget(void) {
+    static int cached = 0;
+    if (cached) return cached;
+    long c = sysconf(_SC_NPROCESSORS_ONLN);
+    int n = c > 0 ? (int)c : 1;
+    long long quota = 0, period = 0;
+    FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char a[64];
+        if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0) quota = atoll(a);
+        fclose(f);
+    } else {
+        FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+        if (q) { if (fscanf(q, "%lld", &quota) != 1) quota = 0; fclose(q); }
+        q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (q) { if (fscanf(q, "%lld", &period) != 1) period = 0; fclose(q); }
+    }
+    if (quota > 0 && period > 0) {
+        const int k = (int)((quota + period - 1) / period);
+        if (k >= 1 && k < n) n = k;
+    }
+    cached = n;
+    return n;
+}
+
 typedef struct {
     PyObject* X;
     Py_ssize_t e0, e1, min_len, max_len;
@@ -544,8 +572,7 @@ static void* par_walk_matrix(void* arg) {
 static PyObject* wl_ingest_threads(PyObject* X, Py_ssize_t min_len, Py_ssize_t max_len, int n_threads, int form, const void* aux, int sp_mode) {
     const Py_ssize_t n_el = PySequence_Fast_GET_SIZE(X);
     if (n_threads <= 0) {
-        long c = sysconf(_SC_NPROCESSORS_ONLN);
-        n_threads = c > 0 ? (int)c : 1;
+        n_threads = cpu_budget();
         if (n_threads > (form == 1 ? GK_PAR_MAX_THREADS : GK_PAR_DEFAULT_THREADS)) n_threads = form == 1 ? GK_PAR_MAX_THREADS : GK_PAR_DEFAULT_THREADS;
     }
     if (n_threads > GK_PAR_MAX_THREADS) n_threads = GK_PAR_MAX_THREADS;
