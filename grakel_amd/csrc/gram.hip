@@ -1742,7 +1742,10 @@ static int host_cpu_budget() {
         if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(q, "%lld", &period) != 1) period = 0; fclose(q); }
     }
     if (quota > 0 && period > 0) {
-        const int c = (int)((quota + period - 1) / period);
+        // two CPUs of the quota stay free for the calling thread (it spins in hipEventSynchronize) and the runtime's own
+        // threads: 16 workers + those were just over a 16-CPU quota, a throttle event (a stall of up to 100 ms) every few calls
+        int c = (int)((quota + period - 1) / period);
+        if (c > 4) c -= 2;
         if (c >= 1 && c < n) n = c;
     }
     cached = n;

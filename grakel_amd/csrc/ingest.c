@@ -209,7 +209,8 @@ static int cpu_budget(void) {
         if (q) { if (fscanf(q, "%lld", &period) != 1) period = 0; fclose(q); }
     }
     if (quota > 0 && period > 0) {
-        const int k = (int)((quota + period - 1) / period);
+        int k = (int)((quota + period - 1) / period);
+        if (k > 4) k -= 2;                  /* headroom for the calling thread and the runtime's threads (gram.hip: host_cpu_budget) */
         if (k >= 1 && k < n) n = k;
     }
     cached = n;
