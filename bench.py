@@ -279,7 +279,7 @@ def host_to_host(eng, wl, steps, warmup):
     return out, Ku
 
 
-def python_objects(eng, wl, Ku, reps=3):
+def python_objects(eng, wl, Ku, reps=7):
     """The estimator on Python dict graphs (SURVEY.md 8d's "from Python objects" wall) and the ingestion share of it."""
     import grakel_amd
     from grakel_amd import batch as _batch
@@ -347,6 +347,9 @@ def python_objects(eng, wl, Ku, reps=3):
     except Exception as e:
         forms["error"] = repr(e)
     return {"ms_per_call": dt_obj * 1e3, "value": N * N / dt_obj, "reps": reps, "other_input_forms": forms,
+            "median_ms_per_call": float(np.median(calls)), "normalised_median_ms_per_call": float(np.median(calls_n)),
+            "host_cpu_note": "the box's container has a CPU quota (cgroup cpu.max, 16 CPUs on the project's MI355X boxes): a call "
+                             "that lands in a throttled period takes 20-40 ms longer -- see the per-call lists",
             "normalised_ms_per_call": dt_objn * 1e3, "calls_ms": [round(c, 3) for c in calls],
             "normalised_calls_ms": [round(c, 3) for c in calls_n],
             "of_which_host_ingestion_ms": dt_ingest * 1e3, "host_ingestion_one_thread_ms": dt_ingest_1 * 1e3,
