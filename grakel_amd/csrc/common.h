@@ -89,6 +89,7 @@ struct gk_opts {
     int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
     int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
     int wl_no_wave_sig = 0;      // 1: nodes of degree 33..1024 keep the workgroup signature kernel and the one-thread verifier (rounds 1-4) instead of the wave-per-node kernels
+    int scan_direct_max = 0;     // test hook: tiles up to which the fused scans (scan_fn.h) sum their predecessors per block (0: 4096); 1 forces the prefixed form
     int tt_no_fused = 0;         // look-up transform: the target classes matched level by level (two launches per level) even for a handful of targets
     int gram_no_avx2 = 0;        // 1: the widening threads keep to SSE2 (what a CPU without AVX2 runs)
     int gram_no_tri = 0;         // 1: a full symmetric matrix does NOT take the triangle form of the compact copy (blocks on / above the diagonal over PCIe, mirrored -- and, for normalised jobs, scaled -- by the host threads)

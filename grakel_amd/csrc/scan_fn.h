@@ -47,19 +47,27 @@ __global__ __launch_bounds__(SF_THREADS) void scan_fn_sums_kernel(F f, T* __rest
 // Striped tile: in row i thread t owns element tile0 + i*256 + t, so value()/emit() of a wave
 // touch 64 consecutive elements (coalesced gathers/scatters in the functors).  One block-wide
 // scan per row; the carry links the rows.
-template <typename T, typename F>
+// PREFIXED: partial[] already holds the EXCLUSIVE prefix of the tile sums (sf_scan_partials_kernel) -- the carry of a tile is
+// one subtraction.  Otherwise (few tiles) every block adds up the sums of the tiles before it in its segment itself, which
+// saves the middle kernel but is quadratic in the tile count: 643 M ShortestPath pair items (314 k tiles) spent 22 ms per scan
+// there (round 5).
+template <typename T, typename F, bool PREFIXED>
 __global__ __launch_bounds__(SF_THREADS) void scan_fn_apply_kernel(F f, const T* __restrict__ partial, i64 n,
                                                                    T* __restrict__ total) {
     __shared__ T wsum[SF_THREADS / 64];
     __shared__ T bsum[SF_THREADS / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    T s = 0;
-    for (int i = (int)f.seg_first_tile(blockIdx.x) + threadIdx.x; i < (int)blockIdx.x; i += SF_THREADS) s += partial[i];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) bsum[w] = s;
-    __syncthreads();
     T carry = 0;
-    for (int q = 0; q < SF_THREADS / 64; ++q) carry += bsum[q];
+    if (PREFIXED) {
+        carry = partial[blockIdx.x] - partial[f.seg_first_tile(blockIdx.x)];
+    } else {
+        T s = 0;
+        for (int i = (int)f.seg_first_tile(blockIdx.x) + threadIdx.x; i < (int)blockIdx.x; i += SF_THREADS) s += partial[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) bsum[w] = s;
+        __syncthreads();
+        for (int q = 0; q < SF_THREADS / 64; ++q) carry += bsum[q];
+    }
     const i64 tile0 = (i64)blockIdx.x * SF_TILE;
 #pragma unroll
     for (int i = 0; i < SF_ITEMS; ++i) {
@@ -85,6 +93,30 @@ __global__ __launch_bounds__(SF_THREADS) void scan_fn_apply_kernel(F f, const T*
     }
 }
 
+// one block: partial[0 .. m) -> its exclusive prefix, in place
+template <typename T>
+__global__ __launch_bounds__(1024) void sf_scan_partials_kernel(T* __restrict__ partial, i64 m) {
+    __shared__ T wsum[16];
+    __shared__ T carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (i64 c0 = 0; c0 < m; c0 += 1024) {
+        const i64 idx = c0 + threadIdx.x;
+        const T x = idx < m ? partial[idx] : (T)0;
+        const T inc = sf_wave_incl_scan(x);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        T woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        const T carry = carry_s;
+        if (idx < m) partial[idx] = carry + woff + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+}
+#define SF_DIRECT_MAX 4096          // tiles up to which every block sums its predecessors itself
+
 // total (device, may be null) receives the grand total.  n == 0: total = 0.
 template <typename T, typename F>
 static int gk_scan_fn(gk_ctx* ctx, const F& f, i64 n, T* total) {
@@ -97,7 +129,11 @@ static int gk_scan_fn(gk_ctx* ctx, const F& f, i64 n, T* total) {
     GK_TRY(partial.alloc(nblk));
     if (nblk > 1)      // a single tile has nothing before it (the apply kernel reads partial[0 .. blockIdx))
         scan_fn_sums_kernel<T, F><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n);
-    scan_fn_apply_kernel<T, F><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n, total);
+    if (nblk > (ctx->opt.scan_direct_max > 0 ? (i64)ctx->opt.scan_direct_max : (i64)SF_DIRECT_MAX)) {
+        sf_scan_partials_kernel<T><<<dim3(1), dim3(1024), 0, ctx->stream>>>(partial.p, nblk);
+        scan_fn_apply_kernel<T, F, true><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n, total);
+    } else
+        scan_fn_apply_kernel<T, F, false><<<dim3((unsigned)nblk), dim3(SF_THREADS), 0, ctx->stream>>>(f, partial.p, n, total);
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }

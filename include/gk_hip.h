@@ -76,6 +76,8 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             thread-per-vertex verifier of rounds 1-4 instead of the wave-per-vertex kernels)
  *             "transform.no_fused" (look-up transform: the target classes matched by two launches per level even when the
  *             targets are few enough for the single-workgroup all-levels kernel)
+ *             "scan.direct_max" (test hook: number of 2 048-item tiles up to which the fused scans add up their predecessors
+ *             per block; 1 forces the form with a scanned tile-sum array that jobs above 8 M items take)
  *             "sort.buckets" (1 never / 2 always the per-bucket finish of the sort)
  *             "wl.bd_slots" (distinct keys a bucket of the sort-free dictionary accepts: small values force its
  *             overflow and with it the second, sorting attempt)

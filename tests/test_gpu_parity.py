@@ -224,6 +224,9 @@ _HOST_ROUTES = [
     # combinations that meet in real jobs: label-major features on top of a sort-free relabel is impossible by
     # construction (feat.no_gm turns both off), the words + no list scan pair is the round-1 data flow
     ("wl.frozen_words", "wl.no_listscan"), ("wl.no_hist0", "wl.no_exact1", "wl.no_bucket_dict"),
+    # round 5: the fused scans (scan_fn.h) with a scanned tile-sum array, the form jobs above 8 M items take, with the
+    # sorting dictionary and the label-major feature builder (their users)
+    ("scan.direct_max",), ("scan.direct_max", "wl.no_bucket_dict", "feat.no_gm"),
 ]
 # round 4: the relabel route without host round trips (wl_stream.hip) is the default; its own switches
 ROUTE_OPTIONS = [(), ("wl.no_exact1",), ("wl.sig_no_regs",), ("feat.gm_no_priv",), ("feat.gm_rows_wg",), ("no_mailbox",)] + \
@@ -905,7 +908,8 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
 
 
 @pytest.mark.parametrize("route", [(), ("sp.no_hist",), ("sp.no_pk",), ("sp.no_reg",), ("sp.no_hist", "sp.no_reg"),
-                                   ("feat.gm_row_lds_max",), ("feat.gm_no_priv",)], ids=lambda r: "+".join(r) or "default")
+                                   ("feat.gm_row_lds_max",), ("feat.gm_no_priv",), ("sp.no_hist", "scan.direct_max")],
+                         ids=lambda r: "+".join(r) or "default")
 def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
     """ShortestPath picks among equivalent routes: all-pairs distances in 16-bit packed registers (one wave per graph up to
     64 vertices, a four-wave workgroup up to 128), in 32-bit registers, or in the LDS workgroup kernel; pair features as
