@@ -95,6 +95,10 @@ struct gk_opts {
     int gram_no_tri = 0;         // 1: a full symmetric matrix does NOT take the triangle form of the compact copy (blocks on / above the diagonal over PCIe, mirrored -- and, for normalised jobs, scaled -- by the host threads)
     // ShortestPath
     int sp_no_hist = 0;          // pair features through explicit pair items + the sorting dictionary instead of per-graph histograms
+    int sp_no_rows = 0;          // histogram form: no per-graph counter rows (a graph whose LDS table overflows sends the job to the pair items)
+    int sp_rows_all = 0;         // test hook: every graph with a pair counts through counter rows (default: graphs above 6 144 pairs)
+    int sp_hist_unit = 0;        // test hook: distance-matrix entries per counting workgroup (0: 262 144)
+    int sp_hist_slots = 0;       // test hook: slots of the counting workgroups' LDS table (0: 8 192; a power of two)
     int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)
     int sp_no_reg = 0;           // all-pairs distances of small graphs by the LDS workgroup kernel instead of wave-per-graph registers
     // plumbing
@@ -256,6 +260,8 @@ struct gk_batch {
     u32* sp_idtab = nullptr;           // [sp_keyspace] key -> dense feature id
     i64 sp_L = 0, sp_dcap = 0, sp_keyspace = 0, sp_src_nodes = 0;
     i32 sp_max_nodes = 0;       // largest source graph (sp_emit_kernel's slab grid)
+    std::vector<i32> sp_h_node_ptr;    // host copies of sp_node_ptr / graph_ptr (pair ranges): the feature builder cuts the
+    std::vector<u32> sp_h_pair_base;   // matrices of the large graphs into row units on the host
     int sp_with_labels = 0;
     // level 0 of a batch with at most GK_HIST0_MAX_LABELS input labels is never sorted: the label-count
     // features of that level come from one LDS histogram per graph (features.hip), perm[0] stays unused

@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
                                                               i64 n_graphs, i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt,
                                                               u32* __restrict__ ent_n, u64* __restrict__ selfk, i64 n_fit, int rectangular,
                                                               u32 df_cap, int prim_max, int wide_above, u32* __restrict__ part,
-                                                              u32* __restrict__ wgmeta, u32* __restrict__ overflow) {
+                                                              u32* __restrict__ wgmeta, u32* __restrict__ overflow, u32 skip_above) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private df histogram | keys[SPH_T] | counts[SPH_T] | labels[SPH_LAB]
     __shared__ u32 n_ent_s, ovf_s, red_m[SPH_THREADS / 64], red_e[SPH_THREADS / 64];
     __shared__ u64 red_x[SPH_THREADS / 64];
@@ -1023,6 +1023,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
             if (tid == 0) ent_n[g] = 0, selfk[g] = 0;
             continue;
         }
+        if (np > skip_above) continue;                    // counted through a counter row (sp_rows_count_kernel)
         u32 T = 64;                                       // a table of at least twice the pairs (distinct keys <= pairs), capped
         while (T < 2u * np && T < (u32)SPH_T) T <<= 1;
         const u32 tmask = T - 1u, t_cap = T - (T >> 2);   // three quarters full at most (only binds at T == SPH_T)
@@ -1149,10 +1150,233 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
     for (int t = tid; t < priv_words; t += SPH_THREADS) mine[t] = priv[t];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large graphs of the histogram form (round 5).  One workgroup and one 8 192-slot LDS table per graph was the whole
+// route: D&D-like graphs hold up to 112 k distinct keys (880 of 1 178 above the table), a 3 782-vertex discussion thread
+// is 14 M matrix entries for ONE workgroup -- both sets fell back to 643 M / 172 M explicit pair items, a three-pass sort
+// of them and the label-major builder (81 / 49 ms).  Now every graph above SPH_SMALL_PAIRS pairs owns a COUNTER ROW in
+// HBM (one u32 per dense key id, Q of them), its matrix is cut into row units of ~256 k entries, and
+//   sp_rows_count_kernel    one workgroup per unit, a wave per matrix row: keys are summed up in an LDS table (hot keys --
+//                           14 M pairs of a thread are a few hundred distinct keys -- never leave the CU), a key that no
+//                           longer fits goes to the graph's counter row with a global atomic, and so does the table when
+//                           the unit ends;
+//   sp_rows_compact_kernel  one workgroup per graph: the non-zero counters of its row become the graph's (id, count)
+//                           entries, with the same per-label statistics sp_hist_kernel leaves.
+// Graphs of at most SPH_SMALL_PAIRS pairs stay with sp_hist_kernel, whose table cannot overflow on them.
+// ---------------------------------------------------------------------------------------------------
+#define SPH_SMALL_PAIRS 6144u       // three quarters of SPH_T: distinct keys <= pairs
+#define SPR_THREADS 1024
+#define SPR_T 8192                  // LDS table slots (key + count)
+#define SPR_COLS 16384              // column terms d1 * label staged in LDS up to this many vertices
+#define SPR_UNIT (256 * 1024)       // matrix entries per unit
+
+struct SpUnit { i32 g, r0, r1, row; };
+
+// one key, c times: LDS table while it has room (half full at most: short probes also for the keys that miss), else the row
+__device__ __forceinline__ void spr_add(i32 key, u32 c, i32* keys, u32* co, u32 tmask, u32 t_cap, u32* n_ent, u32* __restrict__ row,
+                                        const u32* __restrict__ idtab) {
+    u32 h = ((u32)key * 2654435761u) >> 8 & tmask;
+    // the probe bound: claims race past the fill check (up to a thread each), so a small table can fill up completely and a
+    // key that is not in it would circle forever; the row takes any key at any time
+    for (int probe = 0; probe < 32; ++probe) {
+        i32 old = keys[h];
+        if (old == -1) {
+            if (*(volatile u32*)n_ent >= t_cap) break;
+            old = atomicCAS(&keys[h], -1, key);
+            if (old == -1) {
+                atomicAdd(n_ent, 1u);
+                atomicAdd(&co[h], c);
+                return;
+            }
+        }
+        if (old == key) { atomicAdd(&co[h], c); return; }
+        h = (h + 1u) & tmask;
+    }
+    atomicAdd(&row[idtab[key]], c);
+}
+
+__global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSource S, const SpUnit* __restrict__ units, u32* __restrict__ rows,
+                                                                    i64 Q, int slots) {
+    extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // keys[slots] | counts[slots] | column terms[min(n, SPR_COLS)]
+    __shared__ u32 n_ent_s;
+    const SpUnit un = units[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    i32* keys = gm_lds;
+    u32* co = (u32*)(keys + slots);
+    u32* colterm = co + slots;
+    const i32 v0 = S.node_ptr[un.g];
+    const int n = S.node_ptr[un.g + 1] - v0;
+    const u32 tmask = (u32)slots - 1u, t_cap = (u32)slots >> 1;
+    for (int t = tid; t < slots; t += SPR_THREADS) keys[t] = -1, co[t] = 0;
+    const bool col_in_lds = n <= SPR_COLS;
+    const u32 d1 = (u32)S.d1;
+    if (col_in_lds)
+        for (int j = tid; j < n; j += SPR_THREADS) colterm[j] = S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u;
+    if (tid == 0) n_ent_s = 0;
+    __syncthreads();
+    const i32* dg = S.dist + S.dist_ptr[un.g];
+    u32* row = rows + (size_t)un.row * (size_t)Q;
+    for (int i = un.r0 + w; i < un.r1; i += SPR_THREADS / 64) {       // a wave per matrix row: no division per entry
+        const u32 rowterm = S.with_labels ? d1 * (u32)S.L * (u32)S.node_label[v0 + i] : 0u;
+        const i32* dr = dg + (size_t)i * n;
+        for (int j0 = 0; j0 < n; j0 += 256) {
+            i32 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 64 + lane;
+                x[u] = j < n ? dr[j] : SPH_INF;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 64 + lane;
+                i32 key = -1;
+                if (j < n && j != i && x[u] < SPH_INF)
+                    key = (i32)(rowterm + (col_in_lds ? colterm[j] : (S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u)) + (u32)x[u]);
+                // lanes with the same key first add themselves up: 64 LDS atomics on one address serialise, and in a thread
+                // with a hub most of a row IS one key (leaf, leaf, 2)
+                u64 act = __ballot(key >= 0);
+                while (act) {
+                    const int first = __ffsll((unsigned long long)act) - 1;
+                    const i32 k0 = __shfl(key, first, 64);
+                    const u64 m = __ballot(key == k0) & act;
+                    const int c = __popcll(m);
+                    if (c < 8) break;                                  // no run worth a round of its own
+                    if (lane == first) spr_add(k0, (u32)c, keys, co, tmask, t_cap, &n_ent_s, row, S.idtab);
+                    if (key == k0) key = -1;
+                    act &= ~m;
+                }
+                if (key >= 0) spr_add(key, 1u, keys, co, tmask, t_cap, &n_ent_s, row, S.idtab);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < slots; t += SPR_THREADS) {
+        const i32 k = keys[t];
+        if (k >= 0) atomicAdd(&row[S.idtab[k]], co[t]);
+    }
+}
+
+struct SpRowsOut {
+    i32* ent_lab; u32* ent_cnt; u32* ent_n; u64* selfk; u32* part; u32* wgmeta;
+};
+
+__global__ __launch_bounds__(SPR_THREADS) void sp_rows_compact_kernel(const i32* __restrict__ row_graph, int n_rows, const u32* __restrict__ rows,
+                                                                      i64 Q, const i32* __restrict__ pair_base, const GmLevels P,
+                                                                      const GmLabelArrays A, const GmPriv R, const SpRowsOut O, i64 n_fit,
+                                                                      int rectangular, u32 df_cap, int prim_max, int wide_above, int wg0) {
+    extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private df histogram
+    __shared__ u32 n_ent_s, red_m[SPR_THREADS / 64], red_e[SPR_THREADS / 64];
+    __shared__ u64 red_x[SPR_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    u32* priv = (u32*)gm_lds;
+    const int priv_words = R.bins / 2;
+    for (int t = tid; t < priv_words; t += SPR_THREADS) priv[t] = 0;
+    const i32 poff = R.off[0];
+    u32 maxc = 0, entries = 0;
+    for (int k = blockIdx.x; k < n_rows; k += gridDim.x) {
+        const int g = row_graph[k];
+        const u32* row = rows + (size_t)k * (size_t)Q;
+        const i32 base = pair_base[g];
+        const u32 np = (u32)(pair_base[g + 1] - base);
+        const u32 side_bit = g < n_fit ? 1u : 2u;
+        __syncthreads();
+        if (tid == 0) n_ent_s = 0;
+        __syncthreads();
+        u64 extra = 0;
+        for (i64 t0 = 0; t0 < Q; t0 += 4 * SPR_THREADS) {
+            u32 cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const i64 t = t0 + u * SPR_THREADS + tid;
+                cc[u] = t < Q ? row[t] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const i64 t = t0 + u * SPR_THREADS + tid;
+                const u32 c = cc[u];
+                const u64 m = __ballot(c > 0);
+                if (!m) continue;                                  // wave-uniform
+                u32 wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&n_ent_s, (u32)__popcll(m));
+                wbase = __shfl(wbase, 0, 64);
+                if (c == 0) continue;
+                const i32 x = (i32)t;
+                const u32 e = wbase + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                O.ent_lab[base + e] = x, O.ent_cnt[base + e] = c;
+                if (poff >= 0) {                              // df / count class in the workgroup's private histogram (gm_pairs_kernel)
+                    const u32 bin = (u32)poff + (u32)x;
+                    const int sh = 16 * (bin & 1u);
+                    u32 add = 0;
+                    if (rectangular) add |= side_bit << GM_PRIV_SIDE_SHIFT;
+                    if ((int)c > prim_max) add |= GM_PRIV_BIG1;
+                    if ((int)c > wide_above) add |= GM_PRIV_BIG2;
+                    const u32 cur = (priv[bin >> 1] >> sh) & 0xffffu;
+                    const u32 flags = add & ~cur & 0xf000u;
+                    if (flags) atomicOr(&priv[bin >> 1], flags << sh);
+                    atomicAdd(&priv[bin >> 1], 1u << sh);
+                } else {
+                    const i64 q = P.off[0] + x;
+                    if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
+                    if (c >= 2u && __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) atomicMax(&A.cmax[q], c);
+                    if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
+                }
+                extra += (u64)c * c - c;
+                maxc = c > maxc ? c : maxc;
+                ++entries;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) extra += __shfl_down(extra, off, 64);
+        if (lane == 0) red_x[w] = extra;
+        __syncthreads();
+        if (tid == 0) {
+            u64 x = 0;
+            for (int q = 0; q < SPR_THREADS / 64; ++q) x += red_x[q];
+            O.ent_n[g] = n_ent_s;
+            O.selfk[g] = (u64)np + x;                     // sum of c^2 = sum of c + sum of (c^2 - c)
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        entries += __shfl_down(entries, off, 64);
+        const u32 o = __shfl_down(maxc, off, 64);
+        maxc = o > maxc ? o : maxc;
+    }
+    if (lane == 0) red_m[w] = maxc, red_e[w] = entries;
+    __syncthreads();
+    if (tid == 0) {
+        u32 m = 0, e = 0;
+        for (int q = 0; q < SPR_THREADS / 64; ++q) m = red_m[q] > m ? red_m[q] : m, e += red_e[q];
+        O.wgmeta[2 * (wg0 + blockIdx.x)] = m, O.wgmeta[2 * (wg0 + blockIdx.x) + 1] = e;
+    }
+    u32* mine = O.part + (size_t)(wg0 + blockIdx.x) * priv_words;
+    for (int t = tid; t < priv_words; t += SPR_THREADS) mine[t] = priv[t];
+}
+
 int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, int wide_above) {
     const i64 N = pb->n_graphs, V = pb->n_nodes;              // V = pairs = entry slots
     const i64 Q = pb->label_counts.empty() ? 0 : pb->label_counts[0];
     if (V <= 0 || Q <= 0) return GK_ERR_UNSUPPORTED;
+
+    // ---- which graphs count through a counter row, and the row units of their matrices
+    std::vector<SpUnit> units;
+    std::vector<i32> row_graph;
+    u32 skip_above = 0xffffffffu;
+    if (!ctx->opt.sp_no_rows && pb->sp_h_node_ptr.size() == (size_t)N + 1 && pb->sp_h_pair_base.size() == (size_t)N + 1) {
+        skip_above = ctx->opt.sp_rows_all ? 0u : SPH_SMALL_PAIRS;
+        const i64 unit = ctx->opt.sp_hist_unit > 0 ? (i64)ctx->opt.sp_hist_unit : (i64)SPR_UNIT;
+        for (i64 g = 0; g < N; ++g) {
+            const u32 np = pb->sp_h_pair_base[g + 1] - pb->sp_h_pair_base[g];
+            if (np == 0 || np <= skip_above) continue;
+            const i32 n = pb->sp_h_node_ptr[g + 1] - pb->sp_h_node_ptr[g];
+            const i32 row = (i32)row_graph.size();
+            row_graph.push_back((i32)g);
+            const i32 rpu = (i32)std::max<i64>(1, unit / n);
+            for (i32 r0 = 0; r0 < n; r0 += rpu) units.push_back(SpUnit{(i32)g, r0, std::min(n, r0 + rpu), row});
+        }
+        // the rows are N_rows x Q counters: a job whose rows do not fit a modest share of the HBM leaves for the pair items
+        if ((double)row_graph.size() * (double)Q * 4.0 > 16.0 * 1024 * 1024 * 1024) return GK_ERR_UNSUPPORTED;
+    }
+    const i64 n_rows = (i64)row_graph.size();
+    const bool any_small = n_rows < N;
 
     GmLevels P = {};
     P.L = 1, P.off[0] = 0, P.off[1] = Q, P.lab[0] = nullptr, P.flag[0] = nullptr, P.id_base[0] = 0, P.level[0] = 0;
@@ -1165,15 +1389,17 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     GK_TRY(cnt.alloc((size_t)V)); GK_TRY(ent.alloc((size_t)V)); GK_TRY(ent_n.alloc((size_t)N));
     const int rectangular = f->symmetric ? 0 : 1;
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    i64 grid = N < n_cu ? N : n_cu;                       // one workgroup per CU: the table and the private histogram fill its LDS
+    const i64 grid1 = any_small ? (N < n_cu ? N : n_cu) : 0;  // one workgroup per CU: the table and the private histogram fill its LDS
+    const i64 grid2 = n_rows > 0 ? std::min<i64>(n_rows, 2 * (i64)n_cu) : 0;
+    const i64 grid = grid1 + grid2;
     const i64 priv_budget = (160 * 1024 - 1024 - (i64)SPH_T * 8 - (i64)SPH_LAB * 4) / 2;
     GmPriv R;
     R.bins = 0;
     for (int j = 0; j < FEAT_MAX_LEVELS; ++j) R.off[j] = -1;
-    if (!ctx->opt.gm_no_priv && Q <= priv_budget && cdiv(N, grid) + 1 < (i64)GM_PRIV_COUNT_MASK) R.off[0] = 0, R.bins = (int)Q;
+    const i64 per_wg = std::max<i64>(grid1 > 0 ? cdiv(N, grid1) : 0, grid2 > 0 ? cdiv(n_rows, grid2) : 0);
+    if (!ctx->opt.gm_no_priv && Q <= priv_budget && per_wg + 1 < (i64)GM_PRIV_COUNT_MASK) R.off[0] = 0, R.bins = (int)Q;
     R.bins = (R.bins + 1) & ~1;
     const size_t lds = (size_t)R.bins * 2 + (size_t)SPH_T * 8 + (size_t)SPH_LAB * 4;
-    GK_TRY(gk_func_lds(ctx, (const void*)sp_hist_kernel, (int)lds));
     Tmp<u32> part(ctx), wgmeta(ctx);
     GK_TRY(wgmeta.alloc((size_t)grid * 2));
     GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
@@ -1187,9 +1413,38 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
                                                                                           (u32*)A.side);
     SpSource S{pb->sp_node_ptr, pb->sp_node_label, pb->sp_dist_ptr, pb->sp_dist, pb->sp_idtab, pb->graph_ptr,
                (u64)pb->sp_L, (u64)pb->sp_dcap, pb->sp_with_labels};
-    sp_hist_kernel<<<dim3((unsigned)grid), SPH_THREADS, lds, ctx->stream>>>(
-        S, P, A, R, N, ent.p, cnt.p, ent_n.p, f->selfk, f->n_fit, rectangular, (u32)(f->low_df > 2 ? f->low_df : 2), prim_max,
-        wide_above, part.p, wgmeta.p, f->meta + GM_META_OVF);
+    if (grid1 > 0) {
+        GK_TRY(gk_func_lds(ctx, (const void*)sp_hist_kernel, (int)lds));
+        sp_hist_kernel<<<dim3((unsigned)grid1), SPH_THREADS, lds, ctx->stream>>>(
+            S, P, A, R, N, ent.p, cnt.p, ent_n.p, f->selfk, f->n_fit, rectangular, (u32)(f->low_df > 2 ? f->low_df : 2), prim_max,
+            wide_above, part.p, wgmeta.p, f->meta + GM_META_OVF, skip_above);
+    }
+    Tmp<u32> rows(ctx);
+    Tmp<SpUnit> units_dev(ctx);
+    Tmp<i32> row_graph_dev(ctx);
+    if (n_rows > 0) {
+        int slots = SPR_T;
+        if (ctx->opt.sp_hist_slots >= 16 && ctx->opt.sp_hist_slots <= SPR_T && !(ctx->opt.sp_hist_slots & (ctx->opt.sp_hist_slots - 1)))
+            slots = ctx->opt.sp_hist_slots;
+        GK_TRY(rows.alloc((size_t)n_rows * (size_t)Q));
+        GK_TRY(units_dev.alloc(units.size()));
+        GK_TRY(row_graph_dev.alloc((size_t)n_rows));
+        GK_TRY(gk_zero_async(ctx, rows.p, (size_t)n_rows * (size_t)Q * 4));
+        // pageable sources: the copies are complete when the calls return, the vectors may go
+        GK_HIP_CHECK(hipMemcpyAsync(units_dev.p, units.data(), units.size() * sizeof(SpUnit), hipMemcpyHostToDevice, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(row_graph_dev.p, row_graph.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
+        const i64 cols = std::min<i64>(pb->sp_max_nodes > 0 ? pb->sp_max_nodes : 1, SPR_COLS);
+        const size_t lds1 = (size_t)slots * 8 + (size_t)cols * 4;
+        GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_count_kernel, (int)lds1));
+        sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots);
+        const size_t lds2 = (size_t)R.bins * 2;
+        GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_compact_kernel, (int)lds2));
+        SpRowsOut O{ent.p, cnt.p, ent_n.p, f->selfk, part.p, wgmeta.p};
+        sp_rows_compact_kernel<<<dim3((unsigned)grid2), SPR_THREADS, lds2, ctx->stream>>>(
+            row_graph_dev.p, (int)n_rows, rows.p, Q, pb->graph_ptr, P, A, R, O, f->n_fit, rectangular, (u32)(f->low_df > 2 ? f->low_df : 2),
+            prim_max, wide_above, (int)grid1);
+    }
+    GK_HIP_CHECK(hipGetLastError());
     if (R.bins > 0)
         gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(A, table.p, part.p, (int)grid, prim_max, wide_above, rectangular);
     // the overflow word travels with the operand sizes: meta[] is read back once, in gm_finish

@@ -1120,7 +1120,9 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
             if (b->n_levels > 0 && (u64)b->label_counts[0] > L0) L0 = (u64)b->label_counts[0];
         }
         const u64 keyspace = d1 * L0 * L0;
-        if (n_levels == 1 && !ctx->opt.sp_no_hist && L0 < (1u << 15) && keyspace <= (1ull << 22) && h_pairs > 0) {
+        // round 5: the key space cap went from 2^22 to 2^26 keys (a presence byte and a 4-byte id each: 320 MB at the cap) --
+        // 620 degree labels x 14 distances (REDDIT-like) are 5.4 M keys and used to leave for the pair items
+        if (n_levels == 1 && !ctx->opt.sp_no_hist && L0 < (1u << 15) && keyspace <= (1ull << 26) && h_pairs > 0) {
             Tmp<unsigned char> present(ctx);
             Tmp<u32> nk(ctx);
             if ((r = present.alloc((size_t)keyspace)) || (r = nk.alloc(1))) return fail(r);
@@ -1141,7 +1143,15 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
                 gk_set_error("gk_sp_build: %s", hipGetErrorString(hipGetLastError()));
                 return fail(GK_ERR_HIP);
             }
+            // the graph sizes and pair ranges for the host (features_gm.hip cuts large matrices into row units); same sync as nk
+            pb->sp_h_node_ptr.assign((size_t)N + 1, 0), pb->sp_h_pair_base.assign((size_t)N + 1, 0);
+            if (hipMemcpyAsync(pb->sp_h_node_ptr.data(), b->graph_ptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(pb->sp_h_pair_base.data(), pair_base, (size_t)(N + 1) * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+                gk_set_error("gk_sp_build: %s", hipGetErrorString(hipGetLastError()));
+                return fail(GK_ERR_HIP);
+            }
             if ((r = gk_readback(ctx, nk.p, &h_nk, 1))) return fail(r);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(GK_ERR_HIP);
             pb->sp_dist = s.dist.p, s.dist.p = nullptr;             // the matrices move into the pair batch
             pb->sp_dist_ptr = s.dist_ptr.p, s.dist_ptr.p = nullptr;
             pb->sp_hist = true, pb->sp_L = (i64)L0, pb->sp_dcap = (i64)d1, pb->sp_keyspace = (i64)keyspace, pb->sp_src_nodes = V;

@@ -97,6 +97,10 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "gram.no_avx2" (those host threads keep to SSE2, what a CPU without AVX2 runs)
  *   paths:    "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
  *             histograms of the distance matrices),
+ *             "sp.no_rows" (histogram form without the counter rows of the large graphs: one workgroup and one LDS table
+ *             per graph, a table that overflows sends the whole job to the pair items -- the round-4 form),
+ *             "sp.rows_all" / "sp.hist_unit" / "sp.hist_slots" (test hooks of the counter-row route: every graph
+ *             through it, distance-matrix entries per counting workgroup, slots of its LDS table),
  *             "sp.no_pk" (all-pairs distances never in the 16-bit packed register kernel: 32-bit registers up to 64
  *             vertices, the LDS workgroup kernel beyond), "sp.no_reg" (the LDS workgroup kernel for every graph)
  *   plumbing: "no_mailbox" (small read-backs by hipMemcpy instead of the mapped mailbox),

@@ -908,19 +908,24 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
 
 
 @pytest.mark.parametrize("route", [(), ("sp.no_hist",), ("sp.no_pk",), ("sp.no_reg",), ("sp.no_hist", "sp.no_reg"),
-                                   ("feat.gm_row_lds_max",), ("feat.gm_no_priv",), ("sp.no_hist", "scan.direct_max")],
+                                   ("feat.gm_row_lds_max",), ("feat.gm_no_priv",), ("sp.no_hist", "scan.direct_max"),
+                                   ("sp.no_rows",), ("sp.rows_all",), ("sp.rows_all", "sp.hist_unit=1"),
+                                   ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv")],
                          ids=lambda r: "+".join(r) or "default")
 def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
     """ShortestPath picks among equivalent routes: all-pairs distances in 16-bit packed registers (one wave per graph up to
     64 vertices, a four-wave workgroup up to 128), in 32-bit registers, or in the LDS workgroup kernel; pair features as
     per-graph histograms of the distance matrices or through explicit pair items, the sorting dictionary and the
-    label-major builder (also reached when the histogram builder declines: feat.gm_row_lds_max).  Every route must
+    label-major builder (also reached when the histogram builder declines: feat.gm_row_lds_max); the histograms of graphs
+    above 6 144 pairs through counter rows in HBM (sp.rows_all: every graph; one matrix row per counting workgroup; an LDS
+    table of 16 slots, i.e. nearly every key spilled to the row with a global atomic) or not (sp.no_rows).  Every route must
     give the reference's matrix (fit_transform and transform), with unit, integer and dyadic float weights."""
     import sys
     sys.path.insert(0, GOLDEN)
     from small_sets import sp_dyadic_graphs
     for name in route:
-        gkopt(name, 64 if name == "feat.gm_row_lds_max" else 1)
+        name, _, val = name.partition("=")
+        gkopt(name, int(val) if val else (64 if name == "feat.gm_row_lds_max" else 1))
     z = load_golden("nci1_like_sp_300.npz")
     G = nci1_like(300, 0, as_adj=True)
     sp = gk.ShortestPath()
