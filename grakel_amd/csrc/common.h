@@ -95,6 +95,7 @@ struct gk_opts {
     int gram_no_tri = 0;         // 1: a full symmetric matrix does NOT take the triangle form of the compact copy (blocks on / above the diagonal over PCIe, mirrored -- and, for normalised jobs, scaled -- by the host threads)
     // ShortestPath
     int sp_no_hist = 0;          // pair features through explicit pair items + the sorting dictionary instead of per-graph histograms
+    int sp_no_bfs = 0;           // large unit-weight graphs by the row relaxation kernel instead of the bit-parallel breadth-first search
     int sp_no_rows = 0;          // histogram form: no per-graph counter rows (a graph whose LDS table overflows sends the job to the pair items)
     int sp_rows_all = 0;         // test hook: every graph with a pair counts through counter rows (default: graphs above 6 144 pairs)
     int sp_hist_unit = 0;        // test hook: distance-matrix entries per counting workgroup (0: 262 144)

@@ -909,7 +909,7 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
 
 @pytest.mark.parametrize("route", [(), ("sp.no_hist",), ("sp.no_pk",), ("sp.no_reg",), ("sp.no_hist", "sp.no_reg"),
                                    ("feat.gm_row_lds_max",), ("feat.gm_no_priv",), ("sp.no_hist", "scan.direct_max"),
-                                   ("sp.no_rows",), ("sp.rows_all",), ("sp.rows_all", "sp.hist_unit=1"),
+                                   ("sp.no_rows",), ("sp.no_bfs",), ("sp.rows_all",), ("sp.rows_all", "sp.hist_unit=1"),
                                    ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv")],
                          ids=lambda r: "+".join(r) or "default")
 def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
@@ -945,6 +945,31 @@ def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
     assert np.array_equal(spd.fit_transform(D[:16]), zd["K_fit_auto"]) and np.array_equal(spd.transform(D[16:]), zd["K_tr_auto"])
     big = random_labelled_graphs(5, 140, 210, 0.02, 3, 3, fmt="adj") + G[:20]     # graphs above 128 vertices and above the LDS cap
     assert np.array_equal(gk.ShortestPath().fit_transform(big), O.SPOracle().fit_transform(big))
+
+
+@pytest.mark.parametrize("no_bfs", [0, 1])
+def test_large_unit_weight_graphs_directed_hubs_and_unreachable_pairs(gk, gkopt, no_bfs):
+    """Graphs above the Floyd-Warshall LDS cap with unit weights take the bit-parallel breadth-first search (sp.hip:
+    sp_msbfs_kernel; sp.no_bfs = 1: the row relaxation).  What the REDDIT- / D&D-like goldens do not hold: DIRECTED
+    adjacency matrices (d[u][v] follows the out-edges of u), a hub above 32 and one above 1 024 neighbours next to
+    vertices nothing leads to, more than 1 024 vertices (a thread owns several), isolated vertices."""
+    gkopt("sp.no_bfs", no_bfs)
+    rs = np.random.RandomState(5)
+    G = []
+    for n, p in ((230, 0.012), (300, 0.006), (260, 0.02)):
+        A = (rs.rand(n, n) < p).astype(np.int64)
+        np.fill_diagonal(A, 0)
+        G.append([A, dict(enumerate(rs.randint(0, 3, n).tolist()))])
+    n = 1300                                                   # vertex 0: 1 100 out-edges; vertex 1: 40; a directed chain; the rest isolated
+    A = np.zeros((n, n), np.int64)
+    A[0, 100:1200] = 1
+    A[1, 0] = A[1, 60:99] = 1
+    A[np.arange(1200, 1250), np.arange(1201, 1251)] = 1
+    A[150, 1] = A[1250, 1200] = 1
+    G.append([A, dict(enumerate((np.arange(n) % 4).tolist()))])
+    K = gk.ShortestPath().fit_transform(G)
+    assert np.array_equal(K, O.SPOracle().fit_transform(G))
+    assert np.array_equal(gk.ShortestPath(with_labels=False).fit_transform(G), O.SPOracle(with_labels=False).fit_transform(G))
 
 
 def test_sp_float_weights_against_reference_goldens(gk):
