@@ -86,6 +86,7 @@ struct gk_opts {
     int gram_fold = 0;           // rare labels' pair updates INSIDE the tile kernel (which then normalises in its epilogue as well):
                                  // 0 = when it pays (normalised jobs whose separate normalisation pass costs more than the binning), 1 = whenever legal, 2 = never
     int gram_no_split8 = 0;      // counts above 127: 1 = float64 side operand (gram_f64_kernel) instead of split int8 columns
+    int gram_no_split64 = 0;     // float64 side product: one workgroup per tile for the whole K loop (no split, no atomics)
     int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
     int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
     int wl_no_wave_sig = 0;      // 1: nodes of degree 33..1024 keep the workgroup signature kernel and the one-thread verifier (rounds 1-4) instead of the wave-per-node kernels

@@ -1289,15 +1289,30 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
 #define GD_BK 16
 #define GD_LD 17
 
+// Round 5: a diagonal block of a symmetric job only multiplies the tiles on and above its diagonal and adds the result to
+// both halves (tri), and the K loop is split over ksplit workgroups per tile whenever the tiles alone would leave CUs
+// idle -- 19 x 19 tiles of the D&D-like ShortestPath job (1 178 graphs, 9.2 ms) were 1.4 workgroups per CU, the second
+// round of them running with 60 % of the chip empty.  Split partial sums meet in K through float64 atomics (integers
+// below 2^53: exact in any order).  The next operand tile is fetched into registers while the current one multiplies.
 __global__ __launch_bounds__(256) void gram_f64_kernel(
     const double* __restrict__ A, const double* __restrict__ B, i64 ld, int k_tiles,
     const u64* __restrict__ selfk, double* __restrict__ K, i64 M, i64 N, i64 row_base,
-    int symmetric, i64 n_fit, int normalize, int tiles_n, int accumulate, i64 ldk, i64 col_base) {
+    int symmetric, i64 n_fit, int normalize, int tiles_n, int accumulate, i64 ldk, i64 col_base, int tri, int ksplit) {
     __shared__ double sA[GD_BM * GD_LD];
     __shared__ double sB[GD_BN * GD_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+    int t = blockIdx.x / ksplit;
+    const int ks = blockIdx.x - t * ksplit;
+    int bm, bn;
+    if (tri) {                                         // upper triangle, row by row
+        bm = 0;
+        for (int len = tiles_n; t >= len; --len) t -= len, ++bm;
+        bn = bm + t;
+    } else
+        bm = t / tiles_n, bn = t % tiles_n;
+    const int kper = (k_tiles + ksplit - 1) / ksplit;
+    const int kt0 = ks * kper, kt1 = kt0 + kper < k_tiles ? kt0 + kper : k_tiles;
     v4d acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1309,17 +1324,26 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
     const int lrow = tid >> 2, lk = (tid & 3) * 4;
     const double* gA = A + ((i64)bm * GD_BM + lrow) * ld + lk;
     const double* gB = B + ((i64)bn * GD_BN + lrow) * ld + lk;
-    for (int kt = 0; kt < k_tiles; ++kt) {
-        const i64 go = (i64)kt * GD_BK;
+    double ra[4], rb[4];
+    if (kt0 < kt1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[q] = gA[(i64)kt0 * GD_BK + q], rb[q] = gB[(i64)kt0 * GD_BK + q];
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            sA[lrow * GD_LD + lk + q] = gA[go + q];
-            sB[lrow * GD_LD + lk + q] = gB[go + q];
+            sA[lrow * GD_LD + lk + q] = ra[q];
+            sB[lrow * GD_LD + lk + q] = rb[q];
         }
         __syncthreads();
+        if (kt + 1 < kt1) {
+            const i64 go = (i64)(kt + 1) * GD_BK;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = ks * 4 + (lane >> 4);
+            for (int q = 0; q < 4; ++q) ra[q] = gA[go + q], rb[q] = gB[go + q];
+        }
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) {
+            const int kk = ks4 * 4 + (lane >> 4);
             double a0 = sA[(wm * 32 + (lane & 15)) * GD_LD + kk];
             double a1 = sA[(wm * 32 + 16 + (lane & 15)) * GD_LD + kk];
             double b0 = sB[(wn * 32 + (lane & 15)) * GD_LD + kk];
@@ -1331,6 +1355,7 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
         }
         __syncthreads();
     }
+    const bool shared_cell = ksplit > 1;               // other workgroups add to the same entries
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1340,11 +1365,17 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(
             for (int r = 0; r < 4; ++r) {
                 const i64 row = (i64)bm * GD_BM + wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
                 if (row < M && col < N) {
+                    const double v = acc[mt][nt][r];
                     if (accumulate) {       // K already holds the int8 product (and selfk on the diagonal)
-                        if (!(symmetric && row_base + row == col_base + col)) K[row * ldk + col] += acc[mt][nt][r];
+                        if (symmetric && row_base + row == col_base + col) continue;
+                        if (shared_cell) unsafeAtomicAdd(&K[row * ldk + col], v);
+                        else K[row * ldk + col] += v;
+                        if (tri && bm != bn) {             // the mirrored tile (a diagonal tile holds both halves itself)
+                            if (shared_cell) unsafeAtomicAdd(&K[col * ldk + row], v);
+                            else K[col * ldk + row] += v;
+                        }
                     } else {
-                        K[row * ldk + col] = finish_entry(acc[mt][nt][r], row_base + row, col_base + col, symmetric != 0,
-                                                        selfk, n_fit, normalize);
+                        K[row * ldk + col] = finish_entry(v, row_base + row, col_base + col, symmetric != 0, selfk, n_fit, normalize);
                     }
                 }
             }
@@ -1464,10 +1495,17 @@ static int gram_block_launch(gk_ctx* ctx, gk_feat* f, i64 row_lo, i64 row_hi, i6
     if (has_wide) {   // float64 side operand: K += Phi_w . Phi_w^T (diagonal excluded: it is selfk)
         const double* pw = f->phi_w;
         const int tiles_m = (int)cdiv(M, GD_BM), tiles_n = (int)cdiv(NC, GD_BN);
-        gram_f64_kernel<<<dim3((unsigned)(tiles_m * (i64)tiles_n)), dim3(256), 0, ctx->stream>>>(
+        const int k_tiles = (int)(f->n_cols_wide_pad / GD_BK);
+        const int tri64 = (f->symmetric && row_lo == col_lo && row_hi == col_hi && !ctx->opt.gram_no_sym) ? 1 : 0;
+        const i64 tiles = tri64 ? (i64)tiles_n * (tiles_n + 1) / 2 : (i64)tiles_m * tiles_n;
+        // four workgroups per CU hide one another's operand fetches; a slice of the K loop keeps at least 32 steps
+        const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+        int ksplit = (int)std::min<i64>(cdiv(4 * (i64)n_cu, tiles), std::max(1, k_tiles / 32));
+        if (ksplit < 1 || ctx->opt.gram_no_split64) ksplit = 1;
+        gram_f64_kernel<<<dim3((unsigned)(tiles * ksplit)), dim3(256), 0, ctx->stream>>>(
             pw + first_row_graph * f->n_cols_wide_pad, pw + col_lo * f->n_cols_wide_pad, f->n_cols_wide_pad,
-            (int)(f->n_cols_wide_pad / GD_BK), f->selfk, K, M, NC, row_lo, f->symmetric ? 1 : 0, f->n_fit, 0, tiles_n, 1,
-            ldk, col_lo);
+            k_tiles, f->selfk, K, M, NC, row_lo, f->symmetric ? 1 : 0, f->n_fit, 0, tiles_n, 1,
+            ldk, col_lo, tri64, ksplit);
     }
     if (has_low && folded) {
         // applied inside the tile kernel; what did not fit its tile's bucket (usually nothing) follows here

@@ -89,6 +89,7 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             atomics + a normalisation pass afterwards: 0 when it pays, 1 whenever legal, 2 never)
  *             "gram.pair_cap" (test hook: capacity of the per-tile pair buckets of that fold-in)
  *             "gram.no_split8" (labels with counts above 127 in a float64 side operand instead of split int8 columns)
+ *             "gram.no_split64" (the float64 side product with one workgroup per tile: its K loop is not split)
  *             "gram.no_compact" (host copies of integer-valued matrices as plain float64 instead of uint16 / int32 + widening)
  *             "gram.copy_threads" (host threads of that widening; 0: min(hardware threads, 32))
  *             "gram.no_tri" (a WHOLE symmetric matrix bound for the host normally crosses PCIe as the 256 x 256 blocks on and
