@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
 #define SPR_THREADS 1024
 #define SPR_T 8192                  // LDS table slots (key + count)
 #define SPR_COLS 16384              // column terms d1 * label staged in LDS up to this many vertices
-#define SPR_UNIT (256 * 1024)       // matrix entries per unit
+#define SPR_UNIT (128 * 1024)       // matrix entries per unit (measured: 64 k .. 1 M, REDDIT- and D&D-like)
 
 struct SpUnit { i32 g, r0, r1, row; };
 
@@ -1196,7 +1196,7 @@ __device__ __forceinline__ void spr_add(i32 key, u32 c, i32* keys, u32* co, u32 
 }
 
 __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSource S, const SpUnit* __restrict__ units, u32* __restrict__ rows,
-                                                                    i64 Q, int slots) {
+                                                                    i64 Q, int slots, int min_run) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // keys[slots] | counts[slots] | column terms[min(n, SPR_COLS)]
     __shared__ u32 n_ent_s;
     const SpUnit un = units[blockIdx.x];
@@ -1232,15 +1232,17 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSour
                 i32 key = -1;
                 if (j < n && j != i && x[u] < SPH_INF)
                     key = (i32)(rowterm + (col_in_lds ? colterm[j] : (S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u)) + (u32)x[u]);
-                // lanes with the same key first add themselves up: 64 LDS atomics on one address serialise, and in a thread
-                // with a hub most of a row IS one key (leaf, leaf, 2)
+                // lanes with the same key CAN add themselves up first (runs of min_run lanes and more) -- in a thread with a
+                // hub most of a row is one key (leaf, leaf, 2) and 64 LDS atomics on one address serialise.  Measured: they
+                // serialise in ~64 cycles, a round of ballot + single-lane insert is an LDS round trip of its own per run --
+                // REDDIT-like 3.7 ms with merging from 8 lanes on, 2.5 ms without.  Default: off (min_run = 65).
                 u64 act = __ballot(key >= 0);
                 while (act) {
                     const int first = __ffsll((unsigned long long)act) - 1;
                     const i32 k0 = __shfl(key, first, 64);
                     const u64 m = __ballot(key == k0) & act;
                     const int c = __popcll(m);
-                    if (c < 8) break;                                  // no run worth a round of its own
+                    if (c < min_run) break;                            // no run worth a round of its own
                     if (lane == first) spr_add(k0, (u32)c, keys, co, tmask, t_cap, &n_ent_s, row, S.idtab);
                     if (key == k0) key = -1;
                     act &= ~m;
@@ -1436,7 +1438,7 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
         const i64 cols = std::min<i64>(pb->sp_max_nodes > 0 ? pb->sp_max_nodes : 1, SPR_COLS);
         const size_t lds1 = (size_t)slots * 8 + (size_t)cols * 4;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_count_kernel, (int)lds1));
-        sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots);
+        sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots, ctx->opt.sp_hist_run > 0 ? ctx->opt.sp_hist_run : 65);
         const size_t lds2 = (size_t)R.bins * 2;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_compact_kernel, (int)lds2));
         SpRowsOut O{ent.p, cnt.p, ent_n.p, f->selfk, part.p, wgmeta.p};

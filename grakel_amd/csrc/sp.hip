@@ -24,6 +24,25 @@ int gk_dictionary_from_keys(gk_ctx* ctx, const u64* keys, i64 n, int key_bits, i
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
 
+// size classes of the bit-parallel breadth-first search (sp_msbfs_kernel, further down)
+#define SPB_HUB_DEG 32
+#define SPB_HUB_CAP 512
+#define SPB_LDS_MAX (149 * 1024)        // dynamic LDS of a workgroup (the static hub arrays take 10 KiB more)
+#define SPB_LDS0 (42 * 1024)
+#define SPB_LDS1 (69 * 1024)
+#define SPB_OVERFLOW 0xffffffffu
+__host__ __device__ static inline int spb_class(int n, int m) {
+    const long n8 = (n + 7) & ~7, need = 2l * m;
+    // per vertex: two words of G bits + G distance bytes + 4 bytes of padding (SPB row stride)
+    if (n <= 512 && 84 * n8 + need <= SPB_LDS0) return 0;
+    if (n <= 1024 && 84 * n8 + need <= SPB_LDS1) return 1;
+    if (n <= 2048 && 84 * n8 + need <= SPB_LDS_MAX) return 2;
+    if (n <= 4096 && 44 * n8 + need <= SPB_LDS_MAX) return 3;
+    if (24 * n8 <= SPB_LDS_MAX) return 4;
+    return 5;
+}
+#define SPB_MAX_N (SPB_LDS_MAX / 24 / 8 * 8)
+
 static int sp_fw_cap() {
     // largest n with n*(n|1)*4 bytes <= 160 KiB
     int n = 1;
@@ -463,13 +482,18 @@ __global__ __launch_bounds__(64 * SP_REG_WAVES) void sp_fw_pk_kernel(
 
 // packed-kernel classes: 0..3 = (0,16] (16,32] (32,48] (48,64]; 4..7 = (64,80] (80,96] (96,112] (112,128]; 8 = up to the LDS
 // cap; 9 = beyond
-__global__ void sp_bin_pk_kernel(const i32* __restrict__ graph_ptr, i64 n_graphs, int cap, u32* __restrict__ cls_count,
+__global__ void sp_bin_pk_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, i64 n_graphs, int cap, u32* __restrict__ cls_count,
                                  i32* __restrict__ cls_list) {
     const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    int c = -1;
+    int c = -1, bc = -1;
     if (g < n_graphs) {
         const int n = graph_ptr[g + 1] - graph_ptr[g];
         c = n <= 0 ? 0 : (n <= 128 ? (n - 1) >> 4 : (n <= cap ? 8 : 9));
+        if (c == 9) {
+            const int m = row_ptr[graph_ptr[g + 1]] - row_ptr[graph_ptr[g]];
+            atomicMax(&cls_count[10], (u32)m);           // most adjacency entries of a large graph
+            bc = spb_class(n, m);                         // which breadth-first search kernel takes it (unit weights)
+        }
     }
     for (int k = 0; k < 10; ++k) {
         const u64 m = __ballot(c == k);
@@ -479,6 +503,15 @@ __global__ void sp_bin_pk_kernel(const i32* __restrict__ graph_ptr, i64 n_graphs
         if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cls_count[k], (u32)__popcll(m));
         base = __shfl(base, (int)__builtin_ctzll(m), 64);
         if (c == k) cls_list[(i64)k * n_graphs + base + __popcll(m & ((1ull << lane) - 1ull))] = (i32)g;
+    }
+    for (int k = 0; k < 6; ++k) {                         // lists 10..15, counts 11..16: class 9 again, by search class
+        const u64 m = __ballot(bc == k);
+        if (!m) continue;
+        const int lane = threadIdx.x & 63;
+        u32 base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cls_count[11 + k], (u32)__popcll(m));
+        base = __shfl(base, (int)__builtin_ctzll(m), 64);
+        if (bc == k) cls_list[(i64)(10 + k) * n_graphs + base + __popcll(m & ((1ull << lane) - 1ull))] = (i32)g;
     }
 }
 
@@ -518,13 +551,18 @@ __global__ __launch_bounds__(64 * SP_REG_WAVES) void sp_fw_reg_kernel(
 
 // size classes of the graphs: lists for the register kernel (classes 0..7), the LDS kernel (8: 64 < n <= cap) and the
 // row-relaxation kernel (9: n > cap).  cls_count[10]; lists are n_graphs apart.  Wave-aggregated appends.
-__global__ void sp_bin_kernel(const i32* __restrict__ graph_ptr, i64 n_graphs, int cap, u32* __restrict__ cls_count,
+__global__ void sp_bin_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, i64 n_graphs, int cap, u32* __restrict__ cls_count,
                               i32* __restrict__ cls_list) {
     const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    int c = -1;
+    int c = -1, bc = -1;
     if (g < n_graphs) {
         const int n = graph_ptr[g + 1] - graph_ptr[g];
         c = n <= 0 ? 0 : (n <= SP_REG_MAX_N ? (n - 1) >> 3 : (n <= cap ? 8 : 9));
+        if (c == 9) {
+            const int m = row_ptr[graph_ptr[g + 1]] - row_ptr[graph_ptr[g]];
+            atomicMax(&cls_count[10], (u32)m);           // most adjacency entries of a large graph
+            bc = spb_class(n, m);                         // which breadth-first search kernel takes it (unit weights)
+        }
     }
     for (int k = 0; k < 10; ++k) {
         const u64 m = __ballot(c == k);
@@ -534,6 +572,15 @@ __global__ void sp_bin_kernel(const i32* __restrict__ graph_ptr, i64 n_graphs, i
         if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cls_count[k], (u32)__popcll(m));
         base = __shfl(base, (int)__builtin_ctzll(m), 64);
         if (c == k) cls_list[(i64)k * n_graphs + base + __popcll(m & ((1ull << lane) - 1ull))] = (i32)g;
+    }
+    for (int k = 0; k < 6; ++k) {                         // lists 10..15, counts 11..16: class 9 again, by search class
+        const u64 m = __ballot(bc == k);
+        if (!m) continue;
+        const int lane = threadIdx.x & 63;
+        u32 base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cls_count[11 + k], (u32)__popcll(m));
+        base = __shfl(base, (int)__builtin_ctzll(m), 64);
+        if (bc == k) cls_list[(i64)(10 + k) * n_graphs + base + __popcll(m & ((1ull << lane) - 1ull))] = (i32)g;
     }
 }
 
@@ -590,116 +637,170 @@ __global__ __launch_bounds__(SP_THREADS) void sp_relax_kernel(
     block_count_max(cnt, mx, &pair_count[g], maxd);
 }
 
-// Unit weights, graphs above the Floyd-Warshall LDS cap (round 5): BIT-PARALLEL breadth-first search, 64 targets at a time.
-// Grid (graph of size class 9, group of 64 columns).  Bit t of visit[u] says "u reaches column gbase + t"; a sweep is
+struct SpDist {
+    Tmp<u64> sq, dist_ptr, total;
+    Tmp<i32> dist, wdev, esrc;
+    Tmp<u32> pair_count, maxd;
+    explicit SpDist(gk_ctx* c) : sq(c), dist_ptr(c), total(c), dist(c), wdev(c), esrc(c), pair_count(c), maxd(c) {}
+};
+
+// Unit weights, graphs above the Floyd-Warshall LDS cap (round 5): BIT-PARALLEL breadth-first search, G targets at a time.
+// Grid (graph of size class 9, group of G columns).  Bit t of visit[u] says "u reaches column gbase + t"; a sweep is
 //     next[u] = OR over the out-neighbours v of u of front[v],  minus what u reached before
-// -- a pull over u's own adjacency row, no atomics -- and what is new at sweep k is d[u][gbase + t] = k, stored by a wave as
-// ONE 256-byte segment of row u (lane = bit).  One machine word does the work of 64 row relaxations: the relaxation kernel
-// below sweeps all m adjacency entries once per source and distance level (REDDIT-like: 13 levels x 2.3 n entries per
-// source, 11.5 ms; D&D-like: 26 x 5 n, 13.3 ms).  A thread owns up to SPB_VPT vertices of a degree up to SPB_HUB_DEG; hubs
-// (a thread with 2 500 answers to one user) are OR-reduced by a wave each.  Two words of LDS per vertex: n <= SPB_MAX_N.
-#define SPB_THREADS 1024
-#define SPB_MAX_N 8192
-#define SPB_VPT (SPB_MAX_N / SPB_THREADS)
-#define SPB_HUB_DEG 32
-#define SPB_HUB_CAP 1024
-__global__ __launch_bounds__(SPB_THREADS) void sp_msbfs_kernel(
+// -- a pull over u's own adjacency row, no atomics -- and what is new at sweep k is d[u][gbase + t] = k.  One machine word
+// does the work of G row relaxations: the relaxation kernel below sweeps all m adjacency entries once per source and
+// distance level (REDDIT-like: 13 levels x 2.3 n entries per source, 11.5 ms; D&D-like: 26 x 5 n, 13.3 ms).  A thread owns
+// up to SPB_VPT vertices of a degree up to SPB_HUB_DEG; hubs (a thread with 2 500 answers to one user) are OR-reduced by a
+// wave each.
+// The distances of the group are collected in LDS as BYTES (n x G) and leave as whole row segments when the search is
+// over: written level by level straight to HBM every 256-byte segment was touched three or four times with a few lanes
+// each, far apart in time -- 35 M partial stores for 2.6 GB of matrix (5.9 ms, REDDIT-like).  n x G bytes + two words per
+// vertex bound the group width: G = 64, 32 or 16 columns by graph size (spb_class; the relaxation kernel beyond 6 352 vertices).
+// A search that would need level 255 raises maxd to 0xffffffff: the host repeats the job with the relaxation kernel.
+// The graph's adjacency entries (local column numbers, 16 bits) are staged in LDS too when there is room (cols_cap).
+// Size classes (threads, vertices per thread, columns per word).  A graph takes the first class whose LDS holds its
+// vertex arrays AND its adjacency entries (without them a hub's wave walks 24 dependent L2 round trips per sweep while
+// fifteen waves wait at the barrier: 215 us per workgroup on a 3 000-vertex thread, 30 us with the entries in LDS); the
+// workgroups of the small classes share a CU (one class for everything up to 1 907 vertices left the many 300-vertex
+// graphs of a set with one workgroup of mostly idle threads per CU).
+//   class 0: n <= 512,  64 columns, 512 threads,  42 KiB (three per CU)     class 3: n <= 4 096, 32 columns, 149 KiB
+//   class 1: n <= 1 024, 64 columns, 1 024 threads, 69 KiB (two per CU)     class 4: 20 n bytes <= 149 KiB, 16 columns; the
+//   class 2: n <= 2 048, 64 columns, 149 KiB                                         entries in LDS only if they fit
+//   class 5: the relaxation kernel
+template <typename W, int G, int NT, int VPT, int CLS>
+__global__ __launch_bounds__(NT) void sp_msbfs_kernel(
     const i32* __restrict__ big_list, const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
-    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd, int n_lo, int n_hi) {
-    extern __shared__ __attribute__((aligned(16))) u64 spb_lds[];     // visit[n] | front[n]
+    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd, int n_lo,
+    int lds_bytes, int use_cols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char spb_raw[];   // visit[n8] | front[n8] | d8[n8][G] | cols[m]
     __shared__ u64 hub_nx[SPB_HUB_CAP];
-    __shared__ i32 hub_id[SPB_HUB_CAP];
+    __shared__ i32 hub_id[SPB_HUB_CAP], hub_e0[SPB_HUB_CAP], hub_dg[SPB_HUB_CAP];
     __shared__ u32 n_hubs_s;
     const int g = big_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const i32 v0 = graph_ptr[g];
     const int n = graph_ptr[g + 1] - v0;
-    const int gbase = blockIdx.y * 64;
-    if (n <= n_lo || n > n_hi || gbase >= n) return;
-    u64* visit = spb_lds;
-    u64* front = spb_lds + n;
+    const int gbase = blockIdx.y * G;
+    if (n <= n_lo || gbase >= n) return;
+    const i32 eg = row_ptr[v0];
+    const int m = row_ptr[v0 + n] - eg;
+    if (spb_class(n, m) != CLS) return;
+    constexpr int GS = G + 4;                                         // row stride of d8: lanes = consecutive vertices, and a stride of
+    const int n_words = (n + 7) & ~7;                                 // 64 bytes put all of them on two LDS banks
+    W* visit = (W*)spb_raw;
+    W* front = visit + n_words;
+    unsigned char* d8 = (unsigned char*)(front + n_words);
+    unsigned short* cols = (unsigned short*)(d8 + (size_t)n_words * GS);
+    const bool in_lds = use_cols && (long)n_words * (2 * (long)sizeof(W) + GS) + 2l * m <= (long)lds_bytes;   // workgroup-uniform
+    if (in_lds)
+        for (int e = tid; e < m; e += NT) cols[e] = (unsigned short)(col_idx[eg + e] - v0);
+    for (int q = tid; q < n * (GS / 4); q += NT) ((u32*)d8)[q] = 0xffffffffu;   // 255: not reached
     if (tid == 0) n_hubs_s = 0;
     __syncthreads();
-    i32 e0[SPB_VPT], dg[SPB_VPT];                                     // dg < 0: not this thread's to pull (beyond n, or a listed hub)
+    i32 e0[VPT], dg[VPT];                                     // dg < 0: not this thread's to pull (beyond n, or a listed hub)
 #pragma unroll
-    for (int k = 0; k < SPB_VPT; ++k) {
-        const int u = tid + k * SPB_THREADS;
+    for (int k = 0; k < VPT; ++k) {
+        const int u = tid + k * NT;
         e0[k] = 0, dg[k] = -1;
         if (u < n) {
-            e0[k] = row_ptr[v0 + u];
-            int d = row_ptr[v0 + u + 1] - e0[k];
+            e0[k] = row_ptr[v0 + u] - eg;
+            int d = row_ptr[v0 + u + 1] - eg - e0[k];
             if (d > SPB_HUB_DEG) {
                 const u32 slot = atomicAdd(&n_hubs_s, 1u);
-                if (slot < (u32)SPB_HUB_CAP) hub_id[slot] = u, d = -1;
+                if (slot < (u32)SPB_HUB_CAP) hub_id[slot] = u, hub_e0[slot] = e0[k], hub_dg[slot] = d, d = -1;
             }
             dg[k] = d;
-            const u64 bit = (u >= gbase && u < gbase + 64) ? 1ull << (u - gbase) : 0ull;
+            W bit = 0;
+            if (u >= gbase && u < gbase + G) bit = (W)((W)1 << (u - gbase)), d8[u * GS + (u - gbase)] = 0;
             visit[u] = bit, front[u] = bit;
         }
     }
     __syncthreads();
     const int n_hubs = n_hubs_s < (u32)SPB_HUB_CAP ? (int)n_hubs_s : SPB_HUB_CAP;
-    i32* dgm = dist + dist_ptr[g];
+    const i32* cg = col_idx + eg;
     u32 cnt = 0, mx = 0;
     for (int level = 1;; ++level) {
-        u64 nx[SPB_VPT];
+        W nx[VPT];
 #pragma unroll
-        for (int k = 0; k < SPB_VPT; ++k) {
+        for (int k = 0; k < VPT; ++k) {
             nx[k] = 0;
             if (dg[k] >= 0) {
-                u64 acc = 0;
-                for (int e = 0; e < dg[k]; ++e) acc |= front[col_idx[e0[k] + e] - v0];
-                nx[k] = acc & ~visit[tid + k * SPB_THREADS];
+                W acc = 0;
+                if (in_lds)
+                    for (int e = 0; e < dg[k]; ++e) acc |= front[cols[e0[k] + e]];
+                else
+                    for (int e = 0; e < dg[k]; ++e) acc |= front[cg[e0[k] + e] - v0];
+                nx[k] = (W)(acc & ~visit[tid + k * NT]);
             }
         }
-        for (int h = w; h < n_hubs; h += SPB_THREADS / 64) {
-            const int u = hub_id[h];
-            const i32 eh = row_ptr[v0 + u];
-            const int dh = row_ptr[v0 + u + 1] - eh;
+        for (int h = w; h < n_hubs; h += NT / 64) {
+            const int u = hub_id[h], eh = hub_e0[h], dh = hub_dg[h];
             u64 acc = 0;
-            for (int e = lane; e < dh; e += 64) acc |= front[col_idx[eh + e] - v0];
+            if (in_lds) {
+                int e = lane;
+                for (; e + 192 < dh; e += 256)                        // four independent LDS chains in flight
+                    acc |= (u64)(front[cols[eh + e]] | front[cols[eh + e + 64]] | front[cols[eh + e + 128]] | front[cols[eh + e + 192]]);
+                for (; e < dh; e += 64) acc |= (u64)front[cols[eh + e]];
+            } else
+                for (int e = lane; e < dh; e += 64) acc |= (u64)front[cg[eh + e] - v0];
             for (int off = 32; off > 0; off >>= 1) acc |= __shfl_xor(acc, off, 64);
-            if (lane == 0) hub_nx[h] = acc & ~visit[u];
+            if (lane == 0) hub_nx[h] = acc & ~(u64)visit[u];
         }
         __syncthreads();                                              // every read of front[] is done
         int any = 0;
 #pragma unroll
-        for (int k = 0; k < SPB_VPT; ++k) {
-            const int u = tid + k * SPB_THREADS;
+        for (int k = 0; k < VPT; ++k) {
+            const int u = tid + k * NT;
             if (dg[k] >= 0) {
                 front[u] = nx[k];
-                if (nx[k]) visit[u] |= nx[k], any = 1, cnt += (u32)__popcll(nx[k]);
-            }
-            u64 mask = __ballot(nx[k] != 0);                          // the rows of this wave with news: one segment store each
-            while (mask) {
-                const int l = __ffsll((unsigned long long)mask) - 1;
-                mask &= mask - 1;
-                const u64 x = __shfl(nx[k], l, 64);
-                const int uu = (tid & ~63) + l + k * SPB_THREADS;
-                if ((x >> lane) & 1ull) dgm[(size_t)uu * n + gbase + lane] = level;
+                if (nx[k]) {
+                    visit[u] |= nx[k], any = 1, cnt += (u32)__popcll((u64)nx[k]);
+                    u64 x = (u64)nx[k];
+                    while (x) {
+                        const int t = __ffsll((unsigned long long)x) - 1;
+                        x &= x - 1;
+                        d8[u * GS + t] = (unsigned char)level;
+                    }
+                }
             }
         }
-        for (int h = w; h < n_hubs; h += SPB_THREADS / 64) {
+        for (int h = w; h < n_hubs; h += NT / 64) {
             const u64 x = hub_nx[h];
             const int u = hub_id[h];
             if (lane == 0) {
-                front[u] = x;
-                if (x) visit[u] |= x, any = 1, cnt += (u32)__popcll(x);
+                front[u] = (W)x;
+                if (x) visit[u] |= (W)x, any = 1, cnt += (u32)__popcll(x);
             }
-            if ((x >> lane) & 1ull) dgm[(size_t)u * n + gbase + lane] = level;
+            if (lane < G && ((x >> lane) & 1ull)) d8[u * GS + lane] = (unsigned char)level;
         }
         if (!__syncthreads_or(any)) break;
         mx = (u32)level;
+        if (level == 254) {                                           // level 255 is the "not reached" byte
+            if (tid == 0) atomicMax(maxd, SPB_OVERFLOW);
+            return;
+        }
     }
-    // what no sweep reached, and the diagonal
-    for (int u = w; u < n; u += SPB_THREADS / 64) {
-        const u64 vis = visit[u];
-        const int t = gbase + lane;
-        if (t < n) {
-            if (t == u) dgm[(size_t)u * n + t] = 0;
-            else if (!((vis >> lane) & 1ull)) dgm[(size_t)u * n + t] = SP_INF;
+    // the group's columns of every row: whole segments, once
+    i32* dgm = dist + dist_ptr[g];
+    constexpr int RPW = 64 / G;                                       // rows per wave and trip
+    const int t = lane % G, col = gbase + t;
+    for (int u = w * RPW + lane / G; u < n; u += (NT / 64) * RPW) {
+        if (col < n) {
+            const unsigned char x = d8[u * GS + t];
+            dgm[(size_t)u * n + col] = x == 255 ? SP_INF : (i32)x;
         }
     }
     block_count_max(cnt, mx, &pair_count[g], maxd);
+}
+
+template <typename W, int G, int NT, int VPT, int CLS>
+static int sp_msbfs_launch(gk_ctx* ctx, gk_batch* b, SpDist& s, const i32* list, u32 n_list, int cap, int n_hi, int nmax, int lds) {
+    const int hi = nmax < n_hi ? nmax : n_hi;
+    auto kern = sp_msbfs_kernel<W, G, NT, VPT, CLS>;
+    GK_TRY(gk_func_lds(ctx, (const void*)kern, lds));
+    kern<<<dim3(n_list, (unsigned)cdiv(hi, G)), NT, (size_t)lds, ctx->stream>>>(
+        list, b->graph_ptr, b->row_ptr, b->col_idx, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, cap, lds,
+        ctx->opt.sp_bfs_no_lds_cols ? 0 : 1);
+    return GK_OK;
 }
 
 // Pair items / key marks of a graph in SLABS of SP_SLAB rows, grid (graph, slab): a 5 748-vertex graph (D&D has one) is 33 M
@@ -773,6 +874,25 @@ __global__ __launch_bounds__(SP_THREADS) void sp_mark_kernel(
     if (r0 >= n) return;
     const int r1 = r0 + SP_SLAB < n ? r0 + SP_SLAB : n;
     const i32* dg = dist + dist_ptr[g];
+    if (n >= 48) {
+        // a wave per matrix row (round 5): no division per entry, the row's label term once per row, and a lane does not
+        // look up a key it has just marked (a thread with a hub: most of a row is one key) -- 2.6 -> ms on the REDDIT-like set
+        const int lane = tid & 63;
+        for (int i = r0 + (tid >> 6); i < r1; i += SP_THREADS / 64) {
+            const u64 rowterm = with_labels ? d1 * (u64)(u32)node_label[v0 + i] * n_labels : 0ull;
+            const i32* dr = dg + (size_t)i * n;
+            u64 last = ~0ull;
+            for (int j = lane; j < n; j += 64) {
+                const i32 x = dr[j];
+                if (j == i || x >= SP_INF) continue;
+                const u64 key = rowterm + (with_labels ? d1 * (u64)(u32)node_label[v0 + j] : 0ull) + (u64)x;
+                if (key == last) continue;
+                last = key;
+                if (!present[key]) present[key] = 1;       // same value from every writer
+            }
+        }
+        return;
+    }
     for (i64 idx = (i64)r0 * n + tid; idx < (i64)r1 * n; idx += SP_THREADS) {
         const int i = (int)(idx / n), j = (int)(idx - (i64)i * n);
         const i32 x = dg[idx];
@@ -799,14 +919,8 @@ static int bits_for64(u64 v) {
     return b;
 }
 
-struct SpDist {
-    Tmp<u64> sq, dist_ptr, total;
-    Tmp<i32> dist, wdev, esrc;
-    Tmp<u32> pair_count, maxd;
-    explicit SpDist(gk_ctx* c) : sq(c), dist_ptr(c), total(c), dist(c), wdev(c), esrc(c), pair_count(c), maxd(c) {}
-};
 
-static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, SpDist& s, u64* total_sq) {
+static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, SpDist& s, u64* total_sq, bool no_bfs = false) {
     const i64 N = b->n_graphs;
     GK_TRY(s.sq.alloc(N)); GK_TRY(s.dist_ptr.alloc(N)); GK_TRY(s.total.alloc(1));
     GK_TRY(s.pair_count.alloc(N)); GK_TRY(s.maxd.alloc(1));
@@ -816,24 +930,27 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     GK_TRY(gk_scan_u64(ctx, s.sq.p, s.dist_ptr.p, N, true, s.total.p));
     // size classes (one wave per graph in registers up to 64 vertices, the LDS workgroup form up to the LDS cap, row
     // relaxation beyond): binned on the device, counts read back with the matrix total
-    const int cap = sp_fw_cap();
+    // unit weights: everything above the packed register kernels (128 vertices) goes to the breadth-first search -- the
+    // Floyd-Warshall workgroup kernel spent 1.5 ms on the 130..202-vertex graphs of the REDDIT-like set (n^3 each)
+    const bool bfs = !edge_weight && !no_bfs && !ctx->opt.sp_no_bfs && !ctx->opt.sp_no_reg && !ctx->opt.sp_no_pk;
+    const int cap = bfs ? 128 : sp_fw_cap();
     Tmp<u32> cls_count(ctx);
     Tmp<i32> cls_list(ctx);
-    GK_TRY(cls_count.alloc(16)); GK_TRY(cls_list.alloc((size_t)10 * (size_t)N));
-    GK_TRY(gk_zero_async(ctx, cls_count.p, 64));
+    GK_TRY(cls_count.alloc(32)); GK_TRY(cls_list.alloc((size_t)16 * (size_t)N));
+    GK_TRY(gk_zero_async(ctx, cls_count.p, 128));
     // 16-bit packed registers whenever every finite distance of a graph of up to 128 vertices stays below 0x3fff
     i64 wmax = 1;
     if (edge_weight)
         for (i64 e = 0; e < b->n_edges; ++e) wmax = edge_weight[e] > wmax ? edge_weight[e] : wmax;
     const bool use_pk = wmax <= 128 && !ctx->opt.sp_no_reg && !ctx->opt.sp_no_pk;
-    if (use_pk) sp_bin_pk_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, N, cap, cls_count.p, cls_list.p);
-    else sp_bin_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, N, cap, cls_count.p, cls_list.p);
-    u32 h_cls[10];
+    if (use_pk) sp_bin_pk_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, N, cap, cls_count.p, cls_list.p);
+    else sp_bin_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, N, cap, cls_count.p, cls_list.p);
+    u32 h_cls[17];           // [10]: most adjacency entries of a class-9 graph, [11..16]: class 9 by search class (spb_class)
     {   // one mailbox round trip (a hipMemcpyAsync + stream drain pair costs a staging-copy kernel and ~25 us of idle device)
-        u32 hb[12];
-        GK_TRY(gk_readback2(ctx, (const u32*)s.total.p, 2, cls_count.p, 10, hb));
+        u32 hb[19];
+        GK_TRY(gk_readback2(ctx, (const u32*)s.total.p, 2, cls_count.p, 17, hb));
         *total_sq = (u64)hb[0] | ((u64)hb[1] << 32);
-        for (int k = 0; k < 10; ++k) h_cls[k] = hb[2 + k];
+        for (int k = 0; k < 17; ++k) h_cls[k] = hb[2 + k];
     }
     GK_ARG(*total_sq < (1ull << 31), "ShortestPath: sum of n^2 exceeds int32 item indexing");
     GK_TRY(s.dist.alloc(*total_sq));
@@ -907,27 +1024,31 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
             ++n_launch;
         }
     }
-    // unit weights: bit-parallel breadth-first search up to SPB_MAX_N vertices, the row relaxation beyond (and for weights)
-    int relax_above = cap;
-    if (nmax > cap && h_cls[9] > 0 && !w && !ctx->opt.sp_no_bfs) {
-        const int hi = nmax < SPB_MAX_N ? nmax : SPB_MAX_N;
-        const size_t lds = (size_t)hi * 16;
-        GK_TRY(gk_func_lds(ctx, (const void*)sp_msbfs_kernel, (int)lds));
-        sp_msbfs_kernel<<<dim3((unsigned)h_cls[9], (unsigned)cdiv(hi, 64)), SPB_THREADS, lds, ctx->stream>>>(
-            cls_list.p + (size_t)9 * (size_t)N, b->graph_ptr, b->row_ptr, b->col_idx, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p,
-            cap, SPB_MAX_N);
-        relax_above = SPB_MAX_N;
+    // unit weights: bit-parallel breadth-first search (64 / 32 / 16 columns per word by graph size), the row relaxation
+    // beyond its largest class (and for weights)
+    const i32* relax_list = cls_list.p + (size_t)9 * (size_t)N;
+    u32 relax_n = h_cls[9];
+    if (nmax > cap && h_cls[9] > 0 && !w && !no_bfs && !ctx->opt.sp_no_bfs) {       // (with sp.no_reg / sp.no_pk: above the LDS cap only)
+        // a launch per class over the class' own graph list (one grid over all large graphs left 500 k workgroups that
+        // only found out they had nothing to do -- each holding 149 KiB of LDS, i.e. one at a time per CU: 4.7 ms)
+        const i32* L = cls_list.p + (size_t)10 * (size_t)N;
+        if (h_cls[11]) GK_TRY((sp_msbfs_launch<u64, 64, 512, 1, 0>(ctx, b, s, L, h_cls[11], cap, 512, nmax, SPB_LDS0)));
+        if (h_cls[12]) GK_TRY((sp_msbfs_launch<u64, 64, 1024, 1, 1>(ctx, b, s, L + N, h_cls[12], cap, 1024, nmax, SPB_LDS1)));
+        if (h_cls[13]) GK_TRY((sp_msbfs_launch<u64, 64, 1024, 2, 2>(ctx, b, s, L + 2 * N, h_cls[13], cap, 2048, nmax, SPB_LDS_MAX)));
+        if (h_cls[14]) GK_TRY((sp_msbfs_launch<u32, 32, 1024, 4, 3>(ctx, b, s, L + 3 * N, h_cls[14], cap, 4096, nmax, SPB_LDS_MAX)));
+        if (h_cls[15]) GK_TRY((sp_msbfs_launch<unsigned short, 16, 1024, 8, 4>(ctx, b, s, L + 4 * N, h_cls[15], cap, SPB_MAX_N, nmax, SPB_LDS_MAX)));
+        relax_list = L + 5 * N, relax_n = h_cls[16];
     }
-    if (nmax > relax_above && h_cls[9] > 0) {
+    if (nmax > cap && relax_n > 0) {
         GK_ARG(nmax <= SP_ROW_MAX_N, "ShortestPath: graphs above 32768 vertices are not supported");
         size_t lds = (size_t)nmax * 4;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_relax_kernel, (int)lds));
         GK_ARG(nmax <= 65535, "ShortestPath: grid.y overflow");
         GK_TRY(s.esrc.alloc(b->n_edges > 0 ? b->n_edges : 1));
         sp_edge_src_kernel<<<grid_for(b->n_nodes, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->node_graph, b->row_ptr, s.esrc.p, b->n_nodes);
-        sp_relax_kernel<<<dim3((unsigned)h_cls[9], (unsigned)nmax), SP_THREADS, lds, ctx->stream>>>(
-            cls_list.p + (size_t)9 * (size_t)N, b->graph_ptr, b->row_ptr, b->col_idx, s.esrc.p, w, s.dist_ptr.p, s.dist.p,
-            s.pair_count.p, s.maxd.p, relax_above);
+        sp_relax_kernel<<<dim3((unsigned)relax_n, (unsigned)nmax), SP_THREADS, lds, ctx->stream>>>(
+            relax_list, b->graph_ptr, b->row_ptr, b->col_idx, s.esrc.p, w, s.dist_ptr.p, s.dist.p,
+            s.pair_count.p, s.maxd.p, cap);
     }
     (void)n_launch;
     GK_HIP_CHECK(hipGetLastError());
@@ -1204,22 +1325,24 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
     }
     SpDist s(ctx);
     u64 total_sq = 0;
-    if (weight_f64) GK_TRY(sp_compute_dist_f64(ctx, b, weight_f64, graph_algo, s, &total_sq));
-    else GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq));
     // pair offsets double as the pair batch's graph_ptr[N+1]
     Tmp<u32> ptotal(ctx);
-    void* gpq = nullptr;
-    GK_TRY(gk_dev_alloc(ctx, &gpq, (size_t)(N + 1) * 4));
-    struct PtrGuard { gk_ctx* c; void* p; ~PtrGuard() { if (p) gk_dev_free(c, p); } } gp_guard{ctx, gpq};
-    u32* pair_base = (u32*)gpq;
-    GK_TRY(ptotal.alloc(1));
-    GK_TRY(gk_scan_u32(ctx, s.pair_count.p, pair_base, N, true, ptotal.p));
-    GK_HIP_CHECK(hipMemcpyAsync(pair_base + N, ptotal.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
+    struct PtrGuard { gk_ctx* c; void* p; ~PtrGuard() { if (p) gk_dev_free(c, p); } } gp_guard{ctx, nullptr};
+    GK_TRY(gk_dev_alloc(ctx, &gp_guard.p, (size_t)(N + 1) * 4));
+    u32* pair_base = (u32*)gp_guard.p;
     u32 h_pairs = 0, h_maxd = 0;
-    {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // attempt 1: a breadth-first search ran out of its 8-bit levels (a shortest path of 255 edges) -- once more, the
+        // large graphs by row relaxation
+        if (weight_f64) GK_TRY(sp_compute_dist_f64(ctx, b, weight_f64, graph_algo, s, &total_sq));
+        else GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq, attempt == 1));
+        GK_TRY(ptotal.alloc(1));
+        GK_TRY(gk_scan_u32(ctx, s.pair_count.p, pair_base, N, true, ptotal.p));
+        GK_HIP_CHECK(hipMemcpyAsync(pair_base + N, ptotal.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
         u32 hb[2];
         GK_TRY(gk_readback2(ctx, ptotal.p, 1, s.maxd.p, 1, hb));
         h_pairs = hb[0], h_maxd = hb[1];
+        if (h_maxd != SPB_OVERFLOW) break;
     }
     const u64 d1 = (u64)h_maxd + 1;
     gk_batch* pb = new gk_batch();
@@ -1368,7 +1491,12 @@ extern "C" int gk_sp_debug_apsp(gk_ctx* ctx, gk_batch* b, const int32_t* edge_we
     GK_ARG(graph >= 0 && graph < b->n_graphs && !b->is_pair_batch, "gk_sp_debug_apsp: bad graph index");
     SpDist s(ctx);
     u64 total_sq = 0;
-    GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq));
+    for (int attempt = 0; attempt < 2; ++attempt) {      // as gk_sp_build: the row relaxation when a search overflows its levels
+        GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq, attempt == 1));
+        u32 h_maxd = 0;
+        GK_TRY(gk_readback(ctx, s.maxd.p, &h_maxd, 1));
+        if (h_maxd != SPB_OVERFLOW) break;
+    }
     std::vector<i32> gp(2);
     std::vector<u64> dp(1);
     GK_HIP_CHECK(hipMemcpyAsync(gp.data(), b->graph_ptr + graph, 8, hipMemcpyDeviceToHost, ctx->stream));

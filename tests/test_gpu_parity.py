@@ -909,7 +909,7 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
 
 @pytest.mark.parametrize("route", [(), ("sp.no_hist",), ("sp.no_pk",), ("sp.no_reg",), ("sp.no_hist", "sp.no_reg"),
                                    ("feat.gm_row_lds_max",), ("feat.gm_no_priv",), ("sp.no_hist", "scan.direct_max"),
-                                   ("sp.no_rows",), ("sp.no_bfs",), ("gram.no_split64",), ("gram.no_sym",), ("sp.rows_all",), ("sp.rows_all", "sp.hist_unit=1"),
+                                   ("sp.no_rows",), ("sp.no_bfs",), ("sp.bfs_no_lds_cols",), ("gram.no_split64",), ("gram.no_sym",), ("sp.rows_all",), ("sp.rows_all", "sp.hist_unit=1"),
                                    ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv")],
                          ids=lambda r: "+".join(r) or "default")
 def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
@@ -947,13 +947,14 @@ def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
     assert np.array_equal(gk.ShortestPath().fit_transform(big), O.SPOracle().fit_transform(big))
 
 
-@pytest.mark.parametrize("no_bfs", [0, 1])
+@pytest.mark.parametrize("no_bfs", [0, 1, 2])
 def test_large_unit_weight_graphs_directed_hubs_and_unreachable_pairs(gk, gkopt, no_bfs):
     """Graphs above the Floyd-Warshall LDS cap with unit weights take the bit-parallel breadth-first search (sp.hip:
-    sp_msbfs_kernel; sp.no_bfs = 1: the row relaxation).  What the REDDIT- / D&D-like goldens do not hold: DIRECTED
+    sp_msbfs_kernel; 1: the row relaxation instead, 2: the search with the adjacency entries read from HBM instead of LDS).  What the REDDIT- / D&D-like goldens do not hold: DIRECTED
     adjacency matrices (d[u][v] follows the out-edges of u), a hub above 32 and one above 1 024 neighbours next to
     vertices nothing leads to, more than 1 024 vertices (a thread owns several), isolated vertices."""
-    gkopt("sp.no_bfs", no_bfs)
+    gkopt("sp.no_bfs", 1 if no_bfs == 1 else 0)
+    gkopt("sp.bfs_no_lds_cols", 1 if no_bfs == 2 else 0)
     rs = np.random.RandomState(5)
     G = []
     for n, p in ((230, 0.012), (300, 0.006), (260, 0.02)):
@@ -969,6 +970,13 @@ def test_large_unit_weight_graphs_directed_hubs_and_unreachable_pairs(gk, gkopt,
     G.append([A, dict(enumerate((np.arange(n) % 4).tolist()))])
     K = gk.ShortestPath().fit_transform(G)
     assert np.array_equal(K, O.SPOracle().fit_transform(G))
+    # a path of 300 vertices: distances up to 299, the search keeps its levels in bytes -- it reports the overflow and the
+    # job is repeated with the row relaxation
+    n = 300
+    A = np.zeros((n, n), np.int64)
+    A[np.arange(n - 1), np.arange(1, n)] = A[np.arange(1, n), np.arange(n - 1)] = 1
+    P = G[:2] + [[A, dict(enumerate((np.arange(n) % 2).tolist()))]]
+    assert np.array_equal(gk.ShortestPath().fit_transform(P), O.SPOracle().fit_transform(P))
     assert np.array_equal(gk.ShortestPath(with_labels=False).fit_transform(G), O.SPOracle(with_labels=False).fit_transform(G))
 
 
