@@ -100,8 +100,7 @@ struct gk_opts {
     int sp_bfs_no_lds_cols = 0;  // test hook: the breadth-first search reads the adjacency entries from HBM / L2, not from LDS
     int sp_no_rows = 0;          // histogram form: no per-graph counter rows (a graph whose LDS table overflows sends the job to the pair items)
     int sp_rows_all = 0;         // test hook: every graph with a pair counts through counter rows (default: graphs above 6 144 pairs)
-    int sp_hist_unit = 0;        // test hook: distance-matrix entries per counting workgroup (0: 262 144)
-    int sp_hist_run = 0;         // counting workgroups: lanes of a wave with the same key add themselves up from this many on (0: never)
+    int sp_hist_unit = 0;        // test hook: distance-matrix entries per counting workgroup (0: 131 072)
     int sp_hist_slots = 0;       // test hook: slots of the counting workgroups' LDS table (0: 8 192; a power of two)
     int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)
     int sp_no_reg = 0;           // all-pairs distances of small graphs by the LDS workgroup kernel instead of wave-per-graph registers

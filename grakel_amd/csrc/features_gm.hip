@@ -1196,7 +1196,7 @@ __device__ __forceinline__ void spr_add(i32 key, u32 c, i32* keys, u32* co, u32 
 }
 
 __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSource S, const SpUnit* __restrict__ units, u32* __restrict__ rows,
-                                                                    i64 Q, int slots, int min_run) {
+                                                                    i64 Q, int slots) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // keys[slots] | counts[slots] | column terms[min(n, SPR_COLS)]
     __shared__ u32 n_ent_s;
     const SpUnit un = units[blockIdx.x];
@@ -1219,35 +1219,33 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSour
     for (int i = un.r0 + w; i < un.r1; i += SPR_THREADS / 64) {       // a wave per matrix row: no division per entry
         const u32 rowterm = S.with_labels ? d1 * (u32)S.L * (u32)S.node_label[v0 + i] : 0u;
         const i32* dr = dg + (size_t)i * n;
-        for (int j0 = 0; j0 < n; j0 += 256) {
-            i32 x[4];
+        // eight entries per lane and trip, stage by stage: the distance loads together, then the eight table probes together
+        // (one LDS latency instead of eight in a row -- the kernel is bound by dependent round trips, not by bandwidth or by
+        // atomic conflicts: merging equal keys of a wave first, by run detection or by ballot rounds, made it slower), then
+        // the counts as fire-and-forget atomics; a key that is not where its hash points takes the probing path.
+        for (int j0 = 0; j0 < n; j0 += 512) {
+            i32 x[8], key[8], old[8];
+            u32 h[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int j = j0 + u * 64 + lane;
                 x[u] = j < n ? dr[j] : SPH_INF;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int j = j0 + u * 64 + lane;
-                i32 key = -1;
+                key[u] = -1;
                 if (j < n && j != i && x[u] < SPH_INF)
-                    key = (i32)(rowterm + (col_in_lds ? colterm[j] : (S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u)) + (u32)x[u]);
-                // lanes with the same key CAN add themselves up first (runs of min_run lanes and more) -- in a thread with a
-                // hub most of a row is one key (leaf, leaf, 2) and 64 LDS atomics on one address serialise.  Measured: they
-                // serialise in ~64 cycles, a round of ballot + single-lane insert is an LDS round trip of its own per run --
-                // REDDIT-like 3.7 ms with merging from 8 lanes on, 2.5 ms without.  Default: off (min_run = 65).
-                u64 act = __ballot(key >= 0);
-                while (act) {
-                    const int first = __ffsll((unsigned long long)act) - 1;
-                    const i32 k0 = __shfl(key, first, 64);
-                    const u64 m = __ballot(key == k0) & act;
-                    const int c = __popcll(m);
-                    if (c < min_run) break;                            // no run worth a round of its own
-                    if (lane == first) spr_add(k0, (u32)c, keys, co, tmask, t_cap, &n_ent_s, row, S.idtab);
-                    if (key == k0) key = -1;
-                    act &= ~m;
-                }
-                if (key >= 0) spr_add(key, 1u, keys, co, tmask, t_cap, &n_ent_s, row, S.idtab);
+                    key[u] = (i32)(rowterm + (col_in_lds ? colterm[j] : (S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u)) + (u32)x[u]);
+                h[u] = ((u32)key[u] * 2654435761u) >> 8 & tmask;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) old[u] = key[u] >= 0 ? keys[h[u]] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (key[u] < 0) continue;
+                if (old[u] == key[u]) atomicAdd(&co[h[u]], 1u);
+                else spr_add(key[u], 1u, keys, co, tmask, t_cap, &n_ent_s, row, S.idtab);
             }
         }
     }
@@ -1438,7 +1436,7 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
         const i64 cols = std::min<i64>(pb->sp_max_nodes > 0 ? pb->sp_max_nodes : 1, SPR_COLS);
         const size_t lds1 = (size_t)slots * 8 + (size_t)cols * 4;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_count_kernel, (int)lds1));
-        sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots, ctx->opt.sp_hist_run > 0 ? ctx->opt.sp_hist_run : 65);
+        sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots);
         const size_t lds2 = (size_t)R.bins * 2;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_compact_kernel, (int)lds2));
         SpRowsOut O{ent.p, cnt.p, ent_n.p, f->selfk, part.p, wgmeta.p};

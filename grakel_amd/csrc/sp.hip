@@ -882,13 +882,37 @@ __global__ __launch_bounds__(SP_THREADS) void sp_mark_kernel(
             const u64 rowterm = with_labels ? d1 * (u64)(u32)node_label[v0 + i] * n_labels : 0ull;
             const i32* dr = dg + (size_t)i * n;
             u64 last = ~0ull;
-            for (int j = lane; j < n; j += 64) {
-                const i32 x = dr[j];
-                if (j == i || x >= SP_INF) continue;
-                const u64 key = rowterm + (with_labels ? d1 * (u64)(u32)node_label[v0 + j] : 0ull) + (u64)x;
-                if (key == last) continue;
-                last = key;
-                if (!present[key]) present[key] = 1;       // same value from every writer
+            // eight entries per lane and trip, every stage for all eight before the next: the loop is a chain of dependent
+            // round trips (distance -> label -> presence byte) and one entry per trip left the memory system idle (2.7 ms)
+            for (int j0 = 0; j0 < n; j0 += 512) {
+                i32 x[8];
+                u32 lj[8];
+                u64 key[8];
+                unsigned char seen[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * 64 + lane;
+                    x[u] = j < n ? dr[j] : SP_INF;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * 64 + lane;
+                    lj[u] = (with_labels && j < n) ? (u32)node_label[v0 + j] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * 64 + lane;
+                    key[u] = ~0ull;
+                    if (j < n && j != i && x[u] < SP_INF) {
+                        const u64 k = rowterm + d1 * (u64)lj[u] + (u64)x[u];
+                        if (k != last) key[u] = k, last = k;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) seen[u] = key[u] != ~0ull ? present[key[u]] : (unsigned char)1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (!seen[u]) present[key[u]] = 1;     // same value from every writer
             }
         }
         return;
