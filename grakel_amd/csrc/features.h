@@ -38,4 +38,4 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
 // ShortestPath pair batch in histogram form (common.h: gk_batch::sp_hist): features straight from the distance matrices.
 // GK_ERR_UNSUPPORTED: a graph has more distinct features than the LDS table holds or the operand row is too wide -- the
 // caller materialises the pair items (gk_sp_materialise) and takes the label-major builder.
-int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, int wide_above);
+int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, int wide_above, bool force_rows);

@@ -537,14 +537,19 @@ extern "C" int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, i
     // ---- ShortestPath pair batch in histogram form: per-graph histograms of the distance matrices (features_gm.hip);
     // on a decline the pair items are materialised and the label-major builder below takes over
     if (b->is_pair_batch && b->sp_hist) {
-        r = (n_levels == 1 && level_lo == 0 && kind == GK_FEAT_DOT && !ctx->opt.sp_no_hist) ? gk_features_build_sp(ctx, b, f, prim_max, wide_above) : GK_ERR_UNSUPPORTED;
-        if (r == GK_OK) { *out = f; return GK_OK; }
-        if (r != GK_ERR_UNSUPPORTED) return fail(r);
-        for (void* p : f->arena)
-            if (p) gk_dev_free(ctx, p);
-        f->arena.clear();
-        f->gm = false;
-        if (gk_zero_async(ctx, f->meta, n_meta * 4) != GK_OK) return fail(GK_ERR_HIP);
+        const bool hist_ok = n_levels == 1 && level_lo == 0 && kind == GK_FEAT_DOT && !ctx->opt.sp_no_hist;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            // attempt 1: a table of the one-workgroup-per-graph kernel overflowed in a job that had skipped the counter rows
+            r = hist_ok ? gk_features_build_sp(ctx, b, f, prim_max, wide_above, attempt == 1) : GK_ERR_UNSUPPORTED;
+            if (r == GK_OK) { *out = f; return GK_OK; }
+            if (r != GK_ERR_UNSUPPORTED) return fail(r);
+            for (void* p : f->arena)
+                if (p) gk_dev_free(ctx, p);
+            f->arena.clear();
+            f->gm = false;
+            if (gk_zero_async(ctx, f->meta, n_meta * 4) != GK_OK) return fail(GK_ERR_HIP);
+            if (!hist_ok || ctx->opt.sp_no_rows || ctx->opt.sp_rows_all || b->sp_max_nodes > 128) break;   // the rows were in already
+        }
         if ((r = gk_sp_materialise(ctx, b))) return fail(r);
     }
     // ---- graph batches with small graphs: the graph-major builder (features_gm.hip); it declines (row wider

@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_compact_kernel(const i32*
     for (int t = tid; t < priv_words; t += SPR_THREADS) mine[t] = priv[t];
 }
 
-int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, int wide_above) {
+int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, int wide_above, bool force_rows) {
     const i64 N = pb->n_graphs, V = pb->n_nodes;              // V = pairs = entry slots
     const i64 Q = pb->label_counts.empty() ? 0 : pb->label_counts[0];
     if (V <= 0 || Q <= 0) return GK_ERR_UNSUPPORTED;
@@ -1360,7 +1360,17 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     std::vector<SpUnit> units;
     std::vector<i32> row_graph;
     u32 skip_above = 0xffffffffu;
-    if (!ctx->opt.sp_no_rows && pb->sp_h_node_ptr.size() == (size_t)N + 1 && pb->sp_h_pair_base.size() == (size_t)N + 1) {
+    // A job without a graph above 128 vertices keeps to sp_hist_kernel alone (BASELINE config 4: every graph fits its table,
+    // and the row machinery -- two host copies, three launches -- cost 0.16 of 0.72 ms there); should a table overflow after
+    // all, the caller comes back with force_rows instead of leaving for the pair items.
+    const bool use_rows = !ctx->opt.sp_no_rows && (force_rows || ctx->opt.sp_rows_all || pb->sp_max_nodes > 128);
+    if (use_rows && pb->sp_h_node_ptr.size() != (size_t)N + 1) {       // graph sizes and pair ranges for the host, once per pair batch
+        pb->sp_h_node_ptr.assign((size_t)N + 1, 0), pb->sp_h_pair_base.assign((size_t)N + 1, 0);
+        GK_HIP_CHECK(hipMemcpyAsync(pb->sp_h_node_ptr.data(), pb->sp_node_ptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(pb->sp_h_pair_base.data(), pb->graph_ptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    if (use_rows) {
         skip_above = ctx->opt.sp_rows_all ? 0u : SPH_SMALL_PAIRS;
         const i64 unit = ctx->opt.sp_hist_unit > 0 ? (i64)ctx->opt.sp_hist_unit : (i64)SPR_UNIT;
         for (i64 g = 0; g < N; ++g) {

@@ -874,7 +874,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_mark_kernel(
     if (r0 >= n) return;
     const int r1 = r0 + SP_SLAB < n ? r0 + SP_SLAB : n;
     const i32* dg = dist + dist_ptr[g];
-    if (n >= 48) {
+    if (n >= 256) {
         // a wave per matrix row (round 5): no division per entry, the row's label term once per row, and a lane does not
         // look up a key it has just marked (a thread with a hub: most of a row is one key) -- 2.6 -> ms on the REDDIT-like set
         const int lane = tid & 63;
@@ -1413,15 +1413,7 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
                 gk_set_error("gk_sp_build: %s", hipGetErrorString(hipGetLastError()));
                 return fail(GK_ERR_HIP);
             }
-            // the graph sizes and pair ranges for the host (features_gm.hip cuts large matrices into row units); same sync as nk
-            pb->sp_h_node_ptr.assign((size_t)N + 1, 0), pb->sp_h_pair_base.assign((size_t)N + 1, 0);
-            if (hipMemcpyAsync(pb->sp_h_node_ptr.data(), b->graph_ptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipMemcpyAsync(pb->sp_h_pair_base.data(), pair_base, (size_t)(N + 1) * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
-                gk_set_error("gk_sp_build: %s", hipGetErrorString(hipGetLastError()));
-                return fail(GK_ERR_HIP);
-            }
             if ((r = gk_readback(ctx, nk.p, &h_nk, 1))) return fail(r);
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(GK_ERR_HIP);
             pb->sp_dist = s.dist.p, s.dist.p = nullptr;             // the matrices move into the pair batch
             pb->sp_dist_ptr = s.dist_ptr.p, s.dist_ptr.p = nullptr;
             pb->sp_hist = true, pb->sp_L = (i64)L0, pb->sp_dcap = (i64)d1, pb->sp_keyspace = (i64)keyspace, pb->sp_src_nodes = V;

@@ -980,6 +980,21 @@ def test_large_unit_weight_graphs_directed_hubs_and_unreachable_pairs(gk, gkopt,
     assert np.array_equal(gk.ShortestPath(with_labels=False).fit_transform(G), O.SPOracle(with_labels=False).fit_transform(G))
 
 
+def test_sp_histogram_table_overflow_in_a_job_of_small_graphs(gk):
+    """No graph above 128 vertices: the job counts with one workgroup and one LDS table per graph and skips the counter rows
+    (features_gm.hip).  120 vertices with a label each are ~14 000 pairs with nearly as many distinct (label, label,
+    distance) keys -- more than the table's 6 144: the builder reports the overflow and the job is repeated with counter
+    rows instead of leaving for the pair items."""
+    rs = np.random.RandomState(11)
+    G = []
+    for n in (120, 100, 30):
+        A = (rs.rand(n, n) < 0.06).astype(np.int64)
+        A = np.triu(A, 1)
+        A = A + A.T
+        G.append([A, dict(enumerate(rs.permutation(n).tolist()))])
+    assert np.array_equal(gk.ShortestPath().fit_transform(G), O.SPOracle().fit_transform(G))
+
+
 def test_sp_float_weights_against_reference_goldens(gk):
     """Float edge weights that are integer multiples of a power of two (here 1/8): integer distances in that
     unit on the device, the reference's matrices and float-keyed ``_enum`` (graph.py:1767-1794,
