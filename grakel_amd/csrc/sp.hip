@@ -876,7 +876,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_mark_kernel(
     const i32* dg = dist + dist_ptr[g];
     if (n >= 256) {
         // a wave per matrix row (round 5): no division per entry, the row's label term once per row, and a lane does not
-        // look up a key it has just marked (a thread with a hub: most of a row is one key) -- 2.6 -> ms on the REDDIT-like set
+        // look up a key it has just marked (a thread with a hub: most of a row is one key)
         const int lane = tid & 63;
         for (int i = r0 + (tid >> 6); i < r1; i += SP_THREADS / 64) {
             const u64 rowterm = with_labels ? d1 * (u64)(u32)node_label[v0 + i] * n_labels : 0ull;

@@ -99,7 +99,8 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *   paths:    "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
  *             histograms of the distance matrices),
  *             "sp.no_bfs" (graphs above the Floyd-Warshall LDS cap with unit weights: one row relaxation per source
- *             instead of the bit-parallel breadth-first search over 64 columns at a time),
+ *             instead of the bit-parallel breadth-first search over 64 / 32 / 16 columns at a time),
+ *             "sp.bfs_no_lds_cols" (test hook: that search reads the adjacency entries from HBM / L2, not from LDS),
  *             "sp.no_rows" (histogram form without the counter rows of the large graphs: one workgroup and one LDS table
  *             per graph, a table that overflows sends the whole job to the pair items -- the round-4 form),
  *             "sp.rows_all" / "sp.hist_unit" / "sp.hist_slots" (test hooks of the counter-row route: every graph

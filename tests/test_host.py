@@ -578,6 +578,18 @@ def test_c_abi_exports_every_declared_symbol():
             WeisfeilerLehman(n_iter=1).fit_transform(random_labelled_graphs(3, 3, 5, 0.5, 2, 0))
 
 
+def test_every_context_option_is_documented_in_the_header():
+    """The route / tuning options of a context (api.hip: the name table of gk_set_option) are part of the C ABI's contract:
+    include/gk_hip.h names every one of them, and names none that the library does not know."""
+    src = open(os.path.join(ROOT, "grakel_amd", "csrc", "api.hip")).read()
+    known = set(re.findall(r'\{"([a-z0-9_.]+)",\s*&gk_opts::', src))
+    assert len(known) > 40
+    header = open(os.path.join(ROOT, "include", "gk_hip.h")).read()
+    documented = set(re.findall(r'"((?:wl|feat|gram|sp|scan|transform|debug|sort)\.[a-z0-9_]+|no_mailbox)"', header))
+    assert known - documented == set(), sorted(known - documented)
+    assert documented - known == set(), sorted(documented - known)
+
+
 def test_graph_kernel_dispatcher():
     """grakel/graph_kernels.py:452-554 for the accelerated kernels."""
     from grakel_amd import GraphKernel
