@@ -34,6 +34,7 @@ from grakel.datasets.base import read_data  # noqa: E402
 from grakel_amd.synthetic import er_dataset, nci1_like, random_labelled_graphs  # noqa: E402
 sys.path.insert(0, HERE)
 from small_sets import SMALL_SETS, split, sp_inputs, sp_dyadic_graphs, sp_float_graphs, sp_float_big_graphs  # noqa: E402
+from small_sets import sp_large_unit_graphs, sp_large_unit_paths  # noqa: E402
 
 warnings.filterwarnings("ignore")
 
@@ -392,6 +393,24 @@ def round3():
     print("round3.npz", {k: v.shape for k, v in out.items()})
 
 
+def sp_large_unit():
+    """sp_large_unit.npz: ShortestPath of the real reference on unit-weight graphs above 128 vertices (directed, hubs,
+    unreachable pairs, a 300-vertex path) -- what the breadth-first search of round 5 has to reproduce."""
+    t0 = time.time()
+    G = sp_large_unit_graphs()
+    P = sp_large_unit_paths()
+    out = {"K": as_int(ShortestPath().fit_transform(G)),
+           "K_nolabels": as_int(ShortestPath(with_labels=False).fit_transform(G)),
+           "K_paths": as_int(ShortestPath().fit_transform(P))}
+    sp = ShortestPath()
+    sp.fit(G[:3])
+    out["K_tr"] = as_int(sp.transform(G[3:] + P[2:]))
+    out["ref_seconds"] = np.array([time.time() - t0])
+    np.savez_compressed(os.path.join(HERE, "sp_large_unit.npz"), **out)
+    print("sp_large_unit: sums", int(out["K"].sum()), int(out["K_nolabels"].sum()), int(out["K_paths"].sum()), int(out["K_tr"].sum()),
+          "in %.1f s" % (time.time() - t0))
+
+
 def published_like(only=None):
     """Round-5 fixtures: stand-ins for the TU datasets the reference publishes its running times on
     (grakel_amd/synthetic.py: PUBLISHED_LIKE; doc/benchmarks/evaluation.rst:19-73).  WL-subtree h=5 on the FULL sets
@@ -450,6 +469,7 @@ if __name__ == "__main__":
     ap.add_argument("--only-round3", action="store_true", help="only round3.npz (WL over EdgeHistogram, more than 48 levels)")
     ap.add_argument("--only-float", action="store_true", help="only sp_float.npz (ShortestPath on general float edge weights)")
     ap.add_argument("--only-float-big", action="store_true", help="only sp_float_big.npz (general float weights above 143 vertices, CoreFramework)")
+    ap.add_argument("--only-large-unit", action="store_true", help="only sp_large_unit.npz (unit weights above 128 vertices: directed, hubs, a long path)")
     a = ap.parse_args()
     print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
     if a.only_published is not None:
@@ -463,6 +483,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only_float_big:
         sp_float_big()
+        sys.exit(0)
+    if a.only_large_unit:
+        sp_large_unit()
         sys.exit(0)
     sp_dyadic()
     if a.only_dyadic:
@@ -482,4 +505,4 @@ if __name__ == "__main__":
     round3()
     sp_float()
     sp_float_big()
-
+    sp_large_unit()

@@ -113,3 +113,34 @@ def sp_float_big_graphs(seed=5):
         else:
             out.append([A, lab])
     return out
+
+
+def sp_large_unit_graphs():
+    """Unit-weight graphs ABOVE 128 vertices for the bit-parallel breadth-first search (sp.hip: sp_msbfs_kernel, round 5):
+    three DIRECTED sparse adjacency matrices of 230-300 vertices (d[u][v] follows the out-edges of u; many unreachable
+    pairs), and a 1 300-vertex graph with a vertex of 1 100 out-neighbours, one of 40, a directed chain of 50 and isolated
+    vertices (more than 1 024 vertices: a thread owns several; hubs above 32 and above 1 024 neighbours).  `paths()`: two of
+    the first with an undirected PATH of 300 vertices (distances up to 299: the search keeps its levels in bytes and has to
+    hand the job to the row relaxation)."""
+    rs = np.random.RandomState(5)
+    G = []
+    for n, p in ((230, 0.012), (300, 0.006), (260, 0.02)):
+        A = (rs.rand(n, n) < p).astype(np.int64)
+        np.fill_diagonal(A, 0)
+        G.append([A, dict(enumerate(rs.randint(0, 3, n).tolist()))])
+    n = 1300
+    A = np.zeros((n, n), np.int64)
+    A[0, 100:1200] = 1
+    A[1, 0] = A[1, 60:99] = 1
+    A[np.arange(1200, 1250), np.arange(1201, 1251)] = 1
+    A[150, 1] = A[1250, 1200] = 1
+    G.append([A, dict(enumerate((np.arange(n) % 4).tolist()))])
+    return G
+
+
+def sp_large_unit_paths():
+    G = sp_large_unit_graphs()
+    n = 300
+    A = np.zeros((n, n), np.int64)
+    A[np.arange(n - 1), np.arange(1, n)] = A[np.arange(1, n), np.arange(n - 1)] = 1
+    return G[:2] + [[A, dict(enumerate((np.arange(n) % 2).tolist()))]]

@@ -949,35 +949,26 @@ def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
 
 @pytest.mark.parametrize("no_bfs", [0, 1, 2])
 def test_large_unit_weight_graphs_directed_hubs_and_unreachable_pairs(gk, gkopt, no_bfs):
-    """Graphs above the Floyd-Warshall LDS cap with unit weights take the bit-parallel breadth-first search (sp.hip:
-    sp_msbfs_kernel; 1: the row relaxation instead, 2: the search with the adjacency entries read from HBM instead of LDS).  What the REDDIT- / D&D-like goldens do not hold: DIRECTED
-    adjacency matrices (d[u][v] follows the out-edges of u), a hub above 32 and one above 1 024 neighbours next to
-    vertices nothing leads to, more than 1 024 vertices (a thread owns several), isolated vertices."""
+    """Graphs above 128 vertices with unit weights take the bit-parallel breadth-first search (sp.hip: sp_msbfs_kernel;
+    1: the row relaxation instead, 2: the search with the adjacency entries read from HBM instead of LDS).  What the
+    REDDIT- / D&D-like goldens do not hold (tests/golden/small_sets.py: sp_large_unit_graphs; golden from the real
+    reference in sp_large_unit.npz): DIRECTED adjacency matrices (d[u][v] follows the out-edges of u), a hub above 32 and
+    one above 1 024 neighbours next to vertices nothing leads to, more than 1 024 vertices (a thread owns several),
+    isolated vertices -- and a path of 300 vertices: distances up to 299, the search keeps its levels in bytes, reports
+    the overflow and the job is repeated with the row relaxation."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from small_sets import sp_large_unit_graphs, sp_large_unit_paths
     gkopt("sp.no_bfs", 1 if no_bfs == 1 else 0)
     gkopt("sp.bfs_no_lds_cols", 1 if no_bfs == 2 else 0)
-    rs = np.random.RandomState(5)
-    G = []
-    for n, p in ((230, 0.012), (300, 0.006), (260, 0.02)):
-        A = (rs.rand(n, n) < p).astype(np.int64)
-        np.fill_diagonal(A, 0)
-        G.append([A, dict(enumerate(rs.randint(0, 3, n).tolist()))])
-    n = 1300                                                   # vertex 0: 1 100 out-edges; vertex 1: 40; a directed chain; the rest isolated
-    A = np.zeros((n, n), np.int64)
-    A[0, 100:1200] = 1
-    A[1, 0] = A[1, 60:99] = 1
-    A[np.arange(1200, 1250), np.arange(1201, 1251)] = 1
-    A[150, 1] = A[1250, 1200] = 1
-    G.append([A, dict(enumerate((np.arange(n) % 4).tolist()))])
-    K = gk.ShortestPath().fit_transform(G)
-    assert np.array_equal(K, O.SPOracle().fit_transform(G))
-    # a path of 300 vertices: distances up to 299, the search keeps its levels in bytes -- it reports the overflow and the
-    # job is repeated with the row relaxation
-    n = 300
-    A = np.zeros((n, n), np.int64)
-    A[np.arange(n - 1), np.arange(1, n)] = A[np.arange(1, n), np.arange(n - 1)] = 1
-    P = G[:2] + [[A, dict(enumerate((np.arange(n) % 2).tolist()))]]
-    assert np.array_equal(gk.ShortestPath().fit_transform(P), O.SPOracle().fit_transform(P))
-    assert np.array_equal(gk.ShortestPath(with_labels=False).fit_transform(G), O.SPOracle(with_labels=False).fit_transform(G))
+    z = load_golden("sp_large_unit.npz")
+    G, P = sp_large_unit_graphs(), sp_large_unit_paths()
+    assert np.array_equal(gk.ShortestPath().fit_transform(G), z["K"])
+    assert np.array_equal(gk.ShortestPath(with_labels=False).fit_transform(G), z["K_nolabels"])
+    assert np.array_equal(gk.ShortestPath().fit_transform(P), z["K_paths"])
+    sp = gk.ShortestPath()
+    sp.fit(G[:3])
+    assert np.array_equal(sp.transform(G[3:] + P[2:]), z["K_tr"])
 
 
 def test_sp_histogram_table_overflow_in_a_job_of_small_graphs(gk):

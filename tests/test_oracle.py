@@ -238,6 +238,23 @@ def test_sp_general_float_weights_above_143_vertices_against_reference():
         assert np.array([float(k[2]) for k, _ in keys]).view(np.int64).tolist() == z["enum_dist_bits_" + name].tolist()
 
 
+def test_sp_large_unit_weight_graphs_against_reference():
+    """Round 5 golden (tests/golden/sp_large_unit.npz, from the real reference): unit weights above 128 vertices -- directed
+    adjacency matrices, a vertex of 1 100 out-neighbours, isolated vertices, a path of 300 vertices -- the inputs of the
+    device's bit-parallel breadth-first search (test_gpu_parity.py compares the device with this file and with the oracle)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from small_sets import sp_large_unit_graphs, sp_large_unit_paths
+    z = load_golden("sp_large_unit.npz")
+    G, P = sp_large_unit_graphs(), sp_large_unit_paths()
+    assert np.array_equal(O.SPOracle().fit_transform(G), z["K"])
+    assert np.array_equal(O.SPOracle(with_labels=False).fit_transform(G), z["K_nolabels"])
+    assert np.array_equal(O.SPOracle().fit_transform(P), z["K_paths"])
+    sp = O.SPOracle()
+    sp.fit_transform(G[:3])
+    assert np.array_equal(sp.transform(G[3:] + P[2:]), z["K_tr"])
+
+
 def test_what_general_float_weights_mean_in_the_reference():
     """The reference keys ShortestPath features by the float distance as computed (shortest_path.py:389,412-499): with
     weights like 0.1 the key depends on rounding -- a path 0.1 + 0.2 (0.30000000000000004) and an edge 0.3 are DIFFERENT
