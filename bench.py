@@ -358,6 +358,86 @@ def python_objects(eng, wl, Ku, reps=7):
             "note": "grakel_amd.WeisfeilerLehman(n_iter=%d).fit_transform on %d dict graphs" % (h, N)}
 
 
+def check_sp_matrix(K, name):
+    """The host matrix of ShortestPath(with_labels) on a FULL published-like set against (1) the full-set fixture
+    tests/golden/pub_<name>_sp_full.npz -- checksums, diagonal, row sums, a corner, 20 000 sampled entries; written by
+    oracle/sp_fast.py, which tests/test_oracle.py pins to the real reference -- and (2) pub_<name>_sp_big.npz: the block of
+    the set's LARGEST graphs as grakel 0.1.11 itself computed it.  Raises AssertionError on any difference; -> a record."""
+    gdir = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(gdir, "pub_%s_sp_full.npz" % name))
+    Ki = np.rint(K).astype(np.int64)
+    assert np.array_equal(Ki.astype(np.float64), K), "ShortestPath matrix is not integer valued"
+    assert Ki.shape[0] == int(z["n_graphs"][0]), "not the full set"
+    assert int(Ki.sum()) == int(z["K_sum"][0]) and int(np.trace(Ki)) == int(z["K_trace"][0]) and int(Ki.max()) == int(z["K_max"][0])
+    assert np.array_equal(np.diagonal(Ki), z["diag"]) and np.array_equal(Ki.sum(axis=1), z["row_sums"])
+    assert np.array_equal(Ki[:64, :64], z["K_block"]) and np.array_equal(Ki[z["samp_i"], z["samp_j"]], z["samp_v"])
+    assert np.array_equal(Ki, Ki.T)
+    rec = {"K_sum": int(Ki.sum()), "K_trace": int(np.trace(Ki)), "entries_compared": int(len(z["samp_v"]) + 64 * 64 + 2 * Ki.shape[0]),
+           "equals_full_set_fixture": True, "fixture": "tests/golden/pub_%s_sp_full.npz (oracle/sp_fast.py, pinned to grakel 0.1.11)" % name}
+    big = os.path.join(gdir, "pub_%s_sp_big.npz" % name)
+    if os.path.exists(big):
+        zb = np.load(big)
+        ix = zb["index"]
+        assert np.array_equal(Ki[np.ix_(ix, ix)], zb["K"]), "differs from the real reference on the largest graphs"
+        rec["equals_real_reference_on_largest_graphs"] = True
+        rec["largest_graphs_block"] = "%d x %d, graphs of %s vertices, %.0f s of grakel 0.1.11" % (
+            len(ix), len(ix), zb["sizes"].tolist(), float(zb["ref_seconds"][0]))
+    return rec
+
+
+def published_sp(eng, wl, steps=5):
+    """ShortestPath(with_labels) fit_transform on a FULL published-like set from the packed CSR in HBM: ms, phases, and the
+    matrix asserted against the reference-derived fixtures (check_sp_matrix)."""
+    gb = wl.batch
+    db = eng.upload(gb)
+    sizes = np.diff(gb.graph_ptr).astype(np.float64)
+    N = wl.N
+
+    def step(to_host=False):
+        pb = eng.sp_build(db, None, True)
+        feat = eng.features(pb, 1)
+        K = eng.gram(feat, 0, to_host=to_host)
+        info = dict(n_pairs=pb.n_nodes, n_keys=pb.label_counts[0], dense=feat.n_cols, rare=feat.n_cols_low,
+                    max_count=feat.max_count, operand=feat.operand, gram=eng.gram_stats(feat))
+        return info, feat, pb, K
+
+    t0 = time.perf_counter()
+    info, feat, pb, _ = step()
+    eng.synchronize()
+    first = time.perf_counter() - t0
+    feat.close(), pb.close()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        info, feat, pb, _ = step()
+        feat.close(), pb.close()
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    info, feat, pb, K = step(to_host=True)
+    check = None
+    if wl.full_size and os.path.exists(os.path.join(ROOT, "tests", "golden", "pub_%s_sp_full.npz" % wl.name)):
+        zf = np.load(os.path.join(ROOT, "tests", "golden", "pub_%s_sp_full.npz" % wl.name))
+        assert info["n_keys"] == int(zf["n_features"][0]) and info["n_pairs"] == int(zf["n_pairs"][0]), (info, "feature / pair counts")
+        check = check_sp_matrix(K, wl.name)
+    s, tr = float(K.sum()), float(np.trace(K))
+    del K
+    feat.close(), pb.close()
+    eng.profile(True)
+    info2, feat, pb, _ = step()
+    feat.close(), pb.close()
+    ph = {k: round(eng.profile_get(k)[0], 4) for k in ("sp", "sp_fw", "features", "gram")}
+    eng.profile(False)
+    db.close()
+    ops = float((sizes ** 3).sum())
+    return {"workload": wl.describe.replace("WL-subtree h=5", "ShortestPath(with_labels)"), "graphs": N,
+            "first_call_ms": first * 1e3, "ms_per_fit_transform": dt * 1e3, "graph_pairs_per_s": N * N / dt, "phases_ms": ph,
+            "sum_n3_minplus": ops, "sum_n_times_m_bfs": float((sizes * np.diff(gb.row_ptr).sum() / max(gb.n_nodes, 1)).sum()),
+            "fw_G_minplus_per_s": ops / max(ph["sp_fw"], 1e-6) / 1e6, "pairs": info["n_pairs"], "features": info["n_keys"],
+            "dense_columns": info["dense"], "rare_columns": info["rare"], "max_count": info["max_count"],
+            "operand": info["operand"], "gram_kernel_ms": info["gram"][1],
+            "K_sum": s, "K_trace": tr, "checked_against_reference": check,
+            "reference_publishes": wl.published}
+
+
 def config4_sp(eng, steps=5):
     """BASELINE config 4 stand-in (4110 NCI1-like graphs, ShortestPath): ms per fit_transform from the packed
     CSR in HBM, the all-pairs kernels' min-plus rate against an LDS-bandwidth ceiling, the Gram kernel."""
@@ -889,6 +969,13 @@ def main():
                     out["from_python_objects"] = {"error": repr(e)}
             del Ku
             out["extra"] = {}
+            if a.workload in ("dd", "reddit", "collab") and wl.full_size:
+                try:                                       # asserted against the reference-derived full-set fixtures
+                    out["extra"]["shortest_path"] = published_sp(eng, wl)
+                except AssertionError as e:
+                    raise
+                except Exception as e:
+                    out["extra"]["shortest_path"] = {"error": repr(e)}
             if a.workload == "config3" and wl.full_size:
                 for name, fn in (("config4_sp", lambda: config4_sp(eng)),
                                  ("transform", lambda: transform_bench(eng, wl)),

@@ -574,7 +574,7 @@ def _sp_graph_arrays(gobj, labels, with_labels):
     """-> (n, label_values list or None, src, dst, weight, is_dict) with local vertex indices; is_dict: the reference
     holds this element in its dictionary format (and runs dijkstra on it under algorithm_type="auto", graph.py:652-656)."""
     A = _adjacency_array(gobj)
-    is_dict = 0 if A is not None else (0 if getattr(gobj, "_format", None) == "adjacency" else 1)
+    is_dict = _sp_from_dict_flag(gobj)
     if A is not None:
         if A.shape[0] != A.shape[1]:
             raise ValueError('input matrix must be squared')
@@ -616,10 +616,43 @@ def _sp_graph_arrays(gobj, labels, with_labels):
     return n, vals, ii, jj, ww, is_dict
 
 
+def _sp_from_dict_flag(g):
+    """1 when the reference holds this graph object in its dictionary format (and runs dijkstra on it under
+    algorithm_type="auto", graph.py:652-656), 0 for the adjacency forms -- ONE rule for every ingestion path."""
+    if isinstance(g, np.ndarray) or issparse(g) or type(g) is bytes:
+        return 0
+    if _is_graph_object(g):
+        return 0 if getattr(g, "_format", None) == "adjacency" else 1
+    if type(g) is list and len(g) and type(g[0]) is list:          # rows of numbers: a matrix (graph.py:1564-1580)
+        return 0 if _adjacency_array(g) is not None else 1
+    return 1
+
+
+def _sp_first_shows_weights(X):
+    """Does the FIRST element already show edge weights other than 1?  Then the unit-weight walk below would decline after
+    a pass over (part of) the input and the weighted walk would start over: decide the form once."""
+    try:
+        g = X[0][0]
+        if isinstance(g, np.ndarray):
+            return bool(g.size) and (g.dtype.kind not in "biu" or int(g.max()) > 1 or int(g.min()) < 0)
+        if issparse(g):
+            return True                                            # not a form of the unit-weight walk
+        if type(g) is dict:
+            for k, v in g.items():
+                if type(v) is dict:
+                    return any(w != 1 for w in v.values()) or type(next(iter(v.values()), 1)) is float
+                if type(k) is tuple:
+                    return any(w != 1 for w in g.values())
+                break
+    except Exception:
+        pass
+    return False
+
+
 def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_iterable=TypeError):
     if isinstance(X, GraphBatch):
         return X, None
-    if _gk_ingest is not None and with_labels and type(X) in (list, tuple) and len(X):
+    if _gk_ingest is not None and with_labels and type(X) in (list, tuple) and len(X) and not _sp_first_shows_weights(X):
         # round 5: unit-weight graphs whose vertex set IS the label keys in their (sorted) order -- dict of neighbour lists over
         # 0 .. n-1, `(u, v)`-tuple sets / lists / dicts (the fetch_dataset form), 0/1 adjacency matrices -- take the threaded
         # walks of the WL ingestion (csrc/ingest.c, sp_mode); None: weights, unlabelled or unsorted vertices, ... -> below
@@ -635,7 +668,7 @@ def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_ite
             graph_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
             np.cumsum(sizes, out=graph_ptr[1:])
             col = np.frombuffer(col, dtype=np.int32)
-            fd = np.fromiter((0 if (hasattr(x[0], "shape") or type(x[0]) is bytes) else 1 for x in X), np.uint8, len(X))
+            fd = np.fromiter((_sp_from_dict_flag(x[0]) for x in X), np.uint8, len(X))
             return GraphBatch(graph_ptr, np.frombuffer(row_ptr, dtype=np.int32), col, ids, max(n_labels, 1),
                               edge_weight=np.ones(col.shape[0], np.int32), from_dict=fd), mapping
     if _gk_ingest is not None and len_ok is None and type(X) in (list, tuple) and hasattr(_gk_ingest, "sp_ingest"):
@@ -652,7 +685,7 @@ def sp_batch_from_input(X, with_labels, fitted_labels=None, len_ok=None, not_ite
                 n_labels = (len(fitted_labels) + len(mapping)) if fitted_labels is not None else len(mapping)
             else:
                 ids, mapping, n_labels = np.zeros(int(graph_ptr[-1]), np.int32), {}, 1
-            fd = np.fromiter((1 if isinstance(x[0], dict) else 0 for x in X), np.uint8, len(X))
+            fd = np.fromiter((_sp_from_dict_flag(x[0]) for x in X), np.uint8, len(X))
             return GraphBatch(graph_ptr, np.frombuffer(row_ptr, dtype=np.int32), np.frombuffer(col, dtype=np.int32), ids,
                               max(n_labels, 1), edge_weight=np.frombuffer(w, dtype=np.int32), from_dict=fd), mapping
     msg = 'each element of X must have at least one and at most 3 elements\n'

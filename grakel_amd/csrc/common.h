@@ -222,6 +222,7 @@ struct gk_batch {
     i32* col_idx = nullptr;     // [n_edges]
     i32* node_graph = nullptr;  // [n_nodes]
     i32* big_nodes = nullptr;   // [n_big] nodes with degree > deg_small
+    int wave_sig = 1;           // the batch's route for vertices above deg_small, fixed when the batch is created (option wl.no_wave_sig then): wave-per-vertex kernels (1) or the workgroup kernel + one-thread verifier of rounds 1-4 (0)
     int deg_small = 32;         // WL_DEG_SMALL, or 16 once the batch has any vertex above WL_DEG_SMALL (wl.hip: batch_finish)
     i64 n_big = 0;
     i32 max_degree = 0;

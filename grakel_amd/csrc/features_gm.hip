@@ -1083,8 +1083,10 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
                 }
             }
         }
-        __syncthreads();
-        if (ovf_s || __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {   // more distinct keys than the table holds: the caller falls back
+        // ONE decision per workgroup: another workgroup may raise `overflow` between two threads' loads, and
+        // the two paths below meet different barriers -- the OR over the workgroup is what every thread acts on
+        const int void_job = __syncthreads_or((int)(*(volatile u32*)&ovf_s | __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        if (void_job) {                                   // more distinct keys than the table holds: the caller falls back
             if (tid == 0) { atomicOr(overflow, 1u); ent_n[g] = 0; selfk[g] = 0; }
             continue;
         }

@@ -27,6 +27,7 @@
 // follows -- the normalisation K_ij / sqrt(K_ii K_jj) (weisfeiler_lehman.py:323-328,
 // kernel.py:195-204).
 #include "common.h"
+#include "cpu_budget.h"
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -1688,9 +1689,15 @@ static int gram_copy_out_narrow(gk_ctx* ctx, const double* K_dev, i64 n_entries,
             done[(size_t)c].fetch_add(1, std::memory_order_release);
         }
     };
+    // (the workers read n_thr only after `ready` has been raised: it may still shrink here when thread creation fails --
+    // container pid / ulimit limits --, which must not leave the extern "C" entry point as an exception)
     std::vector<std::thread> pool;
     pool.reserve((size_t)n_thr);
-    for (int w = 0; w < n_thr; ++w) pool.emplace_back(worker, w);
+    try {
+        for (int w = 0; w < n_thr; ++w) pool.emplace_back(worker, w);
+    } catch (...) {}
+    const bool inline_widen = pool.empty();
+    n_thr = inline_widen ? 1 : (int)pool.size();
     int rc = GK_OK;
     auto queue_chunk = [&](int c) -> bool {
         const int slot = c % GC_SLOTS;
@@ -1703,6 +1710,10 @@ static int gram_copy_out_narrow(gk_ctx* ctx, const double* K_dev, i64 n_entries,
     for (int c = 0; c < n_chunks && rc == GK_OK; ++c) {
         if (hipEventSynchronize(ctx->stage_ev[c % GC_SLOTS]) != hipSuccess) { rc = GK_ERR_HIP; break; }
         ready.store(c + 1, std::memory_order_release);
+        if (inline_widen) {
+            widen_slice(stage + (size_t)(c % GC_SLOTS) * per_chunk, out_host + (size_t)c * per_chunk, chunk_len(c));
+            done[(size_t)c].store(1, std::memory_order_release);
+        }
         if (c + GC_SLOTS < n_chunks) {          // the slot is refilled once every thread has widened its slice of chunk c
             for (unsigned spins = 0; done[(size_t)c].load(std::memory_order_acquire) < n_thr; ++spins)
                 if (spins < 4096) _mm_pause(); else std::this_thread::yield();
@@ -1755,40 +1766,8 @@ __global__ __launch_bounds__(256) void gram_pack_tri_kernel(const double* __rest
 // written in 2.7 ms), so: AVX2 rows (4 entries per convert, 32-byte non-temporal stores) when the CPU has it, the mirrored
 // block through eight column buffers (every staging cache line read once per eight columns), blocks handed out one by one
 // from an atomic counter (a diagonal block costs half a mirrored one), and a thread pool that outlives the call.
-// How many host threads may run at once: the hardware threads, the affinity mask, and -- what matters on a shared box -- the
-// CPU quota of the container's cgroup (cpu.max: "1600000 100000" = 16 CPUs on the MI355X boxes of this project, which show
-// 256 hardware threads).  More runnable threads than the quota do not go faster, they get the whole cgroup THROTTLED for the
-// rest of the 100 ms period: with 32 widening threads one call in twenty took 30-36 ms instead of 5 (round 5,
-// profiles/r05_cpu_quota.txt).
-static int host_cpu_budget() {
-    static int cached = 0;
-    if (cached) return cached;
-    int n = (int)std::thread::hardware_concurrency();
-    if (n < 1) n = 1;
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) {
-        const int c = CPU_COUNT(&set);
-        if (c >= 1 && c < n) n = c;
-    }
-    long long quota = 0, period = 0;
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // cgroup v2
-        char a[64];
-        if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0) quota = atoll(a);
-        fclose(f);
-    } else {                                                               // cgroup v1
-        if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(q, "%lld", &quota) != 1) quota = 0; fclose(q); }
-        if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(q, "%lld", &period) != 1) period = 0; fclose(q); }
-    }
-    if (quota > 0 && period > 0) {
-        // two CPUs of the quota stay free for the calling thread (it spins in hipEventSynchronize) and the runtime's own
-        // threads: 16 workers + those were just over a 16-CPU quota, a throttle event (a stall of up to 100 ms) every few calls
-        int c = (int)((quota + period - 1) / period);
-        if (c > 4) c -= 2;
-        if (c >= 1 && c < n) n = c;
-    }
-    cached = n;
-    return n;
-}
+// How many host threads may run at once: cpu_budget.h (shared with ingest.c) -- hardware threads, affinity mask, cgroup quota.
+static int host_cpu_budget() { return gk_cpu_budget(); }
 
 struct GkHostPool {
     std::mutex mu;
@@ -1798,9 +1777,13 @@ struct GkHostPool {
     u64 gen = 0;
     int active = 0, finished = 0;
     bool quit = false;
-    void ensure(int n) {
+    // returns how many threads exist afterwards: std::thread's constructor throws std::system_error when the container's
+    // pid / ulimit limits are reached -- that must not cross the extern "C" boundary; the callers work
+    // with however many threads there are (the blocks are handed out from a counter), down to none (inline widening)
+    int ensure(int n) {
         while ((int)threads.size() < n) {
             const int idx = (int)threads.size();
+            try {
             threads.emplace_back([this, idx] {
                 u64 seen = 0;
                 for (;;) {
@@ -1820,15 +1803,20 @@ struct GkHostPool {
                     cv_done.notify_all();
                 }
             });
+            } catch (...) { break; }
         }
+        return (int)threads.size();
     }
-    void start(int n, std::function<void(int)> f) {
-        ensure(n);
+    // wakes min(n, threads that exist) workers; returns that number
+    int start(int n, std::function<void(int)> f) {
+        const int have = ensure(n);
+        if (have < n) n = have;
         {
             std::lock_guard<std::mutex> lk(mu);
             fn = std::move(f), active = n, finished = 0, ++gen;
         }
-        cv_go.notify_all();
+        if (n > 0) cv_go.notify_all();
+        return n;
     }
     void wait() {
         std::unique_lock<std::mutex> lk(mu);
@@ -1953,15 +1941,8 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
     const double* rsp = nullptr;
     const double* dvp = nullptr;
     auto chunk_blocks = [&](int c) { return (int)std::min<i64>((i64)per_chunk, n_blocks - (i64)c * per_chunk); };
-    auto worker = [&](int) {
-        for (;;) {
-            const i64 p = next_block.fetch_add(1, std::memory_order_relaxed);
-            if (p >= n_blocks) return;
+    auto widen_one = [&](i64 p) {
             const int c = (int)(p / per_chunk), k = (int)(p - (i64)c * per_chunk);
-            for (unsigned spins = 0; ready.load(std::memory_order_acquire) <= c; ++spins) {
-                if (stop.load(std::memory_order_relaxed)) return;
-                if (spins < 4096) _mm_pause(); else std::this_thread::yield();
-            }
             int bi = (int)(std::upper_bound(row_first.begin(), row_first.end(), p) - row_first.begin()) - 1;
             const int bj = bi + (int)(p - row_first[(size_t)bi]);
             const i64 r0 = (i64)bi * GC_TB, c0 = (i64)bj * GC_TB;
@@ -1969,9 +1950,21 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
                                (int)std::min<i64>(GC_TB, N - r0), c0, (int)std::min<i64>(GC_TB, N - c0), bj != bi, rsp, dvp, avx2);
             _mm_sfence();
             done[(size_t)c].fetch_add(1, std::memory_order_release);
+    };
+    auto worker = [&](int) {
+        for (;;) {
+            const i64 p = next_block.fetch_add(1, std::memory_order_relaxed);
+            if (p >= n_blocks) return;
+            const int c = (int)(p / per_chunk);
+            for (unsigned spins = 0; ready.load(std::memory_order_acquire) <= c; ++spins) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                if (spins < 4096) _mm_pause(); else std::this_thread::yield();
+            }
+            widen_one(p);
         }
     };
     int rc = GK_OK;
+    int n_workers = 0;                      // pool threads at work; 0 = none could be created: the caller widens inline
     auto queue_chunk = [&](int c) -> bool {
         const int slot = c % GC_SLOTS;
         return hipMemcpyAsync((char*)ctx->stage_host + (size_t)slot * GC_CHUNK, packed.p + (size_t)c * per_chunk * block_elems,
@@ -1996,10 +1989,14 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
                 }
                 rsp = rs.data(), dvp = dv.data();
             }
-            ctx->host_pool->start(n_thr, worker);
-            started = true;
+            n_workers = ctx->host_pool->start(n_thr, worker);
+            started = n_workers > 0;
         }
         ready.store(c + 1, std::memory_order_release);
+        if (n_workers == 0) {               // no host thread to be had: this chunk's blocks on the calling thread
+            const i64 hi = std::min<i64>(n_blocks, (i64)(c + 1) * per_chunk);
+            for (i64 p = (i64)c * per_chunk; p < hi; ++p) widen_one(p);
+        }
         if (c + GC_SLOTS < n_chunks) {          // the slot is refilled once every block of chunk c is done
             const int need = chunk_blocks(c);
             for (unsigned spins = 0; done[(size_t)c].load(std::memory_order_acquire) < need; ++spins)

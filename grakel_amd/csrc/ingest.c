@@ -180,6 +180,7 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
  * ------------------------------------------------------------------------------------------ */
 #if PY_VERSION_HEX < 0x030C0000
 #include <pthread.h>
+#include "cpu_budget.h"
 #include <stdio.h>
 #include <unistd.h>
 #define GK_PAR_MIN_ELEMENTS 256
@@ -189,33 +190,8 @@ static int neighbour_index(PyObject* nb, int identity, Py_ssize_t n, PyObject* p
                                         * on 1 / 8 / 16 / 32 / 64 threads, adjacency matrices 113 / 18 / 11 / 7.8 / 8.8 ms; the tuple-set walk
                                         * is memory-latency bound (a tuple and two int objects per edge) and keeps scaling: 440 / 93 / 47 /
                                         * 25 / 15 ms -- it takes up to 64 */
-/* runnable threads this process may have at once: online CPUs, the affinity mask, the cgroup's CPU quota (see gram.hip:
- * host_cpu_budget -- more threads than the quota get the whole container throttled for the rest of the 100 ms period) */
-static int cpu_budget(void) {
-    static int cached = 0;
-    if (cached) return cached;
-    long c = sysconf(_SC_NPROCESSORS_ONLN);
-    int n = c > 0 ? (int)c : 1;
-    long long quota = 0, period = 0;
-    FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
-    if (f) {
-        char a[64];
-        if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0) quota = atoll(a);
-        fclose(f);
-    } else {
-        FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
-        if (q) { if (fscanf(q, "%lld", &quota) != 1) quota = 0; fclose(q); }
-        q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
-        if (q) { if (fscanf(q, "%lld", &period) != 1) period = 0; fclose(q); }
-    }
-    if (quota > 0 && period > 0) {
-        int k = (int)((quota + period - 1) / period);
-        if (k > 4) k -= 2;                  /* headroom for the calling thread and the runtime's threads (gram.hip: host_cpu_budget) */
-        if (k >= 1 && k < n) n = k;
-    }
-    cached = n;
-    return n;
-}
+/* runnable threads this process may have at once: cpu_budget.h, shared with gram.hip's widening threads */
+static int cpu_budget(void) { return gk_cpu_budget(); }
 
 typedef struct {
     PyObject* X;

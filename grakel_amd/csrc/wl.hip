@@ -974,7 +974,8 @@ static int batch_finish(gk_ctx* ctx, gk_batch* b) {
     }
     b->max_graph_nodes = (i32)h[0], b->max_degree = (i32)h[1], b->n_big = h[2];
     b->deg_small = WL_DEG_SMALL;
-    if (b->n_big > 0 && !ctx->opt.wl_no_wave_sig) {
+    b->wave_sig = ctx->opt.wl_no_wave_sig ? 0 : 1;      // decided HERE, with deg_small and the big_nodes list it shapes
+    if (b->n_big > 0 && b->wave_sig) {
         // A batch with vertices above WL_DEG_SMALL neighbours is off the route without host round trips anyway; its
         // vertices of 17 .. 32 neighbours then go to the wave-per-vertex kernels as well (the thread-per-vertex kernel sorts
         // up to 16 in registers; beyond it had an insertion sort per thread, or -- in a chunk shared with high degrees -- one
@@ -1298,7 +1299,7 @@ int gk_batch_ensure_levels(gk_batch* b, int n_levels) {
 // nodes of degree > WL_DEG_SMALL: a wave per node up to WAVE_DEG_MAX neighbours, a workgroup per node beyond (hubs);
 // option wl.no_wave_sig keeps everything in the workgroup kernel (rounds 1-4)
 static int launch_signature_big(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash_by_node, u64 seed, u64 mask) {
-    const int wave = ctx->opt.wl_no_wave_sig ? 0 : 1;
+    const int wave = b->wave_sig;
     if (wave)
         wl_signature_wave_kernel<<<grid_for(b->n_big * 64, 256), 256, 0, ctx->stream>>>(
             b->big_nodes, b->n_big, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask);
@@ -1630,7 +1631,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         b->perm_valid[level] = no_order_taken ? 0 : 1;
         // the first attempt of a level finds *unresolved_dev cleared by gk_wl_relabel
         if (exact) GK_TRY(gk_zero_async(ctx, unresolved_dev, 4));
-        const int big_apart = (b->n_big > 0 && !ctx->opt.wl_no_wave_sig) ? b->deg_small : 0;
+        const int big_apart = (b->n_big > 0 && b->wave_sig) ? b->deg_small : 0;
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V,
                                                                   flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr, big_apart);
         if (big_apart)

@@ -174,3 +174,4 @@ class Kernel(BaseEstimator, TransformerMixin):
 
 
 __all__ = ["Kernel", "NotFittedError", "check_is_fitted"]
+

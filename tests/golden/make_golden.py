@@ -459,6 +459,99 @@ def published_like(only=None):
         np.savez_compressed(os.path.join(HERE, "pub_%s.npz" % name), **out)
 
 
+def callers():
+    """callers.npz (round 6): the frameworks SURVEY 8b names as CALLERS of the path, run by the real reference on small
+    sets -- HadamardCode (default base VertexHistogram, hadamard_code.py:19,189; and over ShortestPath), so that a test can
+    drive the accelerated base classes through the same per-level calls and compare matrices."""
+    from grakel import HadamardCode
+    out = dict()
+    for name in ("adj_u", "dense_big"):
+        kw = dict(SMALL_SETS)[name]
+        G = random_labelled_graphs(**kw)
+        tr, te = split(G)
+        hc = HadamardCode(n_iter=3)
+        out[name + "/hc_vh_fit"] = as_int(hc.fit_transform(tr))
+        out[name + "/hc_vh_tr"] = as_int(hc.transform(te))
+        hcn = HadamardCode(n_iter=2, normalize=True)
+        out[name + "/hc_vh_norm_fit"] = hcn.fit_transform(tr)
+        out[name + "/hc_vh_norm_tr"] = hcn.transform(te)
+        hs = HadamardCode(n_iter=2, base_graph_kernel=ShortestPath)
+        out[name + "/hc_sp_fit"] = as_int(hs.fit_transform(tr))
+        out[name + "/hc_sp_tr"] = as_int(hs.transform(te))
+        print("callers", name, "HadamardCode sums", out[name + "/hc_vh_fit"].sum(), out[name + "/hc_vh_tr"].sum(),
+              out[name + "/hc_sp_fit"].sum(), out[name + "/hc_sp_tr"].sum())
+    np.savez_compressed(os.path.join(HERE, "callers.npz"), **out)
+
+
+def sp_big_selection(name, graphs):
+    """Which graphs of a published-like set the REAL reference runs ShortestPath on for pub_<set>_sp_big.npz: the
+    largest ones (D&D-like: the 5 748-vertex giant and the runner-up; REDDIT-like: the ten largest threads) next to a
+    handful of small ones -- sizes the round-5 goldens (at most 700 vertices) never reached."""
+    sizes = np.array([g[0] for g in graphs])
+    order = np.argsort(-sizes, kind="stable")
+    big = order[:2] if name == "dd" else order[:10]
+    small = [k for k in range(len(graphs)) if sizes[k] <= 300 and k not in set(big.tolist())][:6]
+    return np.array(sorted(big.tolist()) + small, np.int64)
+
+
+def published_like_sp_big(only=None):
+    """Round-6 fixtures pub_<set>_sp_big.npz: ShortestPath of the REAL reference (adjacency input -> its Floyd-Warshall,
+    graph.py:1767-1794: n^2 numpy row operations per graph -- minutes per graph of thousands of vertices; pair walk
+    shortest_path.py:468-490) on the largest graphs of the D&D-like and REDDIT-like sets against a few small ones."""
+    from grakel_amd import synthetic as S
+    for name in ("dd", "reddit"):
+        if only and name not in only:
+            continue
+        graphs = S.PUBLISHED_LIKE[name][0]()
+        idx = sp_big_selection(name, graphs)
+        sub = [graphs[k] for k in idx.tolist()]
+        print("published-like", name, "ShortestPath through the real reference on graphs", idx.tolist(),
+              "of", [g[0] for g in sub], "vertices", flush=True)
+        Ga = S.as_grakel(sub, adjacency=True)
+        t0 = time.perf_counter()
+        sp = ShortestPath()
+        Ks = sp.fit_transform(Ga)
+        dt = time.perf_counter() - t0
+        out = dict(index=idx, sizes=np.array([g[0] for g in sub], np.int64), K=as_int(Ks),
+                   n_features=np.array([len(sp._enum)], np.int64), ref_seconds=np.array([dt]))
+        spn = ShortestPath(normalize=True)
+        spn.fit(Ga[-6:])
+        out["Kn_tr"] = spn.transform(Ga[:1])            # the largest-index big graph against the small ones, normalised
+        np.savez_compressed(os.path.join(HERE, "pub_%s_sp_big.npz" % name), **out)
+        print("   ref %.1fs" % dt, "sum", out["K"].sum(), "features", len(sp._enum), flush=True)
+
+
+def published_like_sp_full(only=None):
+    """Round-6 fixtures pub_<set>_sp_full.npz: ShortestPath on the FULL published-like sets.  The real reference needs
+    hours for these (evaluation.rst:25,69), so the numbers come from oracle/sp_fast.py -- the vectorised restatement that
+    tests/test_oracle.py pins to the real reference's matrices (pub_<set>.npz[sp_K], pub_<set>_sp_big.npz) and to the
+    literal oracle.  Stored: checksums, diagonal, row sums, a corner, 20 000 sampled entries, feature / pair counts."""
+    from grakel_amd import synthetic as S
+    from oracle import sp_fast
+    for name in ("dd", "reddit", "collab"):
+        if only and name not in only:
+            continue
+        graphs = S.PUBLISHED_LIKE[name][0]()
+        t0 = time.perf_counter()
+        K, nf, pairs = sp_fast.sp_unit_gram(graphs, progress=200)
+        dt = time.perf_counter() - t0
+        i, j, v = sample_entries(K, 20000, 321)
+        out = dict(n_graphs=np.array([len(graphs)], np.int64), n_features=np.array([nf], np.int64),
+                   n_pairs=np.array([pairs], np.int64), K_sum=np.array([K.sum()], np.int64),
+                   K_trace=np.array([np.trace(K)], np.int64), K_max=np.array([K.max()], np.int64),
+                   diag=np.diagonal(K).copy(), row_sums=K.sum(axis=1), K_block=K[:64, :64].copy(),
+                   samp_i=i, samp_j=j, samp_v=v.astype(np.int64), oracle_seconds=np.array([dt]))
+        big = os.path.join(HERE, "pub_%s_sp_big.npz" % name)
+        if os.path.exists(big):                               # the real reference's block of the same matrix
+            zb = np.load(big)
+            ix = zb["index"]
+            assert np.array_equal(K[np.ix_(ix, ix)], zb["K"]), "sp_fast differs from the real reference on " + name
+            print("   equal to the real reference on the %d x %d block of its largest graphs" % (len(ix), len(ix)))
+        np.savez_compressed(os.path.join(HERE, "pub_%s_sp_full.npz" % name), **out)
+        print("published-like", name, "ShortestPath full set (oracle/sp_fast.py, %.0f s): sum" % dt, K.sum(), "trace",
+              np.trace(K), "max", K.max(), "features", nf, "pairs", pairs, flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip config 3 (~100 s) and NCI1-4110")
@@ -470,8 +563,22 @@ if __name__ == "__main__":
     ap.add_argument("--only-float", action="store_true", help="only sp_float.npz (ShortestPath on general float edge weights)")
     ap.add_argument("--only-float-big", action="store_true", help="only sp_float_big.npz (general float weights above 143 vertices, CoreFramework)")
     ap.add_argument("--only-large-unit", action="store_true", help="only sp_large_unit.npz (unit weights above 128 vertices: directed, hubs, a long path)")
+    ap.add_argument("--only-sp-big", nargs="*", default=None, metavar="SET",
+                    help="only pub_<set>_sp_big.npz (round 6: the real reference's ShortestPath on the largest D&D-/REDDIT-like graphs)")
+    ap.add_argument("--only-sp-full", nargs="*", default=None, metavar="SET",
+                    help="only pub_<set>_sp_full.npz (round 6: full-set ShortestPath checksums from oracle/sp_fast.py)")
+    ap.add_argument("--only-callers", action="store_true", help="only callers.npz (round 6: HadamardCode driving the base kernels)")
     a = ap.parse_args()
     print("reference grakel", grakel.__version__, "from", os.path.dirname(grakel.__file__))
+    if a.only_callers:
+        callers()
+        sys.exit(0)
+    if a.only_sp_big is not None:
+        published_like_sp_big(a.only_sp_big or None)
+        sys.exit(0)
+    if a.only_sp_full is not None:
+        published_like_sp_full(a.only_sp_full or None)
+        sys.exit(0)
     if a.only_published is not None:
         published_like(a.only_published or None)
         sys.exit(0)

@@ -1616,6 +1616,38 @@ def test_core_framework_small_sets(gk, name):
     assert np.array_equal(cf.diagonal()[1], want.y_diag)
 
 
+@pytest.mark.parametrize("name", ["adj_u", "dense_big"])
+def test_caller_protocols_of_hadamard_code_and_core_framework(gk, name):
+    """SURVEY 8b "Callers": the accelerated BASE classes driven exactly as the reference's own frameworks drive them --
+    HadamardCode (hadamard_code.py:189-260: per level a list of `(graph, {vertex: tuple-valued label})` elements to
+    `fit_transform` / `transform`, `diagonal()` of every level for the normalisation) and CoreFramework
+    (core_framework.py:173-219: per core level a list of graph OBJECTS to `fit` / `fit_transform` / `transform`, `diagonal()`
+    after both).  The calling sequences are restated in tests/caller_protocols.py (the GPU box has no reference; on the CPU
+    box tests/test_host.py checks that the REAL frameworks hand the accelerated classes the same batches); the matrices are
+    compared with what the real reference's frameworks computed (tests/golden/callers.npz, small_sets.npz)."""
+    from caller_protocols import CoreCaller, HadamardCaller
+    z, zs = load_golden("callers.npz"), load_golden("small_sets.npz")
+    kw = dict(SMALL_SETS)[name]
+    tr, te = split(random_labelled_graphs(**kw))
+    hc = HadamardCaller(lambda: gk.VertexHistogram(normalize=False, verbose=False, n_jobs=None), 3)
+    assert np.array_equal(hc.fit_transform(tr), z[name + "/hc_vh_fit"])
+    assert np.array_equal(hc.transform(te), z[name + "/hc_vh_tr"])
+    hcn = HadamardCaller(lambda: gk.VertexHistogram(normalize=False, verbose=False, n_jobs=None), 2, normalize=True)
+    assert np.allclose(hcn.fit_transform(tr), z[name + "/hc_vh_norm_fit"], rtol=REL_TOL, atol=0)
+    assert np.allclose(hcn.transform(te), z[name + "/hc_vh_norm_tr"], rtol=REL_TOL, atol=0)
+    hs = HadamardCaller(lambda: gk.ShortestPath(normalize=False, verbose=False, n_jobs=None), 2)
+    assert np.array_equal(hs.fit_transform(tr), z[name + "/hc_sp_fit"])
+    assert np.array_equal(hs.transform(te), z[name + "/hc_sp_tr"])
+    for tag, make in (("sp", lambda: gk.ShortestPath(normalize=False, verbose=False, n_jobs=None)),
+                      ("vh", lambda: gk.VertexHistogram(normalize=False, verbose=False, n_jobs=None))):
+        cc = CoreCaller(make)
+        assert np.array_equal(cc.fit_transform(tr), zs[name + "/core_%s_fit" % tag]), tag
+        assert np.array_equal(cc.transform(te), zs[name + "/core_%s_tr" % tag]), tag
+        want = O.CoreOracle(O.SPOracle if tag == "sp" else O.VHOracle)
+        want.fit_transform(tr), want.transform(te)
+        assert np.array_equal(cc.x_diag, want.x_diag) and np.array_equal(cc.y_diag, want.y_diag), tag
+
+
 # ------------------------------------------------------------------------------------------
 # config 5 (BASELINE.json: 50 000 synthetic n=30 graphs, WL h=5).  The reference cannot run it (six dense
 # 50k x 50k float64 matrices, weisfeiler_lehman.py:269-270), so parity is block-wise: a WL kernel value
@@ -2012,6 +2044,47 @@ def test_published_like_sets_against_reference_goldens(gk, name):
         sp = gk.ShortestPath()
         assert np.array_equal(sp.fit_transform(sub), z["sp_K"])
         assert len(sp._enum) == int(z["sp_n_features"][0])
+
+
+@pytest.mark.parametrize("name", ["dd", "reddit", "collab"])
+def test_published_like_sets_shortest_path_at_full_size(gk, name):
+    """Round 6: ShortestPath(with_labels) on the FULL D&D-, REDDIT-BINARY- and COLLAB-like sets (172 M / 643 M / 36 M vertex
+    pairs; graphs of up to 5 748 vertices: the counter-row, row-slab and 64 / 32 / 16-column breadth-first-search size
+    classes at the sizes the README quotes times for).  The matrix is compared with (1) tests/golden/pub_<set>_sp_full.npz --
+    checksums, diagonal, every row sum, a corner and 20 000 sampled entries of the full matrix, written by oracle/sp_fast.py,
+    which tests/test_oracle.py pins entry for entry to the real reference -- and (2) pub_<set>_sp_big.npz: the block of the
+    set's largest graphs (the 5 748-vertex giant; the ten largest REDDIT-like threads) as grakel 0.1.11 itself computed it
+    in 6.5 / ~ 20 minutes.  Feature and pair counts too (= len(ShortestPath._enum), shortest_path.py:468-490)."""
+    import bench
+    from grakel_amd import GraphBatch, synthetic as S
+    from grakel_amd.engine import get_engine
+    z = load_golden("pub_%s_sp_full.npz" % name)
+    graphs = S.PUBLISHED_LIKE[name][0]()
+    gp, rp, ci, lab, nl = S.as_csr(graphs)
+    eng = get_engine()
+    db = eng.upload(GraphBatch(gp, rp, ci, lab, nl))
+    pb = eng.sp_build(db, None, True)
+    feat = eng.features(pb, 1)
+    K = eng.gram(feat, 0, to_host=True)
+    assert pb.label_counts[0] == int(z["n_features"][0]) and pb.n_nodes == int(z["n_pairs"][0])
+    rec = bench.check_sp_matrix(K, name)
+    assert rec["equals_full_set_fixture"] and (name == "collab" or rec["equals_real_reference_on_largest_graphs"])
+    # normalised, through the same job: within REL_TOL of the reference's formula on the exact integers
+    Kn = eng.gram(feat, 2, to_host=True)
+    d = np.sqrt(np.diagonal(K))
+    assert np.abs(Kn - K / np.outer(d, d)).max() <= REL_TOL and np.all(np.diagonal(Kn) == 1.0)
+    feat.close(), pb.close(), db.close()
+    if name == "collab":
+        return
+    # the estimator on Python objects: the largest graphs against the small ones, as the real reference ran them
+    zb = load_golden("pub_%s_sp_big.npz" % name)
+    ix = zb["index"].tolist()
+    sub = S.as_grakel([graphs[i] for i in ix], adjacency=True)
+    sp = gk.ShortestPath()
+    assert np.array_equal(sp.fit_transform(sub), zb["K"]) and len(sp._enum) == int(zb["n_features"][0])
+    spn = gk.ShortestPath(normalize=True)
+    spn.fit(sub[-6:])
+    assert np.allclose(spn.transform(sub[:1]), zb["Kn_tr"], rtol=REL_TOL, atol=0)
 
 
 def test_transform_of_a_generator_above_the_lookup_threshold(gk):

@@ -6,7 +6,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, reference_available
 from golden.small_sets import SMALL_SETS
 from oracle import grakel_oracle as O
 import grakel_amd
@@ -732,3 +732,66 @@ def test_c_header_is_plain_c_and_the_multi_gpu_stub_type_checks():
     stub = open(src).read()
     for call in re.findall(r"\b(gk_[a-z0-9_]+)\(", section.split("```c")[1].split("```")[0]):
         assert call + "(" in stub, call
+
+
+def _same_batch(a, b):
+    """two fitted batches describe the same graphs with the same label partition (ids may be numbered differently)"""
+    return (np.array_equal(a.graph_ptr, b.graph_ptr) and np.array_equal(a.row_ptr, b.row_ptr) and
+            _adjacency_sets(a) == _adjacency_sets(b) and a.n_labels == b.n_labels and
+            np.array_equal(O.canonical_partition(a.node_label.tolist()), O.canonical_partition(b.node_label.tolist())))
+
+
+@pytest.mark.skipif(not reference_available(), reason="needs the real grakel (oracle/build_ref.sh): build container only")
+def test_the_reference_frameworks_drive_the_accelerated_base_classes():
+    """SURVEY 8b "Callers": the REAL grakel.HadamardCode (hadamard_code.py:19,189), CoreFramework (core_framework.py:199-204)
+    and WeisfeilerLehman (weisfeiler_lehman.py:260-285) are constructed over the accelerated classes
+    (grakel_amd.for_grakel: the same classes with the reference's Kernel among their bases, which is what the frameworks'
+    issubclass check asks for), initialised, cloned, pickled -- and FITTED: `fit` is host-only here, so the frameworks'
+    own per-level calls (grakel.Graph objects, tuple-valued Hadamard labels, extras) run through the accelerated
+    ingestion.  Every level's fitted batch must equal the one the test-local restatement of the calling sequence
+    (tests/caller_protocols.py -- what the GPU box, which has no reference, drives the device with) produces."""
+    import sys
+    ref = os.environ.get("GK_REF_BUILD", "/tmp/grakel_oracle")
+    if ref not in sys.path:
+        sys.path.insert(0, ref)
+    import grakel
+    from sklearn.base import clone
+    from grakel_amd import for_grakel as FG
+    from caller_protocols import CoreCaller, HadamardCaller
+    for cls in (FG.VertexHistogram, FG.ShortestPath, FG.WeisfeilerLehman, FG.EdgeHistogram, FG.WeisfeilerLehmanOptimalAssignment):
+        assert type(cls) is type and issubclass(cls, grakel.kernels.Kernel) and issubclass(cls, grakel_amd.Kernel)
+        assert cls.__mro__[1].__module__.startswith("grakel_amd.")            # every method: the accelerated class first
+        k = cls(normalize=False, verbose=False, n_jobs=None)                   # what every framework passes (hadamard_code.py:92-94)
+        assert clone(k).get_params() == k.get_params() and type(pickle.loads(pickle.dumps(k))) is cls
+    G = random_labelled_graphs(**dict(SMALL_SETS)["adj_u"])
+    tr = G[:26]
+    # HadamardCode over VertexHistogram (its default base kernel) and over ShortestPath
+    for base, n_iter in ((FG.VertexHistogram, 3), ((FG.ShortestPath, {"with_labels": True}), 2)):
+        hc = grakel.HadamardCode(base_graph_kernel=base, n_iter=n_iter)
+        hc.fit(tr)
+        assert sorted(hc.X) == list(range(n_iter))
+        bcls = base if type(base) is type else base[0]
+        mine = HadamardCaller(None, n_iter).level_inputs(tr)
+        for i in range(n_iter):
+            assert type(hc.X[i]) is bcls and hc.X[i].get_params()["normalize"] is False
+            assert _same_batch(hc.X[i]._fit_batch, bcls().fit(mine[i])._fit_batch), (base, i)
+        hc2 = pickle.loads(pickle.dumps(hc))                                   # a fitted framework holds the class AND fitted bases
+        assert hc2.base_graph_kernel_[0] is bcls and _same_batch(hc2.X[0]._fit_batch, hc.X[0]._fit_batch)
+    # CoreFramework over ShortestPath (its default base kernel) and VertexHistogram
+    for base in (FG.ShortestPath, FG.VertexHistogram):
+        cf = grakel.CoreFramework(base_graph_kernel=base)
+        cf.fit(tr)
+        mine = CoreCaller(None).level_inputs(tr)
+        assert sorted(cf.X) == sorted(i for i, (subs, idx) in mine.items() if len(idx))
+        for i, k in cf.X.items():
+            subs, idx = mine[i]
+            assert np.array_equal(cf._fit_indexes[i], idx)
+            assert _same_batch(k._fit_batch, base().fit(subs)._fit_batch), (base, i)
+        pickle.loads(pickle.dumps(cf))
+    # the reference's WeisfeilerLehman framework over the accelerated VertexHistogram: level inputs are
+    # (edge dictionary, level labels) lists (weisfeiler_lehman.py:220,257)
+    wl = grakel.WeisfeilerLehman(base_graph_kernel=FG.VertexHistogram, n_iter=2)
+    wl.fit(tr)
+    ref = O.WLOracle(n_iter=2)
+    ref.fit_transform(tr, keep_levels=True)
+    assert [wl.X[i]._fit_batch.n_labels for i in range(3)] == [len(ref.inv_labels[i]) for i in range(3)]

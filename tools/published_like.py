@@ -5,7 +5,8 @@
 
 wl      WL-subtree h=5 device step (packed CSR in HBM -> float64 K in HBM): ms, phases, relabel route, operand, the Gram
         kernel against both roofs, the matrix against the reference's checksums (tests/golden/pub_SET.npz)
-sp      ShortestPath(with_labels) fit_transform on the FULL set from the packed CSR in HBM: ms, phases, all-pairs rate
+sp      ShortestPath(with_labels) fit_transform on the FULL set from the packed CSR in HBM: ms, phases, all-pairs rate; the
+        matrix asserted against the full-set fixture and the real reference's block of the largest graphs (round 6)
 wl_e2e  packed CSR on the host -> float64 K on the host, unnormalised and normalised, entry-wise against the golden
 
 Prints one JSON line.  (Each mode is its own process so that tools/profile_published.sh can put a timeout and a
@@ -23,47 +24,8 @@ import bench  # noqa: E402
 
 
 def sp_summary(eng, wl, steps):
-    gb = wl.batch
-    db = eng.upload(gb)
-    sizes = np.diff(gb.graph_ptr).astype(np.float64)
-    N = wl.N
-
-    def step():
-        pb = eng.sp_build(db, None, True)
-        feat = eng.features(pb, 1)
-        eng.gram(feat, 0, to_host=False)
-        info = dict(n_pairs=pb.n_nodes, n_keys=pb.label_counts[0], dense=feat.n_cols, rare=feat.n_cols_low,
-                    max_count=feat.max_count, operand=feat.operand, gram=eng.gram_stats(feat))
-        return info, feat, pb
-
-    t0 = time.perf_counter()
-    info, feat, pb = step()
-    eng.synchronize()
-    first = time.perf_counter() - t0
-    feat.close(), pb.close()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        info, feat, pb = step()
-        if _ + 1 < steps:
-            feat.close(), pb.close()
-    eng.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    s, tr, asym = eng.gram_checksum(feat)
-    feat.close(), pb.close()
-    eng.profile(True)
-    info2, feat, pb = step()
-    feat.close(), pb.close()
-    ph = {k: round(eng.profile_get(k)[0], 4) for k in ("sp", "sp_fw", "features", "gram")}
-    eng.profile(False)
-    ops = float((sizes ** 3).sum())
-    return {"workload": wl.describe.replace("WL-subtree h=5", "ShortestPath(with_labels)"), "graphs": N,
-            "first_call_ms": first * 1e3, "ms_per_fit_transform": dt * 1e3, "graph_pairs_per_s": N * N / dt, "phases_ms": ph,
-            "sum_n3_minplus": ops, "sum_n_times_m_bfs": float((sizes * np.diff(gb.row_ptr).sum() / max(gb.n_nodes, 1)).sum()),
-            "fw_G_minplus_per_s": ops / max(ph["sp_fw"], 1e-6) / 1e6, "pairs": info["n_pairs"], "features": info["n_keys"],
-            "dense_columns": info["dense"], "rare_columns": info["rare"], "max_count": info["max_count"],
-            "operand": info["operand"], "gram_kernel_ms": info["gram"][1],
-            "K_sum": s, "K_trace": tr, "max_abs_K_minus_KT": asym,
-            "reference_publishes": wl.published}
+    """bench.published_sp: timed, and ASSERTED against tests/golden/pub_<set>_sp_full.npz / pub_<set>_sp_big.npz (round 6)"""
+    return bench.published_sp(eng, wl, steps)
 
 
 def main():
