@@ -222,6 +222,14 @@ def check_host_matrix(K, golden):
     return err, n + K.shape[0]
 
 
+def _read_first(path):
+    try:
+        with open(path) as f:
+            return f.readline().strip()
+    except OSError:
+        return None
+
+
 def host_to_host(eng, wl, steps, warmup):
     """Packed CSR on the host -> float64 K on the host (upload, step, the matrix over PCIe into the pinned output pool),
     unnormalised and normalised, each timed over `steps` calls in its own bracketed region (the first call of a size pins
@@ -242,12 +250,13 @@ def host_to_host(eng, wl, steps, warmup):
             K = one(norm)
             del K
         eng.synchronize()
-        calls = []
+        calls, stages = [], []
         t0 = time.perf_counter()
         for _ in range(steps):
             t1 = time.perf_counter()
             K = one(norm)
             calls.append((time.perf_counter() - t1) * 1e3)
+            stages.append(eng.host_copy_stats()[1])            # a few loads: what the call just did (gk_host_copy_stats)
             if _ + 1 < steps:
                 del K
         eng.synchronize()
@@ -256,7 +265,15 @@ def host_to_host(eng, wl, steps, warmup):
         # the mean over the bracketed region is the figure of record; median and minimum say how much of it is the host's
         # noise (these walls are host-memory and host-thread work: other tenants of the box's CPUs show up here, not in `value`)
         out[tag] = {"ms_per_step": dt * 1e3, "value": N * N / dt, "steps": steps, "median_ms": float(np.median(calls)),
-                    "min_ms": float(np.min(calls)), "max_ms": float(np.max(calls))}
+                    "min_ms": float(np.min(calls)), "max_ms": float(np.max(calls)),
+                    # where the wall goes (medians over the timed calls): the copy-out = pack kernel + PCIe + widening by
+                    # host threads; the rest of a call is the upload of the packed CSR and the device step
+                    "copy_out": {"form": stages[-1]["form"], "widening_threads": stages[-1]["widening_threads"],
+                                 "pcie_MB": stages[-1]["pcie_bytes"] / 1e6,
+                                 "median_ms_until_last_chunk_landed": float(np.median([x["ms_until_last_chunk_landed"] for x in stages])),
+                                 "median_ms_copy_out": float(np.median([x["ms_copy_out"] for x in stages])),
+                                 "median_widen_busy_ms_per_thread": float(np.median([x["widen_busy_ms_mean"] for x in stages])),
+                                 "median_widen_busy_ms_slowest_thread": float(np.median([x["widen_busy_ms_max"] for x in stages]))}}
     Ku, Kn = keep["unnormalised"], keep["normalised"]
     d = np.sqrt(np.diagonal(Ku))
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -270,6 +287,10 @@ def host_to_host(eng, wl, steps, warmup):
         Kp = one(0)
         out["plain_float64_copy_ms"] = (time.perf_counter() - t0) * 1e3
     out["compact_equals_plain"] = bool(np.array_equal(Ku, Kp))
+    # the host this ran on, as the library sees it: its widening / ingestion threads are min(32, online CPUs, affinity mask,
+    # cgroup CPU quota - 2) -- a box with another quota gives other walls, and this is what explains them
+    out["host_threads"] = dict(eng.host_copy_stats()[0], cgroup_cpu_max=_read_first("/sys/fs/cgroup/cpu.max"),
+                               ingestion_threads_setting=int(__import__("grakel_amd.batch", fromlist=["x"]).INGEST_THREADS))
     del Kp
     out["note"] = ("H2D of the packed CSR + the device step + the %d MB float64 K into a pinned, reused output block "
                    "(grakel_amd.engine.PinnedPool).  An integer-valued symmetric matrix crosses PCIe as the uint16 / int32 "
@@ -353,7 +374,7 @@ def python_objects(eng, wl, Ku, reps=7):
             "normalised_ms_per_call": dt_objn * 1e3, "calls_ms": [round(c, 3) for c in calls],
             "normalised_calls_ms": [round(c, 3) for c in calls_n],
             "of_which_host_ingestion_ms": dt_ingest * 1e3, "host_ingestion_one_thread_ms": dt_ingest_1 * 1e3,
-            "host_ingestion_threads": "min(32, host CPUs, the container's cgroup CPU quota)",
+            "host_ingestion_threads": "min(32, host CPUs, affinity mask, the container's cgroup CPU quota - 2) = %d here" % eng.host_copy_stats()[0]["thread_budget"],
             "same_matrix": bool(np.array_equal(Ku, Kobj)),
             "note": "grakel_amd.WeisfeilerLehman(n_iter=%d).fit_transform on %d dict graphs" % (h, N)}
 

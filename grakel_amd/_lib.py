@@ -84,6 +84,7 @@ SIGNATURES = {
     "gk_block_copy": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "gk_gram_normalize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int]),
     "gk_gram_checksum": (c_int, [c_void_p, c_void_p, _f64p, _f64p, _f64p]),
+    "gk_host_copy_stats": (c_int, [c_void_p, POINTER(c_int), _f64p]),
     "gk_sp_build": (c_int, [c_void_p, c_void_p, c_void_p, c_int, _vpp, _i64p, _i64p]),
     "gk_batch_from_shards": (c_int, [c_void_p, c_int, _i64p, c_int64, c_int64, c_int64, c_void_p, c_int, _vpp]),
     "gk_core_numbers": (c_int, [c_void_p, c_void_p, c_void_p]),

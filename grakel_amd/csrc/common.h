@@ -135,6 +135,7 @@ struct gk_ctx {
     void* stage_host = nullptr;
     hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* xfer_host = nullptr;                 // pinned block for small results that come back in one copy (wl_transform.hip)
+    double copy_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last host copy of a Gram matrix (gk_host_copy_stats)
     struct GkHostPool* host_pool = nullptr;    // host threads of that copy's widening (created on first use, joined by gk_destroy)
     u32 mbox_seq = 0;
     int n_cu = 0;                              // compute units of the device (persistent-kernel grids)

@@ -32,6 +32,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <functional>
@@ -1662,6 +1663,7 @@ static int gram_copy_out_narrow(gk_ctx* ctx, const double* K_dev, i64 n_entries,
         ctx->stage_host = h;
         for (int i = 0; i < GC_SLOTS; ++i) GK_HIP_CHECK(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
     }
+    const auto t_narrow0 = std::chrono::steady_clock::now();
     Tmp<T> narrow(ctx);
     GK_TRY(narrow.alloc((size_t)n_entries));
     gram_narrow_kernel<T><<<dim3((unsigned)cdiv(cdiv(n_entries, 4), 256)), dim3(256), 0, ctx->stream>>>(K_dev, n_entries, narrow.p);
@@ -1722,6 +1724,11 @@ static int gram_copy_out_narrow(gk_ctx* ctx, const double* K_dev, i64 n_entries,
     }
     if (rc != GK_OK) stop.store(1);
     for (auto& t : pool) t.join();
+    {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_narrow0).count();
+        const double st[8] = {2.0, (double)n_thr, (double)n_entries * sizeof(T), ms, ms, 0.0, 0.0, (double)n_chunks};
+        memcpy(ctx->copy_stats, st, sizeof st);
+    }
     if (rc != GK_OK) {
         (void)hipGetLastError();
         gk_set_error("gk_gram: the compact device-to-host copy failed");
@@ -1941,6 +1948,9 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
     const double* rsp = nullptr;
     const double* dvp = nullptr;
     auto chunk_blocks = [&](int c) { return (int)std::min<i64>((i64)per_chunk, n_blocks - (i64)c * per_chunk); };
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    std::vector<double> busy((size_t)n_thr + 1, 0.0);                  // per widening thread (last slot: the calling thread, inline mode)
     auto widen_one = [&](i64 p) {
             const int c = (int)(p / per_chunk), k = (int)(p - (i64)c * per_chunk);
             int bi = (int)(std::upper_bound(row_first.begin(), row_first.end(), p) - row_first.begin()) - 1;
@@ -1951,7 +1961,7 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
             _mm_sfence();
             done[(size_t)c].fetch_add(1, std::memory_order_release);
     };
-    auto worker = [&](int) {
+    auto worker = [&](int w) {
         for (;;) {
             const i64 p = next_block.fetch_add(1, std::memory_order_relaxed);
             if (p >= n_blocks) return;
@@ -1960,10 +1970,13 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
                 if (stop.load(std::memory_order_relaxed)) return;
                 if (spins < 4096) _mm_pause(); else std::this_thread::yield();
             }
+            const auto t = std::chrono::steady_clock::now();
             widen_one(p);
+            if (w >= 0 && w < n_thr) busy[(size_t)w] += ms_since(t);
         }
     };
     int rc = GK_OK;
+    double landed_ms = 0.0;
     int n_workers = 0;                      // pool threads at work; 0 = none could be created: the caller widens inline
     auto queue_chunk = [&](int c) -> bool {
         const int slot = c % GC_SLOTS;
@@ -1995,8 +2008,11 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
         ready.store(c + 1, std::memory_order_release);
         if (n_workers == 0) {               // no host thread to be had: this chunk's blocks on the calling thread
             const i64 hi = std::min<i64>(n_blocks, (i64)(c + 1) * per_chunk);
+            const auto t = std::chrono::steady_clock::now();
             for (i64 p = (i64)c * per_chunk; p < hi; ++p) widen_one(p);
+            busy[(size_t)n_thr] += ms_since(t);
         }
+        if (c + 1 == n_chunks) landed_ms = ms_since(t_start);
         if (c + GC_SLOTS < n_chunks) {          // the slot is refilled once every block of chunk c is done
             const int need = chunk_blocks(c);
             for (unsigned spins = 0; done[(size_t)c].load(std::memory_order_acquire) < need; ++spins)
@@ -2006,6 +2022,14 @@ static int gram_copy_out_tri(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 N
     }
     if (rc != GK_OK) stop.store(1);
     if (started) ctx->host_pool->wait();
+    {
+        double sum = 0.0, mx = 0.0;
+        const int used = n_workers > 0 ? n_workers : 1;
+        for (double b : busy) sum += b, mx = std::max(mx, b);
+        const double st[8] = {1.0, (double)used, (double)n_blocks * (double)block_elems * sizeof(T), landed_ms, ms_since(t_start),
+                              sum / used, mx, (double)n_chunks};
+        memcpy(ctx->copy_stats, st, sizeof st);
+    }
     if (rc != GK_OK) {
         (void)hipGetLastError();
         gk_set_error("gk_gram: the compact device-to-host copy failed");
@@ -2034,8 +2058,23 @@ static int gram_copy_out(gk_ctx* ctx, gk_feat* f, const double* K_dev, i64 n_ent
                          f->k_bound < 2147483647.0;
     if (compact && f->k_bound < 65536.0) return gram_copy_out_narrow<uint16_t>(ctx, K_dev, n_entries, out_host);
     if (compact) return gram_copy_out_narrow<int32_t>(ctx, K_dev, n_entries, out_host);
+    const auto t0 = std::chrono::steady_clock::now();
     GK_HIP_CHECK(hipMemcpyAsync(out_host, K_dev, (size_t)n_entries * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double st[8] = {0.0, 0.0, (double)n_entries * 8.0, ms, ms, 0.0, 0.0, 1.0};
+    memcpy(ctx->copy_stats, st, sizeof st);
+    return GK_OK;
+}
+
+extern "C" int gk_host_copy_stats(gk_ctx* ctx, int* out_cpu, double* out_copy) {
+    GK_ARG(ctx, "gk_host_copy_stats: null argument");
+    if (out_cpu) {
+        gk_cpu_info_t o;
+        gk_cpu_info(&o);
+        out_cpu[0] = o.online, out_cpu[1] = o.affinity, out_cpu[2] = o.quota_cpus, out_cpu[3] = o.budget;
+    }
+    if (out_copy) memcpy(out_copy, ctx->copy_stats, sizeof ctx->copy_stats);
     return GK_OK;
 }
 

@@ -557,6 +557,15 @@ class Engine(object):
         check(self.lib.gk_gram_checksum(self.handle, feat.handle, byref(a), byref(b), byref(c)))
         return a.value, b.value, c.value
 
+    def host_copy_stats(self):
+        """(cpu dict, copy dict) -- gk_host_copy_stats: the host-thread budget and the stages of the last host copy."""
+        cpu, cp = (c_int * 4)(), (c_double * 8)()
+        check(self.lib.gk_host_copy_stats(self.handle, cpu, cp))
+        form = {0: "plain float64 copy", 1: "upper-triangle blocks", 2: "rectangular narrow"}.get(int(cp[0]), "?")
+        return (dict(online=cpu[0], affinity=cpu[1], cgroup_quota_cpus=cpu[2], thread_budget=cpu[3]),
+                dict(form=form, widening_threads=int(cp[1]), pcie_bytes=int(cp[2]), ms_until_last_chunk_landed=cp[3],
+                     ms_copy_out=cp[4], widen_busy_ms_mean=cp[5], widen_busy_ms_max=cp[6], chunks=int(cp[7])))
+
     def gram_stats(self, feat):
         fl, ms = c_double(), c_double()
         check(self.lib.gk_gram_last_stats(feat.handle, byref(fl), byref(ms)))

@@ -298,6 +298,15 @@ int gk_gram_normalize_rows(gk_ctx* ctx, gk_feat* f, int64_t row_lo, int64_t row_
  * timed matrix and what the 50 000-graph parity test (a 20 GB matrix) checks without a host copy; the
  * reference has no counterpart (it holds K as one host ndarray, kernel.py:167-204). */
 int gk_gram_checksum(gk_ctx* ctx, gk_feat* f, double* out_sum, double* out_trace, double* out_max_asym);
+/* What the caller-side wall of a gk_gram* call with out_host set is made of (bench.py prints it next to the
+ * host-to-host figures so that they can be reproduced on another box).  out_cpu[4]: online CPUs, CPUs in the affinity
+ * mask, CPUs of the container's cgroup quota (0 = none), the host-thread budget the library derives from them (its
+ * widening and ingestion threads: min(32, those three, quota - 2)).  out_copy[8], of the context's LAST host copy:
+ * [0] form (0 plain float64 copy, 1 upper-triangle blocks, 2 rectangular narrow), [1] host threads that widened,
+ * [2] bytes that crossed PCIe, [3] ms until the last chunk had landed in the staging ring (pack kernel + copies),
+ * [4] ms of the whole copy-out (until the last widening thread was done), [5] / [6] mean / max busy ms of a widening
+ * thread, [7] chunks.  The reference has no counterpart (its matrix is born on the host, kernel.py:167-204). */
+int gk_host_copy_stats(gk_ctx* ctx, int* out_cpu, double* out_copy);
 /* Algorithmic work of the last gk_gram* call, for the roofline: MACs = rows*cols*kept cols. */
 int gk_gram_last_stats(gk_feat* f, double* out_flops, double* out_ms_event);
 
