@@ -64,7 +64,7 @@ F64_DENSE_PEAK_TOPS = 78.6       # v_mfma_f64_16x16x4_f64
 # (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, summarised by
 # tools/pmc_summary.py): 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced read,
 # MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes.  NOT measured in this run.
-PMC_FILES = [os.path.join(ROOT, "profiles", "r%02d_pmc_hbm_bytes.csv" % r) for r in (5, 4, 3)]
+PMC_FILES = [os.path.join(ROOT, "profiles", "r%02d_pmc_hbm_bytes.csv" % r) for r in (6, 5, 4, 3)]
 PMC_FILE = next((p for p in PMC_FILES if os.path.exists(p)), PMC_FILES[0])
 GRAM_KERNELS = ("gram_ws_kernel", "gram_tile_kernel")
 

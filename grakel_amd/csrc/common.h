@@ -82,6 +82,7 @@ struct gk_opts {
     int gram_dd = 0;             // Gram kernel form with two accumulator sets and direct stores (no parked tile, five-stage ring):
                                  // 0 chosen per job (small fp4 jobs), 1 always, 2 never
     int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
+    int gram_strip = 0;          // tile order of the tile kernels: 0 = the rule (gram.hip: launch_tiles), 1 = 8 x 8 patches (rounds 1-5), 2 / 4 / 8 / 16 / 32 = strip walk with strips of that many tile columns
     int gram_pair_cap = 0;       // test hook: capacity of the per-tile pair buckets (0: four times the mean load + 128)
     int gram_fold = 0;           // rare labels' pair updates INSIDE the tile kernel (which then normalises in its epilogue as well):
                                  // 0 = when it pays (normalised jobs whose separate normalisation pass costs more than the binning), 1 = whenever legal, 2 = never

@@ -69,11 +69,50 @@ __device__ __forceinline__ double finish_entry(double val, i64 grow, i64 gcol, b
 // XCD then share 2x(8+8) operand panels instead of ~90, and its 4 MiB L2 serves the re-reads.
 // Symmetric jobs only visit patches/tiles on or above the diagonal.
 #define GI_PATCH 8
+#define GI_STRIP 64          // patch >= GI_STRIP: the strip walk with strips of (patch - GI_STRIP) tile columns
 __device__ __forceinline__ bool gram_map_tile(int b, int tiles_m, int tiles_n, int sym, int patch,
                                               int& bm, int& bn) {
     if (!patch) {
         bm = b / tiles_n, bn = b % tiles_n;
         return !(sym && bn < bm);
+    }
+    if (patch >= GI_STRIP) {
+        // Strip walk (round 6).  The job's tiles in STRIP-MAJOR order -- strips of W tile columns, inside a strip row by
+        // row (a symmetric job: only the tiles on / above the diagonal, and they are the only ones numbered: no holes) --
+        // are cut into eight contiguous ranges, one per XCD; the 32 workgroups of an XCD take consecutive tiles of its range,
+        // i.e. at any time 32 / W rows x W columns of one strip.  The strip's W column panels are re-read by every one of those
+        // rounds and stay in the XCD's L2 for the whole walk down the strip; only the 32 / W row panels of a round are
+        // new.  An 8 x 8 patch walked as two rounds of 4 x 8 fetched 12 panels per 32 tiles; this fetches 32 / W (+ W once per strip).
+        const int W = patch - GI_STRIP;
+        const int xcd = b & 7, i = b >> 3;
+        const i64 total = sym ? (i64)tiles_n * (tiles_n + 1) / 2 : (i64)tiles_m * tiles_n;
+        const i64 per = (total + 7) / 8;
+        i64 g = (i64)xcd * per + i;
+        if (i >= per || g >= total) return false;
+        if (!sym) {
+            const i64 full = (i64)tiles_m * W;
+            const int s = (int)(g / full);
+            g -= (i64)s * full;
+            const int ws = tiles_n - s * W < W ? tiles_n - s * W : W;
+            bm = (int)(g / ws), bn = s * W + (int)(g % ws);
+            return true;
+        }
+        int s = 0, ws = W;
+        for (;; ++s) {                   // strip s: rows 0 .. s W - 1 in full, then the triangle of its diagonal block
+            ws = tiles_n - s * W < W ? tiles_n - s * W : W;
+            const i64 n_s = (i64)s * W * ws + (i64)ws * (ws + 1) / 2;
+            if (g < n_s) break;
+            g -= n_s;
+        }
+        const i64 rect = (i64)s * W * ws;
+        if (g < rect) {
+            bm = (int)(g / ws), bn = s * W + (int)(g % ws);
+        } else {
+            int j = 0, r = (int)(g - rect);
+            while (r >= ws - j) r -= ws - j, ++j;
+            bm = s * W + j, bn = s * W + j + r;
+        }
+        return true;
     }
     const int P = patch;
     const int pm = (tiles_m + P - 1) / P, pn = (tiles_n + P - 1) / P;
@@ -97,6 +136,10 @@ __device__ __forceinline__ bool gram_map_tile(int b, int tiles_m, int tiles_n, i
 
 static inline i64 gram_grid_blocks(int tiles_m, int tiles_n, int sym, int patch) {
     if (!patch) return (i64)tiles_m * tiles_n;
+    if (patch >= GI_STRIP) {
+        const i64 total = sym ? (i64)tiles_n * (tiles_n + 1) / 2 : (i64)tiles_m * tiles_n;
+        return ((total + 7) / 8) * 8;
+    }
     const int P = patch;
     const i64 pm = (tiles_m + P - 1) / P, pn = (tiles_n + P - 1) / P;
     const i64 np = sym ? (pm * pn - pm * (pm - 1) / 2) : pm * pn;   // sym: pm == pn
@@ -1208,7 +1251,21 @@ static int launch_tiles(gk_ctx* ctx, gk_feat* f, const int8_t* a, const int8_t* 
     // a / b: operand rows of the job's first row / first column; K: the job's entry (0, 0)
     const int even = ((uintptr_t)K % 16 == 0 && ldk % 2 == 0) ? 1 : 0;      // 16-byte stores of two float64
     const int tiles_m = (int)cdiv(M, GT_BM), tiles_n = (int)cdiv(n_cols, GT_BM);
-    const int patch_sz = patch ? GI_PATCH : 0;
+    // Tile order (round 6): the strip walk (gram_map_tile) instead of the 8 x 8 patches of rounds 1-5.  The kernel is bound by
+    // what crosses the fabric behind the L2s -- the float64 store of K AND the operand panels every XCD-round has to fetch anew
+    // (PMC: 538 MB of fetches for a 25.5 MB operand at config 3, next to 800 MB of stores) -- and a walk down a strip fetches
+    // 32 / W new panels per 32 tiles where a patch fetched 12.  Strip width per job, measured (profiles/r06_strip_sweep.txt;
+    // tile kernel ms, patches -> best strip): symmetric 4 000 graphs 0.089 -> 0.069 (W = 4), config 3 0.258 -> 0.222 (8),
+    // 20 000 graphs 1.07 -> 0.85 (16), 50 000 graphs 4.61 -> 4.18 (16; W = 4 / 8 lose there: 6.7 / 4.9); row blocks
+    // 1 250 x 10 000 0.083 -> 0.063, 6 250 x 50 000 0.645 -> 0.541, 25 000 x 200 000 17.5 -> 12.2 (8; 16: 14.3).
+    // Option gram.strip: 1 = the patches, 2 .. 32 = that width.
+    int patch_sz = patch ? GI_PATCH : 0;
+    if (patch && ctx->opt.gram_strip != 1) {
+        int W = 8;
+        if (tri) W = tiles_n >= 128 ? 16 : (tiles_n <= 40 ? 4 : 8);
+        if (ctx->opt.gram_strip >= 2 && ctx->opt.gram_strip <= 32 && (ctx->opt.gram_strip & (ctx->opt.gram_strip - 1)) == 0) W = ctx->opt.gram_strip;
+        patch_sz = GI_STRIP + W;
+    }
     const i64 blocks = gram_grid_blocks(tiles_m, tiles_n, tri, patch_sz);
     int k_all = f->k1_steps + f->k8_steps, k8 = f->k8_steps;
     i64 M_store = M;

@@ -84,7 +84,7 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *   features: "feat.no_gm" "feat.gm_no_priv" "feat.gm_rows_wg" "feat.low_df" (df below which a column becomes pair updates; default 24 (N / 10 000)^0.75 within [8, 128])
  *             "feat.gm_row_lds_max" (bytes of operand row the graph-major builder accepts: small values force the
  *             fall-back to the label-major builder)
- *   Gram:     "gram.dd" (the direct-store form of the persistent kernel: 1 always, 2 never, 0 per job) "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc"
+ *   Gram:     "gram.dd" (the direct-store form of the persistent kernel: 1 always, 2 never, 0 per job) "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc" "gram.strip" (tile order: 1 the 8 x 8 patches of rounds 1-5, 2..32 strips of that many tile columns, 0 per job)
  *             "gram.fold" (the rare labels' pair updates inside the tile kernel, which then normalises in its epilogue too, instead of float64
  *             atomics + a normalisation pass afterwards: 0 when it pays, 1 whenever legal, 2 never)
  *             "gram.pair_cap" (test hook: capacity of the per-tile pair buckets of that fold-in)

@@ -96,6 +96,22 @@ int main() {
     int8_t* P; int* sink;
     CK(hipMalloc(&P, (size_t)n_rows * ld)); CK(hipMalloc(&sink, 4));
     CK(hipMemset(P, 1, (size_t)n_rows * ld));
+    // round 6: does the L2 -> LDS rate of a CU depend on HOW MANY waves issue the pieces?  (the Gram kernel's load role is four
+    // waves x 8 pieces per 128-byte K-step of a 128 + 128-row stage; "share 8" is its panel sharing)
+    for (int mode : {0, 2}) {
+        printf("-- 256 rows x 128 B per K-step (32 KiB stage), %s\n", mode == 0 ? "barrier per K-step" : "no barrier");
+        if (mode == 0) {
+            run<2, 16, 0, 128>("glds  2 waves x 16 pieces", P, ld, n_rows, 19, 1, 8, sink);
+            run<4, 8, 0, 128>("glds  4 waves x 8 pieces", P, ld, n_rows, 19, 1, 8, sink);
+            run<8, 4, 0, 128>("glds  8 waves x 4 pieces", P, ld, n_rows, 19, 1, 8, sink);
+            run<16, 2, 0, 128>("glds 16 waves x 2 pieces", P, ld, n_rows, 19, 1, 8, sink);
+        } else {
+            run<2, 16, 2, 128>("glds  2 waves x 16 pieces", P, ld, n_rows, 19, 1, 8, sink);
+            run<4, 8, 2, 128>("glds  4 waves x 8 pieces", P, ld, n_rows, 19, 1, 8, sink);
+            run<8, 4, 2, 128>("glds  8 waves x 4 pieces", P, ld, n_rows, 19, 1, 8, sink);
+            run<16, 2, 2, 128>("glds 16 waves x 2 pieces", P, ld, n_rows, 19, 1, 8, sink);
+        }
+    }
     for (int share : {1, 2, 4, 8, 32}) {
         run<4, 4, 0, 64>("glds 256 rows x 64 B", P, ld, n_rows, 38, 2, share, sink);
         run<8, 4, 0, 64>("glds 512 rows x 64 B", P, ld, n_rows, 38, 1, share, sink);
