@@ -652,6 +652,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip host_to_host, from_python_objects and `extra`")
     ap.add_argument("--plan", choices=["plain", "symmetric"], default="plain",
                     help="N > 1: Gram sharding plan (grakel_amd.dist.gram_plan; plain row blocks is the default)")
+    ap.add_argument("--exchange", choices=["csr", "phi"], default="csr",
+                    help="N > 1: what the ranks exchange besides the packed CSR shards -- csr (default): nothing, the operand is "
+                         "assembled on every rank; phi: every rank assembles its own graphs' operand rows and the row shards are "
+                         "all-gathered (the exchange north_star names; an A/B switch, grakel_amd.dist.ShardedWL)")
     ap.add_argument("--separate-calls", action="store_true",
                     help="step = gk_wl_relabel + gk_features_build + gk_gram as three library calls instead of gk_wl_fit_transform")
     ap.add_argument("--block-rows", type=int, default=-1,
@@ -772,7 +776,7 @@ def main():
         from grakel_amd.dist import ShardedWL, shard_bounds
         b = shard_bounds(N, world)
         local = full.slice_graphs(b[rank], b[rank + 1])
-        sw = ShardedWL(eng, n_iter=h, symmetric=(a.plan == "symmetric"))       # default: plain row blocks (dist.gram_plan)
+        sw = ShardedWL(eng, n_iter=h, symmetric=(a.plan == "symmetric"), exchange=a.exchange)       # default: plain row blocks (dist.gram_plan)
 
         def collect(last=False):
             pass
@@ -965,7 +969,8 @@ def main():
             "phases_hbm": phases_hbm,
         }
         if world > 1:
-            out["rccl"] = {"backend": backend, "ranks": dist.get_world_size(),
+            out["rccl"] = {"backend": backend, "ranks": dist.get_world_size(), "exchange": a.exchange,
+                           "operand_row_bytes_sent_per_rank": int(getattr(sw, "phi_bytes", 0)) if a.exchange == "phi" else 0,
                            "launched_by": "torch.distributed.run (self-launched by `bench.py --gpus N` when WORLD_SIZE is unset)"}
             out["per_rank"] = per_rank
             out["device_step_ms_max_over_ranks"] = ms_per_step

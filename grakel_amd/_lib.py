@@ -62,6 +62,8 @@ SIGNATURES = {
     "gk_features_build_range": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, _vpp]),
     "gk_features_destroy": (c_int, [c_void_p]),
     "gk_features_info": (c_int, [c_void_p, _i64p, _i64p, _i64p, _i64p, POINTER(c_int)]),
+    "gk_features_operand_rows": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), _i64p, _i64p, _i64p, _i64p]),
+    "gk_memcpy_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
     "gk_features_operand": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), _i64p]),
     "gk_features_selfk": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gk_features_debug_phi": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -153,6 +153,26 @@ int gk_readback(gk_ctx* ctx, const u32* src_dev, u32* dst_host, int n_words) {
     return gk_mbox_wait(ctx, seq, dst_host, n_words);
 }
 
+// The same in two halves: gk_readback_post queues the post and returns its ticket, the caller queues whatever the device can
+// do meanwhile (work that does not depend on the values), gk_readback_collect waits -- the device is not idle for the host's
+// round trip.  Ticket 0: the mailbox is unavailable, gk_readback_collect then does the synchronous copy.
+int gk_readback_post(gk_ctx* ctx, const u32* src_dev, int n_words, u32* ticket) {
+    *ticket = (n_words > 0 && n_words <= GK_MBOX_WORDS - 1) ? gk_mbox_begin(ctx) : 0;
+    if (*ticket) {
+        mbox_post_kernel<<<1, 256, 0, ctx->stream>>>(src_dev, n_words, ctx->mbox_dev, *ticket);
+        GK_HIP_CHECK(hipGetLastError());
+    }
+    return GK_OK;
+}
+
+int gk_readback_collect(gk_ctx* ctx, u32 ticket, const u32* src_dev, u32* dst_host, int n_words) {
+    if (n_words <= 0) return GK_OK;
+    if (ticket) return gk_mbox_wait(ctx, ticket, dst_host, n_words);
+    GK_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, (size_t)n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return GK_OK;
+}
+
 __global__ void mbox_post2_kernel(const u32* __restrict__ src1, int n1, const u32* __restrict__ src2, int n2, u32* __restrict__ mbox, u32 seq) {
     for (int i = threadIdx.x; i < n1 + n2; i += blockDim.x)
         __hip_atomic_store(&mbox[1 + i], i < n1 ? src1[i] : src2[i - n1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -224,7 +244,7 @@ static const OptName g_opt_names[] = {
     {"wl.bd_slots", &gk_opts::bd_slots}, {"feat.no_gm", &gk_opts::feat_no_gm}, {"feat.gm_no_priv", &gk_opts::gm_no_priv}, {"feat.gm_rows_wg", &gk_opts::gm_rows_wg},
     {"feat.low_df", &gk_opts::low_df}, {"feat.gm_row_lds_max", &gk_opts::gm_row_lds_max},
     {"gram.dd", &gk_opts::gram_dd}, {"gram.no_fp4", &gk_opts::gram_no_fp4}, {"gram.no_ws", &gk_opts::gram_no_ws}, {"gram.no_sym", &gk_opts::gram_no_sym},
-    {"gram.no_patch", &gk_opts::gram_no_patch}, {"gram.xcc", &gk_opts::gram_xcc}, {"gram.strip", &gk_opts::gram_strip}, {"gram.no_compact", &gk_opts::gram_no_compact}, {"gram.no_split8", &gk_opts::gram_no_split8}, {"gram.no_split64", &gk_opts::gram_no_split64}, {"gram.fold", &gk_opts::gram_fold}, {"gram.pair_cap", &gk_opts::gram_pair_cap}, {"gram.copy_threads", &gk_opts::gram_copy_threads}, {"gram.no_tri", &gk_opts::gram_no_tri}, {"gram.no_avx2", &gk_opts::gram_no_avx2}, {"wl.no_wave_sig", &gk_opts::wl_no_wave_sig}, {"transform.no_fused", &gk_opts::tt_no_fused}, {"scan.direct_max", &gk_opts::scan_direct_max}, {"sp.no_reg", &gk_opts::sp_no_reg}, {"sp.no_pk", &gk_opts::sp_no_pk}, {"sp.no_hist", &gk_opts::sp_no_hist}, {"sp.no_rows", &gk_opts::sp_no_rows}, {"sp.no_bfs", &gk_opts::sp_no_bfs}, {"sp.bfs_no_lds_cols", &gk_opts::sp_bfs_no_lds_cols}, {"sp.rows_all", &gk_opts::sp_rows_all}, {"sp.hist_unit", &gk_opts::sp_hist_unit}, {"sp.hist_slots", &gk_opts::sp_hist_slots}, {"no_mailbox", &gk_opts::no_mailbox},
+    {"gram.no_patch", &gk_opts::gram_no_patch}, {"gram.xcc", &gk_opts::gram_xcc}, {"feat.rows_lo", &gk_opts::feat_rows_lo}, {"feat.rows_hi", &gk_opts::feat_rows_hi}, {"gram.strip", &gk_opts::gram_strip}, {"gram.no_compact", &gk_opts::gram_no_compact}, {"gram.no_split8", &gk_opts::gram_no_split8}, {"gram.no_split64", &gk_opts::gram_no_split64}, {"gram.fold", &gk_opts::gram_fold}, {"gram.pair_cap", &gk_opts::gram_pair_cap}, {"gram.copy_threads", &gk_opts::gram_copy_threads}, {"gram.no_tri", &gk_opts::gram_no_tri}, {"gram.no_avx2", &gk_opts::gram_no_avx2}, {"wl.no_wave_sig", &gk_opts::wl_no_wave_sig}, {"transform.no_fused", &gk_opts::tt_no_fused}, {"scan.direct_max", &gk_opts::scan_direct_max}, {"sp.no_reg", &gk_opts::sp_no_reg}, {"sp.no_pk", &gk_opts::sp_no_pk}, {"sp.no_hist", &gk_opts::sp_no_hist}, {"sp.no_prep", &gk_opts::sp_no_prep}, {"sp.no_rows", &gk_opts::sp_no_rows}, {"sp.no_bfs", &gk_opts::sp_no_bfs}, {"sp.bfs_no_lds_cols", &gk_opts::sp_bfs_no_lds_cols}, {"sp.rows_all", &gk_opts::sp_rows_all}, {"sp.hist_unit", &gk_opts::sp_hist_unit}, {"sp.hist_slots", &gk_opts::sp_hist_slots}, {"no_mailbox", &gk_opts::no_mailbox},
     {"debug.poison", &gk_opts::poison}, {"debug.guard", &gk_opts::guard},
 };
 

@@ -82,6 +82,8 @@ struct gk_opts {
     int gram_dd = 0;             // Gram kernel form with two accumulator sets and direct stores (no parked tile, five-stage ring):
                                  // 0 chosen per job (small fp4 jobs), 1 always, 2 never
     int gram_no_fp4 = 0, gram_no_ws = 0, gram_no_sym = 0, gram_no_patch = 0, gram_xcc = 0;
+    int sp_no_prep = 0;          // 1: the set-up of a ShortestPath job (clears, squares, prefix, size classes) as the seven launches of rounds 3-5 instead of sp_prep_small_kernel
+    int feat_rows_lo = 0, feat_rows_hi = 0;   // hi > lo: the graph-major builder assembles the operand rows of the graphs [lo, hi) only (multi-GPU operand-row exchange; the others are expected through gk_features_operand)
     int gram_strip = 0;          // tile order of the tile kernels: 0 = the rule (gram.hip: launch_tiles), 1 = 8 x 8 patches (rounds 1-5), 2 / 4 / 8 / 16 / 32 = strip walk with strips of that many tile columns
     int gram_pair_cap = 0;       // test hook: capacity of the per-tile pair buckets (0: four times the mean load + 128)
     int gram_fold = 0;           // rare labels' pair updates INSIDE the tile kernel (which then normalises in its epilogue as well):
@@ -339,6 +341,7 @@ struct gk_feat {
     u32* meta = nullptr;        // device: per level {T, R, ncols_cum}, then globals
     u64* selfk = nullptr;       // [n_graphs] exact integer self similarity
     i64 n_cols = 0, n_cols_pad = 0, nnz = 0, max_count = 0, n_low_cols = 0;
+    i64 own_lo = 0, own_hi = 0; // graphs whose operand rows THIS job assembled (all of them unless options feat.rows_lo / feat.rows_hi said otherwise)
     int low_df = 24;            // columns occurring in fewer graphs are applied as pair updates
     i64 n_rows_pad = 0;
     int dtype = 0;              // 0: int8 Phi, 1: f64 Phi
@@ -409,6 +412,8 @@ int gk_sr_collect(gk_ctx* ctx, gk_batch* b, const u32* ctl_words);              
 #define GK_ERR_RETRY (-100)     // internal: the queued stream relabel turned out unusable (collision / overflow) at a later read-back
 // two device arrays in ONE mailbox round trip (n1 + n2 <= GK_MBOX_WORDS - 1; more: two copies)
 int gk_readback2(gk_ctx* ctx, const u32* src1, int n1, const u32* src2, int n2, u32* dst_host);
+int gk_readback_post(gk_ctx* ctx, const u32* src_dev, int n_words, u32* ticket);
+int gk_readback_collect(gk_ctx* ctx, u32 ticket, const u32* src_dev, u32* dst_host, int n_words);
 int gk_batch_rebuild_order(gk_ctx* ctx, gk_batch* b, int level);
 int gk_sp_materialise(gk_ctx* ctx, gk_batch* pair_batch);            // sp.hip: item arrays of a histogram-form pair batch      // perm[level] on demand (sort-free dictionary levels)
 

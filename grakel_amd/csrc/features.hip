@@ -727,6 +727,25 @@ extern "C" int gk_features_operand(gk_feat* f, int* fp4, int* k_steps_primary, i
     return GK_OK;
 }
 
+extern "C" int gk_features_operand_rows(gk_feat* f, void** out_phi, void** out_phi_right, int64_t* out_row_bytes, int64_t* out_n_rows,
+                                        int64_t* out_own_lo, int64_t* out_own_hi) {
+    GK_ARG(f, "gk_features_operand_rows: null");
+    if (out_phi) *out_phi = f->phi;
+    if (out_phi_right) *out_phi_right = f->phi_r;
+    if (out_row_bytes) *out_row_bytes = f->n_cols_pad;
+    if (out_n_rows) *out_n_rows = f->n_graphs;
+    if (out_own_lo) *out_own_lo = f->own_lo;
+    if (out_own_hi) *out_own_hi = f->own_hi;
+    return GK_OK;
+}
+
+extern "C" int gk_memcpy_dev(gk_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t bytes) {
+    GK_ARG(ctx && (bytes == 0 || (dst_dev && src_dev)), "gk_memcpy_dev: null argument");
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    if (bytes) GK_HIP_CHECK(hipMemcpyAsync(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return GK_OK;
+}
+
 extern "C" int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk) {
     GK_ARG(ctx && f && out_selfk, "gk_features_selfk: null argument");
     std::vector<u64> h(f->n_graphs);

@@ -123,6 +123,21 @@ __global__ __launch_bounds__(256) void gm_prep_kernel(const u32* __restrict__ ct
     for (u32 i = blockIdx.x * 256u + threadIdx.x; i < (Q + 3u) / 4u; i += stride) side_words[i] = 0u;
 }
 
+// The same for a layout the HOST knows (the ShortestPath histogram form): the table travels as a kernel argument and block 0
+// stores it -- no staged host-to-device copy (a launch of its own) in front of the job's first kernel.
+__global__ __launch_bounds__(256) void gm_prep_table_kernel(const GmTable Tv, GmTable* __restrict__ Td, u32* __restrict__ df,
+                                                             u32* __restrict__ cmax, u32* __restrict__ cursor, u32* __restrict__ side_words) {
+    if (blockIdx.x == 0) {
+        const u32* src = (const u32*)&Tv;
+        u32* dst = (u32*)Td;
+        for (int i = threadIdx.x; i < (int)(sizeof(GmTable) / 4); i += 256) dst[i] = src[i];
+    }
+    const u32 Q = Tv.Q;
+    const u32 stride = gridDim.x * 256u;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < Q; i += stride) df[i] = 0u, cmax[i] = 0u, cursor[i] = 0u;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < (Q + 3u) / 4u; i += stride) side_words[i] = 0u;
+}
+
 #ifdef GK_ABLATION
 // tools' build only (make abl; tools/dev/feat_ablate.py): timing ablations of gm_pairs_kernel, WRONG results by construction.
 // GK_GM_ABL bit 1: no df / class counting (emit), 2: no sort network, 4: no entry stores, 8: label loads only, 16 / 32: no
@@ -661,9 +676,13 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
                                                       int8_t* __restrict__ phi, i64 ld, i64 prim0 /* first byte of the primary region */,
                                                       int fp4, int kind, double* __restrict__ phi_w, i64 ldw,
                                                       i32* __restrict__ low_graph, i32* __restrict__ low_cnt, i32* __restrict__ low_lab,
-                                                      int8_t* __restrict__ phi_r, int parts) {
+                                                      int8_t* __restrict__ phi_r, int parts, i64 own_lo, i64 own_hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row[];
     const i64 g = blockIdx.x;
+    // multi-GPU, the operand-row exchange (grakel_amd/dist.py: exchange="phi"): a rank assembles and stores the rows of ITS
+    // graphs [own_lo, own_hi) only -- the others arrive with the all-gather --, but every graph's rare-label entries and
+    // float64 side columns are still listed: those stay complete on every rank
+    const bool own = g >= own_lo && g < own_hi;
     const i32 v0 = graph_ptr[g];
     __shared__ u32 pre[FEAT_MAX_LEVELS + 1];                     // entries of this graph in the levels before level j
     if (threadIdx.x < 64) {
@@ -676,9 +695,10 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
     __syncthreads();
     const int n_ent = P.L > 0 ? (int)pre[P.L] : 0;
     int seen_split = 0;
-#define GM_ROWS_BODY(Q_, COL_, C_) seen_split |= gm_row_entry(row, A, g, Q_, COL_, C_, prim0, fp4, kind, parts, phi_w, ldw, low_graph, low_cnt, low_lab);
+#define GM_ROWS_BODY(Q_, COL_, C_) if (own || COL_ < 0) seen_split |= gm_row_entry(row, A, g, Q_, COL_, C_, prim0, fp4, kind, parts, phi_w, ldw, low_graph, low_cnt, low_lab);
     GM_ROWS_GATHER((int)threadIdx.x, (int)blockDim.x)
 #undef GM_ROWS_BODY
+    if (!own) return;                                            // (workgroup-uniform)
     __syncthreads();
     uint4* dst = (uint4*)(phi + g * ld);
     for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) dst[i] = ((const uint4*)row)[i];
@@ -704,7 +724,7 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
                                                            int8_t* __restrict__ phi, i64 ld, i64 prim0, int fp4, int kind,
                                                            double* __restrict__ phi_w, i64 ldw, i32* __restrict__ low_graph,
                                                            i32* __restrict__ low_cnt, i32* __restrict__ low_lab, i64 n_rows_pad,
-                                                           int8_t* __restrict__ phi_r, int parts) {
+                                                           int8_t* __restrict__ phi_r, int parts, i64 own_lo, i64 own_hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row_all[];
     __shared__ u32 pre_all[4][FEAT_MAX_LEVELS + 1];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -735,9 +755,11 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int n_ent = P.L > 0 ? (int)pre[P.L] : 0;
     int seen_split = 0;
-#define GM_ROWS_BODY(Q_, COL_, C_) seen_split |= gm_row_entry(row, A, g, Q_, COL_, C_, prim0, fp4, kind, parts, phi_w, ldw, low_graph, low_cnt, low_lab);
+    const bool own = g >= own_lo && g < own_hi;                 // see gm_rows_kernel (wave-uniform)
+#define GM_ROWS_BODY(Q_, COL_, C_) if (own || COL_ < 0) seen_split |= gm_row_entry(row, A, g, Q_, COL_, C_, prim0, fp4, kind, parts, phi_w, ldw, low_graph, low_cnt, low_lab);
     GM_ROWS_GATHER(lane, 64)
 #undef GM_ROWS_BODY
+    if (!own) return;
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     uint4* dst = (uint4*)(phi + g * ld);
@@ -756,10 +778,13 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
     for (i64 i = lane; i < ld / 16; i += 64) dst[i] = ((const uint4*)row)[i];
 }
 
-// rows [n_graphs, n_rows_pad) of the operand: zero
-__global__ void gm_pad_rows_kernel(int8_t* __restrict__ phi, i64 bytes) {
+// rows [n_graphs, n_rows_pad) of the operand (and of the right operand of split columns, when there is one): zero
+__global__ void gm_pad_rows_kernel(int8_t* __restrict__ phi, int8_t* __restrict__ phi_r, i64 bytes) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < bytes / 16) ((uint4*)phi)[i] = make_uint4(0, 0, 0, 0);
+    if (i < bytes / 16) {
+        ((uint4*)phi)[i] = make_uint4(0, 0, 0, 0);
+        if (phi_r) ((uint4*)phi_r)[i] = make_uint4(0, 0, 0, 0);
+    }
 }
 
 // Second half of the graph-major builder, shared with the ShortestPath histogram form (gk_features_build_sp): column classes
@@ -838,6 +863,10 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
         ll = (i32*)q, f->arena.push_back(q);
     }
     GK_TRY(gk_func_lds(ctx, (const void*)gm_rows_kernel, (int)f->n_cols_pad));
+    // whose operand rows: all of them, or -- options feat.rows_lo / feat.rows_hi, the multi-GPU operand-row exchange -- one rank's
+    i64 own_lo = 0, own_hi = N;
+    if (ctx->opt.feat_rows_hi > ctx->opt.feat_rows_lo) own_lo = ctx->opt.feat_rows_lo, own_hi = std::min<i64>(N, ctx->opt.feat_rows_hi);
+    f->own_lo = own_lo, f->own_hi = own_hi;
     // one workgroup per graph (64- and 128-thread workgroups measured the same 30 us: the chain of dependent loads
     // slot -> entry -> column id binds, not the number of workgroups in flight)
     // small rows AND few entries per graph: a wave per graph, four graphs per workgroup (config 5, ~100 entries per graph:
@@ -845,15 +874,14 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     if (f->n_cols_pad <= GM_ROW_WAVE_MAX && f->nnz <= 192 * N && !ctx->opt.gm_rows_wg)
         gm_rows_wave_kernel<<<dim3((unsigned)cdiv(f->n_rows_pad, 4)), 256, (size_t)f->n_cols_pad * 4, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-            f->n_cols_wide_pad, lg, lc, ll, f->n_rows_pad, (int8_t*)f->phi_r, f->split_parts);        // ... and zeroes the padding rows
+            f->n_cols_wide_pad, lg, lc, ll, f->n_rows_pad, (int8_t*)f->phi_r, f->split_parts, own_lo, own_hi);        // ... and zeroes the padding rows
     else {
         gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
-            f->n_cols_wide_pad, lg, lc, ll, (int8_t*)f->phi_r, f->split_parts);
+            f->n_cols_wide_pad, lg, lc, ll, (int8_t*)f->phi_r, f->split_parts, own_lo, own_hi);
         const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
-        gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi + N * f->n_cols_pad, pad_bytes);
-        if (f->phi_r)
-            gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>((int8_t*)f->phi_r + N * f->n_cols_pad, pad_bytes);
+        gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>(
+            (int8_t*)f->phi + N * f->n_cols_pad, f->phi_r ? (int8_t*)f->phi_r + N * f->n_cols_pad : nullptr, pad_bytes);
     }
     GK_HIP_CHECK(hipGetLastError());
     // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries
@@ -1420,9 +1448,8 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     for (int j = 0; j < FEAT_MAX_LEVELS; ++j) Tv.poff[j] = R.off[j];
     Tmp<GmTable> table(ctx);
     GK_TRY(table.alloc(1));
-    GK_HIP_CHECK(hipMemcpyAsync(table.p, &Tv, sizeof(GmTable), hipMemcpyHostToDevice, ctx->stream));
-    gm_prep_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q, 1024), 1024)), 256, 0, ctx->stream>>>(nullptr, 0, 1, (u32)Q, 0, 0u, table.p, A.df, A.cmax, A.cursor,
-                                                                                          (u32*)A.side);
+    static_assert(sizeof(GmTable) % 4 == 0 && sizeof(GmTable) <= 3072, "GmTable travels as a kernel argument");
+    gm_prep_table_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q, 1024), 1024)), 256, 0, ctx->stream>>>(Tv, table.p, A.df, A.cmax, A.cursor, (u32*)A.side);
     SpSource S{pb->sp_node_ptr, pb->sp_node_label, pb->sp_dist_ptr, pb->sp_dist, pb->sp_idtab, pb->graph_ptr,
                (u64)pb->sp_L, (u64)pb->sp_dcap, pb->sp_with_labels};
     if (grid1 > 0) {

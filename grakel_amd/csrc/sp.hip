@@ -515,6 +515,107 @@ __global__ void sp_bin_pk_kernel(const i32* __restrict__ graph_ptr, const i32* _
     }
 }
 
+// Everything a job of at most SP_PREP_MAX_GRAPHS graphs needs before its all-pairs kernels, in ONE single-workgroup launch
+// (round 6): the counters cleared, n^2 per graph and its exclusive prefix (the matrices' offsets, their total), the size
+// classes of sp_bin_pk_kernel.  BASELINE config 4 queued seven launches of 2-6 us for this (two clears, squares, a two-kernel
+// scan, a clear, the binning) behind a host that had just waited for the previous step: ~60 us of the step's 640.
+#define SP_PREP_MAX_GRAPHS 65536
+__global__ __launch_bounds__(1024) void sp_prep_small_kernel(const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, i64 n_graphs, int cap,
+                                                             u64* __restrict__ dist_ptr, u64* __restrict__ total, u32* __restrict__ pair_count,
+                                                             u32* __restrict__ maxd, u32* __restrict__ cls_count, i32* __restrict__ cls_list) {
+    __shared__ u64 wsum[16];
+    __shared__ u64 carry_s;
+    __shared__ u32 cnt_s[32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 32) cnt_s[tid] = 0;
+    if (tid == 0) carry_s = 0, *maxd = 0;
+    __syncthreads();
+    for (i64 g0 = 0; g0 < n_graphs; g0 += 1024) {
+        const i64 g = g0 + tid;
+        u64 v = 0;
+        int c = -1, bc = -1;
+        if (g < n_graphs) {
+            const int n = graph_ptr[g + 1] - graph_ptr[g];
+            v = (u64)n * (u64)n;
+            pair_count[g] = 0;
+            c = n <= 0 ? 0 : (n <= 128 ? (n - 1) >> 4 : (n <= cap ? 8 : 9));
+            if (c == 9) {
+                const int m = row_ptr[graph_ptr[g + 1]] - row_ptr[graph_ptr[g]];
+                atomicMax(&cnt_s[10], (u32)m);
+                bc = spb_class(n, m);
+            }
+        }
+        u64 incl = v;                                        // inclusive scan of the chunk
+        for (int off = 1; off < 64; off <<= 1) {
+            const u64 o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        u64 before = carry_s;
+        for (int k = 0; k < w; ++k) before += wsum[k];
+        if (g < n_graphs) dist_ptr[g] = before + incl - v;
+        // the classes: slots from the workgroup's LDS counters (one atomic per wave and class)
+        for (int k = 0; k < 10; ++k) {
+            const u64 m = __ballot(c == k);
+            if (!m) continue;
+            u32 base = 0;
+            if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cnt_s[k], (u32)__popcll(m));
+            base = __shfl(base, (int)__builtin_ctzll(m), 64);
+            if (c == k) cls_list[(i64)k * n_graphs + base + __popcll(m & ((1ull << lane) - 1ull))] = (i32)g;
+        }
+        for (int k = 0; k < 6; ++k) {
+            const u64 m = __ballot(bc == k);
+            if (!m) continue;
+            u32 base = 0;
+            if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cnt_s[11 + k], (u32)__popcll(m));
+            base = __shfl(base, (int)__builtin_ctzll(m), 64);
+            if (bc == k) cls_list[(i64)(10 + k) * n_graphs + base + __popcll(m & ((1ull << lane) - 1ull))] = (i32)g;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u64 t = carry_s;
+            for (int k = 0; k < 16; ++k) t += wsum[k];
+            carry_s = t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry_s;
+    if (tid < 32) cls_count[tid] = cnt_s[tid];
+}
+
+// pair counts -> pair ranges of a job of at most SP_PREP_MAX_GRAPHS graphs: out[0 .. n] (exclusive prefix, the total at out[n]
+// and at *total) in one single-workgroup launch instead of a two-kernel scan and a 4-byte device copy
+__global__ __launch_bounds__(1024) void sp_pair_ranges_small_kernel(const u32* __restrict__ cnt, u32* __restrict__ out, i64 n, u32* __restrict__ total) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (i64 g0 = 0; g0 < n; g0 += 1024) {
+        const i64 g = g0 + tid;
+        const u32 v = g < n ? cnt[g] : 0u;
+        u32 incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        u32 before = carry_s;
+        for (int k = 0; k < w; ++k) before += wsum[k];
+        if (g < n) out[g] = before + incl - v;
+        __syncthreads();
+        if (tid == 0) {
+            u32 t = carry_s;
+            for (int k = 0; k < 16; ++k) t += wsum[k];
+            carry_s = t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry_s, *total = carry_s;
+}
+
 // class c = 1..8: graphs of (8(c-1), 8c] vertices, listed in cls_list[(c-1) * n_graphs ..); blocks are dealt to the
 // classes by the prefix cls_first[] (workgroups per class)
 struct SpClasses {
@@ -948,10 +1049,18 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     const i64 N = b->n_graphs;
     GK_TRY(s.sq.alloc(N)); GK_TRY(s.dist_ptr.alloc(N)); GK_TRY(s.total.alloc(1));
     GK_TRY(s.pair_count.alloc(N)); GK_TRY(s.maxd.alloc(1));
-    GK_TRY(gk_zero_async(ctx, s.pair_count.p, (size_t)N * 4));
-    GK_TRY(gk_zero_async(ctx, s.maxd.p, 4));
-    sp_sq_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, s.sq.p, N);
-    GK_TRY(gk_scan_u64(ctx, s.sq.p, s.dist_ptr.p, N, true, s.total.p));
+    // 16-bit packed registers whenever every finite distance of a graph of up to 128 vertices stays below 0x3fff
+    i64 wmax = 1;
+    if (edge_weight)
+        for (i64 e = 0; e < b->n_edges; ++e) wmax = edge_weight[e] > wmax ? edge_weight[e] : wmax;
+    const bool use_pk = wmax <= 128 && !ctx->opt.sp_no_reg && !ctx->opt.sp_no_pk;
+    const bool one_launch = use_pk && N <= SP_PREP_MAX_GRAPHS && !ctx->opt.sp_no_prep;      // sp_prep_small_kernel
+    if (!one_launch) {
+        GK_TRY(gk_zero_async(ctx, s.pair_count.p, (size_t)N * 4));
+        GK_TRY(gk_zero_async(ctx, s.maxd.p, 4));
+        sp_sq_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, s.sq.p, N);
+        GK_TRY(gk_scan_u64(ctx, s.sq.p, s.dist_ptr.p, N, true, s.total.p));
+    }
     // size classes (one wave per graph in registers up to 64 vertices, the LDS workgroup form up to the LDS cap, row
     // relaxation beyond): binned on the device, counts read back with the matrix total
     // unit weights: everything above the packed register kernels (128 vertices) goes to the breadth-first search -- the
@@ -961,13 +1070,11 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     Tmp<u32> cls_count(ctx);
     Tmp<i32> cls_list(ctx);
     GK_TRY(cls_count.alloc(32)); GK_TRY(cls_list.alloc((size_t)16 * (size_t)N));
-    GK_TRY(gk_zero_async(ctx, cls_count.p, 128));
-    // 16-bit packed registers whenever every finite distance of a graph of up to 128 vertices stays below 0x3fff
-    i64 wmax = 1;
-    if (edge_weight)
-        for (i64 e = 0; e < b->n_edges; ++e) wmax = edge_weight[e] > wmax ? edge_weight[e] : wmax;
-    const bool use_pk = wmax <= 128 && !ctx->opt.sp_no_reg && !ctx->opt.sp_no_pk;
-    if (use_pk) sp_bin_pk_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, N, cap, cls_count.p, cls_list.p);
+    if (!one_launch) GK_TRY(gk_zero_async(ctx, cls_count.p, 128));
+    if (one_launch)
+        sp_prep_small_kernel<<<1, 1024, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, N, cap, s.dist_ptr.p, s.total.p, s.pair_count.p, s.maxd.p,
+                                                          cls_count.p, cls_list.p);
+    else if (use_pk) sp_bin_pk_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, N, cap, cls_count.p, cls_list.p);
     else sp_bin_kernel<<<grid_for(N, 256), 256, 0, ctx->stream>>>(b->graph_ptr, b->row_ptr, N, cap, cls_count.p, cls_list.p);
     u32 h_cls[17];           // [10]: most adjacency entries of a class-9 graph, [11..16]: class 9 by search class (spb_class)
     {   // one mailbox round trip (a hipMemcpyAsync + stream drain pair costs a staging-copy kernel and ~25 us of idle device)
@@ -1355,14 +1462,38 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
     GK_TRY(gk_dev_alloc(ctx, &gp_guard.p, (size_t)(N + 1) * 4));
     u32* pair_base = (u32*)gp_guard.p;
     u32 h_pairs = 0, h_maxd = 0;
+    bool defer_rt = false;
+    u64 L0_early = 1;                                        // the alphabet of the keys, as the histogram form computes it below
+    if (with_labels) {
+        L0_early = (u64)(b->n_labels0 > 0 ? b->n_labels0 : 1);
+        if (b->n_levels > 0 && (u64)b->label_counts[0] > L0_early) L0_early = (u64)b->label_counts[0];
+    }
+    u64 dist_bound = 1;                                      // every finite distance is below it
+    {
+        i64 wm = 1;
+        if (edge_weight)
+            for (i64 e = 0; e < b->n_edges; ++e) wm = edge_weight[e] > wm ? edge_weight[e] : wm;
+        dist_bound = (u64)(b->max_graph_nodes > 1 ? b->max_graph_nodes - 1 : 0) * (u64)wm + 1;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         // attempt 1: a breadth-first search ran out of its 8-bit levels (a shortest path of 255 edges) -- once more, the
         // large graphs by row relaxation
         if (weight_f64) GK_TRY(sp_compute_dist_f64(ctx, b, weight_f64, graph_algo, s, &total_sq));
         else GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq, attempt == 1));
-        GK_TRY(ptotal.alloc(1));
-        GK_TRY(gk_scan_u32(ctx, s.pair_count.p, pair_base, N, true, ptotal.p));
-        GK_HIP_CHECK(hipMemcpyAsync(pair_base + N, ptotal.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        GK_TRY(ptotal.alloc(4));                             // [0] pairs, [1] distinct keys of the histogram form (below)
+        if (N <= SP_PREP_MAX_GRAPHS && !ctx->opt.sp_no_prep)
+            sp_pair_ranges_small_kernel<<<1, 1024, 0, ctx->stream>>>(s.pair_count.p, pair_base, N, ptotal.p);
+        else {
+            GK_TRY(gk_scan_u32(ctx, s.pair_count.p, pair_base, N, true, ptotal.p));
+            GK_HIP_CHECK(hipMemcpyAsync(pair_base + N, ptotal.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        // A job of small graphs with a small key space does not wait for the largest distance here (round 6): no breadth-first
+        // search can overflow without a graph above 128 vertices, the key space is laid out for the BOUND (n_max - 1) w_max
+        // of a distance -- any d1 above the largest distance serves -- and the pair count comes back with the number of
+        // distinct keys, one host round trip later.  (BASELINE config 4: four round trips per fit_transform -> three.)
+        defer_rt = !weight_f64 && n_levels == 1 && !ctx->opt.sp_no_hist && !ctx->opt.sp_no_prep && b->max_graph_nodes <= 128 &&
+                   dist_bound * L0_early * L0_early <= (1ull << 22) && L0_early < (1u << 15) && total_sq > (u64)V;
+        if (defer_rt) { h_maxd = (u32)(dist_bound - 1); h_pairs = 0; break; }
         u32 hb[2];
         GK_TRY(gk_readback2(ctx, ptotal.p, 1, s.maxd.p, 1, hb));
         h_pairs = hb[0], h_maxd = hb[1];
@@ -1392,7 +1523,7 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
         const u64 keyspace = d1 * L0 * L0;
         // round 5: the key space cap went from 2^22 to 2^26 keys (a presence byte and a 4-byte id each: 320 MB at the cap) --
         // 620 degree labels x 14 distances (REDDIT-like) are 5.4 M keys and used to leave for the pair items
-        if (n_levels == 1 && !ctx->opt.sp_no_hist && L0 < (1u << 15) && keyspace <= (1ull << 26) && h_pairs > 0) {
+        if (n_levels == 1 && !ctx->opt.sp_no_hist && L0 < (1u << 15) && keyspace <= (1ull << 26) && (h_pairs > 0 || defer_rt)) {
             Tmp<unsigned char> present(ctx);
             Tmp<u32> nk(ctx);
             if ((r = present.alloc((size_t)keyspace)) || (r = nk.alloc(1))) return fail(r);
@@ -1401,19 +1532,37 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
                 b->graph_ptr, b->labels, s.dist_ptr.p, s.dist.p, present.p, L0, d1, with_labels ? 1 : 0);
             if ((r = gk_dev_alloc(ctx, &q, (size_t)keyspace * 4))) return fail(r);
             pb->sp_idtab = (u32*)q;
-            SpIdScan sc{present.p, pb->sp_idtab, nk.p};
+            SpIdScan sc{present.p, pb->sp_idtab, defer_rt ? ptotal.p + 1 : nk.p};
             if ((r = gk_scan_fn<u32, SpIdScan>(ctx, sc, (i64)keyspace, nullptr))) return fail(r);
             if ((r = gk_dev_alloc(ctx, &q, (size_t)(N + 1) * 4))) return fail(r);
             pb->sp_node_ptr = (i32*)q;
             if ((r = gk_dev_alloc(ctx, &q, (size_t)(V > 0 ? V : 1) * 4))) return fail(r);
             pb->sp_node_label = (i32*)q;
             u32 h_nk = 0;
+            // the counts are posted first, the copies of the source graphs' sizes and labels run while the host waits for them
+            u32 ticket = 0;
+            const u32* rb_src = defer_rt ? ptotal.p : nk.p;
+            const int rb_n = defer_rt ? 2 : 1;
+            if ((r = gk_readback_post(ctx, rb_src, rb_n, &ticket))) return fail(r);
             if (hipMemcpyAsync(pb->sp_node_ptr, b->graph_ptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
                 (V > 0 && hipMemcpyAsync(pb->sp_node_label, b->labels, (size_t)V * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)) {
                 gk_set_error("gk_sp_build: %s", hipGetErrorString(hipGetLastError()));
                 return fail(GK_ERR_HIP);
             }
-            if ((r = gk_readback(ctx, nk.p, &h_nk, 1))) return fail(r);
+            if (defer_rt) {                                     // pairs and distinct keys in one read-back
+                u32 hb[2];
+                if ((r = gk_readback_collect(ctx, ticket, rb_src, hb, 2))) return fail(r);
+                h_pairs = hb[0], h_nk = hb[1];
+                pb->n_nodes = h_pairs;
+                if (h_pairs == 0) {                             // no finite pair in the whole job: the general route's empty batch
+                    gk_batch_destroy(pb);
+                    const int keep = ctx->opt.sp_no_prep;
+                    ctx->opt.sp_no_prep = 1;
+                    const int rr = sp_build_impl(ctx, b, edge_weight, weight_f64, graph_algo, with_labels, n_levels, out_pair_batch, out_n_pairs, out_n_keys);
+                    ctx->opt.sp_no_prep = keep;
+                    return rr;
+                }
+            } else if ((r = gk_readback_collect(ctx, ticket, rb_src, &h_nk, 1))) return fail(r);
             pb->sp_dist = s.dist.p, s.dist.p = nullptr;             // the matrices move into the pair batch
             pb->sp_dist_ptr = s.dist_ptr.p, s.dist_ptr.p = nullptr;
             pb->sp_hist = true, pb->sp_L = (i64)L0, pb->sp_dcap = (i64)d1, pb->sp_keyspace = (i64)keyspace, pb->sp_src_nodes = V;

@@ -293,12 +293,38 @@ def tensors_to_batch(graph_ptr, row_ptr, col_idx, labels, n_labels):
                       labels.cpu().numpy(), n_labels)
 
 
+def all_gather_rows(own, bounds, group=None):
+    """All-gather of ROW shards of unequal height: ``own`` is this rank's [n_own x row_bytes] uint8 tensor (rows
+    bounds[rank] .. bounds[rank + 1] of the whole), the result is the [bounds[-1] x row_bytes] tensor of all ranks' rows.
+    The collective wants equal shards (``all_gather_into_tensor``; RCCL on GPUs, gloo on the CPU box): every shard is padded
+    to the tallest one and the padding dropped afterwards.  This is the exchange ``north_star`` names -- the per-graph feature
+    vectors (operand rows of Phi) travel, not the graphs."""
+    import torch
+    import torch.distributed as dist
+    ws = dist.get_world_size(group)
+    heights = [bounds[r + 1] - bounds[r] for r in range(ws)]
+    tall, width = max(heights), own.shape[1]
+    send = own if own.shape[0] == tall else torch.cat([own, own.new_zeros((tall - own.shape[0], width))])
+    recv = own.new_empty((ws * tall, width))
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if all(h == tall for h in heights):
+        return recv
+    return torch.cat([recv[r * tall:r * tall + heights[r]] for r in range(ws)])
+
+
 class ShardedWL(object):
     """WL-subtree Gram with graphs and Gram rows sharded over the ranks of ``group``."""
 
-    def __init__(self, engine, n_iter=5, normalize=False, group=None, symmetric=False):
+    def __init__(self, engine, n_iter=5, normalize=False, group=None, symmetric=False, exchange="csr"):
         import torch.distributed as dist
         self.engine, self.n_iter, self.normalize, self.group = engine, n_iter, normalize, group
+        # What crosses xGMI besides the packed CSR shards (which every rank needs for the global label dictionary either way):
+        # "csr" (default): nothing -- every rank assembles the whole operand Phi_s itself (replicated, DESIGN 5);
+        # "phi": every rank assembles the operand rows of ITS graphs only and the row shards are all-gathered -- the
+        #        exchange north_star names.  Same matrix; an A/B switch for the first multi-GPU node this runs on.
+        if exchange not in ("csr", "phi"):
+            raise ValueError('exchange must be "csr" or "phi"')
+        self.exchange = exchange
         # False (default): plain row blocks, every rank multiplies and stores its whole block, no exchange.
         # True: the symmetric plan (half the multiply-adds, mirrored blocks over xGMI) -- slower as long as the
         # Gram kernel is store-bound (``gram_plan``)
@@ -351,6 +377,31 @@ class ShardedWL(object):
         self.last_events = ev        # elapsed_time(ev[0], ev[1]) = block products + packing, (ev[1], ev[2]) = exchange + placement
         return K
 
+    def _gather_operand_rows(self, eng, feat, bounds, rank, dev):
+        """exchange="phi": this rank's operand rows out of the library's buffer, all-gathered, the whole operand back in
+        (left operand and, when the job has split columns, right operand).  Staged through torch tensors: the collective
+        runs on torch's memory, two device copies of the operand (25-70 MB) are the price of keeping the library's buffers
+        its own.  ``self.phi_bytes`` = what one rank sent."""
+        import torch
+        import torch.distributed as dist
+        left, right, row_bytes, n_rows, own = eng.operand_rows(feat)
+        assert own == (bounds[rank], bounds[rank + 1]) and n_rows == bounds[-1], (own, bounds)
+        on_host = dist.get_backend(self.group) == "gloo"       # the CPU-side test backend has no device collectives
+        self.phi_bytes = 0
+        for ptr in (left, right):
+            if not ptr:
+                continue
+            mine = torch.empty((own[1] - own[0], row_bytes), dtype=torch.uint8, device=dev)
+            eng.memcpy_dev(mine.data_ptr(), ptr + own[0] * row_bytes, mine.numel())
+            if on_host:
+                torch.cuda.current_stream(dev).synchronize()
+                whole = all_gather_rows(mine.cpu(), bounds, self.group).to(dev)
+            else:
+                whole = all_gather_rows(mine, bounds, self.group)
+            eng.memcpy_dev(ptr, whole.data_ptr(), n_rows * row_bytes)
+            self.phi_bytes += mine.numel()
+            self._keepalive = (mine, whole)              # until the copies on the shared stream have run
+
     def _shared_stream(self, dev):
         """One torch side stream carries both the collective and the library's kernels, so the
         all-gather and its consumers are stream-ordered without a host synchronisation.  It has to be
@@ -396,9 +447,14 @@ class ShardedWL(object):
             db = eng.batch_from_shards(ex.all_sizes[:, :3], ex.mg, ex.mv, ex.me, flat.data_ptr(), n_labels)
             pe[1].record()
             counts = eng.wl_relabel(db, self.n_iter)
-            feat = eng.features(db, self.n_iter + 1)
-            pe[2].record()
             rows = (bounds[rank], bounds[rank + 1])
+            if self.exchange == "phi" and self.ws > 1:
+                with eng.options(**{"feat.rows_lo": rows[0], "feat.rows_hi": rows[1]}):
+                    feat = eng.features(db, self.n_iter + 1)
+                self._gather_operand_rows(eng, feat, bounds, rank, dev)
+            else:
+                feat = eng.features(db, self.n_iter + 1)
+            pe[2].record()
             N = db.n_graphs
             if block_rows and block_rows > 0:
                 K, info, gms, gfl = None, dict(), 0.0, 0.0

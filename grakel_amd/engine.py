@@ -495,6 +495,17 @@ class Engine(object):
             parts.append(DeviceFeatures(self, h, db, n_fit))
         return ChunkedFeatures(parts)
 
+    def operand_rows(self, feat):
+        """gk_features_operand_rows: (left operand ptr, right operand ptr or 0, bytes per row, rows, (own_lo, own_hi)) -- device
+        addresses as ints; the multi-GPU operand-row exchange (grakel_amd/dist.py) fills in the rows of the other ranks."""
+        a, b = c_void_p(), c_void_p()
+        rb, nr, lo, hi = c_int64(), c_int64(), c_int64(), c_int64()
+        check(self.lib.gk_features_operand_rows(feat.handle, byref(a), byref(b), byref(rb), byref(nr), byref(lo), byref(hi)))
+        return int(a.value or 0), int(b.value or 0), rb.value, nr.value, (lo.value, hi.value)
+
+    def memcpy_dev(self, dst_ptr, src_ptr, n_bytes):
+        check(self.lib.gk_memcpy_dev(self.handle, c_void_p(int(dst_ptr)), c_void_p(int(src_ptr)), int(n_bytes)))
+
     def selfk(self, feat):
         if isinstance(feat, ChunkedFeatures):
             return sum(self.selfk(p) for p in feat.parts)

@@ -84,7 +84,7 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *   features: "feat.no_gm" "feat.gm_no_priv" "feat.gm_rows_wg" "feat.low_df" (df below which a column becomes pair updates; default 24 (N / 10 000)^0.75 within [8, 128])
  *             "feat.gm_row_lds_max" (bytes of operand row the graph-major builder accepts: small values force the
  *             fall-back to the label-major builder)
- *   Gram:     "gram.dd" (the direct-store form of the persistent kernel: 1 always, 2 never, 0 per job) "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc" "gram.strip" (tile order: 1 the 8 x 8 patches of rounds 1-5, 2..32 strips of that many tile columns, 0 per job)
+ *   Gram:     "gram.dd" (the direct-store form of the persistent kernel: 1 always, 2 never, 0 per job) "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc" "feat.rows_lo" "feat.rows_hi" (the multi-GPU operand-row exchange: gk_features_operand_rows) "gram.strip" (tile order: 1 the 8 x 8 patches of rounds 1-5, 2..32 strips of that many tile columns, 0 per job)
  *             "gram.fold" (the rare labels' pair updates inside the tile kernel, which then normalises in its epilogue too, instead of float64
  *             atomics + a normalisation pass afterwards: 0 when it pays, 1 whenever legal, 2 never)
  *             "gram.pair_cap" (test hook: capacity of the per-tile pair buckets of that fold-in)
@@ -96,7 +96,7 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             above its diagonal only, the host threads widen AND mirror them and -- for a normalised job -- apply the
  *             1 / sqrt(K_ii K_jj) factors; 1 = the rectangular narrow copy, normalised matrices as plain float64)
  *             "gram.no_avx2" (those host threads keep to SSE2, what a CPU without AVX2 runs)
- *   paths:    "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
+ *   paths:    "sp.no_prep" (1: a job's set-up -- clears, n^2 prefix, size classes -- as separate launches instead of one single-workgroup kernel) "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
  *             histograms of the distance matrices),
  *             "sp.no_bfs" (graphs above the Floyd-Warshall LDS cap with unit weights: one row relaxation per source
  *             instead of the bit-parallel breadth-first search over 64 / 32 / 16 columns at a time),
@@ -252,6 +252,16 @@ int gk_features_info(gk_feat* f, int64_t* n_cols_kept, int64_t* n_cols_low, int6
 /* Layout of the dense operand: fp4 != 0 when the primary region holds MX fp4 (e2m1) codes, k_steps_fp4_or_i8 /
  * k_steps_i8_secondary = its 128-byte K-steps, n_cols_f64 = columns of the float64 side operand. */
 int gk_features_operand(gk_feat* f, int* fp4, int* k_steps_primary, int* k_steps_i8_secondary, int64_t* n_cols_f64);
+/* Multi-GPU, the operand-row exchange north_star names ("RCCL all-gather of per-graph feature vectors"; the default
+ * exchange of grakel_amd/dist.py and gk_batch_allgather is the packed CSR, SURVEY 8e / DESIGN 5): with the context options
+ * "feat.rows_lo" / "feat.rows_hi" set, gk_features_build assembles the dense operand rows of the graphs [lo, hi) only (the
+ * rare labels' lists and the float64 side operand stay complete on every rank); gk_features_operand_rows hands out the row
+ * buffers -- left and, when a job has split columns, right operand: [n_rows x row_bytes] bytes each, row g at g * row_bytes
+ * -- so that the caller's collective can fill in the other ranks' rows, and the range this job assembled.  gk_memcpy_dev is
+ * a device-to-device copy on the context's stream (staging buffers of that collective). */
+int gk_features_operand_rows(gk_feat* f, void** out_phi, void** out_phi_right, int64_t* out_row_bytes, int64_t* out_n_rows,
+                             int64_t* out_own_lo, int64_t* out_own_hi);
+int gk_memcpy_dev(gk_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t bytes);
 int gk_features_selfk(gk_ctx* ctx, gk_feat* f, double* out_selfk /* [n_graphs] */);
 /* Test hook: the dense column-compacted Phi_s as float64 [n_graphs x n_cols_kept]. */
 int gk_features_debug_phi(gk_ctx* ctx, gk_feat* f, double* out_phi);

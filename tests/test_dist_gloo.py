@@ -244,3 +244,39 @@ def test_all_gather_rebuilds_the_global_batch_world2(tmp_path):
         assert ok == 1
         rows.append((lo, hi))
     assert rows[0][0] == 0 and rows[0][1] == rows[1][0] and rows[1][1] == 23   # rows partition K
+
+
+def _rows_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from grakel_amd.dist import all_gather_rows, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = []
+        for n, width in ((301, 96), (300, 128), (7, 16), (2, 16)):          # ragged, even, tiny shards
+            b = shard_bounds(n, world)
+            whole = (torch.arange(n * width, dtype=torch.int64).reshape(n, width) % 251).to(torch.uint8)
+            got = all_gather_rows(whole[b[rank]:b[rank + 1]].clone(), b)
+            out.append(bool(torch.equal(got, whole)) and tuple(got.shape) == (n, width))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_operand_row_all_gather_world2():
+    """SURVEY 8e / north_star: "RCCL all-gather of per-graph feature vectors" -- grakel_amd.dist.all_gather_rows (the
+    exchange="phi" payload of ShardedWL) over gloo with two ranks: row shards of unequal height are padded for the
+    collective and come back as the whole operand, byte for byte, on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert got[0] == [True] * 4 and got[1] == [True] * 4

@@ -910,7 +910,7 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
 @pytest.mark.parametrize("route", [(), ("sp.no_hist",), ("sp.no_pk",), ("sp.no_reg",), ("sp.no_hist", "sp.no_reg"),
                                    ("feat.gm_row_lds_max",), ("feat.gm_no_priv",), ("sp.no_hist", "scan.direct_max"),
                                    ("sp.no_rows",), ("sp.no_bfs",), ("sp.bfs_no_lds_cols",), ("gram.no_split64",), ("gram.no_sym",), ("sp.rows_all",), ("sp.rows_all", "sp.hist_unit=1"),
-                                   ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv")],
+                                   ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv"), ("sp.no_prep",)],
                          ids=lambda r: "+".join(r) or "default")
 def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
     """ShortestPath picks among equivalent routes: all-pairs distances in 16-bit packed registers (one wave per graph up to
@@ -1195,7 +1195,16 @@ def _two_rank_worker(rank, world, port, out_dir):
         sw.symmetric = False
         K_full, info_full = sw.step(local, to_host=True)
         assert np.array_equal(K_full, K) and info_full["gram"][0] > 1.8 * info["gram"][0]
-        swn = ShardedWL(get_engine(0), n_iter=3, normalize=True)
+        # the operand-row exchange north_star names (exchange="phi"): every rank assembles the rows of ITS graphs only, the
+        # row shards (151 and 150 rows: ragged) are all-gathered -- same rows of the same matrix, normalised too
+        sp = ShardedWL(get_engine(0), n_iter=3, exchange="phi")
+        sp._stream, sw._stream = sw._stream, None
+        K_phi, info_phi = sp.step(local, to_host=True)
+        assert np.array_equal(K_phi, K) and sp.phi_bytes > 0 and info_phi["n_cols"] == info_full["n_cols"]
+        K_phi2, _ = sp.step(local, to_host=True)
+        assert np.array_equal(K_phi2, K)
+        sw._stream, sp._stream = sp._stream, None
+        swn = ShardedWL(get_engine(0), n_iter=3, normalize=True, exchange="phi")
         swn._stream, sw._stream = sw._stream, None
         Kn, _ = swn.step(local, to_host=True)
         np.save(os.path.join(out_dir, "Kn_%d.npy" % rank), Kn)
