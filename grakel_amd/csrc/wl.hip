@@ -112,8 +112,7 @@ __global__ __launch_bounds__(SIG_THREADS) void wl_signature_small_kernel(
                 todo &= todo - 1ull;
                 const i32 ns = __shfl(s, src, 64);
                 const int nd = __shfl(dv, src, 64);
-                u64 part = wave_node_signature<1>(col_idx, lab_prev, nbr_sorted, ns, nd, lane, seed);
-                for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+                u64 part = wave_sum_u64(wave_node_signature<1>(col_idx, lab_prev, nbr_sorted, ns, nd, lane, seed));
                 const i64 node = v0 + (tid & ~63) + src;
                 if (lane == 0) hash[node] = mix64(sig_head((u32)lab_prev[node], (u32)nd, seed) + part) & mask;
             }
@@ -213,30 +212,63 @@ __global__ __launch_bounds__(256) void wl_signature_wave_kernel(
     else part = wave_node_signature<16>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);      // (32 or 64 registers per lane:
     // the fully unrolled network no longer compiles to registers -- 272 B of scratch per lane, tried; hubs beyond 1024
     // neighbours keep the workgroup kernel, now 1024 threads wide)
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    part = wave_sum_u64(part);
     if (lane == 0) hash[v] = mix64(sig_head((u32)lab_prev[v], (u32)d, seed) + part) & mask;
 }
 
 // the verifier's half for the same nodes: a wave compares the node's sorted list with its class representative's,
 // 64 entries per step (verify_kernel walks a list with ONE thread: 200 us per level on the COLLAB-like batch)
+#define VB_PER_WAVE 4
 __global__ __launch_bounds__(256) void verify_big_kernel(const i32* __restrict__ big_nodes, i64 n_big, const i32* __restrict__ row_ptr,
                                                          const i32* __restrict__ lab_prev, const i32* __restrict__ nbr_sorted,
                                                          const i32* __restrict__ lab, const i32* __restrict__ rep,
                                                          u32* __restrict__ unresolved, const unsigned char* __restrict__ shared) {
-    const i64 w = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    // Round 6: FOUR listed vertices per wave.  One vertex per wave was a chain of four dependent round trips (vertex -> class ->
+    // representative -> its row -> the lists) per wave with nothing to overlap them: 108 us per level on the COLLAB-like batch
+    // (360 k vertices, 44 rounds of waves).  Lanes 0-3 walk the four chains side by side, the wave then compares the lists
+    // one vertex after the other with the first 64 entries of all of them already in flight.
+    const i64 w0 = (((i64)blockIdx.x * 256 + threadIdx.x) >> 6) * VB_PER_WAVE;
     const int lane = threadIdx.x & 63;
-    if (w >= n_big) return;
-    const i32 v = big_nodes[w];
-    if (shared && !shared[v]) return;              // a singleton is its own representative (rep[] has no entry for it)
-    const i32 r = rep[lab[v] & 0x7fffffff];
-    if (r == v) return;
-    const i32 s = row_ptr[v], sr = row_ptr[r];
-    const int d = row_ptr[v + 1] - s;
-    bool ok = lab_prev[v] == lab_prev[r] && d == row_ptr[r + 1] - sr;
-    if (ok)
-        for (int k = lane; k < d; k += 64)
-            if (nbr_sorted[s + k] != nbr_sorted[sr + k]) { ok = false; break; }
-    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull && lane == 0) atomicAdd(unresolved, 1u);
+    if (w0 >= n_big) return;
+    i32 hv = -1, hr = -1, hs = 0, hsr = 0, hd = 0;
+    bool hok = true;
+    if (lane < VB_PER_WAVE && w0 + lane < n_big) {
+        const i32 v = big_nodes[w0 + lane];
+        if (!(shared && !shared[v])) {                 // a singleton is its own representative (rep[] has no entry for it)
+            const i32 r = rep[lab[v] & 0x7fffffff];
+            if (r != v) {
+                hv = v, hr = r, hs = row_ptr[v], hsr = row_ptr[r], hd = row_ptr[v + 1] - hs;
+                hok = lab_prev[v] == lab_prev[r] && hd == row_ptr[r + 1] - hsr;
+            }
+        }
+    }
+    bool bad = false;
+    i32 a0[VB_PER_WAVE], b0[VB_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < VB_PER_WAVE; ++q) {            // the first 64 entries of every pair of lists: eight loads in flight
+        const i32 v = __shfl(hv, q, 64);
+        const int d = __shfl(hd, q, 64);
+        const i32 s = __shfl(hs, q, 64), sr = __shfl(hsr, q, 64);
+        const bool ok = __shfl((int)hok, q, 64) != 0;
+        a0[q] = b0[q] = 0;
+        if (v >= 0 && ok && lane < d) a0[q] = nbr_sorted[s + lane], b0[q] = nbr_sorted[sr + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < VB_PER_WAVE; ++q) {
+        const i32 v = __shfl(hv, q, 64);
+        if (v < 0) continue;                           // (wave-uniform)
+        const int d = __shfl(hd, q, 64);
+        const i32 s = __shfl(hs, q, 64), sr = __shfl(hsr, q, 64);
+        bool ok = __shfl((int)hok, q, 64) != 0;
+        if (ok) {
+            if (a0[q] != b0[q]) ok = false;
+            for (int k = lane + 64; k < d && ok; k += 64)
+                if (nbr_sorted[s + k] != nbr_sorted[sr + k]) ok = false;
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) bad = true;       // one count per vertex, as before
+        if (bad && lane == 0) { atomicAdd(unresolved, 1u); }
+        bad = false;
+    }
 }
 
 __global__ __launch_bounds__(BIG_THREADS) void wl_signature_big_kernel(
@@ -1635,7 +1667,7 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
         verify_kernel<<<grid_for(V, 256), 256, 0, ctx->stream>>>(b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev, V,
                                                                   flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr, big_apart);
         if (big_apart)
-            verify_big_kernel<<<grid_for(b->n_big * 64, 256), 256, 0, ctx->stream>>>(
+            verify_big_kernel<<<grid_for(cdiv(b->n_big, VB_PER_WAVE) * 64, 256), 256, 0, ctx->stream>>>(
                 b->big_nodes, b->n_big, b->row_ptr, prev, b->nbr_sorted, cur, rep.p, unresolved_dev,
                 flag_in_lab ? b->shared_flag + (size_t)level * V : nullptr);
         GK_HIP_CHECK(hipGetLastError());

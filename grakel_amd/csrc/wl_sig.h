@@ -58,6 +58,46 @@ __device__ __forceinline__ void sort_regs(i32 (&x)[16]) {
             }
 }
 
+// lane i <- lane (i ^ J) of a wave.  __shfl_xor is a ds_bpermute: every call goes through the CU's LDS crossbar, and a
+// wave-per-vertex signature makes 21 (sort) + 12 (64-bit reduction) of them per vertex -- round 6: the COLLAB-like batch spent
+// 222 us per level there, bound by that one pipe (360 k vertices x 33 crossbar passes per level).  Distances 1, 2, 4, 8 are
+// data-parallel primitives of the vector ALU (quad_perm, row_shl / row_shr under bank masks, row_ror), 16 is a ds_swizzle
+// (no address, no bank traffic); 32 is v_permlane32_swap: no crossbar pass left.
+template <int J>
+__device__ __forceinline__ i32 lane_xor(i32 x) {
+    if (J == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);            // quad_perm [1, 0, 3, 2]
+    if (J == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);            // quad_perm [2, 3, 0, 1]
+    if (J == 4) {                                                                      // banks 0, 2 <- lane + 4; banks 1, 3 <- lane - 4
+        const i32 t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);      // row_shl:4
+        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);             // row_shr:4
+    }
+    if (J == 8) return __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);            // row_ror:8
+    if (J == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);                       // bit mode: and 0x1f, xor 0x10
+    // 32: v_permlane32_swap (gfx950) exchanges the upper half of one register with the lower half of another; on two copies of x
+    // the first result holds x[0..31] in both halves, the second x[32..63] (tools/micro/lanexor.hip checks every distance)
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return (i32)((threadIdx.x & 32u) ? r[0] : r[1]);
+}
+__device__ __forceinline__ i32 lane_xor_by(i32 x, int j) {      // j a constant after unrolling
+    switch (j) {
+        case 1: return lane_xor<1>(x);
+        case 2: return lane_xor<2>(x);
+        case 4: return lane_xor<4>(x);
+        case 8: return lane_xor<8>(x);
+        case 16: return lane_xor<16>(x);
+        default: return lane_xor<32>(x);
+    }
+}
+// sum of a 64-bit value over the wave, in every lane
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int j = 1; j < 64; j <<= 1) {
+        const u32 lo = (u32)lane_xor_by((i32)(u32)v, j), hi = (u32)lane_xor_by((i32)(u32)(v >> 32), j);
+        v += ((u64)hi << 32) | lo;
+    }
+    return v;
+}
+
 // Bitonic network over ONE WAVE, 64 R elements striped over the lanes (element i = 64 r + lane): partners less than 64
 // apart by a lane shuffle, farther apart in the lane's own registers (static indices).  Pad with 0x7fffffff.
 #define WAVE_DEG_MAX 1024
@@ -83,7 +123,7 @@ __device__ __forceinline__ void wave_bitonic_sort(i32 (&x)[R], int lane) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const i32 a = x[r];
-                    const i32 b = __shfl_xor(a, j, 64);
+                    const i32 b = lane_xor_by(a, j);
                     const bool up = ((r * 64 + lane) & k) == 0;
                     x[r] = (lower == up) ? (a < b ? a : b) : (a < b ? b : a);
                 }
