@@ -31,6 +31,8 @@
 #define GM_META_WORDS 136
 #define GM_META_OVF 135           // gk_features_build_sp: a per-graph histogram table overflowed (last of the NNZ slots, unused otherwise)
 #define GM_MAX_NODES 1024         // largest graph a wave stages in LDS
+#define GM_WG_NODES 320           // ... and, in a job that has such graphs, everything above this many vertices goes to the workgroup kernel too
+#define GM_HUGE_MAX_NODES 8192    // largest graph of the graph-major builder: above GM_MAX_NODES a whole workgroup counts it (gm_pairs_huge_kernel)
 #define GM_ROW_LDS_MAX 65536      // widest operand row (bytes) assembled in LDS
 
 int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int prim_max, int wide_above);

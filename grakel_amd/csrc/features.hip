@@ -554,7 +554,7 @@ extern "C" int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, i
     }
     // ---- graph batches with small graphs: the graph-major builder (features_gm.hip); it declines (row wider
     // than its LDS image) with GK_ERR_UNSUPPORTED and this builder takes over
-    if (!b->is_pair_batch && V > 0 && b->max_graph_nodes <= GM_MAX_NODES && !ctx->opt.feat_no_gm) {
+    if (!b->is_pair_batch && V > 0 && b->max_graph_nodes <= (ctx->opt.gm_no_huge ? GM_MAX_NODES : GM_HUGE_MAX_NODES) && !ctx->opt.feat_no_gm) {
         r = gk_features_build_gm(ctx, b, f, n_levels, prim_max, wide_above);
         if (r == GK_OK) { *out = f; return GK_OK; }
         if (r != GK_ERR_UNSUPPORTED) return fail(r);      // incl. GK_ERR_RETRY: the queued relabel was unusable

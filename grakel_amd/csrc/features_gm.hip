@@ -154,7 +154,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                                                                 i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
                                                                 u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
                                                                 int rectangular, u32 df_cap, int T, int prim_max,
-                                                                int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta) {
+                                                                int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta, int wave_max) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private histogram | per wave: keys[T] | count + owner << 16 [T]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32* priv = (u32*)gm_lds;                                          // two 16-bit bins per word
@@ -163,7 +163,6 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
     __syncthreads();
     i32* keys = gm_lds + priv_cap_words + (size_t)w * 2 * T;
     u32* co = (u32*)(keys + T);
-    const u32 tmask = (u32)T - 1u;
     u32 maxc = 0, entries = 0;
     for (i64 g = (i64)blockIdx.x * WAVES + w; g < n_graphs; g += (i64)gridDim.x * WAVES) {
         const i32 v0 = graph_ptr[g], v1 = graph_ptr[g + 1];
@@ -177,6 +176,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
             if (lane == 0) selfk[g] = 0;
             continue;
         }
+        if (n > wave_max) continue;                           // a whole workgroup's (gm_pairs_huge_kernel)
         // the next level's labels (and flags) are fetched while the current level is counted
         i32 ra = 0, rb = 0;
         u32 fa = 0, fb = 0;                                   // 0: no node at this position / not shared
@@ -329,36 +329,51 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                 if (ca) emit(a, ca);
                 if (cb) emit(b2, cb);
             } else {
-                // ---- larger graphs: open-addressing table in LDS (compare-and-swap insertion, the claimer owns the entry)
-                for (int t = lane; t < T; t += 64) keys[t] = -1, co[t] = 0;
+                // ---- larger graphs: open-addressing table in LDS (compare-and-swap insertion, the claimer owns the entry).
+                // Round 6: the table is sized to THIS graph (2n slots, not twice the job's largest graph: a job with one
+                // graph of 1 000 vertices cleared 2 048 slots per level for every graph of 130), and the entries are stored
+                // compactly (the rows kernel walked a slot per node and level: 2 M slots for the 341 k vertices of the D&D-like set)
+                u32 Tg = 256;
+                while (Tg < 2u * (u32)n && Tg < (u32)T) Tg <<= 1;
+                const u32 gmask = Tg - 1u;
+                for (u32 t = lane; t < Tg; t += 64) keys[t] = -1, co[t] = 0;
                 __builtin_amdgcn_wave_barrier();
                 for (int i = lane; i < n; i += 64) {
                     const i32 x = lab[v0 + i];
                     if (!shareable(x) || (fl && !fl[v0 + i])) continue;
-                    u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+                    u32 h = ((u32)x * 2654435761u) >> 8 & gmask;
                     for (;;) {
                         const i32 old = atomicCAS(&keys[h], -1, x);
                         if (old == -1) { atomicAdd(&co[h], ((u32)i << 16) | 1u); break; }
                         if (old == x) { atomicAdd(&co[h], 1u); break; }
-                        h = (h + 1u) & tmask;
+                        h = (h + 1u) & gmask;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (int i = lane; i < n; i += 64) {
-                    const i32 x = lab[v0 + i];
+                u32 n_ent = 0;                                    // wave-uniform: entries stored so far
+                for (int i0 = 0; i0 < n; i0 += 64) {
+                    const int i = i0 + lane;
+                    i32 x = 0;
                     u32 c = 0;
-                    const bool sh = shareable(x) && (!fl || fl[v0 + i]);
-                    if (sh) {
-                        u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
-                        while (keys[h] != x) h = (h + 1u) & tmask;
-                        const u32 e = co[h];
-                        if ((e >> 16) == (u32)i) c = e & 0xffffu;
+                    if (i < n) {
+                        x = lab[v0 + i];
+                        if (shareable(x) && (!fl || fl[v0 + i])) {
+                            u32 h = ((u32)x * 2654435761u) >> 8 & gmask;
+                            while (keys[h] != x) h = (h + 1u) & gmask;
+                            const u32 e = co[h];
+                            if ((e >> 16) == (u32)i) c = e & 0xffffu;
+                        }
                     }
-                    el[i] = sh ? qof(x) : 0, ec[i] = c;
-                    if (c) emit(x, c);
+                    const u64 m = __ballot(c != 0);
+                    if (c) {
+                        const u32 k = n_ent + (u32)__builtin_popcountll(m & ((1ull << lane) - 1ull));     // k <= i: behind every position still to be read
+                        el[k] = qof(x), ec[k] = c;
+                        emit(x, c);
+                    }
+                    n_ent += (u32)__builtin_popcountll(m);
                 }
-                if (lane == 0) *ne = (u32)n;                      // one slot per node, count 0 = no entry
+                if (lane == 0) *ne = n_ent;
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -395,9 +410,125 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gm_pairs_kernel(const GmLevels 
                                                                 i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n, u64* __restrict__ selfk,
                                                                 u32* __restrict__ meta, int n_levels, int kind, i64 n_fit,
                                                                 int rectangular, u32 df_cap, int T, int prim_max,
-                                                                int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta) {
-    gm_pairs_body<GM_WAVES>(P, A, Tb, priv_cap_words, graph_ptr, n_graphs, V, ent_lab, ent_cnt, ent_n, selfk, meta, n_levels, kind, n_fit, rectangular, df_cap, T, prim_max, wide_above, part, wgmeta);
+                                                                int wide_above, u32* __restrict__ part, u32* __restrict__ wgmeta, int wave_max) {
+    gm_pairs_body<GM_WAVES>(P, A, Tb, priv_cap_words, graph_ptr, n_graphs, V, ent_lab, ent_cnt, ent_n, selfk, meta, n_levels, kind, n_fit, rectangular, df_cap, T, prim_max, wide_above, part, wgmeta, wave_max);
 }
+// Graphs above GM_MAX_NODES vertices (round 6: protein contact graphs of thousands of residues, discussion threads of
+// thousands of posts -- the D&D- and REDDIT-like sets): ONE WORKGROUP counts such a graph, level by level, in a 16 384-slot
+// table that fills its LDS -- the wave form's large-graph path with workgroup barriers.  Rounds 1-5 sent every job with one
+// such graph to the label-major builder, and with it to the relabel route with full sorts (its builder reads the
+// label-grouped node order): the twelve large graphs of the D&D-like set decided the route of the other 1 166.
+// Runs AFTER gm_reduce: its per-label statistics go onto the reduced ones with the guarded global atomics.
+#define GMH_T 16384
+#define GMH_THREADS 1024
+__global__ __launch_bounds__(GMH_THREADS) void gm_pairs_huge_kernel(const GmLevels P, const GmLabelArrays A, const GmTable* __restrict__ Tb,
+                                                                    const i32* __restrict__ graph_ptr, i64 n_graphs, i64 V,
+                                                                    i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt, u32* __restrict__ ent_n,
+                                                                    u64* __restrict__ selfk, int n_levels, int kind, i64 n_fit, int rectangular,
+                                                                    u32 df_cap, u32* __restrict__ wgmeta, int wg_base, int wave_max) {
+    extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // keys[GMH_T] | count + owner << 16 [GMH_T]
+    __shared__ u64 red_x[GMH_THREADS / 64];
+    __shared__ u32 red_m[GMH_THREADS / 64], red_e[GMH_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // (every LDS access indexes the one dynamic array: with derived pointers the compiler loses the address space of the
+    // atomics -- flat instructions on an LDS offset, a fault at address 0 on gfx950)
+    u32* const lds_u = (u32*)gm_lds;
+#define co(h) lds_u[GMH_T + (int)(h)]
+    u32 maxc = 0, entries = 0;
+    for (i64 g = blockIdx.x; g < n_graphs; g += gridDim.x) {
+        const i32 v0 = graph_ptr[g];
+        const int n = graph_ptr[g + 1] - v0;
+        if (n <= wave_max) continue;                          // (workgroup-uniform) a wave's
+        const u32 side_bit = g < n_fit ? 1u : 2u;
+        u64 extra = 0;
+        u32 Tg = 4096;                                        // this graph's table: 2n slots
+        while (Tg < 2u * (u32)n && Tg < (u32)GMH_T) Tg <<= 1;
+        const u32 tmask = Tg - 1u;
+        for (int j = 0; j < P.L; ++j) {
+            const i32* __restrict__ lab = P.lab[j];
+            const unsigned char* __restrict__ fl = P.flag[j];
+            const u32 lo = Tb->lo[j], nsh = Tb->S[j], ncc = Tb->ncc[j], qoff = Tb->off[j];
+            auto shareable = [&](i32 x) __attribute__((always_inline)) { return (u32)x - lo < nsh || (u32)x < ncc; };
+            auto qof = [&](i32 x) __attribute__((always_inline)) { return (i32)(qoff + ((u32)x < ncc ? (u32)x : ncc + ((u32)x - lo))); };
+            i32* __restrict__ el = ent_lab + (i64)j * V + v0;
+            u32* __restrict__ ec = ent_cnt + (i64)j * V + v0;
+            __syncthreads();                                  // the level before is done with the table
+            for (u32 t = tid; t < Tg; t += GMH_THREADS) gm_lds[t] = -1, co(t) = 0;
+            if (tid == 0) lds_u[2 * GMH_T] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += GMH_THREADS) {
+                const i32 x = lab[v0 + i];
+                if (!shareable(x) || (fl && !fl[v0 + i])) continue;
+                u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+                for (;;) {
+                    const i32 old = atomicCAS(&gm_lds[h], -1, x);
+                    if (old == -1) { atomicAdd(&co(h), ((u32)i << 16) | 1u); break; }       // the claimer owns the entry
+                    if (old == x) { atomicAdd(&co(h), 1u); break; }
+                    h = (h + 1u) & tmask;
+                }
+            }
+            __syncthreads();
+            // the entries are stored compactly (any order): a wave reserves its slots with ONE LDS atomic from lane 0 and places them
+            // by ballot -- the per-lane atomic on one counter that this replaced was aggregated by the compiler into a sequence
+            // that faulted on gfx950 (round 6; tools/dev/huge_dbg.py reproduces the job)
+            for (int i0 = w * 64; i0 < n; i0 += GMH_THREADS) {
+                const int i = i0 + lane;
+                i32 x = 0;
+                u32 c = 0;
+                if (i < n) {
+                    x = lab[v0 + i];
+                    if (shareable(x) && (!fl || fl[v0 + i])) {
+                        u32 h = ((u32)x * 2654435761u) >> 8 & tmask;
+                        while (gm_lds[h] != x) h = (h + 1u) & tmask;
+                        const u32 e = co(h);
+                        if ((e >> 16) == (u32)i) c = e & 0xffffu;
+                    }
+                }
+                const u64 m = __ballot(c != 0);
+                u32 base = 0;
+                if (lane == 0 && m) base = atomicAdd(&lds_u[2 * GMH_T], (u32)__builtin_popcountll(m));
+                base = __shfl(base, 0, 64);
+                if (c) {
+                    const u32 k = base + (u32)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    const i64 q = qof(x);
+                    el[k] = (i32)q, ec[k] = c;
+                    if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
+                    if (c >= 2u && __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) atomicMax(&A.cmax[q], c);
+                    if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
+                    if (!kind) extra += (u64)c * c - c;
+                    maxc = c > maxc ? c : maxc;
+                    ++entries;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) ent_n[(i64)j * n_graphs + g] = lds_u[2 * GMH_T];
+        }
+        for (int off = 32; off > 0; off >>= 1) extra += __shfl_down(extra, off, 64);
+        __syncthreads();
+        if (lane == 0) red_x[w] = extra;
+        __syncthreads();
+        if (tid == 0) {
+            u64 x = 0;
+            for (int k = 0; k < GMH_THREADS / 64; ++k) x += red_x[k];
+            selfk[g] = (u64)n * (u64)n_levels + x;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        entries += __shfl_down(entries, off, 64);
+        const u32 o = __shfl_down(maxc, off, 64);
+        maxc = o > maxc ? o : maxc;
+    }
+    __syncthreads();
+    if (lane == 0) red_m[w] = maxc, red_e[w] = entries;
+    __syncthreads();
+    if (tid == 0) {
+        u32 m = 0, e = 0;
+        for (int k = 0; k < GMH_THREADS / 64; ++k) m = red_m[k] > m ? red_m[k] : m, e += red_e[k];
+        wgmeta[2 * (wg_base + (int)blockIdx.x)] = m, wgmeta[2 * (wg_base + (int)blockIdx.x) + 1] = e;
+    }
+}
+#undef co
+
 // sum the workgroups' private histograms: df (saturating at what the column scan distinguishes), the count class as
 // a representative cmax (1, prim_max + 1 or wide_above + 1), the side bits
 __global__ __launch_bounds__(1024) void gm_reduce_kernel(const GmLabelArrays A, const GmTable* __restrict__ Tb,
@@ -792,7 +923,8 @@ __global__ void gm_pad_rows_kernel(int8_t* __restrict__ phi, int8_t* __restrict_
 // (node ranges, or pair ranges of a pair batch), V = items in all; ent / cnt / ent_n = the graphs' (label, count) entries.
 // Q = bound of the label space (the arrays' allocation; the label count itself is Tb->Q on the device)
 static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& A, const GmTable* Tb, i64 Q, const i32* graph_ptr, i64 N, i64 V,
-                     const i32* ent, const u32* cnt, const u32* ent_n, const u32* wgmeta, int grid, int prim_max, int wide_above) {
+                     const i32* ent, const u32* cnt, const u32* ent_n, const u32* wgmeta, int grid, int prim_max, int wide_above,
+                     bool huge_graphs = false) {
     const int kind = f->kind;
     void* q = nullptr;
     std::vector<u32> h(GM_META_WORDS, 0);
@@ -871,7 +1003,7 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     // slot -> entry -> column id binds, not the number of workgroups in flight)
     // small rows AND few entries per graph: a wave per graph, four graphs per workgroup (config 5, ~100 entries per graph:
     // 112 -> 85 us; ShortestPath histograms with ~10x the entries per graph: 30 us by workgroups, 76 us by waves)
-    if (f->n_cols_pad <= GM_ROW_WAVE_MAX && f->nnz <= 192 * N && !ctx->opt.gm_rows_wg)
+    if (f->n_cols_pad <= GM_ROW_WAVE_MAX && f->nnz <= 192 * N && !ctx->opt.gm_rows_wg && !huge_graphs)      // (a graph of thousands of vertices: a workgroup's walk)
         gm_rows_wave_kernel<<<dim3((unsigned)cdiv(f->n_rows_pad, 4)), 256, (size_t)f->n_cols_pad * 4, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
             f->n_cols_wide_pad, lg, lc, ll, f->n_rows_pad, (int8_t*)f->phi_r, f->split_parts, own_lo, own_hi);        // ... and zeroes the padding rows
@@ -966,9 +1098,15 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     const int rectangular = f->symmetric ? 0 : 1;
     // counting table per wave: only graphs of more than 128 nodes use it (smaller ones sort in registers), so a job without
     // such graphs leaves the LDS to the private histograms (config 3: level 2's 6 799 shared classes then count in LDS too)
+    // graphs above wave_max vertices: a workgroup each (gm_pairs_huge_kernel), persistent over the graph list.  A wave counts
+    // a graph of up to GM_MAX_NODES vertices, but as ~ 100 dependent LDS trips per level at a thousand vertices (the tail of
+    // the D&D-like set: 121 us); a job that has graphs above GM_MAX_NODES anyway hands everything above GM_WG_NODES over
+    const int wave_max = (b->max_graph_nodes > GM_MAX_NODES && !ctx->opt.gm_no_huge) ? GM_WG_NODES : GM_MAX_NODES;
     int T = 64;
     if (b->max_graph_nodes > 128)
-        while (T < 2 * b->max_graph_nodes) T <<= 1;
+        while (T < 2 * std::min<int>(b->max_graph_nodes, wave_max)) T <<= 1;
+    const bool huge = b->max_graph_nodes > wave_max;
+    const i64 grid_h = huge ? std::min<i64>(N, 1024) : 0;
     // ---- which levels count in workgroup-private histograms (small label spaces first come, 32 K bins in all)
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     const int waves = GM_WAVES, per_cu = 3;
@@ -992,7 +1130,7 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
     Tmp<u32> part(ctx), wgmeta(ctx);
     Tmp<GmTable> table(ctx);
     GK_TRY(table.alloc(1));
-    GK_TRY(wgmeta.alloc((size_t)grid * 2));
+    GK_TRY(wgmeta.alloc((size_t)(grid + grid_h) * 2));
     GK_TRY(part.alloc((size_t)grid * (size_t)(priv_cap_words > 0 ? priv_cap_words : 1)));
     // host-known layout: the table travels as it is (a by-value kernel argument of this size ends up in per-thread scratch)
     if (!stream) GK_HIP_CHECK(hipMemcpyAsync(table.p, &Tv, sizeof(GmTable), hipMemcpyHostToDevice, ctx->stream));
@@ -1000,10 +1138,16 @@ int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int
         stream ? b->sr_ctl : nullptr, f->level0, P.L, (u32)Q, priv_ok ? 1 : 0, (u32)priv_budget, table.p, A.df, A.cmax, A.cursor, (u32*)A.side);
     gm_pairs_kernel<<<dim3((unsigned)grid), 64 * waves, pairs_lds, ctx->stream>>>(
         P, A, table.p, priv_cap_words, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, f->selfk, f->meta, n_levels, kind, f->n_fit, rectangular,
-        (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p, wgmeta.p);
+        (u32)(f->low_df > 2 ? f->low_df : 2), T, prim_max, wide_above, part.p, wgmeta.p, wave_max);
     if (priv_cap_words > 0)
         gm_reduce_kernel<<<grid_for(priv_cap_words, 64), 1024, 0, ctx->stream>>>(A, table.p, part.p, (int)grid, prim_max, wide_above, rectangular);
-    return gm_finish(ctx, f, P, A, table.p, Q, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
+    if (huge) {
+        GK_TRY(gk_func_lds(ctx, (const void*)gm_pairs_huge_kernel, GMH_T * 8 + 16));
+        gm_pairs_huge_kernel<<<dim3((unsigned)grid_h), GMH_THREADS, GMH_T * 8 + 16, ctx->stream>>>(
+            P, A, table.p, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, f->selfk, n_levels, kind, f->n_fit, rectangular,
+            (u32)(f->low_df > 2 ? f->low_df : 2), wgmeta.p, (int)grid, wave_max);
+    }
+    return gm_finish(ctx, f, P, A, table.p, Q, b->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)(grid + grid_h), prim_max, wide_above, huge);
 }
 
 // ---------------------------------------------------------------------------------------------------

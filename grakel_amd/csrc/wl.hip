@@ -1702,7 +1702,8 @@ static int relabel_pass(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, b
     st.tiny = !ctx->opt.wl_no_tiny;
     // the graph-major feature builder (features_gm.hip) takes graph batches with small graphs: their full levels
     // then need no label-grouped order
-    st.no_order = !b->is_pair_batch && b->max_graph_nodes <= 1024 && !ctx->opt.feat_no_gm && !ctx->opt.wl_no_bucket_dict && !force_sort;
+    st.no_order = !b->is_pair_batch && b->max_graph_nodes <= (ctx->opt.gm_no_huge ? GM_MAX_NODES : GM_HUGE_MAX_NODES) && !ctx->opt.feat_no_gm &&
+                  !ctx->opt.wl_no_bucket_dict && !force_sort;
     st.tiny_level.assign((size_t)n_levels, 0);
     GK_TRY(st.frozen.alloc(V)); GK_TRY(st.act.alloc(V)); GK_TRY(st.fidx.alloc(V)); GK_TRY(st.scratch.alloc(4));
     GK_TRY(st.act2.alloc(V / 4 + 1));      // active-set levels hold at most V/4 active nodes

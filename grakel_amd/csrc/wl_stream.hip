@@ -728,7 +728,7 @@ int gk_sr_enqueue(gk_ctx* ctx, gk_batch* b, int n_levels, int hash_bits, bool de
     // ---- is this the job this route is built for?  (graph batches of small graphs whose features the graph-major builder
     // takes, a handful of input labels; everything else keeps wl.hip's route)
     if (ctx->opt.wl_no_stream || b->is_pair_batch || V <= 0 || n_levels < 2 || b->n_big > 0) return GK_ERR_UNSUPPORTED;
-    if (b->max_graph_nodes > GM_MAX_NODES || ctx->opt.feat_no_gm || ctx->opt.wl_no_bucket_dict || ctx->opt.wl_no_hist0) return GK_ERR_UNSUPPORTED;
+    if (b->max_graph_nodes > (ctx->opt.gm_no_huge ? GM_MAX_NODES : GM_HUGE_MAX_NODES) || ctx->opt.feat_no_gm || ctx->opt.wl_no_bucket_dict || ctx->opt.wl_no_hist0) return GK_ERR_UNSUPPORTED;
     if (!(b->n_labels0 >= 1 && b->n_labels0 <= GK_HIST0_MAX_LABELS)) return GK_ERR_UNSUPPORTED;
     if (hash_bits < 32 || hash_bits > 56 || !gk_bucket_dictionary_fits(ctx, V) || cdiv(V, SR_TILE) > SR_MAX_TILES) return GK_ERR_UNSUPPORTED;
     if (b->n_isolated != n_car || (n_car > 0 && !(b->car_class && b->car_nodes))) return GK_ERR_UNSUPPORTED;    // option wl.no_iso: nothing carried

@@ -2096,6 +2096,43 @@ def test_published_like_sets_shortest_path_at_full_size(gk, name):
     assert np.allclose(spn.transform(sub[:1]), zb["Kn_tr"], rtol=REL_TOL, atol=0)
 
 
+@pytest.mark.parametrize("no_huge", [0, 1])
+def test_graphs_of_thousands_of_vertices_through_the_graph_major_builder(gk, gkopt, no_huge):
+    """Round 6: a graph above 1 024 vertices is counted by a whole workgroup of the graph-major feature builder
+    (gm_pairs_huge_kernel; up to 8 192 vertices) instead of sending the job to the label-major builder and the relabel route
+    with full sorts (option feat.gm_no_huge = 1: rounds 1-5).  Chains with contacts of 1 100 .. 6 000 vertices next to small
+    graphs, few labels so that large classes survive several levels; partitions, matrix, normalised matrix and transform
+    against the oracle, and the route the relabel took."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    gkopt("feat.gm_no_huge", no_huge)
+    rs = np.random.RandomState(17)
+    X = []
+    for n in (1100, 40, 2500, 6000, 25, 1025, 3, 1024, 700):
+        ed = {i: [] for i in range(n)}
+        for v in range(1, n):
+            for u in {v - 1, max(0, v - 3) if rs.rand() < 0.5 else v - 1, int(rs.randint(0, v)) if rs.rand() < 0.05 else v - 1}:
+                if u != v and u not in ed[v]:
+                    ed[v].append(u), ed[u].append(v)
+        X.append([ed, dict(enumerate(rs.randint(0, 3, n).tolist()))])
+    ref = O.WLOracle(n_iter=3)
+    K = ref.fit_transform(X)
+    est = gk.WeisfeilerLehman(n_iter=3)
+    assert np.array_equal(est.fit_transform(X), K)
+    eng = get_engine()
+    db = eng.upload(wl_batch_from_input(X)[0])
+    assert eng.wl_relabel(db, 3) == ref.label_counts
+    assert db.stream_route == (not no_huge)                       # the route without host round trips takes the job now
+    db.close()
+    Kn = gk.WeisfeilerLehman(n_iter=3, normalize=True).fit_transform(X)
+    d = np.sqrt(np.diagonal(K))
+    assert np.allclose(Kn, K / np.outer(d, d), rtol=REL_TOL, atol=0)
+    assert np.array_equal(est.transform(X[2:5]), K[2:5])
+    # the host-driven route (wl.no_stream) with such graphs: the sort-free dictionary, no label-grouped order
+    gkopt("wl.no_stream", 1)
+    assert np.array_equal(gk.WeisfeilerLehman(n_iter=3).fit_transform(X), K)
+
+
 def test_transform_of_a_generator_above_the_lookup_threshold(gk):
     """`transform` ingests its input ONCE: a generator whose targets hold more than 1/32 of the fitted nodes (the look-up
     route declines, the joint route takes over) used to be exhausted by the first ingestion."""
