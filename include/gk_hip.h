@@ -97,7 +97,7 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             above its diagonal only, the host threads widen AND mirror them and -- for a normalised job -- apply the
  *             1 / sqrt(K_ii K_jj) factors; 1 = the rectangular narrow copy, normalised matrices as plain float64)
  *             "gram.no_avx2" (those host threads keep to SSE2, what a CPU without AVX2 runs)
- *   paths:    "sp.no_prep" (1: a job's set-up -- clears, n^2 prefix, size classes -- as separate launches instead of one single-workgroup kernel) "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
+ *   paths:    "sp.bfs_one_stream" (1: the breadth-first search's size classes one after the other instead of on two streams) "sp.no_prep" (1: a job's set-up -- clears, n^2 prefix, size classes -- as separate launches instead of one single-workgroup kernel) "sp.no_hist" (ShortestPath features from explicit pair items and the sorting dictionary instead of per-graph
  *             histograms of the distance matrices),
  *             "sp.no_bfs" (graphs above the Floyd-Warshall LDS cap with unit weights: one row relaxation per source
  *             instead of the bit-parallel breadth-first search over 64 / 32 / 16 columns at a time),
