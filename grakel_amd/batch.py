@@ -635,8 +635,9 @@ def _sp_first_shows_weights(X):
         g = X[0][0]
         if isinstance(g, np.ndarray):
             return bool(g.size) and (g.dtype.kind not in "biu" or int(g.max()) > 1 or int(g.min()) < 0)
-        if issparse(g):
-            return True                                            # not a form of the unit-weight walk
+        if issparse(g):                                            # CSR matrices of 0 / 1 entries take the walk (round 6)
+            d = g.data
+            return g.format != "csr" or (bool(d.size) and (d.dtype.kind not in "biu" or int(d.max()) > 1 or int(d.min()) < 0))
         if type(g) is dict:
             for k, v in g.items():
                 if type(v) is dict:

@@ -237,6 +237,23 @@ def test_pair_and_matrix_ingestion_in_c_equals_the_python_path():
              "matrix_not_square": mats[:5] + [[np.ones((3, 4), int), {0: 1, 1: 1, 2: 1}]],
              "matrix_labels_not_identity": mats[:5] + [[mats[5][0], dict(reversed(list(mats[5][1].items())))]],
              "matrix_fewer_labels": mats[:5] + [[np.ones((3, 3), int), {0: 1, 1: 1}]]}
+    # round 6: scipy.sparse adjacency matrices (graph.py:1564-1580 takes them as adjacency matrices).  CSR matrices take the
+    # threaded walk over indptr / indices / data; other formats, duplicate (non-canonical) entries, weights, explicit zeros,
+    # non-square shapes and a mixed input get the Python path's batch or exception
+    import scipy.sparse as sps
+    csr = [[sps.csr_matrix(a), l] for a, l in mats]
+    dup = sps.csr_matrix((np.array([1, 1, 1]), np.array([1, 1, 0]), np.array([0, 2, 3])), shape=(2, 2))      # (0, 1) twice
+    zero = sps.csr_matrix(mats[0][0] * 1.0)
+    zero.data[0] = 0.0                                                                                       # an explicit zero is no edge
+    cases.update({"csr_int64": csr, "csr_float32": [[sps.csr_matrix(a.astype(np.float32)), l] for a, l in mats],
+                  "csr_bool": [[sps.csr_matrix(a.astype(bool)), l] for a, l in mats],
+                  "csr_int32_indices_int8_data": [[sps.csr_matrix(a.astype(np.int8)), l] for a, l in mats[:64]],
+                  "csc_and_coo": [[sps.csc_matrix(a), l] for a, l in mats[:20]] + [[sps.coo_matrix(a), l] for a, l in mats[20:40]],
+                  "csr_weights_and_negatives": [[sps.csr_matrix(a * 2.5 - (1 - a)), l] for a, l in mats[:40]],
+                  "csr_with_duplicate_entries": csr[:70] + [[dup, {0: 1, 1: 2}]],
+                  "csr_with_an_explicit_zero": [[zero, mats[0][1]]] + csr[1:70],
+                  "csr_not_square": csr[:5] + [[sps.csr_matrix(np.ones((3, 4), int)), {0: 1, 1: 1, 2: 1}]],
+                  "csr_then_dense": csr[:70] + mats[70:80]})
     saved = B.INGEST_THREADS
     try:
         for threads in (0, 1, 3):
@@ -252,6 +269,13 @@ def test_pair_and_matrix_ingestion_in_c_equals_the_python_path():
         # the C module really took them (None = declined)
         assert B._gk_ingest.wl_ingest(sets, 2, False, 0, 0) is not None and B._gk_ingest.wl_ingest(mats, 2, False, 0, 0) is not None
         assert B._gk_ingest.wl_ingest(cases["string_vertices"], 2, False, 0, 0) is None
+        assert B._gk_ingest.wl_ingest(csr, 2, False, 0, 0) is not None and _both_paths(csr)[0][1:5] == ref[1:5]
+        assert B._gk_ingest.wl_ingest(cases["csc_and_coo"], 2, False, 0, 0) is None
+        assert B._gk_ingest.wl_ingest(cases["csr_with_duplicate_entries"], 2, False, 0, 0) is None
+        # ShortestPath's ingestion of unit-weight CSR matrices takes the same walk (sp_mode)
+        gs, _ = B.sp_batch_from_input(csr, True)
+        gd, _ = B.sp_batch_from_input(mats, True)
+        assert np.array_equal(gs.col_idx, gd.col_idx) and np.array_equal(gs.row_ptr, gd.row_ptr) and np.array_equal(gs.from_dict, gd.from_dict)
     finally:
         B.INGEST_THREADS = saved
 
