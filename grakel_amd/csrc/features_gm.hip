@@ -24,6 +24,7 @@
 #include "common.h"
 #include "scan_fn.h"
 #include "features.h"
+#include "wl_sig.h"
 #include <stdlib.h>
 
 static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(n, t) : 1)); }
@@ -265,7 +266,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                         if (GM_ABL(2)) break;
 #pragma unroll
                         for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                            const i32 pa = __shfl_xor(a, jj, 64);
+                            const i32 pa = lane_xor_by(a, jj);               // (DPP / swizzle / permlane: wl_sig.h; no LDS crossbar pass)
                             const bool lower = (lane & jj) == 0;
                             const bool asc = k == 64 ? true : (lane & k) == 0;
                             const i32 mna = a < pa ? a : pa, mxa = a < pa ? pa : a;
@@ -296,7 +297,7 @@ __device__ __forceinline__ void gm_pairs_body(const GmLevels P, const GmLabelArr
                             const i32 mn = a < b2 ? a : b2, mx2 = a < b2 ? b2 : a;
                             a = mn, b2 = mx2;
                         } else {
-                            const i32 pa = __shfl_xor(a, jj, 64), pb = __shfl_xor(b2, jj, 64);
+                            const i32 pa = lane_xor_by(a, jj), pb = lane_xor_by(b2, jj);
                             const bool lower = (lane & jj) == 0;
                             // direction: ascending iff (position & k) == 0; position = lane (+ 64 for the second register)
                             const bool asc_a = k == 128 ? true : (k == 64 ? true : (lane & k) == 0);

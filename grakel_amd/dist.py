@@ -44,11 +44,12 @@ def shard_bounds(n_graphs, world_size):
 
 
 # measured on one MI355X: float64 store rate of the Gram kernel in ROW-BLOCK mode (a rank's rows x all columns: no tile is
-# shared with its mirror image, so the operand stream per output byte is twice the symmetric job's -- 320 GB in 143 ms on
-# config 6's 25 000 x 200 000 sub-blocks, profiles/r05_config6_1gpu.json; the symmetric whole-matrix job reaches 3.2-4.4 TB/s),
+# shared with its mirror image, so the operand stream per output byte is twice the symmetric job's).  Round 6, strip-walk tile
+# order: 3.3 TB/s on config 6's 25 000 x 200 000 sub-blocks, 4.1 on 12 500 x 100 000, 4.6 on 6 250 x 50 000
+# (profiles/r06_strip_sweep.txt; round 5: 2.2-2.3 / 3.6 / 3.9) -- the model uses the lowest of them,
 # device-to-device transposed placement (read + write, profiles/r03_*), and the xGMI link rate per direction
 # (MI355X_MICROARCH.md: 7 links x 153.6 GB/s bidirectional, point to point -- a rank talking to p peers uses p links)
-GRAM_STORE_BPS = 2.2e12
+GRAM_STORE_BPS = 3.3e12
 PLACE_BPS = 1.5e12
 XGMI_LINK_BPS = 76.8e9
 
