@@ -674,6 +674,51 @@ __global__ __launch_bounds__(G3_THREADS) void gm_scan_sums_kernel(const GmColumn
     }
 }
 
+// The operand sizes as soon as they are known (round 6): the tile sums of gm_scan_sums_kernel are all the host waits for --
+// column counts per class, rare entries, the largest count -- so one workgroup adds them up, writes meta[] and POSTS the
+// mailbox itself (meta[], then the control words of a queued stream relabel); gm_scan_apply_kernel, which only turns the
+// same sums into column ids, runs behind it while the host is on its round trip.
+__global__ __launch_bounds__(G3_THREADS) void gm_totals_post_kernel(const GmColumns f, const Gm3* __restrict__ partial, int n_tiles_cap,
+                                                                    int n_meta, const u32* __restrict__ ctl, int n_ctl,
+                                                                    u32* __restrict__ mbox, u32 seq) {
+    __shared__ Gm3 bsum[G3_THREADS / 64];
+    __shared__ u32 pred[G3_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const i64 Q = f.Tb->Q;
+    const int n_tiles = (int)((Q + G3_TILE - 1) / G3_TILE) < n_tiles_cap ? (int)((Q + G3_TILE - 1) / G3_TILE) : n_tiles_cap;
+    const int parts = f.parts_by_block(pred);
+    if (w == 0) {                                      // the pair kernels' per-workgroup statistics
+        u32 m = 0, e = 0;
+        for (int k = lane; k < f.n_wg; k += 64) m = f.wgmeta[2 * k] > m ? f.wgmeta[2 * k] : m, e += f.wgmeta[2 * k + 1];
+        for (int off = 32; off > 0; off >>= 1) {
+            const u32 o = __shfl_down(m, off, 64);
+            m = o > m ? o : m, e += __shfl_down(e, off, 64);
+        }
+        if (lane == 0) f.meta[GM_META_MAXC] = m, f.meta[GM_META_NNZ] = e;
+    }
+    Gm3 s{0, 0, 0};
+    for (int i = threadIdx.x; i < n_tiles; i += G3_THREADS) s += partial[i];
+    for (int off = 32; off > 0; off >>= 1) s += gm3_shfl_down(s, off);
+    if (lane == 0) bsum[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Gm3 t{0, 0, 0};
+        for (int q = 0; q < G3_THREADS / 64; ++q) t += bsum[q];
+        f.finish(t, parts);
+    }
+    __threadfence();
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_meta + n_ctl; i += G3_THREADS)
+        __hip_atomic_store(&mbox[1 + i], i < n_meta ? __hip_atomic_load(&f.meta[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ctl[i - n_meta],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(G3_THREADS) void gm_scan_apply_kernel(const GmColumns f, const Gm3* __restrict__ partial) {
     __shared__ Gm3 wsum[G3_THREADS / 64];
     __shared__ Gm3 bsum[G3_THREADS / 64];
@@ -929,6 +974,7 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     const int kind = f->kind;
     void* q = nullptr;
     std::vector<u32> h(GM_META_WORDS, 0);
+    u32 early_seq = 0;
     if (Q > 0) {
         // counts above 127 under an int8 operand: split columns unless the option keeps the float64 side operand
         const int allow_split = (kind == GK_FEAT_DOT && f->dtype == 0 && !ctx->opt.gram_no_split8) ? 1 : 0;
@@ -936,11 +982,23 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
         const i64 nblk = cdiv(Q, G3_TILE);
         Tmp<Gm3> partial(ctx);
         GK_TRY(partial.alloc((size_t)nblk));
-        if (nblk > 1) gm_scan_sums_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
+        // the sizes are posted from the tile sums, the column ids follow behind the post (gm_totals_post_kernel)
+        const int nw0 = (f->batch && f->batch->sr_pending > 0) ? f->batch->sr_pending * SR_CTL : 0;
+        if (GM_META_WORDS + nw0 <= GK_MBOX_WORDS - 1 && !ctx->opt.gm_no_early_post) early_seq = gk_mbox_begin(ctx);
+        if (nblk > 1 || early_seq) gm_scan_sums_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
+        if (early_seq)
+            gm_totals_post_kernel<<<1, G3_THREADS, 0, ctx->stream>>>(gc, partial.p, (int)nblk, GM_META_WORDS, nw0 ? f->batch->sr_ctl : nullptr, nw0,
+                                                                     ctx->mbox_dev, early_seq);
         gm_scan_apply_kernel<<<dim3((unsigned)nblk), G3_THREADS, 0, ctx->stream>>>(gc, partial.p);
     }
     gk_batch* fb = f->batch;
-    if (fb && fb->sr_pending > 0) {
+    if (early_seq) {
+        const int nw = (fb && fb->sr_pending > 0) ? fb->sr_pending * SR_CTL : 0;
+        std::vector<u32> h2((size_t)GM_META_WORDS + (size_t)nw);
+        GK_TRY(gk_mbox_wait(ctx, early_seq, h2.data(), GM_META_WORDS + nw));
+        std::copy(h2.begin(), h2.begin() + GM_META_WORDS, h.begin());
+        if (nw && gk_sr_collect(ctx, fb, h2.data() + GM_META_WORDS) != GK_OK) return GK_ERR_RETRY;
+    } else if (fb && fb->sr_pending > 0) {
         // the relabel in front of this job was only queued (gk_sr_enqueue): its control words ride on the same round trip
         const int nw = fb->sr_pending * SR_CTL;
         std::vector<u32> h2((size_t)GM_META_WORDS + (size_t)nw);

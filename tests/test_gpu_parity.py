@@ -227,9 +227,12 @@ _HOST_ROUTES = [
     # round 5: the fused scans (scan_fn.h) with a scanned tile-sum array, the form jobs above 8 M items take, with the
     # sorting dictionary and the label-major feature builder (their users)
     ("scan.direct_max",), ("scan.direct_max", "wl.no_bucket_dict", "feat.no_gm"),
+    # round 6: the operand sizes read back after the column scan (rounds 2-5) instead of posted from its tile sums
+    ("feat.gm_no_early_post",),
 ]
 # round 4: the relabel route without host round trips (wl_stream.hip) is the default; its own switches
-ROUTE_OPTIONS = [(), ("wl.no_exact1",), ("wl.sig_no_regs",), ("feat.gm_no_priv",), ("feat.gm_rows_wg",), ("no_mailbox",)] + \
+ROUTE_OPTIONS = [(), ("wl.no_exact1",), ("wl.sig_no_regs",), ("feat.gm_no_priv",), ("feat.gm_rows_wg",), ("no_mailbox",),
+                 ("feat.gm_no_early_post",)] + \
     [r + ("wl.no_stream",) for r in _HOST_ROUTES]
 
 
