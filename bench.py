@@ -948,8 +948,8 @@ def main():
                        "gram_columns_rare": info.get("n_cols_low")},
             "checks": checks,
             "roofline": {
-                "kernel": "gram_ws_kernel (persistent, warp-specialised 128x128 tiles; MX fp4 operands for counts <= 4, "
-                          "int8 for 5..127; float64 store of K)",
+                "kernel": "gram_ws_kernel (persistent, warp-specialised 128x128 tiles, strip-walk tile order; MX fp4 operands "
+                          "for counts <= 4, int8 for 5..127; float64 store of K)",
                 "bound": bound,
                 "achieved": roofs["GB_per_s"] if bound == "hbm" else roofs["TFLOP_per_s"],
                 "peak": HBM_PEAK_GBS if bound == "hbm" else roofs["mfma_peak_TFLOP_per_s"],
