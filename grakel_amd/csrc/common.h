@@ -104,8 +104,10 @@ struct gk_opts {
     int sp_no_hist = 0;          // pair features through explicit pair items + the sorting dictionary instead of per-graph histograms
     int sp_no_bfs = 0;           // large unit-weight graphs by the row relaxation kernel instead of the bit-parallel breadth-first search
     int sp_bfs_no_lds_cols = 0;  // test hook: the breadth-first search reads the adjacency entries from HBM / L2, not from LDS
+    int sp_bfs_no_bytes = 0;     // 1: the breadth-first search stores its distance matrices as 32-bit entries (round 5) instead of BYTES (round 6)
     int sp_no_rows = 0;          // histogram form: no per-graph counter rows (a graph whose LDS table overflows sends the job to the pair items)
     int sp_rows_all = 0;         // test hook: every graph with a pair counts through counter rows (default: graphs above 6 144 pairs)
+    int sp_rows_no_merge = 0;    // 1: the counting workgroups add every matrix entry to the LDS table on its own (round 5) instead of per-lane runs of equal keys
     int sp_hist_unit = 0;        // test hook: distance-matrix entries per counting workgroup (0: 131 072)
     int sp_hist_slots = 0;       // test hook: slots of the counting workgroups' LDS table (0: 8 192; a power of two)
     int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)
@@ -302,6 +304,35 @@ struct gk_batch {
 #define SR_UNRES 5      // nodes whose full signature differs from their class representative's (hash collision)
 #define SR_NCC 6        // carried classes (isolated vertices by input label)
 #define SR_OVF 7        // a bucket of the dictionary overflowed
+
+// ---------------------------------------------------------------------------------------
+// ShortestPath distance matrices: 32-bit entries (SP_INF = unreachable), or -- round 6, the graphs the bit-parallel
+// breadth-first search takes (unit weights, every distance below 255) -- BYTES (255 = unreachable).  A byte matrix lives at
+// the start of the graph's own 32-bit region (n > 128: n * round_up(n, 16) + 15 <= 4 n^2), rows padded to 16 bytes so that a
+// lane fetches eight entries with one load; bit 63 of the graph's dist_ptr word says which form it is (set by the search
+// kernel itself, cleared whenever the offsets are computed again).  The matrices of the REDDIT-like set are 2.6 GB as
+// 32-bit entries, written once and read twice.
+// ---------------------------------------------------------------------------------------
+#define SP_BYTE_FLAG (1ull << 63)
+struct SpMat {
+    const i32* d32; const unsigned char* d8; int ns;      // d8 != nullptr: byte form, row stride ns
+};
+__device__ __forceinline__ SpMat sp_mat(const i32* __restrict__ dist, const u64* __restrict__ dist_ptr, i64 g, int n) {
+    const u64 o = dist_ptr[g];
+    SpMat m;
+    m.d32 = dist + (o & ~SP_BYTE_FLAG);
+    m.d8 = (o & SP_BYTE_FLAG) ? (const unsigned char*)(((uintptr_t)m.d32 + 15) & ~(uintptr_t)15) : nullptr;
+    m.ns = (n + 15) & ~15;
+    return m;
+}
+// entry (i, j) as a 32-bit distance with `inf` for an unreachable pair
+__device__ __forceinline__ i32 sp_mat_at(const SpMat& m, int n, int i, int j, i32 inf) {
+    if (m.d8) {
+        const unsigned char x = m.d8[(size_t)i * m.ns + j];
+        return x == 255 ? inf : (i32)x;
+    }
+    return m.d32[(size_t)i * n + j];
+}
 
 // ---------------------------------------------------------------------------------------
 // Features

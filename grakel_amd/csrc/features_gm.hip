@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
             for (int i = tid; i < n; i += SPH_THREADS) lab_s[i] = S.node_label[v0 + i];
         if (tid == 0) n_ent_s = 0, ovf_s = 0;
         __syncthreads();
-        const i32* dg = S.dist + S.dist_ptr[g];
+        const SpMat M = sp_mat(S.dist, S.dist_ptr, g, n);     // 32-bit entries, or bytes behind the breadth-first search (common.h)
         const u32 side_bit = g < n_fit ? 1u : 2u;
         // four matrix entries per thread and trip: the four distance loads are in flight together, then the four id
         // look-ups (the kernel is a chain of dependent round trips otherwise: one workgroup per CU, 16 graphs each)
@@ -1277,7 +1277,10 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = idx0 + u * SPH_THREADS + tid;
-                x[u] = idx < n * n ? dg[idx] : SPH_INF;
+                if (M.d8) {                                   // workgroup-uniform
+                    const int i = idx / n;
+                    x[u] = idx < n * n ? sp_mat_at(M, n, i, idx - i * n, SPH_INF) : SPH_INF;
+                } else x[u] = idx < n * n ? M.d32[idx] : SPH_INF;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1428,12 +1431,78 @@ __device__ __forceinline__ void spr_add(i32 key, u32 c, i32* keys, u32* co, u32 
     atomicAdd(&row[idtab[key]], c);
 }
 
+// the counting loop of sp_rows_count_kernel over a unit's matrix rows, for 32-bit and for byte matrices (B8; a branch on
+// the form inside the unrolled stages kept the compiler from batching the loads: 2.29 instead of 1.50 ms REDDIT-like)
+template <bool B8>
+__device__ __forceinline__ void spr_count_rows(const SpSource& S, const SpUnit& un, const SpMat& M, int n, i32 v0, u32 d1, bool col_in_lds,
+                                               const u32* colterm, i32* keys, u32* co, u32 tmask, u32 t_cap, u32* n_ent,
+                                               u32* __restrict__ row, bool merge) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const i32* dg = M.d32;
+    for (int i = un.r0 + w; i < un.r1; i += SPR_THREADS / 64) {       // a wave per matrix row: no division per entry
+        const u32 rowterm = S.with_labels ? d1 * (u32)S.L * (u32)S.node_label[v0 + i] : 0u;
+        const i32* dr = dg + (size_t)i * n;
+        const unsigned char* dr8 = M.d8 + (size_t)i * M.ns;          // byte matrix (round 6): same lane <-> column mapping, a byte per lane
+        // eight entries per lane and trip, stage by stage: the distance loads together, then the eight table probes together
+        // (one LDS latency instead of eight in a row -- the kernel is bound by dependent round trips, not by bandwidth or by
+        // atomic conflicts: merging equal keys of a wave first, by run detection or by ballot rounds, made it slower), then
+        // the counts as fire-and-forget atomics; a key that is not where its hash points takes the probing path.
+        // Round 6: a lane's consecutive entries (columns 64 apart) mostly carry the SAME key on the rows that cost most -- a hub
+        // reaches nearly every vertex in one or two steps and the labels are few -- and the count of a key is an LDS atomic
+        // that serialises over the lanes holding it.  A lane therefore adds up runs of equal keys first: inside a trip, and
+        // across trips through one PENDING (key, count) pair that is flushed when its key changes and at the end of the row.
+        // (Merging ACROSS lanes -- ballot rounds, run detection by shuffle -- cost more than it saved in round 5.)
+        i32 pk = -1;
+        u32 pc = 0;
+        for (int j0 = 0; j0 < n; j0 += 512) {
+            i32 x[8], key[8], old[8];
+            u32 h[8], c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * 64 + lane;
+                if (B8) {
+                    const unsigned char b8 = j < n ? dr8[j] : (unsigned char)255;
+                    x[u] = b8 == 255 ? SPH_INF : (i32)b8;
+                } else x[u] = j < n ? dr[j] : SPH_INF;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * 64 + lane;
+                key[u] = -1, c[u] = 1u;
+                if (j < n && j != i && x[u] < SPH_INF)
+                    key[u] = (i32)(rowterm + (col_in_lds ? colterm[j] : (S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u)) + (u32)x[u]);
+            }
+            if (merge) {
+                if (pk >= 0 && key[0] == pk) c[0] += pc, pk = -1;      // the pending pair joins the trip's first entry ...
+#pragma unroll
+                for (int u = 1; u < 8; ++u)
+                    if (key[u] >= 0 && key[u] == key[u - 1]) c[u] += c[u - 1], key[u - 1] = -1;
+                const i32 fk = pk;                                     // ... or is flushed with it (slot 7); the trip's last entry waits
+                const u32 fc = pc;
+                pk = key[7], pc = c[7];
+                key[7] = fk, c[7] = fc;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = ((u32)key[u] * 2654435761u) >> 8 & tmask;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) old[u] = key[u] >= 0 ? keys[h[u]] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (key[u] < 0) continue;
+                if (old[u] == key[u]) atomicAdd(&co[h[u]], c[u]);
+                else spr_add(key[u], c[u], keys, co, tmask, t_cap, n_ent, row, S.idtab);
+            }
+        }
+        if (pk >= 0) spr_add(pk, pc, keys, co, tmask, t_cap, n_ent, row, S.idtab);
+    }
+}
+
 __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSource S, const SpUnit* __restrict__ units, u32* __restrict__ rows,
-                                                                    i64 Q, int slots) {
+                                                                    i64 Q, int slots, int merge) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // keys[slots] | counts[slots] | column terms[min(n, SPR_COLS)]
     __shared__ u32 n_ent_s;
     const SpUnit un = units[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x;
     i32* keys = gm_lds;
     u32* co = (u32*)(keys + slots);
     u32* colterm = co + slots;
@@ -1447,41 +1516,10 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSour
         for (int j = tid; j < n; j += SPR_THREADS) colterm[j] = S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u;
     if (tid == 0) n_ent_s = 0;
     __syncthreads();
-    const i32* dg = S.dist + S.dist_ptr[un.g];
+    const SpMat M = sp_mat(S.dist, S.dist_ptr, un.g, n);
     u32* row = rows + (size_t)un.row * (size_t)Q;
-    for (int i = un.r0 + w; i < un.r1; i += SPR_THREADS / 64) {       // a wave per matrix row: no division per entry
-        const u32 rowterm = S.with_labels ? d1 * (u32)S.L * (u32)S.node_label[v0 + i] : 0u;
-        const i32* dr = dg + (size_t)i * n;
-        // eight entries per lane and trip, stage by stage: the distance loads together, then the eight table probes together
-        // (one LDS latency instead of eight in a row -- the kernel is bound by dependent round trips, not by bandwidth or by
-        // atomic conflicts: merging equal keys of a wave first, by run detection or by ballot rounds, made it slower), then
-        // the counts as fire-and-forget atomics; a key that is not where its hash points takes the probing path.
-        for (int j0 = 0; j0 < n; j0 += 512) {
-            i32 x[8], key[8], old[8];
-            u32 h[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * 64 + lane;
-                x[u] = j < n ? dr[j] : SPH_INF;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * 64 + lane;
-                key[u] = -1;
-                if (j < n && j != i && x[u] < SPH_INF)
-                    key[u] = (i32)(rowterm + (col_in_lds ? colterm[j] : (S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u)) + (u32)x[u]);
-                h[u] = ((u32)key[u] * 2654435761u) >> 8 & tmask;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) old[u] = key[u] >= 0 ? keys[h[u]] : -1;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (key[u] < 0) continue;
-                if (old[u] == key[u]) atomicAdd(&co[h[u]], 1u);
-                else spr_add(key[u], 1u, keys, co, tmask, t_cap, &n_ent_s, row, S.idtab);
-            }
-        }
-    }
+    if (M.d8) spr_count_rows<true>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, merge != 0);
+    else spr_count_rows<false>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, merge != 0);
     __syncthreads();
     for (int t = tid; t < slots; t += SPR_THREADS) {
         const i32 k = keys[t];
@@ -1678,7 +1716,8 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
         const i64 cols = std::min<i64>(pb->sp_max_nodes > 0 ? pb->sp_max_nodes : 1, SPR_COLS);
         const size_t lds1 = (size_t)slots * 8 + (size_t)cols * 4;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_count_kernel, (int)lds1));
-        sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots);
+        sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots,
+                                                                                              ctx->opt.sp_rows_no_merge ? 0 : 1);
         const size_t lds2 = (size_t)R.bins * 2;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_compact_kernel, (int)lds2));
         SpRowsOut O{ent.p, cnt.p, ent_n.p, f->selfk, part.p, wgmeta.p};

@@ -771,8 +771,8 @@ struct SpDist {
 template <typename W, int G, int NT, int VPT, int CLS>
 __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
     const i32* __restrict__ big_list, const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
-    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd, int n_lo,
-    int lds_bytes, int use_cols) {
+    u64* dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd, int n_lo,
+    int lds_bytes, int use_cols, int bytes_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spb_raw[];   // visit[n8] | front[n8] | d8[n8][G] | cols[m]
     __shared__ u64 hub_nx[SPB_HUB_CAP];
     __shared__ i32 hub_id[SPB_HUB_CAP], hub_e0[SPB_HUB_CAP], hub_dg[SPB_HUB_CAP];
@@ -881,13 +881,26 @@ __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
         }
     }
     // the group's columns of every row: whole segments, once
-    i32* dgm = dist + dist_ptr[g];
-    constexpr int RPW = 64 / G;                                       // rows per wave and trip
-    const int t = lane % G, col = gbase + t;
-    for (int u = w * RPW + lane / G; u < n; u += (NT / 64) * RPW) {
-        if (col < n) {
-            const unsigned char x = d8[u * GS + t];
-            dgm[(size_t)u * n + col] = x == 255 ? SP_INF : (i32)x;
+    const u64 moff = dist_ptr[g] & ~SP_BYTE_FLAG;                      // (workgroup y == 0 sets the flag while the others read)
+    i32* dgm = dist + moff;
+    if (bytes_out) {
+        // round 6: the matrix stays BYTES (common.h: SpMat) -- a quarter of the store here and of the two passes that read it
+        // (key marks, counting).  Four columns per lane: G / 4 lanes per row, 256 / G rows per wave and trip.
+        unsigned char* d8m = (unsigned char*)(((uintptr_t)dgm + 15) & ~(uintptr_t)15);
+        const int ns = (n + 15) & ~15;
+        constexpr int LPR = G / 4, RPW = 64 / LPR;
+        const int q = lane % LPR, col = gbase + 4 * q;
+        for (int u = w * RPW + lane / LPR; u < n; u += (NT / 64) * RPW)
+            if (col < ns) *(u32*)(d8m + (size_t)u * ns + col) = *(const u32*)(d8 + u * GS + 4 * q);
+        if (blockIdx.y == 0 && tid == 0) dist_ptr[g] = moff | SP_BYTE_FLAG;
+    } else {
+        constexpr int RPW = 64 / G;                                   // rows per wave and trip
+        const int t = lane % G, col = gbase + t;
+        for (int u = w * RPW + lane / G; u < n; u += (NT / 64) * RPW) {
+            if (col < n) {
+                const unsigned char x = d8[u * GS + t];
+                dgm[(size_t)u * n + col] = x == 255 ? SP_INF : (i32)x;
+            }
         }
     }
     block_count_max(cnt, mx, &pair_count[g], maxd);
@@ -901,7 +914,7 @@ static int sp_msbfs_launch(gk_ctx* ctx, gk_batch* b, SpDist& s, const i32* list,
     GK_TRY(gk_func_lds(ctx, (const void*)kern, lds));
     kern<<<dim3(n_list, (unsigned)cdiv(hi, G)), NT, (size_t)lds, st>>>(
         list, b->graph_ptr, b->row_ptr, b->col_idx, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, cap, lds,
-        ctx->opt.sp_bfs_no_lds_cols ? 0 : 1);
+        ctx->opt.sp_bfs_no_lds_cols ? 0 : 1, ctx->opt.sp_bfs_no_bytes ? 0 : 1);
     return GK_OK;
 }
 
@@ -910,6 +923,9 @@ static int sp_msbfs_launch(gk_ctx* ctx, gk_batch* b, SpDist& s, const i32* list,
 // finite pairs, reserves its range in the graph's item range with ONE atomic on the graph's cursor, and numbers its items
 // inside (the order of the items of a graph is immaterial: they are sorted by key afterwards).
 #define SP_SLAB 64
+#define SPM_SEEN_BITS 11
+#define SPM_SEEN (1 << SPM_SEEN_BITS)      // sp_mark_kernel: keys of the workgroup's LDS cache
+#define SPM_COLS 4096                      // ... and column terms staged in LDS up to this many vertices
 __global__ __launch_bounds__(SP_THREADS) void sp_emit_kernel(
     const i32* __restrict__ graph_ptr, const i32* __restrict__ node_label, const u64* __restrict__ dist_ptr,
     const i32* __restrict__ dist, const u32* __restrict__ pair_base, u64* __restrict__ keys,
@@ -921,12 +937,12 @@ __global__ __launch_bounds__(SP_THREADS) void sp_emit_kernel(
     const int r0 = blockIdx.y * SP_SLAB;
     if (r0 >= n) return;
     const int r1 = r0 + SP_SLAB < n ? r0 + SP_SLAB : n;
-    const i32* dg = dist + dist_ptr[g];
+    const SpMat M = sp_mat(dist, dist_ptr, g, n);
     const i64 lo = (i64)r0 * n, hi = (i64)r1 * n;
     u32 mine = 0;
     for (i64 idx = lo + tid; idx < hi; idx += SP_THREADS) {
         const int i = (int)(idx / n), j = (int)(idx - (i64)i * n);
-        if (i != j && dg[idx] < SP_INF) ++mine;
+        if (i != j && sp_mat_at(M, n, i, j, SP_INF) < SP_INF) ++mine;
     }
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
     if ((tid & 63) == 0) wsum[tid >> 6] = mine;
@@ -944,7 +960,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_emit_kernel(
         u64 key = 0;
         if (idx < hi) {
             const int i = (int)(idx / n), j = (int)(idx - (i64)i * n);
-            const i32 x = dg[idx];
+            const i32 x = sp_mat_at(M, n, i, j, SP_INF);
             if (i != j && x < SP_INF) {
                 ok = true;
                 key = (u64)x;
@@ -965,6 +981,62 @@ __global__ __launch_bounds__(SP_THREADS) void sp_emit_kernel(
     }
 }
 
+// the row loop of sp_mark_kernel (a wave per matrix row), for 32-bit and for byte matrices (B8: the form is a template
+// parameter -- a branch inside the unrolled stages keeps the compiler from batching the loads)
+template <bool B8>
+__device__ __forceinline__ void spm_mark_rows(const SpMat& M, int n, i32 v0, int r0, int r1, const i32* __restrict__ node_label,
+                                              unsigned char* __restrict__ present, u64 n_labels, u64 d1, int with_labels, bool col_in_lds,
+                                              const u32* colt_s, u32* seen_s) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const i32* dg = M.d32;
+    for (int i = r0 + (tid >> 6); i < r1; i += SP_THREADS / 64) {
+        const u32 rowterm = with_labels ? (u32)(d1 * (u64)(u32)node_label[v0 + i] * n_labels) : 0u;
+        const i32* dr = dg + (size_t)i * n;
+        const unsigned char* dr8 = M.d8 + (size_t)i * M.ns;
+        u32 last = 0xffffffffu;
+        // eight entries per lane and trip, every stage for all eight before the next: the loop is a chain of dependent
+        // round trips (distance -> label -> presence byte) and one entry per trip left the memory system idle (2.7 ms)
+        for (int j0 = 0; j0 < n; j0 += 512) {
+            i32 x[8];
+            u32 lj[8], key[8], hs[8], cached[8];
+            unsigned char seen[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * 64 + lane;
+                if (B8) {
+                    const unsigned char b8 = j < n ? dr8[j] : (unsigned char)255;
+                    x[u] = b8 == 255 ? SP_INF : (i32)b8;
+                } else x[u] = j < n ? dr[j] : SP_INF;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * 64 + lane;
+                lj[u] = j < n ? (col_in_lds ? colt_s[j] : (with_labels ? (u32)d1 * (u32)node_label[v0 + j] : 0u)) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * 64 + lane;
+                key[u] = 0xffffffffu;
+                if (j < n && j != i && x[u] < SP_INF) {
+                    const u32 k = rowterm + lj[u] + (u32)x[u];
+                    if (k != last) key[u] = k, last = k;
+                }
+                hs[u] = (key[u] * 2654435761u) >> (32 - SPM_SEEN_BITS);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cached[u] = key[u] != 0xffffffffu ? seen_s[hs[u]] : 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) seen[u] = cached[u] != key[u] ? present[key[u]] : (unsigned char)1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (cached[u] != key[u]) {
+                    if (!seen[u]) present[key[u]] = 1;  // same value from every writer
+                    seen_s[hs[u]] = key[u];             // (any racing writer leaves a key that has been marked)
+                }
+        }
+    }
+}
+
 // histogram form of the pair batch (features_gm.hip: gk_features_build_sp): which keys occur at all ...
 __global__ __launch_bounds__(SP_THREADS) void sp_mark_kernel(
     const i32* __restrict__ graph_ptr, const i32* __restrict__ node_label, const u64* __restrict__ dist_ptr,
@@ -975,48 +1047,25 @@ __global__ __launch_bounds__(SP_THREADS) void sp_mark_kernel(
     const int r0 = blockIdx.y * SP_SLAB;
     if (r0 >= n) return;
     const int r1 = r0 + SP_SLAB < n ? r0 + SP_SLAB : n;
-    const i32* dg = dist + dist_ptr[g];
-    if (n >= 256) {
+    const SpMat M = sp_mat(dist, dist_ptr, g, n);
+    const i32* dg = M.d32;
+    if (n >= 256 || M.d8) {
         // a wave per matrix row (round 5): no division per entry, the row's label term once per row, and a lane does not
-        // look up a key it has just marked (a thread with a hub: most of a row is one key)
-        const int lane = tid & 63;
-        for (int i = r0 + (tid >> 6); i < r1; i += SP_THREADS / 64) {
-            const u64 rowterm = with_labels ? d1 * (u64)(u32)node_label[v0 + i] * n_labels : 0ull;
-            const i32* dr = dg + (size_t)i * n;
-            u64 last = ~0ull;
-            // eight entries per lane and trip, every stage for all eight before the next: the loop is a chain of dependent
-            // round trips (distance -> label -> presence byte) and one entry per trip left the memory system idle (2.7 ms)
-            for (int j0 = 0; j0 < n; j0 += 512) {
-                i32 x[8];
-                u32 lj[8];
-                u64 key[8];
-                unsigned char seen[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u * 64 + lane;
-                    x[u] = j < n ? dr[j] : SP_INF;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u * 64 + lane;
-                    lj[u] = (with_labels && j < n) ? (u32)node_label[v0 + j] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u * 64 + lane;
-                    key[u] = ~0ull;
-                    if (j < n && j != i && x[u] < SP_INF) {
-                        const u64 k = rowterm + d1 * (u64)lj[u] + (u64)x[u];
-                        if (k != last) key[u] = k, last = k;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) seen[u] = key[u] != ~0ull ? present[key[u]] : (unsigned char)1;
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (!seen[u]) present[key[u]] = 1;     // same value from every writer
-            }
-        }
+        // look up a key it has just marked (a thread with a hub: most of a row is one key).  Byte matrices (round 6) are read
+        // with the same lane <-> column mapping, a byte per lane: eight consecutive entries per lane from one 8-byte load put
+        // the label loads of a wave on sixteen cache lines instead of two and cost more than the bytes saved (2.35 vs 1.48 ms).
+        // Round 6: the slab's 64 n entries are a few hundred distinct keys (REDDIT-like: at most 544 per GRAPH), and the
+        // presence bytes are a scattered gather per entry -- a direct-mapped LDS cache of keys this workgroup has marked
+        // answers nearly all of them (a lane that finds its key there skips the gather); the column terms d1 * label of the
+        // graph are staged in LDS once per workgroup instead of being fetched for every row.
+        __shared__ u32 seen_s[SPM_SEEN], colt_s[SPM_COLS];
+        const bool col_in_lds = n <= SPM_COLS;
+        for (int t = tid; t < SPM_SEEN; t += SP_THREADS) seen_s[t] = 0xffffffffu;          // (key space <= 2^26: never a key)
+        if (col_in_lds)
+            for (int j = tid; j < n; j += SP_THREADS) colt_s[j] = with_labels ? (u32)d1 * (u32)node_label[v0 + j] : 0u;
+        __syncthreads();
+        if (M.d8) spm_mark_rows<true>(M, n, v0, r0, r1, node_label, present, n_labels, d1, with_labels, col_in_lds, colt_s, seen_s);
+        else spm_mark_rows<false>(M, n, v0, r0, r1, node_label, present, n_labels, d1, with_labels, col_in_lds, colt_s, seen_s);
         return;
     }
     for (i64 idx = (i64)r0 * n + tid; idx < (i64)r1 * n; idx += SP_THREADS) {
@@ -1680,6 +1729,17 @@ extern "C" int gk_sp_debug_apsp(gk_ctx* ctx, gk_batch* b, const int32_t* edge_we
     GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const i64 n = gp[1] - gp[0];
     std::vector<i32> h((size_t)(n * n > 0 ? n * n : 1));
+    if (n > 0 && (dp[0] & SP_BYTE_FLAG)) {               // byte form (common.h: SpMat)
+        const i32* base = s.dist.p + (dp[0] & ~SP_BYTE_FLAG);
+        const unsigned char* d8 = (const unsigned char*)(((uintptr_t)base + 15) & ~(uintptr_t)15);
+        const i64 ns = (n + 15) & ~15ll;
+        std::vector<unsigned char> hb((size_t)(n * ns));
+        GK_HIP_CHECK(hipMemcpyAsync(hb.data(), d8, (size_t)(n * ns), hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (i64 i = 0; i < n; ++i)
+            for (i64 j = 0; j < n; ++j) out_dist[i * n + j] = hb[(size_t)(i * ns + j)] == 255 ? -1 : (i32)hb[(size_t)(i * ns + j)];
+        return GK_OK;
+    }
     if (n > 0) {
         GK_HIP_CHECK(hipMemcpyAsync(h.data(), s.dist.p + dp[0], (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -913,7 +913,8 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
 @pytest.mark.parametrize("route", [(), ("sp.no_hist",), ("sp.no_pk",), ("sp.no_reg",), ("sp.no_hist", "sp.no_reg"),
                                    ("feat.gm_row_lds_max",), ("feat.gm_no_priv",), ("sp.no_hist", "scan.direct_max"),
                                    ("sp.no_rows",), ("sp.no_bfs",), ("sp.bfs_no_lds_cols",), ("gram.no_split64",), ("gram.no_sym",), ("sp.rows_all",), ("sp.rows_all", "sp.hist_unit=1"),
-                                   ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv"), ("sp.no_prep",), ("sp.bfs_one_stream",)],
+                                   ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv"), ("sp.no_prep",), ("sp.bfs_one_stream",), ("sp.bfs_no_bytes",), ("sp.rows_all", "sp.rows_no_merge"),
+                                   ("sp.no_hist", "sp.bfs_no_bytes")],
                          ids=lambda r: "+".join(r) or "default")
 def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
     """ShortestPath picks among equivalent routes: all-pairs distances in 16-bit packed registers (one wave per graph up to
@@ -950,10 +951,12 @@ def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
     assert np.array_equal(gk.ShortestPath().fit_transform(big), O.SPOracle().fit_transform(big))
 
 
-@pytest.mark.parametrize("no_bfs", [0, 1, 2])
+@pytest.mark.parametrize("no_bfs", [0, 1, 2, 3, 4, 5])
 def test_large_unit_weight_graphs_directed_hubs_and_unreachable_pairs(gk, gkopt, no_bfs):
     """Graphs above 128 vertices with unit weights take the bit-parallel breadth-first search (sp.hip: sp_msbfs_kernel;
-    1: the row relaxation instead, 2: the search with the adjacency entries read from HBM instead of LDS).  What the
+    1: the row relaxation instead, 2: the search with the adjacency entries read from HBM instead of LDS, 3: the search
+    leaving 32-bit matrices instead of byte matrices, 4 / 5: byte matrices read by the pair-item route / by the LDS-table
+    histograms of every graph that fits one).  What the
     REDDIT- / D&D-like goldens do not hold (tests/golden/small_sets.py: sp_large_unit_graphs; golden from the real
     reference in sp_large_unit.npz): DIRECTED adjacency matrices (d[u][v] follows the out-edges of u), a hub above 32 and
     one above 1 024 neighbours next to vertices nothing leads to, more than 1 024 vertices (a thread owns several),
@@ -964,6 +967,9 @@ def test_large_unit_weight_graphs_directed_hubs_and_unreachable_pairs(gk, gkopt,
     from small_sets import sp_large_unit_graphs, sp_large_unit_paths
     gkopt("sp.no_bfs", 1 if no_bfs == 1 else 0)
     gkopt("sp.bfs_no_lds_cols", 1 if no_bfs == 2 else 0)
+    gkopt("sp.bfs_no_bytes", 1 if no_bfs == 3 else 0)
+    gkopt("sp.no_hist", 1 if no_bfs == 4 else 0)
+    gkopt("sp.no_rows", 1 if no_bfs == 5 else 0)
     z = load_golden("sp_large_unit.npz")
     G, P = sp_large_unit_graphs(), sp_large_unit_paths()
     assert np.array_equal(gk.ShortestPath().fit_transform(G), z["K"])
