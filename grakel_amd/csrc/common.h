@@ -107,7 +107,8 @@ struct gk_opts {
     int sp_bfs_no_bytes = 0;     // 1: the breadth-first search stores its distance matrices as 32-bit entries (round 5) instead of BYTES (round 6)
     int sp_no_rows = 0;          // histogram form: no per-graph counter rows (a graph whose LDS table overflows sends the job to the pair items)
     int sp_rows_all = 0;         // test hook: every graph with a pair counts through counter rows (default: graphs above 6 144 pairs)
-    int sp_rows_no_merge = 0;    // 1: the counting workgroups add every matrix entry to the LDS table on its own (round 5) instead of per-lane runs of equal keys
+    int sp_rows_no_merge = 0;    // bit 0: the counting workgroups add every matrix entry to the LDS table on its own (round 5) instead of per-lane runs of equal keys;
+                                 // bit 1: they walk a graph's rows in matrix order and never empty the table (round 5) instead of label by label, emptying it when it fills
     int sp_hist_unit = 0;        // test hook: distance-matrix entries per counting workgroup (0: 131 072)
     int sp_hist_slots = 0;       // test hook: slots of the counting workgroups' LDS table (0: 8 192; a power of two)
     int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)

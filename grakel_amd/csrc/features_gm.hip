@@ -1404,6 +1404,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
 #define SPR_THREADS 1024
 #define SPR_T 8192                  // LDS table slots (key + count)
 #define SPR_COLS 16384              // column terms d1 * label staged in LDS up to this many vertices
+#define SPR_CHECK_MAX 64            // rounds (of one matrix row per wave) between two fill checks of the table, at most
 #define SPR_UNIT (128 * 1024)       // matrix entries per unit (measured: 64 k .. 1 M, REDDIT- and D&D-like)
 
 struct SpUnit { i32 g, r0, r1, row; };
@@ -1436,10 +1437,24 @@ __device__ __forceinline__ void spr_add(i32 key, u32 c, i32* keys, u32* co, u32 
 template <bool B8>
 __device__ __forceinline__ void spr_count_rows(const SpSource& S, const SpUnit& un, const SpMat& M, int n, i32 v0, u32 d1, bool col_in_lds,
                                                const u32* colterm, i32* keys, u32* co, u32 tmask, u32 t_cap, u32* n_ent,
-                                               u32* __restrict__ row, bool merge) {
+                                               u32* __restrict__ row, bool merge, const i32* __restrict__ order, bool flush) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const i32* dg = M.d32;
-    for (int i = un.r0 + w; i < un.r1; i += SPR_THREADS / 64) {       // a wave per matrix row: no division per entry
+    // Rounds of one row per wave, in the LABEL-SORTED order of the graph's rows (sp_row_order_kernel), and the table is
+    // emptied into the counter row whenever it is nearly full (round 6).  A key (l_u, l_v, d) belongs to the rows of ONE label:
+    // walked label by label, a table epoch holds the keys of a few row labels and every key leaves it once or twice -- a
+    // D&D-like unit in matrix order met more distinct keys than the table holds and most of its counts were memory-side
+    // atomics on the row (172 M of them, 2.5 ms).  A job whose tables never fill (REDDIT-like) only pays the barrier.
+    // The fill checks are barriers, and a barrier per round costs a job whose tables never fill 14 % (REDDIT-like: 1.41 ->
+    // 1.61 ms): the next check is scheduled from the growth the table showed between the last two (every wave computes the
+    // same round from the same snapshot), at most SPR_CHECK_MAX rounds ahead.
+    const u32 soft_cap = t_cap - (t_cap >> 2);
+    __shared__ u32 fill_snap;
+    int round = 0, next_check = 0, last_round = -1;
+    u32 last_fill = 0;
+    for (int rr = un.r0; rr < un.r1; rr += SPR_THREADS / 64, ++round) {
+      if (rr + w < un.r1) {
+        const int i = order ? order[v0 + rr + w] : rr + w;
         const u32 rowterm = S.with_labels ? d1 * (u32)S.L * (u32)S.node_label[v0 + i] : 0u;
         const i32* dr = dg + (size_t)i * n;
         const unsigned char* dr8 = M.d8 + (size_t)i * M.ns;          // byte matrix (round 6): same lane <-> column mapping, a byte per lane
@@ -1494,11 +1509,68 @@ __device__ __forceinline__ void spr_count_rows(const SpSource& S, const SpUnit& 
             }
         }
         if (pk >= 0) spr_add(pk, pc, keys, co, tmask, t_cap, n_ent, row, S.idtab);
+      }
+      if (flush && round == next_check && rr + SPR_THREADS / 64 < un.r1) {        // workgroup-uniform
+          __syncthreads();
+          if (threadIdx.x == 0) fill_snap = *(volatile u32*)n_ent;
+          __syncthreads();
+          u32 fill = fill_snap;
+          const u32 grown = fill > last_fill ? fill - last_fill : 0u;
+          const u32 rate = grown / (u32)(round - last_round) + 1u;               // new keys per round, rounded up
+          if (fill >= soft_cap) {
+              for (u32 t = threadIdx.x; t <= tmask; t += SPR_THREADS) {
+                  const i32 k = keys[t];
+                  if (k >= 0) atomicAdd(&row[S.idtab[k]], co[t]), keys[t] = -1, co[t] = 0;
+              }
+              if (threadIdx.x == 0) *n_ent = 0;
+              __syncthreads();
+              fill = 0;
+          }
+          u32 ahead = (soft_cap - fill) / rate / 2u;
+          ahead = ahead < 1u ? 1u : (ahead > (u32)SPR_CHECK_MAX ? (u32)SPR_CHECK_MAX : ahead);
+          last_fill = fill, last_round = round, next_check = round + (int)ahead;
+      }
     }
 }
 
+// rows of a graph grouped by label (any order inside a label): order[v0 + p] = local row at position p.  One workgroup
+// per counter-row graph, a counting sort on an LDS histogram of the job's labels (identity beyond SPO_LABELS labels).
+#define SPO_LABELS 8192
+__global__ __launch_bounds__(256) void sp_row_order_kernel(const i32* __restrict__ row_graph, const i32* __restrict__ node_ptr,
+                                                           const i32* __restrict__ node_label, i32* __restrict__ order, int L, int with_labels) {
+    __shared__ u32 hist[SPO_LABELS];
+    __shared__ u32 wsum[4];
+    const int g = row_graph[blockIdx.x], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const i32 v0 = node_ptr[g];
+    const int n = node_ptr[g + 1] - v0;
+    if (!with_labels || L > SPO_LABELS) {
+        for (int r = tid; r < n; r += 256) order[v0 + r] = r;
+        return;
+    }
+    for (int t = tid; t < L; t += 256) hist[t] = 0;
+    __syncthreads();
+    for (int r = tid; r < n; r += 256) atomicAdd(&hist[node_label[v0 + r]], 1u);
+    __syncthreads();
+    const int per = (L + 255) / 256;                         // exclusive prefix: a contiguous run of bins per thread
+    u32 mine = 0;
+    for (int q = 0; q < per; ++q) mine += tid * per + q < L ? hist[tid * per + q] : 0u;
+    u32 inc = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 run = inc - mine;
+    for (int q = 0; q < w; ++q) run += wsum[q];
+    for (int q = 0; q < per; ++q)
+        if (tid * per + q < L) { const u32 c = hist[tid * per + q]; hist[tid * per + q] = run; run += c; }
+    __syncthreads();
+    for (int r = tid; r < n; r += 256) order[v0 + atomicAdd(&hist[node_label[v0 + r]], 1u)] = r;
+}
+
 __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSource S, const SpUnit* __restrict__ units, u32* __restrict__ rows,
-                                                                    i64 Q, int slots, int merge) {
+                                                                    i64 Q, int slots, int merge, const i32* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // keys[slots] | counts[slots] | column terms[min(n, SPR_COLS)]
     __shared__ u32 n_ent_s;
     const SpUnit un = units[blockIdx.x];
@@ -1518,8 +1590,8 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSour
     __syncthreads();
     const SpMat M = sp_mat(S.dist, S.dist_ptr, un.g, n);
     u32* row = rows + (size_t)un.row * (size_t)Q;
-    if (M.d8) spr_count_rows<true>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, merge != 0);
-    else spr_count_rows<false>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, merge != 0);
+    if (M.d8) spr_count_rows<true>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, (merge & 1) != 0, order, (merge & 2) == 0);
+    else spr_count_rows<false>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, (merge & 1) != 0, order, (merge & 2) == 0);
     __syncthreads();
     for (int t = tid; t < slots; t += SPR_THREADS) {
         const i32 k = keys[t];
@@ -1716,8 +1788,17 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
         const i64 cols = std::min<i64>(pb->sp_max_nodes > 0 ? pb->sp_max_nodes : 1, SPR_COLS);
         const size_t lds1 = (size_t)slots * 8 + (size_t)cols * 4;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_count_kernel, (int)lds1));
+        // rows walked label by label, the table emptied when it fills (option sp.rows_no_merge: 1 = no per-lane runs, 2 = matrix
+        // order and no emptying -- the round-5 walk --, 3 = both)
+        const int walk = ctx->opt.sp_rows_no_merge;
+        Tmp<i32> order(ctx);
+        if (!(walk & 2)) {
+            GK_TRY(order.alloc((size_t)(pb->sp_src_nodes > 0 ? pb->sp_src_nodes : 1)));
+            sp_row_order_kernel<<<dim3((unsigned)n_rows), 256, 0, ctx->stream>>>(row_graph_dev.p, pb->sp_node_ptr, pb->sp_node_label, order.p,
+                                                                                (int)pb->sp_L, pb->sp_with_labels);
+        }
         sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots,
-                                                                                              ctx->opt.sp_rows_no_merge ? 0 : 1);
+                                                                                              (walk & 1 ? 0 : 1) | (walk & 2), (walk & 2) ? nullptr : order.p);
         const size_t lds2 = (size_t)R.bins * 2;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_compact_kernel, (int)lds2));
         SpRowsOut O{ent.p, cnt.p, ent_n.p, f->selfk, part.p, wgmeta.p};

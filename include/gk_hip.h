@@ -105,8 +105,9 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "sp.bfs_no_bytes" (1: that search leaves 32-bit distance matrices -- rounds 3-5 -- instead of byte matrices),
  *             "sp.no_rows" (histogram form without the counter rows of the large graphs: one workgroup and one LDS table
  *             per graph, a table that overflows sends the whole job to the pair items -- the round-4 form),
- *             "sp.rows_no_merge" (1: the counter-row route adds every matrix entry to its LDS table on its own instead of
- *             per-lane runs of equal keys),
+ *             "sp.rows_no_merge" (bit 0: the counter-row route adds every matrix entry to its LDS table on its own instead of
+ *             per-lane runs of equal keys; bit 1: it walks a graph's rows in matrix order and never empties the table
+ *             instead of label by label with the table emptied into the counter row when it fills),
  *             "sp.rows_all" / "sp.hist_unit" / "sp.hist_slots" (test hooks of the counter-row route: every graph
  *             through it, distance-matrix entries per counting workgroup, slots of its LDS table),
  *             "sp.no_pk" (all-pairs distances never in the 16-bit packed register kernel: 32-bit registers up to 64
