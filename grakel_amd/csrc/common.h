@@ -107,6 +107,7 @@ struct gk_opts {
     int sp_bfs_no_bytes = 0;     // 1: the breadth-first search stores its distance matrices as 32-bit entries (round 5) instead of BYTES (round 6)
     int sp_no_rows = 0;          // histogram form: no per-graph counter rows (a graph whose LDS table overflows sends the job to the pair items)
     int sp_rows_all = 0;         // test hook: every graph with a pair counts through counter rows (default: graphs above 6 144 pairs)
+    int sp_static_type = 0;      // 1: the operand type of a ShortestPath histogram job from the a-priori bound pairs^2 (rounds 3-5) instead of the job's largest self similarity
     int sp_rows_no_merge = 0;    // bit 0: the counting workgroups add every matrix entry to the LDS table on its own (round 5) instead of per-lane runs of equal keys;
                                  // bit 1: they walk a graph's rows in matrix order and never empty the table (round 5) instead of label by label, emptying it when it fills
     int sp_hist_unit = 0;        // test hook: distance-matrix entries per counting workgroup (0: 131 072)
@@ -380,6 +381,7 @@ struct gk_feat {
     int low_df = 24;            // columns occurring in fewer graphs are applied as pair updates
     i64 n_rows_pad = 0;
     int dtype = 0;              // 0: int8 Phi, 1: f64 Phi
+    bool dyn_type = false;      // the operand type of this job was decided on the device from the exact self similarities (features.h: GM_META_TYPE)
     // Dense MFMA operand, [n_rows_pad][n_cols_pad BYTES], K-steps of 128 B per row:
     //   [secondary: n_cols8 int8 columns, k8_steps steps]  -- only when the primary region is fp4: counts 5..127
     //   [primary: n_cols1 columns, k1_steps steps]          -- phi_fp4: two columns per byte as MX fp4 (e2m1) codes of

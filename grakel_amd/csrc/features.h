@@ -26,6 +26,9 @@
 #define GM_META_RARE 3
 #define GM_META_RARE_ENTRIES 4
 #define GM_META_SPLIT 5           // parts of the split columns (0: labels with counts above 127 go to the float64 operand)
+#define GM_META_TYPE 6            // ShortestPath histogram jobs (round 6): operand type decided ON THE DEVICE from the largest self
+                                  // similarity (K_ij <= sqrt(K_ii K_jj)): 0 = fp4 + int8 (below 2^24), 1 = int8 (below 2^31), 2 = float64
+#define GM_META_SELFMAX 7         // ... and that largest K_ii, saturated to 32 bits: the job's entry bound
 #define GM_META_MAXC 8            // 64 partial maxima
 #define GM_META_NNZ 72            // 64 partial sums
 #define GM_META_WORDS 136

@@ -538,10 +538,20 @@ extern "C" int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, i
     // on a decline the pair items are materialised and the label-major builder below takes over
     if (b->is_pair_batch && b->sp_hist) {
         const bool hist_ok = n_levels == 1 && level_lo == 0 && kind == GK_FEAT_DOT && !ctx->opt.sp_no_hist;
+        // Round 6: the operand type of a histogram job is decided ON THE DEVICE from the largest self similarity the histograms
+        // leave (K_ij <= sqrt(K_ii K_jj) <= max K_ii: exact, where the a-priori bound is (pairs of the largest graph)^2 --
+        // 1.4 x 10^8 at BASELINE config 4, whose largest K_ii is a few 10^5: fp4 + int8 instead of int8 only; 5.8 x 10^10 on the
+        // COLLAB-like set: int8 instead of float64).  The counts are classified against 4 / 127 whatever the type turns out to be.
+        const bool dyn = hist_ok && !ctx->opt.sp_static_type;
+        const int static_dtype = f->dtype;
+        const bool static_fp4 = f->phi_fp4;
         for (int attempt = 0; attempt < 2; ++attempt) {
             // attempt 1: a table of the one-workgroup-per-graph kernel overflowed in a job that had skipped the counter rows
-            r = hist_ok ? gk_features_build_sp(ctx, b, f, prim_max, wide_above, attempt == 1) : GK_ERR_UNSUPPORTED;
+            f->dyn_type = dyn;
+            r = hist_ok ? gk_features_build_sp(ctx, b, f, dyn ? (ctx->opt.gram_no_fp4 ? 127 : 4) : prim_max, dyn ? 127 : wide_above, attempt == 1)
+                        : GK_ERR_UNSUPPORTED;
             if (r == GK_OK) { *out = f; return GK_OK; }
+            f->dyn_type = false, f->dtype = static_dtype, f->phi_fp4 = static_fp4, f->k_bound = bound;
             if (r != GK_ERR_UNSUPPORTED) return fail(r);
             for (void* p : f->arena)
                 if (p) gk_dev_free(ctx, p);

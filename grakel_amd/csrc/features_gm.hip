@@ -594,6 +594,7 @@ struct GmColumns {
     GmLabelArrays A; const GmTable* Tb; int symmetric; int low_df; int kind; int prim_max; int wide_above; u32* meta;
     const u32* wgmeta; int n_wg;                  // gm_pairs_kernel's per-workgroup (largest count, entries)
     int allow_split;                              // labels with counts above wide_above: split int8 columns (features.h) when <= GM_SPLIT_MAX_PARTS parts do
+    const u32* dyn;                               // ShortestPath histogram jobs: meta[GM_META_TYPE], 2 = every dense column to the float64 operand (nullptr: the type is the host's)
     // parts of the split columns from the largest count of the job: every workgroup of the scans derives the same from the pair
     // kernel's per-workgroup maxima, all of its threads loading at once (a single wave walking the list was 3 us per workgroup)
     __device__ __forceinline__ int parts_by_block(u32* red /* [G3_THREADS / 64] shared */) const {
@@ -616,6 +617,8 @@ struct GmColumns {
         Gm3 v{0, 0, 0};
         const u32 df = A.df[q];
         if (df == 0) return v;
+        int prim_max = this->prim_max, wide_above = this->wide_above;
+        if (dyn && *dyn == 2u) prim_max = -1, wide_above = -1, parts = 0;
         const bool useful = symmetric ? df >= 2u : A.side[q] == 3;
         if (!useful) return v;
         if ((int)df < low_df) { v.b = 1ull << 32, v.c = df; return v; }
@@ -977,8 +980,9 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     u32 early_seq = 0;
     if (Q > 0) {
         // counts above 127 under an int8 operand: split columns unless the option keeps the float64 side operand
-        const int allow_split = (kind == GK_FEAT_DOT && f->dtype == 0 && !ctx->opt.gram_no_split8) ? 1 : 0;
-        GmColumns gc{A, Tb, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta, grid, allow_split};
+        const int allow_split = (kind == GK_FEAT_DOT && (f->dtype == 0 || f->dyn_type) && !ctx->opt.gram_no_split8) ? 1 : 0;
+        GmColumns gc{A, Tb, f->symmetric ? 1 : 0, f->low_df, kind, prim_max, wide_above, f->meta, wgmeta, grid, allow_split,
+                     f->dyn_type ? f->meta + GM_META_TYPE : nullptr};
         const i64 nblk = cdiv(Q, G3_TILE);
         Tmp<Gm3> partial(ctx);
         GK_TRY(partial.alloc((size_t)nblk));
@@ -1008,6 +1012,13 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
     } else
         GK_TRY(gk_readback(ctx, f->meta, h.data(), GM_META_WORDS));     // one host sync: sizes of the operand
     if (h[GM_META_OVF]) return GK_ERR_UNSUPPORTED;                  // a histogram table of gk_features_build_sp overflowed
+    if (f->dyn_type) {                                              // the type the device chose (sp_type_kernel)
+        const u32 type = h[GM_META_TYPE];
+        f->dtype = type == 2u ? 1 : 0;
+        f->phi_fp4 = type == 0u && !ctx->opt.gram_no_fp4;
+        if (type < 2u) f->k_bound = (double)h[GM_META_SELFMAX] + 1.0;
+        else h[GM_META_SPLIT] = 0;                                  // (the column scan ignored the split in that case)
+    }
     f->n_cols1 = h[GM_META_PRIM], f->n_cols8 = h[GM_META_INT8], f->n_cols = f->n_cols1 + f->n_cols8;
     f->n_cols_wide = h[GM_META_F64], f->n_low_cols = h[GM_META_RARE];
     f->split_parts = 0, f->n_split_labels = 0;
@@ -1533,6 +1544,24 @@ __device__ __forceinline__ void spr_count_rows(const SpSource& S, const SpUnit& 
     }
 }
 
+// operand type of a histogram job from its largest self similarity (features.h: GM_META_TYPE); one workgroup
+__global__ __launch_bounds__(1024) void sp_type_kernel(const u64* __restrict__ selfk, i64 n, u32* __restrict__ meta, int fp4_ok) {
+    __shared__ u64 red[16];
+    u64 m = 0;
+    for (i64 g = threadIdx.x; g < n; g += 1024) m = selfk[g] > m ? selfk[g] : m;
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 16; ++q) m = red[q] > m ? red[q] : m;
+        meta[GM_META_TYPE] = (m < (1ull << 24) && fp4_ok) ? 0u : (m < 0x7fffffffull ? 1u : 2u);
+        meta[GM_META_SELFMAX] = m < 0xffffffffull ? (u32)m : 0xffffffffu;
+    }
+}
+
 // rows of a graph grouped by label (any order inside a label): order[v0 + p] = local row at position p.  One workgroup
 // per counter-row graph, a counting sort on an LDS histogram of the job's labels (identity beyond SPO_LABELS labels).
 #define SPO_LABELS 8192
@@ -1809,6 +1838,7 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     GK_HIP_CHECK(hipGetLastError());
     if (R.bins > 0)
         gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(A, table.p, part.p, (int)grid, prim_max, wide_above, rectangular);
+    if (f->dyn_type) sp_type_kernel<<<1, 1024, 0, ctx->stream>>>(f->selfk, N, f->meta, ctx->opt.gram_no_fp4 ? 0 : 1);
     // the overflow word travels with the operand sizes: meta[] is read back once, in gm_finish
     return gm_finish(ctx, f, P, A, table.p, Q, pb->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
 }
