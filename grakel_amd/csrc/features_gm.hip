@@ -1239,148 +1239,281 @@ struct SpSource {
     u64 L, d1; int with_labels;
 };
 
+// Round 6: BATCHES of graphs.  One workgroup per CU walks its graphs one after the other, and every graph is four phases
+// (clear, walk, void check, compaction) with a barrier and a chain of dependent round trips each -- 16 graphs x ~7 us per
+// workgroup at BASELINE config 4, whatever the 900 entries of a graph cost.  The table is 8 192 slots because ONE graph may need
+// them; a 30-vertex graph needs 2 048.  So a workgroup now takes as many of its graphs at a time as fit the table (regions of
+// T_k slots, T_k = the power of two >= 2 pairs, up to SPH_BATCH graphs, their labels together within SPH_LAB) and runs every
+// phase once for all of them: an entry finds its graph by a scan over at most eight prefix values, a 64-slot chunk of the
+// table belongs to one graph (regions are multiples of 64), everything else is as before.  bmax = 1 is the round-5 walk.
+#ifdef GK_ABLATION
+// tools' build only: workgroup 0's cycles per phase of sp_hist_kernel (batch selection, clear + labels, walk, void check,
+// compaction, finish) and its batches / graphs: tools/dev/sph_times.py
+__device__ unsigned long long g_sph_dbg[8];
+#define SPH_DBG_DECL unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_x = __builtin_readcyclecounter();
+#define SPH_DBG(k) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_y = __builtin_readcyclecounter(); t_ph[k] += t_y - t_x; t_x = t_y; } }
+#define SPH_DBG_CNT(k, v) { if (blockIdx.x == 0 && threadIdx.x == 0) t_ph[k] += (v); }
+#define SPH_DBG_OUT() { if (blockIdx.x == 0 && threadIdx.x == 0) for (int q_ = 0; q_ < 8; ++q_) g_sph_dbg[q_] = t_ph[q_]; }
+extern "C" int gk_debug_sph_times(gk_ctx* ctx, unsigned long long* out8) {
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    GK_HIP_CHECK(hipDeviceSynchronize());
+    GK_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sph_dbg), sizeof(unsigned long long) * 8));
+    return GK_OK;
+}
+#else
+#define SPH_DBG_DECL
+#define SPH_DBG(k)
+#define SPH_DBG_CNT(k, v)
+#define SPH_DBG_OUT()
+#endif
+#define SPH_BATCH 8
+#define SPH_CAND 8                  // candidate graphs wave 0 fetches per batch
+// A barrier that waits for the wave's LDS traffic only.  The threads of this kernel talk through LDS alone -- nothing it writes
+// to HBM is read back -- and __syncthreads() waits for every outstanding global access as well: a round of the kernel was
+// five phases of "global latency + barrier" (workgroup 0 at config 4, cycles per phase and round: select 4 900, clear + labels
+// 3 400, walk 8 600, void check 3 000, compaction 13 700 of which ~4 000 waiting for the entry stores to be acknowledged).
+__device__ __forceinline__ void sph_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, const GmLevels P, const GmLabelArrays A, const GmPriv R,
                                                               i64 n_graphs, i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt,
                                                               u32* __restrict__ ent_n, u64* __restrict__ selfk, i64 n_fit, int rectangular,
                                                               u32 df_cap, int prim_max, int wide_above, u32* __restrict__ part,
-                                                              u32* __restrict__ wgmeta, u32* __restrict__ overflow, u32 skip_above) {
-    extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private df histogram | keys[SPH_T] | counts[SPH_T] | labels[SPH_LAB]
-    __shared__ u32 n_ent_s, ovf_s, red_m[SPH_THREADS / 64], red_e[SPH_THREADS / 64];
-    __shared__ u64 red_x[SPH_THREADS / 64];
+                                                              u32* __restrict__ wgmeta, u32* __restrict__ overflow, u32 skip_above, int bmax) {
+    extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private df histogram | keys[SPH_T] | counts[SPH_T]
+    __shared__ u32 ovf_s, void_s, red_m[SPH_THREADS / 64], red_e[SPH_THREADS / 64];
+    __shared__ int b_g[SPH_BATCH], b_n[SPH_BATCH], b_v0[SPH_BATCH], b_base[SPH_BATCH], b_ns[SPH_BATCH];
+    __shared__ u32 b_t0[SPH_BATCH + 1], b_e0[SPH_BATCH + 1], b_np[SPH_BATCH], b_nent[SPH_BATCH];
+    __shared__ const i32* b_d32[SPH_BATCH];
+    __shared__ const unsigned char* b_d8[SPH_BATCH];
+    __shared__ unsigned long long b_extra[SPH_BATCH];
+    __shared__ int nb_s, done_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     u32* priv = (u32*)gm_lds;
     const int priv_words = R.bins / 2;
     for (int t = tid; t < priv_words; t += SPH_THREADS) priv[t] = 0;
     i32* keys = gm_lds + priv_words;
     u32* co = (u32*)(keys + SPH_T);
-    i32* lab_s = (i32*)(co + SPH_T);                     // the graph's node labels (n <= SPH_LAB), else read from HBM
+    unsigned short* clist = (unsigned short*)(co + SPH_T);           // claimed slots of every region, in claim order
     const i32 poff = R.off[0];
     u32 maxc = 0, entries = 0;
-    for (i64 g = blockIdx.x; g < n_graphs; g += gridDim.x) {
-        const i32 v0 = S.node_ptr[g];
-        const int n = S.node_ptr[g + 1] - v0;
-        const i32 base = S.pair_base[g];
-        const u32 np = (u32)(S.pair_base[g + 1] - base);
-        if (np == 0) {                                    // workgroup-uniform
-            if (tid == 0) ent_n[g] = 0, selfk[g] = 0;
+    // wave 0 selects the batches; the candidates of the NEXT selection are fetched right after the current one (their
+    // latency passes under the round's work instead of in front of it)
+    i64 next = blockIdx.x;                               // (uniform over the lanes of wave 0)
+    int cn = 0;
+    i32 cv0 = 0, cbase = 0;
+    u32 cnp = 0;
+    u64 cd = 0;
+    auto fetch = [&]() __attribute__((always_inline)) {
+        const i64 g = next + (i64)lane * (i64)gridDim.x;
+        cn = 0, cv0 = 0, cbase = 0, cnp = 0, cd = 0;
+        if (lane < SPH_CAND && g < n_graphs) {
+            cv0 = S.node_ptr[g], cn = S.node_ptr[g + 1] - cv0;
+            cbase = S.pair_base[g], cnp = (u32)(S.pair_base[g + 1] - cbase);
+            cd = S.dist_ptr[g];
+        }
+    };
+    if (w == 0) fetch();
+    SPH_DBG_DECL
+    for (;;) {
+        // ---- the next batch of this workgroup's graphs (g = blockIdx.x + k gridDim.x): the first sixteen lanes of wave 0 hold a
+        // candidate each, every lane of the wave runs the same selection over them
+        if (w == 0) {
+            int nb = 0, used = 0;
+            u32 slots = 0, ents = 0;
+#pragma unroll
+            for (int q = 0; q < SPH_CAND; ++q) {
+                const i64 gq = next + (i64)q * (i64)gridDim.x;
+                if (gq >= n_graphs) break;
+                // (v_readlane, not __shfl: a ds_bpermute per word and candidate made the selection 4 800 cycles per batch)
+                const int n = __builtin_amdgcn_readlane(cn, q);
+                const u32 np = (u32)__builtin_amdgcn_readlane((int)cnp, q);
+                const i32 v0 = __builtin_amdgcn_readlane(cv0, q), base = __builtin_amdgcn_readlane(cbase, q);
+                const u64 dp = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(cd >> 32), q) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)cd, q);
+                if (np == 0 || np > skip_above) { used = q + 1; continue; }     // nothing to count / counted through a counter row
+                if (nb == bmax) break;
+                u32 T = 64;                               // a table of at least twice the pairs (distinct keys <= pairs), capped
+                while (T < 2u * np && T < (u32)SPH_T) T <<= 1;
+                if (nb > 0 && (slots + T > (u32)SPH_T || (u64)ents + (u64)n * (u64)n > 0x7fffffffull)) break;
+                if (lane == 0) {
+                    const i32* d32 = S.dist + (dp & ~SP_BYTE_FLAG);
+                    b_g[nb] = (int)gq, b_n[nb] = n, b_v0[nb] = v0, b_base[nb] = base, b_np[nb] = np;
+                    b_d32[nb] = d32, b_ns[nb] = (n + 15) & ~15;
+                    b_d8[nb] = (dp & SP_BYTE_FLAG) ? (const unsigned char*)(((uintptr_t)d32 + 15) & ~(uintptr_t)15) : nullptr;
+                    b_t0[nb] = slots, b_e0[nb] = ents, b_nent[nb] = 0, b_extra[nb] = 0ull;
+                }
+                slots += T, ents += (u32)n * (u32)n;
+                ++nb, used = q + 1;
+            }
+            const i64 g_mine = next + (i64)lane * (i64)gridDim.x;
+            if (lane < used && g_mine < n_graphs && cnp == 0) ent_n[g_mine] = 0, selfk[g_mine] = 0;
+            next += (i64)used * (i64)gridDim.x;
+            if (lane == 0) {
+                b_t0[nb] = slots, b_e0[nb] = ents;
+                for (int q = nb + 1; q <= SPH_BATCH; ++q) b_t0[q] = 0xffffffffu, b_e0[q] = 0xffffffffu;
+                nb_s = nb, ovf_s = 0, void_s = 0, done_s = next >= n_graphs ? 1 : 0;
+            }
+            fetch();
+        }
+        sph_lds_barrier();
+        SPH_DBG(0)
+        const int nb = nb_s;
+        SPH_DBG_CNT(6, 1) SPH_DBG_CNT(7, nb)
+        if (nb == 0) {                                    // workgroup-uniform
+            if (done_s) break;
+            sph_lds_barrier();                            // (wave 0 rewrites the words just read)
             continue;
         }
-        if (np > skip_above) continue;                    // counted through a counter row (sp_rows_count_kernel)
-        u32 T = 64;                                       // a table of at least twice the pairs (distinct keys <= pairs), capped
-        while (T < 2u * np && T < (u32)SPH_T) T <<= 1;
-        const u32 tmask = T - 1u, t_cap = T - (T >> 2);   // three quarters full at most (only binds at T == SPH_T)
-        __syncthreads();                                  // the previous graph's compaction is done with the table
-        for (u32 t = tid; t < T; t += SPH_THREADS) keys[t] = -1, co[t] = 0;
-        const bool lab_in_lds = S.with_labels && n <= SPH_LAB;
-        if (lab_in_lds)
-            for (int i = tid; i < n; i += SPH_THREADS) lab_s[i] = S.node_label[v0 + i];
-        if (tid == 0) n_ent_s = 0, ovf_s = 0;
-        __syncthreads();
-        const SpMat M = sp_mat(S.dist, S.dist_ptr, g, n);     // 32-bit entries, or bytes behind the breadth-first search (common.h)
-        const u32 side_bit = g < n_fit ? 1u : 2u;
-        // four matrix entries per thread and trip: the four distance loads are in flight together, then the four id
-        // look-ups (the kernel is a chain of dependent round trips otherwise: one workgroup per CU, 16 graphs each)
-        for (int idx0 = 0; idx0 < n * n; idx0 += 4 * SPH_THREADS) {
+        u32 e0r[SPH_BATCH], t0r[SPH_BATCH + 1];           // prefix values of the batch: uniform, kept in scalar registers
+#pragma unroll
+        for (int q = 0; q < SPH_BATCH; ++q) e0r[q] = (u32)__builtin_amdgcn_readfirstlane((int)b_e0[q]);
+#pragma unroll
+        for (int q = 0; q <= SPH_BATCH; ++q) t0r[q] = (u32)__builtin_amdgcn_readfirstlane((int)b_t0[q]);
+        const u32 T_all = (u32)__builtin_amdgcn_readfirstlane((int)b_t0[nb]), E_all = (u32)__builtin_amdgcn_readfirstlane((int)b_e0[nb]);
+        for (u32 t = tid; t < T_all; t += SPH_THREADS) keys[t] = -1, co[t] = 0;
+        sph_lds_barrier();
+        SPH_DBG(1)
+        const bool single_full = nb == 1 && T_all == (u32)SPH_T;     // the one case in which a table can fill up
+        const u32 t_cap = (u32)SPH_T - ((u32)SPH_T >> 2);           // three quarters full at most
+        // four entries per thread and trip: the four distances and the eight labels are in flight together, then the four id
+        // look-ups (the kernel is a chain of dependent round trips otherwise)
+        for (u32 idx0 = 0; idx0 < E_all; idx0 += 4 * SPH_THREADS) {
             // an overflowing table -- here or in any other workgroup -- voids the whole job (the caller falls back to pair
             // items): stop walking.  Round 5: the 33 M pairs of a 5 748-vertex graph were walked to the end for nothing (122 ms)
-            if (*(volatile u32*)&ovf_s || (idx0 % (64 * SPH_THREADS) == 0 && __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+            if (single_full &&
+                (*(volatile u32*)&ovf_s || (idx0 % (64 * SPH_THREADS) == 0 && __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))))
+                break;
             i32 x[4], id[4];
+            u32 li[4], lj[4];
+            int kk[4];
+            bool diag[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int idx = idx0 + u * SPH_THREADS + tid;
-                if (M.d8) {                                   // workgroup-uniform
-                    const int i = idx / n;
-                    x[u] = idx < n * n ? sp_mat_at(M, n, i, idx - i * n, SPH_INF) : SPH_INF;
-                } else x[u] = idx < n * n ? M.d32[idx] : SPH_INF;
+                const u32 e = idx0 + (u32)u * SPH_THREADS + (u32)tid;
+                x[u] = SPH_INF, kk[u] = 0, li[u] = 0, lj[u] = 0, diag[u] = true;
+                if (e < E_all) {
+                    int k = 0;
+                    u32 eb = 0;
+#pragma unroll
+                    for (int q = 1; q < SPH_BATCH; ++q) k += e >= e0r[q] ? 1 : 0, eb = e >= e0r[q] ? e0r[q] : eb;
+                    const int n = b_n[k];
+                    const u32 loc = e - eb;
+                    const int i = (int)(loc / (u32)n), j = (int)(loc - (u32)i * (u32)n);
+                    kk[u] = k, diag[u] = i == j;
+                    if (b_d8[k]) {
+                        const unsigned char b8 = b_d8[k][(size_t)i * b_ns[k] + j];
+                        x[u] = b8 == 255 ? SPH_INF : (i32)b8;
+                    } else x[u] = b_d32[k][loc];
+                    if (S.with_labels) li[u] = (u32)S.node_label[b_v0[k] + i], lj[u] = (u32)S.node_label[b_v0[k] + j];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int idx = idx0 + u * SPH_THREADS + tid;
-                const int i = idx / n, j = idx - i * n;
                 id[u] = -1;
-                if (idx < n * n && i != j && x[u] < SPH_INF) {
-                    u64 key = (u64)x[u];
-                    if (S.with_labels) {
-                        const u32 li = (u32)(lab_in_lds ? lab_s[i] : S.node_label[v0 + i]), lj = (u32)(lab_in_lds ? lab_s[j] : S.node_label[v0 + j]);
-                        key += S.d1 * ((u64)li * S.L + (u64)lj);
-                    }
-                    id[u] = (i32)S.idtab[key];
-                }
+                if (!diag[u] && x[u] < SPH_INF) id[u] = (i32)S.idtab[(u64)x[u] + S.d1 * ((u64)li[u] * S.L + (u64)lj[u])];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (id[u] < 0) continue;
+                u32 t0 = 0, t1 = t0r[1];
+#pragma unroll
+                for (int q = 1; q < SPH_BATCH; ++q)
+                    if (kk[u] >= q) t0 = t0r[q], t1 = t0r[q + 1];
+                const u32 tmask = t1 - t0 - 1u;
                 u32 h = ((u32)id[u] * 2654435761u) >> 8 & tmask;
                 for (;;) {
-                    i32 old = keys[h];
+                    i32 old = keys[t0 + h];
                     if (old == -1) {
-                        if (*(volatile u32*)&ovf_s) break;
-                        old = atomicCAS(&keys[h], -1, id[u]);
+                        if (single_full && *(volatile u32*)&ovf_s) break;
+                        old = atomicCAS(&keys[t0 + h], -1, id[u]);
                         if (old == -1) {
-                            // claims only need counting when the table is at its largest (smaller ones hold every pair)
-                            if (T == (u32)SPH_T && atomicAdd(&n_ent_s, 1u) + 1u > t_cap) ovf_s = 1u;
-                            atomicAdd(&co[h], 1u);
+                            // the claim takes the key's entry slot and lists the table slot: the compaction walks the claims, not
+                            // the table (a 30-vertex graph fills a seventh of its 2 048 slots)
+                            const u32 e = atomicAdd(&b_nent[kk[u]], 1u);
+                            clist[t0 + e] = (unsigned short)h;
+                            if (single_full && e + 1u > t_cap) ovf_s = 1u;
+                            atomicAdd(&co[t0 + h], 1u);
                             break;
                         }
                     }
-                    if (old == id[u]) { atomicAdd(&co[h], 1u); break; }
+                    if (old == id[u]) { atomicAdd(&co[t0 + h], 1u); break; }
                     h = (h + 1u) & tmask;
                 }
             }
         }
-        // ONE decision per workgroup: another workgroup may raise `overflow` between two threads' loads, and
-        // the two paths below meet different barriers -- the OR over the workgroup is what every thread acts on
-        const int void_job = __syncthreads_or((int)(*(volatile u32*)&ovf_s | __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-        if (void_job) {                                   // more distinct keys than the table holds: the caller falls back
-            if (tid == 0) { atomicOr(overflow, 1u); ent_n[g] = 0; selfk[g] = 0; }
-            continue;
-        }
-        if (tid == 0) n_ent_s = 0;
-        __syncthreads();
-        u64 extra = 0;
-        for (u32 t0 = 0; t0 < T; t0 += SPH_THREADS) {      // T is a multiple of 64: whole waves
-            const u32 t = t0 + tid;
-            const i32 x = t < T ? keys[t] : -1;
-            // entry slots: one LDS atomic per wave (hundreds of lanes adding to ONE counter serialise)
-            const u64 m = __ballot(x >= 0);
-            u32 wbase = 0;
-            if (lane == 0 && m) wbase = atomicAdd(&n_ent_s, (u32)__popcll(m));
-            wbase = __shfl(wbase, 0, 64);
-            if (x < 0) continue;
-            const u32 c = co[t];
-            const u32 e = wbase + (u32)__popcll(m & ((1ull << lane) - 1ull));
-            ent_lab[base + e] = x, ent_cnt[base + e] = c;
-            if (poff >= 0) {                              // df / count class in the workgroup's private histogram (gm_pairs_kernel)
-                const u32 bin = (u32)poff + (u32)x;
-                const int sh = 16 * (bin & 1u);
-                u32 add = 0;
-                if (rectangular) add |= side_bit << GM_PRIV_SIDE_SHIFT;
-                if ((int)c > prim_max) add |= GM_PRIV_BIG1;
-                if ((int)c > wide_above) add |= GM_PRIV_BIG2;
-                const u32 cur = (priv[bin >> 1] >> sh) & 0xffffu;
-                const u32 flags = add & ~cur & 0xf000u;
-                if (flags) atomicOr(&priv[bin >> 1], flags << sh);
-                atomicAdd(&priv[bin >> 1], 1u << sh);
-            } else {
-                const i64 q = P.off[0] + x;
-                if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
-                if (c >= 2u && __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) atomicMax(&A.cmax[q], c);
-                if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
+        SPH_DBG(2)
+        if (single_full) {
+            // ONE decision per workgroup: another workgroup may raise `overflow` between two threads' loads, and
+            // the two paths below meet different barriers -- what every thread acts on is the workgroup's word
+            if (*(volatile u32*)&ovf_s | __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) void_s = 1u;
+            sph_lds_barrier();
+            if (*(volatile u32*)&void_s) {                // more distinct keys than the table holds: the caller falls back
+                if (tid == 0) { atomicOr(overflow, 1u); ent_n[b_g[0]] = 0, selfk[b_g[0]] = 0; }
+                sph_lds_barrier();                        // the batch words are rewritten by wave 0 next
+                continue;
             }
-            extra += (u64)c * c - c;
-            maxc = c > maxc ? c : maxc;
-            ++entries;
         }
-        for (int off = 32; off > 0; off >>= 1) extra += __shfl_down(extra, off, 64);
-        if (lane == 0) red_x[w] = extra;
-        __syncthreads();
-        if (tid == 0) {
-            u64 x = 0;
-            for (int k = 0; k < SPH_THREADS / 64; ++k) x += red_x[k];
-            ent_n[g] = n_ent_s;
-            selfk[g] = (u64)np + x;                       // sum of c^2 = sum of c + sum of (c^2 - c)
+        sph_lds_barrier();
+        SPH_DBG(3)
+        u32 n0r[SPH_BATCH + 1];                           // prefix of the graphs' entry counts (uniform)
+        n0r[0] = 0;
+#pragma unroll
+        for (int q = 0; q < SPH_BATCH; ++q) n0r[q + 1] = q < nb ? n0r[q] + (u32)__builtin_amdgcn_readfirstlane((int)b_nent[q]) : 0xffffffffu;
+        const u32 N_all = n0r[nb];
+        for (u32 i0 = 0; i0 < N_all; i0 += SPH_THREADS) {
+            const u32 i = i0 + (u32)tid;
+            const bool act = i < N_all;
+            int k = 0;
+            u32 nb0 = 0, t0 = 0;
+#pragma unroll
+            for (int q = 1; q < SPH_BATCH; ++q)
+                if (act && i >= n0r[q]) k = q, nb0 = n0r[q], t0 = t0r[q];
+            u64 extra = 0;
+            if (act) {
+                const u32 e = i - nb0;
+                const u32 t = t0 + (u32)clist[t0 + e];
+                const i32 x = keys[t];
+                const u32 c = co[t];
+                const i32 base = b_base[k];
+                ent_lab[base + e] = x, ent_cnt[base + e] = c;
+                if (poff >= 0) {                              // df / count class in the workgroup's private histogram (gm_pairs_kernel)
+                    const u32 bin = (u32)poff + (u32)x;
+                    const int sh = 16 * (bin & 1u);
+                    u32 add = 0;
+                    if (rectangular) add |= (b_g[k] < n_fit ? 1u : 2u) << GM_PRIV_SIDE_SHIFT;
+                    if ((int)c > prim_max) add |= GM_PRIV_BIG1;
+                    if ((int)c > wide_above) add |= GM_PRIV_BIG2;
+                    const u32 cur = (priv[bin >> 1] >> sh) & 0xffffu;
+                    const u32 flags = add & ~cur & 0xf000u;
+                    if (flags) atomicOr(&priv[bin >> 1], flags << sh);
+                    atomicAdd(&priv[bin >> 1], 1u << sh);
+                } else {
+                    const u32 side_bit = b_g[k] < n_fit ? 1u : 2u;
+                    const i64 q = P.off[0] + x;
+                    if (__hip_atomic_load(&A.df[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < df_cap) atomicAdd(&A.df[q], 1u);
+                    if (c >= 2u && __hip_atomic_load(&A.cmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) atomicMax(&A.cmax[q], c);
+                    if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
+                }
+                extra = (u64)c * c - c;
+                maxc = c > maxc ? c : maxc;
+                ++entries;
+            }
+            // sum of c^2 - c per graph: one LDS atomic per wave where the wave's entries belong to one graph, else one per lane
+            const int k0 = __builtin_amdgcn_readfirstlane(k);
+            if (__ballot(act && k != k0) == 0ull) {
+                extra = wave_sum_u64(extra);
+                if (lane == 0 && extra) atomicAdd(&b_extra[k0], (unsigned long long)extra);
+            } else if (extra) atomicAdd(&b_extra[k], (unsigned long long)extra);
         }
+        sph_lds_barrier();
+        SPH_DBG(4)
+        if (tid < nb) {
+            ent_n[b_g[tid]] = b_nent[tid];
+            selfk[b_g[tid]] = (u64)b_np[tid] + (u64)b_extra[tid];      // sum of c^2 = sum of c + sum of (c^2 - c)
+        }
+        sph_lds_barrier();                                // the batch words are rewritten by wave 0 next
+        SPH_DBG(5)
     }
+    SPH_DBG_OUT()
     for (int off = 32; off > 0; off >>= 1) {
         entries += __shfl_down(entries, off, 64);
         const u32 o = __shfl_down(maxc, off, 64);
@@ -1774,14 +1907,14 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     const i64 grid1 = any_small ? (N < n_cu ? N : n_cu) : 0;  // one workgroup per CU: the table and the private histogram fill its LDS
     const i64 grid2 = n_rows > 0 ? std::min<i64>(n_rows, 2 * (i64)n_cu) : 0;
     const i64 grid = grid1 + grid2;
-    const i64 priv_budget = (160 * 1024 - 1024 - (i64)SPH_T * 8 - (i64)SPH_LAB * 4) / 2;
+    const i64 priv_budget = (160 * 1024 - 1024 - (i64)SPH_T * 10) / 2;
     GmPriv R;
     R.bins = 0;
     for (int j = 0; j < FEAT_MAX_LEVELS; ++j) R.off[j] = -1;
     const i64 per_wg = std::max<i64>(grid1 > 0 ? cdiv(N, grid1) : 0, grid2 > 0 ? cdiv(n_rows, grid2) : 0);
     if (!ctx->opt.gm_no_priv && Q <= priv_budget && per_wg + 1 < (i64)GM_PRIV_COUNT_MASK) R.off[0] = 0, R.bins = (int)Q;
     R.bins = (R.bins + 1) & ~1;
-    const size_t lds = (size_t)R.bins * 2 + (size_t)SPH_T * 8 + (size_t)SPH_LAB * 4;
+    const size_t lds = (size_t)R.bins * 2 + (size_t)SPH_T * 10;
     Tmp<u32> part(ctx), wgmeta(ctx);
     GK_TRY(wgmeta.alloc((size_t)grid * 2));
     GK_TRY(part.alloc((size_t)grid * (size_t)(R.bins / 2 > 0 ? R.bins / 2 : 1)));
@@ -1798,7 +1931,7 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
         GK_TRY(gk_func_lds(ctx, (const void*)sp_hist_kernel, (int)lds));
         sp_hist_kernel<<<dim3((unsigned)grid1), SPH_THREADS, lds, ctx->stream>>>(
             S, P, A, R, N, ent.p, cnt.p, ent_n.p, f->selfk, f->n_fit, rectangular, (u32)(f->low_df > 2 ? f->low_df : 2), prim_max,
-            wide_above, part.p, wgmeta.p, f->meta + GM_META_OVF, skip_above);
+            wide_above, part.p, wgmeta.p, f->meta + GM_META_OVF, skip_above, ctx->opt.sp_hist_no_batch ? 1 : SPH_BATCH);
     }
     Tmp<u32> rows(ctx);
     Tmp<SpUnit> units_dev(ctx);

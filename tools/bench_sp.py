@@ -20,6 +20,8 @@ t0 = time.perf_counter()
 gb, _ = sp_batch_from_input(G, True)
 t_ingest = time.perf_counter() - t0
 eng = get_engine()
+for _o in os.environ.get("GK_TOOL_OPTS", "").split():          # e.g. GK_TOOL_OPTS="sp.hist_no_batch=1"
+    eng.set_option(_o.split("=")[0], int(_o.split("=")[1]))
 db = eng.upload(gb)
 sizes = np.diff(gb.graph_ptr).astype(np.float64)
 
