@@ -1318,38 +1318,50 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
         // ---- the next batch of this workgroup's graphs (g = blockIdx.x + k gridDim.x): the first sixteen lanes of wave 0 hold a
         // candidate each, every lane of the wave runs the same selection over them
         if (w == 0) {
-            int nb = 0, used = 0;
-            u32 slots = 0, ents = 0;
-#pragma unroll
-            for (int q = 0; q < SPH_CAND; ++q) {
-                const i64 gq = next + (i64)q * (i64)gridDim.x;
-                if (gq >= n_graphs) break;
-                // (v_readlane, not __shfl: a ds_bpermute per word and candidate made the selection 4 800 cycles per batch)
-                const int n = __builtin_amdgcn_readlane(cn, q);
-                const u32 np = (u32)__builtin_amdgcn_readlane((int)cnp, q);
-                const i32 v0 = __builtin_amdgcn_readlane(cv0, q), base = __builtin_amdgcn_readlane(cbase, q);
-                const u64 dp = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(cd >> 32), q) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)cd, q);
-                if (np == 0 || np > skip_above) { used = q + 1; continue; }     // nothing to count / counted through a counter row
-                if (nb == bmax) break;
-                u32 T = 64;                               // a table of at least twice the pairs (distinct keys <= pairs), capped
-                while (T < 2u * np && T < (u32)SPH_T) T <<= 1;
-                if (nb > 0 && (slots + T > (u32)SPH_T || (u64)ents + (u64)n * (u64)n > 0x7fffffffull)) break;
-                if (lane == 0) {
-                    const i32* d32 = S.dist + (dp & ~SP_BYTE_FLAG);
-                    b_g[nb] = (int)gq, b_n[nb] = n, b_v0[nb] = v0, b_base[nb] = base, b_np[nb] = np;
-                    b_d32[nb] = d32, b_ns[nb] = (n + 15) & ~15;
-                    b_d8[nb] = (dp & SP_BYTE_FLAG) ? (const unsigned char*)(((uintptr_t)d32 + 15) & ~(uintptr_t)15) : nullptr;
-                    b_t0[nb] = slots, b_e0[nb] = ents, b_nent[nb] = 0, b_extra[nb] = 0ull;
-                }
-                slots += T, ents += (u32)n * (u32)n;
-                ++nb, used = q + 1;
-            }
+            // every candidate lane sizes its own graph; inclusive prefixes over the candidates (DPP row shifts) say which of them
+            // still fit -- the batch ends in front of the first real candidate that does not (one lane walking the candidates
+            // one after the other was 3 500 cycles per batch with fifteen waves waiting)
             const i64 g_mine = next + (i64)lane * (i64)gridDim.x;
-            if (lane < used && g_mine < n_graphs && cnp == 0) ent_n[g_mine] = 0, selfk[g_mine] = 0;
+            const bool valid = lane < SPH_CAND && g_mine < n_graphs;
+            const bool real = valid && cnp != 0 && cnp <= skip_above;
+            u32 T = 0, E = 0, one = real ? 1u : 0u;
+            if (real) {
+                // a table region of 21/16 of the pairs (distinct keys <= pairs: never full), a multiple of 64, capped.  Round 6: NOT a
+                // power of two (the slot is hash * T >> 32) -- twice the pairs rounded up to one put four 30-vertex graphs into a
+                // batch where seven fit
+                T = (cnp + (cnp >> 2) + (cnp >> 4) + 64u) & ~63u;
+                if (T > (u32)SPH_T) T = (u32)SPH_T;
+                E = (u32)cn * (u32)cn;                    // (a histogram graph has at most 6 144 pairs... but any number of vertices)
+            }
+            const u32 E_sat = (u64)cn * (u64)cn > 0x0fffffffull ? 0x0fffffffu : E;      // saturating: eight of them stay below 2^31
+            u32 pT = T, pE = E_sat, pN = one;
+#define SPH_SCAN_STEP(CTRL)                                                                 \
+            pT += (u32)__builtin_amdgcn_update_dpp(0, (int)pT, CTRL, 0xF, 0xF, false);          \
+            pE += (u32)__builtin_amdgcn_update_dpp(0, (int)pE, CTRL, 0xF, 0xF, false);          \
+            pN += (u32)__builtin_amdgcn_update_dpp(0, (int)pN, CTRL, 0xF, 0xF, false);
+            SPH_SCAN_STEP(0x111) SPH_SCAN_STEP(0x112) SPH_SCAN_STEP(0x114)                      // row_shr:1 / 2 / 4, zeros shifted in
+#undef SPH_SCAN_STEP
+            static_assert(SPH_CAND == 8, "the prefix above covers eight candidate lanes");
+            // the first real candidate always fits (pN == 1); a graph whose n^2 saturates travels alone
+            const bool fits = !real || pN == 1u || (pT <= (u32)SPH_T && pN <= (u32)bmax && pE < 0x0fffffffu && E_sat < 0x0fffffffu);
+            const u64 stop = __ballot(lane < SPH_CAND && (!valid || !fits)) | (1ull << SPH_CAND);
+            const int used = (int)__builtin_ctzll(stop);
+            const bool acc = real && lane < used;
+            const int nb = (int)__popcll(__ballot(acc));
+            if (acc) {
+                const int at = (int)pN - 1;
+                const i32* d32 = S.dist + (cd & ~SP_BYTE_FLAG);
+                b_g[at] = (int)g_mine, b_n[at] = cn, b_v0[at] = cv0, b_base[at] = cbase, b_np[at] = cnp;
+                b_d32[at] = d32, b_ns[at] = (cn + 15) & ~15;
+                b_d8[at] = (cd & SP_BYTE_FLAG) ? (const unsigned char*)(((uintptr_t)d32 + 15) & ~(uintptr_t)15) : nullptr;
+                b_t0[at] = pT - T, b_e0[at] = pE - E_sat, b_nent[at] = 0, b_extra[at] = 0ull;
+                if (at == nb - 1) b_t0[nb] = pT, b_e0[nb] = E_sat >= 0x0fffffffu ? E : pE;
+            }
+            if (valid && lane < used && cnp == 0) ent_n[g_mine] = 0, selfk[g_mine] = 0;
             next += (i64)used * (i64)gridDim.x;
+            if (lane > nb && lane <= SPH_BATCH) b_t0[lane] = 0xffffffffu, b_e0[lane] = 0xffffffffu;
             if (lane == 0) {
-                b_t0[nb] = slots, b_e0[nb] = ents;
-                for (int q = nb + 1; q <= SPH_BATCH; ++q) b_t0[q] = 0xffffffffu, b_e0[q] = 0xffffffffu;
+                if (nb == 0) b_t0[0] = 0, b_e0[0] = 0;
                 nb_s = nb, ovf_s = 0, void_s = 0, done_s = next >= n_graphs ? 1 : 0;
             }
             fetch();
@@ -1418,8 +1430,8 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
 #pragma unroll
                 for (int q = 1; q < SPH_BATCH; ++q)
                     if (kk[u] >= q) t0 = t0r[q], t1 = t0r[q + 1];
-                const u32 tmask = t1 - t0 - 1u;
-                u32 h = ((u32)id[u] * 2654435761u) >> 8 & tmask;
+                const u32 T = t1 - t0;
+                u32 h = (u32)(((u64)((u32)id[u] * 2654435761u) * (u64)T) >> 32);
                 for (;;) {
                     i32 old = keys[t0 + h];
                     if (old == -1) {
@@ -1436,7 +1448,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
                         }
                     }
                     if (old == id[u]) { atomicAdd(&co[t0 + h], 1u); break; }
-                    h = (h + 1u) & tmask;
+                    h = h + 1u == T ? 0u : h + 1u;
                 }
             }
         }
