@@ -107,6 +107,7 @@ struct gk_opts {
     int sp_bfs_no_bytes = 0;     // 1: the breadth-first search stores its distance matrices as 32-bit entries (round 5) instead of BYTES (round 6)
     int sp_no_rows = 0;          // histogram form: no per-graph counter rows (a graph whose LDS table overflows sends the job to the pair items)
     int sp_rows_all = 0;         // test hook: every graph with a pair counts through counter rows (default: graphs above 6 144 pairs)
+    int sp_no_fused_mark = 0;    // 1: the key marks of a small-graph job by sp_mark_kernel over the stored matrices (rounds 4-5) instead of inside the packed all-pairs kernels
     int sp_hist_no_batch = 0;    // 1: the one-workgroup-per-CU histogram kernel takes its graphs one at a time (rounds 4-5) instead of as many as fit its table
     int sp_static_type = 0;      // 1: the operand type of a ShortestPath histogram job from the a-priori bound pairs^2 (rounds 3-5) instead of the job's largest self similarity
     int sp_rows_no_merge = 0;    // bit 0: the counting workgroups add every matrix entry to the LDS table on its own (round 5) instead of per-lane runs of equal keys;

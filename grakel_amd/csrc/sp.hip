@@ -225,10 +225,39 @@ __device__ __forceinline__ void sp_fw_reg_body(i32* __restrict__ lds, int n, con
 #define SP_PK_INF 0x3fffu
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
+// Key marks of the histogram form straight from the packed kernels' LDS matrices (round 6): a job of graphs of at most 128
+// vertices whose key space is known beforehand (gk_sp_build: defer_rt) does not run sp_mark_kernel over the matrices it
+// has just written -- BASELINE config 4: 30 us of 510.  present == nullptr: no marks.
+struct SpMark {
+    unsigned char* present; const i32* labels; u64 L, d1; int with_labels;
+};
+// row i of a packed LDS matrix, columns [j0, j1): eight entries per trip, stage by stage
+__device__ __forceinline__ void sp_pk_mark_row(const unsigned short* __restrict__ ldsrow, int i, int j0, int j1, i32 v0, const SpMark& mk) {
+    const u64 rowterm = mk.with_labels ? mk.d1 * (u64)(u32)mk.labels[v0 + i] * mk.L : 0ull;
+    for (int j = j0; j < j1; j += 8) {
+        u32 x[8];
+        u64 key[8];
+        unsigned char seen[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = j + u < j1 ? (u32)ldsrow[j + u] : (u32)SP_PK_INF;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            key[u] = ~0ull;
+            if (j + u < j1 && j + u != i && x[u] < (u32)SP_PK_INF)
+                key[u] = rowterm + (mk.with_labels ? mk.d1 * (u64)(u32)mk.labels[v0 + j + u] : 0ull) + (u64)x[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) seen[u] = key[u] != ~0ull ? mk.present[key[u]] : (unsigned char)1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (!seen[u]) mk.present[key[u]] = 1;          // same value from every writer
+    }
+}
+
 template <int NP2, int ROWS>
 __device__ __forceinline__ void sp_fw_pk_body(unsigned short* __restrict__ lds, int n, const i32* __restrict__ row_ptr,
                                               const i32* __restrict__ col_idx, const i32* __restrict__ w, i32 v0,
-                                              i32* __restrict__ out, u32* __restrict__ pair_count_g, u32* __restrict__ maxd) {
+                                              i32* __restrict__ out, u32* __restrict__ pair_count_g, u32* __restrict__ maxd, const SpMark& mk) {
     constexpr int NC = 2 * NP2, LD = NC + 8;           // columns; row pitch in halfwords (16-byte aligned rows)
     constexpr int NR = 64 * ROWS;
     const int lane = threadIdx.x & 63;
@@ -317,6 +346,11 @@ __device__ __forceinline__ void sp_fw_pk_body(unsigned short* __restrict__ lds, 
         *pair_count_g = cnt;
         if (mx) atomicMax(maxd, mx);
     }
+    if (mk.present) {
+#pragma unroll
+        for (int s = 0; s < ROWS; ++s)
+            if (lane + 64 * s < n) sp_pk_mark_row(lds + (lane + 64 * s) * LD, lane + 64 * s, 0, n, v0, mk);
+    }
 }
 
 // Graphs of 65..128 vertices: the single-wave form above is one long dependent chain (43 k instructions for n = 110,
@@ -329,7 +363,7 @@ __device__ __forceinline__ void sp_fw_pk_body(unsigned short* __restrict__ lds, 
 template <int NP2>
 __device__ __forceinline__ void sp_fw_pkw_body(unsigned short* __restrict__ lds, int n, const i32* __restrict__ row_ptr,
                                                const i32* __restrict__ col_idx, const i32* __restrict__ w, i32 v0,
-                                               i32* __restrict__ out, u32* __restrict__ pair_count_g, u32* __restrict__ maxd) {
+                                               i32* __restrict__ out, u32* __restrict__ pair_count_g, u32* __restrict__ maxd, const SpMark& mk) {
     constexpr int NC = 2 * NP2, LD = NC + 8, S = NP2 / 4;      // S registers (column pairs) per wave and row set
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned short* xch = lds + 128 * LD;                       // [2][128] pivot-column exchange
@@ -415,12 +449,16 @@ __device__ __forceinline__ void sp_fw_pkw_body(unsigned short* __restrict__ lds,
         if (i != j && x < SP_PK_INF) { ++cnt; mx = x > mx ? x : mx; }
     }
     block_count_max(cnt, mx, pair_count_g, maxd);
+    if (mk.present) {                                           // a thread per row and half of its columns
+        const int i = tid & 127, half = tid >> 7, mid = (n + 1) >> 1;
+        if (i < n) sp_pk_mark_row(lds + i * LD, i, half ? mid : 0, half ? n : mid, v0, mk);
+    }
 }
 
 __global__ __launch_bounds__(256) void sp_fw_pkw_kernel(
     const i32* __restrict__ cls_list, i64 n_graphs, int c4, int c5, int c6, int c7, const i32* __restrict__ graph_ptr,
     const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ w,
-    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd) {
+    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd, const SpMark mk) {
     extern __shared__ __attribute__((aligned(16))) i32 sp_lds[];
     int gi = blockIdx.x, c = 4;                          // classes 4..7 (80 / 96 / 112 / 128 columns), one workgroup per graph
     if (gi >= c4) { gi -= c4, c = 5; if (gi >= c5) { gi -= c5, c = 6; if (gi >= c6) { gi -= c6, c = 7; if (gi >= c7) return; } } }
@@ -431,10 +469,10 @@ __global__ __launch_bounds__(256) void sp_fw_pkw_kernel(
     unsigned short* lds = (unsigned short*)sp_lds;
     u32* pc = &pair_count[g];
     switch (c) {
-        case 4: sp_fw_pkw_body<40>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-        case 5: sp_fw_pkw_body<48>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-        case 6: sp_fw_pkw_body<56>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-        default: sp_fw_pkw_body<64>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+        case 4: sp_fw_pkw_body<40>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+        case 5: sp_fw_pkw_body<48>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+        case 6: sp_fw_pkw_body<56>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+        default: sp_fw_pkw_body<64>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
     }
 }
 
@@ -448,7 +486,7 @@ template <int BIG>
 __global__ __launch_bounds__(64 * SP_REG_WAVES) void sp_fw_pk_kernel(
     const SpPkClasses C, const i32* __restrict__ cls_list, i64 n_graphs, const i32* __restrict__ graph_ptr,
     const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx, const i32* __restrict__ w,
-    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd) {
+    const u64* __restrict__ dist_ptr, i32* __restrict__ dist, u32* __restrict__ pair_count, u32* __restrict__ maxd, const SpMark mk) {
     extern __shared__ __attribute__((aligned(16))) i32 sp_lds[];
     // BIG = 0: the launch covers classes 0..3, BIG = 1: classes 4..7 (their LDS staging areas differ by 4x)
     int c = BIG ? 4 : 0;
@@ -465,17 +503,17 @@ __global__ __launch_bounds__(64 * SP_REG_WAVES) void sp_fw_pk_kernel(
     u32* pc = &pair_count[g];
     if (!BIG) {
         switch (c) {
-            case 0: sp_fw_pk_body<8, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-            case 1: sp_fw_pk_body<16, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-            case 2: sp_fw_pk_body<24, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-            default: sp_fw_pk_body<32, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+            case 0: sp_fw_pk_body<8, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+            case 1: sp_fw_pk_body<16, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+            case 2: sp_fw_pk_body<24, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+            default: sp_fw_pk_body<32, 1>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
         }
     } else {
         switch (c) {
-            case 4: sp_fw_pk_body<40, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-            case 5: sp_fw_pk_body<48, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-            case 6: sp_fw_pk_body<56, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
-            default: sp_fw_pk_body<64, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd); break;
+            case 4: sp_fw_pk_body<40, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+            case 5: sp_fw_pk_body<48, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+            case 6: sp_fw_pk_body<56, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
+            default: sp_fw_pk_body<64, 2>(lds, n, row_ptr, col_idx, w, v0, out, pc, maxd, mk); break;
         }
     }
 }
@@ -1095,7 +1133,8 @@ static int bits_for64(u64 v) {
 }
 
 
-static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, SpDist& s, u64* total_sq, bool no_bfs = false) {
+static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, SpDist& s, u64* total_sq, bool no_bfs = false,
+                           const SpMark* mark = nullptr, bool* marked = nullptr) {
     const i64 N = b->n_graphs;
     GK_TRY(s.sq.alloc(N)); GK_TRY(s.dist_ptr.alloc(N)); GK_TRY(s.total.alloc(1));
     GK_TRY(s.pair_count.alloc(N)); GK_TRY(s.maxd.alloc(1));
@@ -1144,6 +1183,9 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
     const int nmax = b->max_graph_nodes;
     i64 n_launch = 0;
     ProfScope prof_fw(ctx, "sp_fw", 2);       // the all-pairs kernels alone (bench.py: min-plus rate)
+    const SpMark no_mark{nullptr, nullptr, 0, 0, 0};
+    const SpMark mk = (mark && use_pk && b->max_graph_nodes <= 128) ? *mark : no_mark;       // every graph through the packed kernels
+    if (marked) *marked = mk.present != nullptr;
     if (use_pk) {
         SpPkClasses C;
         int wg = 0;
@@ -1160,14 +1202,14 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
         if (both) GK_TRY(gk_side_fork(ctx, &st_pk));
         if (C.first[4] > 0) {
             sp_fw_pk_kernel<0><<<dim3((unsigned)C.first[4]), 64 * SP_REG_WAVES, SP_REG_WAVES * 64 * 72 * 2, st_pk>>>(
-                C, cls_list.p, N, b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p);
+                C, cls_list.p, N, b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, mk);
             ++n_launch;
         }
         if (n_big > 0) {                     // 65..128 vertices: a workgroup per graph, columns split over its four waves
             const int lds = (128 * 136 + 256) * 2;
             sp_fw_pkw_kernel<<<dim3(n_big), 256, lds, ctx->stream>>>(
                 cls_list.p, N, (int)h_cls[4], (int)h_cls[5], (int)h_cls[6], (int)h_cls[7], b->graph_ptr, b->row_ptr, b->col_idx, w,
-                s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p);
+                s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, mk);
             ++n_launch;
         }
         if (both) GK_TRY(gk_side_join(ctx));
@@ -1535,11 +1577,23 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
             for (i64 e = 0; e < b->n_edges; ++e) wm = edge_weight[e] > wm ? edge_weight[e] : wm;
         dist_bound = (u64)(b->max_graph_nodes > 1 ? b->max_graph_nodes - 1 : 0) * (u64)wm + 1;
     }
+    // key marks from inside the packed all-pairs kernels (SpMark) wherever the job will skip the read-back of the largest
+    // distance anyway (defer_rt below: small graphs, a key space laid out for the bound of a distance)
+    Tmp<unsigned char> present_early(ctx);
+    SpMark mark{nullptr, b->labels, L0_early, dist_bound, with_labels ? 1 : 0};
+    bool marked = false;
+    if (!weight_f64 && n_levels == 1 && !ctx->opt.sp_no_hist && !ctx->opt.sp_no_prep && !ctx->opt.sp_no_fused_mark && b->max_graph_nodes <= 128 &&
+        dist_bound * L0_early * L0_early <= (1ull << 22) && L0_early < (1u << 15) && N > 0) {
+        const size_t ks = (size_t)(dist_bound * L0_early * L0_early);
+        GK_TRY(present_early.alloc(ks));
+        GK_TRY(gk_zero_async(ctx, present_early.p, ks));
+        mark.present = present_early.p;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         // attempt 1: a breadth-first search ran out of its 8-bit levels (a shortest path of 255 edges) -- once more, the
         // large graphs by row relaxation
         if (weight_f64) GK_TRY(sp_compute_dist_f64(ctx, b, weight_f64, graph_algo, s, &total_sq));
-        else GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq, attempt == 1));
+        else GK_TRY(sp_compute_dist(ctx, b, edge_weight, s, &total_sq, attempt == 1, mark.present ? &mark : nullptr, &marked));
         GK_TRY(ptotal.alloc(4));                             // [0] pairs, [1] distinct keys of the histogram form (below)
         if (N <= SP_PREP_MAX_GRAPHS && !ctx->opt.sp_no_prep)
             sp_pair_ranges_small_kernel<<<1, 1024, 0, ctx->stream>>>(s.pair_count.p, pair_base, N, ptotal.p);
@@ -1586,13 +1640,19 @@ static int sp_build_impl(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight, c
         if (n_levels == 1 && !ctx->opt.sp_no_hist && L0 < (1u << 15) && keyspace <= (1ull << 26) && (h_pairs > 0 || defer_rt)) {
             Tmp<unsigned char> present(ctx);
             Tmp<u32> nk(ctx);
-            if ((r = present.alloc((size_t)keyspace)) || (r = nk.alloc(1))) return fail(r);
-            if ((r = gk_zero_async(ctx, present.p, (size_t)keyspace))) return fail(r);
-            sp_mark_kernel<<<dim3((unsigned)N, (unsigned)cdiv(b->max_graph_nodes > 0 ? b->max_graph_nodes : 1, SP_SLAB)), SP_THREADS, 0, ctx->stream>>>(
-                b->graph_ptr, b->labels, s.dist_ptr.p, s.dist.p, present.p, L0, d1, with_labels ? 1 : 0);
+            if ((r = nk.alloc(1))) return fail(r);
+            // (marked: the packed kernels left the marks in present_early -- same alphabet, same d1)
+            const bool have_marks = marked && defer_rt && mark.present && mark.L == L0 && mark.d1 == d1;
+            if (!have_marks) {
+                if ((r = present.alloc((size_t)keyspace))) return fail(r);
+                if ((r = gk_zero_async(ctx, present.p, (size_t)keyspace))) return fail(r);
+                sp_mark_kernel<<<dim3((unsigned)N, (unsigned)cdiv(b->max_graph_nodes > 0 ? b->max_graph_nodes : 1, SP_SLAB)), SP_THREADS, 0, ctx->stream>>>(
+                    b->graph_ptr, b->labels, s.dist_ptr.p, s.dist.p, present.p, L0, d1, with_labels ? 1 : 0);
+            }
+            const unsigned char* present_p = have_marks ? present_early.p : present.p;
             if ((r = gk_dev_alloc(ctx, &q, (size_t)keyspace * 4))) return fail(r);
             pb->sp_idtab = (u32*)q;
-            SpIdScan sc{present.p, pb->sp_idtab, defer_rt ? ptotal.p + 1 : nk.p};
+            SpIdScan sc{present_p, pb->sp_idtab, defer_rt ? ptotal.p + 1 : nk.p};
             if ((r = gk_scan_fn<u32, SpIdScan>(ctx, sc, (i64)keyspace, nullptr))) return fail(r);
             if ((r = gk_dev_alloc(ctx, &q, (size_t)(N + 1) * 4))) return fail(r);
             pb->sp_node_ptr = (i32*)q;

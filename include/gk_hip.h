@@ -105,6 +105,8 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "sp.bfs_no_bytes" (1: that search leaves 32-bit distance matrices -- rounds 3-5 -- instead of byte matrices),
  *             "sp.no_rows" (histogram form without the counter rows of the large graphs: one workgroup and one LDS table
  *             per graph, a table that overflows sends the whole job to the pair items -- the round-4 form),
+ *             "sp.no_fused_mark" (1: which keys occur is found by a pass over the stored distance matrices instead of inside the
+ *             packed all-pairs kernels of a job of small graphs),
  *             "sp.hist_no_batch" (1: the LDS-table histogram kernel walks its graphs one at a time instead of as many at a time
  *             as fit its table),
  *             "sp.static_type" (1: the Gram operand type of a histogram-form job -- fp4 + int8, int8 or float64 -- from the
