@@ -231,25 +231,23 @@ typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 struct SpMark {
     unsigned char* present; const i32* labels; u64 L, d1; int with_labels;
 };
-// row i of a packed LDS matrix, columns [j0, j1): eight entries per trip, stage by stage
-__device__ __forceinline__ void sp_pk_mark_row(const unsigned short* __restrict__ ldsrow, int i, int j0, int j1, i32 v0, const SpMark& mk) {
-    const u64 rowterm = mk.with_labels ? mk.d1 * (u64)(u32)mk.labels[v0 + i] * mk.L : 0ull;
-    for (int j = j0; j < j1; j += 8) {
-        u32 x[8];
-        u64 key[8];
-        unsigned char seen[8];
+// row i of a packed LDS matrix, columns [j0, j1): sixteen entries per trip, stage by stage; colterm[j] = d1 * label of column j
+// (staged in LDS by the caller: the marks of a row are then ONE global round trip per trip, the presence bytes)
+__device__ __forceinline__ void sp_pk_mark_row(const unsigned short* __restrict__ ldsrow, int i, int j0, int j1, const u32* colterm, const SpMark& mk) {
+    const u32 rowterm = mk.with_labels ? colterm[i] * (u32)mk.L : 0u;
+    for (int j = j0; j < j1; j += 16) {
+        u32 key[16];
+        unsigned char seen[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = j + u < j1 ? (u32)ldsrow[j + u] : (u32)SP_PK_INF;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            key[u] = ~0ull;
-            if (j + u < j1 && j + u != i && x[u] < (u32)SP_PK_INF)
-                key[u] = rowterm + (mk.with_labels ? mk.d1 * (u64)(u32)mk.labels[v0 + j + u] : 0ull) + (u64)x[u];
+        for (int u = 0; u < 16; ++u) {
+            const u32 x = j + u < j1 ? (u32)ldsrow[j + u] : (u32)SP_PK_INF;
+            key[u] = 0xffffffffu;
+            if (j + u < j1 && j + u != i && x < (u32)SP_PK_INF) key[u] = rowterm + colterm[j + u] + x;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) seen[u] = key[u] != ~0ull ? mk.present[key[u]] : (unsigned char)1;
+        for (int u = 0; u < 16; ++u) seen[u] = key[u] != 0xffffffffu ? mk.present[key[u]] : (unsigned char)1;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (!seen[u]) mk.present[key[u]] = 1;          // same value from every writer
     }
 }
@@ -347,9 +345,14 @@ __device__ __forceinline__ void sp_fw_pk_body(unsigned short* __restrict__ lds, 
         if (mx) atomicMax(maxd, mx);
     }
     if (mk.present) {
+        u32* colterm = (u32*)(lds + NR * LD);          // [NR] behind the wave's matrix (the launch sizes the region for it)
 #pragma unroll
         for (int s = 0; s < ROWS; ++s)
-            if (lane + 64 * s < n) sp_pk_mark_row(lds + (lane + 64 * s) * LD, lane + 64 * s, 0, n, v0, mk);
+            if (lane + 64 * s < n) colterm[lane + 64 * s] = mk.with_labels ? (u32)mk.d1 * (u32)mk.labels[v0 + lane + 64 * s] : 0u;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < ROWS; ++s)
+            if (lane + 64 * s < n) sp_pk_mark_row(lds + (lane + 64 * s) * LD, lane + 64 * s, 0, n, colterm, mk);
     }
 }
 
@@ -450,8 +453,11 @@ __device__ __forceinline__ void sp_fw_pkw_body(unsigned short* __restrict__ lds,
     }
     block_count_max(cnt, mx, pair_count_g, maxd);
     if (mk.present) {                                           // a thread per row and half of its columns
+        u32* colterm = (u32*)(xch + 256);                       // [128] behind the exchange area
+        if (tid < n) colterm[tid] = mk.with_labels ? (u32)mk.d1 * (u32)mk.labels[v0 + tid] : 0u;
+        __syncthreads();
         const int i = tid & 127, half = tid >> 7, mid = (n + 1) >> 1;
-        if (i < n) sp_pk_mark_row(lds + i * LD, i, half ? mid : 0, half ? n : mid, v0, mk);
+        if (i < n) sp_pk_mark_row(lds + i * LD, i, half ? mid : 0, half ? n : mid, colterm, mk);
     }
 }
 
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(64 * SP_REG_WAVES) void sp_fw_pk_kernel(
     const i32 v0 = graph_ptr[g];
     const int n = graph_ptr[g + 1] - v0;
     i32* out = dist + dist_ptr[g];
-    unsigned short* lds = (unsigned short*)sp_lds + (size_t)wave * (BIG ? 128 * 136 : 64 * 72);
+    unsigned short* lds = (unsigned short*)sp_lds + (size_t)wave * (BIG ? 128 * 136 + 256 : 64 * 72 + 128);      // matrix + column terms (SpMark)
     u32* pc = &pair_count[g];
     if (!BIG) {
         switch (c) {
@@ -1201,12 +1207,12 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
         hipStream_t st_pk = ctx->stream;
         if (both) GK_TRY(gk_side_fork(ctx, &st_pk));
         if (C.first[4] > 0) {
-            sp_fw_pk_kernel<0><<<dim3((unsigned)C.first[4]), 64 * SP_REG_WAVES, SP_REG_WAVES * 64 * 72 * 2, st_pk>>>(
+            sp_fw_pk_kernel<0><<<dim3((unsigned)C.first[4]), 64 * SP_REG_WAVES, SP_REG_WAVES * (64 * 72 + 128) * 2, st_pk>>>(
                 C, cls_list.p, N, b->graph_ptr, b->row_ptr, b->col_idx, w, s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, mk);
             ++n_launch;
         }
         if (n_big > 0) {                     // 65..128 vertices: a workgroup per graph, columns split over its four waves
-            const int lds = (128 * 136 + 256) * 2;
+            const int lds = (128 * 136 + 256) * 2 + 128 * 4;    // matrix, pivot-column exchange, column terms (SpMark)
             sp_fw_pkw_kernel<<<dim3(n_big), 256, lds, ctx->stream>>>(
                 cls_list.p, N, (int)h_cls[4], (int)h_cls[5], (int)h_cls[6], (int)h_cls[7], b->graph_ptr, b->row_ptr, b->col_idx, w,
                 s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, mk);
