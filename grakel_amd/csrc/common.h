@@ -111,7 +111,8 @@ struct gk_opts {
     int sp_hist_no_batch = 0;    // 1: the one-workgroup-per-CU histogram kernel takes its graphs one at a time (rounds 4-5) instead of as many as fit its table
     int sp_static_type = 0;      // 1: the operand type of a ShortestPath histogram job from the a-priori bound pairs^2 (rounds 3-5) instead of the job's largest self similarity
     int sp_rows_no_merge = 0;    // bit 0: the counting workgroups add every matrix entry to the LDS table on its own (round 5) instead of per-lane runs of equal keys;
-                                 // bit 1: they walk a graph's rows in matrix order and never empty the table (round 5) instead of label by label, emptying it when it fills
+                                 // bit 1: they walk a graph's rows in matrix order and never empty the table (round 5) instead of label by label, emptying it when it fills;
+                                 // bit 2: a wave takes one matrix row at a time instead of up to four neighbouring rows of the sorted order together
     int sp_hist_unit = 0;        // test hook: distance-matrix entries per counting workgroup (0: 131 072)
     int sp_hist_slots = 0;       // test hook: slots of the counting workgroups' LDS table (0: 8 192; a power of two)
     int sp_no_pk = 0;            // never the 16-bit packed register kernel (32-bit registers up to 64 vertices, LDS beyond)

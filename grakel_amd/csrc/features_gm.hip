@@ -1590,13 +1590,13 @@ __device__ __forceinline__ void spr_add(i32 key, u32 c, i32* keys, u32* co, u32 
 
 // the counting loop of sp_rows_count_kernel over a unit's matrix rows, for 32-bit and for byte matrices (B8; a branch on
 // the form inside the unrolled stages kept the compiler from batching the loads: 2.29 instead of 1.50 ms REDDIT-like)
-template <bool B8>
+template <bool B8, int RPW>
 __device__ __forceinline__ void spr_count_rows(const SpSource& S, const SpUnit& un, const SpMat& M, int n, i32 v0, u32 d1, bool col_in_lds,
                                                const u32* colterm, i32* keys, u32* co, u32 tmask, u32 t_cap, u32* n_ent,
                                                u32* __restrict__ row, bool merge, const i32* __restrict__ order, bool flush) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const i32* dg = M.d32;
-    // Rounds of one row per wave, in the LABEL-SORTED order of the graph's rows (sp_row_order_kernel), and the table is
+    // Rounds of RPW rows per wave, in the LABEL-SORTED order of the graph's rows (sp_row_order_kernel), and the table is
     // emptied into the counter row whenever it is nearly full (round 6).  A key (l_u, l_v, d) belongs to the rows of ONE label:
     // walked label by label, a table epoch holds the keys of a few row labels and every key leaves it once or twice -- a
     // D&D-like unit in matrix order met more distinct keys than the table holds and most of its counts were memory-side
@@ -1604,44 +1604,65 @@ __device__ __forceinline__ void spr_count_rows(const SpSource& S, const SpUnit& 
     // The fill checks are barriers, and a barrier per round costs a job whose tables never fill 14 % (REDDIT-like: 1.41 ->
     // 1.61 ms): the next check is scheduled from the growth the table showed between the last two (every wave computes the
     // same round from the same snapshot), at most SPR_CHECK_MAX rounds ahead.
+    // RPW (1, 2 or 4 by the unit's row count): a wave takes RPW neighbouring rows of the sorted order TOGETHER -- eight entries
+    // per lane and trip are then 8 / RPW columns of RPW rows: one column term per RPW entries instead of one each, and rows of
+    // the same label give the same key wherever their distances agree, which the run merging below folds into one count.
+    constexpr int NCS = 8 / RPW;                          // columns per lane and trip
     const u32 soft_cap = t_cap - (t_cap >> 2);
     __shared__ u32 fill_snap;
     int round = 0, next_check = 0, last_round = -1;
     u32 last_fill = 0;
-    for (int rr = un.r0; rr < un.r1; rr += SPR_THREADS / 64, ++round) {
-      if (rr + w < un.r1) {
-        const int i = order ? order[v0 + rr + w] : rr + w;
-        const u32 rowterm = S.with_labels ? d1 * (u32)S.L * (u32)S.node_label[v0 + i] : 0u;
-        const i32* dr = dg + (size_t)i * n;
-        const unsigned char* dr8 = M.d8 + (size_t)i * M.ns;          // byte matrix (round 6): same lane <-> column mapping, a byte per lane
+    for (int rr = un.r0; rr < un.r1; rr += RPW * (SPR_THREADS / 64), ++round) {
+      const int rbase = rr + RPW * w;
+      if (rbase < un.r1) {
+        int ri[RPW];
+        u32 rowterm[RPW];
+        const i32* dr[RPW];
+        const unsigned char* dr8[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            ri[q] = -1, rowterm[q] = 0, dr[q] = dg, dr8[q] = M.d8;
+            if (rbase + q < un.r1) {
+                const int i = order ? order[v0 + rbase + q] : rbase + q;
+                ri[q] = i;
+                rowterm[q] = S.with_labels ? d1 * (u32)S.L * (u32)S.node_label[v0 + i] : 0u;
+                dr[q] = dg + (size_t)i * n;
+                dr8[q] = M.d8 + (size_t)i * M.ns;         // byte matrix (round 6): same lane <-> column mapping, a byte per lane
+            }
+        }
         // eight entries per lane and trip, stage by stage: the distance loads together, then the eight table probes together
         // (one LDS latency instead of eight in a row -- the kernel is bound by dependent round trips, not by bandwidth or by
         // atomic conflicts: merging equal keys of a wave first, by run detection or by ballot rounds, made it slower), then
         // the counts as fire-and-forget atomics; a key that is not where its hash points takes the probing path.
-        // Round 6: a lane's consecutive entries (columns 64 apart) mostly carry the SAME key on the rows that cost most -- a hub
-        // reaches nearly every vertex in one or two steps and the labels are few -- and the count of a key is an LDS atomic
-        // that serialises over the lanes holding it.  A lane therefore adds up runs of equal keys first: inside a trip, and
-        // across trips through one PENDING (key, count) pair that is flushed when its key changes and at the end of the row.
+        // Round 6: a lane's consecutive entries mostly carry the SAME key on the rows that cost most -- a hub reaches nearly
+        // every vertex in one or two steps and the labels are few -- and the count of a key is an LDS atomic that serialises
+        // over the lanes holding it.  A lane therefore adds up runs of equal keys first: inside a trip, and across trips through
+        // one PENDING (key, count) pair that is flushed when its key changes and at the end of the rows.
         // (Merging ACROSS lanes -- ballot rounds, run detection by shuffle -- cost more than it saved in round 5.)
         i32 pk = -1;
         u32 pc = 0;
-        for (int j0 = 0; j0 < n; j0 += 512) {
+        for (int j0 = 0; j0 < n; j0 += NCS * 64) {
             i32 x[8], key[8], old[8];
-            u32 h[8], c[8];
+            u32 h[8], c[8], ct[NCS];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * 64 + lane;
+            for (int u = 0; u < 8; ++u) {                 // entry u: row u % RPW, column step u / RPW
+                const int q = u % RPW, j = j0 + (u / RPW) * 64 + lane;
+                const bool have = ri[q] >= 0 && j < n;
                 if (B8) {
-                    const unsigned char b8 = j < n ? dr8[j] : (unsigned char)255;
+                    const unsigned char b8 = have ? dr8[q][j] : (unsigned char)255;
                     x[u] = b8 == 255 ? SPH_INF : (i32)b8;
-                } else x[u] = j < n ? dr[j] : SPH_INF;
+                } else x[u] = have ? dr[q][j] : SPH_INF;
+            }
+#pragma unroll
+            for (int cs = 0; cs < NCS; ++cs) {
+                const int j = j0 + cs * 64 + lane;
+                ct[cs] = j < n ? (col_in_lds ? colterm[j] : (S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u)) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * 64 + lane;
+                const int q = u % RPW, j = j0 + (u / RPW) * 64 + lane;
                 key[u] = -1, c[u] = 1u;
-                if (j < n && j != i && x[u] < SPH_INF)
-                    key[u] = (i32)(rowterm + (col_in_lds ? colterm[j] : (S.with_labels ? d1 * (u32)S.node_label[v0 + j] : 0u)) + (u32)x[u]);
+                if (j != ri[q] && x[u] < SPH_INF) key[u] = (i32)(rowterm[q] + ct[u / RPW] + (u32)x[u]);
             }
             if (merge) {
                 if (pk >= 0 && key[0] == pk) c[0] += pc, pk = -1;      // the pending pair joins the trip's first entry ...
@@ -1666,7 +1687,7 @@ __device__ __forceinline__ void spr_count_rows(const SpSource& S, const SpUnit& 
         }
         if (pk >= 0) spr_add(pk, pc, keys, co, tmask, t_cap, n_ent, row, S.idtab);
       }
-      if (flush && round == next_check && rr + SPR_THREADS / 64 < un.r1) {        // workgroup-uniform
+      if (flush && round == next_check && rr + RPW * (SPR_THREADS / 64) < un.r1) {        // workgroup-uniform
           __syncthreads();
           if (threadIdx.x == 0) fill_snap = *(volatile u32*)n_ent;
           __syncthreads();
@@ -1764,8 +1785,13 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSour
     __syncthreads();
     const SpMat M = sp_mat(S.dist, S.dist_ptr, un.g, n);
     u32* row = rows + (size_t)un.row * (size_t)Q;
-    if (M.d8) spr_count_rows<true>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, (merge & 1) != 0, order, (merge & 2) == 0);
-    else spr_count_rows<false>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, (merge & 1) != 0, order, (merge & 2) == 0);
+    // rows per wave by the unit's row count (a unit of a 5 748-vertex graph is 22 rows: sixteen waves of four would leave ten idle)
+    const int n_unit_rows = un.r1 - un.r0;
+    const int rpw = (merge & 4) ? 1 : (n_unit_rows >= 4 * (SPR_THREADS / 64) ? 4 : (n_unit_rows >= 2 * (SPR_THREADS / 64) ? 2 : 1));
+#define SPR_GO(B8_, RPW_) spr_count_rows<B8_, RPW_>(S, un, M, n, v0, d1, col_in_lds, colterm, keys, co, tmask, t_cap, &n_ent_s, row, (merge & 1) != 0, order, (merge & 2) == 0)
+    if (M.d8) { if (rpw == 4) SPR_GO(true, 4); else if (rpw == 2) SPR_GO(true, 2); else SPR_GO(true, 1); }
+    else { if (rpw == 4) SPR_GO(false, 4); else if (rpw == 2) SPR_GO(false, 2); else SPR_GO(false, 1); }
+#undef SPR_GO
     __syncthreads();
     for (int t = tid; t < slots; t += SPR_THREADS) {
         const i32 k = keys[t];
@@ -1963,7 +1989,7 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
         const size_t lds1 = (size_t)slots * 8 + (size_t)cols * 4;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_count_kernel, (int)lds1));
         // rows walked label by label, the table emptied when it fills (option sp.rows_no_merge: 1 = no per-lane runs, 2 = matrix
-        // order and no emptying -- the round-5 walk --, 3 = both)
+        // order and no emptying -- the round-5 walk --, 4 = one matrix row per wave and round instead of up to four)
         const int walk = ctx->opt.sp_rows_no_merge;
         Tmp<i32> order(ctx);
         if (!(walk & 2)) {
@@ -1972,7 +1998,7 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
                                                                                 (int)pb->sp_L, pb->sp_with_labels);
         }
         sp_rows_count_kernel<<<dim3((unsigned)units.size()), SPR_THREADS, lds1, ctx->stream>>>(S, units_dev.p, rows.p, Q, slots,
-                                                                                              (walk & 1 ? 0 : 1) | (walk & 2), (walk & 2) ? nullptr : order.p);
+                                                                                              (walk & 1 ? 0 : 1) | (walk & 6), (walk & 2) ? nullptr : order.p);
         const size_t lds2 = (size_t)R.bins * 2;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_compact_kernel, (int)lds2));
         SpRowsOut O{ent.p, cnt.p, ent_n.p, f->selfk, part.p, wgmeta.p};

@@ -113,7 +113,8 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             a-priori bound (pairs of the largest graph)^2 instead of the job's largest self similarity, found on the device),
  *             "sp.rows_no_merge" (bit 0: the counter-row route adds every matrix entry to its LDS table on its own instead of
  *             per-lane runs of equal keys; bit 1: it walks a graph's rows in matrix order and never empties the table
- *             instead of label by label with the table emptied into the counter row when it fills),
+ *             instead of label by label with the table emptied into the counter row when it fills; bit 2: a wave counts one
+ *             matrix row at a time instead of up to four neighbouring rows of the sorted order together),
  *             "sp.rows_all" / "sp.hist_unit" / "sp.hist_slots" (test hooks of the counter-row route: every graph
  *             through it, distance-matrix entries per counting workgroup, slots of its LDS table),
  *             "sp.no_pk" (all-pairs distances never in the 16-bit packed register kernel: 32-bit registers up to 64

@@ -3,7 +3,7 @@ out=gpurun_out/r06n; mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "shortest or large_unit or sp_ or published" > $out/tests.txt 2>&1; tail -5 $out/tests.txt
 for w in reddit dd collab; do
   timeout 300 python tools/published_like.py $w sp 6 > $out/pub_${w}_sp.json 2> $out/pub_${w}_sp.log; cut -c1-600 $out/pub_${w}_sp.json
-  GK_TOOL_OPTS="sp.rows_no_merge=2" timeout 300 python tools/published_like.py $w sp 6 > $out/pub_${w}_sp_nomerge.json 2>> $out/pub_${w}_sp.log; cut -c150-420 $out/pub_${w}_sp_nomerge.json
+  GK_TOOL_OPTS="sp.rows_no_merge=4" timeout 300 python tools/published_like.py $w sp 6 > $out/pub_${w}_sp_nomerge.json 2>> $out/pub_${w}_sp.log; cut -c150-420 $out/pub_${w}_sp_nomerge.json
 done
 root=$(pwd); cd /tmp; export TMPDIR=/tmp
 for w in reddit dd; do
