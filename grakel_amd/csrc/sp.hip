@@ -1033,37 +1033,49 @@ __device__ __forceinline__ void spm_mark_rows(const SpMat& M, int n, i32 v0, int
                                               const u32* colt_s, u32* seen_s) {
     const int tid = threadIdx.x, lane = tid & 63;
     const i32* dg = M.d32;
-    for (int i = r0 + (tid >> 6); i < r1; i += SP_THREADS / 64) {
-        const u32 rowterm = with_labels ? (u32)(d1 * (u64)(u32)node_label[v0 + i] * n_labels) : 0u;
-        const i32* dr = dg + (size_t)i * n;
-        const unsigned char* dr8 = M.d8 + (size_t)i * M.ns;
-        u32 last = 0xffffffffu;
+    // FOUR neighbouring rows per wave and trip (round 6): eight entries per lane are two columns of four rows -- one column
+    // term per four entries instead of one each (the loop is bound by its LDS reads and the chain distance -> key -> cache)
+    constexpr int RPW = 4, NCS = 2;
+    for (int ib = r0 + RPW * (tid >> 6); ib < r1; ib += RPW * (SP_THREADS / 64)) {
+        int ri[RPW];
+        u32 rowterm[RPW], last[RPW];
+        const i32* dr[RPW];
+        const unsigned char* dr8[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int i = ib + q < r1 ? ib + q : -1;
+            ri[q] = i, last[q] = 0xffffffffu;
+            rowterm[q] = (with_labels && i >= 0) ? (u32)(d1 * (u64)(u32)node_label[v0 + i] * n_labels) : 0u;
+            dr[q] = dg + (size_t)(i >= 0 ? i : 0) * n;
+            dr8[q] = M.d8 + (size_t)(i >= 0 ? i : 0) * M.ns;
+        }
         // eight entries per lane and trip, every stage for all eight before the next: the loop is a chain of dependent
         // round trips (distance -> label -> presence byte) and one entry per trip left the memory system idle (2.7 ms)
-        for (int j0 = 0; j0 < n; j0 += 512) {
+        for (int j0 = 0; j0 < n; j0 += NCS * 64) {
             i32 x[8];
-            u32 lj[8], key[8], hs[8], cached[8];
+            u32 lj[NCS], key[8], hs[8], cached[8];
             unsigned char seen[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * 64 + lane;
+            for (int u = 0; u < 8; ++u) {                 // entry u: row u % RPW, column step u / RPW
+                const int q = u % RPW, j = j0 + (u / RPW) * 64 + lane;
+                const bool have = ri[q] >= 0 && j < n;
                 if (B8) {
-                    const unsigned char b8 = j < n ? dr8[j] : (unsigned char)255;
+                    const unsigned char b8 = have ? dr8[q][j] : (unsigned char)255;
                     x[u] = b8 == 255 ? SP_INF : (i32)b8;
-                } else x[u] = j < n ? dr[j] : SP_INF;
+                } else x[u] = have ? dr[q][j] : SP_INF;
+            }
+#pragma unroll
+            for (int cs = 0; cs < NCS; ++cs) {
+                const int j = j0 + cs * 64 + lane;
+                lj[cs] = j < n ? (col_in_lds ? colt_s[j] : (with_labels ? (u32)d1 * (u32)node_label[v0 + j] : 0u)) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * 64 + lane;
-                lj[u] = j < n ? (col_in_lds ? colt_s[j] : (with_labels ? (u32)d1 * (u32)node_label[v0 + j] : 0u)) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * 64 + lane;
+                const int q = u % RPW, j = j0 + (u / RPW) * 64 + lane;
                 key[u] = 0xffffffffu;
-                if (j < n && j != i && x[u] < SP_INF) {
-                    const u32 k = rowterm + lj[u] + (u32)x[u];
-                    if (k != last) key[u] = k, last = k;
+                if (j != ri[q] && x[u] < SP_INF) {
+                    const u32 k = rowterm[q] + lj[u / RPW] + (u32)x[u];
+                    if (k != last[q]) key[u] = k, last[q] = k;     // (a lane does not look up the key it marked last in this row)
                 }
                 hs[u] = (key[u] * 2654435761u) >> (32 - SPM_SEEN_BITS);
             }
