@@ -109,7 +109,8 @@ struct gk_opts {
     int sp_rows_all = 0;         // test hook: every graph with a pair counts through counter rows (default: graphs above 6 144 pairs)
     int sp_no_fused_mark = 0;    // 1: the key marks of a small-graph job by sp_mark_kernel over the stored matrices (rounds 4-5) instead of inside the packed all-pairs kernels
     int sp_hist_no_batch = 0;    // 1: the one-workgroup-per-CU histogram kernel takes its graphs one at a time (rounds 4-5) instead of as many as fit its table
-    int sp_static_type = 0;      // 1: the operand type of a ShortestPath histogram job from the a-priori bound pairs^2 (rounds 3-5) instead of the job's largest self similarity
+    int sp_static_type = 0;      // 1: the operand type of a ShortestPath histogram job from the a-priori bound pairs^2 (rounds 3-5) instead of the job's largest self similarity;
+                                 // 2: the device decision without the mixed type (int8 operand + float64 side operand when only the int8 columns' part stays below 2^31)
     int sp_rows_no_merge = 0;    // bit 0: the counting workgroups add every matrix entry to the LDS table on its own (round 5) instead of per-lane runs of equal keys;
                                  // bit 1: they walk a graph's rows in matrix order and never empty the table (round 5) instead of label by label, emptying it when it fills;
                                  // bit 2: a wave takes one matrix row at a time instead of up to four neighbouring rows of the sorted order together

@@ -27,7 +27,8 @@
 #define GM_META_RARE_ENTRIES 4
 #define GM_META_SPLIT 5           // parts of the split columns (0: labels with counts above 127 go to the float64 operand)
 #define GM_META_TYPE 6            // ShortestPath histogram jobs (round 6): operand type decided ON THE DEVICE from the largest self
-                                  // similarity (K_ij <= sqrt(K_ii K_jj)): 0 = fp4 + int8 (below 2^24), 1 = int8 (below 2^31), 2 = float64
+                                  // similarity (K_ij <= sqrt(K_ii K_jj)): 0 = fp4 + int8 (below 2^24), 1 = int8 (below 2^31), 2 = float64,
+                                  // 3 = int8 + float64 side operand (the int8 columns' part of every self similarity below 2^31)
 #define GM_META_SELFMAX 7         // ... and that largest K_ii, saturated to 32 bits: the job's entry bound
 #define GM_META_MAXC 8            // 64 partial maxima
 #define GM_META_NNZ 72            // 64 partial sums
@@ -36,7 +37,7 @@
 #define GM_MAX_NODES 1024         // largest graph a wave stages in LDS
 #define GM_WG_NODES 320           // ... and, in a job that has such graphs, everything above this many vertices goes to the workgroup kernel too
 #define GM_HUGE_MAX_NODES 8192    // largest graph of the graph-major builder: above GM_MAX_NODES a whole workgroup counts it (gm_pairs_huge_kernel)
-#define GM_ROW_LDS_MAX 65536      // widest operand row (bytes) assembled in LDS
+#define GM_ROW_LDS_MAX 147456     // widest operand row (bytes) assembled in LDS (round 6: 144 KiB -- 64 KiB sent the D&D-like ShortestPath job with its 90 k int8 columns to the label-major builder)
 
 int gk_features_build_gm(gk_ctx* ctx, gk_batch* b, gk_feat* f, int n_levels, int prim_max, int wide_above);
 

@@ -542,7 +542,7 @@ extern "C" int gk_features_build_range(gk_ctx* ctx, gk_batch* b, int level_lo, i
         // leave (K_ij <= sqrt(K_ii K_jj) <= max K_ii: exact, where the a-priori bound is (pairs of the largest graph)^2 --
         // 1.4 x 10^8 at BASELINE config 4, whose largest K_ii is a few 10^5: fp4 + int8 instead of int8 only; 5.8 x 10^10 on the
         // COLLAB-like set: int8 instead of float64).  The counts are classified against 4 / 127 whatever the type turns out to be.
-        const bool dyn = hist_ok && !ctx->opt.sp_static_type;
+        const bool dyn = hist_ok && !(ctx->opt.sp_static_type & 1);
         const int static_dtype = f->dtype;
         const bool static_fp4 = f->phi_fp4;
         for (int attempt = 0; attempt < 2; ++attempt) {

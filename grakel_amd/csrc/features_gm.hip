@@ -618,7 +618,11 @@ struct GmColumns {
         const u32 df = A.df[q];
         if (df == 0) return v;
         int prim_max = this->prim_max, wide_above = this->wide_above;
-        if (dyn && *dyn == 2u) prim_max = -1, wide_above = -1, parts = 0;
+        if (dyn) {
+            const u32 type = *dyn;
+            if (type == 2u) prim_max = -1, wide_above = -1, parts = 0;
+            else if (type == 3u) prim_max = 127, wide_above = 127, parts = 0;       // int8 + float64 side operand
+        }
         const bool useful = symmetric ? df >= 2u : A.side[q] == 3;
         if (!useful) return v;
         if ((int)df < low_df) { v.b = 1ull << 32, v.c = df; return v; }
@@ -1013,7 +1017,7 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
         GK_TRY(gk_readback(ctx, f->meta, h.data(), GM_META_WORDS));     // one host sync: sizes of the operand
     if (h[GM_META_OVF]) return GK_ERR_UNSUPPORTED;                  // a histogram table of gk_features_build_sp overflowed
     if (f->dyn_type) {                                              // the type the device chose (sp_type_kernel)
-        const u32 type = h[GM_META_TYPE];
+        const u32 type = h[GM_META_TYPE];                           // 3: int8 operand + float64 side operand (sp_type8_kernel)
         f->dtype = type == 2u ? 1 : 0;
         f->phi_fp4 = type == 0u && !ctx->opt.gram_no_fp4;
         if (type < 2u) f->k_bound = (double)h[GM_META_SELFMAX] + 1.0;
@@ -1278,7 +1282,8 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
                                                               i64 n_graphs, i32* __restrict__ ent_lab, u32* __restrict__ ent_cnt,
                                                               u32* __restrict__ ent_n, u64* __restrict__ selfk, i64 n_fit, int rectangular,
                                                               u32 df_cap, int prim_max, int wide_above, u32* __restrict__ part,
-                                                              u32* __restrict__ wgmeta, u32* __restrict__ overflow, u32 skip_above, int bmax) {
+                                                              u32* __restrict__ wgmeta, u32* __restrict__ overflow, u32 skip_above, int bmax,
+                                                              u64* __restrict__ selfk8) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private df histogram | keys[SPH_T] | counts[SPH_T]
     __shared__ u32 ovf_s, void_s, red_m[SPH_THREADS / 64], red_e[SPH_THREADS / 64];
     __shared__ int b_g[SPH_BATCH], b_n[SPH_BATCH], b_v0[SPH_BATCH], b_base[SPH_BATCH], b_ns[SPH_BATCH];
@@ -1286,6 +1291,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
     __shared__ const i32* b_d32[SPH_BATCH];
     __shared__ const unsigned char* b_d8[SPH_BATCH];
     __shared__ unsigned long long b_extra[SPH_BATCH];
+    __shared__ u32 b_sq8[SPH_BATCH];                     // sum of c^2 over the entries with c <= 127 (at most 6 144 x 127^2: 32 bits)
     __shared__ int nb_s, done_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     u32* priv = (u32*)gm_lds;
@@ -1354,10 +1360,10 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
                 b_g[at] = (int)g_mine, b_n[at] = cn, b_v0[at] = cv0, b_base[at] = cbase, b_np[at] = cnp;
                 b_d32[at] = d32, b_ns[at] = (cn + 15) & ~15;
                 b_d8[at] = (cd & SP_BYTE_FLAG) ? (const unsigned char*)(((uintptr_t)d32 + 15) & ~(uintptr_t)15) : nullptr;
-                b_t0[at] = pT - T, b_e0[at] = pE - E_sat, b_nent[at] = 0, b_extra[at] = 0ull;
+                b_t0[at] = pT - T, b_e0[at] = pE - E_sat, b_nent[at] = 0, b_extra[at] = 0ull, b_sq8[at] = 0u;
                 if (at == nb - 1) b_t0[nb] = pT, b_e0[nb] = E_sat >= 0x0fffffffu ? E : pE;
             }
-            if (valid && lane < used && cnp == 0) ent_n[g_mine] = 0, selfk[g_mine] = 0;
+            if (valid && lane < used && cnp == 0) { ent_n[g_mine] = 0, selfk[g_mine] = 0; if (selfk8) selfk8[g_mine] = 0; }
             next += (i64)used * (i64)gridDim.x;
             if (lane > nb && lane <= SPH_BATCH) b_t0[lane] = 0xffffffffu, b_e0[lane] = 0xffffffffu;
             if (lane == 0) {
@@ -1459,7 +1465,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
             if (*(volatile u32*)&ovf_s | __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) void_s = 1u;
             sph_lds_barrier();
             if (*(volatile u32*)&void_s) {                // more distinct keys than the table holds: the caller falls back
-                if (tid == 0) { atomicOr(overflow, 1u); ent_n[b_g[0]] = 0, selfk[b_g[0]] = 0; }
+                if (tid == 0) { atomicOr(overflow, 1u); ent_n[b_g[0]] = 0, selfk[b_g[0]] = 0; if (selfk8) selfk8[b_g[0]] = 0; }
                 sph_lds_barrier();                        // the batch words are rewritten by wave 0 next
                 continue;
             }
@@ -1508,6 +1514,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
                 extra = (u64)c * c - c;
                 maxc = c > maxc ? c : maxc;
                 ++entries;
+                if (selfk8 && c <= 127u) atomicAdd(&b_sq8[k], c * c);
             }
             // sum of c^2 - c per graph: one LDS atomic per wave where the wave's entries belong to one graph, else one per lane
             const int k0 = __builtin_amdgcn_readfirstlane(k);
@@ -1521,6 +1528,7 @@ __global__ __launch_bounds__(SPH_THREADS) void sp_hist_kernel(const SpSource S, 
         if (tid < nb) {
             ent_n[b_g[tid]] = b_nent[tid];
             selfk[b_g[tid]] = (u64)b_np[tid] + (u64)b_extra[tid];      // sum of c^2 = sum of c + sum of (c^2 - c)
+            if (selfk8) selfk8[b_g[tid]] = (u64)b_sq8[tid];
         }
         sph_lds_barrier();                                // the batch words are rewritten by wave 0 next
         SPH_DBG(5)
@@ -1710,20 +1718,32 @@ __device__ __forceinline__ void spr_count_rows(const SpSource& S, const SpUnit& 
     }
 }
 
-// operand type of a histogram job from its largest self similarity (features.h: GM_META_TYPE); one workgroup
-__global__ __launch_bounds__(1024) void sp_type_kernel(const u64* __restrict__ selfk, i64 n, u32* __restrict__ meta, int fp4_ok) {
-    __shared__ u64 red[16];
-    u64 m = 0;
-    for (i64 g = threadIdx.x; g < n; g += 1024) m = selfk[g] > m ? selfk[g] : m;
-    for (int off = 32; off > 0; off >>= 1) {
-        const u64 o = __shfl_down(m, off, 64);
-        m = o > m ? o : m;
+// operand type of a histogram job from its largest self similarity (features.h: GM_META_TYPE); one workgroup.
+// Type 3, int8 operand + float64 side operand: where the full self similarities say float64 (2), does the INT8 PART of the
+// operand stay exact?  The columns whose largest count is above 127 go to the float64 side operand whatever happens; what the
+// int32 accumulators of the MFMA product see is the rest: K8_ij <= sqrt(K8_ii K8_jj), and K8_gg <= selfk8[g] = the sum of c^2 over
+// the graph's entries with c <= 127 (the histogram kernels leave it next to selfk).  Below 2^31: exact.  The D&D-like set
+// multiplied 96 k columns in float64 because ONE graph of 5 748 vertices has a self similarity above 2^31 -- most of those
+// columns never hold a count above 127.
+__global__ __launch_bounds__(1024) void sp_type_kernel(const u64* __restrict__ selfk, const u64* __restrict__ selfk8, i64 n, u32* __restrict__ meta,
+                                                       int fp4_ok) {
+    __shared__ u64 red[16], red8[16];
+    u64 m = 0, m8 = 0;
+    for (i64 g = threadIdx.x; g < n; g += 1024) {
+        m = selfk[g] > m ? selfk[g] : m;
+        if (selfk8) m8 = selfk8[g] > m8 ? selfk8[g] : m8;
     }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_down(m, off, 64), o8 = __shfl_down(m8, off, 64);
+        m = o > m ? o : m, m8 = o8 > m8 ? o8 : m8;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m, red8[threadIdx.x >> 6] = m8;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int q = 1; q < 16; ++q) m = red[q] > m ? red[q] : m;
-        meta[GM_META_TYPE] = (m < (1ull << 24) && fp4_ok) ? 0u : (m < 0x7fffffffull ? 1u : 2u);
+        for (int q = 1; q < 16; ++q) m = red[q] > m ? red[q] : m, m8 = red8[q] > m8 ? red8[q] : m8;
+        u32 type = (m < (1ull << 24) && fp4_ok) ? 0u : (m < 0x7fffffffull ? 1u : 2u);
+        if (type == 2u && selfk8 && m8 < 0x7fffffffull) type = 3u;
+        meta[GM_META_TYPE] = type;
         meta[GM_META_SELFMAX] = m < 0xffffffffull ? (u32)m : 0xffffffffu;
     }
 }
@@ -1800,7 +1820,7 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSour
 }
 
 struct SpRowsOut {
-    i32* ent_lab; u32* ent_cnt; u32* ent_n; u64* selfk; u32* part; u32* wgmeta;
+    i32* ent_lab; u32* ent_cnt; u32* ent_n; u64* selfk; u32* part; u32* wgmeta; u64* selfk8;
 };
 
 __global__ __launch_bounds__(SPR_THREADS) void sp_rows_compact_kernel(const i32* __restrict__ row_graph, int n_rows, const u32* __restrict__ rows,
@@ -1809,7 +1829,7 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_compact_kernel(const i32*
                                                                       int rectangular, u32 df_cap, int prim_max, int wide_above, int wg0) {
     extern __shared__ __attribute__((aligned(16))) i32 gm_lds[];      // private df histogram
     __shared__ u32 n_ent_s, red_m[SPR_THREADS / 64], red_e[SPR_THREADS / 64];
-    __shared__ u64 red_x[SPR_THREADS / 64];
+    __shared__ u64 red_x[SPR_THREADS / 64], red_8[SPR_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     u32* priv = (u32*)gm_lds;
     const int priv_words = R.bins / 2;
@@ -1825,7 +1845,7 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_compact_kernel(const i32*
         __syncthreads();
         if (tid == 0) n_ent_s = 0;
         __syncthreads();
-        u64 extra = 0;
+        u64 extra = 0, sq8 = 0;                            // sq8: sum of c^2 over the entries with c <= 127 (sp_type_kernel)
         for (i64 t0 = 0; t0 < Q; t0 += 4 * SPR_THREADS) {
             u32 cc[4];
 #pragma unroll
@@ -1864,18 +1884,21 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_compact_kernel(const i32*
                     if (rectangular && !(A.side[q] & side_bit)) atomicOr((u32*)(A.side + (q & ~3ll)), side_bit << (8 * (q & 3)));
                 }
                 extra += (u64)c * c - c;
+                if (c <= 127u) sq8 += (u64)c * c;
                 maxc = c > maxc ? c : maxc;
                 ++entries;
             }
         }
-        for (int off = 32; off > 0; off >>= 1) extra += __shfl_down(extra, off, 64);
-        if (lane == 0) red_x[w] = extra;
+        extra = wave_sum_u64(extra), sq8 = wave_sum_u64(sq8);
+        if (lane == 0) red_x[w] = extra, red_8[w] = sq8;
         __syncthreads();
         if (tid == 0) {
             u64 x = 0;
-            for (int q = 0; q < SPR_THREADS / 64; ++q) x += red_x[q];
+            u64 x8 = 0;
+            for (int q = 0; q < SPR_THREADS / 64; ++q) x += red_x[q], x8 += red_8[q];
             O.ent_n[g] = n_ent_s;
             O.selfk[g] = (u64)np + x;                     // sum of c^2 = sum of c + sum of (c^2 - c)
+            if (O.selfk8) O.selfk8[g] = x8;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -1965,11 +1988,13 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     gm_prep_table_kernel<<<dim3((unsigned)std::min<i64>(cdiv(Q, 1024), 1024)), 256, 0, ctx->stream>>>(Tv, table.p, A.df, A.cmax, A.cursor, (u32*)A.side);
     SpSource S{pb->sp_node_ptr, pb->sp_node_label, pb->sp_dist_ptr, pb->sp_dist, pb->sp_idtab, pb->graph_ptr,
                (u64)pb->sp_L, (u64)pb->sp_dcap, pb->sp_with_labels};
+    Tmp<u64> selfk8(ctx);                                 // per graph: sum of c^2 over its entries with c <= 127 (sp_type_kernel: type 3)
+    if (f->dyn_type && f->k_bound >= 2147483647.0 && !(ctx->opt.sp_static_type & 2)) GK_TRY(selfk8.alloc((size_t)N));       // (below that bound the type cannot be 2)
     if (grid1 > 0) {
         GK_TRY(gk_func_lds(ctx, (const void*)sp_hist_kernel, (int)lds));
         sp_hist_kernel<<<dim3((unsigned)grid1), SPH_THREADS, lds, ctx->stream>>>(
             S, P, A, R, N, ent.p, cnt.p, ent_n.p, f->selfk, f->n_fit, rectangular, (u32)(f->low_df > 2 ? f->low_df : 2), prim_max,
-            wide_above, part.p, wgmeta.p, f->meta + GM_META_OVF, skip_above, ctx->opt.sp_hist_no_batch ? 1 : SPH_BATCH);
+            wide_above, part.p, wgmeta.p, f->meta + GM_META_OVF, skip_above, ctx->opt.sp_hist_no_batch ? 1 : SPH_BATCH, selfk8.p);
     }
     Tmp<u32> rows(ctx);
     Tmp<SpUnit> units_dev(ctx);
@@ -2001,7 +2026,7 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
                                                                                               (walk & 1 ? 0 : 1) | (walk & 6), (walk & 2) ? nullptr : order.p);
         const size_t lds2 = (size_t)R.bins * 2;
         GK_TRY(gk_func_lds(ctx, (const void*)sp_rows_compact_kernel, (int)lds2));
-        SpRowsOut O{ent.p, cnt.p, ent_n.p, f->selfk, part.p, wgmeta.p};
+        SpRowsOut O{ent.p, cnt.p, ent_n.p, f->selfk, part.p, wgmeta.p, selfk8.p};
         sp_rows_compact_kernel<<<dim3((unsigned)grid2), SPR_THREADS, lds2, ctx->stream>>>(
             row_graph_dev.p, (int)n_rows, rows.p, Q, pb->graph_ptr, P, A, R, O, f->n_fit, rectangular, (u32)(f->low_df > 2 ? f->low_df : 2),
             prim_max, wide_above, (int)grid1);
@@ -2009,7 +2034,8 @@ int gk_features_build_sp(gk_ctx* ctx, gk_batch* pb, gk_feat* f, int prim_max, in
     GK_HIP_CHECK(hipGetLastError());
     if (R.bins > 0)
         gm_reduce_kernel<<<grid_for(R.bins / 2, 64), 1024, 0, ctx->stream>>>(A, table.p, part.p, (int)grid, prim_max, wide_above, rectangular);
-    if (f->dyn_type) sp_type_kernel<<<1, 1024, 0, ctx->stream>>>(f->selfk, N, f->meta, ctx->opt.gram_no_fp4 ? 0 : 1);
+    if (f->dyn_type) sp_type_kernel<<<1, 1024, 0, ctx->stream>>>(f->selfk, selfk8.p, N, f->meta, ctx->opt.gram_no_fp4 ? 0 : 1);
+
     // the overflow word travels with the operand sizes: meta[] is read back once, in gm_finish
     return gm_finish(ctx, f, P, A, table.p, Q, pb->graph_ptr, N, V, ent.p, cnt.p, ent_n.p, wgmeta.p, (int)grid, prim_max, wide_above);
 }

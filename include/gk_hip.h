@@ -110,7 +110,9 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "sp.hist_no_batch" (1: the LDS-table histogram kernel walks its graphs one at a time instead of as many at a time
  *             as fit its table),
  *             "sp.static_type" (1: the Gram operand type of a histogram-form job -- fp4 + int8, int8 or float64 -- from the
- *             a-priori bound (pairs of the largest graph)^2 instead of the job's largest self similarity, found on the device),
+ *             a-priori bound (pairs of the largest graph)^2 instead of the job's largest self similarity, found on the device;
+ *             2: found on the device, but without the mixed type -- int8 columns + a float64 side operand for the columns
+ *             holding counts above 127 -- where only the int8 columns' part of the self similarities stays below 2^31),
  *             "sp.rows_no_merge" (bit 0: the counter-row route adds every matrix entry to its LDS table on its own instead of
  *             per-lane runs of equal keys; bit 1: it walks a graph's rows in matrix order and never empties the table
  *             instead of label by label with the table emptied into the counter row when it fills; bit 2: a wave counts one
