@@ -11,7 +11,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 for s in $sets; do
   for mode in wl sp wl_e2e; do
-    timeout ${PUB_TIMEOUT:-150} python $root/tools/published_like.py $s $mode 3 > "$out/pub_${s}_${mode}.json" 2> "$out/pub_${s}_${mode}.log" \
+    timeout ${PUB_TIMEOUT:-150} python $root/tools/published_like.py $s $mode 6 > "$out/pub_${s}_${mode}.json" 2> "$out/pub_${s}_${mode}.log" \
       || echo "{\"error\": \"rc $? (timeout ${PUB_TIMEOUT:-150}s or failure)\"}" >> "$out/pub_${s}_${mode}.json"
     tail -c 700 "$out/pub_${s}_${mode}.json"; echo
   done
