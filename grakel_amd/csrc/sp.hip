@@ -26,6 +26,7 @@ static inline dim3 grid_for(i64 n, int t) { return dim3((unsigned)(n > 0 ? cdiv(
 
 // size classes of the bit-parallel breadth-first search (sp_msbfs_kernel, further down)
 #define SPB_HUB_DEG 32
+#define SPB_BITWISE_MAX 6      // new bits of a vertex and sweep up to which the levels are stored byte by byte
 #define SPB_HUB_CAP 512
 #define SPB_LDS_MAX (149 * 1024)        // dynamic LDS of a workgroup (the static hub arrays take 10 KiB more)
 #define SPB_LDS0 (42 * 1024)
@@ -812,6 +813,25 @@ struct SpDist {
 //   class 1: n <= 1 024, 64 columns, 1 024 threads, 69 KiB (two per CU)     class 4: 20 n bytes <= 149 KiB, 16 columns; the
 //   class 2: n <= 2 048, 64 columns, 149 KiB                                         entries in LDS only if they fit
 //   class 5: the relaxation kernel
+#ifdef GK_ABLATION
+// tools' build only: cycles per phase of sp_msbfs_kernel summed over all workgroups of a class (thread 0's stamps):
+// [class][0] staging, [1] set-up, [2] pull, [3] update, [4] epilogue, [5] workgroups, [6] levels; tools/dev/msbfs_times.py
+__device__ unsigned long long g_spb_dbg[6][8];
+#define SPB_DBG_DECL unsigned long long t_x = __builtin_readcyclecounter(), t_ph[5] = {0, 0, 0, 0, 0};
+#define SPB_DBG(k) { if (threadIdx.x == 0) { const unsigned long long t_y = __builtin_readcyclecounter(); t_ph[k] += t_y - t_x; t_x = t_y; } }
+#define SPB_DBG_OUT(cls, levels) { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 5; ++q_) atomicAdd(&g_spb_dbg[cls][q_], t_ph[q_]); atomicAdd(&g_spb_dbg[cls][5], 1ull); atomicAdd(&g_spb_dbg[cls][6], (unsigned long long)(levels)); } }
+extern "C" int gk_debug_spb_times(gk_ctx* ctx, unsigned long long* out48, int reset) {
+    GK_HIP_CHECK(hipSetDevice(ctx->device));
+    GK_HIP_CHECK(hipDeviceSynchronize());
+    GK_HIP_CHECK(hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_spb_dbg), sizeof(unsigned long long) * 48));
+    if (reset) { unsigned long long z[48] = {0}; GK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_spb_dbg), z, sizeof(z))); }
+    return GK_OK;
+}
+#else
+#define SPB_DBG_DECL
+#define SPB_DBG(k)
+#define SPB_DBG_OUT(cls, levels)
+#endif
 template <typename W, int G, int NT, int VPT, int CLS>
 __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
     const i32* __restrict__ big_list, const i32* __restrict__ graph_ptr, const i32* __restrict__ row_ptr, const i32* __restrict__ col_idx,
@@ -836,11 +856,13 @@ __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
     unsigned char* d8 = (unsigned char*)(front + n_words);
     unsigned short* cols = (unsigned short*)(d8 + (size_t)n_words * GS);
     const bool in_lds = use_cols && (long)n_words * (2 * (long)sizeof(W) + GS) + 2l * m <= (long)lds_bytes;   // workgroup-uniform
+    SPB_DBG_DECL
     if (in_lds)
         for (int e = tid; e < m; e += NT) cols[e] = (unsigned short)(col_idx[eg + e] - v0);
     for (int q = tid; q < n * (GS / 4); q += NT) ((u32*)d8)[q] = 0xffffffffu;   // 255: not reached
     if (tid == 0) n_hubs_s = 0;
     __syncthreads();
+    SPB_DBG(0)
     i32 e0[VPT], dg[VPT];                                     // dg < 0: not this thread's to pull (beyond n, or a listed hub)
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
@@ -863,6 +885,7 @@ __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
     const int n_hubs = n_hubs_s < (u32)SPB_HUB_CAP ? (int)n_hubs_s : SPB_HUB_CAP;
     const i32* cg = col_idx + eg;
     u32 cnt = 0, mx = 0;
+    SPB_DBG(1)
     for (int level = 1;; ++level) {
         W nx[VPT];
 #pragma unroll
@@ -891,6 +914,7 @@ __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
             if (lane == 0) hub_nx[h] = acc & ~(u64)visit[u];
         }
         __syncthreads();                                              // every read of front[] is done
+        SPB_DBG(2)
         int any = 0;
 #pragma unroll
         for (int k = 0; k < VPT; ++k) {
@@ -898,12 +922,30 @@ __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
             if (dg[k] >= 0) {
                 front[u] = nx[k];
                 if (nx[k]) {
-                    visit[u] |= nx[k], any = 1, cnt += (u32)__popcll((u64)nx[k]);
+                    const int pc = __popcll((u64)nx[k]);
+                    visit[u] |= nx[k], any = 1, cnt += (u32)pc;
                     u64 x = (u64)nx[k];
-                    while (x) {
-                        const int t = __ffsll((unsigned long long)x) - 1;
-                        x &= x - 1;
-                        d8[u * GS + t] = (unsigned char)level;
+                    if (pc <= SPB_BITWISE_MAX) {
+                        while (x) {
+                            const int t = __ffsll((unsigned long long)x) - 1;
+                            x &= x - 1;
+                            d8[u * GS + t] = (unsigned char)level;
+                        }
+                    } else {
+                        // many columns reach the vertex in the same sweep (a thread with a hub: nearly every vertex two steps
+                        // from nearly every column): the level goes into the row four bytes at a time -- the group's four bits
+                        // spread to a byte mask -- instead of one byte store and ten instructions per bit (the update was the
+                        // longer half of a sweep: 5 800 of 9 800 cycles per level on the REDDIT-like set)
+                        u32* row32 = (u32*)(d8 + u * GS);
+                        const u32 lv4 = (u32)level * 0x01010101u;
+#pragma unroll
+                        for (int q = 0; q < G / 4; ++q) {
+                            const u32 b4 = (u32)(x >> (4 * q)) & 15u;
+                            if (b4) {
+                                const u32 m = ((b4 * 0x00204081u) & 0x01010101u) * 0xffu;
+                                row32[q] = (row32[q] & ~m) | (lv4 & m);
+                            }
+                        }
                     }
                 }
             }
@@ -917,7 +959,9 @@ __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
             }
             if (lane < G && ((x >> lane) & 1ull)) d8[u * GS + lane] = (unsigned char)level;
         }
-        if (!__syncthreads_or(any)) break;
+        const int more = __syncthreads_or(any);
+        SPB_DBG(3)
+        if (!more) break;
         mx = (u32)level;
         if (level == 254) {                                           // level 255 is the "not reached" byte
             if (tid == 0) atomicMax(maxd, SPB_OVERFLOW);
@@ -948,6 +992,8 @@ __global__ __launch_bounds__(NT) void sp_msbfs_kernel(
         }
     }
     block_count_max(cnt, mx, &pair_count[g], maxd);
+    SPB_DBG(4)
+    SPB_DBG_OUT(CLS, mx)
 }
 
 template <typename W, int G, int NT, int VPT, int CLS>
