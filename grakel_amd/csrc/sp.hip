@@ -370,7 +370,7 @@ __device__ __forceinline__ void sp_fw_pkw_body(unsigned short* __restrict__ lds,
                                                i32* __restrict__ out, u32* __restrict__ pair_count_g, u32* __restrict__ maxd, const SpMark& mk) {
     constexpr int NC = 2 * NP2, LD = NC + 8, S = NP2 / 4;      // S registers (column pairs) per wave and row set
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned short* xch = lds + 128 * LD;                       // [2][128] pivot-column exchange
+    unsigned short* xch = lds + 128 * LD;                       // [2 slots][2 columns][128] pivot-column exchange
     {
         u32* z = (u32*)lds;
         for (int idx = tid; idx < 128 * LD / 2; idx += 256) z[idx] = SP_PK_INF | (SP_PK_INF << 16);
@@ -396,37 +396,61 @@ __device__ __forceinline__ void sp_fw_pkw_body(unsigned short* __restrict__ lds,
         return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(v2us, x), a));
     };
     int slot = 0;
+    // Round 6: TWO pivots per barrier.  The two halves of an owner's register 0 are the pivot columns k and k + 1; the owner
+    // publishes column k as it is and column k + 1 as it will be AFTER pivot k -- min(d[i][k+1], d[i][k] + d[k][k+1]), everything
+    // of which it holds itself -- and every wave relaxes with k, then with k + 1 (whose pivot row it reads from its own registers
+    // after the first relaxation).  One exchange and one barrier per column pair instead of per column: the pivots are a chain
+    // of (LDS write, barrier, LDS read) round trips, 0.83 us each at config 4.
 #pragma clang loop unroll(disable)
     for (int m = 0; m < S; ++m) {
 #pragma clang loop unroll(disable)
-        for (int q = 0; q < 8; ++q) {                           // owner wave q >> 1, half q & 1 of its register 0
-            const int ow = q >> 1, sh = (q & 1) << 4;
-            const int k = 2 * (ow * S + m) + (q & 1);           // the column that register holds (workgroup-uniform)
+        for (int ow = 0; ow < 4; ++ow) {                        // owner wave of the pair
+            const int k = 2 * (ow * S + m);                     // the columns its register 0 holds: k, k + 1 (workgroup-uniform)
             if (k < n) {
+                const int kl = k & 63;                          // row k (and k + 1): lane kl (kl + 1) of row set k / 64
                 if (wv == ow) {
-                    xch[slot * 128 + lane] = (unsigned short)(d[0][0] >> sh);
-                    xch[slot * 128 + 64 + lane] = (unsigned short)(d[1][0] >> sh);
+                    const u32 dk_k1 = (u32)__builtin_amdgcn_readlane((int)(k < 64 ? d[0][0] : d[1][0]), kl) >> 16;      // d[k][k + 1]
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const u32 h0 = d[s][0] & 0xffffu, h1 = d[s][0] >> 16;
+                        const u32 via = h0 + dk_k1;
+                        xch[slot * 256 + 64 * s + lane] = (unsigned short)h0;
+                        xch[slot * 256 + 128 + 64 * s + lane] = (unsigned short)(via < h1 ? via : h1);
+                    }
                 }
                 __syncthreads();
-                u32 dik2[2];
+                u32 dik2[2], dik2b[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const u32 h = xch[slot * 128 + 64 * s + lane];
-                    dik2[s] = h | (h << 16);
+                    const u32 h = xch[slot * 256 + 64 * s + lane], hb = xch[slot * 256 + 128 + 64 * s + lane];
+                    dik2[s] = h | (h << 16), dik2b[s] = hb | (hb << 16);
                 }
                 slot ^= 1;
-                const int kl = k & 63;
                 if (k < 64) {
 #pragma unroll
                     for (int r = 0; r < S; ++r) {
                         const u32 pk = (u32)__builtin_amdgcn_readlane((int)d[0][r], kl);
                         d[0][r] = relax(d[0][r], dik2[0], pk), d[1][r] = relax(d[1][r], dik2[1], pk);
                     }
+                    if (k + 1 < n) {
+#pragma unroll
+                        for (int r = 0; r < S; ++r) {
+                            const u32 pk = (u32)__builtin_amdgcn_readlane((int)d[0][r], kl + 1);
+                            d[0][r] = relax(d[0][r], dik2b[0], pk), d[1][r] = relax(d[1][r], dik2b[1], pk);
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < S; ++r) {
                         const u32 pk = (u32)__builtin_amdgcn_readlane((int)d[1][r], kl);
                         d[0][r] = relax(d[0][r], dik2[0], pk), d[1][r] = relax(d[1][r], dik2[1], pk);
+                    }
+                    if (k + 1 < n) {
+#pragma unroll
+                        for (int r = 0; r < S; ++r) {
+                            const u32 pk = (u32)__builtin_amdgcn_readlane((int)d[1][r], kl + 1);
+                            d[0][r] = relax(d[0][r], dik2b[0], pk), d[1][r] = relax(d[1][r], dik2b[1], pk);
+                        }
                     }
                 }
             }
@@ -454,7 +478,7 @@ __device__ __forceinline__ void sp_fw_pkw_body(unsigned short* __restrict__ lds,
     }
     block_count_max(cnt, mx, pair_count_g, maxd);
     if (mk.present) {                                           // a thread per row and half of its columns
-        u32* colterm = (u32*)(xch + 256);                       // [128] behind the exchange area
+        u32* colterm = (u32*)(xch + 512);                       // [128] behind the exchange area
         if (tid < n) colterm[tid] = mk.with_labels ? (u32)mk.d1 * (u32)mk.labels[v0 + tid] : 0u;
         __syncthreads();
         const int i = tid & 127, half = tid >> 7, mid = (n + 1) >> 1;
@@ -1270,7 +1294,7 @@ static int sp_compute_dist(gk_ctx* ctx, gk_batch* b, const int32_t* edge_weight,
             ++n_launch;
         }
         if (n_big > 0) {                     // 65..128 vertices: a workgroup per graph, columns split over its four waves
-            const int lds = (128 * 136 + 256) * 2 + 128 * 4;    // matrix, pivot-column exchange, column terms (SpMark)
+            const int lds = (128 * 136 + 512) * 2 + 128 * 4;    // matrix, pivot-column exchange, column terms (SpMark)
             sp_fw_pkw_kernel<<<dim3(n_big), 256, lds, ctx->stream>>>(
                 cls_list.p, N, (int)h_cls[4], (int)h_cls[5], (int)h_cls[6], (int)h_cls[7], b->graph_ptr, b->row_ptr, b->col_idx, w,
                 s.dist_ptr.p, s.dist.p, s.pair_count.p, s.maxd.p, mk);
