@@ -917,6 +917,7 @@ __global__ __launch_bounds__(1024) void bucket_assign_kernel(const u32* __restri
             if (!mbox) return;
             __hip_atomic_store(&mbox[1], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&mbox[2], extra ? *extra : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mbox[3], bases[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // labels of the level (wl.hip: convergence)
             __threadfence_system();
             __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }

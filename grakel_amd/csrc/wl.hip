@@ -387,6 +387,7 @@ struct HeadAssignSplit {
         if (mbox) {
             __hip_atomic_store(&mbox[1], (u32)(total >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&mbox[2], extra ? *extra : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mbox[3], (u32)(total & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // labels of the level
             __threadfence_system();
             __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1440,7 +1441,13 @@ struct RelabelState {
     bool default_bits = true;              // the caller did not force a hash width (tests do, to provoke collisions)
     std::vector<char> full_level;          // levels that sorted every node (their perm is split: shared classes first)
     bool split = true;                     // option wl.no_split: keep the plain label-grouped order
-    u32 posted_seq = 0;                    // mailbox message {listed nodes, top-digit max} of the previous (full) level
+    u32 posted_seq = 0;                    // mailbox message {listed nodes, top-digit max, labels} of the previous (full) level
+    // Round 6: the partition has CONVERGED when a level has as many labels as the one before (classes only split: equal counts
+    // mean the same partition, and every later level repeats it).  The posts of two consecutive full levels tell the host;
+    // the remaining levels are copies of the last computed one (labels, order, flags, counts).  The COLLAB-like batch -- dense
+    // ego networks -- is stable after level 1: levels 3..5 cost 3 x 0.29 ms of signatures and verification for nothing.
+    bool converged = false;
+    i64 count_of_prev = -1;                // labels of the previous level when its post said so, else -1
     Tmp<u32> frozen, act, fidx, scratch;   // [V] each; scratch[0] = dictionary count, [1] = n_active, [2] = top-digit max
     bool frozen_in_shared = false;         // the last full level wrote its singleton flags to shared_flag only (never with
                                            // option wl.no_listscan: every level then scans frozen[] of all nodes)
@@ -1494,16 +1501,37 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
     // it as active is still correct (freezing is an optimisation), and skipping the scan saves two
     // launches and a read-back; the sort probes its buckets instead of using the previous level's bound
     bool decided = false;
+    auto repeat_previous_level = [&]() -> int {        // the level is the previous one again (a converged partition)
+        GK_HIP_CHECK(hipMemcpyAsync(cur, prev, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(perm, perm - V, V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(b->shared_flag + (size_t)level * V, b->shared_flag + (size_t)(level - 1) * V, V, hipMemcpyDeviceToDevice, ctx->stream));
+        GK_HIP_CHECK(hipMemcpyAsync(count_dev, count_dev - 1, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (listed_dev) GK_HIP_CHECK(hipMemcpyAsync(listed_dev, listed_dev - 1, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        b->n_sorted[level] = b->n_sorted[level - 1], b->active_layout[level] = b->active_layout[level - 1];
+        b->perm_valid[level] = b->perm_valid[level - 1];
+        st.full_level[level] = st.full_level[level - 1], st.tiny_level[level] = 0;
+        st.posted_seq = 0;
+        return GK_OK;
+    };
+    if (st.converged && !exact) return repeat_previous_level();
     if (!exact && st.posted_seq && level >= 2) {
         // the previous level sorted every node and told the host how many nodes sit in shared classes:
         // when even without the isolated ones they are more than a quarter of the batch this level takes
         // the full path again, and the active-set scan (two launches over all nodes) is not needed
-        u32 back[2] = {0, 0};
-        GK_TRY(gk_mbox_wait(ctx, st.posted_seq, back, 2));
+        u32 back[3] = {0, 0, 0};
+        GK_TRY(gk_mbox_wait(ctx, st.posted_seq, back, 3));
+        const i64 count_prev = (i64)back[2], count_prev2 = st.count_of_prev;
+        st.count_of_prev = count_prev;
+        if (level >= 3 && count_prev2 >= 0 && count_prev == count_prev2 && st.full_level[level - 1] && st.full_level[level - 2] &&
+            !ctx->opt.wl_no_converge) {
+            st.converged = true;
+            if (ctx->opt.wl_debug) fprintf(stderr, "[gk] level %d: the partition is stable since level %d (%lld labels): copied\n", level, level - 2, (long long)count_prev);
+            return repeat_previous_level();
+        }
         if (((i64)back[0] - n_car) * 4 > V && !ctx->opt.wl_no_active_set) {
             n_act = back[0], st.prev_top_max = back[1], decided = true;
         }
-    }
+    } else st.count_of_prev = -1;
     st.posted_seq = 0;
     bool list_based = false;               // this level's active list came from the previous level's list
     if (decided) {

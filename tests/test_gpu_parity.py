@@ -2156,14 +2156,15 @@ def test_transform_of_a_generator_above_the_lookup_threshold(gk):
     assert np.array_equal(est.transform(x for x in X[40:]), Kt)
 
 
-@pytest.mark.parametrize("no_wave", [0, 1])
+@pytest.mark.parametrize("no_wave", [0, 1, 2])
 def test_dense_graphs_and_hubs_through_the_wave_signature_kernels(gk, gkopt, no_wave):
     """Graphs whose vertices have 33..1024 neighbours (near-cliques, ego networks: the COLLAB kind) take the wave-per-node
     signature and verification kernels (round 5), hubs beyond 1024 the workgroup kernel; option wl.no_wave_sig = 1 keeps the
     rounds 1-4 kernels.  Partitions, matrix and transform against the oracle either way."""
     from grakel_amd.batch import wl_batch_from_input
     from grakel_amd.engine import get_engine
-    gkopt("wl.no_wave_sig", no_wave)
+    gkopt("wl.no_wave_sig", 1 if no_wave == 1 else 0)
+    gkopt("wl.no_converge", 1 if no_wave == 2 else 0)          # (2: every level computed even when the partition has converged)
     rs = np.random.RandomState(3)
     X = random_labelled_graphs(12, 60, 90, 0.7, 3, 17, fmt="dict")                  # degree ~ 50
     X += random_labelled_graphs(3, 150, 160, 0.9, 2, 18, fmt="dict")                # degree ~ 140 (R = 4)
@@ -2187,6 +2188,35 @@ def test_dense_graphs_and_hubs_through_the_wave_signature_kernels(gk, gkopt, no_
     est = gk.WeisfeilerLehman(n_iter=3)
     assert np.array_equal(est.fit_transform(X), K)
     assert np.array_equal(est.transform(X[3:9]), K[3:9])
+
+
+@pytest.mark.parametrize("no_converge", [0, 1])
+def test_converged_partition_levels_are_copies(gk, gkopt, no_converge):
+    """The host-driven relabel stops computing once two consecutive levels have the same number of labels (classes only
+    split: the partition has converged and every later level repeats it; wl.hip: RelabelState::converged) and copies the
+    remaining levels.  Dense graphs (degree ~ 50: off the stream route) converge after a level or two; n_iter = 7 leaves five
+    levels to copy.  Counts, partitions, matrix and transform against the oracle, with the shortcut and without
+    (wl.no_converge)."""
+    from grakel_amd.batch import wl_batch_from_input
+    from grakel_amd.engine import get_engine
+    gkopt("wl.no_converge", no_converge)
+    X = random_labelled_graphs(14, 60, 90, 0.7, 3, 21, fmt="dict")
+    X.append(X[0]), X.append(X[5])                                    # isomorphic copies: shared classes at every level
+    wl, K, levels = _oracle_levels(X, 7)
+    counts_ref = [len(set(l.tolist())) for l in levels]
+    assert counts_ref[-1] == counts_ref[-2] == counts_ref[-3]         # (the case the test is about)
+    gb, _ = wl_batch_from_input(X)
+    eng = get_engine()
+    db = eng.upload(gb)
+    assert eng.wl_relabel(db, 7) == counts_ref
+    for lvl in range(8):
+        assert same_partition(eng.wl_labels(db, lvl), levels[lvl])
+    est = gk.WeisfeilerLehman(n_iter=7)
+    assert np.array_equal(est.fit_transform(X), K)
+    assert np.array_equal(est.transform(X[2:9]), K[2:9])
+    estn = gk.WeisfeilerLehman(n_iter=7, normalize=True)
+    refn = O.WLOracle(n_iter=7, normalize=True)
+    assert np.allclose(estn.fit_transform(X), refn.fit_transform(X), rtol=REL_TOL, atol=0)
 
 
 @pytest.mark.parametrize("gpus", [1, 2])
