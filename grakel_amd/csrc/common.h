@@ -95,6 +95,7 @@ struct gk_opts {
     int gram_no_split64 = 0;     // float64 side product: one workgroup per tile for the whole K loop (no split, no atomics)
     int gram_no_compact = 0;     // host copies of integer-valued matrices travel as uint16 / int32 and are widened by host threads: 1 = plain float64 copy
     int gram_copy_threads = 0;   // host threads of that widening (0: min(hardware threads, 16))
+    int wl_no_frozen_skip = 0;   // 1: the wave / workgroup signature kernels of a full level gather and sort the neighbours of nodes that are alone in their class already
     int wl_no_converge = 0;      // 1: the host-driven relabel computes every level even when two consecutive levels have the same number of labels (a converged partition; round 6 copies the rest)
     int wl_no_wave_sig = 0;      // 1: nodes of degree 33..1024 keep the workgroup signature kernel and the one-thread verifier (rounds 1-4) instead of the wave-per-node kernels
     int scan_direct_max = 0;     // test hook: tiles up to which the fused scans (scan_fn.h) sum their predecessors per block (0: 4096); 1 forces the prefixed form

@@ -43,6 +43,13 @@
 
 #include "wl_sig.h"
 
+// Round 6: a node whose class was a singleton at the level before stays alone for ever (classes only split) -- at a FULL level
+// (every node gets a key) the wave / workgroup kernels do not gather, sort and hash its neighbours: its key is a hash of its own
+// (unique) label under a degree no node has.  A thread starter with 2 500 answers is alone from level 1 on; its 78-barrier
+// LDS sort was 40 us of every level of the REDDIT-like batch.  Nobody reads the sorted list of a singleton (it is its own
+// representative); a collision of the made-up key with a real one is what the exact verification and the redo are for.
+#define SIG_FROZEN_KEY(own_label, seed) mix64(sig_head((u32)(own_label), 0xffffffffu, (seed)))
+
 // ---------------------------------------------------------------------------------------
 // Nodes of degree WL_DEG_SMALL + 1 .. WAVE_DEG_MAX (round 5): ONE WAVE per node, the neighbour labels in registers
 // (striped: element i = 64 r + lane, R = 1, 2, 4, 8 or 16 registers per lane), a bitonic network over the wave -- partners
@@ -196,7 +203,7 @@ __device__ __forceinline__ void block_bitonic_sort(P x, int n) {
 __global__ __launch_bounds__(256) void wl_signature_wave_kernel(
     const i32* __restrict__ big_nodes, i64 n_big, const i32* __restrict__ row_ptr,
     const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
-    i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask) {
+    i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask, const unsigned char* __restrict__ shared_prev) {
     const i64 w = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (w >= n_big) return;
@@ -204,6 +211,10 @@ __global__ __launch_bounds__(256) void wl_signature_wave_kernel(
     const i32 e0 = row_ptr[v];
     const int d = row_ptr[v + 1] - e0;
     if (d > WAVE_DEG_MAX) return;                 // the workgroup kernel's
+    if (shared_prev && !shared_prev[v]) {         // alone in its class already: SIG_FROZEN_KEY
+        if (lane == 0) hash[v] = SIG_FROZEN_KEY(lab_prev[v], seed) & mask;
+        return;
+    }
     u64 part;
     if (d <= 64) part = wave_node_signature<1>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
     else if (d <= 128) part = wave_node_signature<2>(col_idx, lab_prev, nbr_sorted, e0, d, lane, seed);
@@ -274,7 +285,8 @@ __global__ __launch_bounds__(256) void verify_big_kernel(const i32* __restrict__
 __global__ __launch_bounds__(BIG_THREADS) void wl_signature_big_kernel(
     const i32* __restrict__ big_nodes, const i32* __restrict__ row_ptr,
     const i32* __restrict__ col_idx, const i32* __restrict__ lab_prev,
-    i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask, int wave_done) {
+    i32* __restrict__ nbr_sorted, u64* __restrict__ hash, u64 seed, u64 mask, int wave_done,
+    const unsigned char* __restrict__ shared_prev) {
     __shared__ i32 buf[BIG_LDS_CAP];
     __shared__ u64 red[BIG_THREADS / 64];
     const int tid = threadIdx.x;
@@ -282,6 +294,10 @@ __global__ __launch_bounds__(BIG_THREADS) void wl_signature_big_kernel(
     const i32 e0 = row_ptr[v];
     const int d = row_ptr[v + 1] - e0;
     if (wave_done && d <= WAVE_DEG_MAX) return;        // wl_signature_wave_kernel's
+    if (shared_prev && !shared_prev[v]) {              // alone in its class already: SIG_FROZEN_KEY (workgroup-uniform)
+        if (tid == 0) hash[v] = SIG_FROZEN_KEY(lab_prev[v], seed) & mask;
+        return;
+    }
     u64 part = 0;
     if (d <= BIG_LDS_CAP) {
         for (int i = tid; i < d; i += BIG_THREADS) {
@@ -1331,25 +1347,27 @@ int gk_batch_ensure_levels(gk_batch* b, int n_levels) {
 
 // nodes of degree > WL_DEG_SMALL: a wave per node up to WAVE_DEG_MAX neighbours, a workgroup per node beyond (hubs);
 // option wl.no_wave_sig keeps everything in the workgroup kernel (rounds 1-4)
-static int launch_signature_big(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash_by_node, u64 seed, u64 mask) {
+static int launch_signature_big(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash_by_node, u64 seed, u64 mask,
+                                const unsigned char* shared_prev = nullptr) {
     const int wave = b->wave_sig;
     if (wave)
         wl_signature_wave_kernel<<<grid_for(b->n_big * 64, 256), 256, 0, ctx->stream>>>(
-            b->big_nodes, b->n_big, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask);
+            b->big_nodes, b->n_big, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask, shared_prev);
     if (!wave || b->max_degree > WAVE_DEG_MAX)
         wl_signature_big_kernel<<<dim3((unsigned)b->n_big), BIG_THREADS, 0, ctx->stream>>>(
-            b->big_nodes, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask, wave);
+            b->big_nodes, b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash_by_node, seed, mask, wave, shared_prev);
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }
 
-static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash, u64 seed, u64 mask) {
+static int launch_signature(gk_ctx* ctx, gk_batch* b, const i32* lab_prev, u64* hash, u64 seed, u64 mask,
+                            const unsigned char* shared_prev = nullptr) {
     i64 V = b->n_nodes;
     if (V == 0) return GK_OK;
     const int sig_regs = ctx->opt.wl_sig_no_regs ? 0 : 1;      // route option: insertion sort in LDS instead
     wl_signature_small_kernel<<<grid_for(V, SIG_THREADS), SIG_THREADS, 0, ctx->stream>>>(
         b->row_ptr, b->col_idx, lab_prev, b->nbr_sorted, hash, V, seed, mask, sig_regs, b->deg_small);
-    if (b->n_big > 0) GK_TRY(launch_signature_big(ctx, b, lab_prev, hash, seed, mask));
+    if (b->n_big > 0) GK_TRY(launch_signature_big(ctx, b, lab_prev, hash, seed, mask, shared_prev));
     GK_HIP_CHECK(hipGetLastError());
     return GK_OK;
 }
@@ -1672,7 +1690,11 @@ static int relabel_level(gk_ctx* ctx, gk_batch* b, int level, int hash_bits, boo
             GK_HIP_CHECK(hipGetLastError());
             break;
         }
-        GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), full_mask));
+        // (singletons of the previous FULL level keep to themselves: SIG_FROZEN_KEY; not in the exact redo, whose rounds refine
+        // every node's key)
+        const unsigned char* skip = (!exact && round == 0 && level >= 2 && st.full_level[level - 1] && !ctx->opt.wl_no_frozen_skip)
+                                        ? b->shared_flag + (size_t)(level - 1) * V : nullptr;
+        GK_TRY(launch_signature(ctx, b, prev, hash.p, level_seed(level, round), full_mask, skip));
         bool flag_in_lab = false;
         int bits = hash_bits;
         const u64* sort_keys = hash.p;           // round 0: the sort reads the hashes in place

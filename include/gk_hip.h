@@ -74,6 +74,8 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             route of wl.hip, which all the other "wl.*" switches select within)
  *             "wl.no_wave_sig" (vertices of degree 33..1024 by the workgroup-per-vertex signature kernel and the
  *             thread-per-vertex verifier of rounds 1-4 instead of the wave-per-vertex kernels)
+ *             "wl.no_frozen_skip" (1: at a full level of the host-driven route the wave / workgroup signature kernels also gather and
+ *             sort the neighbours of vertices that were alone in their class at the level before)
  *             "wl.no_converge" (1: the host-driven route computes every level even after two consecutive levels with the same
  *             number of labels -- a converged partition, whose remaining levels are copies)
  *             "transform.no_fused" (look-up transform: the target classes matched by two launches per level even when the

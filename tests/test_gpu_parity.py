@@ -2156,7 +2156,7 @@ def test_transform_of_a_generator_above_the_lookup_threshold(gk):
     assert np.array_equal(est.transform(x for x in X[40:]), Kt)
 
 
-@pytest.mark.parametrize("no_wave", [0, 1, 2])
+@pytest.mark.parametrize("no_wave", [0, 1, 2, 3])
 def test_dense_graphs_and_hubs_through_the_wave_signature_kernels(gk, gkopt, no_wave):
     """Graphs whose vertices have 33..1024 neighbours (near-cliques, ego networks: the COLLAB kind) take the wave-per-node
     signature and verification kernels (round 5), hubs beyond 1024 the workgroup kernel; option wl.no_wave_sig = 1 keeps the
@@ -2165,6 +2165,7 @@ def test_dense_graphs_and_hubs_through_the_wave_signature_kernels(gk, gkopt, no_
     from grakel_amd.engine import get_engine
     gkopt("wl.no_wave_sig", 1 if no_wave == 1 else 0)
     gkopt("wl.no_converge", 1 if no_wave == 2 else 0)          # (2: every level computed even when the partition has converged)
+    gkopt("wl.no_frozen_skip", 1 if no_wave == 3 else 0)       # (3: hubs that are alone in their class are sorted at every level all the same)
     rs = np.random.RandomState(3)
     X = random_labelled_graphs(12, 60, 90, 0.7, 3, 17, fmt="dict")                  # degree ~ 50
     X += random_labelled_graphs(3, 150, 160, 0.9, 2, 18, fmt="dict")                # degree ~ 140 (R = 4)
