@@ -863,6 +863,15 @@ __global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const Gm
                                                       int8_t* __restrict__ phi_r, int parts, i64 own_lo, i64 own_hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row[];
     const i64 g = blockIdx.x;
+    if (g >= n_graphs) {                                         // a padding row (the grid covers n_rows_pad): zeros, both operands
+        uint4* z = (uint4*)(phi + g * ld);
+        for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
+        if (phi_r) {
+            z = (uint4*)(phi_r + g * ld);
+            for (i64 i = threadIdx.x; i < ld / 16; i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
     // multi-GPU, the operand-row exchange (grakel_amd/dist.py: exchange="phi"): a rank assembles and stores the rows of ITS
     // graphs [own_lo, own_hi) only -- the others arrive with the all-gather --, but every graph's rare-label entries and
     // float64 side columns are still listed: those stay complete on every rank
@@ -960,15 +969,6 @@ __global__ __launch_bounds__(256) void gm_rows_wave_kernel(const GmLevels P, con
     }
     dst = (uint4*)(phi_r + g * ld);
     for (i64 i = lane; i < ld / 16; i += 64) dst[i] = ((const uint4*)row)[i];
-}
-
-// rows [n_graphs, n_rows_pad) of the operand (and of the right operand of split columns, when there is one): zero
-__global__ void gm_pad_rows_kernel(int8_t* __restrict__ phi, int8_t* __restrict__ phi_r, i64 bytes) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < bytes / 16) {
-        ((uint4*)phi)[i] = make_uint4(0, 0, 0, 0);
-        if (phi_r) ((uint4*)phi_r)[i] = make_uint4(0, 0, 0, 0);
-    }
 }
 
 // Second half of the graph-major builder, shared with the ShortestPath histogram form (gk_features_build_sp): column classes
@@ -1082,12 +1082,10 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
             f->n_cols_wide_pad, lg, lc, ll, f->n_rows_pad, (int8_t*)f->phi_r, f->split_parts, own_lo, own_hi);        // ... and zeroes the padding rows
     else {
-        gm_rows_kernel<<<dim3((unsigned)N), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
+        // (the grid covers the padding rows too: workgroups behind the last graph zero one row each -- a launch less)
+        gm_rows_kernel<<<dim3((unsigned)f->n_rows_pad), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
             f->n_cols_wide_pad, lg, lc, ll, (int8_t*)f->phi_r, f->split_parts, own_lo, own_hi);
-        const i64 pad_bytes = (f->n_rows_pad - N) * f->n_cols_pad;
-        gm_pad_rows_kernel<<<grid_for(pad_bytes / 16, 256), 256, 0, ctx->stream>>>(
-            (int8_t*)f->phi + N * f->n_cols_pad, f->phi_r ? (int8_t*)f->phi_r + N * f->n_cols_pad : nullptr, pad_bytes);
     }
     GK_HIP_CHECK(hipGetLastError());
     // ---- what gram.hip needs for the rare labels: their list, per label the start / length of its entries
