@@ -244,7 +244,7 @@ static const OptName g_opt_names[] = {
     {"wl.bd_slots", &gk_opts::bd_slots}, {"feat.no_gm", &gk_opts::feat_no_gm}, {"feat.gm_no_priv", &gk_opts::gm_no_priv}, {"feat.gm_rows_wg", &gk_opts::gm_rows_wg},
     {"feat.low_df", &gk_opts::low_df}, {"feat.gm_row_lds_max", &gk_opts::gm_row_lds_max},
     {"gram.dd", &gk_opts::gram_dd}, {"gram.no_fp4", &gk_opts::gram_no_fp4}, {"gram.no_ws", &gk_opts::gram_no_ws}, {"gram.no_sym", &gk_opts::gram_no_sym},
-    {"gram.no_patch", &gk_opts::gram_no_patch}, {"gram.xcc", &gk_opts::gram_xcc}, {"feat.gm_no_huge", &gk_opts::gm_no_huge}, {"feat.gm_no_early_post", &gk_opts::gm_no_early_post}, {"feat.rows_lo", &gk_opts::feat_rows_lo}, {"feat.rows_hi", &gk_opts::feat_rows_hi}, {"gram.strip", &gk_opts::gram_strip}, {"gram.no_compact", &gk_opts::gram_no_compact}, {"gram.no_split8", &gk_opts::gram_no_split8}, {"gram.no_split64", &gk_opts::gram_no_split64}, {"gram.fold", &gk_opts::gram_fold}, {"gram.pair_cap", &gk_opts::gram_pair_cap}, {"gram.copy_threads", &gk_opts::gram_copy_threads}, {"gram.no_tri", &gk_opts::gram_no_tri}, {"gram.no_avx2", &gk_opts::gram_no_avx2}, {"wl.no_wave_sig", &gk_opts::wl_no_wave_sig}, {"wl.no_frozen_skip", &gk_opts::wl_no_frozen_skip}, {"wl.no_converge", &gk_opts::wl_no_converge}, {"transform.no_fused", &gk_opts::tt_no_fused}, {"scan.direct_max", &gk_opts::scan_direct_max}, {"sp.no_reg", &gk_opts::sp_no_reg}, {"sp.no_pk", &gk_opts::sp_no_pk}, {"sp.no_hist", &gk_opts::sp_no_hist}, {"sp.no_prep", &gk_opts::sp_no_prep}, {"sp.no_rows", &gk_opts::sp_no_rows}, {"sp.no_bfs", &gk_opts::sp_no_bfs}, {"sp.bfs_one_stream", &gk_opts::sp_bfs_one_stream}, {"sp.bfs_no_lds_cols", &gk_opts::sp_bfs_no_lds_cols}, {"sp.bfs_no_bytes", &gk_opts::sp_bfs_no_bytes}, {"sp.rows_all", &gk_opts::sp_rows_all}, {"sp.no_fused_mark", &gk_opts::sp_no_fused_mark}, {"sp.hist_no_batch", &gk_opts::sp_hist_no_batch}, {"sp.static_type", &gk_opts::sp_static_type}, {"sp.rows_no_merge", &gk_opts::sp_rows_no_merge}, {"sp.hist_unit", &gk_opts::sp_hist_unit}, {"sp.hist_slots", &gk_opts::sp_hist_slots}, {"no_mailbox", &gk_opts::no_mailbox},
+    {"gram.no_patch", &gk_opts::gram_no_patch}, {"gram.xcc", &gk_opts::gram_xcc}, {"feat.gm_no_huge", &gk_opts::gm_no_huge}, {"feat.gm_rows_256", &gk_opts::gm_rows_256}, {"feat.gm_no_early_post", &gk_opts::gm_no_early_post}, {"feat.rows_lo", &gk_opts::feat_rows_lo}, {"feat.rows_hi", &gk_opts::feat_rows_hi}, {"gram.strip", &gk_opts::gram_strip}, {"gram.no_compact", &gk_opts::gram_no_compact}, {"gram.no_split8", &gk_opts::gram_no_split8}, {"gram.no_split64", &gk_opts::gram_no_split64}, {"gram.fold", &gk_opts::gram_fold}, {"gram.pair_cap", &gk_opts::gram_pair_cap}, {"gram.copy_threads", &gk_opts::gram_copy_threads}, {"gram.no_tri", &gk_opts::gram_no_tri}, {"gram.no_avx2", &gk_opts::gram_no_avx2}, {"wl.no_wave_sig", &gk_opts::wl_no_wave_sig}, {"wl.no_frozen_skip", &gk_opts::wl_no_frozen_skip}, {"wl.no_converge", &gk_opts::wl_no_converge}, {"transform.no_fused", &gk_opts::tt_no_fused}, {"scan.direct_max", &gk_opts::scan_direct_max}, {"sp.no_reg", &gk_opts::sp_no_reg}, {"sp.no_pk", &gk_opts::sp_no_pk}, {"sp.no_hist", &gk_opts::sp_no_hist}, {"sp.no_prep", &gk_opts::sp_no_prep}, {"sp.no_rows", &gk_opts::sp_no_rows}, {"sp.no_bfs", &gk_opts::sp_no_bfs}, {"sp.bfs_one_stream", &gk_opts::sp_bfs_one_stream}, {"sp.bfs_no_lds_cols", &gk_opts::sp_bfs_no_lds_cols}, {"sp.bfs_no_bytes", &gk_opts::sp_bfs_no_bytes}, {"sp.rows_all", &gk_opts::sp_rows_all}, {"sp.no_fused_mark", &gk_opts::sp_no_fused_mark}, {"sp.hist_no_batch", &gk_opts::sp_hist_no_batch}, {"sp.static_type", &gk_opts::sp_static_type}, {"sp.rows_no_merge", &gk_opts::sp_rows_no_merge}, {"sp.hist_unit", &gk_opts::sp_hist_unit}, {"sp.hist_slots", &gk_opts::sp_hist_slots}, {"no_mailbox", &gk_opts::no_mailbox},
     {"debug.poison", &gk_opts::poison}, {"debug.guard", &gk_opts::guard},
 };
 

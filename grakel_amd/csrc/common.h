@@ -86,6 +86,7 @@ struct gk_opts {
     int feat_rows_lo = 0, feat_rows_hi = 0;   // hi > lo: the graph-major builder assembles the operand rows of the graphs [lo, hi) only (multi-GPU operand-row exchange; the others are expected through gk_features_operand)
     int sp_bfs_one_stream = 0;   // 1: the size classes of the bit-parallel breadth-first search one after the other on the context's stream (round 5) instead of alternating over two streams
     int gm_no_early_post = 0;    // 1: the graph-major builder's operand sizes are read back after the column scan (rounds 2-5) instead of being posted from its tile sums
+    int gm_rows_256 = 0;         // 1: the workgroup-per-graph operand-row kernel always with 256 threads (1 024 where the graphs hold thousands of entries each, round 6)
     int gm_no_huge = 0;          // 1: graphs above 1 024 vertices send the job to the label-major feature builder (and off the relabel route without host round trips), as in rounds 1-5
     int gram_strip = 0;          // tile order of the tile kernels: 0 = the rule (gram.hip: launch_tiles), 1 = 8 x 8 patches (rounds 1-5), 2 / 4 / 8 / 16 / 32 = strip walk with strips of that many tile columns
     int gram_pair_cap = 0;       // test hook: capacity of the per-tile pair buckets (0: four times the mean load + 128)

@@ -854,7 +854,7 @@ __device__ __forceinline__ int gm_row_entry(unsigned char* row, const GmLabelArr
     }
 
 // one workgroup per graph: the operand row in LDS (row_bytes <= GM_ROW_LDS_MAX), written once
-__global__ __launch_bounds__(256) void gm_rows_kernel(const GmLevels P, const GmLabelArrays A,
+__global__ __launch_bounds__(1024) void gm_rows_kernel(const GmLevels P, const GmLabelArrays A,
                                                       const i32* __restrict__ graph_ptr, i64 V, const i32* __restrict__ ent_lab,
                                                       const u32* __restrict__ cnt, const u32* __restrict__ ent_n, i64 n_graphs,
                                                       int8_t* __restrict__ phi, i64 ld, i64 prim0 /* first byte of the primary region */,
@@ -1083,7 +1083,10 @@ static int gm_finish(gk_ctx* ctx, gk_feat* f, const GmLevels& P, GmLabelArrays& 
             f->n_cols_wide_pad, lg, lc, ll, f->n_rows_pad, (int8_t*)f->phi_r, f->split_parts, own_lo, own_hi);        // ... and zeroes the padding rows
     else {
         // (the grid covers the padding rows too: workgroups behind the last graph zero one row each -- a launch less)
-        gm_rows_kernel<<<dim3((unsigned)f->n_rows_pad), 256, (size_t)f->n_cols_pad, ctx->stream>>>(
+        // 1 024 threads per graph where the graphs hold thousands of entries each (the D&D-like ShortestPath job: 13 k on average,
+        // 112 k in its largest graph -- 440 trips of dependent loads for 256 threads: 558 -> 217 us), 256 otherwise
+        const int rows_threads = (f->nnz > 2048 * N && !ctx->opt.gm_rows_256) ? 1024 : 256;
+        gm_rows_kernel<<<dim3((unsigned)f->n_rows_pad), rows_threads, (size_t)f->n_cols_pad, ctx->stream>>>(
             P, A, graph_ptr, V, ent, cnt, ent_n, N, (int8_t*)f->phi, f->n_cols_pad, n8p, f->phi_fp4 ? 1 : 0, kind, f->phi_w,
             f->n_cols_wide_pad, lg, lc, ll, (int8_t*)f->phi_r, f->split_parts, own_lo, own_hi);
     }
@@ -1817,6 +1820,7 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_count_kernel(const SpSour
     }
 }
 
+#define SPC_TRIP 16
 struct SpRowsOut {
     i32* ent_lab; u32* ent_cnt; u32* ent_n; u64* selfk; u32* part; u32* wgmeta; u64* selfk8;
 };
@@ -1844,15 +1848,15 @@ __global__ __launch_bounds__(SPR_THREADS) void sp_rows_compact_kernel(const i32*
         if (tid == 0) n_ent_s = 0;
         __syncthreads();
         u64 extra = 0, sq8 = 0;                            // sq8: sum of c^2 over the entries with c <= 127 (sp_type_kernel)
-        for (i64 t0 = 0; t0 < Q; t0 += 4 * SPR_THREADS) {
-            u32 cc[4];
+        for (i64 t0 = 0; t0 < Q; t0 += SPC_TRIP * SPR_THREADS) {      // (sixteen counters per thread in flight: the scan is a chain of latencies)
+            u32 cc[SPC_TRIP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SPC_TRIP; ++u) {
                 const i64 t = t0 + u * SPR_THREADS + tid;
                 cc[u] = t < Q ? row[t] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SPC_TRIP; ++u) {
                 const i64 t = t0 + u * SPR_THREADS + tid;
                 const u32 c = cc[u];
                 const u64 m = __ballot(c > 0);

@@ -86,7 +86,7 @@ int gk_profile_get(gk_ctx* ctx, const char* name, double* out_ms, int64_t* out_l
  *             "wl.bd_slots" (distinct keys a bucket of the sort-free dictionary accepts: small values force its
  *             overflow and with it the second, sorting attempt)
  *   features: "feat.no_gm" "feat.gm_no_priv" "feat.gm_rows_wg" "feat.low_df" (df below which a column becomes pair updates; default 24 (N / 10 000)^0.75 within [8, 128])
- *             "feat.gm_no_early_post" (1: the operand sizes are read back after the column scan instead of being posted from its tile sums) "feat.gm_no_huge" (1: a graph above 1 024 vertices sends the job to the label-major builder, rounds 1-5; default: a workgroup counts such a graph, up to 8 192 vertices)
+ *             "feat.gm_no_early_post" (1: the operand sizes are read back after the column scan instead of being posted from its tile sums) "feat.gm_no_huge" (1: a graph above 1 024 vertices sends the job to the label-major builder, rounds 1-5; default: a workgroup counts such a graph, up to 8 192 vertices) "feat.gm_rows_256" (1: the workgroup-per-graph operand-row kernel with 256 threads even where the graphs hold thousands of entries each)
  *             "feat.gm_row_lds_max" (bytes of operand row the graph-major builder accepts: small values force the
  *             fall-back to the label-major builder)
  *   Gram:     "gram.dd" (the direct-store form of the persistent kernel: 1 always, 2 never, 0 per job) "gram.no_fp4" "gram.no_ws" "gram.no_sym" "gram.no_patch" "gram.xcc" "feat.rows_lo" "feat.rows_hi" (the multi-GPU operand-row exchange: gk_features_operand_rows) "gram.strip" (tile order: 1 the 8 x 8 patches of rounds 1-5, 2..32 strips of that many tile columns, 0 per job)

@@ -913,7 +913,7 @@ def test_sharded_shortest_path_two_processes_on_one_gpu(gk, tmp_path, n_graphs, 
 @pytest.mark.parametrize("route", [(), ("sp.no_hist",), ("sp.no_pk",), ("sp.no_reg",), ("sp.no_hist", "sp.no_reg"),
                                    ("feat.gm_row_lds_max",), ("feat.gm_no_priv",), ("sp.no_hist", "scan.direct_max"),
                                    ("sp.no_rows",), ("sp.no_bfs",), ("sp.bfs_no_lds_cols",), ("gram.no_split64",), ("gram.no_sym",), ("sp.rows_all",), ("sp.rows_all", "sp.hist_unit=1"),
-                                   ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv"), ("sp.no_prep",), ("sp.bfs_one_stream",), ("sp.bfs_no_bytes",), ("sp.hist_no_batch",), ("sp.static_type",), ("sp.static_type=2",), ("sp.no_fused_mark",), ("sp.rows_all", "sp.rows_no_merge"), ("sp.rows_all", "sp.rows_no_merge=2"), ("sp.rows_all", "sp.rows_no_merge=4"), ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16", "sp.rows_no_merge=3"),
+                                   ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16"), ("sp.hist_slots=32", "feat.gm_no_priv"), ("sp.no_prep",), ("sp.bfs_one_stream",), ("sp.bfs_no_bytes",), ("sp.hist_no_batch",), ("feat.gm_rows_256",), ("sp.static_type",), ("sp.static_type=2",), ("sp.no_fused_mark",), ("sp.rows_all", "sp.rows_no_merge"), ("sp.rows_all", "sp.rows_no_merge=2"), ("sp.rows_all", "sp.rows_no_merge=4"), ("sp.rows_all", "sp.hist_unit=300", "sp.hist_slots=16", "sp.rows_no_merge=3"),
                                    ("sp.no_hist", "sp.bfs_no_bytes")],
                          ids=lambda r: "+".join(r) or "default")
 def test_every_shortest_path_route_gives_the_reference_matrix(gk, gkopt, route):
